@@ -1,0 +1,158 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path
+(`rlcf_amd/`); only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py` may use it, and only as the checker / the timed CPU baseline.
+
+CPU fp32 restatement (plain torch ops, functional style over an OpenAI-layout
+state dict) of the CLIP modules the RLCF hot path drives.  Each function cites
+the reference lines it restates (paths relative to /root/reference).
+
+Parity pin: the reference ships no tests or golden vectors, so
+this restatement is pinned against outputs of the reference itself, imported in
+the build container by `tests/golden/make_golden.py`; the resulting fixtures
+are committed under `tests/golden/` and checked by `tests/test_oracle_golden.py`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+HEAD_DIM = 64          # every CLIP tower uses width // 64 heads (TPT/clip/model.py:272,421)
+LN_EPS = 1e-5          # nn.LayerNorm default, used by TPT/clip/model.py:157-163
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """TPT/clip/model.py:157-163 — LayerNorm evaluated in fp32, biased variance."""
+    x = x.float()
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """TPT/clip/model.py:166-168."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def causal_mask(length: int) -> torch.Tensor:
+    """TPT/clip/model.py:328-334 — additive mask, -inf strictly above the diagonal."""
+    m = torch.full((length, length), float("-inf"))
+    return torch.triu(m, diagonal=1)
+
+
+def multi_head_attention(x: torch.Tensor, sd: SD, p: str, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.MultiheadAttention as used at TPT/clip/model.py:175,185-187 (packed
+    in-proj rows [q;k;v], scale 1/sqrt(head_dim), additive mask, softmax over
+    keys, out-proj).  x is batch-first here: [B, L, W]."""
+    B, L, W = x.shape
+    H = W // HEAD_DIM
+    qkv = x @ sd[p + "attn.in_proj_weight"].t() + sd[p + "attn.in_proj_bias"]
+    q, k, v = qkv.split(W, dim=-1)
+    q = q.reshape(B, L, H, HEAD_DIM).transpose(1, 2)
+    k = k.reshape(B, L, H, HEAD_DIM).transpose(1, 2)
+    v = v.reshape(B, L, H, HEAD_DIM).transpose(1, 2)
+    s = (q * (HEAD_DIM ** -0.5)) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s + mask
+    a = torch.softmax(s, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, L, W)
+    return a @ sd[p + "attn.out_proj.weight"].t() + sd[p + "attn.out_proj.bias"]
+
+
+def residual_block(x: torch.Tensor, sd: SD, p: str, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """TPT/clip/model.py:189-192 — pre-LN block."""
+    x = x + multi_head_attention(layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]), sd, p, mask)
+    h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+    h = quick_gelu(h @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"])
+    return x + (h @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"])
+
+
+def n_blocks(sd: SD, prefix: str) -> int:
+    return len([k for k in sd if k.startswith(prefix + ".resblocks.") and k.endswith("attn.in_proj_weight")])
+
+
+def transformer(x: torch.Tensor, sd: SD, prefix: str, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """TPT/clip/model.py:195-203."""
+    for i in range(n_blocks(sd, prefix)):
+        x = residual_block(x, sd, f"{prefix}.resblocks.{i}.", mask)
+    return x
+
+
+def encode_image(sd: SD, images: torch.Tensor) -> torch.Tensor:
+    """VisionTransformer.forward, TPT/clip/model.py:223-240 (== CLIP.encode_image
+    :340-341).  The stride==kernel convolution is written as patch gather + GEMM."""
+    w = sd["visual.conv1.weight"]
+    width, _, ps, _ = w.shape
+    n = images.shape[0]
+    patches = F.unfold(images.float(), kernel_size=ps, stride=ps)        # [N, 3*ps*ps, G*G], (c,i,j) major
+    x = patches.transpose(1, 2) @ w.reshape(width, -1).t()               # [N, G*G, width]
+    cls = sd["visual.class_embedding"].expand(n, 1, width)
+    x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
+    x = transformer(x, sd, "visual.transformer", None)
+    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"])
+    return x @ sd["visual.proj"]
+
+
+def text_tower(sd: SD, x: torch.Tensor, eot: torch.Tensor) -> torch.Tensor:
+    """TextEncoder.forward, TPT/clip/custom_clip.py:62-73 (== the tail of
+    CLIP.encode_text, TPT/clip/model.py:346-354).  x: token/prompt embeddings
+    [C, L, W] WITHOUT positional embedding; eot: int64 [C] row index of EOT."""
+    L = x.shape[1]
+    x = x + sd["positional_embedding"][:L]
+    x = transformer(x, sd, "transformer", causal_mask(L))
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
+    return x[torch.arange(x.shape[0]), eot] @ sd["text_projection"]
+
+
+def encode_text(sd: SD, tokens: torch.Tensor, truncate: bool = False) -> torch.Tensor:
+    """CLIP.encode_text, TPT/clip/model.py:343-356.  EOT = argmax of the ids.
+    ``truncate`` crops to max(EOT)+1 — exact under the causal mask (SURVEY.md §0
+    fact 4); default is the dense 77-token reference graph."""
+    eot = tokens.argmax(dim=-1)
+    if truncate:
+        tokens = tokens[:, : int(eot.max()) + 1]
+    return text_tower(sd, sd["token_embedding.weight"][tokens], eot)
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """x / x.norm(dim=-1, keepdim=True) — TPT/clip/custom_clip.py:320,330; clip_reward.py:136,148."""
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def prompt_embeddings(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+    """PromptLearner.forward with class_token_position == 'end' and a 2-D ctx,
+    TPT/clip/custom_clip.py:198-238: [SOS | ctx | class tokens, '.', EOS, pad]."""
+    emb = sd["token_embedding.weight"][tokens]
+    n_ctx = ctx.shape[0]
+    c = tokens.shape[0]
+    return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(c, -1, -1), emb[:, 1 + n_ctx:]], dim=1)
+
+
+def ctx_from_tokens(sd: SD, ctx_token_ids) -> torch.Tensor:
+    """ctx_init words -> token embeddings, TPT/clip/custom_clip.py:90-107."""
+    ids = torch.as_tensor(list(ctx_token_ids), dtype=torch.int64)
+    return sd["token_embedding.weight"][ids].clone()
+
+
+def student_text_features(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor, truncate: bool = False) -> torch.Tensor:
+    """ClipTestTimeTuning.get_text_features, TPT/clip/custom_clip.py:315-323
+    (the stack+mean over a one-element list is the identity)."""
+    eot = tokens.argmax(dim=-1)
+    x = prompt_embeddings(sd, tokens, ctx)
+    if truncate:
+        x = x[:, : int(eot.max()) + 1]
+    return l2_normalize(text_tower(sd, x, eot))
+
+
+def student_logits(sd: SD, images: torch.Tensor, tokens: torch.Tensor, ctx: torch.Tensor,
+                   truncate: bool = False) -> torch.Tensor:
+    """ClipTestTimeTuning.inference, TPT/clip/custom_clip.py:325-335: image tower
+    under no_grad, text tower differentiable w.r.t. ctx."""
+    with torch.no_grad():
+        img = l2_normalize(encode_image(sd, images))
+    txt = student_text_features(sd, tokens, ctx, truncate)
+    return sd["logit_scale"].exp() * img @ txt.t()

@@ -1,0 +1,151 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/clip_ref.py header; same rules,
+same parity pin: fixtures generated from the imported reference by
+tests/golden/make_golden.py).
+
+CPU fp32 restatement of the RLCF per-sample test-time-adaptation step:
+TPT/tpt_cls_rl.py:32-79 (select / entropy / tuning loop), :251-262 (reset, final
+inference), TPT/clip_reward.py:111-165 (CLIPScore, reward post-processing) and
+the torch.optim.AdamW update the harness applies (TPT/tpt_cls_rl.py:120).
+This is the dense reference graph: 77-token text tower, autograd backward.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import clip_ref as C
+
+
+@dataclass
+class TTAHyper:
+    """Flags read on the path (TPT/params.py:13-98; script values
+    TPT/scripts/rlcf-prompt.sh:13-41)."""
+    selection_p: float = 0.1
+    tta_steps: int = 1
+    sample_k: int = 3
+    lr: float = 7e-3
+    weight_decay: float = 5e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    reward_process: bool = True
+    process_batch: bool = False
+    reward_amplify: bool = False
+    clipscore_weight: float = 2.5
+    min_entropy_reg: bool = False
+    min_entropy_w: float = 0.2
+
+
+def entropy_rows(logits: torch.Tensor) -> torch.Tensor:
+    """-(softmax * log_softmax).sum(1), TPT/tpt_cls_rl.py:33."""
+    lp = logits.log_softmax(dim=1)
+    return -(lp.exp() * lp).sum(dim=1)
+
+
+def select_confident_samples(logits: torch.Tensor, top: float):
+    """TPT/tpt_cls_rl.py:32-35 — lowest-entropy int(N*top) rows, ascending."""
+    ent = entropy_rows(logits)
+    idx = torch.argsort(ent, descending=False)[: int(ent.shape[0] * top)]
+    return logits[idx], idx
+
+
+def avg_entropy(outputs: torch.Tensor) -> torch.Tensor:
+    """TPT/tpt_cls_rl.py:38-44 — entropy of the view-averaged distribution."""
+    lp = outputs - outputs.logsumexp(dim=-1, keepdim=True)
+    avg = lp.logsumexp(dim=0) - math.log(lp.shape[0])
+    avg = torch.clamp(avg, min=torch.finfo(avg.dtype).min)
+    return -(avg * avg.exp()).sum(dim=-1)
+
+
+def clip_score(class_features: torch.Tensor, image_features: torch.Tensor, class_index: torch.Tensor,
+               sample_k: int, weight: float = 2.5) -> torch.Tensor:
+    """CLIPRewards.CLIPScore(pairwise=False), TPT/clip_reward.py:111-128."""
+    t = class_features[class_index]
+    i = torch.repeat_interleave(image_features, sample_k, dim=0)
+    s = weight * (t * i).sum(dim=-1)
+    return torch.clamp_min(s, 0.0).squeeze()
+
+
+def rewards_post_process(score: torch.Tensor, reward_process: bool, amplify: bool) -> torch.Tensor:
+    """CLIPRewards.rewards_post_process, TPT/clip_reward.py:152-165 (torch.std is
+    the unbiased estimator)."""
+    if score.shape[-1] > 1 and reward_process:
+        mean = score.mean(dim=-1, keepdim=True)
+        std = score.std(dim=-1, keepdim=True) + 1e-5 if amplify else 1.0
+        score = (score - mean) / std
+    return score.flatten()
+
+
+def adamw_step(p, g, m, v, step: int, hp: TTAHyper):
+    """torch.optim.AdamW (amsgrad=False, maximize=False) single-tensor update."""
+    p = p * (1.0 - hp.lr * hp.weight_decay)
+    m = hp.beta1 * m + (1.0 - hp.beta1) * g
+    v = hp.beta2 * v + (1.0 - hp.beta2) * g * g
+    bc1 = 1.0 - hp.beta1 ** step
+    bc2 = 1.0 - hp.beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + hp.eps
+    p = p - (hp.lr / bc1) * (m / denom)
+    return p, m, v
+
+
+def reward_class_features(reward_sd, tokens: torch.Tensor, truncate: bool = False) -> torch.Tensor:
+    """BaseRewards.set_class_features -> extract_text_features(tokenized_cap=...),
+    TPT/clip_reward.py:55-57,139-150; called once per dataset (tpt_cls_rl.py:182-183)."""
+    with torch.no_grad():
+        return C.l2_normalize(C.encode_text(reward_sd, tokens, truncate).float())
+
+
+def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor, ctx_init: torch.Tensor,
+               hp: TTAHyper, reward_cls: Optional[torch.Tensor] = None, truncate: bool = False
+               ) -> Dict[str, torch.Tensor]:
+    """One iteration of the harness loop TPT/tpt_cls_rl.py:251-262: reset ->
+    test_time_tuning (:47-79) -> final one-view inference on views[0].
+    Returns every intermediate of the first tuning step plus the final outputs."""
+    out: Dict[str, torch.Tensor] = {}
+    if reward_cls is None:
+        reward_cls = reward_class_features(reward_sd, tokens, truncate)
+    ctx = ctx_init.clone()                                  # model.reset(), custom_clip.py:161-164
+    m = torch.zeros_like(ctx)                               # optimizer.load_state_dict(optim_state), :255
+    v = torch.zeros_like(ctx)
+    selected = None
+    for j in range(hp.tta_steps):
+        ctx = ctx.detach().requires_grad_(True)
+        if selected is None:                                # tpt_cls_rl.py:57-59
+            logits_all = C.student_logits(student_sd, views, tokens, ctx, truncate)
+            output, selected = select_confident_samples(logits_all, hp.selection_p)
+            with torch.no_grad():                           # clip_reward.py:130-137
+                rimg = C.l2_normalize(C.encode_image(reward_sd, views[selected]).float())
+        else:                                               # tpt_cls_rl.py:55
+            logits_all = None
+            output = C.student_logits(student_sd, views[selected], tokens, ctx, truncate)
+        bs = output.shape[0]
+        _, index = torch.topk(output, hp.sample_k, dim=-1)  # :63
+        flat = index.flatten()
+        score = clip_score(reward_cls, rimg, flat, hp.sample_k, hp.clipscore_weight)
+        rewards = rewards_post_process(score if hp.process_batch else score.reshape(bs, -1),
+                                       hp.reward_process, hp.reward_amplify)
+        rep = torch.repeat_interleave(output, hp.sample_k, dim=0)
+        ce = torch.nn.functional.cross_entropy(rep, flat, reduction="none")
+        loss = torch.mean(rewards * ce)                     # :69-71
+        if hp.min_entropy_reg:                              # :73-74
+            loss = loss + hp.min_entropy_w * avg_entropy(output)
+        grad, dlogits = torch.autograd.grad(loss, [ctx, output])
+        if j == 0:
+            out.update(logits=logits_all.detach(), entropy=entropy_rows(logits_all.detach()),
+                       selected_idx=selected.clone(), topk_idx=index.clone(), clip_score=score.detach().clone(),
+                       rewards=rewards.detach().clone(), loss=loss.detach().clone(), ctx_grad=grad.clone(),
+                       dlogits=dlogits.clone(),
+                       reward_image_features=rimg.clone())
+        with torch.no_grad():
+            new_ctx, m, v = adamw_step(ctx.detach(), grad, m, v, j + 1, hp)
+        ctx = new_ctx
+        out[f"ctx_after_step{j + 1}"] = ctx.detach().clone()
+    with torch.no_grad():                                   # tpt_cls_rl.py:260-262
+        final = C.student_logits(student_sd, views[:1], tokens, ctx.detach(), truncate)
+    out["ctx_after"] = ctx.detach().clone()
+    out["final_logits"] = final
+    out["top5"] = torch.topk(final, min(5, final.shape[1]), dim=-1).indices[0]
+    return out

@@ -1,0 +1,216 @@
+"""Seeded synthetic CLIP weights, views and class-token banks.
+
+Everything here is produced by a counter-based integer hash evaluated with torch
+int64 ops, so the same (seed, name, index) gives bit-identical fp32 values on the
+CPU (this container, oracle + golden fixtures) and on the GPU box (HIP path) with
+no dependence on torch's own generators.  Weight statistics follow
+``CLIP.initialize_parameters`` (reference TPT/clip/model.py:299-326); the key
+layout is the OpenAI state-dict layout accepted by ``build_model``
+(TPT/clip/model.py:399-436, SURVEY.md §8 a-W).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_M32 = 0xFFFFFFFF
+
+
+@dataclass(frozen=True)
+class ClipGeometry:
+    """Constructor arguments of the reference ``CLIP`` class, same order
+    (TPT/clip/model.py:244-257).  ViT image towers only."""
+    embed_dim: int
+    image_resolution: int
+    vision_layers: int
+    vision_width: int
+    vision_patch_size: int
+    context_length: int
+    vocab_size: int
+    transformer_width: int
+    transformer_heads: int
+    transformer_layers: int
+
+    @property
+    def vision_heads(self) -> int:
+        return self.vision_width // 64
+
+    @property
+    def grid(self) -> int:
+        return self.image_resolution // self.vision_patch_size
+
+    @property
+    def vision_tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    def as_tuple(self) -> Tuple[int, ...]:
+        return (self.embed_dim, self.image_resolution, self.vision_layers, self.vision_width,
+                self.vision_patch_size, self.context_length, self.vocab_size,
+                self.transformer_width, self.transformer_heads, self.transformer_layers)
+
+
+GEOMETRIES: Dict[str, ClipGeometry] = {
+    # the OpenAI checkpoints the reference loads (TPT/clip/clip.py:30-40)
+    "ViT-B/16": ClipGeometry(512, 224, 12, 768, 16, 77, 49408, 512, 8, 12),
+    "ViT-B/32": ClipGeometry(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12),
+    "ViT-L/14": ClipGeometry(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12),
+    # reduced geometries for tests (head_dim stays 64 as in every CLIP)
+    "tiny": ClipGeometry(128, 32, 2, 128, 8, 77, 1024, 128, 2, 2),
+    "tiny-r": ClipGeometry(64, 32, 2, 128, 8, 77, 1024, 64, 1, 2),
+    "small": ClipGeometry(256, 64, 4, 256, 16, 77, 4096, 256, 4, 4),
+}
+
+
+def _hash32(x: torch.Tensor) -> torch.Tensor:
+    """lowbias32-style avalanche on int64 tensors holding 32-bit values."""
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _keys(seed: int, name: str) -> Tuple[int, int]:
+    k1 = zlib.crc32(name.encode()) & _M32
+    k2 = (zlib.crc32((name + "#").encode()) ^ (seed * 0x9E3779B1)) & _M32
+    return k1, k2
+
+
+def raw_u32(seed: int, name: str, n: int, lane: int, device="cpu") -> torch.Tensor:
+    """n 32-bit words of stream (seed, name, lane) as int64."""
+    k1, k2 = _keys(seed, name)
+    c = torch.arange(n, dtype=torch.int64, device=device) * 4 + lane
+    h = _hash32((c + k1 * 0x9E3779B1) & _M32)
+    return _hash32(h ^ k2)
+
+
+_IH_STD = math.sqrt(8.0 * (65536.0 ** 2 - 1.0) / 12.0)
+
+
+def normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0,
+           device="cpu") -> torch.Tensor:
+    """Approximately normal fp32 tensor: Irwin-Hall sum of eight 16-bit uniforms,
+    exact in integer arithmetic, then one fp64 scale and one fp32 rounding."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    acc = torch.zeros(n, dtype=torch.int64, device=device)
+    for lane in range(4):
+        w = raw_u32(seed, name, n, lane, device)
+        acc += (w & 0xFFFF) + (w >> 16)
+    z = (acc.to(torch.float64) - 8 * 32767.5) / _IH_STD
+    return (z * std + mean).to(torch.float32).reshape(*shape)
+
+
+def randint(seed: int, name: str, n: int, low: int, high: int, device="cpu") -> torch.Tensor:
+    return low + raw_u32(seed, name, n, 0, device) % (high - low)
+
+
+# --------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------
+
+def _block(sd, seed, prefix, width, layers, attn_std, proj_std, fc_std, device):
+    for i in range(layers):
+        p = f"{prefix}.resblocks.{i}."
+        sd[p + "attn.in_proj_weight"] = normal(seed, p + "in_w", (3 * width, width), attn_std, device=device)
+        sd[p + "attn.in_proj_bias"] = normal(seed, p + "in_b", (3 * width,), 0.02, device=device)
+        sd[p + "attn.out_proj.weight"] = normal(seed, p + "out_w", (width, width), proj_std, device=device)
+        sd[p + "attn.out_proj.bias"] = normal(seed, p + "out_b", (width,), 0.02, device=device)
+        sd[p + "ln_1.weight"] = normal(seed, p + "ln1_w", (width,), 0.1, 1.0, device=device)
+        sd[p + "ln_1.bias"] = normal(seed, p + "ln1_b", (width,), 0.05, device=device)
+        sd[p + "mlp.c_fc.weight"] = normal(seed, p + "fc_w", (4 * width, width), fc_std, device=device)
+        sd[p + "mlp.c_fc.bias"] = normal(seed, p + "fc_b", (4 * width,), 0.02, device=device)
+        sd[p + "mlp.c_proj.weight"] = normal(seed, p + "proj_w", (width, 4 * width), proj_std, device=device)
+        sd[p + "mlp.c_proj.bias"] = normal(seed, p + "proj_b", (width,), 0.02, device=device)
+        sd[p + "ln_2.weight"] = normal(seed, p + "ln2_w", (width,), 0.1, 1.0, device=device)
+        sd[p + "ln_2.bias"] = normal(seed, p + "ln2_b", (width,), 0.05, device=device)
+
+
+def make_state_dict(geo: ClipGeometry, seed: int, device="cpu",
+                    logit_scale: float = math.log(100.0)) -> Dict[str, torch.Tensor]:
+    """fp32 state dict in the OpenAI CLIP key layout.  LayerNorm gains/biases and
+    linear biases are non-trivial on purpose so every epilogue is exercised.
+    ``logit_scale`` defaults to ln(100), the value of the released checkpoints
+    (a random-init CLIP has ln(1/0.07))."""
+    sd: Dict[str, torch.Tensor] = {}
+    vw, tw = geo.vision_width, geo.transformer_width
+    ps = geo.vision_patch_size
+    sc = vw ** -0.5
+    sd["visual.conv1.weight"] = normal(seed, "v.conv1", (vw, 3, ps, ps), (3 * ps * ps) ** -0.5, device=device)
+    sd["visual.class_embedding"] = normal(seed, "v.cls", (vw,), sc, device=device)
+    sd["visual.positional_embedding"] = normal(seed, "v.pos", (geo.vision_tokens, vw), sc, device=device)
+    sd["visual.ln_pre.weight"] = normal(seed, "v.lnpre_w", (vw,), 0.1, 1.0, device=device)
+    sd["visual.ln_pre.bias"] = normal(seed, "v.lnpre_b", (vw,), 0.05, device=device)
+    v_proj_std = (vw ** -0.5) * ((2 * geo.vision_layers) ** -0.5)
+    _block(sd, seed, "visual.transformer", vw, geo.vision_layers, vw ** -0.5, v_proj_std,
+           (2 * vw) ** -0.5, device)
+    sd["visual.ln_post.weight"] = normal(seed, "v.lnpost_w", (vw,), 0.1, 1.0, device=device)
+    sd["visual.ln_post.bias"] = normal(seed, "v.lnpost_b", (vw,), 0.05, device=device)
+    sd["visual.proj"] = normal(seed, "v.proj", (vw, geo.embed_dim), sc, device=device)
+
+    sd["token_embedding.weight"] = normal(seed, "t.tok", (geo.vocab_size, tw), 0.02, device=device)
+    sd["positional_embedding"] = normal(seed, "t.pos", (geo.context_length, tw), 0.01, device=device)
+    t_proj_std = (tw ** -0.5) * ((2 * geo.transformer_layers) ** -0.5)
+    _block(sd, seed, "transformer", tw, geo.transformer_layers, tw ** -0.5, t_proj_std,
+           (2 * tw) ** -0.5, device)
+    sd["ln_final.weight"] = normal(seed, "t.lnf_w", (tw,), 0.1, 1.0, device=device)
+    sd["ln_final.bias"] = normal(seed, "t.lnf_b", (tw,), 0.05, device=device)
+    sd["text_projection"] = normal(seed, "t.proj", (tw, geo.embed_dim), tw ** -0.5, device=device)
+    sd["logit_scale"] = torch.tensor(logit_scale, dtype=torch.float32, device=device)
+    return sd
+
+
+# --------------------------------------------------------------------------
+# inputs
+# --------------------------------------------------------------------------
+
+def make_views(seed: int, n_views: int, resolution: int, device="cpu") -> torch.Tensor:
+    """[N,3,R,R] fp32 N(0,1): post-``Normalize`` statistics of the reference loader
+    (TPT/tpt_cls_rl.py:132-133).  View 0 plays the clean centre crop."""
+    return normal(seed, "views", (n_views, 3, resolution, resolution), device=device)
+
+
+# name-length pmf chosen to reproduce the ImageNet prompt statistics measured in
+# SURVEY.md §0 fact 4 (total length min 8 / mean 9.16 / max 18 with n_ctx = 4)
+_NAME_LEN_PMF = ((1, 420), (2, 300), (3, 140), (4, 70), (5, 30), (6, 20), (7, 10), (8, 5), (9, 3), (11, 2))
+
+
+def make_token_bank(geo: ClipGeometry, n_cls: int, seed: int = 7, n_ctx: int = 4,
+                    ctx_token_ids: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+    """int64 [C, context_length] rows ``[SOT, ctx.., name.., '.', EOT, 0..]`` in the
+    format ``clip.tokenize`` produces (TPT/clip/clip.py:197-233).  EOT is the
+    largest id of the vocabulary, as ``argmax`` EOT lookup requires
+    (TPT/clip/custom_clip.py:71)."""
+    sot, eot = geo.vocab_size - 2, geo.vocab_size - 1
+    if ctx_token_ids is None:
+        ctx_token_ids = ctx_token_ids_default(geo, n_ctx)
+    assert len(ctx_token_ids) == n_ctx
+    dot = 269 % (geo.vocab_size - 2)
+    cum, tot = [], 0
+    for ln, w in _NAME_LEN_PMF:
+        tot += w
+        cum.append((tot, ln))
+    u = raw_u32(seed, "bank.len", n_cls, 0) % tot
+    toks = torch.zeros(n_cls, geo.context_length, dtype=torch.int64)
+    ids = raw_u32(seed, "bank.ids", n_cls * 16, 1).reshape(n_cls, 16) % (geo.vocab_size - 2)
+    for c in range(n_cls):
+        ln = next(l for t, l in cum if int(u[c]) < t)
+        if c == n_cls - 1 and n_cls >= 100:
+            ln = 11
+        row = [sot, *ctx_token_ids, *ids[c, :ln].tolist(), dot, eot]
+        toks[c, :len(row)] = torch.tensor(row, dtype=torch.int64)
+    return toks
+
+
+def ctx_token_ids_default(geo: ClipGeometry, n_ctx: int) -> Tuple[int, ...]:
+    """ids of the hand-crafted context words; (320,1125,539,320) is
+    'a photo of a' under the CLIP BPE."""
+    base = (320, 1125, 539, 320)
+    out = tuple(base[i % 4] % (geo.vocab_size - 2) for i in range(n_ctx))
+    return out

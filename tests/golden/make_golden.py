@@ -1,0 +1,307 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE
+itself (imported read-only from /root/reference/TPT) on this repo's seeded
+synthetic weights / views / token banks.
+
+Runs only in the build container (the reference does not travel).  The fixtures
+hold inputs that cannot be regenerated from a seed (none — everything comes from
+rlcf_amd.synth) and the reference's OUTPUTS, as small .npz files.
+
+    python tests/golden/make_golden.py [--only tiny,small,ops,b16n8,b16n64,modules]
+
+Import recipe: SURVEY.md Appendix B (stub torchvision/ftfy, open the
+DOWNLOAD_ROOT gate, replace clip.load by a factory that builds the reference's
+own `CLIP` class and loads our state dict, replace the BPE `tokenize` by a
+lookup into the synthetic token bank).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from rlcf_amd import synth  # noqa: E402
+
+REF = "/root/reference/TPT"
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    tv = types.ModuleType("torchvision")
+    tv.__path__ = []
+    tvt = types.ModuleType("torchvision.transforms")
+    tvd = types.ModuleType("torchvision.datasets")
+    for n in ["Compose", "Resize", "CenterCrop", "ToTensor", "Normalize", "RandomResizedCrop",
+              "RandomHorizontalFlip"]:
+        setattr(tvt, n, type(n, (), {"__init__": lambda s, *a, **k: None}))
+    tvt.InterpolationMode = type("InterpolationMode", (), {"BICUBIC": "bicubic"})
+    tv.transforms, tv.datasets = tvt, tvd
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.datasets": tvd})
+    ft = types.ModuleType("ftfy")
+    ft.fix_text = lambda s: s
+    sys.modules["ftfy"] = ft
+    _exists = os.path.exists
+    os.path.exists = lambda p: True if p == "/YOUR/PATH" else _exists(p)
+    sys.path.insert(0, REF)
+    import clip  # noqa
+    import clip.clip as cc
+    import clip.custom_clip as custom
+    import clip_reward
+    from clip import model as refmodel
+    import tpt_cls_rl
+    os.path.exists = _exists
+    return types.SimpleNamespace(clip=clip, cc=cc, custom=custom, clip_reward=clip_reward,
+                                 refmodel=refmodel, tpt=tpt_cls_rl)
+
+
+class Bank:
+    """Synthetic tokenizer: 'a photo of a c<i>.' -> row i of the token bank."""
+
+    def __init__(self, geo, n_cls, n_ctx=4, seed=7):
+        self.geo, self.n_ctx = geo, n_ctx
+        self.tokens = synth.make_token_bank(geo, n_cls, seed=seed, n_ctx=n_ctx)
+        self.ctx_ids = synth.ctx_token_ids_default(geo, n_ctx)
+        self.classnames = [f"c{i}" for i in range(n_cls)]
+
+    def tokenize(self, texts, context_length=77, truncate=False):
+        if isinstance(texts, str):
+            texts = [texts]
+        rows = []
+        for t in texts:
+            t = t.strip()
+            if t.endswith("."):
+                rows.append(self.tokens[int(t.rstrip(".").split("c")[-1])])
+            else:  # the ctx_init words
+                r = torch.zeros(self.geo.context_length, dtype=torch.int64)
+                ids = [self.geo.vocab_size - 2, *self.ctx_ids, self.geo.vocab_size - 1]
+                r[: len(ids)] = torch.tensor(ids)
+                rows.append(r)
+        return torch.stack(rows)
+
+
+def install_models(ref, sds):
+    """sds: arch name -> (geometry, state dict).  Makes every `load` in the
+    reference return the reference's own CLIP class with our weights."""
+
+    def fake_load(name, device="cpu", jit=False, download_root=None):
+        geo, sd = sds[name]
+        m = ref.refmodel.CLIP(*geo.as_tuple())
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        return m.eval().float(), geo.embed_dim, None
+
+    ref.cc.load = ref.clip.load = ref.custom.load = fake_load
+    ref.clip_reward.clip.load = fake_load
+
+
+def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4):
+    """The harness body TPT/tpt_cls_rl.py:251-262 around the reference's own
+    test_time_tuning, with taps on its intermediates."""
+    s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    s_sd = synth.make_state_dict(s_geo, seed=11)
+    r_sd = synth.make_state_dict(r_geo, seed=23)
+    install_models(ref, {student: (s_geo, s_sd)})
+    bank = Bank(s_geo, n_cls, n_ctx)
+    ref.custom.tokenize = bank.tokenize
+    model = ref.custom.ClipTestTimeTuning("cpu", bank.classnames, None, arch=student, n_ctx=n_ctx,
+                                          ctx_init="a_photo_of_a")
+    for name, p in model.named_parameters():
+        if "prompt_learner" not in name:
+            p.requires_grad_(False)
+    optimizer = torch.optim.AdamW(model.prompt_learner.parameters(), hp["lr"], weight_decay=hp["weight_decay"])
+    args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"],
+                                 min_entropy_reg=hp.get("min_entropy_reg", 0),
+                                 min_entropy_w=hp.get("min_entropy_w", 0.2), gpu=None, tpt=True)
+    install_models(ref, {reward: (r_geo, r_sd)})      # student and reward may share an arch name
+    rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True,
+                                     amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
+                                     reward_process=hp.get("reward_process", True),
+                                     process_batch=hp.get("process_batch", False))
+    assert torch.equal(model.prompt_learner.tokenized_prompts, bank.tokens)
+    rm.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scaler = torch.cuda.amp.GradScaler(init_scale=1000)
+    views = synth.make_views(view_seed, n_views, s_geo.image_resolution)
+
+    taps = {}
+    orig_select = ref.tpt.select_confident_samples
+
+    def tap_select(logits, top):
+        out, idx = orig_select(logits, top)
+        if "logits" not in taps:
+            taps["logits"] = logits.detach().clone()
+            taps["selected_idx"] = idx.clone()
+        return out, idx
+
+    orig_score, orig_post = rm.CLIPScore, rm.rewards_post_process
+
+    def tap_score(*a, **k):
+        s = orig_score(*a, **k)
+        if "clip_score" not in taps:
+            taps["clip_score"] = s.detach().clone()
+            taps["topk_idx"] = k["class_index"].clone()
+        return s
+
+    def tap_post(x):
+        r = orig_post(x)
+        taps.setdefault("rewards", r.detach().clone())
+        return r
+
+    ref.tpt.select_confident_samples = tap_select
+    rm.CLIPScore, rm.rewards_post_process = tap_score, tap_post
+    grads = []
+    model.prompt_learner.ctx.register_hook(lambda g: grads.append(g.detach().clone()))
+
+    model.eval()
+    with torch.no_grad():
+        model.reset()
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.tpt.test_time_tuning(model, views, optimizer, scaler, args, reward_model=rm)
+        t1 = time.time()
+        with torch.no_grad():
+            final = model(views[:1])
+    t2 = time.time()
+    ref.tpt.select_confident_samples = orig_select
+    lg = taps["logits"]
+    lp = lg.log_softmax(1)
+    out = dict(
+        logits=lg, entropy=-(lp.exp() * lp).sum(1), selected_idx=taps["selected_idx"],
+        topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]), clip_score=taps["clip_score"],
+        rewards=taps["rewards"], ctx_grad=grads[0], ctx_after=model.prompt_learner.ctx.detach().clone(),
+        final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0],
+        reward_image_features=rm.image_features.clone(), reward_class_features=rm.class_features.clone(),
+        ref_seconds=torch.tensor([t1 - t0, t2 - t1]),
+    )
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def save(name, arrays, meta):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+BASE_HP = dict(lr=7e-3, weight_decay=5e-4, sample_k=3, tta_steps=1, selection_p=0.5)
+
+TTA_CASES = {
+    # name: (student, reward, N, C, hp overrides)
+    "tta_tiny_s1": ("tiny", "tiny-r", 8, 16, {}),
+    "tta_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(tta_steps=3)),
+    "tta_tiny_amplify": ("tiny", "tiny-r", 8, 16, dict(reward_amplify=True)),
+    "tta_tiny_batchproc": ("tiny", "tiny-r", 8, 16, dict(process_batch=True)),
+    "tta_tiny_minent": ("tiny", "tiny-r", 8, 16, dict(min_entropy_reg=1, min_entropy_w=0.2)),
+    "tta_tiny_k1": ("tiny", "tiny-r", 8, 16, dict(sample_k=1, view_seed=1006)),
+    "tta_small_s1": ("small", "small", 16, 40, dict(selection_p=0.25)),
+    "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
+    "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1)),
+}
+GROUPS = {
+    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny")],
+    "small": ["tta_small_s1"],
+    "b16n8": ["tta_b16_n8"],
+    "b16n64": ["tta_b16_n64"],
+}
+
+
+def gen_ops(ref):
+    """G0: op-level vectors from the reference's own modules / functions."""
+    torch.manual_seed(0)
+    out = {}
+    x = synth.normal(3, "ops.x", (5, 3, 128))
+    ln = ref.refmodel.LayerNorm(128)
+    ln.weight.data = synth.normal(3, "ops.lnw", (128,), 0.1, 1.0)
+    ln.bias.data = synth.normal(3, "ops.lnb", (128,), 0.05)
+    out["ln_y"] = ln(x).detach()
+    out["gelu_y"] = ref.refmodel.QuickGELU()(x)
+    geo = synth.GEOMETRIES["tiny"]
+    sd = synth.make_state_dict(geo, seed=5)
+    for masked in (False, True):
+        L = 9
+        mask = torch.full((L, L), float("-inf")).triu_(1) if masked else None
+        blk = ref.refmodel.ResidualAttentionBlock(128, 2, mask)
+        blk.load_state_dict({k[len("transformer.resblocks.0."):]: v for k, v in sd.items()
+                             if k.startswith("transformer.resblocks.0.")})
+        xb = synth.normal(4, "ops.blk", (L, 3, 128)).requires_grad_(True)      # LND
+        y = blk(xb)
+        gy = synth.normal(4, "ops.blk.g", (L, 3, 128))
+        (gx,) = torch.autograd.grad((y * gy).sum(), xb)
+        out[f"block_y_{int(masked)}"] = y.detach()
+        out[f"block_gx_{int(masked)}"] = gx
+    lg = synth.normal(6, "ops.logits", (16, 50), 3.0)
+    for p in (0.1, 0.25, 0.5, 0.05):
+        sel, idx = ref.tpt.select_confident_samples(lg, p)
+        out[f"select_idx_{p}"] = idx
+    out["avg_entropy"] = ref.tpt.avg_entropy(lg[:4])
+    # AdamW vs torch.optim.AdamW, 3 steps with weight decay
+    p = torch.nn.Parameter(synth.normal(8, "ops.p", (4, 64), 0.02))
+    opt = torch.optim.AdamW([p], 7e-3, weight_decay=5e-4)
+    for s in range(3):
+        p.grad = synth.normal(8, f"ops.g{s}", (4, 64), 1e-3)
+        opt.step()
+        out[f"adamw_p{s + 1}"] = p.detach().clone()
+    # reward post-processing, all switch combinations incl. the K==1 guard
+    sc = synth.normal(9, "ops.score", (4, 3), 0.3, 0.5).clamp_min(0)
+    for amp in (False, True):
+        for pb in (False, True):
+            rm = types.SimpleNamespace(reward_process=True, amplify_rewards=amp)
+            out[f"rewards_amp{int(amp)}_pb{int(pb)}"] = ref.clip_reward.CLIPRewards.rewards_post_process(
+                rm, sc.flatten() if pb else sc)
+    rm = types.SimpleNamespace(reward_process=True, amplify_rewards=True)
+    out["rewards_k1"] = ref.clip_reward.CLIPRewards.rewards_post_process(rm, sc[:, :1])
+    out["rewards_in"] = sc
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def gen_modules(ref):
+    """G4: encode_image / encode_text of the reference CLIP class at full geometries."""
+    out = {}
+    for arch, tag in (("ViT-B/16", "b16"), ("ViT-L/14", "l14")):
+        geo = synth.GEOMETRIES[arch]
+        sd = synth.make_state_dict(geo, seed=11)
+        m = ref.refmodel.CLIP(*geo.as_tuple())
+        m.load_state_dict(sd)
+        m = m.eval().float()
+        views = synth.make_views(1000, 2, geo.image_resolution)
+        toks = synth.make_token_bank(geo, 8, seed=7)
+        with torch.no_grad():
+            out[f"{tag}_image"] = m.encode_image(views)
+            out[f"{tag}_text"] = m.encode_text(toks)
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="tiny,small,ops")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    ref = import_reference()
+    for grp in a.only.split(","):
+        if grp == "ops":
+            save("ops", gen_ops(ref), {})
+        elif grp == "modules":
+            save("modules", gen_modules(ref), {})
+        else:
+            for name in GROUPS[grp]:
+                student, reward, n, c, over = TTA_CASES[name]
+                hp = dict(BASE_HP, **over)
+                vseed = hp.pop("view_seed", 1000)
+                t0 = time.time()
+                arrays = run_reference_tta(ref, student, reward, n, c, hp, view_seed=vseed)
+                meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23,
+                            view_seed=vseed, bank_seed=7, n_ctx=4, **hp)
+                save(name, arrays, meta)
+                print(f"  {name}: {time.time() - t0:.1f}s  idx={arrays['selected_idx']}  top5={arrays['top5']}")
+
+
+if __name__ == "__main__":
+    main()

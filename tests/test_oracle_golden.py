@@ -1,0 +1,114 @@
+"""CPU: the oracle restatement (oracle/) against the fixtures generated from the
+imported reference (tests/golden/make_golden.py).  This is the oracle's parity pin."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref as C
+from oracle import rlcf_ref as R
+from rlcf_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("meta_")}
+    meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+    return arrays, meta
+
+
+def hyper(meta):
+    return R.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"],
+                      lr=meta["lr"], weight_decay=meta["weight_decay"],
+                      reward_amplify=bool(meta.get("reward_amplify", False)),
+                      process_batch=bool(meta.get("process_batch", False)),
+                      min_entropy_reg=bool(meta.get("min_entropy_reg", 0)),
+                      min_entropy_w=float(meta.get("min_entropy_w", 0.2)))
+
+
+def run_oracle(meta, truncate=False):
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    rsd = synth.make_state_dict(rg, meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
+    ctx0 = C.ctx_from_tokens(ssd, synth.ctx_token_ids_default(sg, meta["n_ctx"]))
+    return R.tta_sample(ssd, rsd, views, tokens, ctx0, hyper(meta), truncate=truncate)
+
+
+TINY = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
+        "tta_small_s1"]
+
+
+@pytest.mark.parametrize("name", TINY)
+@pytest.mark.parametrize("truncate", [False, True])
+def test_tta_matches_reference(name, truncate):
+    g, meta = load(name)
+    o = run_oracle(meta, truncate)
+    assert torch.equal(o["selected_idx"], g["selected_idx"])
+    assert torch.equal(o["topk_idx"], g["topk_idx"])
+    assert torch.equal(o["top5"], g["top5"])
+    torch.testing.assert_close(o["logits"], g["logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(o["entropy"], g["entropy"], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(o["clip_score"].reshape(-1), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=1e-3, rtol=0)
+    if meta["tta_steps"] == 1:
+        gr, og = g["ctx_grad"], o["ctx_grad"]
+        assert gr.norm() > 0
+        assert (og - gr).norm() / gr.norm() < 1e-3
+        big = gr.abs() > 1e-3 * gr.abs().max()
+        assert torch.equal(torch.sign(og[big]), torch.sign(gr[big]))
+    # Adam's first step is ~ -lr*sign(g): compare ctx where the reference gradient is not ~0
+    d = (o["ctx_after"] - g["ctx_after"]).abs()
+    assert (d > 1e-4).float().mean() < 0.01
+
+
+def test_ops_fixture():
+    g, _ = load("ops")
+    x = synth.normal(3, "ops.x", (5, 3, 128))
+    w = synth.normal(3, "ops.lnw", (128,), 0.1, 1.0)
+    b = synth.normal(3, "ops.lnb", (128,), 0.05)
+    torch.testing.assert_close(C.layer_norm(x, w, b), g["ln_y"], atol=2e-6, rtol=1e-6)
+    torch.testing.assert_close(C.quick_gelu(x), g["gelu_y"], atol=1e-6, rtol=1e-6)
+    sd = synth.make_state_dict(synth.GEOMETRIES["tiny"], seed=5)
+    for masked in (0, 1):
+        L = 9
+        xb = synth.normal(4, "ops.blk", (L, 3, 128)).transpose(0, 1).contiguous().requires_grad_(True)  # -> NLD
+        y = C.residual_block(xb, sd, "transformer.resblocks.0.", C.causal_mask(L) if masked else None)
+        gy = synth.normal(4, "ops.blk.g", (L, 3, 128)).transpose(0, 1)
+        (gx,) = torch.autograd.grad((y * gy).sum(), xb)
+        torch.testing.assert_close(y.transpose(0, 1), g[f"block_y_{masked}"], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(gx.transpose(0, 1), g[f"block_gx_{masked}"], atol=2e-5, rtol=1e-4)
+    lg = synth.normal(6, "ops.logits", (16, 50), 3.0)
+    for p in (0.1, 0.25, 0.5, 0.05):
+        _, idx = R.select_confident_samples(lg, p)
+        assert torch.equal(idx, g[f"select_idx_{p}"])
+    assert g["select_idx_0.05"].numel() == 0          # int(16*0.05) == 0: the N*p<1 edge
+    torch.testing.assert_close(R.avg_entropy(lg[:4]), g["avg_entropy"], atol=1e-6, rtol=1e-6)
+    hp = R.TTAHyper()
+    p = synth.normal(8, "ops.p", (4, 64), 0.02)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(3):
+        p, m, v = R.adamw_step(p, synth.normal(8, f"ops.g{s}", (4, 64), 1e-3), m, v, s + 1, hp)
+        torch.testing.assert_close(p, g[f"adamw_p{s + 1}"], atol=1e-7, rtol=1e-6)
+    sc = g["rewards_in"]
+    for amp in (0, 1):
+        for pb in (0, 1):
+            r = R.rewards_post_process(sc.flatten() if pb else sc, True, bool(amp))
+            torch.testing.assert_close(r, g[f"rewards_amp{amp}_pb{pb}"], atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(R.rewards_post_process(sc[:, :1], True, True), g["rewards_k1"])
+
+
+def test_synth_is_deterministic():
+    a = synth.normal(1, "x", (1000,))
+    b = synth.normal(1, "x", (1000,))
+    assert torch.equal(a, b)
+    assert abs(a.mean()) < 0.15 and abs(a.std() - 1) < 0.1
+    assert not torch.equal(a, synth.normal(2, "x", (1000,)))
+    t = synth.make_token_bank(synth.GEOMETRIES["ViT-B/16"], 1000)
+    eot = t.argmax(-1)
+    assert eot.min() == 7 and eot.max() == 17 and abs(eot.float().mean().item() + 1 - 9.16) < 0.25
