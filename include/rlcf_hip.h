@@ -1,0 +1,185 @@
+/* rlcf_hip.h — C ABI of librlcf_hip.so: the MI355X (gfx950) implementation of the
+ * RLCF per-sample test-time-adaptation hot path.
+ *
+ * The reference (mzhaoshuai/RLCF, TPT/) is pure Python on torch ops and has no FFI;
+ * this header is the boundary a maintainer would bind from Python (ctypes, see
+ * INTEGRATION.md).  Every entry point cites the reference call site it replaces
+ * (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - all `const float*` / `float*` / `int32_t*` arguments are DEVICE pointers into
+ *     caller-owned (torch) memory, contiguous row-major, unless marked HOST;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, negative rlcf_status on error (rlcf_last_error() has text);
+ *   - an engine is not thread-safe; no allocation happens on the per-sample path.
+ */
+#ifndef RLCF_HIP_H
+#define RLCF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rlcf_stream;            /* hipStream_t */
+typedef struct rlcf_engine rlcf_engine;
+
+enum rlcf_status { RLCF_OK = 0, RLCF_ERR_ARG = -1, RLCF_ERR_HIP = -2, RLCF_ERR_STATE = -3, RLCF_ERR_NOMEM = -4 };
+enum rlcf_precision {
+    RLCF_PREC_F32 = 0,   /* parity mode: f32 storage, f32-input MFMA (exact f32 FMA chains)            */
+    RLCF_PREC_BF16 = 1,  /* performance mode: bf16 GEMM/attention operands, f32 accumulate/LN/softmax */
+    RLCF_PREC_F16X3 = 2  /* split-f16 mode: each f32 operand = hi+lo f16, 3 f16 MFMAs per product      */
+};
+enum rlcf_epilogue {     /* GEMM epilogues (TPT/clip/model.py:166-168,177-181,190-191) */
+    RLCF_EPI_NONE = 0,
+    RLCF_EPI_QUICKGELU = 1,      /* y = v*sigmoid(1.702 v)                                   */
+    RLCF_EPI_QUICKGELU_BWD = 2   /* y = v * d/df[f*sigmoid(1.702 f)] with f = aux            */
+};
+enum rlcf_text_mode {
+    RLCF_TEXT_DENSE = 0,   /* reference graph: every class runs all context_length positions */
+    RLCF_TEXT_PACKED = 1,  /* rows after EOT dropped (exact under the causal mask)          */
+    RLCF_TEXT_SHARED = 2   /* PACKED + the class-independent [SOT|ctx] rows computed once    */
+};
+enum rlcf_which { RLCF_STUDENT = 0, RLCF_REWARD = 1 };
+
+const char* rlcf_last_error(void);
+int rlcf_version(void);
+
+/* CLIP geometry: constructor arguments of the reference `CLIP` class (TPT/clip/model.py:244-257). */
+typedef struct {
+    int embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size;
+    int context_length, vocab_size, text_width, text_heads, text_layers;
+} rlcf_clip_cfg;
+
+/* One attention sequence over a packed token matrix: queries are rows
+ * [q_start, q_start+q_len); keys are rows [pre_start, pre_start+pre_len) followed by the
+ * query rows themselves.  Causal: query i sees all prefix keys and own keys <= i. */
+typedef struct { int q_start, q_len, pre_start, pre_len; } rlcf_seq;
+
+/* ------------------------------------------------------------------ op level ----
+ * Stateless kernels, exposed for parity tests and for autograd glue. */
+
+/* C[M,N] = epi(alpha * A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]).  Replaces the
+ * nn.Linear / in_proj / out_proj / `@ proj` call sites TPT/clip/model.py:175-191,235-238,
+ * custom_clip.py:71,332-333.  K % 16 == 0.  bias/residual/aux may be NULL. */
+int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias,
+                 const float* residual, int ldr, const float* aux, int ldaux,
+                 float* C, int ldc, int M, int N, int K, float alpha, int epilogue, int precision,
+                 rlcf_stream stream);
+
+/* Row LayerNorm, fp32, eps 1e-5, biased variance (TPT/clip/model.py:157-163). */
+int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       int rows, int width, rlcf_stream stream);
+/* dx (and, if dgamma/dbeta non-NULL, ACCUMULATED parameter grads) of the above. */
+int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx,
+                       float* dgamma, float* dbeta, int rows, int width, rlcf_stream stream);
+
+/* Multi-head attention core of nn.MultiheadAttention (TPT/clip/model.py:175,185-187):
+ * qkv[T,3W] packed [q|k|v], head_dim 64, scale 1/8, softmax over keys, out[T,W].
+ * seqs: DEVICE array of n_seq descriptors; max_q_len bounds q_len; lse[T,H] optional. */
+int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len,
+                       int width, int causal, float* out, float* lse, int precision, rlcf_stream stream);
+/* Backward (dX only): dqkv[T,3W] from dout[T,W]; dqkv must be zero-filled by the caller
+ * (prefix keys accumulate across sequences).  key count per sequence <= 96 (text tower). */
+int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys,
+                       int width, int causal, float* dqkv, rlcf_stream stream);
+
+/* Per-row entropy H = -sum softmax*log_softmax and the int(N*top) lowest-entropy rows in
+ * ascending order: select_confident_samples, TPT/tpt_cls_rl.py:32-35.  idx[n_sel]. */
+int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy,
+                        int32_t* idx, rlcf_stream stream);
+
+/* Flags of rlcf_reward_loss (TPT/params.py:55-59,65-66). */
+enum { RLCF_F_REWARD_PROCESS = 1, RLCF_F_AMPLIFY = 2, RLCF_F_PROCESS_BATCH = 4, RLCF_F_MIN_ENTROPY = 8 };
+/* The loss section of test_time_tuning (TPT/tpt_cls_rl.py:63-74) with
+ * CLIPRewards.CLIPScore / rewards_post_process (TPT/clip_reward.py:111-128,152-165):
+ * rows = logits[sel[i]] (sel NULL: rows = logits[i]); top-K classes per row; CLIPScore
+ * against class_feat[C,Dr] and reward_img[n_sel,Dr]; baseline; loss = mean(r*CE)
+ * (+ w*avg_entropy); dlogits[n_sel,C] = dloss/drows (dense).  All outputs optional but dlogits. */
+int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
+                     const float* class_feat, const float* reward_img, int Dr,
+                     float clipscore_weight, int flags, float min_entropy_w,
+                     int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                     float* dlogits, rlcf_stream stream);
+
+/* torch.optim.AdamW single step (amsgrad off), TPT/tpt_cls_rl.py:78,120. step is 1-based. */
+int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    rlcf_stream stream);
+
+/* ------------------------------------------------------------------ engine ------
+ * Owns device copies of the weights (plus derived layouts) and all workspace. */
+rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward /*NULL: none*/,
+                                int max_views, int max_classes, int precision);
+void rlcf_engine_destroy(rlcf_engine*);
+/* Copy one OpenAI-layout state-dict tensor (TPT/clip/model.py:399-436) into the engine. */
+int rlcf_engine_load_weight(rlcf_engine*, int which, const char* key, const float* dev_ptr, int64_t numel);
+/* After all weights: checks completeness, builds transposed / low-precision copies. */
+int rlcf_engine_finalize(rlcf_engine*, rlcf_stream stream);
+
+/* PromptLearner.__init__/reset_classnames (TPT/clip/custom_clip.py:77-196) +
+ * BaseRewards.set_class_features (TPT/clip_reward.py:55-57): tokens HOST int32 [C,context_length]
+ * as produced by clip.tokenize; builds the packed text layout, gathers token embeddings and
+ * caches the reward model's class features.  ctx_init DEVICE [n_ctx,W] becomes ctx_init_state. */
+int rlcf_engine_set_class_bank(rlcf_engine*, const int32_t* tokens_host, int C, int n_ctx,
+                               const float* ctx_init, int text_mode, rlcf_stream stream);
+
+/* encode_image + L2 normalise (TPT/clip/model.py:223-240,340-341; custom_clip.py:327-330;
+ * clip_reward.py:130-137).  images [n,3,R,R]; feats [n,D]. */
+int rlcf_encode_image(rlcf_engine*, int which, const float* images, int n, float* feats, rlcf_stream stream);
+/* ClipTestTimeTuning.get_text_features (custom_clip.py:315-323): txt [C,D] normalised. */
+int rlcf_text_features(rlcf_engine*, const float* ctx, float* txt, rlcf_stream stream);
+/* reward class bank cached by set_class_bank: copies [C,Dr] out. */
+int rlcf_reward_class_features(rlcf_engine*, float* out, rlcf_stream stream);
+/* logits = exp(logit_scale) * img @ txt^T (custom_clip.py:332-333). */
+int rlcf_logits(rlcf_engine*, const float* img, int n, const float* txt, int C, float* logits, rlcf_stream stream);
+/* d loss / d ctx given dlogits[n,C] w.r.t. logits = scale*img@txt(ctx)^T — what autograd does for
+ * loss.backward() at TPT/tpt_cls_rl.py:77.  Dense over classes (any dlogits). */
+int rlcf_text_backward_dense(rlcf_engine*, const float* ctx, const float* img, int n, const float* dlogits,
+                             float* dctx, rlcf_stream stream);
+
+typedef struct {                 /* flags read on the path, TPT/params.py:13-98 */
+    float selection_p; int tta_steps; int sample_k;
+    float lr, weight_decay, beta1, beta2, eps;
+    int flags;                   /* RLCF_F_* */
+    float clipscore_weight, min_entropy_w;
+    int sparse_backward;         /* 1: back-propagate only the n_sel*K touched classes when exact */
+} rlcf_tta_args;
+
+typedef struct {                 /* every pointer optional (NULL = not wanted); DEVICE */
+    float* logits;               /* [N,C] first-step student logits          */
+    float* entropy;              /* [N]                                      */
+    int32_t* selected_idx;       /* [n_sel]                                  */
+    int32_t* topk_idx;           /* [n_sel,K] first step                     */
+    float* clip_score;           /* [n_sel*K]                                */
+    float* rewards;              /* [n_sel*K]                                */
+    float* loss;                 /* [1]                                      */
+    float* dlogits;              /* [n_sel,C]                                */
+    float* ctx_grad;             /* [n_ctx,W] first step                     */
+    float* ctx_after;            /* [n_ctx,W]                                */
+    float* reward_image_features;/* [n_sel,Dr]                               */
+    float* final_logits;         /* [C]                                      */
+    int32_t* top5;               /* [5]                                      */
+} rlcf_tta_out;
+
+/* One iteration of the harness loop TPT/tpt_cls_rl.py:251-262: reset ctx and optimizer state,
+ * test_time_tuning (:47-79), final one-view inference on views[0], top-5.  views [N,3,R,R]. */
+int rlcf_tta_sample(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args,
+                    const rlcf_tta_out* out, rlcf_stream stream);
+/* Same for `count` consecutive samples (views [count,N,3,R,R]); top5 [count,5], final_logits
+ * [count,C] (optional).  One host call per batch of test images. */
+int rlcf_tta_batch(rlcf_engine*, const float* views, int count, int N, const rlcf_tta_args* args,
+                   float* final_logits, int32_t* top5, rlcf_stream stream);
+
+/* bookkeeping for bench/roofline: FLOPs actually executed by the last rlcf_tta_sample. */
+double rlcf_engine_last_flops(rlcf_engine*);
+int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
+
+/* Optional per-launch timing (HIP events on the launch stream) of the dominant GEMM kernel:
+ * enable, run one sample, read {launches, total ms, total algorithmic FLOPs}. */
+int rlcf_profile_gemm(int enable);
+int rlcf_profile_read(int* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""ctypes binding of librlcf_hip.so (include/rlcf_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing this module raises.  `build()` compiles it in-tree with hipcc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librlcf_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+PREC_F32, PREC_BF16, PREC_F16X3 = 0, 1, 2
+EPI_NONE, EPI_QUICKGELU, EPI_QUICKGELU_BWD = 0, 1, 2
+TEXT_DENSE, TEXT_PACKED, TEXT_SHARED = 0, 1, 2
+STUDENT, REWARD = 0, 1
+F_REWARD_PROCESS, F_AMPLIFY, F_PROCESS_BATCH, F_MIN_ENTROPY = 1, 2, 4, 8
+
+
+class ClipCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("embed_dim", "image_resolution", "vision_layers", "vision_width",
+                                       "vision_patch_size", "context_length", "vocab_size", "text_width",
+                                       "text_heads", "text_layers")]
+
+
+class Seq(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("q_start", "q_len", "pre_start", "pre_len")]
+
+
+class TTAArgs(C.Structure):
+    _fields_ = [("selection_p", C.c_float), ("tta_steps", C.c_int), ("sample_k", C.c_int),
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("flags", C.c_int), ("clipscore_weight", C.c_float),
+                ("min_entropy_w", C.c_float), ("sparse_backward", C.c_int)]
+
+
+TTA_OUT_FIELDS = ("logits", "entropy", "selected_idx", "topk_idx", "clip_score", "rewards", "loss", "dlogits",
+                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5")
+
+
+class TTAOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TTA_OUT_FIELDS]
+
+
+P, I, F, I64, D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
+
+# name -> (restype, argtypes): every symbol include/rlcf_hip.h declares
+SIGNATURES = {
+    "rlcf_last_error": (C.c_char_p, []),
+    "rlcf_version": (I, []),
+    "rlcf_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, P, I, I, I, I, F, I, I, P]),
+    "rlcf_layernorm_fwd": (I, [P, P, P, P, I, I, P]),
+    "rlcf_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
+    "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),
+    "rlcf_attention_bwd": (I, [P, P, P, I, I, I, I, P, P]),
+    "rlcf_entropy_select": (I, [P, I, I, I, P, P, P]),
+    "rlcf_reward_loss": (I, [P, I, P, I, I, I, P, P, I, F, I, F, P, P, P, P, P, P]),
+    "rlcf_adamw_step": (I, [P, P, P, P, I64, I, F, F, F, F, F, P]),
+    "rlcf_engine_create": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I]),
+    "rlcf_engine_destroy": (None, [P]),
+    "rlcf_engine_load_weight": (I, [P, I, C.c_char_p, P, I64]),
+    "rlcf_engine_finalize": (I, [P, P]),
+    "rlcf_engine_set_class_bank": (I, [P, P, I, I, P, I, P]),
+    "rlcf_encode_image": (I, [P, I, P, I, P, P]),
+    "rlcf_text_features": (I, [P, P, P, P]),
+    "rlcf_reward_class_features": (I, [P, P, P]),
+    "rlcf_logits": (I, [P, P, I, P, I, P, P]),
+    "rlcf_text_backward_dense": (I, [P, P, P, I, P, P, P]),
+    "rlcf_tta_sample": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_tta_batch": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
+    "rlcf_engine_last_flops": (D, [P]),
+    "rlcf_engine_text_rows": (I, [P]),
+    "rlcf_profile_gemm": (I, [I]),
+    "rlcf_profile_read": (I, [C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile librlcf_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError("building librlcf_hip.so failed:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+class RlcfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (loudly) if it is absent — there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RlcfError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(the RLCF HIP path has no CPU fallback)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RlcfError(f"{what} failed ({rc}): {lib().rlcf_last_error().decode(errors='replace')}")

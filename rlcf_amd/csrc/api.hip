@@ -1,0 +1,226 @@
+// extern "C" surface of librlcf_hip.so (include/rlcf_hip.h): argument validation, error text,
+// engine construction.  No torch types cross this boundary.
+#include "engine.h"
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[1024] = "";
+void rlcf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* rlcf_last_error(void) { return g_err; }
+int rlcf_version(void) { return 1; }
+
+// ------------------------------------------------------------------ op level
+int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                 const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
+                 int precision, rlcf_stream stream) {
+    RLCF_ARG_CHECK(A && W && C && precision == RLCF_PREC_F32);
+    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_QUICKGELU_BWD);
+    RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.out_bf16 = 0;
+    return launch_gemm_f32(g, (hipStream_t)stream);
+}
+int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, rlcf_stream stream) {
+    RLCF_ARG_CHECK(x && gamma && beta && y);
+    return launch_layernorm_fwd(x, gamma, beta, y, nullptr, rows, width, (hipStream_t)stream);
+}
+int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
+                       int width, rlcf_stream stream) {
+    RLCF_ARG_CHECK(x && gamma && dy && dx);
+    return launch_layernorm_bwd(x, gamma, dy, nullptr, dx, dgamma, dbeta, rows, width, (hipStream_t)stream);
+}
+int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
+                       float* lse, int precision, rlcf_stream stream) {
+    RLCF_ARG_CHECK(qkv && seqs && out && precision == RLCF_PREC_F32);
+    return launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, width, causal, out, lse, (hipStream_t)stream);
+}
+int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width, int causal,
+                       float* dqkv, rlcf_stream stream) {
+    RLCF_ARG_CHECK(qkv && dout && seqs && dqkv);
+    return launch_attention_bwd(qkv, dout, seqs, n_seq, max_keys, width, causal, dqkv, (hipStream_t)stream);
+}
+int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, rlcf_stream stream) {
+    RLCF_ARG_CHECK(logits && entropy && (idx || n_sel == 0));
+    return launch_entropy_select(logits, n, C, n_sel, entropy, idx, (hipStream_t)stream);
+}
+int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K, const float* class_feat,
+                     const float* reward_img, int Dr, float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx,
+                     float* clip_score, float* rewards, float* loss, float* dlogits, rlcf_stream stream) {
+    RLCF_ARG_CHECK(logits && class_feat && reward_img);
+    return launch_reward_loss(logits, ld_logits, sel, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags, min_entropy_w,
+                              topk_idx, clip_score, rewards, loss, dlogits, (hipStream_t)stream);
+}
+int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, rlcf_stream stream) {
+    RLCF_ARG_CHECK(p && g && m && v);
+    return launch_adamw(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ engine
+static bool cfg_ok(const rlcf_clip_cfg* c) {
+    return c && c->embed_dim > 0 && c->vision_width % HEAD_DIM == 0 && c->text_width % HEAD_DIM == 0 && c->vision_width <= 1024 &&
+           c->text_width <= 1024 && c->vision_patch_size > 0 && c->image_resolution % c->vision_patch_size == 0 &&
+           c->vision_layers > 0 && c->text_layers > 0 && c->context_length > 3 && c->vocab_size > 2 && c->embed_dim % 4 == 0 &&
+           c->text_heads * HEAD_DIM == c->text_width;
+}
+
+rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward, int max_views, int max_classes, int precision) {
+    if (!cfg_ok(student) || (reward && !cfg_ok(reward)) || max_views <= 0 || max_classes <= 0) {
+        rlcf_set_error("rlcf_engine_create: bad geometry / sizes");
+        return nullptr;
+    }
+    if (precision != RLCF_PREC_F32) { rlcf_set_error("rlcf_engine_create: precision %d not built", precision); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rlcf_set_error("no HIP device"); return nullptr; }
+    rlcf_engine* e = new (std::nothrow) rlcf_engine();
+    if (!e) return nullptr;
+    e->precision = precision; e->max_views = max_views; e->max_classes = max_classes;
+    e->model[0].cfg = *student; e->model[0].present = true;
+    if (reward) { e->model[1].cfg = *reward; e->model[1].present = true; }
+    int Tmax = 0, Wmax = 0, Pmax = 0, Kpmax = 0, Dmax = 0;
+    std::vector<rlcf_seq> seqs((size_t)2 * max_views);
+    for (int w = 0; w < 2; ++w) {
+        if (!e->model[w].present) continue;
+        const rlcf_clip_cfg& c = e->model[w].cfg;
+        const int g = c.image_resolution / c.vision_patch_size, tok = g * g + 1;
+        Tmax = std::max(Tmax, max_views * tok); Wmax = std::max(Wmax, c.vision_width); Pmax = std::max(Pmax, max_views * g * g);
+        Kpmax = std::max(Kpmax, (3 * c.vision_patch_size * c.vision_patch_size + 15) / 16 * 16); Dmax = std::max(Dmax, c.embed_dim);
+        for (int i = 0; i < max_views; ++i) seqs[(size_t)w * max_views + i] = rlcf_seq{i * tok, tok, 0, 0};
+    }
+    bool ok = true;
+    {
+        Tower& t = e->vt;
+        const size_t n = (size_t)Tmax * Wmax * sizeof(float);
+        ok = ok && t.x.ensure(n) == 0 && t.h.ensure(n) == 0 && t.qkv.ensure(3 * n) == 0 && t.a.ensure(n) == 0 && t.f.ensure(4 * n) == 0;
+        t.T = Tmax; t.width = Wmax;
+    }
+    ok = ok && e->patches.ensure((size_t)Pmax * Kpmax * sizeof(float)) == 0 && e->patch_out.ensure((size_t)Pmax * Wmax * sizeof(float)) == 0;
+    ok = ok && e->cls_rows.ensure((size_t)max_views * Wmax * sizeof(float)) == 0 && e->cls_ln.ensure((size_t)max_views * Wmax * sizeof(float)) == 0;
+    ok = ok && e->feat_raw.ensure((size_t)max_views * Dmax * sizeof(float)) == 0;
+    ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0;
+    if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { rlcf_engine_destroy(e); return nullptr; }
+    return e;
+}
+
+static void release_tower(Tower& t) { t.x.release(); t.h.release(); t.qkv.release(); t.a.release(); t.f.release(); t.saved.release(); }
+static void release_layout(TextLayout& L) {
+    L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
+    L.class_eot_off.release(); L.ctx_rows_list.release();
+}
+void rlcf_engine_destroy(rlcf_engine* e) {
+    if (!e) return;
+    (void)hipDeviceSynchronize();
+    for (auto& m : e->model) {
+        for (auto& kv : m.raw) kv.second.release();
+        for (auto& d : m.derived) d.release();
+    }
+    release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
+    release_layout(e->lay[0]); release_layout(e->lay[1]);
+    DevBuf* all[] = {&e->patches, &e->patch_out, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
+                     &e->inv_norm, &e->txt, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->reward_cls, &e->sp_seqs,
+                     &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
+                     &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
+                     &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,
+                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5};
+    for (DevBuf* d : all) d->release();
+    delete e;
+}
+
+int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const float* dev_ptr, int64_t numel) {
+    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && key && dev_ptr && numel > 0);
+    if (!e->model[which].present) { rlcf_set_error("model %d not configured", which); return RLCF_ERR_STATE; }
+    DevBuf& d = e->model[which].raw[key];
+    if (d.bytes != (size_t)numel * sizeof(float)) { d.release(); int rc = d.ensure((size_t)numel * sizeof(float)); if (rc) return rc; }
+    RLCF_HIP_CHECK(hipMemcpy(d.p, dev_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice));
+    e->model[which].finalized = false;
+    return RLCF_OK;
+}
+int rlcf_engine_finalize(rlcf_engine* e, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e);
+    for (int w = 0; w < 2; ++w)
+        if (e->model[w].present) { int rc = engine_finalize(e, w, (hipStream_t)stream); if (rc) return rc; }
+    return RLCF_OK;
+}
+int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
+                               rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && tokens_host && ctx_init);
+    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream);
+}
+int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && images && feats);
+    return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream);
+}
+int rlcf_text_features(rlcf_engine* e, const float* ctx, float* txt, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && ctx && txt);
+    return engine_text_features(e, RLCF_STUDENT, ctx, txt, (hipStream_t)stream);
+}
+int rlcf_reward_class_features(rlcf_engine* e, float* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && out);
+    if (!e->model[1].present || e->C <= 0) { rlcf_set_error("reward class bank not set"); return RLCF_ERR_STATE; }
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, e->reward_cls.p, (size_t)e->C * e->model[1].cfg.embed_dim * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return RLCF_OK;
+}
+int rlcf_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && img && txt && logits && n > 0 && C > 0);
+    return engine_logits(e, img, n, txt, C, logits, (hipStream_t)stream);
+}
+int rlcf_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx,
+                             rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && ctx && img && dlogits && dctx && n > 0);
+    return engine_text_backward_dense(e, ctx, img, n, dlogits, dctx, (hipStream_t)stream);
+}
+int rlcf_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && views && args);
+    return engine_tta_sample(e, views, N, args, out, (hipStream_t)stream);
+}
+int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
+                   rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
+    const size_t per = (size_t)N * 3 * e->model[0].cfg.image_resolution * e->model[0].cfg.image_resolution;
+    double flops = 0.0;
+    for (int i = 0; i < count; ++i) {
+        rlcf_tta_out o{};
+        o.top5 = top5 + (size_t)i * 5;
+        o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
+        int rc = engine_tta_sample(e, views + (size_t)i * per, N, args, &o, (hipStream_t)stream);
+        if (rc) return rc;
+        flops += e->last_flops;
+    }
+    e->last_flops = flops / count;
+    return RLCF_OK;
+}
+double rlcf_engine_last_flops(rlcf_engine* e) { return e ? e->last_flops : 0.0; }
+int rlcf_engine_text_rows(rlcf_engine* e) { return e ? e->lay[0].T : 0; }
+
+// per-launch timing of the GEMM kernel (bench.py roofline leg)
+int rlcf_profile_gemm(int enable) {
+    g_prof.enabled = enable != 0;
+    g_prof.n = 0;
+    return RLCF_OK;
+}
+int rlcf_profile_read(int* launches, double* total_ms, double* total_flops) {
+    RLCF_ARG_CHECK(launches && total_ms && total_flops);
+    double ms = 0.0, fl = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        RLCF_HIP_CHECK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        float t = 0.f;
+        RLCF_HIP_CHECK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        ms += t; fl += g_prof.flops[i];
+    }
+    *launches = g_prof.n; *total_ms = ms; *total_flops = fl;
+    return RLCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Multi-head attention core (nn.MultiheadAttention as used by TPT/clip/model.py:175,185-187),
+// parity mode: f32 storage, f32-input MFMA, online softmax in f32 with accurate expf.
+//
+// Forward: one wave = one 32-query block of one (sequence, head); keys streamed in chunks of 32
+// through LDS.  Both contractions are computed TRANSPOSED so that every lane owns ONE query:
+//     S^T[key][q] = sum_d K[key][d] Q[q][d]        (A = K from LDS, B = Q held in 32 VGPRs)
+//     O^T[d][q]  += sum_key V[key][d] P[q][key]    (A = V from LDS, B = P = the S^T accumulator)
+// In the 32x32 MFMA C layout a lane holds column (lane&31) = its query and 16 rows (keys / d),
+// so row max / row sum / rescale are lane-local plus one exchange between the two half-waves,
+// and P feeds the second MFMA straight from the accumulator registers (no LDS round trip).
+#include "kernels.h"
+
+__global__ __launch_bounds__(64) void attention_fwd_f32_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
+                                                               int width, int causal, float* __restrict__ out,
+                                                               float* __restrict__ lse) {
+    const rlcf_seq sq = seqs[blockIdx.y];
+    const int qb = blockIdx.x, head = blockIdx.z;
+    if (qb * 32 >= sq.q_len) return;
+    __shared__ float Ks[32][65];
+    __shared__ float Vs[32][64];
+    const int lane = threadIdx.x, l32 = lane & 31, h = lane >> 5;
+    const int ld = 3 * width, H = width / HEAD_DIM;
+    const int qi = min(qb * 32 + l32, sq.q_len - 1);            // clamp: duplicate last query, never stored
+    const int nkeys = sq.pre_len + sq.q_len;
+    const int qpos = sq.pre_len + qi;                           // last key this query may see when causal
+    const int kend = causal ? min(nkeys, sq.pre_len + qb * 32 + 32) : nkeys;
+
+    float q[32];
+    {
+        const float* qp = qkv + (size_t)(sq.q_start + qi) * ld + head * HEAD_DIM + h * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 t = *(const float4*)(qp + j * 4);
+            q[4 * j] = t.x * 0.125f; q[4 * j + 1] = t.y * 0.125f; q[4 * j + 2] = t.z * 0.125f; q[4 * j + 3] = t.w * 0.125f;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+
+    for (int kc = 0; kc < kend; kc += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + i * 64, key = idx >> 4, c4 = (idx & 15) * 4;
+            const int kap = kc + key;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (kap < nkeys) {
+                const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                const float* p = qkv + (size_t)row * ld + head * HEAD_DIM + c4;
+                kv = *(const float4*)(p + width);
+                vv = *(const float4*)(p + 2 * width);
+            }
+            Ks[key][c4] = kv.x; Ks[key][c4 + 1] = kv.y; Ks[key][c4 + 2] = kv.z; Ks[key][c4 + 3] = kv.w;
+            *(float4*)&Vs[key][c4] = vv;
+        }
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l32][h * 32 + st], q[st], s, 0, 0, 0);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kc + mfma32_row(r, h);
+            if (key >= nkeys || (causal && key > qpos)) s[r] = -INFINITY;
+            cm = fmaxf(cm, s[r]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mn); ps += s[r]; }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int kk = mfma32_row(st, h);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kk][l32], s[st], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[kk][32 + l32], s[st], o1, 0, 0, 0);
+        }
+        m = mn;
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32);
+    if (qb * 32 + l32 < sq.q_len) {
+        const float inv = 1.0f / ltot;
+        float* op = out + (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;
+            *(float4*)(op + d) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *(float4*)(op + 32 + d) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+        if (lse && h == 0) lse[(size_t)(sq.q_start + qi) * H + head] = m + logf(ltot);
+    }
+}
+
+int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal,
+                             float* out, float* lse, hipStream_t st) {
+    RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0);
+    dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
+    RLCF_ARG_CHECK(grid.y <= 65535 && grid.z <= 65535);
+    attention_fwd_f32_kernel<<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, lse);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward (dX only) for short sequences (text tower: <= 96 keys): one 256-thread workgroup per
+// (sequence, head) with Q,K,V,dO and the probability matrix resident in LDS.  The default
+// RLCF configuration back-propagates only n_sel*K (= 18) class prompts,
+// so this kernel is latency- not throughput-critical and stays on the f32 VALU.
+//   P = softmax(QK^T/8 + mask); dV = P^T dO; dP = dO V^T; dS = P*(dP - rowsum(P*dP));
+//   dQ = dS K / 8; dK = dS^T Q / 8.   dK/dV use atomicAdd: prefix keys are shared by sequences.
+#define ABWD_MAXK 96
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                            const rlcf_seq* __restrict__ seqs, int width, int causal,
+                                                            float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const rlcf_seq sq = seqs[blockIdx.x];
+    const int head = blockIdx.y;
+    const int nq = sq.q_len, nk = sq.pre_len + sq.q_len;
+    if (nq <= 0) return;
+    const int ld = 3 * width, t = threadIdx.x;
+    const int LDQ = 65, LDP = nk + 1;
+    float* Qs = sm;                       // [nq][65]  (scaled by 1/8)
+    float* Ks = Qs + nq * LDQ;            // [nk][65]
+    float* Vs = Ks + nk * LDQ;            // [nk][65]
+    float* Gs = Vs + nk * LDQ;            // [nq][65]  dO
+    float* Ps = Gs + nq * LDQ;            // [nq][nk+1]
+    for (int idx = t; idx < nq * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63;
+        Qs[i * LDQ + d] = qkv[(size_t)(sq.q_start + i) * ld + head * HEAD_DIM + d] * 0.125f;
+        Gs[i * LDQ + d] = dout[(size_t)(sq.q_start + i) * width + head * HEAD_DIM + d];
+    }
+    for (int idx = t; idx < nk * 64; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
+        Ks[j * LDQ + d] = qkv[(size_t)row * ld + width + head * HEAD_DIM + d];
+        Vs[j * LDQ + d] = qkv[(size_t)row * ld + 2 * width + head * HEAD_DIM + d];
+    }
+    __syncthreads();
+    for (int idx = t; idx < nq * nk; idx += 256) {
+        const int i = idx / nk, j = idx % nk;
+        float s = -INFINITY;
+        if (!causal || j <= sq.pre_len + i) {
+            s = 0.f;
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) s += Qs[i * LDQ + d] * Ks[j * LDQ + d];
+        }
+        Ps[i * LDP + j] = s;
+    }
+    __syncthreads();
+    for (int i = t; i < nq; i += 256) {
+        float mx = -INFINITY;
+        for (int j = 0; j < nk; ++j) mx = fmaxf(mx, Ps[i * LDP + j]);
+        float sum = 0.f;
+        for (int j = 0; j < nk; ++j) { float e = expf(Ps[i * LDP + j] - mx); Ps[i * LDP + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < nk; ++j) Ps[i * LDP + j] *= inv;
+    }
+    __syncthreads();
+    // dV[j][d] = sum_i P[i][j] dO[i][d]
+    for (int idx = t; idx < nk * 64; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        float s = 0.f;
+        for (int i = 0; i < nq; ++i) s += Ps[i * LDP + j] * Gs[i * LDQ + d];
+        const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
+        atomicAdd(dqkv + (size_t)row * ld + 2 * width + head * HEAD_DIM + d, s);
+    }
+    __syncthreads();
+    // dS = P * (dP - D), D_i = sum_j P_ij dP_ij, dP_ij = dO_i . V_j
+    for (int i = t; i < nq; i += 256) {
+        float D = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            float dp = 0.f;
+            const float p = Ps[i * LDP + j];
+            if (p != 0.f) {
+#pragma unroll 16
+                for (int d = 0; d < 64; ++d) dp += Gs[i * LDQ + d] * Vs[j * LDQ + d];
+            }
+            D += p * dp;
+        }
+        // stash D in the padding column
+        Ps[i * LDP + nk] = D;
+    }
+    __syncthreads();
+    for (int idx = t; idx < nq * nk; idx += 256) {
+        const int i = idx / nk, j = idx % nk;
+        const float p = Ps[i * LDP + j];
+        float dp = 0.f;
+        if (p != 0.f) {
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) dp += Gs[i * LDQ + d] * Vs[j * LDQ + d];
+        }
+        Ps[i * LDP + j] = p * (dp - Ps[i * LDP + nk]);
+    }
+    __syncthreads();
+    // dQ[i][d] = sum_j dS[i][j] K[j][d] / 8 ;  dK[j][d] = sum_i dS[i][j] Qs[i][d]  (Qs already /8)
+    for (int idx = t; idx < nq * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63;
+        float s = 0.f;
+        for (int j = 0; j < nk; ++j) s += Ps[i * LDP + j] * Ks[j * LDQ + d];
+        dqkv[(size_t)(sq.q_start + i) * ld + head * HEAD_DIM + d] = s * 0.125f;
+    }
+    for (int idx = t; idx < nk * 64; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        float s = 0.f;
+        for (int i = 0; i < nq; ++i) s += Ps[i * LDP + j] * Qs[i * LDQ + d];
+        const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
+        atomicAdd(dqkv + (size_t)row * ld + width + head * HEAD_DIM + d, s);
+    }
+}
+
+int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,
+                         int causal, float* dqkv, hipStream_t st) {
+    RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_keys > 0 && max_keys <= ABWD_MAXK);
+    const size_t bytes = (size_t)(4 * max_keys * 65 + max_keys * (max_keys + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const size_t cap = (size_t)(4 * ABWD_MAXK * 65 + ABWD_MAXK * (ABWD_MAXK + 1)) * sizeof(float);
+        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
+        attr_set = true;
+    }
+    attention_bwd_kernel<<<dim3(n_seq, width / HEAD_DIM), dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

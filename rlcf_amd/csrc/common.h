@@ -1,0 +1,75 @@
+// Shared helpers for the gfx950 kernels of librlcf_hip.so (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/rlcf_hip.h"
+
+void rlcf_set_error(const char* fmt, ...);
+
+#define RLCF_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            rlcf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return RLCF_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+#define RLCF_LAUNCH_CHECK() RLCF_HIP_CHECK(hipGetLastError())
+#define RLCF_ARG_CHECK(cond)                                                              \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            rlcf_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond);         \
+            return RLCF_ERR_ARG;                                                          \
+        }                                                                                 \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+#define LN_EPS 1e-5f
+#define HEAD_DIM 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// row of a 32x32 MFMA accumulator register r held by a lane in half h (cdna guide §3)
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + expf(-1.702f * v)); }
+__device__ __forceinline__ float quick_gelu_grad(float f) {
+    float s = 1.0f / (1.0f + expf(-1.702f * f));
+    return s * (1.0f + 1.702f * f * (1.0f - s));
+}
+
+// bf16 helpers (round-to-nearest-even)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+// ---- internal launchers shared between translation units (all async on `st`) ----
+struct GemmArgs {
+    const void* A; int lda;        // [M,K]   f32 (F32 mode) or bf16 (BF16 mode)
+    const void* W; int ldw;        // [N,K]
+    const float* bias;             // [N] or null
+    const float* residual; int ldr;
+    const float* aux; int ldaux;
+    void* C; int ldc;              // f32, or bf16 when out_bf16
+    int M, N, K;
+    float alpha; int epilogue;
+    int out_bf16;
+};
+int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
+int launch_gemm_bf16(const GemmArgs& g, hipStream_t st);

@@ -1,0 +1,103 @@
+// Host-side runtime of the RLCF hot path: owns weights, layouts and workspace, sequences the
+// HIP kernels of one CLIP tower pass / one TTA sample on a stream.  No allocation per sample.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "kernels.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n);            // (re)allocate if smaller; contents undefined after growth
+    void release();
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct BlockW {                      // one ResidualAttentionBlock (TPT/clip/model.py:171-192)
+    const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b;
+    const float *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;   // for dX = dY.W
+    const unsigned short *in_w16 = nullptr, *out_w16 = nullptr, *fc_w16 = nullptr, *proj_w16 = nullptr;  // bf16 copies
+};
+struct TowerW {
+    int layers = 0, width = 0;
+    std::vector<BlockW> blk;
+};
+
+struct TextLayout {                  // packed token matrix of a class bank
+    int T = 0, C = 0, n_seq = 0, max_q_len = 0, max_keys = 0, pre_rows = 0, lmax = 0, n_copies = 0, n_ctx = 0;
+    DevBuf seqs, eot_rows, ctx_row, E, class_start, class_len, class_eot_off, ctx_rows_list;
+    long tokens_total = 0;           // sum of rows that carry real tokens (FLOP accounting)
+    long attn_pairs = 0;             // visible (query,key) pairs over all sequences
+    double mean_len = 0;             // mean class_len
+};
+
+struct SavedLayer { float *x, *qkv, *a, *x1, *f; };
+
+struct Tower {                       // workspace of one transformer pass over T rows
+    int T = 0, width = 0;
+    DevBuf x, h, qkv, a, f;          // f32 (F32 mode); bf16 views allocated separately
+    DevBuf h16, qkv16, a16, f16;     // bf16 operands (BF16 mode)
+    DevBuf saved;                    // per-layer saved activations for backward
+    std::vector<SavedLayer> sv;
+    int saved_T = 0, saved_layers = 0;
+};
+
+struct ClipModel {
+    rlcf_clip_cfg cfg{};
+    bool present = false, finalized = false;
+    std::map<std::string, DevBuf> raw;     // state-dict tensors as loaded
+    std::vector<DevBuf> derived;           // transposed / bf16 copies
+    TowerW vis, txt;
+    const float *conv_w = nullptr;         // [Wv, Kp] zero padded
+    const unsigned short* conv_w16 = nullptr;
+    const float *cls = nullptr, *vpos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr, *lnpost_b = nullptr;
+    const float *vprojT = nullptr;         // [D, Wv]
+    const float *tok_emb = nullptr, *tpos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+    const float *tproj = nullptr;          // [Wt, D] as stored
+    const float *tprojT = nullptr;         // [D, Wt]
+    float logit_scale_exp = 1.f;
+    int Kp = 0, tokens = 0;
+};
+
+struct rlcf_engine {
+    int precision = RLCF_PREC_F32, max_views = 0, max_classes = 0;
+    ClipModel model[2];
+    // ViT workspace (shared by student and reward passes)
+    Tower vt;
+    DevBuf patches, patch_out, vit_seqs /*[2][max_views]*/, cls_rows, cls_ln, feat_raw;
+    // text
+    int text_mode = RLCF_TEXT_SHARED, n_ctx = 0, C = 0;
+    TextLayout lay[2];               // [student], [reward]
+    Tower tt;                        // text workspace (max of both layouts)
+    DevBuf eot_x, eot_ln, u, inv_norm, txt;          // [C,*]
+    DevBuf ctx_init, ctx, adam_m, adam_v, ctx_grad;  // [n_ctx, Wt]
+    DevBuf reward_cls;               // [C, Dr]
+    // sparse backward layout (n_e entries)
+    int sp_max_e = 0, sp_T = 0;
+    DevBuf sp_seqs, sp_eot_rows, sp_row_src, sp_ctx_rows_list, sp_dtxt, sp_txt, sp_inv_norm, sp_eot_x, sp_eot_ln, sp_u, sp_du, sp_dxe;
+    Tower st;                        // sparse pass workspace (with saved activations)
+    DevBuf dX, dA, dH, dF, dQKV;     // backward scratch (sized for the largest backward pass)
+    int bwd_T = 0;
+    // TTA step scratch
+    DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg, views_sel, topk_idx, clip_score, rewards, loss, dlogits,
+        dtxt_dense, final_logits, top5;
+    double last_flops = 0.0;
+};
+
+struct GemmProfile {                 // optional per-launch timing of the dominant (GEMM) kernel
+    bool enabled = false;
+    int n = 0;
+    std::vector<hipEvent_t> ev;      // 2 per launch
+    std::vector<double> flops;
+};
+extern GemmProfile g_prof;
+
+// engine internals used by api.hip
+int engine_finalize(rlcf_engine* e, int which, hipStream_t st);
+int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st);
+int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st);
+int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt, hipStream_t st);
+int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st);
+int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);
+int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);

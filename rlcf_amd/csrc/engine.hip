@@ -1,0 +1,610 @@
+// Host runtime of the RLCF hot path (see engine.h).  Every function cites the reference lines
+// whose behaviour it reproduces; the arithmetic itself lives in the kernels it sequences.
+#include "engine.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != RLCF_OK) return rc_; } while (0)
+
+int DevBuf::ensure(size_t n) {
+    if (n <= bytes && p) return RLCF_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    if (n == 0) return RLCF_OK;
+    hipError_t err = hipMalloc(&p, n);
+    if (err != hipSuccess) { rlcf_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(err)); p = nullptr; return RLCF_ERR_NOMEM; }
+    bytes = n;
+    return RLCF_OK;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+
+// ------------------------------------------------------------------ profiling of GEMM launches
+GemmProfile g_prof;
+static int prof_begin(hipStream_t st, double flops) {
+    if (!g_prof.enabled) return -1;
+    if ((int)g_prof.ev.size() < 2 * (g_prof.n + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        g_prof.ev.push_back(a); g_prof.ev.push_back(b);
+    }
+    g_prof.flops.resize(g_prof.n + 1);
+    g_prof.flops[g_prof.n] = flops;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+    return g_prof.n;
+}
+static void prof_end(int slot, hipStream_t st) {
+    if (slot < 0) return;
+    (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    g_prof.n = slot + 1;
+}
+
+// C = epi(alpha A W^T + b) (+res): dispatch on the engine precision
+static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
+                const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi; g.out_bf16 = 0;
+    const int slot = prof_begin(st, 2.0 * M * N * K);
+    int rc = launch_gemm_f32(g, st);
+    prof_end(slot, st);
+    e->last_flops += 2.0 * M * N * K;
+    return rc;
+}
+
+// ------------------------------------------------------------------ weights
+static const float* rawp(ClipModel& m, const std::string& k, size_t numel) {
+    auto it = m.raw.find(k);
+    if (it == m.raw.end()) { rlcf_set_error("missing weight '%s'", k.c_str()); return nullptr; }
+    if (it->second.bytes != numel * sizeof(float)) {
+        rlcf_set_error("weight '%s': expected %zu elements, got %zu", k.c_str(), numel, it->second.bytes / sizeof(float));
+        return nullptr;
+    }
+    return it->second.as<float>();
+}
+static const float* make_transposed(ClipModel& m, const float* w, int rows, int cols, hipStream_t st) {
+    m.derived.emplace_back();
+    DevBuf& d = m.derived.back();
+    if (d.ensure((size_t)rows * cols * sizeof(float)) != RLCF_OK) return nullptr;
+    if (launch_transpose(w, d.as<float>(), rows, cols, st) != RLCF_OK) return nullptr;
+    return d.as<float>();
+}
+#define NEED(ptr) do { if (!(ptr)) return RLCF_ERR_STATE; } while (0)
+
+static int resolve_tower(ClipModel& m, TowerW& t, const std::string& prefix, int layers, int width, bool need_T, hipStream_t st) {
+    t.layers = layers; t.width = width;
+    t.blk.resize(layers);
+    const size_t W = width;
+    for (int i = 0; i < layers; ++i) {
+        const std::string p = prefix + ".resblocks." + std::to_string(i) + ".";
+        BlockW& b = t.blk[i];
+        NEED(b.ln1_w = rawp(m, p + "ln_1.weight", W));  NEED(b.ln1_b = rawp(m, p + "ln_1.bias", W));
+        NEED(b.in_w = rawp(m, p + "attn.in_proj_weight", 3 * W * W));  NEED(b.in_b = rawp(m, p + "attn.in_proj_bias", 3 * W));
+        NEED(b.out_w = rawp(m, p + "attn.out_proj.weight", W * W));  NEED(b.out_b = rawp(m, p + "attn.out_proj.bias", W));
+        NEED(b.ln2_w = rawp(m, p + "ln_2.weight", W));  NEED(b.ln2_b = rawp(m, p + "ln_2.bias", W));
+        NEED(b.fc_w = rawp(m, p + "mlp.c_fc.weight", 4 * W * W));  NEED(b.fc_b = rawp(m, p + "mlp.c_fc.bias", 4 * W));
+        NEED(b.proj_w = rawp(m, p + "mlp.c_proj.weight", 4 * W * W));  NEED(b.proj_b = rawp(m, p + "mlp.c_proj.bias", W));
+        if (need_T) {
+            NEED(b.in_wT = make_transposed(m, b.in_w, 3 * width, width, st));
+            NEED(b.out_wT = make_transposed(m, b.out_w, width, width, st));
+            NEED(b.fc_wT = make_transposed(m, b.fc_w, 4 * width, width, st));
+            NEED(b.proj_wT = make_transposed(m, b.proj_w, width, 4 * width, st));
+        }
+    }
+    return RLCF_OK;
+}
+
+// pad conv1.weight [Wv, 3*ps*ps] to [Wv, Kp]
+__global__ void pad_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int k, int kp) {
+    const long total = (long)rows * kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / kp), c = (int)(i % kp);
+        out[i] = c < k ? in[(size_t)r * k + c] : 0.f;
+    }
+}
+
+int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
+    ClipModel& m = e->model[which];
+    if (!m.present) { rlcf_set_error("model %d not configured", which); return RLCF_ERR_STATE; }
+    const rlcf_clip_cfg& c = m.cfg;
+    for (auto& d : m.derived) d.release();
+    m.derived.clear();
+    m.derived.reserve(4 * (c.vision_layers + c.text_layers) + 8);
+    const int Wv = c.vision_width, Wt = c.text_width, ps = c.vision_patch_size, D = c.embed_dim;
+    const int K = 3 * ps * ps;
+    m.Kp = (K + 15) / 16 * 16;
+    m.tokens = (c.image_resolution / ps) * (c.image_resolution / ps) + 1;
+    const float* conv = rawp(m, "visual.conv1.weight", (size_t)Wv * K);
+    NEED(conv);
+    if (m.Kp == K) m.conv_w = conv;
+    else {
+        m.derived.emplace_back();
+        TRY(m.derived.back().ensure((size_t)Wv * m.Kp * sizeof(float)));
+        pad_rows_kernel<<<dim3(1024), dim3(256), 0, st>>>(conv, m.derived.back().as<float>(), Wv, K, m.Kp);
+        RLCF_LAUNCH_CHECK();
+        m.conv_w = m.derived.back().as<float>();
+    }
+    NEED(m.cls = rawp(m, "visual.class_embedding", Wv));
+    NEED(m.vpos = rawp(m, "visual.positional_embedding", (size_t)m.tokens * Wv));
+    NEED(m.lnpre_w = rawp(m, "visual.ln_pre.weight", Wv));   NEED(m.lnpre_b = rawp(m, "visual.ln_pre.bias", Wv));
+    NEED(m.lnpost_w = rawp(m, "visual.ln_post.weight", Wv)); NEED(m.lnpost_b = rawp(m, "visual.ln_post.bias", Wv));
+    const float* vproj = rawp(m, "visual.proj", (size_t)Wv * D);
+    NEED(vproj);
+    NEED(m.vprojT = make_transposed(m, vproj, Wv, D, st));
+    TRY(resolve_tower(m, m.vis, "visual.transformer", c.vision_layers, Wv, false, st));
+    NEED(m.tok_emb = rawp(m, "token_embedding.weight", (size_t)c.vocab_size * Wt));
+    NEED(m.tpos = rawp(m, "positional_embedding", (size_t)c.context_length * Wt));
+    NEED(m.lnf_w = rawp(m, "ln_final.weight", Wt));  NEED(m.lnf_b = rawp(m, "ln_final.bias", Wt));
+    NEED(m.tproj = rawp(m, "text_projection", (size_t)Wt * D));
+    NEED(m.tprojT = make_transposed(m, m.tproj, Wt, D, st));
+    TRY(resolve_tower(m, m.txt, "transformer", c.text_layers, Wt, which == RLCF_STUDENT, st));
+    const float* ls = rawp(m, "logit_scale", 1);
+    NEED(ls);
+    float lsh = 0.f;
+    RLCF_HIP_CHECK(hipMemcpyAsync(&lsh, ls, sizeof(float), hipMemcpyDeviceToHost, st));
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    m.logit_scale_exp = expf(lsh);
+    m.finalized = true;
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ workspaces
+static int tower_ensure(Tower& t, int T, int width) {
+    if (T <= t.T && width <= t.width) return RLCF_OK;
+    T = std::max(T, t.T); width = std::max(width, t.width);
+    const size_t n = (size_t)T * width * sizeof(float);
+    TRY(t.x.ensure(n)); TRY(t.h.ensure(n)); TRY(t.qkv.ensure(3 * n)); TRY(t.a.ensure(n)); TRY(t.f.ensure(4 * n));
+    RLCF_HIP_CHECK(hipMemset(t.a.p, 0, n));
+    t.T = T; t.width = width;
+    return RLCF_OK;
+}
+static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
+    if (T <= t.saved_T && layers <= t.saved_layers && (int)t.sv.size() == layers) return RLCF_OK;
+    const size_t per = (size_t)T * width;               // floats
+    const size_t per_layer = per * (1 + 3 + 1 + 1 + 4);
+    TRY(t.saved.ensure(per_layer * layers * sizeof(float)));
+    RLCF_HIP_CHECK(hipMemset(t.saved.p, 0, per_layer * layers * sizeof(float)));
+    t.sv.resize(layers);
+    float* p = t.saved.as<float>();
+    for (int l = 0; l < layers; ++l) {
+        t.sv[l].x = p; p += per;
+        t.sv[l].qkv = p; p += 3 * per;
+        t.sv[l].a = p; p += per;
+        t.sv[l].x1 = p; p += per;
+        t.sv[l].f = p; p += 4 * per;
+    }
+    t.saved_T = T; t.saved_layers = layers;
+    return RLCF_OK;
+}
+static int bwd_ensure(rlcf_engine* e, int T, int width) {
+    if (T <= e->bwd_T) return RLCF_OK;
+    const size_t n = (size_t)T * width * sizeof(float);
+    TRY(e->dX.ensure(n)); TRY(e->dA.ensure(n)); TRY(e->dH.ensure(n)); TRY(e->dF.ensure(4 * n)); TRY(e->dQKV.ensure(3 * n));
+    e->bwd_T = T;
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ transformer passes
+// Transformer.forward, TPT/clip/model.py:195-203 with ResidualAttentionBlock :189-192.
+// x0: [T,W] input (ws.x, or sv[0].x when saving).  Result always lands in ws.x.
+static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
+                               long attn_pairs, int causal, int T, bool save, hipStream_t st) {
+    const int W = w.width, L = w.layers;
+    for (int l = 0; l < L; ++l) {
+        const BlockW& b = w.blk[l];
+        float* xin = save ? ws.sv[l].x : ws.x.as<float>();
+        float* x1 = save ? ws.sv[l].x1 : ws.x.as<float>();
+        float* xout = (save && l + 1 < L) ? ws.sv[l + 1].x : ws.x.as<float>();
+        float* qkv = save ? ws.sv[l].qkv : ws.qkv.as<float>();
+        float* a = save ? ws.sv[l].a : ws.a.as<float>();
+        float* h = ws.h.as<float>();
+        float* f = ws.f.as<float>();
+        TRY(launch_layernorm_fwd(xin, b.ln1_w, b.ln1_b, h, nullptr, T, W, st));
+        TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
+        TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, st));
+        e->last_flops += 4.0 * attn_pairs * W;
+        TRY(gemm(e, a, W, b.out_w, W, b.out_b, xin, W, nullptr, 0, x1, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
+        TRY(launch_layernorm_fwd(x1, b.ln2_w, b.ln2_b, h, nullptr, T, W, st));
+        if (save) {
+            TRY(gemm(e, h, W, b.fc_w, W, b.fc_b, nullptr, 0, nullptr, 0, ws.sv[l].f, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_NONE, st));
+            TRY(launch_quickgelu(ws.sv[l].f, f, (int64_t)T * 4 * W, st));
+        } else {
+            TRY(gemm(e, h, W, b.fc_w, W, b.fc_b, nullptr, 0, nullptr, 0, f, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU, st));
+        }
+        TRY(gemm(e, f, 4 * W, b.proj_w, 4 * W, b.proj_b, x1, W, nullptr, 0, xout, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st));
+    }
+    return RLCF_OK;
+}
+
+// dX-only backward of the above (all weights frozen: TPT/tpt_cls_rl.py:103-105); dX in/out in e->dX.
+static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_keys,
+                                long attn_pairs, int causal, int T, hipStream_t st) {
+    const int W = w.width, L = w.layers;
+    float *dX = e->dX.as<float>(), *dA = e->dA.as<float>(), *dH = e->dH.as<float>(), *dF = e->dF.as<float>(), *dQKV = e->dQKV.as<float>();
+    for (int l = L - 1; l >= 0; --l) {
+        const BlockW& b = w.blk[l];
+        const SavedLayer& s = ws.sv[l];
+        TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st));
+        TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st));
+        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, nullptr, nullptr, T, W, st));
+        TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
+        TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
+        e->last_flops += 10.0 * attn_pairs * W;
+        TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st));
+        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, nullptr, nullptr, T, W, st));
+    }
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ image tower
+// VisionTransformer.forward (TPT/clip/model.py:223-240) + L2 normalise (custom_clip.py:330,
+// clip_reward.py:136).  Runs under no_grad in the reference (custom_clip.py:325-327).
+int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st) {
+    ClipModel& m = e->model[which];
+    if (!m.finalized) { rlcf_set_error("model %d not finalized", which); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(n > 0 && n <= e->max_views);
+    const rlcf_clip_cfg& c = m.cfg;
+    const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
+    TRY(launch_im2col(images, e->patches.as<float>(), nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
+    TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv,
+             n * G2, Wv, m.Kp, 1.f, RLCF_EPI_NONE, st));
+    TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.x.as<float>(), n, tok, Wv, st));
+    TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
+                            false, st));
+    TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
+    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), nullptr, n, Wv, st));
+    TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
+             RLCF_EPI_NONE, st));
+    TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, nullptr, n, D, st));
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ text layouts
+__global__ void build_E_kernel(const float* __restrict__ tok_emb, const float* __restrict__ pos, const int32_t* __restrict__ row_token,
+                               const int32_t* __restrict__ row_pos, float* __restrict__ E, int rows, int width) {
+    const int r = blockIdx.x;
+    const int tkn = row_token[r], ps = row_pos[r];
+    for (int c = threadIdx.x; c < width; c += blockDim.x)
+        E[(size_t)r * width + c] = pos[(size_t)ps * width + c] + (tkn >= 0 ? tok_emb[(size_t)tkn * width + c] : 0.f);
+}
+
+template <typename T>
+static int upload(DevBuf& d, const std::vector<T>& v, hipStream_t st) {
+    TRY(d.ensure(std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) RLCF_HIP_CHECK(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));     // v is a host temporary
+    return RLCF_OK;
+}
+
+// Builds the packed layout of a class bank.  tokens: HOST [C, L] as clip.tokenize produces
+// (TPT/clip/clip.py:197-233); EOT = argmax id (custom_clip.py:71).  n_ctx > 0: rows 1..n_ctx of
+// every prompt are the learnable context (custom_clip.py:198-238).
+static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32_t* tokens, int C, int n_ctx, bool has_ctx, int mode,
+                        hipStream_t st) {
+    const int CL = m.cfg.context_length, Wt = m.cfg.text_width;
+    std::vector<int> eot(C);
+    for (int c = 0; c < C; ++c) {
+        int best = 0;
+        for (int j = 1; j < CL; ++j) if (tokens[(size_t)c * CL + j] > tokens[(size_t)c * CL + best]) best = j;
+        eot[c] = best;
+    }
+    int pre = 0;
+    if (mode == RLCF_TEXT_SHARED) {
+        pre = 1 + n_ctx;
+        bool ok = true;
+        for (int c = 0; c < C && ok; ++c) {
+            if (eot[c] < pre) ok = false;
+            for (int j = 0; j < pre && ok; ++j) {
+                const bool is_ctx = has_ctx && j >= 1;
+                if (!is_ctx && tokens[(size_t)c * CL + j] != tokens[j]) ok = false;
+            }
+        }
+        if (!ok) { pre = 0; mode = RLCF_TEXT_PACKED; }
+    }
+    std::vector<int32_t> row_token, row_pos, ctx_row, class_start(C), class_len(C), class_eot_off(C), eot_rows(C), ctx_list;
+    std::vector<rlcf_seq> seqs;
+    auto push_row = [&](int token, int pos_idx, int cr) { row_token.push_back(token); row_pos.push_back(pos_idx); ctx_row.push_back(cr); };
+    for (int j = 0; j < pre; ++j) {
+        const bool is_ctx = has_ctx && j >= 1;
+        push_row(is_ctx ? -1 : tokens[j], j, is_ctx ? j - 1 : -1);
+    }
+    long pairs = 0;
+    int lmax = 0;
+    L.tokens_total = pre;
+    for (int c = 0; c < C; ++c) {
+        const int first = pre, last = (mode == RLCF_TEXT_DENSE) ? CL - 1 : eot[c];
+        class_start[c] = (int)row_token.size();
+        class_len[c] = last - first + 1;
+        class_eot_off[c] = eot[c] - first;
+        eot_rows[c] = class_start[c] + class_eot_off[c];
+        for (int j = first; j <= last; ++j) {
+            const bool is_ctx = has_ctx && j >= 1 && j <= n_ctx;
+            push_row(is_ctx ? -1 : tokens[(size_t)c * CL + j], j, is_ctx ? j - 1 : -1);
+        }
+        seqs.push_back(rlcf_seq{class_start[c], class_len[c], 0, pre});
+        lmax = std::max(lmax, class_len[c]);
+        for (int i = 0; i < class_len[c]; ++i) pairs += pre + i + 1;
+        L.tokens_total += class_len[c];
+        if (has_ctx && pre == 0) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(class_start[c] + 1 + j);
+    }
+    if (pre > 0) {
+        seqs.push_back(rlcf_seq{0, pre, 0, 0});
+        for (int i = 0; i < pre; ++i) pairs += i + 1;
+        if (has_ctx) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(1 + j);
+    }
+    L.T = (int)row_token.size(); L.C = C; L.n_seq = (int)seqs.size(); L.pre_rows = pre; L.lmax = lmax;
+    L.max_q_len = std::max(lmax, pre); L.max_keys = pre + lmax; L.n_ctx = has_ctx ? n_ctx : 0;
+    L.n_copies = has_ctx ? (pre > 0 ? 1 : C) : 0;
+    L.attn_pairs = pairs;
+    TRY(upload(L.seqs, seqs, st)); TRY(upload(L.eot_rows, eot_rows, st)); TRY(upload(L.ctx_row, ctx_row, st));
+    TRY(upload(L.class_start, class_start, st)); TRY(upload(L.class_len, class_len, st));
+    TRY(upload(L.class_eot_off, class_eot_off, st)); TRY(upload(L.ctx_rows_list, ctx_list, st));
+    DevBuf d_tok, d_pos;
+    TRY(upload(d_tok, row_token, st)); TRY(upload(d_pos, row_pos, st));
+    TRY(L.E.ensure((size_t)L.T * Wt * sizeof(float)));
+    build_E_kernel<<<dim3(L.T), dim3(128), 0, st>>>(m.tok_emb, m.tpos, d_tok.as<int32_t>(), d_pos.as<int32_t>(), L.E.as<float>(), L.T, Wt);
+    RLCF_LAUNCH_CHECK();
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    d_tok.release(); d_pos.release();
+    double mean_len = 0;
+    for (int c = 0; c < C; ++c) mean_len += class_len[c];
+    L.mean_len = mean_len / C;
+    return RLCF_OK;
+}
+
+// Text tower over a layout: TextEncoder.forward (custom_clip.py:62-73) / CLIP.encode_text
+// (model.py:343-356), then L2 normalise (custom_clip.py:320).  row_src != null: sparse re-pack.
+struct TextPassIO {
+    const rlcf_seq* seqs; int n_seq, max_q_len, T, n_cls; long attn_pairs;
+    const int32_t* eot_rows; const int32_t* row_src;
+    float *eot_x, *eot_ln, *u, *inv_norm, *txt;
+};
+static int text_forward(rlcf_engine* e, ClipModel& m, const TextLayout& L, Tower& ws, const float* ctx, const TextPassIO& io, bool save,
+                        hipStream_t st) {
+    const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
+    float* x0 = save ? ws.sv[0].x : ws.x.as<float>();
+    TRY(launch_text_assemble(L.E.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), ctx, x0, io.T, Wt, st));
+    TRY(transformer_forward(e, m.txt, ws, io.seqs, io.n_seq, io.max_q_len, io.attn_pairs, 1, io.T, save, st));
+    TRY(launch_gather_rows(ws.x.as<float>(), Wt, io.eot_rows, io.eot_x, Wt, io.n_cls, Wt, st));
+    TRY(launch_layernorm_fwd(io.eot_x, m.lnf_w, m.lnf_b, io.eot_ln, nullptr, io.n_cls, Wt, st));
+    TRY(gemm(e, io.eot_ln, Wt, m.tprojT, Wt, nullptr, nullptr, 0, nullptr, 0, io.u, D, io.n_cls, D, Wt, 1.f, RLCF_EPI_NONE, st));
+    TRY(launch_l2norm_rows(io.u, io.txt, io.inv_norm, io.n_cls, D, st));
+    return RLCF_OK;
+}
+// Backward of text_forward w.r.t. ctx, given dtxt [n_cls, D] (autograd's work at tpt_cls_rl.py:77).
+static int text_backward(rlcf_engine* e, ClipModel& m, Tower& ws, const TextPassIO& io, int max_keys, const float* dtxt, float* du,
+                         float* dxe, const int32_t* ctx_rows_list, int n_copies, int n_ctx, float* dctx, hipStream_t st) {
+    const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
+    TRY(launch_l2norm_bwd(io.txt, dtxt, io.inv_norm, du, io.n_cls, D, st));
+    TRY(gemm(e, du, D, m.tproj, D, nullptr, nullptr, 0, nullptr, 0, dxe, Wt, io.n_cls, Wt, D, 1.f, RLCF_EPI_NONE, st));
+    TRY(launch_layernorm_bwd(io.eot_x, m.lnf_w, dxe, nullptr, dxe, nullptr, nullptr, io.n_cls, Wt, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)io.T * Wt * sizeof(float), st));
+    TRY(launch_scatter_rows(dxe, io.eot_rows, e->dX.as<float>(), io.n_cls, Wt, st));
+    TRY(transformer_backward(e, m.txt, ws, io.seqs, io.n_seq, max_keys, io.attn_pairs, 1, io.T, st));
+    TRY(launch_ctx_grad(e->dX.as<float>(), ctx_rows_list, n_copies, n_ctx, Wt, dctx, st));
+    return RLCF_OK;
+}
+
+static TextPassIO full_io(rlcf_engine* e, const TextLayout& L) {
+    TextPassIO io{};
+    io.seqs = L.seqs.as<rlcf_seq>(); io.n_seq = L.n_seq; io.max_q_len = L.max_q_len; io.T = L.T; io.n_cls = L.C;
+    io.attn_pairs = L.attn_pairs; io.eot_rows = L.eot_rows.as<int32_t>(); io.row_src = nullptr;
+    io.eot_x = e->eot_x.as<float>(); io.eot_ln = e->eot_ln.as<float>(); io.u = e->u.as<float>();
+    io.inv_norm = e->inv_norm.as<float>(); io.txt = e->txt.as<float>();
+    return io;
+}
+
+int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    if (!s.finalized) { rlcf_set_error("student not finalized"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(C > 0 && C <= e->max_classes && n_ctx > 0 && n_ctx + 3 <= s.cfg.context_length);
+    RLCF_ARG_CHECK(text_mode >= RLCF_TEXT_DENSE && text_mode <= RLCF_TEXT_SHARED);
+    e->text_mode = text_mode; e->n_ctx = n_ctx; e->C = C;
+    const int Wt = s.cfg.text_width, D = s.cfg.embed_dim;
+    TRY(build_layout(e, s, e->lay[0], tokens, C, n_ctx, true, text_mode, st));
+    int Tmax = e->lay[0].T, Wmax = Wt, Dmax = D;
+    ClipModel& r = e->model[RLCF_REWARD];
+    if (r.present) {
+        if (!r.finalized) { rlcf_set_error("reward not finalized"); return RLCF_ERR_STATE; }
+        RLCF_ARG_CHECK(r.cfg.context_length == s.cfg.context_length);
+        TRY(build_layout(e, r, e->lay[1], tokens, C, n_ctx, false, text_mode, st));
+        Tmax = std::max(Tmax, e->lay[1].T); Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim);
+    }
+    TRY(tower_ensure(e->tt, Tmax, Wmax));
+    const size_t cw = (size_t)C * Wmax * sizeof(float), cd = (size_t)C * Dmax * sizeof(float);
+    TRY(e->eot_x.ensure(cw)); TRY(e->eot_ln.ensure(cw)); TRY(e->u.ensure(cd)); TRY(e->inv_norm.ensure(C * sizeof(float)));
+    TRY(e->txt.ensure(cd)); TRY(e->dtxt_dense.ensure(cd));
+    const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
+    TRY(e->ctx_init.ensure(cb)); TRY(e->ctx.ensure(cb)); TRY(e->adam_m.ensure(cb)); TRY(e->adam_v.ensure(cb)); TRY(e->ctx_grad.ensure(cb));
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ctx_init.p, ctx_init, cb, hipMemcpyDeviceToDevice, st));
+    // TTA scratch
+    const int N = e->max_views;
+    TRY(e->img_feat.ensure((size_t)N * D * sizeof(float))); TRY(e->logits.ensure((size_t)N * C * sizeof(float)));
+    TRY(e->entropy.ensure(N * sizeof(float))); TRY(e->sel_idx.ensure(N * sizeof(int32_t)));
+    TRY(e->topk_idx.ensure((size_t)N * 16 * sizeof(int32_t))); TRY(e->clip_score.ensure((size_t)N * 16 * sizeof(float)));
+    TRY(e->rewards.ensure((size_t)N * 16 * sizeof(float))); TRY(e->loss.ensure(sizeof(float)));
+    TRY(e->dlogits.ensure((size_t)N * C * sizeof(float))); TRY(e->final_logits.ensure((size_t)C * sizeof(float)));
+    TRY(e->top5.ensure(5 * sizeof(int32_t))); TRY(e->sel_feat.ensure((size_t)N * D * sizeof(float)));
+    TRY(e->sel_logits.ensure((size_t)N * C * sizeof(float)));
+    if (r.present) {
+        const int Dr = r.cfg.embed_dim, R = r.cfg.image_resolution;
+        TRY(e->rimg.ensure((size_t)N * Dr * sizeof(float)));
+        TRY(e->views_sel.ensure((size_t)N * 3 * R * R * sizeof(float)));
+        TRY(e->reward_cls.ensure((size_t)C * Dr * sizeof(float)));
+        // BaseRewards.set_class_features (clip_reward.py:55-57,139-150): once per class bank
+        TextPassIO io = full_io(e, e->lay[1]);
+        io.txt = e->reward_cls.as<float>();
+        TRY(text_forward(e, r, e->lay[1], e->tt, nullptr, io, false, st));
+    }
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    e->sp_max_e = 0;    // sparse layout is (re)built lazily for the requested n_sel*K
+    return RLCF_OK;
+}
+
+int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt, hipStream_t st) {
+    ClipModel& m = e->model[which];
+    if (e->C <= 0) { rlcf_set_error("class bank not set"); return RLCF_ERR_STATE; }
+    TextPassIO io = full_io(e, e->lay[which]);
+    if (txt) io.txt = txt;
+    return text_forward(e, m, e->lay[which], e->tt, ctx, io, false, st);
+}
+
+int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const int D = m.cfg.embed_dim;
+    return gemm(e, img, D, txt, D, nullptr, nullptr, 0, nullptr, 0, logits, C, n, C, D, m.logit_scale_exp, RLCF_EPI_NONE, st);
+}
+
+// Dense backward: forward with saved activations over the full layout, then backward.
+int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    if (e->C <= 0) { rlcf_set_error("class bank not set"); return RLCF_ERR_STATE; }
+    const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
+    TRY(tower_ensure_saved(e->tt, L.T, Wt, m.cfg.text_layers));
+    TRY(bwd_ensure(e, L.T, Wt));
+    TRY(e->sp_du.ensure((size_t)L.C * D * sizeof(float)));
+    TRY(e->sp_dxe.ensure((size_t)L.C * Wt * sizeof(float)));
+    TextPassIO io = full_io(e, L);
+    TRY(text_forward(e, m, L, e->tt, ctx, io, true, st));
+    TRY(launch_dtxt_dense(dlogits, img, n, L.C, D, m.logit_scale_exp, e->dtxt_dense.as<float>(), st));
+    TRY(text_backward(e, m, e->tt, io, L.max_keys, e->dtxt_dense.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
+                      L.ctx_rows_list.as<int32_t>(), L.n_copies, L.n_ctx, dctx, st));
+    return RLCF_OK;
+}
+
+// Sparse backward layout for n_e = n_sel*K sampled (view, class) pairs.
+static int sparse_ensure(rlcf_engine* e, int n_e, hipStream_t st) {
+    if (n_e <= e->sp_max_e) return RLCF_OK;
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
+    const int T = L.pre_rows + n_e * L.lmax;
+    TRY(e->sp_seqs.ensure((size_t)(n_e + 1) * sizeof(rlcf_seq))); TRY(e->sp_eot_rows.ensure(n_e * sizeof(int32_t)));
+    TRY(e->sp_row_src.ensure((size_t)T * sizeof(int32_t)));
+    std::vector<int32_t> list;
+    if (L.pre_rows > 0) for (int j = 0; j < L.n_ctx; ++j) list.push_back(1 + j);
+    else for (int k = 0; k < n_e; ++k) for (int j = 0; j < L.n_ctx; ++j) list.push_back(k * L.lmax + 1 + j);
+    TRY(upload(e->sp_ctx_rows_list, list, st));
+    TRY(e->sp_dtxt.ensure((size_t)n_e * D * sizeof(float))); TRY(e->sp_txt.ensure((size_t)n_e * D * sizeof(float)));
+    TRY(e->sp_inv_norm.ensure(n_e * sizeof(float))); TRY(e->sp_eot_x.ensure((size_t)n_e * Wt * sizeof(float)));
+    TRY(e->sp_eot_ln.ensure((size_t)n_e * Wt * sizeof(float))); TRY(e->sp_u.ensure((size_t)n_e * D * sizeof(float)));
+    TRY(e->sp_du.ensure((size_t)std::max(n_e, L.C) * D * sizeof(float))); TRY(e->sp_dxe.ensure((size_t)std::max(n_e, L.C) * Wt * sizeof(float)));
+    TRY(tower_ensure(e->st, T, Wt));
+    TRY(tower_ensure_saved(e->st, T, Wt, m.cfg.text_layers));
+    TRY(bwd_ensure(e, T, Wt));
+    e->sp_max_e = n_e; e->sp_T = T;
+    return RLCF_OK;
+}
+
+static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_feat, const int32_t* cls, int n_e, int K,
+                           const float* dlogits, float* dctx, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    const int D = m.cfg.embed_dim;
+    const int T = L.pre_rows + n_e * L.lmax;
+    TRY(launch_build_sparse_layout(cls, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
+                                   L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
+                                   e->sp_row_src.as<int32_t>(), st));
+    TextPassIO io{};
+    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = n_e + (L.pre_rows > 0 ? 1 : 0); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = n_e;
+    io.attn_pairs = (long)(n_e * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
+    io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
+    io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
+    io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
+    TRY(text_forward(e, m, L, e->st, ctx, io, true, st));
+    TRY(launch_dtxt_sparse(dlogits, cls, sel_feat, n_e, K, L.C, D, m.logit_scale_exp, e->sp_dtxt.as<float>(), st));
+    TRY(text_backward(e, m, e->st, io, L.max_keys, e->sp_dtxt.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
+                      e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, L.n_ctx, dctx, st));
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ one test sample
+// Harness body TPT/tpt_cls_rl.py:251-262 around test_time_tuning (:47-79).
+#define COPY_OUT(dst, src, bytes) do { if (dst) RLCF_HIP_CHECK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, st)); } while (0)
+int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    ClipModel& r = e->model[RLCF_REWARD];
+    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16);
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
+    const int n_sel = (int)(N * a->selection_p);              // int() truncation, tpt_cls_rl.py:34
+    RLCF_ARG_CHECK(K <= C);
+    if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
+    RLCF_ARG_CHECK(r.cfg.image_resolution == s.cfg.image_resolution);   // bicubic resample (clip_reward.py:133-134): not built yet
+    const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
+    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const rlcf_tta_out none{};
+    if (!out) out = &none;
+    const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
+                           !(a->flags & RLCF_F_MIN_ENTROPY) && K > 1;
+    const int n_e = n_sel * K;
+    if (a->tta_steps > 0) {
+        if (sparse_ok) TRY(sparse_ensure(e, n_e, st));
+        else {
+            TRY(tower_ensure_saved(e->tt, e->lay[0].T, Wt, s.cfg.text_layers));
+            TRY(bwd_ensure(e, e->lay[0].T, Wt));
+            TRY(e->sp_du.ensure((size_t)C * D * sizeof(float))); TRY(e->sp_dxe.ensure((size_t)C * Wt * sizeof(float)));
+        }
+    }
+    e->last_flops = 0.0;
+    float* ctx = e->ctx.as<float>();
+    // model.reset() + optimizer.load_state_dict(optim_state): custom_clip.py:161-164, tpt_cls_rl.py:251-255
+    RLCF_HIP_CHECK(hipMemcpyAsync(ctx, e->ctx_init.p, cb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->adam_m.p, 0, cb, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->adam_v.p, 0, cb, st));
+    // student image features of all N views: computed once (the image tower is frozen, custom_clip.py:325-327)
+    TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
+    TextPassIO io = full_io(e, e->lay[0]);
+    for (int j = 0; j < a->tta_steps; ++j) {
+        TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, !sparse_ok, st));
+        const float* rows_logits;
+        if (j == 0) {   // tpt_cls_rl.py:57-59
+            TRY(engine_logits(e, e->img_feat.as<float>(), N, e->txt.as<float>(), C, e->logits.as<float>(), st));
+            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+            TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
+            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
+            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st));
+            TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
+            rows_logits = e->sel_logits.as<float>();
+            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
+            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
+            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
+            COPY_OUT(out->reward_image_features, e->rimg.p, (size_t)n_sel * Dr * sizeof(float));
+        } else {        // tpt_cls_rl.py:55 — selected views only; their image features are unchanged
+            TRY(engine_logits(e, e->sel_feat.as<float>(), n_sel, e->txt.as<float>(), C, e->sel_logits.as<float>(), st));
+            rows_logits = e->sel_logits.as<float>();
+        }
+        TRY(launch_reward_loss(rows_logits, C, nullptr, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
+                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
+        if (sparse_ok) {
+            TRY(sparse_backward(e, ctx, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(),
+                                e->ctx_grad.as<float>(), st));
+        } else {
+            TRY(launch_dtxt_dense(e->dlogits.as<float>(), e->sel_feat.as<float>(), n_sel, C, D, s.logit_scale_exp, e->dtxt_dense.as<float>(), st));
+            TRY(text_backward(e, s, e->tt, io, e->lay[0].max_keys, e->dtxt_dense.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
+                              e->lay[0].ctx_rows_list.as<int32_t>(), e->lay[0].n_copies, n_ctx, e->ctx_grad.as<float>(), st));
+        }
+        if (j == 0) {
+            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
+            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->loss, e->loss.p, sizeof(float));
+            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
+            COPY_OUT(out->ctx_grad, e->ctx_grad.p, cb);
+        }
+        TRY(launch_adamw(ctx, e->ctx_grad.as<float>(), e->adam_m.as<float>(), e->adam_v.as<float>(), (int64_t)n_ctx * Wt, j + 1, a->lr,
+                         a->beta1, a->beta2, a->eps, a->weight_decay, st));
+    }
+    // final inference on the clean view (views[0]) with the adapted prompt, tpt_cls_rl.py:260-262;
+    // its image feature is row 0 of img_feat (frozen image tower: identical to re-encoding it).
+    TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, false, st));
+    TRY(engine_logits(e, e->img_feat.as<float>(), 1, e->txt.as<float>(), C, e->final_logits.as<float>(), st));
+    TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
+    COPY_OUT(out->ctx_after, ctx, cb);
+    COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
+    COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    return RLCF_OK;
+}

@@ -1,0 +1,52 @@
+// Internal launchers (device pointers, async on the stream).  One per fused kernel.
+#pragma once
+#include "common.h"
+
+// LayerNorm fwd: y f32 (y) and/or bf16 (y_bf16) — either may be null.
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                         unsigned short* y_bf16, int rows, int width, hipStream_t st);
+int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
+                         float* dgamma, float* dbeta, int rows, int width, hipStream_t st);
+// images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 or bf16)
+int launch_im2col(const float* images, float* out, unsigned short* out_bf16, int n, int R, int ps, int Kp, hipStream_t st);
+// x[n,1+G*G,W] = ln_pre([cls | patch_out] + pos)
+int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                        const float* beta, float* x, int n, int tokens, int width, hipStream_t st);
+// X[r] = E[r] + (ctx_row[r] >= 0 ? ctx[ctx_row[r]] : 0)
+int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
+                         int width, hipStream_t st);
+// out[i] = in[idx[i]] rows (idx device, may be null = identity)
+int launch_gather_rows(const float* in, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st);
+int launch_l2norm_rows(const float* in, float* out, float* inv_norm, int rows, int width, hipStream_t st);
+// backward of t = u/|u|: du = (dt - t <t,dt>) * inv_norm
+int launch_l2norm_bwd(const float* t, const float* dt, const float* inv_norm, float* du, int rows, int width, hipStream_t st);
+// dst[rows[i]] = src[i] (scatter rows; rows device)
+int launch_scatter_rows(const float* src, const int32_t* rows_idx, float* dst, int n, int width, hipStream_t st);
+// dctx[j] = sum_s dX[ctx_rows[s*n_ctx + j]]   (n_copies sequences carry the ctx rows)
+int launch_ctx_grad(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, float* dctx, hipStream_t st);
+// dtxt[c,:] = scale * sum_i dlogits[i,c] * img[i,:]
+int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int D, float scale, float* dtxt, hipStream_t st);
+int launch_f32_to_bf16(const float* in, unsigned short* out, int64_t n, hipStream_t st);
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);   // out[cols,rows]
+
+int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
+                             int causal, float* out, float* lse, hipStream_t st);
+int launch_attention_fwd_bf16(const unsigned short* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
+                              int causal, unsigned short* out, hipStream_t st);
+int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,
+                         int causal, float* dqkv, hipStream_t st);
+
+int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, hipStream_t st);
+int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
+                       const float* class_feat, const float* reward_img, int Dr, float clipscore_weight,
+                       int flags, float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards,
+                       float* loss, float* dlogits, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
+                 float b2, float eps, float wd, hipStream_t st);
+int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st);
+int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st);
+int launch_build_sparse_layout(const int32_t* cls, int n_e, const int32_t* class_start, const int32_t* class_len,
+                               const int32_t* class_eot_off, int lmax, int pre_rows, rlcf_seq* seqs, int32_t* eot_rows,
+                               int32_t* row_src, hipStream_t st);
+int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* img, int n_e, int K, int C, int D, float scale,
+                       float* dtxt, hipStream_t st);

@@ -1,0 +1,452 @@
+// HBM-bound row kernels of the CLIP towers: LayerNorm fwd/bwd, patch gather, embedding
+// assembly, L2 normalisation, row gathers.  One wave (64 lanes) per row, shuffle reductions,
+// float4 accesses where the width allows.
+#include "kernels.h"
+
+#define ROWS_PER_BLOCK 4
+#define MAX_PER_LANE 16   // width <= 1024
+
+// ---------------------------------------------------------------- LayerNorm fwd
+// TPT/clip/model.py:157-163 (fp32, eps 1e-5, biased variance about the mean)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            unsigned short* __restrict__ yb, int rows, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * width;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+    const bool vec = (width & 255) == 0;
+    const int n4 = width >> 8;                  // float4 groups per lane when vec
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE / 4; ++j)
+            if (j < n4) {
+                float4 t = *(const float4*)(xr + j * 256 + lane * 4);
+                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+                s += t.x + t.y + t.z + t.w;
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            v[j] = c < width ? xr[c] : 0.f;
+            s += v[j];
+        }
+    }
+    const float mu = wave_sum(s) / width;
+    float q = 0.f;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j)
+            if ((j >> 2) < n4) { float d = v[j] - mu; q += d * d; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) { float d = v[j] - mu; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE / 4; ++j)
+            if (j < n4) {
+                const int c = j * 256 + lane * 4;
+                float4 gg = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c), o;
+                o.x = (v[4 * j] - mu) * rstd * gg.x + bb.x;
+                o.y = (v[4 * j + 1] - mu) * rstd * gg.y + bb.y;
+                o.z = (v[4 * j + 2] - mu) * rstd * gg.z + bb.z;
+                o.w = (v[4 * j + 3] - mu) * rstd * gg.w + bb.w;
+                if (y) *(float4*)(y + (size_t)row * width + c) = o;
+                if (yb) {
+                    ushort4 ob = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
+                    *(ushort4*)(yb + (size_t)row * width + c) = ob;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                float o = (v[j] - mu) * rstd * gamma[c] + beta[c];
+                if (y) y[(size_t)row * width + c] = o;
+                if (yb) yb[(size_t)row * width + c] = f2bf(o);
+            }
+        }
+    }
+}
+
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, unsigned short* y_bf16,
+                         int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
+    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, y_bf16, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- LayerNorm bwd
+// dx = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += dy*xhat; dbeta += dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, const float* __restrict__ dres,
+                                                            float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)row * width;
+    const float* dr = dy + (size_t)row * width;
+    float v[MAX_PER_LANE], d[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        v[j] = c < width ? xr[c] : 0.f;
+        d[j] = c < width ? dr[c] : 0.f;
+        s += v[j];
+    }
+    const float mu = wave_sum(s) / width;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) { float t = v[j] - mu; q += t * t; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) {
+            float xh = (v[j] - mu) * rstd;
+            float gd = d[j] * gamma[c];
+            if (dgamma) atomicAdd(dgamma + c, d[j] * xh);
+            if (dbeta) atomicAdd(dbeta + c, d[j]);
+            v[j] = xh; d[j] = gd;
+            s1 += gd; s2 += gd * xh;
+        }
+    }
+    s1 = wave_sum(s1) / width;
+    s2 = wave_sum(s2) / width;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) {
+            float o = rstd * (d[j] - s1 - v[j] * s2);
+            if (dres) o += dres[(size_t)row * width + c];
+            dx[(size_t)row * width + c] = o;
+        }
+    }
+}
+
+int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
+                         float* dbeta, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
+    layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- patch gather (im2col)
+// stride==kernel convolution of TPT/clip/model.py:211,224 written as gather + GEMM.
+__global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__ out, unsigned short* __restrict__ outb,
+                              int n, int R, int ps, int Kp) {
+    const int G = R / ps;
+    const int K = 3 * ps * ps;
+    const int kq = Kp >> 2;                               // float4 groups per patch row
+    const long total = (long)n * G * G * kq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(idx % kq) * 4;
+        const long p = idx / kq;
+        const int gx = (int)(p % G), gy = (int)((p / G) % G), b = (int)(p / ((long)G * G));
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 + e;
+            if (k < K) {
+                const int c = k / (ps * ps), i = (k / ps) % ps, j = k % ps;
+                o[e] = img[(((size_t)b * 3 + c) * R + gy * ps + i) * R + gx * ps + j];
+            } else o[e] = 0.f;
+        }
+        if (out) *(float4*)(out + (size_t)p * Kp + k4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (outb) *(ushort4*)(outb + (size_t)p * Kp + k4) = make_ushort4(f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3]));
+    }
+}
+int launch_im2col(const float* images, float* out, unsigned short* out_bf16, int n, int R, int ps, int Kp, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && R % ps == 0 && Kp % 4 == 0 && Kp >= 3 * ps * ps);
+    const long total = (long)n * (R / ps) * (R / ps) * (Kp / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    im2col_kernel<<<dim3(blocks), dim3(256), 0, st>>>(images, out, out_bf16, n, R, ps, Kp);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- ViT embed assemble + ln_pre
+// TPT/clip/model.py:227-229: x = ln_pre(cat([cls, patches]) + pos)
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ x,
+                                                           int n, int tokens, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= n * tokens) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / tokens, tok = row % tokens;
+    const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
+    const float* pr = pos + (size_t)tok * width;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        v[j] = c < width ? src[c] + pr[c] : 0.f;
+        s += v[j];
+    }
+    const float mu = wave_sum(s) / width;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) { float d = v[j] - mu; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) x[(size_t)row * width + c] = (v[j] - mu) * rstd * gamma[c] + beta[c];
+    }
+}
+int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,
+                        float* x, int n, int tokens, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE);
+    const int rows = n * tokens;
+    vit_assemble_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, gamma, beta, x, n, tokens, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- text assemble
+// PromptLearner.forward + positional add (TPT/clip/custom_clip.py:198-238,63): E already holds
+// token embedding (non-ctx rows) + positional embedding; ctx rows add the learnable vectors.
+// row_src (optional): X row r is built from row row_src[r] of E / ctx_row (-1: zero row) — the
+// sparse-backward layout re-packs a few class prompts this way.
+__global__ void text_assemble_kernel(const float* __restrict__ E, const int32_t* __restrict__ row_src, const int32_t* __restrict__ ctx_row,
+                                     const float* __restrict__ ctx, float* __restrict__ X, int rows, int w4) {
+    const long total = (long)rows * w4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / w4), c = (int)(idx % w4);
+        const int sr = row_src ? row_src[r] : r;
+        if (sr < 0) { ((float4*)X)[idx] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        float4 e = ((const float4*)E)[(size_t)sr * w4 + c];
+        const int cr = ctx_row[sr];
+        if (cr >= 0) {
+            float4 t = ((const float4*)ctx)[(size_t)cr * w4 + c];
+            e.x += t.x; e.y += t.y; e.z += t.z; e.w += t.w;
+        }
+        ((float4*)X)[idx] = e;
+    }
+}
+int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
+                         int width, hipStream_t st) {
+    RLCF_ARG_CHECK(width % 4 == 0 && rows > 0);
+    const long total = (long)rows * (width / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    text_assemble_kernel<<<dim3(blocks), dim3(256), 0, st>>>(E, row_src, ctx_row, ctx, X, rows, width / 4);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- row gather / scatter
+__global__ void gather_rows_kernel(const float* __restrict__ in, int ld_in, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                   int ld_out, int rows, int width) {
+    const int r = blockIdx.x;
+    const int src = idx ? idx[r] : r;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)r * ld_out + c] = in[(size_t)src * ld_in + c];
+}
+int launch_gather_rows(const float* in, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0);
+    gather_rows_kernel<<<dim3(rows), dim3(256), 0, st>>>(in, ld_in, idx, out, ld_out, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows_idx, float* __restrict__ dst, int width) {
+    const int r = blockIdx.x;
+    const int d = rows_idx[r];
+    for (int c = threadIdx.x; c < width; c += blockDim.x) dst[(size_t)d * width + c] = src[(size_t)r * width + c];
+}
+int launch_scatter_rows(const float* src, const int32_t* rows_idx, float* dst, int n, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0);
+    scatter_rows_kernel<<<dim3(n), dim3(256), 0, st>>>(src, rows_idx, dst, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- L2 normalise (custom_clip.py:320,330)
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ inv_norm,
+                                                     int rows, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < width; c += 64) { float v = in[(size_t)row * width + c]; s += v * v; }
+    const float nrm = sqrtf(wave_sum(s));
+    for (int c = lane; c < width; c += 64) out[(size_t)row * width + c] = in[(size_t)row * width + c] / nrm;
+    if (inv_norm && lane == 0) inv_norm[row] = 1.0f / nrm;
+}
+int launch_l2norm_rows(const float* in, float* out, float* inv_norm, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0);
+    l2norm_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(in, out, inv_norm, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ t, const float* __restrict__ dt,
+                                                         const float* __restrict__ inv_norm, float* __restrict__ du, int rows, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < width; c += 64) s += t[(size_t)row * width + c] * dt[(size_t)row * width + c];
+    s = wave_sum(s);
+    const float inv = inv_norm[row];
+    for (int c = lane; c < width; c += 64)
+        du[(size_t)row * width + c] = (dt[(size_t)row * width + c] - t[(size_t)row * width + c] * s) * inv;
+}
+int launch_l2norm_bwd(const float* t, const float* dt, const float* inv_norm, float* du, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0);
+    l2norm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(t, dt, inv_norm, du, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- ctx gradient (custom_clip.py:198-238 backward)
+__global__ void ctx_grad_kernel(const float* __restrict__ dX, const int32_t* __restrict__ ctx_rows, int n_copies, int n_ctx,
+                                int width, float* __restrict__ dctx) {
+    const int j = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int k = 0; k < n_copies; ++k) s += dX[(size_t)ctx_rows[k * n_ctx + j] * width + c];
+    dctx[(size_t)j * width + c] = s;
+}
+int launch_ctx_grad(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, float* dctx, hipStream_t st) {
+    RLCF_ARG_CHECK(n_copies > 0 && n_ctx > 0);
+    ctx_grad_kernel<<<dim3((width + 63) / 64, n_ctx), dim3(64), 0, st>>>(dX, ctx_rows, n_copies, n_ctx, width, dctx);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- d txt from d logits (dense)
+__global__ void dtxt_dense_kernel(const float* __restrict__ dlogits, const float* __restrict__ img, int n, int C, int D, float scale,
+                                  float* __restrict__ dtxt) {
+    const int c = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += dlogits[(size_t)i * C + c] * img[(size_t)i * D + d];
+        dtxt[(size_t)c * D + d] = scale * s;
+    }
+}
+int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int D, float scale, float* dtxt, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && C > 0);
+    dtxt_dense_kernel<<<dim3(C), dim3(256), 0, st>>>(dlogits, img, n, C, D, scale, dtxt);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- conversions
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+int launch_f32_to_bf16(const float* in, unsigned short* out, int64_t n, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    f32_to_bf16_kernel<<<dim3(blocks), dim3(256), 0, st>>>(in, out, n);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
+    transpose_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st>>>(in, out, rows, cols);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- QuickGELU elementwise (model.py:166-168)
+__global__ void quickgelu_kernel(const float* __restrict__ f, float* __restrict__ g, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = ((const float4*)f)[i];
+        v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+        ((float4*)g)[i] = v;
+    }
+}
+int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st) {
+    RLCF_ARG_CHECK(n % 4 == 0);
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    quickgelu_kernel<<<dim3(blocks), dim3(256), 0, st>>>(f, g, n / 4);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- sparse-backward layout
+// entry e re-packs class cls[e] (device) at rows [pre_rows + e*lmax, +class_len): builds the
+// sequence descriptors, EOT rows and the row_src indirection consumed by text_assemble.
+__global__ void build_sparse_layout_kernel(const int32_t* __restrict__ cls, int n_e, const int32_t* __restrict__ class_start,
+                                           const int32_t* __restrict__ class_len, const int32_t* __restrict__ class_eot_off,
+                                           int lmax, int pre_rows, rlcf_seq* __restrict__ seqs, int32_t* __restrict__ eot_rows,
+                                           int32_t* __restrict__ row_src) {
+    const int e = blockIdx.x;
+    if (e == n_e) {                                   // the shared prefix rows (and its own sequence)
+        for (int r = threadIdx.x; r < pre_rows; r += blockDim.x) row_src[r] = r;
+        if (threadIdx.x == 0 && pre_rows > 0) { rlcf_seq s = {0, pre_rows, 0, 0}; seqs[n_e] = s; }
+        return;
+    }
+    const int c = cls[e];
+    const int base = pre_rows + e * lmax, len = class_len[c], st = class_start[c];
+    for (int j = threadIdx.x; j < lmax; j += blockDim.x) row_src[base + j] = j < len ? st + j : -1;
+    if (threadIdx.x == 0) {
+        rlcf_seq s = {base, len, 0, pre_rows};
+        seqs[e] = s;
+        eot_rows[e] = base + class_eot_off[c];
+    }
+}
+int launch_build_sparse_layout(const int32_t* cls, int n_e, const int32_t* class_start, const int32_t* class_len,
+                               const int32_t* class_eot_off, int lmax, int pre_rows, rlcf_seq* seqs, int32_t* eot_rows,
+                               int32_t* row_src, hipStream_t st) {
+    RLCF_ARG_CHECK(n_e > 0 && lmax > 0);
+    build_sparse_layout_kernel<<<dim3(n_e + 1), dim3(64), 0, st>>>(cls, n_e, class_start, class_len, class_eot_off, lmax, pre_rows,
+                                                                  seqs, eot_rows, row_src);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// dtxt[e,:] = scale * dlogits[e / K, cls[e]] * img[e / K,:]   (one entry per sampled (view, class) pair)
+__global__ void dtxt_sparse_kernel(const float* __restrict__ dlogits, const int32_t* __restrict__ cls, const float* __restrict__ img,
+                                   int K, int C, int D, float scale, float* __restrict__ dtxt) {
+    const int e = blockIdx.x, i = e / K;
+    const float g = scale * dlogits[(size_t)i * C + cls[e]];
+    // duplicates of one class within a row share one dlogits entry: split it evenly
+    int dup = 0;
+    for (int k = 0; k < K; ++k) dup += (cls[i * K + k] == cls[e]) ? 1 : 0;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dtxt[(size_t)e * D + d] = g / dup * img[(size_t)i * D + d];
+}
+int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* img, int n_e, int K, int C, int D, float scale,
+                       float* dtxt, hipStream_t st) {
+    RLCF_ARG_CHECK(n_e > 0 && K > 0);
+    dtxt_sparse_kernel<<<dim3(n_e), dim3(256), 0, st>>>(dlogits, cls, img, K, C, D, scale, dtxt);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -1,0 +1,291 @@
+// The small, latency-bound kernels of the RLCF step: per-view entropy + confidence selection
+// (TPT/tpt_cls_rl.py:32-35), top-K sampling + CLIPScore + baseline + reward-weighted CE and its
+// gradient (TPT/tpt_cls_rl.py:63-74, TPT/clip_reward.py:111-128,152-165), AdamW (TPT/tpt_cls_rl.py:78,120),
+// top-5 of the final logits (TPT/utils/tools.py:84-98).  Wave-shuffle reductions, f32 throughout.
+#include "kernels.h"
+
+#define TTA_THREADS 256
+#define MAX_K 16
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < TTA_THREADS / 64; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < TTA_THREADS / 64; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+// argmax over (value, index) with lowest index winning ties
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* redv, int* redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(v, o);
+        int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    v = redv[0]; i = redi[0];
+    for (int w = 1; w < TTA_THREADS / 64; ++w)
+        if (redv[w] > v || (redv[w] == v && redi[w] < i)) { v = redv[w]; i = redi[w]; }
+}
+
+// ---------------------------------------------------------------- entropy per row
+__global__ __launch_bounds__(TTA_THREADS) void row_entropy_kernel(const float* __restrict__ logits, int C, float* __restrict__ entropy) {
+    __shared__ float red[TTA_THREADS / 64];
+    const float* x = logits + (size_t)blockIdx.x * C;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) mx = fmaxf(mx, x[c]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) s += expf(x[c] - mx);
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+    float hsum = 0.f;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) { float lp = x[c] - lse; hsum += expf(lp) * lp; }
+    hsum = block_sum(hsum, red);
+    if (threadIdx.x == 0) entropy[blockIdx.x] = -hsum;
+}
+// rank-select the n_sel lowest entropies, ascending (argsort semantics; ties by index)
+__global__ void select_lowest_kernel(const float* __restrict__ entropy, int n, int n_sel, int32_t* __restrict__ idx) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = entropy[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float f = entropy[j];
+            rank += (f < e || (f == e && j < i)) ? 1 : 0;
+        }
+        if (rank < n_sel) idx[rank] = i;
+    }
+}
+int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && C > 0 && n_sel >= 0 && n_sel <= n);
+    row_entropy_kernel<<<dim3(n), dim3(TTA_THREADS), 0, st>>>(logits, C, entropy);
+    RLCF_LAUNCH_CHECK();
+    if (n_sel > 0) {
+        select_lowest_kernel<<<dim3(1), dim3(256), 0, st>>>(entropy, n, n_sel, idx);
+        RLCF_LAUNCH_CHECK();
+    }
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- reward loss, stage A (one block per selected row)
+// top-K classes, log-sum-exp, CE per sampled class, CLIPScore per sampled class.
+// stats[i] = {lse, ce[K], score[K]} packed as 1 + 2*MAX_K floats.
+#define STAT_LD (1 + 2 * MAX_K)
+__global__ __launch_bounds__(TTA_THREADS) void reward_stage_a_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ sel,
+                                                                     int C, int K, const float* __restrict__ class_feat,
+                                                                     const float* __restrict__ reward_img, int Dr, float weight,
+                                                                     int32_t* __restrict__ topk_idx, float* __restrict__ stats) {
+    __shared__ float red[TTA_THREADS / 64];
+    __shared__ float redv[TTA_THREADS / 64];
+    __shared__ int redi[TTA_THREADS / 64];
+    __shared__ int chosen[MAX_K];
+    const int i = blockIdx.x;
+    const float* x = logits + (size_t)(sel ? sel[i] : i) * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) mx = fmaxf(mx, x[c]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) s += expf(x[c] - mx);
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+    for (int k = 0; k < K; ++k) {                      // torch.topk order: descending value
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
+            bool used = false;
+            for (int p = 0; p < k; ++p) used |= (chosen[p] == c);
+            const float v = x[c];
+            if (!used && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+        block_argmax(bv, bi, redv, redi);
+        if (threadIdx.x == 0) {
+            chosen[k] = bi;
+            topk_idx[i * K + k] = bi;
+            stats[i * STAT_LD + 1 + k] = lse - bv;     // cross entropy of class bi
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < K; ++k) {                      // CLIPScore: w * <class_feat[idx], img_i>, clamped at 0
+        const float* t = class_feat + (size_t)chosen[k] * Dr;
+        const float* im = reward_img + (size_t)i * Dr;
+        float d = 0.f;
+        for (int c = threadIdx.x; c < Dr; c += TTA_THREADS) d += t[c] * im[c];
+        d = block_sum(d, red);
+        if (threadIdx.x == 0) stats[i * STAT_LD + 1 + MAX_K + k] = fmaxf(weight * d, 0.f);
+    }
+    if (threadIdx.x == 0) stats[i * STAT_LD] = lse;
+}
+
+// stage B (one block per selected row): rewards for every (row, k), loss, dense dlogits of the row.
+__global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ sel,
+                                                                     int n_sel, int C, int K, int flags, float min_entropy_w,
+                                                                     const int32_t* __restrict__ topk_idx, const float* __restrict__ stats,
+                                                                     float* __restrict__ clip_score, float* __restrict__ rewards,
+                                                                     float* __restrict__ loss, float* __restrict__ dlogits) {
+    extern __shared__ float avg[];                      // [C] log of the view-averaged probability (min-entropy only)
+    __shared__ float red[TTA_THREADS / 64];
+    __shared__ float r_row[MAX_K];
+    __shared__ float r_all_sum;
+    const int i = blockIdx.x;
+    const int total = n_sel * K;
+    // ---- rewards_post_process (clip_reward.py:152-165); every block recomputes the tiny table
+    float batch_mean = 0.f, batch_std = 1.f;
+    const bool process = (flags & RLCF_F_REWARD_PROCESS) != 0;
+    const bool amplify = (flags & RLCF_F_AMPLIFY) != 0;
+    const bool batch = (flags & RLCF_F_PROCESS_BATCH) != 0;
+    const int grp = batch ? total : K;                  // size of the last dimension the baseline runs over
+    if (batch) {
+        float s = 0.f;
+        for (int e = 0; e < total; ++e) s += stats[(e / K) * STAT_LD + 1 + MAX_K + e % K];
+        batch_mean = s / total;
+        float q = 0.f;
+        for (int e = 0; e < total; ++e) { float d = stats[(e / K) * STAT_LD + 1 + MAX_K + e % K] - batch_mean; q += d * d; }
+        batch_std = sqrtf(q / (total - 1)) + 1e-5f;
+    }
+    auto reward_of = [&](int row, int k) -> float {
+        const float sc = stats[row * STAT_LD + 1 + MAX_K + k];
+        if (!(process && grp > 1)) return sc;
+        float mean = batch_mean, sd = batch_std;
+        if (!batch) {
+            float s = 0.f;
+            for (int kk = 0; kk < K; ++kk) s += stats[row * STAT_LD + 1 + MAX_K + kk];
+            mean = s / K;
+            if (amplify) {
+                float q = 0.f;
+                for (int kk = 0; kk < K; ++kk) { float d = stats[row * STAT_LD + 1 + MAX_K + kk] - mean; q += d * d; }
+                sd = sqrtf(q / (K - 1)) + 1e-5f;
+            }
+        }
+        return amplify ? (sc - mean) / sd : (sc - mean);
+    };
+    if (threadIdx.x < K) r_row[threadIdx.x] = reward_of(i, threadIdx.x);
+    __syncthreads();
+    float rsum = 0.f;
+    for (int k = 0; k < K; ++k) rsum += r_row[k];
+    if (i == 0 && threadIdx.x == 0) {
+        float l = 0.f;
+        for (int e = 0; e < total; ++e) {
+            const float r = reward_of(e / K, e % K);
+            if (rewards) rewards[e] = r;
+            if (clip_score) clip_score[e] = stats[(e / K) * STAT_LD + 1 + MAX_K + e % K];
+            l += r * stats[(e / K) * STAT_LD + 1 + e % K];
+        }
+        r_all_sum = l / total;
+    }
+    // ---- optional min-entropy regulariser (tpt_cls_rl.py:38-44,73-74)
+    const float* x = logits + (size_t)(sel ? sel[i] : i) * ld;
+    const float lse = stats[i * STAT_LD];
+    float pa_dot = 0.f, hreg = 0.f;
+    const bool minent = (flags & RLCF_F_MIN_ENTROPY) != 0;
+    if (minent) {
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
+            float mx = -INFINITY;
+            for (int j = 0; j < n_sel; ++j) mx = fmaxf(mx, logits[(size_t)(sel ? sel[j] : j) * ld + c] - stats[j * STAT_LD]);
+            float s = 0.f;
+            for (int j = 0; j < n_sel; ++j) s += expf(logits[(size_t)(sel ? sel[j] : j) * ld + c] - stats[j * STAT_LD] - mx);
+            float a = mx + logf(s) - logf((float)n_sel);
+            a = fmaxf(a, -3.4028234663852886e38f);
+            avg[c] = a;
+            pa_dot += expf(x[c] - lse) * a;
+            hreg += a * expf(a);
+        }
+        pa_dot = block_sum(pa_dot, red);
+        hreg = block_sum(hreg, red);
+    }
+    __syncthreads();
+    if (i == 0 && threadIdx.x == 0 && loss) loss[0] = r_all_sum + (minent ? -min_entropy_w * hreg : 0.f);
+    // ---- dlogits row: d/dx of mean_{i,k} r_ik * CE(x_i, idx_ik)  (+ w * d avg_entropy)
+    const float inv_total = 1.0f / total;
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
+        const float p = expf(x[c] - lse);
+        float g = p * rsum;
+        for (int k = 0; k < K; ++k)
+            if (topk_idx[i * K + k] == c) g -= r_row[k];
+        g *= inv_total;
+        if (minent) g += min_entropy_w * (p / n_sel) * (pa_dot - avg[c]);
+        dlogits[(size_t)i * C + c] = g;
+    }
+}
+
+static float* g_stats = nullptr;     // [max rows][STAT_LD] scratch owned by the library
+static int g_stats_rows = 0;
+int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
+                       const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
+                       float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                       float* dlogits, hipStream_t st) {
+    RLCF_ARG_CHECK(n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx);
+    if (g_stats_rows < n_sel) {                          // grows only on a new maximum (setup time)
+        if (g_stats) (void)hipFree(g_stats);
+        g_stats_rows = n_sel < 64 ? 64 : n_sel;
+        RLCF_HIP_CHECK(hipMalloc(&g_stats, (size_t)g_stats_rows * STAT_LD * sizeof(float)));
+    }
+    reward_stage_a_kernel<<<dim3(n_sel), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, class_feat, reward_img, Dr,
+                                                                     clipscore_weight, topk_idx, g_stats);
+    RLCF_LAUNCH_CHECK();
+    const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
+    reward_stage_b_kernel<<<dim3(n_sel), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
+                                                                      topk_idx, g_stats, clip_score, rewards, loss, dlogits);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- AdamW
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2,
+                 float eps, float wd, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && step >= 1);
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    adamw_kernel<<<dim3(blocks), dim3(256), 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- top-5 of one logits row
+__global__ __launch_bounds__(TTA_THREADS) void top5_kernel(const float* __restrict__ x, int C, int32_t* __restrict__ top5) {
+    __shared__ float redv[TTA_THREADS / 64];
+    __shared__ int redi[TTA_THREADS / 64];
+    __shared__ int chosen[5];
+    const int n = C < 5 ? C : 5;
+    for (int k = 0; k < n; ++k) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
+            bool used = false;
+            for (int p = 0; p < k; ++p) used |= (chosen[p] == c);
+            const float v = x[c];
+            if (!used && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+        block_argmax(bv, bi, redv, redi);
+        if (threadIdx.x == 0) { chosen[k] = bi; top5[k] = bi; }
+        __syncthreads();
+    }
+}
+int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st) {
+    top5_kernel<<<dim3(1), dim3(TTA_THREADS), 0, st>>>(logits, C, top5);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

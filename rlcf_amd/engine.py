@@ -1,0 +1,181 @@
+"""Python face of the HIP engine: torch tensors in, torch tensors out, every FLOP in
+librlcf_hip.so.  torch is used for device memory and the stream only."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .synth import ClipGeometry
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cfg(g: ClipGeometry) -> L.ClipCfg:
+    return L.ClipCfg(g.embed_dim, g.image_resolution, g.vision_layers, g.vision_width, g.vision_patch_size,
+                     g.context_length, g.vocab_size, g.transformer_width, g.transformer_heads, g.transformer_layers)
+
+
+@dataclass
+class TTAConfig:
+    """Flags read on the path (reference TPT/params.py:13-98; script values TPT/scripts/rlcf-prompt.sh)."""
+    selection_p: float = 0.1
+    tta_steps: int = 1
+    sample_k: int = 3
+    lr: float = 7e-3
+    weight_decay: float = 5e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    reward_process: bool = True
+    process_batch: bool = False
+    reward_amplify: bool = False
+    clipscore_weight: float = 2.5
+    min_entropy_reg: bool = False
+    min_entropy_w: float = 0.2
+    sparse_backward: bool = True
+
+    def flags(self) -> int:
+        return ((L.F_REWARD_PROCESS if self.reward_process else 0) | (L.F_AMPLIFY if self.reward_amplify else 0) |
+                (L.F_PROCESS_BATCH if self.process_batch else 0) | (L.F_MIN_ENTROPY if self.min_entropy_reg else 0))
+
+    def c_args(self) -> L.TTAArgs:
+        return L.TTAArgs(self.selection_p, self.tta_steps, self.sample_k, self.lr, self.weight_decay, self.beta1,
+                         self.beta2, self.eps, self.flags(), self.clipscore_weight, self.min_entropy_w,
+                         1 if self.sparse_backward else 0)
+
+
+class Engine:
+    """One student CLIP (+ optional frozen reward CLIP) resident on the current GPU."""
+
+    def __init__(self, student: ClipGeometry, reward: Optional[ClipGeometry], max_views: int, max_classes: int,
+                 precision: int = L.PREC_F32):
+        if not torch.cuda.is_available():
+            raise L.RlcfError("rlcf_amd.Engine needs a GPU: the HIP path has no CPU fallback")
+        self.lib = L.lib()
+        self.student, self.reward = student, reward
+        self.max_views, self.max_classes, self.precision = max_views, max_classes, precision
+        sc = _cfg(student)
+        rc = _cfg(reward) if reward is not None else None
+        self.h = self.lib.rlcf_engine_create(C.byref(sc), C.byref(rc) if rc is not None else None, max_views,
+                                             max_classes, precision)
+        if not self.h:
+            raise L.RlcfError("rlcf_engine_create: " + self.lib.rlcf_last_error().decode())
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_cls = 0
+        self.n_ctx = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rlcf_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -----------------------------------------------------------------
+    def load_state_dict(self, which: int, sd: Dict[str, torch.Tensor]) -> None:
+        """OpenAI-layout CLIP state dict (reference TPT/clip/model.py:399-436)."""
+        for k, v in sd.items():
+            t = v.detach().to(self.device, torch.float32).contiguous().reshape(-1)
+            L.check(self.lib.rlcf_engine_load_weight(self.h, which, k.encode(), t.data_ptr(), t.numel()), f"load {k}")
+        torch.cuda.synchronize()
+
+    def finalize(self) -> None:
+        L.check(self.lib.rlcf_engine_finalize(self.h, _stream()), "finalize")
+
+    def set_class_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor,
+                       text_mode: int = L.TEXT_SHARED) -> None:
+        tok = np.ascontiguousarray(tokens.detach().cpu().numpy().astype(np.int32))
+        ci = ctx_init.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_set_class_bank(self.h, tok.ctypes.data, tok.shape[0], n_ctx, ci.data_ptr(),
+                                                    text_mode, _stream()), "set_class_bank")
+        self.n_cls, self.n_ctx = tok.shape[0], n_ctx
+
+    # ---- tower passes ------------------------------------------------------------
+    def encode_image(self, which: int, images: torch.Tensor) -> torch.Tensor:
+        g = self.student if which == L.STUDENT else self.reward
+        images = images.to(self.device, torch.float32).contiguous()
+        out = torch.empty(images.shape[0], g.embed_dim, device=self.device)
+        L.check(self.lib.rlcf_encode_image(self.h, which, _ptr(images), images.shape[0], _ptr(out), _stream()),
+                "encode_image")
+        return out
+
+    def text_features(self, ctx: torch.Tensor) -> torch.Tensor:
+        ctx = ctx.detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty(self.n_cls, self.student.embed_dim, device=self.device)
+        L.check(self.lib.rlcf_text_features(self.h, _ptr(ctx), _ptr(out), _stream()), "text_features")
+        return out
+
+    def reward_class_features(self) -> torch.Tensor:
+        out = torch.empty(self.n_cls, self.reward.embed_dim, device=self.device)
+        L.check(self.lib.rlcf_reward_class_features(self.h, _ptr(out), _stream()), "reward_class_features")
+        return out
+
+    def logits(self, img: torch.Tensor, txt: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(img.shape[0], txt.shape[0], device=self.device)
+        L.check(self.lib.rlcf_logits(self.h, _ptr(img.contiguous()), img.shape[0], _ptr(txt.contiguous()), txt.shape[0],
+                                     _ptr(out), _stream()), "logits")
+        return out
+
+    def text_backward_dense(self, ctx: torch.Tensor, img: torch.Tensor, dlogits: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(self.n_ctx, self.student.transformer_width, device=self.device)
+        L.check(self.lib.rlcf_text_backward_dense(self.h, _ptr(ctx.contiguous()), _ptr(img.contiguous()), img.shape[0],
+                                                  _ptr(dlogits.contiguous()), _ptr(out), _stream()), "text_backward")
+        return out
+
+    # ---- the per-sample step -----------------------------------------------------
+    def tta_sample(self, views: torch.Tensor, cfg: TTAConfig, want_intermediates: bool = True) -> Dict[str, torch.Tensor]:
+        views = views.to(self.device, torch.float32).contiguous()
+        N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
+        n_sel = int(N * cfg.selection_p)
+        D, Dr, Wt = self.student.embed_dim, self.reward.embed_dim, self.student.transformer_width
+        dev = self.device
+        o: Dict[str, torch.Tensor] = {
+            "final_logits": torch.empty(1, Cn, device=dev), "top5": torch.empty(5, dtype=torch.int32, device=dev),
+            "ctx_after": torch.empty(self.n_ctx, Wt, device=dev)}
+        if want_intermediates and cfg.tta_steps > 0:
+            o.update(logits=torch.empty(N, Cn, device=dev), entropy=torch.empty(N, device=dev),
+                     selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
+                     topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev),
+                     clip_score=torch.empty(n_sel * K, device=dev), rewards=torch.empty(n_sel * K, device=dev),
+                     loss=torch.empty(1, device=dev), dlogits=torch.empty(n_sel, Cn, device=dev),
+                     ctx_grad=torch.empty(self.n_ctx, Wt, device=dev),
+                     reward_image_features=torch.empty(n_sel, Dr, device=dev))
+        co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
+        a = cfg.c_args()
+        L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
+        return o
+
+    def tta_batch(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):
+        """views [count,N,3,R,R] -> top5 [count,5] (and final logits [count,C])."""
+        views = views.to(self.device, torch.float32).contiguous()
+        count, N = views.shape[0], views.shape[1]
+        top5 = torch.empty(count, 5, dtype=torch.int32, device=self.device)
+        fl = torch.empty(count, self.n_cls, device=self.device) if want_logits else None
+        a = cfg.c_args()
+        L.check(self.lib.rlcf_tta_batch(self.h, _ptr(views), count, N, C.byref(a), _ptr(fl), _ptr(top5), _stream()),
+                "tta_batch")
+        return (top5, fl) if want_logits else top5
+
+    def last_flops(self) -> float:
+        return float(self.lib.rlcf_engine_last_flops(self.h))
+
+    def text_rows(self) -> int:
+        return int(self.lib.rlcf_engine_text_rows(self.h))

@@ -1,0 +1,364 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden fixtures generated from the imported reference.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref as CR
+from oracle import rlcf_ref as RR
+from rlcf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rlcf_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("meta_")}
+    meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+    return arrays, meta
+
+
+# ------------------------------------------------------------------------------ op level
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 300, 128), (1000, 64, 512), (37, 1000, 64), (2049, 768, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_nt(L, dev, M, N, K, epi):
+    a = synth.normal(1, "g.a", (M, K)).to(dev)
+    w = synth.normal(1, "g.w", (N, K), K ** -0.5).to(dev)
+    b = synth.normal(1, "g.b", (N,), 0.1).to(dev)
+    r = synth.normal(1, "g.r", (M, N)).to(dev)
+    aux = synth.normal(1, "g.aux", (M, N)).to(dev)
+    c = torch.empty(M, N, device=dev)
+    L.check(L.lib().rlcf_gemm_nt(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), r.data_ptr(), N, aux.data_ptr(), N,
+                                 c.data_ptr(), N, M, N, K, 0.5, epi, L.PREC_F32, st()))
+    v = 0.5 * (a.double().cpu() @ w.double().cpu().t()) + b.double().cpu()
+    if epi == 1:
+        v = v * torch.sigmoid(1.702 * v)
+    elif epi == 2:
+        f = aux.double().cpu()
+        s = torch.sigmoid(1.702 * f)
+        v = v * (s * (1 + 1.702 * f * (1 - s)))
+    v = v + r.double().cpu()
+    torch.testing.assert_close(c.cpu().double(), v, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("rows,width", [(5, 128), (1000, 512), (197 * 3, 768), (7, 1024), (9, 64)])
+def test_layernorm(L, dev, rows, width):
+    x = synth.normal(2, "ln.x", (rows, width), 2.0, 0.3).to(dev)
+    g = synth.normal(2, "ln.g", (width,), 0.1, 1.0).to(dev)
+    b = synth.normal(2, "ln.b", (width,), 0.05).to(dev)
+    dy = synth.normal(2, "ln.dy", (rows, width)).to(dev)
+    y = torch.empty_like(x)
+    L.check(L.lib().rlcf_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), rows, width, st()))
+    xc = x.cpu().double().requires_grad_(True)
+    gc = g.cpu().double().requires_grad_(True)
+    bc = b.cpu().double().requires_grad_(True)
+    yc = CR.layer_norm(xc.float(), gc.float(), bc.float()) if False else torch.nn.functional.layer_norm(xc, (width,), gc, bc, 1e-5)
+    torch.testing.assert_close(y.cpu().double(), yc.detach(), atol=5e-6, rtol=1e-5)
+    torch.testing.assert_close(y.cpu(), CR.layer_norm(x.cpu(), g.cpu(), b.cpu()), atol=5e-6, rtol=1e-5)
+    (yc * dy.cpu().double()).sum().backward()
+    dx = torch.empty_like(x)
+    dg = torch.zeros_like(g)
+    db = torch.zeros_like(b)
+    L.check(L.lib().rlcf_layernorm_bwd(x.data_ptr(), g.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                       db.data_ptr(), rows, width, st()))
+    torch.testing.assert_close(dx.cpu().double(), xc.grad, atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(dg.cpu().double(), gc.grad, atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(db.cpu().double(), bc.grad, atol=1e-3, rtol=1e-4)
+
+
+def _attn_ref(qkv, seqs, W, causal):
+    """float64 reference of the attention core over packed sequences (differentiable)."""
+    H = W // 64
+    out = torch.zeros(qkv.shape[0], W, dtype=qkv.dtype)
+    for (qs, ql, ps, pl) in seqs:
+        rows = list(range(ps, ps + pl)) + list(range(qs, qs + ql))
+        q = qkv[qs:qs + ql, :W].reshape(ql, H, 64).transpose(0, 1)
+        k = qkv[rows, W:2 * W].reshape(len(rows), H, 64).transpose(0, 1)
+        v = qkv[rows, 2 * W:].reshape(len(rows), H, 64).transpose(0, 1)
+        s = (q * 0.125) @ k.transpose(-1, -2)
+        if causal:
+            i = torch.arange(ql)[:, None]
+            j = torch.arange(len(rows))[None, :]
+            s = s.masked_fill(j > pl + i, float("-inf"))
+        o = torch.softmax(s, -1) @ v
+        out[qs:qs + ql] = o.transpose(0, 1).reshape(ql, W)
+    return out
+
+
+ATT_CASES = [
+    ("vit", [(0, 50, 0, 0), (50, 50, 0, 0), (100, 50, 0, 0)], 150, 128, 0),
+    ("vit197", [(i * 197, 197, 0, 0) for i in range(2)], 394, 128, 0),
+    ("dense_causal", [(i * 77, 77, 0, 0) for i in range(3)], 231, 128, 1),
+    ("shared", [(5, 4, 0, 5), (9, 13, 0, 5), (22, 1, 0, 5), (23, 7, 0, 5), (0, 5, 0, 0)], 30, 192, 1),
+    ("ragged", [(0, 33, 0, 0), (33, 1, 0, 0), (34, 64, 0, 0), (98, 65, 0, 0)], 163, 64, 1),
+]
+
+
+@pytest.mark.parametrize("name,seqs,T,W,causal", ATT_CASES)
+def test_attention_fwd_bwd(L, dev, name, seqs, T, W, causal):
+    qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5)
+    sq = (L.Seq * len(seqs))(*[L.Seq(*s) for s in seqs])
+    sbuf = torch.frombuffer(bytearray(bytes(sq)), dtype=torch.int32).to(dev)
+    qd = qkv.to(dev)
+    out = torch.zeros(T, W, device=dev)
+    lse = torch.zeros(T, W // 64, device=dev)
+    mq = max(s[1] for s in seqs)
+    L.check(L.lib().rlcf_attention_fwd(qd.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, causal, out.data_ptr(),
+                                       lse.data_ptr(), L.PREC_F32, st()))
+    q64 = qkv.double().requires_grad_(True)
+    ref = _attn_ref(q64, seqs, W, causal)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=3e-6, rtol=1e-5)
+    mk = max(s[1] + s[3] for s in seqs)
+    if mk <= 96:
+        do = synth.normal(3, "att.do." + name, (T, W))
+        (ref * do.double()).sum().backward()
+        dq = torch.zeros(T, 3 * W, device=dev)
+        L.check(L.lib().rlcf_attention_bwd(qd.data_ptr(), do.to(dev).data_ptr(), sbuf.data_ptr(), len(seqs), mk, W, causal,
+                                           dq.data_ptr(), st()))
+        torch.testing.assert_close(dq.cpu().double(), q64.grad, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,Cn,p", [(16, 50, 0.25), (64, 1000, 0.1), (8, 16, 0.5), (16, 50, 0.05)])
+def test_entropy_select(L, dev, n, Cn, p):
+    lg = synth.normal(6, "ops.logits", (16, 50), 3.0) if (n, Cn) == (16, 50) else synth.normal(6, "es", (n, Cn), 3.0)
+    ent = torch.empty(n, device=dev)
+    n_sel = int(n * p)
+    idx = torch.full((max(n_sel, 1),), -1, dtype=torch.int32, device=dev)
+    L.check(L.lib().rlcf_entropy_select(lg.to(dev).data_ptr(), n, Cn, n_sel, ent.data_ptr(), idx.data_ptr(), st()))
+    torch.testing.assert_close(ent.cpu(), RR.entropy_rows(lg), atol=2e-6, rtol=1e-5)
+    _, ref_idx = RR.select_confident_samples(lg, p)
+    assert idx.cpu()[:n_sel].tolist() == ref_idx.tolist()
+    if (n, Cn) == (16, 50):            # the reference's own output (tests/golden/ops.npz)
+        g, _ = load_golden("ops")
+        assert idx.cpu()[:n_sel].tolist() == g[f"select_idx_{p}"].tolist()
+
+
+@pytest.mark.parametrize("flags_kw", [dict(), dict(reward_amplify=True), dict(process_batch=True),
+                                      dict(min_entropy_reg=True), dict(reward_process=False),
+                                      dict(process_batch=True, reward_amplify=True, min_entropy_reg=True)])
+@pytest.mark.parametrize("n_sel,Cn,K,Dr", [(4, 16, 3, 64), (6, 1000, 3, 512), (3, 40, 1, 128), (5, 200, 5, 768)])
+def test_reward_loss(L, dev, flags_kw, n_sel, Cn, K, Dr):
+    from rlcf_amd.engine import TTAConfig
+    cfg = TTAConfig(sample_k=K, **flags_kw)
+    logits = synth.normal(7, "rl.logits", (n_sel, Cn), 2.0)
+    cf = CR.l2_normalize(synth.normal(7, "rl.cf", (Cn, Dr)))
+    ri = CR.l2_normalize(synth.normal(7, "rl.ri", (n_sel, Dr)) + 0.5)
+    d = lambda t: t.to(dev).contiguous()
+    topk = torch.empty(n_sel, K, dtype=torch.int32, device=dev)
+    score = torch.empty(n_sel * K, device=dev)
+    rew = torch.empty(n_sel * K, device=dev)
+    loss = torch.empty(1, device=dev)
+    dl = torch.empty(n_sel, Cn, device=dev)
+    lg, cfd, rid = d(logits), d(cf), d(ri)
+    L.check(L.lib().rlcf_reward_loss(lg.data_ptr(), Cn, None, n_sel, Cn, K, cfd.data_ptr(), rid.data_ptr(), Dr,
+                                     cfg.clipscore_weight, cfg.flags(), cfg.min_entropy_w, topk.data_ptr(), score.data_ptr(),
+                                     rew.data_ptr(), loss.data_ptr(), dl.data_ptr(), st()))
+    x = logits.clone().requires_grad_(True)
+    _, index = torch.topk(x, K, dim=-1)
+    flat = index.flatten()
+    sc = RR.clip_score(cf, ri, flat, K, cfg.clipscore_weight).reshape(-1)
+    r = RR.rewards_post_process(sc if cfg.process_batch else sc.reshape(n_sel, -1), cfg.reward_process, cfg.reward_amplify)
+    ce = torch.nn.functional.cross_entropy(torch.repeat_interleave(x, K, dim=0), flat, reduction="none")
+    ref_loss = torch.mean(r * ce)
+    if cfg.min_entropy_reg:
+        ref_loss = ref_loss + cfg.min_entropy_w * RR.avg_entropy(x)
+    ref_loss.backward()
+    assert topk.cpu().tolist() == index.tolist()
+    torch.testing.assert_close(score.cpu(), sc, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(rew.cpu(), r, atol=5e-5, rtol=2e-4)
+    torch.testing.assert_close(loss.cpu()[0], ref_loss.detach(), atol=1e-5, rtol=2e-4)
+    torch.testing.assert_close(dl.cpu(), x.grad, atol=2e-6, rtol=5e-4)
+
+
+def test_adamw_matches_reference_fixture(L, dev):
+    g, _ = load_golden("ops")
+    p = synth.normal(8, "ops.p", (4, 64), 0.02).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(3):
+        gr = synth.normal(8, f"ops.g{s}", (4, 64), 1e-3).to(dev)
+        L.check(L.lib().rlcf_adamw_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), s + 1, 7e-3,
+                                        0.9, 0.999, 1e-8, 5e-4, st()))
+        torch.testing.assert_close(p.cpu(), g[f"adamw_p{s + 1}"], atol=1e-7, rtol=1e-6)
+
+
+def test_block_fixture_through_ops(L, dev):
+    """One ResidualAttentionBlock (reference output in ops.npz) assembled from the op-level ABI."""
+    g, _ = load_golden("ops")
+    sd = {k: v.to(dev) for k, v in synth.make_state_dict(synth.GEOMETRIES["tiny"], seed=5).items()}
+    p = "transformer.resblocks.0."
+    W, Lq, B = 128, 9, 3
+    for masked in (0, 1):
+        x = synth.normal(4, "ops.blk", (Lq, B, W)).transpose(0, 1).contiguous().reshape(B * Lq, W).to(dev)
+        T = B * Lq
+        lib = L.lib()
+        h = torch.empty_like(x)
+        L.check(lib.rlcf_layernorm_fwd(x.data_ptr(), sd[p + "ln_1.weight"].data_ptr(), sd[p + "ln_1.bias"].data_ptr(),
+                                       h.data_ptr(), T, W, st()))
+        qkv = torch.empty(T, 3 * W, device=dev)
+        L.check(lib.rlcf_gemm_nt(h.data_ptr(), W, sd[p + "attn.in_proj_weight"].data_ptr(), W,
+                                 sd[p + "attn.in_proj_bias"].data_ptr(), None, 0, None, 0, qkv.data_ptr(), 3 * W, T, 3 * W, W,
+                                 1.0, 0, 0, st()))
+        seqs = [(i * Lq, Lq, 0, 0) for i in range(B)]
+        sq = (L.Seq * B)(*[L.Seq(*s) for s in seqs])
+        sbuf = torch.frombuffer(bytearray(bytes(sq)), dtype=torch.int32).to(dev)
+        a = torch.empty(T, W, device=dev)
+        L.check(lib.rlcf_attention_fwd(qkv.data_ptr(), sbuf.data_ptr(), B, Lq, W, masked, a.data_ptr(), None, 0, st()))
+        x1 = torch.empty_like(x)
+        L.check(lib.rlcf_gemm_nt(a.data_ptr(), W, sd[p + "attn.out_proj.weight"].data_ptr(), W,
+                                 sd[p + "attn.out_proj.bias"].data_ptr(), x.data_ptr(), W, None, 0, x1.data_ptr(), W, T, W, W,
+                                 1.0, 0, 0, st()))
+        L.check(lib.rlcf_layernorm_fwd(x1.data_ptr(), sd[p + "ln_2.weight"].data_ptr(), sd[p + "ln_2.bias"].data_ptr(),
+                                       h.data_ptr(), T, W, st()))
+        f = torch.empty(T, 4 * W, device=dev)
+        L.check(lib.rlcf_gemm_nt(h.data_ptr(), W, sd[p + "mlp.c_fc.weight"].data_ptr(), W, sd[p + "mlp.c_fc.bias"].data_ptr(),
+                                 None, 0, None, 0, f.data_ptr(), 4 * W, T, 4 * W, W, 1.0, 1, 0, st()))
+        y = torch.empty_like(x)
+        L.check(lib.rlcf_gemm_nt(f.data_ptr(), 4 * W, sd[p + "mlp.c_proj.weight"].data_ptr(), 4 * W,
+                                 sd[p + "mlp.c_proj.bias"].data_ptr(), x1.data_ptr(), W, None, 0, y.data_ptr(), W, T, W, 4 * W,
+                                 1.0, 0, 0, st()))
+        ref = g[f"block_y_{masked}"].transpose(0, 1).reshape(T, W)
+        torch.testing.assert_close(y.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------ engine level
+def make_engine(meta_or_names, n_views, n_cls, text_mode, student_seed=11, reward_seed=23, bank_seed=7, n_ctx=4):
+    from rlcf_amd import _lib
+    from rlcf_amd.engine import Engine
+    s_name, r_name = meta_or_names
+    sg, rg = synth.GEOMETRIES[s_name], synth.GEOMETRIES[r_name]
+    ssd = synth.make_state_dict(sg, student_seed)
+    rsd = synth.make_state_dict(rg, reward_seed)
+    eng = Engine(sg, rg, n_views, n_cls)
+    eng.load_state_dict(_lib.STUDENT, ssd)
+    eng.load_state_dict(_lib.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(sg, n_cls, seed=bank_seed, n_ctx=n_ctx)
+    ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(sg, n_ctx))
+    eng.set_class_bank(tokens, n_ctx, ctx0, text_mode)
+    return eng, ssd, rsd, tokens, ctx0
+
+
+@pytest.mark.parametrize("geo", ["tiny", "small"])
+def test_encode_image_vs_oracle(L, dev, geo):
+    eng, ssd, rsd, tokens, ctx0 = make_engine((geo, geo), 8, 16, L.TEXT_SHARED)
+    views = synth.make_views(1000, 5, synth.GEOMETRIES[geo].image_resolution)
+    for which, sd in ((L.STUDENT, ssd), (L.REWARD, rsd)):
+        f = eng.encode_image(which, views.to(dev)).cpu()
+        ref = CR.l2_normalize(CR.encode_image(sd, views))
+        torch.testing.assert_close(f, ref, atol=5e-6, rtol=1e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("geo,n_cls", [("tiny", 16), ("small", 40)])
+def test_text_features_vs_oracle(L, dev, mode, geo, n_cls):
+    eng, ssd, rsd, tokens, ctx0 = make_engine((geo, geo), 8, n_cls, mode)
+    ctx = ctx0 + synth.normal(5, "ctx.delta", tuple(ctx0.shape), 0.01)
+    t = eng.text_features(ctx.to(dev)).cpu()
+    ref = CR.student_text_features(ssd, tokens, ctx)
+    torch.testing.assert_close(t, ref, atol=5e-6, rtol=1e-4)
+    rc = eng.reward_class_features().cpu()
+    torch.testing.assert_close(rc, RR.reward_class_features(rsd, tokens), atol=5e-6, rtol=1e-4)
+    # dense backward of an arbitrary dlogits against autograd on the oracle
+    img = CR.l2_normalize(synth.normal(5, "img", (3, ssd["text_projection"].shape[1])))
+    dl = synth.normal(5, "dl", (3, n_cls), 0.01)
+    cg = ctx.clone().requires_grad_(True)
+    logits = ssd["logit_scale"].exp() * img @ CR.student_text_features(ssd, tokens, cg).t()
+    (logits * dl).sum().backward()
+    g = eng.text_backward_dense(ctx.to(dev), img.to(dev), dl.to(dev)).cpu()
+    assert (g - cg.grad).norm() / cg.grad.norm() < 2e-4
+    eng.close()
+
+
+TTA_FIXTURES = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
+                "tta_small_s1"]
+
+
+def _cfg_from_meta(meta, sparse=True):
+    from rlcf_amd.engine import TTAConfig
+    return TTAConfig(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                     weight_decay=meta["weight_decay"], reward_amplify=bool(meta.get("reward_amplify", False)),
+                     process_batch=bool(meta.get("process_batch", False)), min_entropy_reg=bool(meta.get("min_entropy_reg", 0)),
+                     min_entropy_w=float(meta.get("min_entropy_w", 0.2)), sparse_backward=sparse)
+
+
+def _check_against(o, g, meta, final_atol=1e-3):
+    c = lambda k: o[k].cpu()
+    assert c("selected_idx").tolist() == g["selected_idx"].tolist()
+    assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
+    torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(c("entropy"), g["entropy"], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(c("clip_score"), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=final_atol, rtol=0)
+    if meta["tta_steps"] == 1:
+        gr, og = g["ctx_grad"], c("ctx_grad")
+        assert (og - gr).norm() / gr.norm() < 1e-3
+        big = gr.abs() > 1e-3 * gr.abs().max()
+        assert torch.equal(torch.sign(og[big]), torch.sign(gr[big]))
+    d = (c("ctx_after") - g["ctx_after"]).abs()
+    assert (d > 1e-4).float().mean() < 0.01
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("name", TTA_FIXTURES)
+def test_tta_sample_matches_reference_fixture(L, dev, name, sparse, mode):
+    g, meta = load_golden(name)
+    eng, ssd, rsd, tokens, ctx0 = make_engine((meta["student"], meta["reward"]), meta["n_views"], meta["n_cls"], mode,
+                                              meta["student_seed"], meta["reward_seed"], meta["bank_seed"], meta["n_ctx"])
+    views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution)
+    o = eng.tta_sample(views.to(dev), _cfg_from_meta(meta, sparse))
+    torch.cuda.synchronize()
+    _check_against(o, g, meta)
+    eng.close()
+
+
+def test_tta_batch_and_reset(L, dev):
+    """Per-sample reset (tpt_cls_rl.py:251-255): a batch gives the same predictions as one-by-one calls."""
+    g, meta = load_golden("tta_tiny_s1")
+    eng, *_ = make_engine((meta["student"], meta["reward"]), 8, 16, L.TEXT_SHARED)
+    cfg = _cfg_from_meta(meta)
+    R = synth.GEOMETRIES["tiny"].image_resolution
+    vs = torch.stack([synth.make_views(1000 + i, 8, R) for i in range(3)]).to(dev)
+    top5, fl = eng.tta_batch(vs, cfg, want_logits=True)
+    for i in (2, 0, 1):
+        o = eng.tta_sample(vs[i], cfg, want_intermediates=False)
+        assert o["top5"].tolist() == top5[i].tolist()
+        torch.testing.assert_close(o["final_logits"][0], fl[i], atol=0, rtol=0)
+    assert top5[0].cpu().tolist() == g["top5"].tolist()
+    eng.close()
+
+
+def test_errors_are_loud(L, dev):
+    from rlcf_amd.engine import TTAConfig
+    eng, *_ = make_engine(("tiny", "tiny-r"), 8, 16, L.TEXT_SHARED)
+    views = synth.make_views(1000, 8, 32).to(dev)
+    with pytest.raises(L.RlcfError):     # int(8*0.1) == 0 selected views
+        eng.tta_sample(views, TTAConfig(selection_p=0.1))
+    with pytest.raises(L.RlcfError):
+        eng.tta_sample(torch.cat([views, views]), TTAConfig(selection_p=0.5))   # more views than max_views
+    eng.close()
