@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""RLCF hot-path benchmark: test-images/sec of the per-sample test-time-adaptation step.
+
+A "step" = one test image: N=64 augmented 224x224 views -> student ViT-B/16 image tower,
+prompt text tower over a 1000-class bank, confidence selection, frozen ViT-B/16 reward model on
+the selected views, top-K CLIP-reward REINFORCE loss, backward to the prompt, one AdamW step,
+final clean-view inference, top-5 (reference: TPT/tpt_cls_rl.py:219-279 with
+TPT/scripts/rlcf-prompt.sh hyper-parameters, tta_steps=1).  BASELINE.json configs[1].
+
+Inputs (seeded synthetic views, weights, token bank) are resident in HBM before the timed region.
+One process per GPU; independent test images shard across ranks with no collective on the data
+path (weak scaling); only the barrier and the max-over-ranks of the elapsed time use RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from rlcf_amd import _lib, synth  # noqa: E402
+from rlcf_amd.engine import Engine, TTAConfig  # noqa: E402
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks)
+
+
+def cpu_baseline(ssd, rsd, geo, n_ctx=4):
+    """Times the oracle (CPU torch restatement of the reference graph: dense 77-token text tower,
+    autograd backward) on the host cores.  Bounded sample: cfg-1 shape (N=8 views, selection_p=0.5)
+    on class banks of 32 and 96 prompts; the per-image cost at C=1000 is the linear extrapolation
+    (image towers are C-independent, text tower fwd+bwd is linear in C)."""
+    from oracle import clip_ref as CR, rlcf_ref as RR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    views = synth.make_views(1000, 8, geo.image_resolution)
+    ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(geo, n_ctx))
+    hp = RR.TTAHyper(selection_p=0.5)
+    times = {}
+    for c in (32, 96):
+        tokens = synth.make_token_bank(geo, c, seed=7, n_ctx=n_ctx)
+        rc = RR.reward_class_features(rsd, tokens)          # once per dataset in the reference: not timed
+        t0 = time.time()
+        RR.tta_sample(ssd, rsd, views, tokens, ctx0, hp, reward_cls=rc)
+        times[c] = time.time() - t0
+    per_class = (times[96] - times[32]) / 64.0
+    t_full = times[32] + per_class * (1000 - 32)
+    return {"value": 1.0 / t_full, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU torch fp32, dense-77 reference graph), 1 image x N=8 views (selection_p=0.5), "
+                      f"timed at C=32 ({times[32]:.2f}s) and C=96 ({times[96]:.2f}s), extrapolated linearly to "
+                      f"C=1000 ({t_full:.1f}s/image); N=64 would add only image-tower time",
+            "seconds_per_image_extrapolated": t_full}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    geo = synth.GEOMETRIES["ViT-B/16"]
+    n_ctx = 4
+    ssd = synth.make_state_dict(geo, 11, device=dev)
+    rsd = synth.make_state_dict(geo, 23, device=dev)
+    tokens = synth.make_token_bank(geo, a.classes, seed=7, n_ctx=n_ctx)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, n_ctx), device=dev)].clone()
+    eng = Engine(geo, geo, a.views, a.classes)
+    eng.load_state_dict(_lib.STUDENT, ssd)
+    eng.load_state_dict(_lib.REWARD, rsd)
+    eng.finalize()
+    mode = {"dense": _lib.TEXT_DENSE, "packed": _lib.TEXT_PACKED, "shared": _lib.TEXT_SHARED}[a.text_mode]
+    eng.set_class_bank(tokens, n_ctx, ctx0, mode)
+    cfg = TTAConfig(selection_p=0.1, tta_steps=1, sample_k=3, lr=7e-3, weight_decay=5e-4)
+
+    # independent test images: rank r takes samples r*(W+K) .. ; seeds are per sample
+    total = a.warmup + a.steps
+    base = 1000 + rank * total
+    views = torch.stack([synth.make_views(base + i, a.views, geo.image_resolution, device=dev) for i in range(total)])
+    torch.cuda.synchronize()
+
+    if a.warmup:
+        eng.tta_batch(views[: a.warmup], cfg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    top5 = eng.tta_batch(views[a.warmup:], cfg)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    flops_exec = eng.last_flops()
+
+    if rank == 0:
+        # roofline of the dominant kernel (the f32-MFMA GEMM): per-launch HIP-event timing of one sample
+        lib = _lib.lib()
+        lib.rlcf_profile_gemm(1)
+        eng.tta_batch(views[:1], cfg)
+        torch.cuda.synchronize()
+        import ctypes as C
+        n_l, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
+        _lib.check(lib.rlcf_profile_read(C.byref(n_l), C.byref(ms), C.byref(fl)))
+        lib.rlcf_profile_gemm(0)
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        peak = PEAK_TFLOPS["f32"]
+        out = {
+            "metric": "test_images_per_sec", "value": a.steps * world / dt, "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + ViT-B/16 reward, N=64 views, "
+                                   "1000-class bank, selection_p=0.1, K=3, 1 AdamW step (BASELINE configs[1])",
+                       "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
+                       "tta_steps": 1, "parallelism": f"sample-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "launches_per_image": n_l.value, "avg_launch_ms": ms.value / max(n_l.value, 1),
+                         "gemm_flops_per_image": fl.value},
+            "flops_exec_per_image": flops_exec,
+            "whole_step_tflops": flops_exec * a.steps / dt / 1e12,
+            "top1_first": int(top5[0, 0].item()),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -348,7 +348,8 @@ def test_tta_batch_and_reset(L, dev):
     for i in (2, 0, 1):
         o = eng.tta_sample(vs[i], cfg, want_intermediates=False)
         assert o["top5"].tolist() == top5[i].tolist()
-        torch.testing.assert_close(o["final_logits"][0], fl[i], atol=0, rtol=0)
+        # dK/dV of shared prefix keys accumulate with float atomics: order-dependent in the last bits
+        torch.testing.assert_close(o["final_logits"][0], fl[i], atol=2e-4, rtol=0)
     assert top5[0].cpu().tolist() == g["top5"].tolist()
     eng.close()
 
@@ -362,3 +363,49 @@ def test_errors_are_loud(L, dev):
     with pytest.raises(L.RlcfError):
         eng.tta_sample(torch.cat([views, views]), TTAConfig(selection_p=0.5))   # more views than max_views
     eng.close()
+
+
+# ------------------------------------------------------------------------------ full geometry (BASELINE configs 0/1)
+@pytest.mark.parametrize("name", ["tta_b16_n8", "tta_b16_n64"])
+@pytest.mark.parametrize("mode,sparse", [(2, True), (1, True), (0, False)])
+def test_vit_b16_tta_matches_reference_fixture(L, dev, name, mode, sparse):
+    """ViT-B/16 student + ViT-B/16 reward, C=1000, outputs of the REFERENCE itself
+    (tests/golden/make_golden.py --only b16n8,b16n64): logits within 1e-3, identical top-1/top-5."""
+    g, meta = load_golden(name)
+    geo = synth.GEOMETRIES[meta["student"]]
+    from rlcf_amd.engine import Engine
+    ssd = synth.make_state_dict(geo, meta["student_seed"], device=dev)
+    rsd = synth.make_state_dict(geo, meta["reward_seed"], device=dev)
+    eng = Engine(geo, geo, meta["n_views"], meta["n_cls"])
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(geo, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, meta["n_ctx"]), device=dev)].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, mode)
+    rc = eng.reward_class_features().cpu()
+    torch.testing.assert_close(rc[: g["reward_class_features"].shape[0]], g["reward_class_features"], atol=2e-5, rtol=1e-4)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], geo.image_resolution, device=dev)
+    o = eng.tta_sample(views, _cfg_from_meta(meta, sparse))
+    torch.cuda.synchronize()
+    _check_against(o, g, meta)
+    assert int(o["final_logits"].argmax()) == int(g["final_logits"].argmax())
+    torch.testing.assert_close(o["reward_image_features"].cpu(), g["reward_image_features"], atol=2e-5, rtol=1e-4)
+    eng.close()
+
+
+def test_modules_fixture(L, dev):
+    """encode_image of the reference CLIP class at ViT-B/16 and ViT-L/14 geometry (modules.npz)."""
+    g, _ = load_golden("modules")
+    from rlcf_amd.engine import Engine
+    for arch, tag in (("ViT-B/16", "b16"), ("ViT-L/14", "l14")):
+        geo = synth.GEOMETRIES[arch]
+        sd = synth.make_state_dict(geo, 11, device=dev)
+        eng = Engine(geo, None, 2, 8)
+        eng.load_state_dict(L.STUDENT, sd)
+        eng.finalize()
+        views = synth.make_views(1000, 2, geo.image_resolution, device=dev)
+        f = eng.encode_image(L.STUDENT, views).cpu()
+        ref = g[f"{tag}_image"]
+        torch.testing.assert_close(f, ref / ref.norm(dim=-1, keepdim=True), atol=2e-5, rtol=1e-4)
+        eng.close()
