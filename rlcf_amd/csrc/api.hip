@@ -22,9 +22,20 @@ int rlcf_version(void) { return 1; }
 int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
                  const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
                  int precision, rlcf_stream stream) {
-    RLCF_ARG_CHECK(A && W && C && precision == RLCF_PREC_F32);
+    RLCF_ARG_CHECK(A && W && C && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3));
     RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_QUICKGELU_BWD);
     RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
+    if (precision == RLCF_PREC_F16X3) {          // op-level convenience: split both operands into library scratch
+        static DevBuf ah, al, wh, wl;
+        RLCF_ARG_CHECK(lda == K && ldw == K);
+        int rc;
+        if ((rc = ah.ensure((size_t)M * K * 2)) || (rc = al.ensure((size_t)M * K * 2)) || (rc = wh.ensure((size_t)N * K * 2)) ||
+            (rc = wl.ensure((size_t)N * K * 2))) return rc;
+        if ((rc = launch_split_f16x2(A, ah.p, al.p, (int64_t)M * K, (hipStream_t)stream))) return rc;
+        if ((rc = launch_split_f16x2(W, wh.p, wl.p, (int64_t)N * K, (hipStream_t)stream))) return rc;
+        return launch_gemm_f16x3(ah.p, al.p, K, wh.p, wl.p, K, bias, residual, ldr, aux, ldaux, C, ldc, nullptr, nullptr, 0, M, N, K,
+                                 alpha, epilogue, (hipStream_t)stream);
+    }
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.out_bf16 = 0;
@@ -79,7 +90,10 @@ rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cf
         rlcf_set_error("rlcf_engine_create: bad geometry / sizes");
         return nullptr;
     }
-    if (precision != RLCF_PREC_F32) { rlcf_set_error("rlcf_engine_create: precision %d not built", precision); return nullptr; }
+    if (precision != RLCF_PREC_F32 && precision != RLCF_PREC_F16X3) {
+        rlcf_set_error("rlcf_engine_create: precision %d not built", precision);
+        return nullptr;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rlcf_set_error("no HIP device"); return nullptr; }
     rlcf_engine* e = new (std::nothrow) rlcf_engine();
@@ -94,7 +108,7 @@ rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cf
         const rlcf_clip_cfg& c = e->model[w].cfg;
         const int g = c.image_resolution / c.vision_patch_size, tok = g * g + 1;
         Tmax = std::max(Tmax, max_views * tok); Wmax = std::max(Wmax, c.vision_width); Pmax = std::max(Pmax, max_views * g * g);
-        Kpmax = std::max(Kpmax, (3 * c.vision_patch_size * c.vision_patch_size + 15) / 16 * 16); Dmax = std::max(Dmax, c.embed_dim);
+        Kpmax = std::max(Kpmax, (3 * c.vision_patch_size * c.vision_patch_size + 63) / 64 * 64); Dmax = std::max(Dmax, c.embed_dim);
         for (int i = 0; i < max_views; ++i) seqs[(size_t)w * max_views + i] = rlcf_seq{i * tok, tok, 0, 0};
     }
     bool ok = true;
@@ -108,6 +122,10 @@ rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cf
     ok = ok && e->cls_rows.ensure((size_t)max_views * Wmax * sizeof(float)) == 0 && e->cls_ln.ensure((size_t)max_views * Wmax * sizeof(float)) == 0;
     ok = ok && e->feat_raw.ensure((size_t)max_views * Dmax * sizeof(float)) == 0;
     ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0;
+    if (precision == RLCF_PREC_F16X3) {
+        e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
+        ok = ok && e->a_hi.ensure(e->a_split_elems * 2) == 0 && e->a_lo.ensure(e->a_split_elems * 2) == 0;
+    }
     if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { rlcf_engine_destroy(e); return nullptr; }
     return e;
@@ -132,7 +150,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,
-                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5};
+                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo};
     for (DevBuf* d : all) d->release();
     delete e;
 }

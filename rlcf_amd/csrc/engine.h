@@ -2,6 +2,7 @@
 // HIP kernels of one CLIP tower pass / one TTA sample on a stream.  No allocation per sample.
 #pragma once
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -58,6 +59,7 @@ struct ClipModel {
     const float *tprojT = nullptr;         // [D, Wt]
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
+    std::unordered_map<const float*, std::pair<void*, void*>> split_of;   // f32 weight -> (hi, lo) f16 copies (F16X3 mode)
 };
 
 struct rlcf_engine {
@@ -82,6 +84,8 @@ struct rlcf_engine {
     // TTA step scratch
     DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg, views_sel, topk_idx, clip_score, rewards, loss, dlogits,
         dtxt_dense, final_logits, top5;
+    DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
+    size_t a_split_elems = 0;
     double last_flops = 0.0;
 };
 

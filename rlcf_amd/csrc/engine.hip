@@ -45,10 +45,23 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi; g.out_bf16 = 0;
+    e->last_flops += 2.0 * M * N * K;
+    if (e->precision == RLCF_PREC_F16X3 && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
+        // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
+        const std::pair<void*, void*>* sp = nullptr;
+        for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
+        if (sp && (size_t)M * K <= e->a_split_elems) {
+            TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st));
+            const int slot = prof_begin(st, 2.0 * M * N * K);
+            int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->first, sp->second, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
+                                       nullptr, 0, M, N, K, alpha, epi, st);
+            prof_end(slot, st);
+            return rc;
+        }
+    }
     const int slot = prof_begin(st, 2.0 * M * N * K);
     int rc = launch_gemm_f32(g, st);
     prof_end(slot, st);
-    e->last_flops += 2.0 * M * N * K;
     return rc;
 }
 
@@ -61,6 +74,17 @@ static const float* rawp(ClipModel& m, const std::string& k, size_t numel) {
         return nullptr;
     }
     return it->second.as<float>();
+}
+static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
+    if (e->precision != RLCF_PREC_F16X3 || !w) return RLCF_OK;
+    DevBuf hi, lo;
+    TRY(hi.ensure(numel * 2));
+    TRY(lo.ensure(numel * 2));
+    TRY(launch_split_f16x2(w, hi.p, lo.p, (int64_t)numel, st));
+    m.split_of[w] = {hi.p, lo.p};
+    m.derived.push_back(hi);
+    m.derived.push_back(lo);
+    return RLCF_OK;
 }
 static const float* make_transposed(ClipModel& m, const float* w, int rows, int cols, hipStream_t st) {
     m.derived.emplace_back();
@@ -109,10 +133,11 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     const rlcf_clip_cfg& c = m.cfg;
     for (auto& d : m.derived) d.release();
     m.derived.clear();
-    m.derived.reserve(4 * (c.vision_layers + c.text_layers) + 8);
+    m.derived.reserve(16 * (c.vision_layers + c.text_layers) + 16);
+    m.split_of.clear();
     const int Wv = c.vision_width, Wt = c.text_width, ps = c.vision_patch_size, D = c.embed_dim;
     const int K = 3 * ps * ps;
-    m.Kp = (K + 15) / 16 * 16;
+    m.Kp = (K + 63) / 64 * 64;
     m.tokens = (c.image_resolution / ps) * (c.image_resolution / ps) + 1;
     const float* conv = rawp(m, "visual.conv1.weight", (size_t)Wv * K);
     NEED(conv);
@@ -144,6 +169,17 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     RLCF_HIP_CHECK(hipMemcpyAsync(&lsh, ls, sizeof(float), hipMemcpyDeviceToHost, st));
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     m.logit_scale_exp = expf(lsh);
+    // split-f16 copies of every forward GEMM weight (F16X3 mode)
+    TRY(make_split(e, m, m.conv_w, (size_t)Wv * m.Kp, st));
+    TRY(make_split(e, m, m.vprojT, (size_t)Wv * D, st));
+    TRY(make_split(e, m, m.tprojT, (size_t)Wt * D, st));
+    for (TowerW* t : {&m.vis, &m.txt})
+        for (BlockW& b : t->blk) {
+            const size_t W2 = (size_t)t->width * t->width;
+            TRY(make_split(e, m, b.in_w, 3 * W2, st)); TRY(make_split(e, m, b.out_w, W2, st));
+            TRY(make_split(e, m, b.fc_w, 4 * W2, st)); TRY(make_split(e, m, b.proj_w, 4 * W2, st));
+        }
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
     m.finalized = true;
     return RLCF_OK;
 }
@@ -412,6 +448,10 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
         Tmax = std::max(Tmax, e->lay[1].T); Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim);
     }
     TRY(tower_ensure(e->tt, Tmax, Wmax));
+    if (e->precision == RLCF_PREC_F16X3 && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
+        e->a_split_elems = (size_t)Tmax * Wmax * 4;
+        TRY(e->a_hi.ensure(e->a_split_elems * 2)); TRY(e->a_lo.ensure(e->a_split_elems * 2));
+    }
     const size_t cw = (size_t)C * Wmax * sizeof(float), cd = (size_t)C * Dmax * sizeof(float);
     TRY(e->eot_x.ensure(cw)); TRY(e->eot_ln.ensure(cw)); TRY(e->u.ensure(cd)); TRY(e->inv_norm.ensure(C * sizeof(float)));
     TRY(e->txt.ensure(cd)); TRY(e->dtxt_dense.ensure(cd));

@@ -119,13 +119,62 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
         }
 }
 
+// Small-M variant (sparse backward, reward views): one 32x32 output tile per 4-wave block, the
+// waves split K between them (64-wide chunks, operands straight from global memory into the
+// MFMA registers: lane (row, half) owns 32 consecutive k of its row) and the four partial tiles
+// are summed through LDS in a fixed order (deterministic).  Latency of a K=2048 GEMM: ~7 us
+// instead of ~110 us for the 64x64-per-wave tiling, and M=239 fills 128+ CUs instead of 32.
+__global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
+    __shared__ float part[4][32 * 33];
+    const int tiles_n = (g.N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
+    const float* __restrict__ ap = (const float*)g.A + (size_t)min(m0 + l32, g.M - 1) * g.lda + h * 32;
+    const float* __restrict__ wp = (const float*)g.W + (size_t)min(n0 + l32, g.N - 1) * g.ldw + h * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = g.K / 64;
+    for (int c = wave; c < nchunk; c += 4) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = *(const float4*)(ap + c * 64 + j * 4); b[j] = *(const float4*)(wp + c * 64 + j * 4); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][mfma32_row(r, h) * 33 + l32] = acc[r];
+    __syncthreads();
+    float* __restrict__ C = (float*)g.C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = t + e * 256, rr = idx >> 5, cc = idx & 31;
+        const int row = m0 + rr, col = n0 + cc;
+        if (row >= g.M || col >= g.N) continue;
+        float v = ((part[0][rr * 33 + cc] + part[1][rr * 33 + cc]) + part[2][rr * 33 + cc]) + part[3][rr * 33 + cc];
+        v = g.alpha * v + (g.bias ? g.bias[col] : 0.f);
+        if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
+        else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
+        if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+        C[(size_t)row * g.ldc + col] = v;
+    }
+}
+
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
     RLCF_ARG_CHECK(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 16 == 0);
     RLCF_ARG_CHECK(g.lda % 4 == 0 && g.ldw % 4 == 0);
     RLCF_ARG_CHECK(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0);
     RLCF_ARG_CHECK(!g.out_bf16);
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (big >= 192) {
+    if (g.M <= 512 && g.K % 64 == 0) {
+        const long nb = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+        gemm_nt_f32_splitk_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(g);
+    } else if (big >= 192) {
         gemm_nt_f32_kernel<128, 128><<<dim3((unsigned)big), dim3(256), 0, st>>>(g);
     } else {
         const long small = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);

@@ -50,3 +50,7 @@ int launch_build_sparse_layout(const int32_t* cls, int n_e, const int32_t* class
                                int32_t* row_src, hipStream_t st);
 int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* img, int n_e, int K, int C, int D, float scale,
                        float* dtxt, hipStream_t st);
+int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
+                      const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st);
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
