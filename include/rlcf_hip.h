@@ -66,6 +66,14 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
                  float* C, int ldc, int M, int N, int K, float alpha, int epilogue, int precision,
                  rlcf_stream stream);
 
+/* Split-f16 operand pairs (RLCF_PREC_F16X3): x = hi + lo*2^-11 with hi = f16(x), lo = f16((x-hi)*2^11);
+ * n % 8 == 0.  rlcf_gemm_f16x3 is rlcf_gemm_nt on pre-split operands (3 f16 MFMAs per product,
+ * f32 accumulate); output f32 (C) and/or a split pair (Chi, Clo).  K % 32 == 0. */
+int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream stream);
+int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
+                    const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo,
+                    int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream);
+
 /* Row LayerNorm, fp32, eps 1e-5, biased variance (TPT/clip/model.py:157-163). */
 int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        int rows, int width, rlcf_stream stream);

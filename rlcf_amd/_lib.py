@@ -52,6 +52,8 @@ SIGNATURES = {
     "rlcf_last_error": (C.c_char_p, []),
     "rlcf_version": (I, []),
     "rlcf_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, P, I, I, I, I, F, I, I, P]),
+    "rlcf_split_f16x2": (I, [P, P, P, I64, P]),
+    "rlcf_gemm_f16x3": (I, [P, P, I, P, P, I, P, P, I, P, I, P, I, P, P, I, I, I, I, F, I, P]),
     "rlcf_layernorm_fwd": (I, [P, P, P, P, I, I, P]),
     "rlcf_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),

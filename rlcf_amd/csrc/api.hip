@@ -41,6 +41,17 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.out_bf16 = 0;
     return launch_gemm_f32(g, (hipStream_t)stream);
 }
+int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream stream) {
+    RLCF_ARG_CHECK(x && hi && lo);
+    return launch_split_f16x2(x, hi, lo, n, (hipStream_t)stream);
+}
+int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
+                    const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
+                    int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {
+    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_QUICKGELU_BWD && (epilogue != RLCF_EPI_QUICKGELU_BWD || aux));
+    return launch_gemm_f16x3(Ahi, Alo, lda, Whi, Wlo, ldw, bias, residual, ldr, aux, ldaux, C, ldc, Chi, Clo, ldch, M, N, K, alpha,
+                             epilogue, (hipStream_t)stream);
+}
 int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, rlcf_stream stream) {
     RLCF_ARG_CHECK(x && gamma && beta && y);
     return launch_layernorm_fwd(x, gamma, beta, y, nullptr, rows, width, (hipStream_t)stream);

@@ -58,40 +58,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
 
-    // staging: each operand tile = 128 rows x 64 B = 512 16-B chunks, 2 per thread
-    const _Float16* src[4][2];
-    int dst[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = t + i * 256, row = idx >> 2, c = idx & 3;
-        const size_t ra = (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
-        const size_t rw = (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
-        src[0][i] = g.Ahi + ra; src[1][i] = g.Alo + ra; src[2][i] = g.Whi + rw; src[3][i] = g.Wlo + rw;
-        dst[i] = row * X3_LD + c * 8;
+    // staging: each operand tile = 128 rows x 64 B = 512 16-B chunks, 2 per thread (rows r0 and r0+64)
+    const int r0 = t >> 2, c8 = (t & 3) * 8;
+    const size_t ra0 = (size_t)min(m0 + r0, g.M - 1) * g.lda + c8, ra1 = (size_t)min(m0 + r0 + 64, g.M - 1) * g.lda + c8;
+    const size_t rw0 = (size_t)min(n0 + r0, g.N - 1) * g.ldw + c8, rw1 = (size_t)min(n0 + r0 + 64, g.N - 1) * g.ldw + c8;
+    const _Float16 *pah0 = g.Ahi + ra0, *pah1 = g.Ahi + ra1, *pal0 = g.Alo + ra0, *pal1 = g.Alo + ra1;
+    const _Float16 *pwh0 = g.Whi + rw0, *pwh1 = g.Whi + rw1, *pwl0 = g.Wlo + rw0, *pwl1 = g.Wlo + rw1;
+    const int d0 = r0 * X3_LD + c8, d1 = (r0 + 64) * X3_LD + c8;
+    uint4 sah0, sah1, sal0, sal1, swh0, swh1, swl0, swl1;
+#define X3_GLOAD(k0)                                                                              \
+    sah0 = *(const uint4*)(pah0 + (k0)); sah1 = *(const uint4*)(pah1 + (k0));                     \
+    sal0 = *(const uint4*)(pal0 + (k0)); sal1 = *(const uint4*)(pal1 + (k0));                     \
+    swh0 = *(const uint4*)(pwh0 + (k0)); swh1 = *(const uint4*)(pwh1 + (k0));                     \
+    swl0 = *(const uint4*)(pwl0 + (k0)); swl1 = *(const uint4*)(pwl1 + (k0));
+#define X3_LSTORE(buf)                                                                            \
+    {                                                                                             \
+        _Float16* b_ = lds + (buf) * 4 * X3_TILE;                                                 \
+        *(uint4*)(b_ + 0 * X3_TILE + d0) = sah0; *(uint4*)(b_ + 0 * X3_TILE + d1) = sah1;         \
+        *(uint4*)(b_ + 1 * X3_TILE + d0) = sal0; *(uint4*)(b_ + 1 * X3_TILE + d1) = sal1;         \
+        *(uint4*)(b_ + 2 * X3_TILE + d0) = swh0; *(uint4*)(b_ + 2 * X3_TILE + d1) = swh1;         \
+        *(uint4*)(b_ + 3 * X3_TILE + d0) = swl0; *(uint4*)(b_ + 3 * X3_TILE + d1) = swl1;         \
     }
-    uint4 stage[4][2];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) stage[a][i] = *(const uint4*)(src[a][i] + k0);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) *(uint4*)(lds + (buf * 4 + a) * X3_TILE + dst[i]) = stage[a][i];
-    };
 
     const int nk = g.K / X3_BK;
-    gload(0);
-    lstore(0);
+    X3_GLOAD(0)
+    X3_LSTORE(0)
     __syncthreads();
     const int arow = (wm * 64 + l32) * X3_LD + h * 8;
     const int brow = (wn * 64 + l32) * X3_LD + h * 8;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * X3_BK);
+        if (kt + 1 < nk) { X3_GLOAD((kt + 1) * X3_BK) }
         const _Float16* base = lds + cur * 4 * X3_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                     cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+        if (kt + 1 < nk) X3_LSTORE(cur ^ 1)
         __syncthreads();
     }
 
