@@ -151,6 +151,8 @@ typedef struct {                 /* flags read on the path, TPT/params.py:13-98 
     int flags;                   /* RLCF_F_* */
     float clipscore_weight, min_entropy_w;
     int sparse_backward;         /* 1: back-propagate only the n_sel*K touched classes when exact */
+    int skip_final;              /* 1: tuning steps only (test_time_tuning); the caller runs the final inference */
+    const float* ctx_in;         /* DEVICE [n_ctx,W] starting prompt, NULL = ctx_init_state (model.reset()) */
 } rlcf_tta_args;
 
 typedef struct {                 /* every pointer optional (NULL = not wanted); DEVICE */

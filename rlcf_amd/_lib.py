@@ -34,7 +34,8 @@ class TTAArgs(C.Structure):
     _fields_ = [("selection_p", C.c_float), ("tta_steps", C.c_int), ("sample_k", C.c_int),
                 ("lr", C.c_float), ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("flags", C.c_int), ("clipscore_weight", C.c_float),
-                ("min_entropy_w", C.c_float), ("sparse_backward", C.c_int)]
+                ("min_entropy_w", C.c_float), ("sparse_backward", C.c_int), ("skip_final", C.c_int),
+                ("ctx_in", C.c_void_p)]
 
 
 TTA_OUT_FIELDS = ("logits", "entropy", "selected_idx", "topk_idx", "clip_score", "rewards", "loss", "dlogits",

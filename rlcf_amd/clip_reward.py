@@ -1,0 +1,115 @@
+"""Host-side mirror of the reference reward surface (TPT/clip_reward.py): `get_reward_model` (:29-40),
+`BaseRewards` (:43-73), `CLIPRewards` (:76-177).  The frozen reward CLIP lives in the shared HIP
+engine (rlcf_amd.runtime); this class carries the flags the tuning loop reads and the cached features."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import clip_store, runtime
+
+
+def get_reward_model(device, args):
+    """TPT/clip_reward.py:29-40."""
+    if getattr(args, "multiple_reward_models", 0):
+        raise NotImplementedError("CLIPRewardsMultiple (reward ensemble, clip_reward.py:180-307) is a 'next' row "
+                                  "(SURVEY.md §8f-3): not built yet")
+    return CLIPRewards(device, arch=args.reward_arch, classification=True, amplify_rewards=args.reward_amplify,
+                       sample_k=args.sample_k, reward_process=args.reward_process, process_batch=args.process_batch)
+
+
+class BaseRewards(nn.Module):
+    """TPT/clip_reward.py:43-73."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+    @torch.no_grad()
+    def extract_image_features(self, images):
+        pass
+
+    @torch.no_grad()
+    def extract_text_features(self, captions=None, tokenized_cap=None):
+        pass
+
+    @torch.no_grad()
+    def set_class_features(self, classnames=None, tokenized_classes=None):
+        self.class_features = self.extract_text_features(captions=classnames, tokenized_cap=tokenized_classes)
+
+    @torch.no_grad()
+    def set_image_features(self, images):
+        self.image_features = self.extract_image_features(images)
+
+    @torch.no_grad()
+    def confidence_gap(self, predictions):
+        value, index = torch.topk(predictions, 2, dim=-1)
+        gap = value[:, 0] - value[:, 1]
+        return gap - torch.mean(gap)
+
+
+class CLIPRewards(BaseRewards):
+    """TPT/clip_reward.py:76-177."""
+
+    def __init__(self, device, arch="ViT-B/16", clipscore_weight=2.5, classification=True, amplify_rewards=False,
+                 sample_k=5, reward_process=True, process_batch=False, default_resolutions=224) -> None:
+        super().__init__()
+        self.default_resolutions = default_resolutions
+        self.clip_model, self.embed_dim, self.preprocess = clip_store.load(arch, device=device)
+        runtime.SESSION.set_reward(self.clip_model)
+        self.resolutions = self.clip_model.geometry.image_resolution
+        if self.resolutions != default_resolutions:
+            raise NotImplementedError("reward models that need the bicubic resolution change (clip_reward.py:133-134) "
+                                      "are a 'next' row (SURVEY.md §8f-3)")
+        self.clipscore_weight, self.device, self.classification = clipscore_weight, device, classification
+        self.class_features = None
+        self.image_features = None
+        self.amplify_rewards, self.sample_k = amplify_rewards, sample_k
+        self.reward_process, self.process_batch = reward_process, process_batch
+
+    @torch.no_grad()
+    def extract_image_features(self, images):
+        """clip_reward.py:130-137: encode_image, float, L2 normalise."""
+        return runtime.SESSION.engine(images.shape[0]).encode_image(L.REWARD, images)
+
+    @torch.no_grad()
+    def extract_text_features(self, captions=None, tokenized_cap=None):
+        """clip_reward.py:139-150.  The class bank of the reward model is the tokenised bank of the student
+        (tpt_cls_rl.py:183); the engine caches its features in rlcf_engine_set_class_bank."""
+        if tokenized_cap is None:
+            tokenized_cap = clip_store.tokenize(captions)
+        bank = runtime.SESSION.tokens
+        if bank is None or bank.shape != tokenized_cap.shape or not torch.equal(bank, tokenized_cap.detach().cpu()):
+            raise NotImplementedError("reward class bank must be the student's tokenized_prompts (tpt_cls_rl.py:183)")
+        return runtime.SESSION.engine().reward_class_features()
+
+    @torch.no_grad()
+    def CLIPScore(self, class_index, images=None, image_features=None, captions=None, tokenized_cap=None, text_features=None,
+                  pairwise=True):
+        """clip_reward.py:111-128 (classification branch).  Stand-alone convenience on device tensors; the
+        tuning loop gets the same numbers from the fused rlcf_reward_loss kernel."""
+        text_features = self.class_features[class_index.long()]
+        image_features = self.image_features if image_features is None else image_features
+        if pairwise:
+            similarity = self.clipscore_weight * text_features @ image_features.t()
+        else:
+            image_features = torch.repeat_interleave(image_features, self.sample_k, dim=0)
+            similarity = self.clipscore_weight * torch.sum(text_features * image_features, dim=-1)
+        return torch.maximum(similarity, torch.zeros_like(similarity)).squeeze()
+
+    @torch.no_grad()
+    def rewards_post_process(self, clip_score):
+        """clip_reward.py:152-165."""
+        if clip_score.shape[-1] > 1 and self.reward_process:
+            mean = torch.mean(clip_score, dim=-1, keepdim=True)
+            if self.amplify_rewards:
+                std = torch.std(clip_score, dim=-1, keepdim=True) + 1e-5
+            else:
+                std = 1.0
+            clip_score = (clip_score - mean) / std
+        return clip_score.flatten()
+
+    @torch.no_grad()
+    def calulate_similarity(self):
+        """clip_reward.py:167-177."""
+        return self.clipscore_weight * self.image_features @ self.class_features.t()

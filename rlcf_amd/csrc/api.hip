@@ -157,7 +157,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
     release_layout(e->lay[0]); release_layout(e->lay[1]);
     DevBuf* all[] = {&e->patches, &e->patch_out, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
-                     &e->inv_norm, &e->txt, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->reward_cls, &e->sp_seqs,
+                     &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->reward_cls, &e->sp_seqs,
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,

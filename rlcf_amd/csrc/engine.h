@@ -72,7 +72,7 @@ struct rlcf_engine {
     int text_mode = RLCF_TEXT_SHARED, n_ctx = 0, C = 0;
     TextLayout lay[2];               // [student], [reward]
     Tower tt;                        // text workspace (max of both layouts)
-    DevBuf eot_x, eot_ln, u, inv_norm, txt;          // [C,*]
+    DevBuf eot_x, eot_ln, u, inv_norm, txt, txt0;    // [C,*]; txt0 = text features at ctx_init
     DevBuf ctx_init, ctx, adam_m, adam_v, ctx_grad;  // [n_ctx, Wt]
     DevBuf reward_cls;               // [C, Dr]
     // sparse backward layout (n_e entries)

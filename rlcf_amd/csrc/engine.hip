@@ -477,6 +477,14 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
         io.txt = e->reward_cls.as<float>();
         TRY(text_forward(e, r, e->lay[1], e->tt, nullptr, io, false, st));
     }
+    // Text features of the pristine prompt: every test sample starts from ctx_init (model.reset(),
+    // tpt_cls_rl.py:251-253), so the first-step text forward is sample-independent -> computed once here.
+    TRY(e->txt0.ensure(cd));
+    {
+        TextPassIO io0 = full_io(e, e->lay[0]);
+        io0.txt = e->txt0.as<float>();
+        TRY(text_forward(e, s, e->lay[0], e->tt, e->ctx_init.as<float>(), io0, false, st));
+    }
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     e->sp_max_e = 0;    // sparse layout is (re)built lazily for the requested n_sel*K
     return RLCF_OK;
@@ -591,17 +599,21 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     e->last_flops = 0.0;
     float* ctx = e->ctx.as<float>();
     // model.reset() + optimizer.load_state_dict(optim_state): custom_clip.py:161-164, tpt_cls_rl.py:251-255
-    RLCF_HIP_CHECK(hipMemcpyAsync(ctx, e->ctx_init.p, cb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(ctx, a->ctx_in ? (const void*)a->ctx_in : e->ctx_init.p, cb, hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->adam_m.p, 0, cb, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->adam_v.p, 0, cb, st));
     // student image features of all N views: computed once (the image tower is frozen, custom_clip.py:325-327)
     TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
     TextPassIO io = full_io(e, e->lay[0]);
     for (int j = 0; j < a->tta_steps; ++j) {
-        TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, !sparse_ok, st));
+        // step 0 runs on ctx == ctx_init: its text features are the cached txt0 (the dense-backward
+        // path still needs this pass for its saved activations)
+        const bool cached = (j == 0 && sparse_ok && !a->ctx_in);
+        if (!cached) TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, !sparse_ok, st));
+        const float* txt_j = cached ? e->txt0.as<float>() : e->txt.as<float>();
         const float* rows_logits;
         if (j == 0) {   // tpt_cls_rl.py:57-59
-            TRY(engine_logits(e, e->img_feat.as<float>(), N, e->txt.as<float>(), C, e->logits.as<float>(), st));
+            TRY(engine_logits(e, e->img_feat.as<float>(), N, txt_j, C, e->logits.as<float>(), st));
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
@@ -613,7 +625,7 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
             COPY_OUT(out->reward_image_features, e->rimg.p, (size_t)n_sel * Dr * sizeof(float));
         } else {        // tpt_cls_rl.py:55 — selected views only; their image features are unchanged
-            TRY(engine_logits(e, e->sel_feat.as<float>(), n_sel, e->txt.as<float>(), C, e->sel_logits.as<float>(), st));
+            TRY(engine_logits(e, e->sel_feat.as<float>(), n_sel, txt_j, C, e->sel_logits.as<float>(), st));
             rows_logits = e->sel_logits.as<float>();
         }
         TRY(launch_reward_loss(rows_logits, C, nullptr, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
@@ -640,10 +652,11 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     }
     // final inference on the clean view (views[0]) with the adapted prompt, tpt_cls_rl.py:260-262;
     // its image feature is row 0 of img_feat (frozen image tower: identical to re-encoding it).
+    COPY_OUT(out->ctx_after, ctx, cb);
+    if (a->skip_final) return RLCF_OK;
     TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, false, st));
     TRY(engine_logits(e, e->img_feat.as<float>(), 1, e->txt.as<float>(), C, e->final_logits.as<float>(), st));
     TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
-    COPY_OUT(out->ctx_after, ctx, cb);
     COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
     COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
     return RLCF_OK;

@@ -15,6 +15,7 @@
 // that every ds_read_b128 operand fetch is bank-conflict free (16-lane groups hit 16 distinct
 // 16-B slots); one barrier per K tile.
 #include "kernels.h"
+#include <cstdlib>
 
 struct GemmX3Args {
     const _Float16 *Ahi, *Alo; int lda;
@@ -138,6 +139,125 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// v2: 256x128 block tile, 8 waves (4x2) of 64x64, BK = 32, operands DMA'd straight into LDS
+// (global_load_lds_dwordx4, no staging registers, no ds_write) through a 3-stage ring with a
+// counted s_waitcnt vmcnt so that two K tiles stay in flight across the single barrier per tile.
+// glds writes LDS lane-linearly (wave-uniform base + lane*16 B), so the bank swizzle is applied
+// to the per-lane SOURCE address and undone on the ds_read side: 16-B chunk c of row r lives at
+// chunk slot c ^ ((r>>2)&3); a 16-lane ds_read_b128 group then touches 16 distinct slots.
+#define V2_BM 256
+#define V2_BN 128
+#define V2_STAGE 49152                  // bytes: Ahi 16K | Alo 16K | Whi 8K | Wlo 8K
+#define V2_ALO 16384
+#define V2_WHI 32768
+#define V2_WLO 40960
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [3][V2_STAGE]
+    const int tiles_n = (g.N + V2_BN - 1) / V2_BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / tiles_n) * V2_BM, n0 = (bid % tiles_n) * V2_BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+
+    // DMA sources: A tile = 1024 chunks (2 wave-instructions per wave per array), W tile = 512 (1 each)
+    const int qa0 = (wave * 2) * 64 + lane, qa1 = qa0 + 64, qw = wave * 64 + lane;
+    const int ra0 = qa0 >> 2, ra1 = qa1 >> 2, rw = qw >> 2;
+    const size_t sa0 = (size_t)min(m0 + ra0, g.M - 1) * g.lda + (((qa0 & 3) ^ ((ra0 >> 2) & 3)) * 8);
+    const size_t sa1 = (size_t)min(m0 + ra1, g.M - 1) * g.lda + (((qa1 & 3) ^ ((ra1 >> 2) & 3)) * 8);
+    const size_t sw = (size_t)min(n0 + rw, g.N - 1) * g.ldw + (((qw & 3) ^ ((rw >> 2) & 3)) * 8);
+    const int da0 = (wave * 2) * 1024, da1 = da0 + 1024, dw = wave * 1024;     // wave-uniform LDS byte offsets
+#define V2_ISSUE(k0, stage)                                                                                              \
+    {                                                                                                                    \
+        char* sb_ = smem + (stage) * V2_STAGE;                                                                           \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa0 + (k0)), (lptr_t)(sb_ + da0), 16, 0, 0);                  \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa1 + (k0)), (lptr_t)(sb_ + da1), 16, 0, 0);                  \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa0 + (k0)), (lptr_t)(sb_ + V2_ALO + da0), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa1 + (k0)), (lptr_t)(sb_ + V2_ALO + da1), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw + (k0)), (lptr_t)(sb_ + V2_WHI + dw), 16, 0, 0);           \
+        __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw + (k0)), (lptr_t)(sb_ + V2_WLO + dw), 16, 0, 0);           \
+    }
+
+    const int nk = g.K / X3_BK;
+    V2_ISSUE(0, 0)
+    if (nk > 1) V2_ISSUE(X3_BK, 1)
+    const int swz = (l32 >> 2) & 3;
+    const int aoff = (wm * 64 + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) {
+            const int nxt = cur >= 1 ? cur - 1 : 2;                           // (cur + 2) % 3
+            V2_ISSUE((kt + 2) * X3_BK, nxt)
+        }
+        const char* sb = smem + cur * V2_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = ((ks * 2 + h) ^ swz) * 16;
+            h16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const h16x8*)(sb + aoff + i * 2048 + co);
+                al[i] = *(const h16x8*)(sb + V2_ALO + aoff + i * 2048 + co);
+                bh[i] = *(const h16x8*)(sb + V2_WHI + boff + i * 2048 + co);
+                bl[i] = *(const h16x8*)(sb + V2_WLO + boff + i * 2048 + co);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
+                }
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, h);
+                if (row >= g.M) continue;
+                float v = g.alpha * (acc[i][j][r] + cor[i][j][r] * 0.00048828125f) + bv;
+                if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
+                else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
+                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                if (g.C) g.C[(size_t)row * g.ldc + col] = v;
+                if (g.Chi) {
+                    const _Float16 hi = (_Float16)v;
+                    g.Chi[(size_t)row * g.ldch + col] = hi;
+                    g.Clo[(size_t)row * g.ldch + col] = (_Float16)((v - (float)hi) * 2048.0f);
+                }
+            }
+        }
+}
+
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st) {
@@ -152,6 +272,20 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     if (!attr) {
         RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr = true;
+    }
+    const int blocks2 = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
+    static int force = -1;                                   // RLCF_X3_KERNEL=1|2 pins a variant (benchmarks)
+    if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
+    if (force == 2 || (force == 0 && blocks2 >= 256)) {
+        const size_t sh2 = (size_t)3 * V2_STAGE;
+        static bool attr2 = false;
+        if (!attr2) {
+            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
+            attr2 = true;
+        }
+        gemm_nt_f16x3_v2_kernel<<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
     }
     const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
     gemm_nt_f16x3_kernel<<<dim3(blocks), dim3(256), sh, st>>>(g);

@@ -1,0 +1,144 @@
+"""Host-side mirror of the reference prompt-tuning model surface (TPT/clip/custom_clip.py):
+`PromptLearner` (:76-289), `TextEncoder` (:53-73), `ClipTestTimeTuning` (:292-344), `get_coop`
+(:347-361).  Same names, argument meaning and error behaviour; every FLOP of the towers runs in
+librlcf_hip.so (rlcf_amd.engine) — these classes hold parameters and bookkeeping only."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import clip_store, runtime
+from . import _lib as L
+
+
+class PromptLearner(nn.Module):
+    """TPT/clip/custom_clip.py:76-289.  Holds the learnable context `ctx` [n_ctx, W], its pristine copy
+    `ctx_init_state`, and `tokenized_prompts` int64 [C, 77] of "<prefix> <class>."."""
+
+    def __init__(self, clip_model, classnames, batch_size=None, n_ctx=16, ctx_init=None, ctx_position="end",
+                 learned_cls=False):
+        super().__init__()
+        if batch_size is not None or learned_cls or ctx_position != "end":
+            raise NotImplementedError("batch-wise ctx, learned_cls and ctx_position != 'end' are not on the RLCF path "
+                                      "(never set by TPT/scripts/rlcf-*.sh)")
+        self.clip_model = clip_model
+        self.learned_cls, self.batch_size, self.class_token_position = learned_cls, batch_size, ctx_position
+        sd = clip_model.state_dict
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.ctx_dim = sd["ln_final.weight"].shape[0]
+        self.dtype = torch.float32
+        if ctx_init:                                   # custom_clip.py:90-107
+            ctx_init = ctx_init.replace("_", " ")
+            if "[CLS]" in ctx_init:
+                raise NotImplementedError("'[CLS]' (middle class-token position) is not on the RLCF path")
+            self.split_idx = None
+            n_ctx = len(ctx_init.split(" "))
+            prompt = clip_store.tokenize(ctx_init)
+            ctx_vectors = sd["token_embedding.weight"][prompt[0, 1:1 + n_ctx].to(sd["token_embedding.weight"].device)].float()
+            prompt_prefix = ctx_init
+        else:                                          # custom_clip.py:108-112
+            ctx_vectors = torch.empty(n_ctx, self.ctx_dim)
+            nn.init.normal_(ctx_vectors, std=0.02)
+            prompt_prefix = " ".join(["X"] * n_ctx)
+        self.prompt_prefix, self.n_ctx, self.ctx_init = prompt_prefix, n_ctx, ctx_init
+        ctx_vectors = ctx_vectors.detach().to(self.device).clone()
+        self.ctx_init_state = ctx_vectors.detach().clone()
+        self.ctx = nn.Parameter(ctx_vectors)
+        self._set_classnames(classnames)
+
+    def _set_classnames(self, classnames: List[str]) -> None:
+        classnames = [name.replace("_", " ") for name in classnames]
+        prompts = [self.prompt_prefix + " " + name + "." for name in classnames]
+        self.tokenized_prompts = clip_store.tokenize(prompts).to(self.device)      # custom_clip.py:154
+        self.n_cls, self.classnames = len(classnames), classnames
+        runtime.SESSION.set_bank(self.tokenized_prompts, self.n_ctx, self.ctx_init_state)
+
+    def reset(self):                                   # custom_clip.py:161-167
+        self.ctx.data.copy_(self.ctx_init_state)
+
+    def reset_classnames(self, classnames, arch):      # custom_clip.py:169-196 (without re-loading CLIP from disk)
+        self._set_classnames(classnames)
+
+    def forward(self, init=None):
+        """Materialised prompts [C, 77, W] = [SOS | ctx | class tokens . EOS pad] (custom_clip.py:198-238).
+        The HIP text tower never needs this tensor; provided for API completeness."""
+        ctx = init if init is not None else self.ctx
+        emb = self.clip_model.state_dict["token_embedding.weight"].to(ctx.device)[self.tokenized_prompts]
+        return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(self.n_cls, -1, -1), emb[:, 1 + self.n_ctx:]], dim=1)
+
+
+class TextEncoder(nn.Module):
+    """TPT/clip/custom_clip.py:53-73 — kept as a named sub-module; its arithmetic is rlcf_text_features."""
+
+    def __init__(self, clip_model):
+        super().__init__()
+        self.clip_model = clip_model
+
+    def forward(self, prompts, tokenized_prompts):
+        raise NotImplementedError("call ClipTestTimeTuning.get_text_features(): the HIP text tower consumes ctx directly")
+
+
+class _LogitsFn(torch.autograd.Function):
+    """logits = exp(logit_scale) * norm(img) @ norm(txt(ctx))^T; image tower under no_grad
+    (custom_clip.py:325-335).  backward = rlcf_text_backward_dense (what loss.backward() does at tpt_cls_rl.py:77)."""
+
+    @staticmethod
+    def forward(fn_ctx, ctx, images, model):
+        eng = runtime.SESSION.engine(images.shape[0])
+        img = eng.encode_image(L.STUDENT, images)
+        txt = eng.text_features(ctx)
+        fn_ctx.save_for_backward(ctx.detach().clone(), img)
+        return eng.logits(img, txt)
+
+    @staticmethod
+    def backward(fn_ctx, dlogits):
+        ctx, img = fn_ctx.saved_tensors
+        eng = runtime.SESSION.engine(img.shape[0])
+        return eng.text_backward_dense(ctx, img, dlogits.contiguous().float()), None, None
+
+
+class ClipTestTimeTuning(nn.Module):
+    """TPT/clip/custom_clip.py:292-344."""
+
+    def __init__(self, device, classnames, batch_size, criterion="cosine", arch="ViT-L/14", n_ctx=16, ctx_init=None,
+                 ctx_position="end", learned_cls=False):
+        super().__init__()
+        clip, _, _ = clip_store.load(arch, device=device)
+        self.clip = clip
+        runtime.SESSION.set_student(clip)
+        self.text_encoder = TextEncoder(clip)
+        self.logit_scale = clip.state_dict["logit_scale"].detach().clone()
+        self.prompt_learner = PromptLearner(clip, classnames, batch_size, n_ctx, ctx_init, ctx_position, learned_cls)
+        self.criterion = criterion
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def reset(self):
+        self.prompt_learner.reset()
+
+    def reset_classnames(self, classnames, arch):
+        self.prompt_learner.reset_classnames(classnames, arch)
+
+    def get_text_features(self):
+        return runtime.SESSION.engine().text_features(self.prompt_learner.ctx)
+
+    def inference(self, image):
+        return _LogitsFn.apply(self.prompt_learner.ctx, image, self)
+
+    def forward(self, input):
+        if isinstance(input, tuple) or input.dim() == 2:
+            # the reference dispatches these to methods it never defines (custom_clip.py:338-342)
+            raise AttributeError("contrast_prompt_tuning / directional_prompt_tuning are undefined in the reference")
+        return self.inference(input)
+
+
+def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, classnames: Optional[List[str]] = None):
+    """TPT/clip/custom_clip.py:347-361.  The reference picks class-name lists from its data package by
+    `test_set`; here the caller passes them (default: placeholders until reset_classnames)."""
+    if classnames is None:
+        classnames = ["c0"]
+    return ClipTestTimeTuning(device, classnames, None, arch=clip_arch, n_ctx=n_ctx, ctx_init=ctx_init, learned_cls=learned_cls)

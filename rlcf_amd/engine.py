@@ -52,10 +52,11 @@ class TTAConfig:
         return ((L.F_REWARD_PROCESS if self.reward_process else 0) | (L.F_AMPLIFY if self.reward_amplify else 0) |
                 (L.F_PROCESS_BATCH if self.process_batch else 0) | (L.F_MIN_ENTROPY if self.min_entropy_reg else 0))
 
-    def c_args(self) -> L.TTAArgs:
+    def c_args(self, skip_final: bool = False, ctx_in: Optional[torch.Tensor] = None) -> L.TTAArgs:
         return L.TTAArgs(self.selection_p, self.tta_steps, self.sample_k, self.lr, self.weight_decay, self.beta1,
                          self.beta2, self.eps, self.flags(), self.clipscore_weight, self.min_entropy_w,
-                         1 if self.sparse_backward else 0)
+                         1 if self.sparse_backward else 0, 1 if skip_final else 0,
+                         ctx_in.data_ptr() if ctx_in is not None else None)
 
 
 class Engine:
@@ -141,7 +142,8 @@ class Engine:
         return out
 
     # ---- the per-sample step -----------------------------------------------------
-    def tta_sample(self, views: torch.Tensor, cfg: TTAConfig, want_intermediates: bool = True) -> Dict[str, torch.Tensor]:
+    def tta_sample(self, views: torch.Tensor, cfg: TTAConfig, want_intermediates: bool = True, skip_final: bool = False,
+                   ctx_in: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
         n_sel = int(N * cfg.selection_p)
@@ -159,7 +161,9 @@ class Engine:
                      ctx_grad=torch.empty(self.n_ctx, Wt, device=dev),
                      reward_image_features=torch.empty(n_sel, Dr, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
-        a = cfg.c_args()
+        if ctx_in is not None:
+            ctx_in = ctx_in.detach().to(dev, torch.float32).contiguous()
+        a = cfg.c_args(skip_final, ctx_in)
         L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
         return o
 

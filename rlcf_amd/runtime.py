@@ -1,0 +1,80 @@
+"""Process-wide binding between the reference-shaped Python objects (ClipTestTimeTuning,
+CLIPRewards) and the one HIP engine that serves them.  The reference keeps the student and the
+reward model as two independent torch modules (TPT/tpt_cls_rl.py:94,124); here both live inside
+one `rlcf_engine` so that the fused per-sample step needs a single C call."""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .engine import Engine
+
+PRECISIONS = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
+TEXT_MODES = {"dense": L.TEXT_DENSE, "packed": L.TEXT_PACKED, "shared": L.TEXT_SHARED}
+
+
+class Session:
+    def __init__(self):
+        self.student = None          # ClipCheckpoint
+        self.reward = None           # ClipCheckpoint
+        self.tokens: Optional[torch.Tensor] = None
+        self.n_ctx = 0
+        self.ctx_init: Optional[torch.Tensor] = None
+        self.max_views = int(os.environ.get("RLCF_MAX_VIEWS", "64"))
+        self.precision = PRECISIONS[os.environ.get("RLCF_PRECISION", "f16x3")]
+        self.text_mode = TEXT_MODES[os.environ.get("RLCF_TEXT_MODE", "shared")]
+        self._engine: Optional[Engine] = None
+        self._key = None
+        self._bank_key = None
+
+    def set_student(self, ckpt):
+        self.student = ckpt
+
+    def set_reward(self, ckpt):
+        self.reward = ckpt
+
+    def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor):
+        self.tokens, self.n_ctx, self.ctx_init = tokens.detach().cpu(), n_ctx, ctx_init.detach().clone()
+
+    def engine(self, n_views: int = 1) -> Engine:
+        if self.student is None:
+            raise L.RlcfError("no student CLIP bound: construct ClipTestTimeTuning / get_coop first")
+        if n_views > self.max_views:
+            self.max_views = n_views
+        n_cls = int(self.tokens.shape[0]) if self.tokens is not None else 1
+        key = (id(self.student), id(self.reward), self.max_views, self.precision)
+        if self._engine is None or key != self._key or n_cls > self._engine.max_classes:
+            if self._engine is not None:
+                self._engine.close()
+            eng = Engine(self.student.geometry, self.reward.geometry if self.reward else None, self.max_views,
+                         max(n_cls, 1), self.precision)
+            eng.load_state_dict(L.STUDENT, self.student.state_dict)
+            if self.reward:
+                eng.load_state_dict(L.REWARD, self.reward.state_dict)
+            eng.finalize()
+            self._engine, self._key, self._bank_key = eng, key, None
+        if self.tokens is not None:
+            bkey = (id(self.tokens), self.n_ctx, self.text_mode, float(self.ctx_init.float().abs().sum()))
+            if bkey != self._bank_key:
+                self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode)
+                self._bank_key = bkey
+        return self._engine
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+        self._key = self._bank_key = None
+
+
+SESSION = Session()
+
+
+def reset_session() -> Session:
+    global SESSION
+    SESSION.close()
+    SESSION = Session()
+    return SESSION

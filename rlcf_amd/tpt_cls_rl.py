@@ -1,0 +1,112 @@
+"""Host-side mirror of the RLCF prompt-tuning entry (TPT/tpt_cls_rl.py): `select_confident_samples`
+(:32-35), `avg_entropy` (:38-44), `test_time_tuning` (:47-79), `test_time_adapt_eval` (:219-279) and
+`accuracy` (TPT/utils/tools.py:84-98).  Same signatures; the arithmetic is one call into the HIP engine."""
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+
+from . import _lib as L
+from . import runtime
+from .engine import TTAConfig
+
+
+def select_confident_samples(logits, top):
+    """TPT/tpt_cls_rl.py:32-35 -> (logits[idx], idx): the int(N*top) lowest-entropy rows, ascending."""
+    logits = logits.contiguous().float()
+    n, c = logits.shape
+    n_sel = int(n * top)
+    ent = torch.empty(n, device=logits.device)
+    idx = torch.empty(max(n_sel, 1), dtype=torch.int32, device=logits.device)
+    L.check(L.lib().rlcf_entropy_select(logits.data_ptr(), n, c, n_sel, ent.data_ptr(), idx.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "entropy_select")
+    idx = idx[:n_sel].long()
+    return logits[idx], idx
+
+
+def avg_entropy(outputs):
+    """TPT/tpt_cls_rl.py:38-44 (stand-alone convenience on device tensors; inside the tuning step the
+    regulariser and its gradient come from the fused rlcf_reward_loss kernel)."""
+    logits = outputs - outputs.logsumexp(dim=-1, keepdim=True)
+    avg_logits = logits.logsumexp(dim=0) - math.log(logits.shape[0])
+    avg_logits = torch.clamp(avg_logits, min=torch.finfo(avg_logits.dtype).min)
+    return -(avg_logits * torch.exp(avg_logits)).sum(dim=-1)
+
+
+def _config(args, optimizer, reward_model) -> TTAConfig:
+    g = optimizer.param_groups[0]
+    b1, b2 = g.get("betas", (0.9, 0.999))
+    return TTAConfig(selection_p=args.selection_p, tta_steps=args.tta_steps, sample_k=reward_model.sample_k, lr=g["lr"],
+                     weight_decay=g.get("weight_decay", 0.0), beta1=b1, beta2=b2, eps=g.get("eps", 1e-8),
+                     reward_process=bool(reward_model.reward_process), process_batch=bool(reward_model.process_batch),
+                     reward_amplify=bool(reward_model.amplify_rewards), clipscore_weight=reward_model.clipscore_weight,
+                     min_entropy_reg=bool(getattr(args, "min_entropy_reg", 0)),
+                     min_entropy_w=float(getattr(args, "min_entropy_w", 0.2)))
+
+
+def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
+    """TPT/tpt_cls_rl.py:47-79.  `optimizer` supplies the AdamW hyper-parameters (its state is reset per
+    sample by the harness, :255, so the fused step starts from step 1); `scaler` is accepted and unused:
+    the HIP path computes in f32-grade precision, there is no loss scaling to apply."""
+    if reward_model is None:
+        raise ValueError("RLCF needs a reward model (get_reward_model)")
+    if args.tta_steps <= 0:
+        return
+    cfg = _config(args, optimizer, reward_model)
+    eng = runtime.SESSION.engine(inputs.shape[0])
+    pl = model.prompt_learner
+    ctx_in = None if torch.equal(pl.ctx.data, pl.ctx_init_state) else pl.ctx.data
+    out = eng.tta_sample(inputs, cfg, want_intermediates=False, skip_final=True, ctx_in=ctx_in)
+    with torch.no_grad():
+        pl.ctx.data.copy_(out["ctx_after"])
+    pl.ctx.grad = None
+    return
+
+
+def accuracy(output, target, topk=(1,)):
+    """TPT/utils/tools.py:84-98."""
+    with torch.no_grad():
+        maxk = max(topk)
+        batch_size = target.size(0)
+        _, pred = output.topk(maxk, 1, True, True)
+        pred = pred.t()
+        correct = pred.eq(target.view(1, -1).expand_as(pred))
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]
+
+
+def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None):
+    """TPT/tpt_cls_rl.py:219-279: per test image: reset -> tune -> clean-view inference -> top-1/top-5."""
+    n, s1, s5 = 0, 0.0, 0.0
+    model.eval()
+    with torch.no_grad():
+        model.reset()
+    end = time.time()
+    for i, (images, target) in enumerate(val_loader):
+        assert args.gpu is not None
+        if isinstance(images, list):
+            images = [im.cuda(args.gpu, non_blocking=True) for im in images]
+            image = images[0]
+        else:
+            if images.dim() > 4:
+                assert images.size(0) == 1
+                images = images.squeeze(0)
+            images = images.cuda(args.gpu, non_blocking=True)
+            image = images
+        target = target.cuda(args.gpu, non_blocking=True)
+        if args.tpt and isinstance(images, list):
+            images = torch.cat(images, dim=0)
+        if args.tta_steps > 0:
+            with torch.no_grad():
+                model.reset()
+        optimizer.load_state_dict(optim_state)
+        test_time_tuning(model, images, optimizer, scaler, args, reward_model=reward_model)
+        with torch.no_grad():
+            output = model(image)
+        acc1, acc5 = accuracy(output, target, topk=(1, 5))
+        n += image.size(0); s1 += float(acc1[0]) * image.size(0); s5 += float(acc5[0]) * image.size(0)
+        if (i + 1) % getattr(args, "print_freq", 200) == 0:
+            print(f"Test: [{i + 1}/{len(val_loader)}] Time {time.time() - end:6.3f} Acc@1 {s1 / n:6.2f} Acc@5 {s5 / n:6.2f}")
+        end = time.time()
+    return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]

@@ -416,3 +416,78 @@ def test_modules_fixture(L, dev, prec):
         ref = ref / ref.norm(dim=-1, keepdim=True)
         torch.testing.assert_close(f, torch.cat([ref, ref, ref, ref]), atol=2e-5, rtol=1e-4)
         eng.close()
+
+
+# ------------------------------------------------------------------------------ reference-shaped Python surface
+def _harness_objects(dev, meta):
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint(meta["student"], sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint(meta["reward"] + "#r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
+                                 min_entropy_reg=meta.get("min_entropy_reg", 0), min_entropy_w=meta.get("min_entropy_w", 0.2),
+                                 reward_arch=meta["reward"] + "#r", multiple_reward_models=0, sample_k=meta["sample_k"],
+                                 reward_amplify=meta.get("reward_amplify", False), reward_process=True,
+                                 process_batch=meta.get("process_batch", False))
+    model = custom_clip.get_coop(meta["student"], "I", dev, meta["n_ctx"], "a_photo_of_a", classnames=bank.classnames)
+    for name, p in model.named_parameters():            # tpt_cls_rl.py:103-105
+        if "prompt_learner" not in name:
+            p.requires_grad_(False)
+    optimizer = torch.optim.AdamW(model.prompt_learner.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    reward_model = clip_reward.get_reward_model(dev, args)
+    model.reset_classnames(bank.classnames, meta["student"])
+    reward_model.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
+    return model, optimizer, optim_state, reward_model, args
+
+
+@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1"])
+def test_reference_harness_runs_on_the_hip_path(L, dev, name):
+    """The reference's main_worker/test_time_adapt_eval call sequence (tpt_cls_rl.py:94-190,219-279) with this
+    package's classes in place of the reference's: same ctx update and final logits as the reference run."""
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden(name)
+    model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution)
+    target = int(g["top5"][0])
+    loader = [([v.unsqueeze(0) for v in views], torch.tensor([target]))]
+    acc = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model)
+    assert acc == [100.0, 100.0]
+    d = (model.prompt_learner.ctx.detach().cpu() - g["ctx_after"]).abs()
+    assert (d > 1e-4).float().mean() < 0.01
+    with torch.no_grad():
+        out = model(views[:1].to(dev))
+    torch.testing.assert_close(out.cpu(), g["final_logits"], atol=1e-3, rtol=0)
+    runtime.reset_session()
+
+
+def test_autograd_route_matches_reference_gradient(L, dev):
+    """model(images) is differentiable w.r.t. ctx exactly like the reference module: an unmodified copy of the
+    reference loop (torch ops for the loss, loss.backward()) yields the reference's ctx.grad."""
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden("tta_tiny_s1")
+    model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
+    output = model(views)
+    torch.testing.assert_close(output.detach().cpu(), g["logits"], atol=1e-3, rtol=0)
+    output, idx = tpt_cls_rl.select_confident_samples(output, args.selection_p)
+    assert idx.cpu().tolist() == g["selected_idx"].tolist()
+    reward_model.set_image_features(views[idx])
+    bs, K = output.shape[0], reward_model.sample_k
+    value, index = torch.topk(output, K, dim=-1)
+    flat = index.flatten()
+    score = reward_model.CLIPScore(class_index=flat, pairwise=False)
+    rewards = reward_model.rewards_post_process(score if reward_model.process_batch else score.reshape(bs, -1))
+    rep = torch.repeat_interleave(output, K, dim=0)
+    loss = torch.mean(rewards * torch.nn.functional.cross_entropy(rep, flat, reduction="none"))
+    optimizer.zero_grad()
+    loss.backward()
+    gr, og = g["ctx_grad"], model.prompt_learner.ctx.grad.cpu()
+    assert (og - gr).norm() / gr.norm() < 1e-3
+    torch.testing.assert_close(tpt_cls_rl.avg_entropy(output.detach()).cpu(), RR.avg_entropy(output.detach().cpu()), atol=1e-5, rtol=1e-5)
+    runtime.reset_session()
