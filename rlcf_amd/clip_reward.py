@@ -58,9 +58,6 @@ class CLIPRewards(BaseRewards):
         self.clip_model, self.embed_dim, self.preprocess = clip_store.load(arch, device=device)
         runtime.SESSION.set_reward(self.clip_model)
         self.resolutions = self.clip_model.geometry.image_resolution
-        if self.resolutions != default_resolutions:
-            raise NotImplementedError("reward models that need the bicubic resolution change (clip_reward.py:133-134) "
-                                      "are a 'next' row (SURVEY.md §8f-3)")
         self.clipscore_weight, self.device, self.classification = clipscore_weight, device, classification
         self.class_features = None
         self.image_features = None
@@ -70,6 +67,9 @@ class CLIPRewards(BaseRewards):
     @torch.no_grad()
     def extract_image_features(self, images):
         """clip_reward.py:130-137: encode_image, float, L2 normalise."""
+        if images.shape[-1] != self.resolutions:
+            raise NotImplementedError("reward models that need the bicubic resolution change (clip_reward.py:133-134) "
+                                      "are a 'next' row (SURVEY.md §8f-3)")
         return runtime.SESSION.engine(images.shape[0]).encode_image(L.REWARD, images)
 
     @torch.no_grad()

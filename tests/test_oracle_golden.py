@@ -112,3 +112,31 @@ def test_synth_is_deterministic():
     t = synth.make_token_bank(synth.GEOMETRIES["ViT-B/16"], 1000)
     eot = t.argmax(-1)
     assert eot.min() == 7 and eot.max() == 17 and abs(eot.float().mean().item() + 1 - 9.16) < 0.25
+
+
+def test_oracle_full_geometry_vit_b16():
+    """BASELINE configs[0] (ViT-B/16 + ViT-B/16, N=8, C=1000): the reference's own run vs the oracle.  The oracle runs
+    its exact EOT-truncated text tower here to keep the CPU suite short; dense-77 is covered by the small cases."""
+    g, meta = load("tta_b16_n8")
+    o = run_oracle(meta, truncate=True)
+    assert torch.equal(o["selected_idx"], g["selected_idx"])
+    assert torch.equal(o["topk_idx"], g["topk_idx"])
+    assert torch.equal(o["top5"], g["top5"])
+    torch.testing.assert_close(o["logits"], g["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=1e-3, rtol=0)
+    gr, og = g["ctx_grad"], o["ctx_grad"]
+    assert (og - gr).norm() / gr.norm() < 1e-3
+
+
+def test_oracle_modules_fixture():
+    """encode_image / encode_text of the reference CLIP class at ViT-B/16 and ViT-L/14 geometry."""
+    g, _ = load("modules")
+    for arch, tag in (("ViT-B/16", "b16"), ("ViT-L/14", "l14")):
+        geo = synth.GEOMETRIES[arch]
+        sd = synth.make_state_dict(geo, 11)
+        views = synth.make_views(1000, 2, geo.image_resolution)
+        toks = synth.make_token_bank(geo, 8, seed=7)
+        with torch.no_grad():
+            torch.testing.assert_close(C.encode_image(sd, views), g[f"{tag}_image"], atol=2e-5, rtol=1e-4)
+            torch.testing.assert_close(C.encode_text(sd, toks), g[f"{tag}_text"], atol=2e-5, rtol=1e-4)
+            torch.testing.assert_close(C.encode_text(sd, toks, truncate=True), g[f"{tag}_text"], atol=2e-5, rtol=1e-4)
