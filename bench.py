@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--batch", type=int, default=4, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -86,7 +87,7 @@ def main():
     tokens = synth.make_token_bank(geo, a.classes, seed=7, n_ctx=n_ctx)
     ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, n_ctx), device=dev)].clone()
     prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[a.precision]
-    eng = Engine(geo, geo, a.views, a.classes, prec)
+    eng = Engine(geo, geo, a.views * max(a.batch, 1), a.classes, prec)
     eng.load_state_dict(_lib.STUDENT, ssd)
     eng.load_state_dict(_lib.REWARD, rsd)
     eng.finalize()
@@ -122,8 +123,9 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (the f32-MFMA GEMM): per-launch HIP-event timing of one sample
         lib = _lib.lib()
+        nprof = max(a.batch, 1) if total >= max(a.batch, 1) else 1
         lib.rlcf_profile_gemm(1)
-        eng.tta_batch(views[:1], cfg)
+        eng.tta_batch(views[:nprof], cfg)
         torch.cuda.synchronize()
         import ctypes as C
         n_l, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
@@ -141,13 +143,14 @@ def main():
             "config": {"workload": "RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + ViT-B/16 reward, N=64 views, "
                                    "1000-class bank, selection_p=0.1, K=3, 1 AdamW step (BASELINE configs[1])",
                        "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
-                       "tta_steps": 1, "parallelism": f"sample-sharded x{world}, no data-path collective"},
+                       "tta_steps": 1, "images_per_pass": a.batch,
+                       "parallelism": f"sample-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,
                          "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
                          else "gemm_nt_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product) + small-M f32 GEMMs",
-                         "launches_per_image": n_l.value, "avg_launch_ms": ms.value / max(n_l.value, 1),
-                         "gemm_flops_per_image": fl.value},
+                         "launches_per_image": n_l.value / nprof, "avg_launch_ms": ms.value / max(n_l.value, 1),
+                         "gemm_flops_per_image": fl.value / nprof},
             "flops_exec_per_image": flops_exec,
             "whole_step_tflops": flops_exec * a.steps / dt / 1e12,
             "top1_first": int(top5[0, 0].item()),

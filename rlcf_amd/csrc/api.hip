@@ -161,7 +161,8 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,
-                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo};
+                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
+                     &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits};
     for (DevBuf* d : all) d->release();
     delete e;
 }
@@ -217,18 +218,7 @@ int rlcf_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_ar
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
-    const size_t per = (size_t)N * 3 * e->model[0].cfg.image_resolution * e->model[0].cfg.image_resolution;
-    double flops = 0.0;
-    for (int i = 0; i < count; ++i) {
-        rlcf_tta_out o{};
-        o.top5 = top5 + (size_t)i * 5;
-        o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
-        int rc = engine_tta_sample(e, views + (size_t)i * per, N, args, &o, (hipStream_t)stream);
-        if (rc) return rc;
-        flops += e->last_flops;
-    }
-    e->last_flops = flops / count;
-    return RLCF_OK;
+    return engine_tta_batch(e, views, count, N, args, final_logits, top5, (hipStream_t)stream);
 }
 double rlcf_engine_last_flops(rlcf_engine* e) { return e ? e->last_flops : 0.0; }
 int rlcf_engine_text_rows(rlcf_engine* e) { return e ? e->lay[0].T : 0; }

@@ -84,6 +84,9 @@ struct rlcf_engine {
     // TTA step scratch
     DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg, views_sel, topk_idx, clip_score, rewards, loss, dlogits,
         dtxt_dense, final_logits, top5;
+    // sample-batched step (rlcf_tta_batch): B test images share every tower pass
+    DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;
+    int b_cap = 0, sp_groups = 0;
     DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
     double last_flops = 0.0;
@@ -105,3 +108,5 @@ int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt
 int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st);
 int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                     hipStream_t st);

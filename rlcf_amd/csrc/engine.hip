@@ -133,7 +133,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     const rlcf_clip_cfg& c = m.cfg;
     for (auto& d : m.derived) d.release();
     m.derived.clear();
-    m.derived.reserve(16 * (c.vision_layers + c.text_layers) + 16);
+    m.derived.reserve(24 * (c.vision_layers + c.text_layers) + 16);
     m.split_of.clear();
     const int Wv = c.vision_width, Wt = c.text_width, ps = c.vision_patch_size, D = c.embed_dim;
     const int K = 3 * ps * ps;
@@ -178,6 +178,10 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
             const size_t W2 = (size_t)t->width * t->width;
             TRY(make_split(e, m, b.in_w, 3 * W2, st)); TRY(make_split(e, m, b.out_w, W2, st));
             TRY(make_split(e, m, b.fc_w, 4 * W2, st)); TRY(make_split(e, m, b.proj_w, 4 * W2, st));
+            if (b.in_wT) {                               // backward (dX = dY.W) operands of the student text tower
+                TRY(make_split(e, m, b.in_wT, 3 * W2, st)); TRY(make_split(e, m, b.out_wT, W2, st));
+                TRY(make_split(e, m, b.fc_wT, 4 * W2, st)); TRY(make_split(e, m, b.proj_wT, 4 * W2, st));
+            }
         }
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     m.finalized = true;
@@ -395,12 +399,13 @@ struct TextPassIO {
     const rlcf_seq* seqs; int n_seq, max_q_len, T, n_cls; long attn_pairs;
     const int32_t* eot_rows; const int32_t* row_src;
     float *eot_x, *eot_ln, *u, *inv_norm, *txt;
+    int rep_rows = 0, ctx_stride = 0;      // replicated layout: one replica (and one prompt) per test sample
 };
 static int text_forward(rlcf_engine* e, ClipModel& m, const TextLayout& L, Tower& ws, const float* ctx, const TextPassIO& io, bool save,
                         hipStream_t st) {
     const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
     float* x0 = save ? ws.sv[0].x : ws.x.as<float>();
-    TRY(launch_text_assemble(L.E.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), ctx, x0, io.T, Wt, st));
+    TRY(launch_text_assemble(L.E.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), ctx, x0, io.T, Wt, io.rep_rows, io.ctx_stride, st));
     TRY(transformer_forward(e, m.txt, ws, io.seqs, io.n_seq, io.max_q_len, io.attn_pairs, 1, io.T, save, st));
     TRY(launch_gather_rows(ws.x.as<float>(), Wt, io.eot_rows, io.eot_x, Wt, io.n_cls, Wt, st));
     TRY(launch_layernorm_fwd(io.eot_x, m.lnf_w, m.lnf_b, io.eot_ln, nullptr, io.n_cls, Wt, st));
@@ -486,7 +491,7 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
         TRY(text_forward(e, s, e->lay[0], e->tt, e->ctx_init.as<float>(), io0, false, st));
     }
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
-    e->sp_max_e = 0;    // sparse layout is (re)built lazily for the requested n_sel*K
+    e->sp_max_e = 0; e->sp_groups = 0; e->b_cap = 0;   // sparse / batch layouts are (re)built lazily
     return RLCF_OK;
 }
 
@@ -523,17 +528,20 @@ int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* im
 }
 
 // Sparse backward layout for n_e = n_sel*K sampled (view, class) pairs.
-static int sparse_ensure(rlcf_engine* e, int n_e, hipStream_t st) {
-    if (n_e <= e->sp_max_e) return RLCF_OK;
+static int sparse_ensure(rlcf_engine* e, int n_e_per_group, hipStream_t st, int groups = 1) {
+    if (n_e_per_group <= e->sp_max_e && groups <= e->sp_groups) return RLCF_OK;
     ClipModel& m = e->model[RLCF_STUDENT];
     const TextLayout& L = e->lay[0];
     const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
-    const int T = L.pre_rows + n_e * L.lmax;
-    TRY(e->sp_seqs.ensure((size_t)(n_e + 1) * sizeof(rlcf_seq))); TRY(e->sp_eot_rows.ensure(n_e * sizeof(int32_t)));
+    groups = std::max(groups, e->sp_groups);
+    n_e_per_group = std::max(n_e_per_group, e->sp_max_e);
+    const int T = groups * (L.pre_rows + n_e_per_group * L.lmax);
+    const int n_e = groups * n_e_per_group;
+    TRY(e->sp_seqs.ensure((size_t)(n_e + groups) * sizeof(rlcf_seq))); TRY(e->sp_eot_rows.ensure(n_e * sizeof(int32_t)));
     TRY(e->sp_row_src.ensure((size_t)T * sizeof(int32_t)));
     std::vector<int32_t> list;
     if (L.pre_rows > 0) for (int j = 0; j < L.n_ctx; ++j) list.push_back(1 + j);
-    else for (int k = 0; k < n_e; ++k) for (int j = 0; j < L.n_ctx; ++j) list.push_back(k * L.lmax + 1 + j);
+    else for (int k = 0; k < n_e_per_group; ++k) for (int j = 0; j < L.n_ctx; ++j) list.push_back(k * L.lmax + 1 + j);
     TRY(upload(e->sp_ctx_rows_list, list, st));
     TRY(e->sp_dtxt.ensure((size_t)n_e * D * sizeof(float))); TRY(e->sp_txt.ensure((size_t)n_e * D * sizeof(float)));
     TRY(e->sp_inv_norm.ensure(n_e * sizeof(float))); TRY(e->sp_eot_x.ensure((size_t)n_e * Wt * sizeof(float)));
@@ -542,7 +550,7 @@ static int sparse_ensure(rlcf_engine* e, int n_e, hipStream_t st) {
     TRY(tower_ensure(e->st, T, Wt));
     TRY(tower_ensure_saved(e->st, T, Wt, m.cfg.text_layers));
     TRY(bwd_ensure(e, T, Wt));
-    e->sp_max_e = n_e; e->sp_T = T;
+    e->sp_max_e = n_e_per_group; e->sp_T = T; e->sp_groups = groups;
     return RLCF_OK;
 }
 
@@ -552,7 +560,7 @@ static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_fe
     const TextLayout& L = e->lay[0];
     const int D = m.cfg.embed_dim;
     const int T = L.pre_rows + n_e * L.lmax;
-    TRY(launch_build_sparse_layout(cls, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
+    TRY(launch_build_sparse_layout(cls, 1, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
                                    L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
                                    e->sp_row_src.as<int32_t>(), st));
     TextPassIO io{};
@@ -659,5 +667,136 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
     COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
     COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ B test samples per pass
+// Same arithmetic per sample as engine_tta_sample (default RLCF configuration: one tuning step, sparse class backward),
+// but every tower pass runs once for the whole batch: B*N views through the student image tower, B*n_sel views through
+// the reward tower, B*n_sel*K class prompts through the sparse forward/backward (each sample with its own copy of the
+// prompt prefix), B adapted prompts through one replicated final text pass.  Samples stay independent (no cross-sample
+// arithmetic); larger M per GEMM is what fills 256 CUs.
+static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
+    if (B <= e->b_cap) return RLCF_OK;
+    ClipModel& s = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    const int Wt = s.cfg.text_width, D = s.cfg.embed_dim, C = L.C;
+    TRY(e->b_seqs_rep.ensure((size_t)B * L.n_seq * sizeof(rlcf_seq))); TRY(e->b_eot_rep.ensure((size_t)B * C * sizeof(int32_t)));
+    TRY(launch_replicate_layout(L.seqs.as<rlcf_seq>(), L.n_seq, L.eot_rows.as<int32_t>(), C, L.T, B, e->b_seqs_rep.as<rlcf_seq>(),
+                                e->b_eot_rep.as<int32_t>(), st));
+    const size_t cb = (size_t)B * e->n_ctx * Wt * sizeof(float);
+    TRY(e->b_ctx.ensure(cb)); TRY(e->b_m.ensure(cb)); TRY(e->b_v.ensure(cb)); TRY(e->b_grad.ensure(cb));
+    TRY(e->b_txt.ensure((size_t)B * C * D * sizeof(float))); TRY(e->b_u.ensure((size_t)B * C * D * sizeof(float)));
+    TRY(e->b_eot_x.ensure((size_t)B * C * Wt * sizeof(float))); TRY(e->b_eot_ln.ensure((size_t)B * C * Wt * sizeof(float)));
+    TRY(e->b_inv.ensure((size_t)B * C * sizeof(float))); TRY(e->b_logits.ensure((size_t)B * C * sizeof(float)));
+    TRY(tower_ensure(e->tt, B * L.T, Wt));
+    if (e->precision == RLCF_PREC_F16X3 && (size_t)B * L.T * Wt * 4 > e->a_split_elems) {
+        e->a_split_elems = (size_t)B * L.T * Wt * 4;
+        TRY(e->a_hi.ensure(e->a_split_elems * 2)); TRY(e->a_lo.ensure(e->a_split_elems * 2));
+    }
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    e->b_cap = B;
+    return RLCF_OK;
+}
+
+static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                           hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    ClipModel& r = e->model[RLCF_REWARD];
+    const TextLayout& L = e->lay[0];
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
+    const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
+    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    TRY(batch_ensure(e, B, st));
+    TRY(sparse_ensure(e, n_e, st, B));
+    e->last_flops = 0.0;
+    // 1. student image features of all B*N views; first-step logits against the cached pristine-prompt text features
+    TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
+    TRY(engine_logits(e, e->img_feat.as<float>(), BN, e->txt0.as<float>(), C, e->logits.as<float>(), st));
+    // 2. per-sample confidence selection (global row ids), gathers, reward features of the selected views
+    TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+    TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
+    TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
+    TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), BS, e->rimg.as<float>(), st));
+    TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
+    // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
+    TRY(launch_reward_loss_grouped(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+                                   a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
+                                   e->dlogits.as<float>(), st));
+    // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
+    const int gT = L.pre_rows + n_e * L.lmax, T = B * gT, nE = B * n_e;
+    TRY(launch_build_sparse_layout(e->topk_idx.as<int32_t>(), B, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(),
+                                   L.class_eot_off.as<int32_t>(), L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
+                                   e->sp_row_src.as<int32_t>(), st));
+    TextPassIO io{};
+    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = B * (n_e + (L.pre_rows > 0 ? 1 : 0)); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = nE;
+    io.attn_pairs = (long)(nE * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
+    io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
+    io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
+    io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
+    io.rep_rows = 0; io.ctx_stride = 0;                        // every group starts from ctx_init
+    TRY(text_forward(e, s, L, e->st, e->ctx_init.as<float>(), io, true, st));
+    TRY(launch_dtxt_sparse(e->dlogits.as<float>(), e->topk_idx.as<int32_t>(), e->sel_feat.as<float>(), nE, K, C, D, s.logit_scale_exp,
+                           e->sp_dtxt.as<float>(), st));
+    {   // text_backward with the per-sample (grouped) ctx-gradient reduction
+        TRY(launch_l2norm_bwd(io.txt, e->sp_dtxt.as<float>(), io.inv_norm, e->sp_du.as<float>(), nE, D, st));
+        TRY(gemm(e, e->sp_du.as<float>(), D, s.tproj, D, nullptr, nullptr, 0, nullptr, 0, e->sp_dxe.as<float>(), Wt, nE, Wt, D, 1.f, RLCF_EPI_NONE, st));
+        TRY(launch_layernorm_bwd(io.eot_x, s.lnf_w, e->sp_dxe.as<float>(), nullptr, e->sp_dxe.as<float>(), nullptr, nullptr, nE, Wt, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wt * sizeof(float), st));
+        TRY(launch_scatter_rows(e->sp_dxe.as<float>(), io.eot_rows, e->dX.as<float>(), nE, Wt, st));
+        TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, L.max_keys, io.attn_pairs, 1, T, st));
+        TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
+                                    e->b_grad.as<float>(), st));
+    }
+    // 5. one AdamW step per sample from the reset state (ctx_init, m = v = 0)
+    const int64_t np = (int64_t)n_ctx * Wt;
+    TRY(launch_broadcast_rows(e->ctx_init.as<float>(), e->b_ctx.as<float>(), (int)np, B, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->b_m.p, 0, (size_t)B * np * sizeof(float), st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->b_v.p, 0, (size_t)B * np * sizeof(float), st));
+    TRY(launch_adamw(e->b_ctx.as<float>(), e->b_grad.as<float>(), e->b_m.as<float>(), e->b_v.as<float>(), B * np, 1, a->lr, a->beta1, a->beta2,
+                     a->eps, a->weight_decay, st));
+    // 6. final clean-view inference: B adapted prompts through one replicated text pass
+    TextPassIO fo{};
+    fo.seqs = e->b_seqs_rep.as<rlcf_seq>(); fo.n_seq = B * L.n_seq; fo.max_q_len = L.max_q_len; fo.T = B * L.T; fo.n_cls = B * C;
+    fo.attn_pairs = (long)B * L.attn_pairs; fo.eot_rows = e->b_eot_rep.as<int32_t>(); fo.row_src = nullptr;
+    fo.eot_x = e->b_eot_x.as<float>(); fo.eot_ln = e->b_eot_ln.as<float>(); fo.u = e->b_u.as<float>(); fo.inv_norm = e->b_inv.as<float>();
+    fo.txt = e->b_txt.as<float>(); fo.rep_rows = L.T; fo.ctx_stride = (int)np;
+    TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
+    float* fl = final_logits ? final_logits : e->b_logits.as<float>();
+    TRY(launch_final_logits_batched(e->img_feat.as<float>(), N, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, fl, st));
+    e->last_flops += 2.0 * B * C * D;
+    TRY(launch_top5_batched(fl, B, C, top5, st));
+    return RLCF_OK;
+}
+
+int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                     hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    ClipModel& r = e->model[RLCF_REWARD];
+    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const int n_sel = (int)(N * a->selection_p);
+    const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
+                           !(a->flags & RLCF_F_MIN_ENTROPY) && a->sample_k > 1;
+    const int Bmax = e->max_views / N;
+    const bool fused = Bmax >= 2 && a->tta_steps == 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0 &&
+                       r.cfg.image_resolution == s.cfg.image_resolution;
+    double flops = 0.0;
+    int i = 0;
+    while (i < count) {
+        const int B = fused ? std::min(Bmax, count - i) : 1;
+        if (fused && B >= 2) {
+            TRY(tta_batch_fused(e, views + (size_t)i * per, B, N, a, final_logits ? final_logits + (size_t)i * e->C : nullptr, top5 + (size_t)i * 5, st));
+        } else {
+            rlcf_tta_out o{};
+            o.top5 = top5 + (size_t)i * 5;
+            o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
+            TRY(engine_tta_sample(e, views + (size_t)i * per, N, a, &o, st));
+        }
+        flops += e->last_flops;
+        i += B;
+    }
+    e->last_flops = flops / count;
     return RLCF_OK;
 }

@@ -14,7 +14,7 @@ int launch_vit_assemble(const float* patch_out, const float* cls, const float* p
                         const float* beta, float* x, int n, int tokens, int width, hipStream_t st);
 // X[r] = E[r] + (ctx_row[r] >= 0 ? ctx[ctx_row[r]] : 0)
 int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
-                         int width, hipStream_t st);
+                         int width, int rep_rows, int ctx_stride, hipStream_t st);
 // out[i] = in[idx[i]] rows (idx device, may be null = identity)
 int launch_gather_rows(const float* in, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st);
 int launch_l2norm_rows(const float* in, float* out, float* inv_norm, int rows, int width, hipStream_t st);
@@ -45,7 +45,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int st
                  float b2, float eps, float wd, hipStream_t st);
 int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st);
 int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st);
-int launch_build_sparse_layout(const int32_t* cls, int n_e, const int32_t* class_start, const int32_t* class_len,
+int launch_build_sparse_layout(const int32_t* cls, int groups, int n_e, const int32_t* class_start, const int32_t* class_len,
                                const int32_t* class_eot_off, int lmax, int pre_rows, rlcf_seq* seqs, int32_t* eot_rows,
                                int32_t* row_src, hipStream_t st);
 int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* img, int n_e, int K, int C, int D, float scale,
@@ -54,3 +54,16 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st);
 int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st);
+int launch_ctx_grad_grouped(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, int groups, int group_rows,
+                            float* dctx, hipStream_t st);
+int launch_replicate_layout(const rlcf_seq* seqs, int n_seq, const int32_t* eot_rows, int C, int T, int B, rlcf_seq* seqs_rep,
+                            int32_t* eot_rep, hipStream_t st);
+int launch_broadcast_rows(const float* in, float* out, int n, int B, hipStream_t st);
+int launch_entropy_select_batched(const float* logits, int B, int n, int C, int n_sel, float* entropy, int32_t* idx_global, hipStream_t st);
+int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
+                               const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
+                               float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                               float* dlogits, hipStream_t st);
+int launch_final_logits_batched(const float* img, int img_row_stride, const float* txt, int B, int C, int D, float scale, float* out,
+                                hipStream_t st);
+int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);

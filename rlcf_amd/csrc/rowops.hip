@@ -232,29 +232,33 @@ int launch_vit_assemble(const float* patch_out, const float* cls, const float* p
 // token embedding (non-ctx rows) + positional embedding; ctx rows add the learnable vectors.
 // row_src (optional): X row r is built from row row_src[r] of E / ctx_row (-1: zero row) — the
 // sparse-backward layout re-packs a few class prompts this way.
+// rep_rows > 0: the layout is replicated (row r of replica r / rep_rows is layout row r % rep_rows) and replica b
+// reads its own context block ctx + b * ctx_stride4 (one prompt per test sample).
 __global__ void text_assemble_kernel(const float* __restrict__ E, const int32_t* __restrict__ row_src, const int32_t* __restrict__ ctx_row,
-                                     const float* __restrict__ ctx, float* __restrict__ X, int rows, int w4) {
+                                     const float* __restrict__ ctx, float* __restrict__ X, int rows, int w4, int rep_rows, int ctx_stride4) {
     const long total = (long)rows * w4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / w4), c = (int)(idx % w4);
-        const int sr = row_src ? row_src[r] : r;
+        const int rep = rep_rows > 0 ? r / rep_rows : 0;
+        const int rl = rep_rows > 0 ? r - rep * rep_rows : r;
+        const int sr = row_src ? row_src[rl] : rl;
         if (sr < 0) { ((float4*)X)[idx] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         float4 e = ((const float4*)E)[(size_t)sr * w4 + c];
         const int cr = ctx_row[sr];
         if (cr >= 0) {
-            float4 t = ((const float4*)ctx)[(size_t)cr * w4 + c];
+            float4 t = ((const float4*)ctx)[(size_t)rep * ctx_stride4 + (size_t)cr * w4 + c];
             e.x += t.x; e.y += t.y; e.z += t.z; e.w += t.w;
         }
         ((float4*)X)[idx] = e;
     }
 }
 int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
-                         int width, hipStream_t st) {
+                         int width, int rep_rows, int ctx_stride, hipStream_t st) {
     RLCF_ARG_CHECK(width % 4 == 0 && rows > 0);
     const long total = (long)rows * (width / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    text_assemble_kernel<<<dim3(blocks), dim3(256), 0, st>>>(E, row_src, ctx_row, ctx, X, rows, width / 4);
+    text_assemble_kernel<<<dim3(blocks), dim3(256), 0, st>>>(E, row_src, ctx_row, ctx, X, rows, width / 4, rep_rows, ctx_stride / 4);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -323,17 +327,22 @@ int launch_l2norm_bwd(const float* t, const float* dt, const float* inv_norm, fl
 
 // ---------------------------------------------------------------- ctx gradient (custom_clip.py:198-238 backward)
 __global__ void ctx_grad_kernel(const float* __restrict__ dX, const int32_t* __restrict__ ctx_rows, int n_copies, int n_ctx,
-                                int width, float* __restrict__ dctx) {
-    const int j = blockIdx.y;
+                                int width, int group_rows, float* __restrict__ dctx) {
+    const int j = blockIdx.y, b = blockIdx.z;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= width) return;
     float s = 0.f;
-    for (int k = 0; k < n_copies; ++k) s += dX[(size_t)ctx_rows[k * n_ctx + j] * width + c];
-    dctx[(size_t)j * width + c] = s;
+    for (int k = 0; k < n_copies; ++k) s += dX[((size_t)b * group_rows + ctx_rows[k * n_ctx + j]) * width + c];
+    dctx[((size_t)b * n_ctx + j) * width + c] = s;
 }
 int launch_ctx_grad(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, float* dctx, hipStream_t st) {
-    RLCF_ARG_CHECK(n_copies > 0 && n_ctx > 0);
-    ctx_grad_kernel<<<dim3((width + 63) / 64, n_ctx), dim3(64), 0, st>>>(dX, ctx_rows, n_copies, n_ctx, width, dctx);
+    return launch_ctx_grad_grouped(dX, ctx_rows, n_copies, n_ctx, width, 1, 0, dctx, st);
+}
+// dctx[b] from group b's rows: ctx_rows are group-relative, group b starts at row b*group_rows
+int launch_ctx_grad_grouped(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, int groups, int group_rows,
+                            float* dctx, hipStream_t st) {
+    RLCF_ARG_CHECK(n_copies > 0 && n_ctx > 0 && groups > 0);
+    ctx_grad_kernel<<<dim3((width + 63) / 64, n_ctx, groups), dim3(64), 0, st>>>(dX, ctx_rows, n_copies, n_ctx, width, group_rows, dctx);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -409,26 +418,29 @@ __global__ void build_sparse_layout_kernel(const int32_t* __restrict__ cls, int 
                                            const int32_t* __restrict__ class_len, const int32_t* __restrict__ class_eot_off,
                                            int lmax, int pre_rows, rlcf_seq* __restrict__ seqs, int32_t* __restrict__ eot_rows,
                                            int32_t* __restrict__ row_src) {
-    const int e = blockIdx.x;
-    if (e == n_e) {                                   // the shared prefix rows (and its own sequence)
-        for (int r = threadIdx.x; r < pre_rows; r += blockDim.x) row_src[r] = r;
-        if (threadIdx.x == 0 && pre_rows > 0) { rlcf_seq s = {0, pre_rows, 0, 0}; seqs[n_e] = s; }
+    // blockIdx.y = test sample (group): each group owns pre_rows + n_e*lmax rows and its own copy of the prefix
+    const int e = blockIdx.x, b = blockIdx.y;
+    const int gbase = b * (pre_rows + n_e * lmax);
+    const int nseq_g = n_e + (pre_rows > 0 ? 1 : 0);
+    if (e == n_e) {                                   // the group's prefix rows (and their own sequence)
+        for (int r = threadIdx.x; r < pre_rows; r += blockDim.x) row_src[gbase + r] = r;
+        if (threadIdx.x == 0 && pre_rows > 0) { rlcf_seq s = {gbase, pre_rows, 0, 0}; seqs[b * nseq_g + n_e] = s; }
         return;
     }
-    const int c = cls[e];
-    const int base = pre_rows + e * lmax, len = class_len[c], st = class_start[c];
+    const int c = cls[b * n_e + e];
+    const int base = gbase + pre_rows + e * lmax, len = class_len[c], st = class_start[c];
     for (int j = threadIdx.x; j < lmax; j += blockDim.x) row_src[base + j] = j < len ? st + j : -1;
     if (threadIdx.x == 0) {
-        rlcf_seq s = {base, len, 0, pre_rows};
-        seqs[e] = s;
-        eot_rows[e] = base + class_eot_off[c];
+        rlcf_seq s = {base, len, gbase, pre_rows};
+        seqs[b * nseq_g + e] = s;
+        eot_rows[b * n_e + e] = base + class_eot_off[c];
     }
 }
-int launch_build_sparse_layout(const int32_t* cls, int n_e, const int32_t* class_start, const int32_t* class_len,
+int launch_build_sparse_layout(const int32_t* cls, int groups, int n_e, const int32_t* class_start, const int32_t* class_len,
                                const int32_t* class_eot_off, int lmax, int pre_rows, rlcf_seq* seqs, int32_t* eot_rows,
                                int32_t* row_src, hipStream_t st) {
-    RLCF_ARG_CHECK(n_e > 0 && lmax > 0);
-    build_sparse_layout_kernel<<<dim3(n_e + 1), dim3(64), 0, st>>>(cls, n_e, class_start, class_len, class_eot_off, lmax, pre_rows,
+    RLCF_ARG_CHECK(n_e > 0 && lmax > 0 && groups > 0);
+    build_sparse_layout_kernel<<<dim3(n_e + 1, groups), dim3(64), 0, st>>>(cls, n_e, class_start, class_len, class_eot_off, lmax, pre_rows,
                                                                   seqs, eot_rows, row_src);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -447,6 +459,37 @@ int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* im
                        float* dtxt, hipStream_t st) {
     RLCF_ARG_CHECK(n_e > 0 && K > 0);
     dtxt_sparse_kernel<<<dim3(n_e), dim3(256), 0, st>>>(dlogits, cls, img, K, C, D, scale, dtxt);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- replicated text layout (one replica per test sample)
+__global__ void replicate_layout_kernel(const rlcf_seq* __restrict__ seqs, int n_seq, const int32_t* __restrict__ eot_rows, int C, int T,
+                                        int B, rlcf_seq* __restrict__ seqs_rep, int32_t* __restrict__ eot_rep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * n_seq) {
+        const int b = i / n_seq;
+        rlcf_seq s = seqs[i - b * n_seq];
+        s.q_start += b * T; s.pre_start += b * T;
+        seqs_rep[i] = s;
+    }
+    if (i < B * C) { const int b = i / C; eot_rep[i] = eot_rows[i - b * C] + b * T; }
+}
+int launch_replicate_layout(const rlcf_seq* seqs, int n_seq, const int32_t* eot_rows, int C, int T, int B, rlcf_seq* seqs_rep,
+                            int32_t* eot_rep, hipStream_t st) {
+    const int n = B * (n_seq > C ? n_seq : C);
+    replicate_layout_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(seqs, n_seq, eot_rows, C, T, B, seqs_rep, eot_rep);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// out[b, :] = in[:] for b < B
+__global__ void broadcast_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int B) {
+    const long total = (long)n * B;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) out[i] = in[i % n];
+}
+int launch_broadcast_rows(const float* in, float* out, int n, int B, hipStream_t st) {
+    const long total = (long)n * B;
+    broadcast_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(in, out, n, B);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

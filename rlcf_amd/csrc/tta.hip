@@ -69,6 +69,27 @@ __global__ void select_lowest_kernel(const float* __restrict__ entropy, int n, i
         if (rank < n_sel) idx[rank] = i;
     }
 }
+// B samples of n views each: idx[b*n_sel + r] = b*n + (view with the r-th lowest entropy of sample b)  (global row ids)
+__global__ void select_lowest_batched_kernel(const float* __restrict__ entropy, int n, int n_sel, int32_t* __restrict__ idx) {
+    const float* ent = entropy + (size_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = ent[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float f = ent[j];
+            rank += (f < e || (f == e && j < i)) ? 1 : 0;
+        }
+        if (rank < n_sel) idx[blockIdx.x * n_sel + rank] = blockIdx.x * n + i;
+    }
+}
+int launch_entropy_select_batched(const float* logits, int B, int n, int C, int n_sel, float* entropy, int32_t* idx_global, hipStream_t st) {
+    RLCF_ARG_CHECK(B > 0 && n > 0 && C > 0 && n_sel > 0 && n_sel <= n);
+    row_entropy_kernel<<<dim3(B * n), dim3(TTA_THREADS), 0, st>>>(logits, C, entropy);
+    RLCF_LAUNCH_CHECK();
+    select_lowest_batched_kernel<<<dim3(B), dim3(256), 0, st>>>(entropy, n, n_sel, idx_global);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, hipStream_t st) {
     RLCF_ARG_CHECK(n > 0 && C > 0 && n_sel >= 0 && n_sel <= n);
     row_entropy_kernel<<<dim3(n), dim3(TTA_THREADS), 0, st>>>(logits, C, entropy);
@@ -134,11 +155,19 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
                                                                      const int32_t* __restrict__ topk_idx, const float* __restrict__ stats,
                                                                      float* __restrict__ clip_score, float* __restrict__ rewards,
                                                                      float* __restrict__ loss, float* __restrict__ dlogits) {
+    // rows are grouped per test sample: n_sel consecutive rows form one group (gridDim.x = groups * n_sel)
     extern __shared__ float avg[];                      // [C] log of the view-averaged probability (min-entropy only)
     __shared__ float red[TTA_THREADS / 64];
     __shared__ float r_row[MAX_K];
     __shared__ float r_all_sum;
+    const int grp0 = (blockIdx.x / n_sel) * n_sel;      // first row of this row's group
     const int i = blockIdx.x;
+    const bool first = (i == grp0);
+    stats += (size_t)grp0 * STAT_LD;                    // group-relative views of the per-row tables
+    if (clip_score) clip_score += (size_t)grp0 * K;
+    if (rewards) rewards += (size_t)grp0 * K;
+    if (loss) loss += blockIdx.x / n_sel;
+    const int il = i - grp0;                            // row within the group
     const int total = n_sel * K;
     // ---- rewards_post_process (clip_reward.py:152-165); every block recomputes the tiny table
     float batch_mean = 0.f, batch_std = 1.f;
@@ -170,11 +199,11 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
         }
         return amplify ? (sc - mean) / sd : (sc - mean);
     };
-    if (threadIdx.x < K) r_row[threadIdx.x] = reward_of(i, threadIdx.x);
+    if (threadIdx.x < K) r_row[threadIdx.x] = reward_of(il, threadIdx.x);
     __syncthreads();
     float rsum = 0.f;
     for (int k = 0; k < K; ++k) rsum += r_row[k];
-    if (i == 0 && threadIdx.x == 0) {
+    if (first && threadIdx.x == 0) {
         float l = 0.f;
         for (int e = 0; e < total; ++e) {
             const float r = reward_of(e / K, e % K);
@@ -186,15 +215,15 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
     }
     // ---- optional min-entropy regulariser (tpt_cls_rl.py:38-44,73-74)
     const float* x = logits + (size_t)(sel ? sel[i] : i) * ld;
-    const float lse = stats[i * STAT_LD];
+    const float lse = stats[il * STAT_LD];
     float pa_dot = 0.f, hreg = 0.f;
     const bool minent = (flags & RLCF_F_MIN_ENTROPY) != 0;
     if (minent) {
         for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
             float mx = -INFINITY;
-            for (int j = 0; j < n_sel; ++j) mx = fmaxf(mx, logits[(size_t)(sel ? sel[j] : j) * ld + c] - stats[j * STAT_LD]);
+            for (int j = 0; j < n_sel; ++j) mx = fmaxf(mx, logits[(size_t)(sel ? sel[grp0 + j] : grp0 + j) * ld + c] - stats[j * STAT_LD]);
             float s = 0.f;
-            for (int j = 0; j < n_sel; ++j) s += expf(logits[(size_t)(sel ? sel[j] : j) * ld + c] - stats[j * STAT_LD] - mx);
+            for (int j = 0; j < n_sel; ++j) s += expf(logits[(size_t)(sel ? sel[grp0 + j] : grp0 + j) * ld + c] - stats[j * STAT_LD] - mx);
             float a = mx + logf(s) - logf((float)n_sel);
             a = fmaxf(a, -3.4028234663852886e38f);
             avg[c] = a;
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
         hreg = block_sum(hreg, red);
     }
     __syncthreads();
-    if (i == 0 && threadIdx.x == 0 && loss) loss[0] = r_all_sum + (minent ? -min_entropy_w * hreg : 0.f);
+    if (first && threadIdx.x == 0 && loss) loss[0] = r_all_sum + (minent ? -min_entropy_w * hreg : 0.f);
     // ---- dlogits row: d/dx of mean_{i,k} r_ik * CE(x_i, idx_ik)  (+ w * d avg_entropy)
     const float inv_total = 1.0f / total;
     for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
@@ -221,24 +250,33 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
 
 static float* g_stats = nullptr;     // [max rows][STAT_LD] scratch owned by the library
 static int g_stats_rows = 0;
+// groups test samples of n_sel rows each (rows = groups*n_sel); loss[groups]; everything else row-major over all rows
+int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
+                               const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
+                               float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                               float* dlogits, hipStream_t st) {
+    RLCF_ARG_CHECK(groups > 0 && n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx);
+    const int rows = groups * n_sel;
+    if (g_stats_rows < rows) {                           // grows only on a new maximum (setup time)
+        if (g_stats) (void)hipFree(g_stats);
+        g_stats_rows = rows < 64 ? 64 : rows;
+        RLCF_HIP_CHECK(hipMalloc(&g_stats, (size_t)g_stats_rows * STAT_LD * sizeof(float)));
+    }
+    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, class_feat, reward_img, Dr,
+                                                                    clipscore_weight, topk_idx, g_stats);
+    RLCF_LAUNCH_CHECK();
+    const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
+    reward_stage_b_kernel<<<dim3(rows), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
+                                                                     topk_idx, g_stats, clip_score, rewards, loss, dlogits);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                        const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                        float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
                        float* dlogits, hipStream_t st) {
-    RLCF_ARG_CHECK(n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx);
-    if (g_stats_rows < n_sel) {                          // grows only on a new maximum (setup time)
-        if (g_stats) (void)hipFree(g_stats);
-        g_stats_rows = n_sel < 64 ? 64 : n_sel;
-        RLCF_HIP_CHECK(hipMalloc(&g_stats, (size_t)g_stats_rows * STAT_LD * sizeof(float)));
-    }
-    reward_stage_a_kernel<<<dim3(n_sel), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, class_feat, reward_img, Dr,
-                                                                     clipscore_weight, topk_idx, g_stats);
-    RLCF_LAUNCH_CHECK();
-    const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
-    reward_stage_b_kernel<<<dim3(n_sel), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
-                                                                      topk_idx, g_stats, clip_score, rewards, loss, dlogits);
-    RLCF_LAUNCH_CHECK();
-    return RLCF_OK;
+    return launch_reward_loss_grouped(logits, ld_logits, sel, 1, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags,
+                                      min_entropy_w, topk_idx, clip_score, rewards, loss, dlogits, st);
 }
 
 // ---------------------------------------------------------------- AdamW
@@ -267,6 +305,8 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int st
 
 // ---------------------------------------------------------------- top-5 of one logits row
 __global__ __launch_bounds__(TTA_THREADS) void top5_kernel(const float* __restrict__ x, int C, int32_t* __restrict__ top5) {
+    x += (size_t)blockIdx.x * C;
+    top5 += blockIdx.x * 5;
     __shared__ float redv[TTA_THREADS / 64];
     __shared__ int redi[TTA_THREADS / 64];
     __shared__ int chosen[5];
@@ -283,6 +323,29 @@ __global__ __launch_bounds__(TTA_THREADS) void top5_kernel(const float* __restri
         if (threadIdx.x == 0) { chosen[k] = bi; top5[k] = bi; }
         __syncthreads();
     }
+}
+// per-sample final logits: out[b, c] = scale * <img[b * img_stride_rows], txt[b, c]>   (one wave per class)
+__global__ __launch_bounds__(256) void final_logits_batched_kernel(const float* __restrict__ img, int img_row_stride, const float* __restrict__ txt,
+                                                                   int C, int D, float scale, float* __restrict__ out) {
+    const int b = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const float* im = img + (size_t)b * img_row_stride * D;
+    const float* t = txt + ((size_t)b * C + c) * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += im[d] * t[d];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)b * C + c] = scale * s;
+}
+int launch_final_logits_batched(const float* img, int img_row_stride, const float* txt, int B, int C, int D, float scale, float* out,
+                                hipStream_t st) {
+    final_logits_batched_kernel<<<dim3((C + 3) / 4, B), dim3(256), 0, st>>>(img, img_row_stride, txt, C, D, scale, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st) {
+    top5_kernel<<<dim3(B), dim3(TTA_THREADS), 0, st>>>(logits, C, top5);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
 }
 int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st) {
     top5_kernel<<<dim3(1), dim3(TTA_THREADS), 0, st>>>(logits, C, top5);

@@ -358,6 +358,27 @@ def test_tta_batch_and_reset(L, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("geo,reward,n_cls,p", [("tiny", "tiny-r", 16, 0.5), ("small", "small", 40, 0.25)])
+def test_fused_sample_batch_equals_per_sample(L, dev, geo, reward, n_cls, p, mode):
+    """rlcf_tta_batch runs B samples per tower pass when the engine has room for B*N views; every sample must come
+    out as if it had been processed alone (independent units)."""
+    from rlcf_amd.engine import TTAConfig
+    N, B = 8, 3
+    R = synth.GEOMETRIES[geo].image_resolution
+    cfg = TTAConfig(selection_p=p)
+    vs = torch.stack([synth.make_views(2000 + i, N, R) for i in range(B + 2)]).to(dev)     # 5 samples: 3 fused + 2 fused
+    one, *_ = make_engine((geo, reward), N, n_cls, mode)
+    ref = [one.tta_sample(vs[i], cfg, want_intermediates=False) for i in range(B + 2)]
+    one.close()
+    big, *_ = make_engine((geo, reward), N * B, n_cls, mode)
+    top5, fl = big.tta_batch(vs, cfg, want_logits=True)
+    for i in range(B + 2):
+        assert top5[i].tolist() == ref[i]["top5"].tolist()
+        torch.testing.assert_close(fl[i], ref[i]["final_logits"][0], atol=2e-4, rtol=0)
+    big.close()
+
+
 def test_errors_are_loud(L, dev):
     from rlcf_amd.engine import TTAConfig
     eng, *_ = make_engine(("tiny", "tiny-r"), 8, 16, L.TEXT_SHARED)
