@@ -142,7 +142,10 @@ rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cf
     return e;
 }
 
-static void release_tower(Tower& t) { t.x.release(); t.h.release(); t.qkv.release(); t.a.release(); t.f.release(); t.saved.release(); }
+static void release_tower(Tower& t) {
+    t.x.release(); t.h.release(); t.qkv.release(); t.a.release(); t.f.release(); t.saved.release();
+    t.hh.release(); t.hl.release(); t.ah.release(); t.al.release(); t.fh.release(); t.fl.release();
+}
 static void release_layout(TextLayout& L) {
     L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
     L.class_eot_off.release(); L.ctx_rows_list.release();

@@ -12,7 +12,8 @@
 
 __global__ __launch_bounds__(64) void attention_fwd_f32_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                int width, int causal, float* __restrict__ out,
-                                                               float* __restrict__ lse) {
+                                                               float* __restrict__ lse, _Float16* __restrict__ oh,
+                                                               _Float16* __restrict__ ol) {
     const rlcf_seq sq = seqs[blockIdx.y];
     const int qb = blockIdx.x, head = blockIdx.z;
     if (qb * 32 >= sq.q_len) return;
@@ -88,23 +89,37 @@ __global__ __launch_bounds__(64) void attention_fwd_f32_kernel(const float* __re
     const float ltot = lsum + __shfl_xor(lsum, 32);
     if (qb * 32 + l32 < sq.q_len) {
         const float inv = 1.0f / ltot;
-        float* op = out + (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
+        const size_t obase = (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d = 8 * g + 4 * h;
-            *(float4*)(op + d) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            *(float4*)(op + 32 + d) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            const float v0[4] = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            const float v1[4] = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            if (out) {
+                *(float4*)(out + obase + d) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+                *(float4*)(out + obase + 32 + d) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            }
+            if (oh) {                                   // split-f16 pair for the out-proj GEMM
+                h16x4 h0, l0, h1, l1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)((v0[q] - (float)h0[q]) * 2048.0f);
+                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)((v1[q] - (float)h1[q]) * 2048.0f);
+                }
+                *(h16x4*)(oh + obase + d) = h0; *(h16x4*)(ol + obase + d) = l0;
+                *(h16x4*)(oh + obase + 32 + d) = h1; *(h16x4*)(ol + obase + 32 + d) = l1;
+            }
         }
         if (lse && h == 0) lse[(size_t)(sq.q_start + qi) * H + head] = m + logf(ltot);
     }
 }
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal,
-                             float* out, float* lse, hipStream_t st) {
+                             float* out, float* lse, hipStream_t st, void* out_hi, void* out_lo) {
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0);
     dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
     RLCF_ARG_CHECK(grid.y <= 65535 && grid.z <= 65535);
-    attention_fwd_f32_kernel<<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, lse);
+    attention_fwd_f32_kernel<<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, lse, (_Float16*)out_hi, (_Float16*)out_lo);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

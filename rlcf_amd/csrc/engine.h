@@ -38,7 +38,8 @@ struct SavedLayer { float *x, *qkv, *a, *x1, *f; };
 struct Tower {                       // workspace of one transformer pass over T rows
     int T = 0, width = 0;
     DevBuf x, h, qkv, a, f;          // f32 (F32 mode); bf16 views allocated separately
-    DevBuf h16, qkv16, a16, f16;     // bf16 operands (BF16 mode)
+    DevBuf hh, hl, ah, al, fh, fl;   // split-f16 operand pairs written by the producers (F16X3 mode)
+    int x3_T = 0, x3_W = 0;
     DevBuf saved;                    // per-layer saved activations for backward
     std::vector<SavedLayer> sv;
     int saved_T = 0, saved_layers = 0;

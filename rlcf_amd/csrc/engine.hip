@@ -65,6 +65,30 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
     return rc;
 }
 
+// pre-split A operand (written by the producing kernel): C f32 and/or a split pair
+static const std::pair<void*, void*>* split_of(rlcf_engine* e, const float* W) {
+    for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) return &it->second; }
+    return nullptr;
+}
+static int gemm_pre(rlcf_engine* e, const void* Ahi, const void* Alo, int lda, const float* W, const float* bias, const float* res, int ldr,
+                    float* C, int ldc, void* Chi, void* Clo, int ldch, int M, int N, int K, int epi, hipStream_t st) {
+    const std::pair<void*, void*>* sp = split_of(e, W);
+    if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
+    e->last_flops += 2.0 * M * N * K;
+    const int slot = prof_begin(st, 2.0 * M * N * K);
+    int rc = launch_gemm_f16x3(Ahi, Alo, lda, sp->first, sp->second, K, bias, res, ldr, nullptr, 0, C, ldc, Chi, Clo, ldch, M, N, K, 1.f, epi, st);
+    prof_end(slot, st);
+    return rc;
+}
+static int x3_ensure(Tower& t, int T, int W) {
+    if (T <= t.x3_T && W <= t.x3_W) return RLCF_OK;
+    T = std::max(T, t.x3_T); W = std::max(W, t.x3_W);
+    const size_t n = (size_t)T * W * 2;
+    TRY(t.hh.ensure(n)); TRY(t.hl.ensure(n)); TRY(t.ah.ensure(n)); TRY(t.al.ensure(n)); TRY(t.fh.ensure(4 * n)); TRY(t.fl.ensure(4 * n));
+    t.x3_T = T; t.x3_W = W;
+    return RLCF_OK;
+}
+
 // ------------------------------------------------------------------ weights
 static const float* rawp(ClipModel& m, const std::string& k, size_t numel) {
     auto it = m.raw.find(k);
@@ -230,6 +254,23 @@ static int bwd_ensure(rlcf_engine* e, int T, int width) {
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
                                long attn_pairs, int causal, int T, bool save, hipStream_t st) {
     const int W = w.width, L = w.layers;
+    if (e->precision == RLCF_PREC_F16X3 && !save && T > 512 && W % 32 == 0) {
+        // split-f16 pipeline: LN, attention and the QuickGELU epilogue emit (hi, lo) f16 pairs for the next GEMM
+        TRY(x3_ensure(ws, T, W));
+        float* x = ws.x.as<float>();
+        for (int l = 0; l < L; ++l) {
+            const BlockW& b = w.blk[l];
+            TRY(launch_layernorm_fwd_split(x, b.ln1_w, b.ln1_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));
+            TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            TRY(launch_attention_fwd_f32(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, nullptr, st, ws.ah.p, ws.al.p));
+            e->last_flops += 4.0 * attn_pairs * W;
+            TRY(gemm_pre(e, ws.ah.p, ws.al.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
+            TRY(launch_layernorm_fwd_split(x, b.ln2_w, b.ln2_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));
+            TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.fh.p, ws.fl.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
+            TRY(gemm_pre(e, ws.fh.p, ws.fl.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
+        }
+        return RLCF_OK;
+    }
     for (int l = 0; l < L; ++l) {
         const BlockW& b = w.blk[l];
         float* xin = save ? ws.sv[l].x : ws.x.as<float>();
@@ -286,9 +327,15 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     RLCF_ARG_CHECK(n > 0 && n <= e->max_views);
     const rlcf_clip_cfg& c = m.cfg;
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
-    TRY(launch_im2col(images, e->patches.as<float>(), nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
-    TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv,
-             n * G2, Wv, m.Kp, 1.f, RLCF_EPI_NONE, st));
+    if (e->precision == RLCF_PREC_F16X3 && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
+        TRY(launch_im2col(images, nullptr, e->a_hi.p, e->a_lo.p, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
+        TRY(gemm_pre(e, e->a_hi.p, e->a_lo.p, m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, nullptr, 0, n * G2, Wv,
+                     m.Kp, RLCF_EPI_NONE, st));
+    } else {
+        TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
+        TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv,
+                 n * G2, Wv, m.Kp, 1.f, RLCF_EPI_NONE, st));
+    }
     TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.x.as<float>(), n, tok, Wv, st));
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
                             false, st));

@@ -8,7 +8,9 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                          float* dgamma, float* dbeta, int rows, int width, hipStream_t st);
 // images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 or bf16)
-int launch_im2col(const float* images, float* out, unsigned short* out_bf16, int n, int R, int ps, int Kp, hipStream_t st);
+int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st);
+int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
+                               hipStream_t st);
 // x[n,1+G*G,W] = ln_pre([cls | patch_out] + pos)
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                         const float* beta, float* x, int n, int tokens, int width, hipStream_t st);
@@ -30,7 +32,7 @@ int launch_f32_to_bf16(const float* in, unsigned short* out, int64_t n, hipStrea
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);   // out[cols,rows]
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
-                             int causal, float* out, float* lse, hipStream_t st);
+                             int causal, float* out, float* lse, hipStream_t st, void* out_hi = nullptr, void* out_lo = nullptr);
 int launch_attention_fwd_bf16(const unsigned short* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
                               int causal, unsigned short* out, hipStream_t st);
 int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,

@@ -10,7 +10,8 @@
 // TPT/clip/model.py:157-163 (fp32, eps 1e-5, biased variance about the mean)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                            unsigned short* __restrict__ yb, int rows, int width) {
+                                                            unsigned short* __restrict__ yb, _Float16* __restrict__ yh,
+                                                            _Float16* __restrict__ yl, int rows, int width) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -64,6 +65,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                     ushort4 ob = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
                     *(ushort4*)(yb + (size_t)row * width + c) = ob;
                 }
+                if (yh) {                               // split-f16 pair for the consuming GEMM (gemm_f16x3.hip)
+                    h16x4 hh, ll;
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)((ov[q] - (float)hh[q]) * 2048.0f); }
+                    *(h16x4*)(yh + (size_t)row * width + c) = hh;
+                    *(h16x4*)(yl + (size_t)row * width + c) = ll;
+                }
             }
     } else {
 #pragma unroll
@@ -73,6 +82,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 float o = (v[j] - mu) * rstd * gamma[c] + beta[c];
                 if (y) y[(size_t)row * width + c] = o;
                 if (yb) yb[(size_t)row * width + c] = f2bf(o);
+                if (yh) {
+                    const _Float16 hh = (_Float16)o;
+                    yh[(size_t)row * width + c] = hh;
+                    yl[(size_t)row * width + c] = (_Float16)((o - (float)hh) * 2048.0f);
+                }
             }
         }
     }
@@ -80,8 +94,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, unsigned short* y_bf16,
                          int rows, int width, hipStream_t st) {
+    return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st);
+}
+int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
+                               hipStream_t st) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
-    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, y_bf16, rows, width);
+    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, nullptr, (_Float16*)yh,
+                                                                                                   (_Float16*)yl, rows, width);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -151,7 +170,7 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
 
 // ---------------------------------------------------------------- patch gather (im2col)
 // stride==kernel convolution of TPT/clip/model.py:211,224 written as gather + GEMM.
-__global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__ out, unsigned short* __restrict__ outb,
+__global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__ out, _Float16* __restrict__ oh, _Float16* __restrict__ ol,
                               int n, int R, int ps, int Kp) {
     const int G = R / ps;
     const int K = 3 * ps * ps;
@@ -171,15 +190,21 @@ __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__
             } else o[e] = 0.f;
         }
         if (out) *(float4*)(out + (size_t)p * Kp + k4) = make_float4(o[0], o[1], o[2], o[3]);
-        if (outb) *(ushort4*)(outb + (size_t)p * Kp + k4) = make_ushort4(f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3]));
+        if (oh) {
+            h16x4 hh, ll;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)o[q]; ll[q] = (_Float16)((o[q] - (float)hh[q]) * 2048.0f); }
+            *(h16x4*)(oh + (size_t)p * Kp + k4) = hh;
+            *(h16x4*)(ol + (size_t)p * Kp + k4) = ll;
+        }
     }
 }
-int launch_im2col(const float* images, float* out, unsigned short* out_bf16, int n, int R, int ps, int Kp, hipStream_t st) {
+int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st) {
     RLCF_ARG_CHECK(n > 0 && R % ps == 0 && Kp % 4 == 0 && Kp >= 3 * ps * ps);
     const long total = (long)n * (R / ps) * (R / ps) * (Kp / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    im2col_kernel<<<dim3(blocks), dim3(256), 0, st>>>(images, out, out_bf16, n, R, ps, Kp);
+    im2col_kernel<<<dim3(blocks), dim3(256), 0, st>>>(images, out, (_Float16*)out_hi, (_Float16*)out_lo, n, R, ps, Kp);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
