@@ -1,0 +1,195 @@
+// Attention forward on the f16 matrix cores with f32-grade accuracy (split-f16, see gemm_f16x3.hip):
+// every operand of both contractions is carried as hi + lo*2^-11 and each product costs three
+// v_mfma_f32_32x32x16_f16.  Same dataflow as attention_f32.hip (one wave = 32 queries, both
+// contractions transposed so a lane owns one query, online softmax lane-local), but
+//   * NW waves (= NW query blocks of one (sequence, head)) share each converted K/V chunk in LDS;
+//   * K is stored [key][d] (rows padded to 144 B), V is stored TRANSPOSED [d][key-slot] (rows padded
+//     to 80 B) in the key order the S^T accumulator already has, so P feeds the second MFMA from
+//     registers and every operand fetch is one conflict-free ds_read_b128.
+// Replaces nn.MultiheadAttention's core (TPT/clip/model.py:175,185-187) in RLCF_PREC_F16X3 mode.
+#include "kernels.h"
+
+#define AX_KLD 72      // halves per K row  (64 + 8 pad  = 144 B)
+#define AX_VLD 40      // halves per Vt row (32 + 8 pad  =  80 B)
+
+__device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
+                                                                    int width, int causal, float* __restrict__ out,
+                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol) {
+    const rlcf_seq sq = seqs[blockIdx.y];
+    const int head = blockIdx.z;
+    if (blockIdx.x * NW * 32 >= sq.q_len) return;
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * AX_KLD], Kl[32 * AX_KLD], Vh[64 * AX_VLD], Vl[64 * AX_VLD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
+    const int ld = 3 * width;
+    const int qb = blockIdx.x * NW + wave;
+    const bool active = qb * 32 < sq.q_len;                      // waves past the end only help loading
+    const int qi = min(qb * 32 + l32, sq.q_len - 1);
+    const int nkeys = sq.pre_len + sq.q_len;
+    const int qpos = sq.pre_len + qi;
+    const int last_q = min(blockIdx.x * NW * 32 + NW * 32, sq.q_len);      // one past the last query of this workgroup
+    const int kend = causal ? min(nkeys, sq.pre_len + last_q) : nkeys;
+    const int my_kend = causal ? min(nkeys, sq.pre_len + qb * 32 + 32) : nkeys;
+
+    // Q fragments: lane (q, h) owns d = ks*16 + h*8 + [0,8) for ks = 0..3; scaled by 1/8 (exact) then split
+    h16x8 qh[4], ql[4];
+    {
+        const float* qp = qkv + (size_t)(sq.q_start + qi) * ld + head * HEAD_DIM + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 a = *(const float4*)(qp + ks * 16), b = *(const float4*)(qp + ks * 16 + 4);
+            const float v[8] = {a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f, b.x * 0.125f, b.y * 0.125f, b.z * 0.125f, b.w * 0.125f};
+            split8(v, qh[ks], ql[ks]);
+        }
+    }
+    f32x16 o0, o1, c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; c0[r] = 0.f; c1[r] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+
+    // chunk staging: thread -> (key, PER consecutive d); the key's V slot in the transposed tile is the position its
+    // score occupies in the S^T accumulator: key = (e&3) + 8*(2t + (e>>2)) + 4h  <->  slot = 16t + 8h + e
+    constexpr int PER = 32 / NW, PARTS = 64 / PER;
+    const int lkey = t / PARTS, d0 = (t % PARTS) * PER;
+    const int slot = ((lkey >> 4) << 4) | (((lkey >> 2) & 1) << 3) | (((lkey >> 3) & 1) << 2) | (lkey & 3);
+
+    for (int kc = 0; kc < kend; kc += 32) {
+        {
+            const int kap = kc + lkey;
+            float kv[PER], vv[PER];
+            if (kap < nkeys) {
+                const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                const float* p = qkv + (size_t)row * ld + head * HEAD_DIM + d0;
+#pragma unroll
+                for (int j = 0; j < PER / 4; ++j) {
+                    const float4 a = *(const float4*)(p + width + 4 * j), b = *(const float4*)(p + 2 * width + 4 * j);
+                    kv[4 * j] = a.x; kv[4 * j + 1] = a.y; kv[4 * j + 2] = a.z; kv[4 * j + 3] = a.w;
+                    vv[4 * j] = b.x; vv[4 * j + 1] = b.y; vv[4 * j + 2] = b.z; vv[4 * j + 3] = b.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) { kv[j] = 0.f; vv[j] = 0.f; }
+            }
+#pragma unroll
+            for (int j = 0; j < PER / 8; ++j) {
+                h16x8 a, b;
+                split8(kv + 8 * j, a, b);
+                *(h16x8*)(Kh + lkey * AX_KLD + d0 + 8 * j) = a;
+                *(h16x8*)(Kl + lkey * AX_KLD + d0 + 8 * j) = b;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const _Float16 hh = (_Float16)vv[j];
+                Vh[(d0 + j) * AX_VLD + slot] = hh;
+                Vl[(d0 + j) * AX_VLD + slot] = (_Float16)((vv[j] - (float)hh) * 2048.0f);
+            }
+        }
+        __syncthreads();
+        if (active && kc < my_kend) {
+            f32x16 s, sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; sc[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kh = *(const h16x8*)(Kh + l32 * AX_KLD + ks * 16 + h * 8);
+                const h16x8 kl = *(const h16x8*)(Kl + l32 * AX_KLD + ks * 16 + h * 8);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+            }
+            float cm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] += sc[r] * 0.00048828125f;
+                const int key = kc + mfma32_row(r, h);
+                if (key >= nkeys || (causal && key > qpos)) s[r] = -INFINITY;
+                cm = fmaxf(cm, s[r]);
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float mn = fmaxf(m, cm);
+            const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mn); ps += s[r]; }
+            lsum = lsum * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; c0[r] *= alpha; c1[r] *= alpha; }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float pv[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 8; ++e2) pv[e2] = s[8 * tt + e2];
+                h16x8 ph, pl;
+                split8(pv, ph, pl);
+                const h16x8 v0h = *(const h16x8*)(Vh + l32 * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v0l = *(const h16x8*)(Vl + l32 * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v1h = *(const h16x8*)(Vh + (32 + l32) * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v1l = *(const h16x8*)(Vl + (32 + l32) * AX_VLD + tt * 16 + h * 8);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, c0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, c1, 0, 0, 0);
+            }
+            m = mn;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const float ltot = lsum + __shfl_xor(lsum, 32);
+    if (qb * 32 + l32 < sq.q_len) {
+        const float inv = 1.0f / ltot;
+        const size_t obase = (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;
+            float v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v0[q] = (o0[4 * g + q] + c0[4 * g + q] * 0.00048828125f) * inv;
+                v1[q] = (o1[4 * g + q] + c1[4 * g + q] * 0.00048828125f) * inv;
+            }
+            if (out) {
+                *(float4*)(out + obase + d) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+                *(float4*)(out + obase + 32 + d) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            }
+            if (oh) {
+                h16x4 h0, l0, h1, l1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)((v0[q] - (float)h0[q]) * 2048.0f);
+                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)((v1[q] - (float)h1[q]) * 2048.0f);
+                }
+                *(h16x4*)(oh + obase + d) = h0; *(h16x4*)(ol + obase + d) = l0;
+                *(h16x4*)(oh + obase + 32 + d) = h1; *(h16x4*)(ol + obase + 32 + d) = l1;
+            }
+        }
+    }
+}
+
+int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
+                            void* out_hi, void* out_lo, hipStream_t st) {
+    RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
+    RLCF_ARG_CHECK(n_seq <= 65535 * 16);
+    if (max_q_len > 32) {
+        dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
+        RLCF_ARG_CHECK(grid.y <= 65535);
+        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+    } else {
+        dim3 grid(1, n_seq, width / HEAD_DIM);
+        RLCF_ARG_CHECK(grid.y <= 65535);
+        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+    }
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -262,7 +262,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             const BlockW& b = w.blk[l];
             TRY(launch_layernorm_fwd_split(x, b.ln1_w, b.ln1_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));
             TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
-            TRY(launch_attention_fwd_f32(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, nullptr, st, ws.ah.p, ws.al.p));
+            TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.ah.p, ws.al.p, st));
             e->last_flops += 4.0 * attn_pairs * W;
             TRY(gemm_pre(e, ws.ah.p, ws.al.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
             TRY(launch_layernorm_fwd_split(x, b.ln2_w, b.ln2_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 // chunk slot c ^ ((r>>2)&3); a 16-lane ds_read_b128 group then touches 16 distinct slots.
 #define V2_BM 256
 #define V2_BN 128
+#define V2_GROUP_M 4
 #define V2_STAGE 49152                  // bytes: Ahi 16K | Alo 16K | Whi 8K | Wlo 8K
 #define V2_ALO 16384
 #define V2_WHI 32768
@@ -164,7 +165,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / tiles_n) * V2_BM, n0 = (bid % tiles_n) * V2_BN;
+    // grouped order inside an XCD's range: V2_GROUP_M tile-rows are walked column by column, so the ~32 blocks an XCD
+    // runs concurrently form a 4 x 8 patch that shares 4 A panels and 8 W panels in its L2
+    const int tiles_m = (g.M + V2_BM - 1) / V2_BM;
+    const int per_group = V2_GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * V2_GROUP_M;
+    const int gsize = min(tiles_m - first_m, V2_GROUP_M), in_g = bid - grp * per_group;
+    const int m0 = (first_m + in_g % gsize) * V2_BM, n0 = (in_g / gsize) * V2_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
 

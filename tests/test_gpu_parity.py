@@ -118,6 +118,19 @@ ATT_CASES = [
 
 
 @pytest.mark.parametrize("name,seqs,T,W,causal", ATT_CASES)
+def test_attention_fwd_split_f16(L, dev, name, seqs, T, W, causal):
+    """The split-f16 attention kernel (3 f16 MFMAs per product) against the f64 reference: f32-grade."""
+    qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5)
+    sq = (L.Seq * len(seqs))(*[L.Seq(*s) for s in seqs])
+    sbuf = torch.frombuffer(bytearray(bytes(sq)), dtype=torch.int32).to(dev)
+    out = torch.zeros(T, W, device=dev)
+    L.check(L.lib().rlcf_attention_fwd(qkv.to(dev).data_ptr(), sbuf.data_ptr(), len(seqs), max(s[1] for s in seqs), W, causal,
+                                       out.data_ptr(), None, L.PREC_F16X3, st()))
+    ref = _attn_ref(qkv.double(), seqs, W, causal)
+    torch.testing.assert_close(out.cpu().double(), ref, atol=5e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,seqs,T,W,causal", ATT_CASES)
 def test_attention_fwd_bwd(L, dev, name, seqs, T, W, causal):
     qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5)
     sq = (L.Seq * len(seqs))(*[L.Seq(*s) for s in seqs])
