@@ -60,13 +60,13 @@ def cpu_baseline(ssd, rsd, geo, n_ctx=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
-    ap.add_argument("--batch", type=int, default=4, help="independent test images per tower pass (engine-internal batching)")
+    ap.add_argument("--batch", type=int, default=8, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -101,6 +101,8 @@ def main():
     views = torch.stack([synth.make_views(base + i, a.views, geo.image_resolution, device=dev) for i in range(total)])
     torch.cuda.synchronize()
 
+    eng.tta_batch(views[: min(total, max(a.batch, 1))], cfg)      # engine setup: sizes the batch workspaces once (not a step)
+    torch.cuda.synchronize()
     if a.warmup:
         eng.tta_batch(views[: a.warmup], cfg)
     torch.cuda.synchronize()
