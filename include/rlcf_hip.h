@@ -87,7 +87,7 @@ int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, floa
 int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len,
                        int width, int causal, float* out, float* lse, int precision, rlcf_stream stream);
 /* Backward (dX only): dqkv[T,3W] from dout[T,W]; dqkv must be zero-filled by the caller
- * (prefix keys accumulate across sequences).  key count per sequence <= 96 (text tower). */
+ * (keys accumulate across query blocks / sequences).  max_keys (prefix + queries) <= 320. */
 int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys,
                        int width, int causal, float* dqkv, rlcf_stream stream);
 
@@ -169,12 +169,23 @@ typedef struct {                 /* every pointer optional (NULL = not wanted); 
     float* reward_image_features;/* [n_sel,Dr]                               */
     float* final_logits;         /* [C]                                      */
     int32_t* top5;               /* [5]                                      */
+    float* ln_grad;              /* [(4L+4)*Wv] first-step gradient of the visual LayerNorm parameters (rlcf_tta_sample_ln) */
+    float* ln_after;             /* [(4L+4)*Wv] adapted LayerNorm parameters                                                 */
 } rlcf_tta_out;
 
 /* One iteration of the harness loop TPT/tpt_cls_rl.py:251-262: reset ctx and optimizer state,
  * test_time_tuning (:47-79), final one-view inference on views[0], top-5.  views [N,3,R,R]. */
 int rlcf_tta_sample(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args,
                     const rlcf_tta_out* out, rlcf_stream stream);
+/* LayerNorm-tuning variant (TPT/tune_cls_rl.py with CLIPCLS_TTA(only_visual=True, only_norm=True),
+ * custom_clip.py:364-497): the class text features are cached, the IMAGE encoder runs with grad and the tunable set is
+ * every visual LayerNorm weight/bias, laid out [ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w,
+ * ln_post.b].  Per call: reset LN state + optimizer, S tuning steps (backward through the n_sel selected views only:
+ * the other views get zero gradient), final clean-view inference.  ctx_in / sparse_backward / skip_final are ignored. */
+int rlcf_tta_sample_ln(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
+                       rlcf_stream stream);
+int rlcf_engine_ln_param_count(rlcf_engine*);
+
 /* Same for `count` consecutive samples (views [count,N,3,R,R]); top5 [count,5], final_logits
  * [count,C] (optional).  One host call per batch of test images. */
 int rlcf_tta_batch(rlcf_engine*, const float* views, int count, int N, const rlcf_tta_args* args,

@@ -149,3 +149,74 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
     out["final_logits"] = final
     out["top5"] = torch.topk(final, min(5, final.shape[1]), dim=-1).indices[0]
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm / backbone tuning variant (BASELINE configs[2]): TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True)
+
+def visual_ln_keys(sd):
+    """CLIPCLS_TTA.parameters() with only_norm: visual parameters whose name contains 'ln'
+    (TPT/clip/custom_clip.py:477-485), in named_parameters() order: ln_pre, per block ln_1, ln_2, ln_post."""
+    n = C.n_blocks(sd, "visual.transformer")
+    keys = ["visual.ln_pre.weight", "visual.ln_pre.bias"]
+    for i in range(n):
+        p = f"visual.transformer.resblocks.{i}."
+        keys += [p + "ln_1.weight", p + "ln_1.bias", p + "ln_2.weight", p + "ln_2.bias"]
+    return keys + ["visual.ln_post.weight", "visual.ln_post.bias"]
+
+
+def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor, hp: TTAHyper,
+                  reward_cls: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """One iteration of the harness loop TPT/tune_cls_rl.py:183-256 with model = CLIPCLS_TTA(only_visual=True,
+    only_norm=True): reset visual state -> test_time_tuning (tpt_cls_rl.py:47-79; the image encoder runs WITH grad,
+    custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference."""
+    out: Dict[str, torch.Tensor] = {}
+    if reward_cls is None:
+        reward_cls = reward_class_features(reward_sd, tokens)
+    with torch.no_grad():
+        cls_feat = C.l2_normalize(C.encode_text(student_sd, tokens))            # get_class_features, custom_clip.py:405-409
+    keys = visual_ln_keys(student_sd)
+    params = {k: student_sd[k].clone() for k in keys}                           # model.reset(): pristine visual state
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    scale = student_sd["logit_scale"].exp()
+
+    def logits_of(x, prm):
+        sd = dict(student_sd)
+        sd.update(prm)
+        return scale * C.l2_normalize(C.encode_image(sd, x)) @ cls_feat.t()
+
+    selected = None
+    for j in range(hp.tta_steps):
+        prm = {k: p.detach().requires_grad_(True) for k, p in params.items()}
+        if selected is None:
+            logits_all = logits_of(views, prm)
+            output, selected = select_confident_samples(logits_all, hp.selection_p)
+            with torch.no_grad():
+                rimg = C.l2_normalize(C.encode_image(reward_sd, views[selected]).float())
+        else:
+            logits_all = None
+            output = logits_of(views[selected], prm)
+        bs = output.shape[0]
+        _, index = torch.topk(output, hp.sample_k, dim=-1)
+        flat = index.flatten()
+        score = clip_score(reward_cls, rimg, flat, hp.sample_k, hp.clipscore_weight)
+        rewards = rewards_post_process(score if hp.process_batch else score.reshape(bs, -1), hp.reward_process, hp.reward_amplify)
+        rep = torch.repeat_interleave(output, hp.sample_k, dim=0)
+        loss = torch.mean(rewards * torch.nn.functional.cross_entropy(rep, flat, reduction="none"))
+        if hp.min_entropy_reg:
+            loss = loss + hp.min_entropy_w * avg_entropy(output)
+        grads = torch.autograd.grad(loss, [prm[k] for k in keys])
+        if j == 0:
+            out.update(logits=logits_all.detach(), selected_idx=selected.clone(), topk_idx=index.clone(),
+                       clip_score=score.detach().clone(), rewards=rewards.detach().clone(), loss=loss.detach().clone(),
+                       ln_grad=torch.cat([g.reshape(-1) for g in grads]))
+        with torch.no_grad():
+            for k, g in zip(keys, grads):
+                params[k], m[k], v2[k] = adamw_step(prm[k].detach(), g, m[k], v2[k], j + 1, hp)
+    with torch.no_grad():
+        final = logits_of(views[:1], params)
+    out["ln_after"] = torch.cat([params[k].reshape(-1) for k in keys])
+    out["final_logits"] = final
+    out["top5"] = torch.topk(final, min(5, final.shape[1]), dim=-1).indices[0]
+    return out

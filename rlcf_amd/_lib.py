@@ -39,7 +39,7 @@ class TTAArgs(C.Structure):
 
 
 TTA_OUT_FIELDS = ("logits", "entropy", "selected_idx", "topk_idx", "clip_score", "rewards", "loss", "dlogits",
-                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5")
+                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5", "ln_grad", "ln_after")
 
 
 class TTAOut(C.Structure):
@@ -74,6 +74,8 @@ SIGNATURES = {
     "rlcf_text_backward_dense": (I, [P, P, P, I, P, P, P]),
     "rlcf_tta_sample": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_batch": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
+    "rlcf_tta_sample_ln": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_engine_ln_param_count": (I, [P]),
     "rlcf_engine_last_flops": (D, [P]),
     "rlcf_engine_text_rows": (I, [P]),
     "rlcf_profile_gemm": (I, [I]),

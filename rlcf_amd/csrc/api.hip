@@ -73,6 +73,7 @@ int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int ma
 int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width, int causal,
                        float* dqkv, rlcf_stream stream) {
     RLCF_ARG_CHECK(qkv && dout && seqs && dqkv);
+    if (max_keys > 96) return launch_attention_bwd_long(qkv, dout, seqs, n_seq, max_keys, max_keys, width, causal, dqkv, (hipStream_t)stream);
     return launch_attention_bwd(qkv, dout, seqs, n_seq, max_keys, width, causal, dqkv, (hipStream_t)stream);
 }
 int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, rlcf_stream stream) {
@@ -169,7 +170,8 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,
                      &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
-                     &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits};
+                     &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
+                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat};
     for (DevBuf* d : all) d->release();
     delete e;
 }
@@ -222,6 +224,11 @@ int rlcf_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_ar
     RLCF_ARG_CHECK(e && views && args);
     return engine_tta_sample(e, views, N, args, out, (hipStream_t)stream);
 }
+int rlcf_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && views && args);
+    return engine_tta_sample_ln(e, views, N, args, out, (hipStream_t)stream);
+}
+int rlcf_engine_ln_param_count(rlcf_engine* e) { return e ? e->ln_count : 0; }
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);

@@ -245,3 +245,147 @@ int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* se
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward (dX only) for long sequences (image tower: 197 / 257 keys, LayerNorm-tuning path of
+// TPT/tune_cls_rl.py): one 256-thread workgroup per (sequence, head, 32-query block); K/V streamed in
+// 64-key chunks, the block's probability and dP rows resident in LDS.  dQ is stored, dK/dV are
+// accumulated with atomicAdd (several query blocks and, with a shared prefix, several sequences hit
+// the same key rows).  f32 VALU: the backward touches only the n_sel selected views.
+#define ABL_MAXK 320
+__global__ __launch_bounds__(256) void attention_bwd_long_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                 const rlcf_seq* __restrict__ seqs, int width, int causal,
+                                                                 float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const rlcf_seq sq = seqs[blockIdx.y];
+    const int head = blockIdx.z, q0 = blockIdx.x * 32;
+    if (q0 >= sq.q_len) return;
+    const int nk = sq.pre_len + sq.q_len, ld = 3 * width, t = threadIdx.x;
+    const int LDP = ABL_MAXK + 1;
+    float* Qs = sm;                  // [32][65]
+    float* Gs = Qs + 32 * 65;        // [32][65]
+    float* Ps = Gs + 32 * 65;        // [32][LDP]
+    float* Ds = Ps + 32 * LDP;       // [32][LDP]  dP
+    float* Kc = Ds + 32 * LDP;       // [64][65]
+    float* Dr = Kc + 64 * 65;        // [32] row terms D_i
+    for (int idx = t; idx < 32 * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63, qi = q0 + i;
+        const bool ok = qi < sq.q_len;
+        Qs[i * 65 + d] = ok ? qkv[(size_t)(sq.q_start + qi) * ld + head * HEAD_DIM + d] * 0.125f : 0.f;
+        Gs[i * 65 + d] = ok ? dout[(size_t)(sq.q_start + qi) * width + head * HEAD_DIM + d] : 0.f;
+    }
+    auto load_chunk = [&](int kc, int which /*1 = K, 2 = V*/) {
+        for (int idx = t; idx < 64 * 64; idx += 256) {
+            const int j = idx >> 6, d = idx & 63, kap = kc + j;
+            float v = 0.f;
+            if (kap < nk) {
+                const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                v = qkv[(size_t)row * ld + which * width + head * HEAD_DIM + d];
+            }
+            Kc[j * 65 + d] = v;
+        }
+    };
+    // pass 1: scores
+    for (int kc = 0; kc < nk; kc += 64) {
+        __syncthreads();
+        load_chunk(kc, 1);
+        __syncthreads();
+        for (int idx = t; idx < 32 * 64; idx += 256) {
+            const int i = idx >> 6, j = idx & 63, kap = kc + j;
+            float s = -INFINITY;
+            if (kap < nk && (!causal || kap <= sq.pre_len + q0 + i)) {
+                s = 0.f;
+#pragma unroll 16
+                for (int d = 0; d < 64; ++d) s += Qs[i * 65 + d] * Kc[j * 65 + d];
+            }
+            if (kap < ABL_MAXK) Ps[i * LDP + kap] = s;
+        }
+    }
+    __syncthreads();
+    if (t < 32) {
+        float mx = -INFINITY;
+        for (int j = 0; j < nk; ++j) mx = fmaxf(mx, Ps[t * LDP + j]);
+        float sum = 0.f;
+        for (int j = 0; j < nk; ++j) { const float e = expf(Ps[t * LDP + j] - mx); Ps[t * LDP + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < nk; ++j) Ps[t * LDP + j] *= inv;
+    }
+    // pass 2: dP = dO V^T, dV += P^T dO
+    for (int kc = 0; kc < nk; kc += 64) {
+        __syncthreads();
+        load_chunk(kc, 2);
+        __syncthreads();
+        for (int idx = t; idx < 32 * 64; idx += 256) {
+            const int i = idx >> 6, j = idx & 63, kap = kc + j;
+            if (kap >= nk) continue;
+            float dp = 0.f;
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) dp += Gs[i * 65 + d] * Kc[j * 65 + d];
+            Ds[i * LDP + kap] = dp;
+        }
+        for (int idx = t; idx < 64 * 64; idx += 256) {
+            const int j = idx >> 6, d = idx & 63, kap = kc + j;
+            if (kap >= nk) continue;
+            float s = 0.f;
+            for (int i = 0; i < 32; ++i) s += Ps[i * LDP + kap] * Gs[i * 65 + d];
+            const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+            atomicAdd(dqkv + (size_t)row * ld + 2 * width + head * HEAD_DIM + d, s);
+        }
+    }
+    __syncthreads();
+    if (t < 32) {
+        float D = 0.f;
+        for (int j = 0; j < nk; ++j) D += Ps[t * LDP + j] * Ds[t * LDP + j];
+        Dr[t] = D;
+    }
+    __syncthreads();
+    for (int idx = t; idx < 32 * nk; idx += 256) {
+        const int i = idx / nk, j = idx - i * nk;
+        Ps[i * LDP + j] = Ps[i * LDP + j] * (Ds[i * LDP + j] - Dr[i]);      // dS
+    }
+    // pass 3: dQ = dS K / 8, dK += dS^T Q / 8  (Qs already carries the 1/8)
+    const int qi_t = t >> 3, d0 = (t & 7) * 8;
+    float dq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] = 0.f;
+    for (int kc = 0; kc < nk; kc += 64) {
+        __syncthreads();
+        load_chunk(kc, 1);
+        __syncthreads();
+        const int jn = min(64, nk - kc);
+        for (int j = 0; j < jn; ++j) {
+            const float ds = Ps[qi_t * LDP + kc + j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dq[e] += ds * Kc[j * 65 + d0 + e];
+        }
+        for (int idx = t; idx < 64 * 64; idx += 256) {
+            const int j = idx >> 6, d = idx & 63, kap = kc + j;
+            if (kap >= nk) continue;
+            float s = 0.f;
+            for (int i = 0; i < 32; ++i) s += Ps[i * LDP + kap] * Qs[i * 65 + d];
+            const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+            atomicAdd(dqkv + (size_t)row * ld + width + head * HEAD_DIM + d, s);
+        }
+    }
+    if (q0 + qi_t < sq.q_len) {
+        float* p = dqkv + (size_t)(sq.q_start + q0 + qi_t) * ld + head * HEAD_DIM + d0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = dq[e] * 0.125f;
+    }
+}
+
+int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,
+                              int width, int causal, float* dqkv, hipStream_t st) {
+    RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_keys > 0 && max_keys <= ABL_MAXK && max_q_len > 0);
+    const size_t bytes = (size_t)(2 * 32 * 65 + 2 * 32 * (ABL_MAXK + 1) + 64 * 65 + 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
+    RLCF_ARG_CHECK(grid.y <= 65535);
+    attention_bwd_long_kernel<<<grid, dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -58,6 +58,7 @@ struct ClipModel {
     const float *tok_emb = nullptr, *tpos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
     const float *tproj = nullptr;          // [Wt, D] as stored
     const float *tprojT = nullptr;         // [D, Wt]
+    const float* vproj = nullptr;          // [Wv, D] as stored (backward operand)
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
     std::unordered_map<const float*, std::pair<void*, void*>> split_of;   // f32 weight -> (hi, lo) f16 copies (F16X3 mode)
@@ -88,6 +89,10 @@ struct rlcf_engine {
     // sample-batched step (rlcf_tta_batch): B test images share every tower pass
     DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;
     int b_cap = 0, sp_groups = 0;
+    // LayerNorm-tuning path (CLIPCLS_TTA only_norm): all visual LN parameters of the student in one tunable buffer
+    DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
+    int ln_count = 0;                // (4*layers + 4) * Wv
+    size_t bwd_elems = 0;
     DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
     double last_flops = 0.0;
@@ -109,5 +114,6 @@ int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt
 int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st);
 int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                      hipStream_t st);

@@ -179,8 +179,32 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     NEED(m.lnpost_w = rawp(m, "visual.ln_post.weight", Wv)); NEED(m.lnpost_b = rawp(m, "visual.ln_post.bias", Wv));
     const float* vproj = rawp(m, "visual.proj", (size_t)Wv * D);
     NEED(vproj);
+    m.vproj = vproj;
     NEED(m.vprojT = make_transposed(m, vproj, Wv, D, st));
     TRY(resolve_tower(m, m.vis, "visual.transformer", c.vision_layers, Wv, false, st));
+    if (which == RLCF_STUDENT) {
+        // every visual LayerNorm parameter in one tunable buffer (CLIPCLS_TTA.parameters() with only_norm,
+        // custom_clip.py:477-485, in named_parameters order); the towers read LN weights from it
+        const int L = c.vision_layers;
+        e->ln_count = (4 * L + 4) * Wv;
+        const size_t nb = (size_t)e->ln_count * sizeof(float);
+        TRY(e->ln_params.ensure(nb)); TRY(e->ln_init.ensure(nb)); TRY(e->ln_grad.ensure(nb)); TRY(e->ln_m.ensure(nb)); TRY(e->ln_v.ensure(nb));
+        float* P = e->ln_params.as<float>();
+        std::vector<const float**> slots = {&m.lnpre_w, &m.lnpre_b};
+        for (BlockW& b : m.vis.blk) { slots.push_back(&b.ln1_w); slots.push_back(&b.ln1_b); slots.push_back(&b.ln2_w); slots.push_back(&b.ln2_b); }
+        slots.push_back(&m.lnpost_w); slots.push_back(&m.lnpost_b);
+        for (size_t i = 0; i < slots.size(); ++i) {
+            RLCF_HIP_CHECK(hipMemcpyAsync(P + i * Wv, *slots[i], Wv * sizeof(float), hipMemcpyDeviceToDevice, st));
+            *slots[i] = P + i * Wv;
+        }
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_init.p, P, nb, hipMemcpyDeviceToDevice, st));
+        std::vector<int32_t> idx(e->max_views);
+        for (int i = 0; i < e->max_views; ++i) idx[i] = i * m.tokens;
+        TRY(e->cls_row_idx.ensure(idx.size() * sizeof(int32_t)));
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->cls_row_idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        RLCF_HIP_CHECK(hipStreamSynchronize(st));
+        TRY(e->vit_inv_norm.ensure(e->max_views * sizeof(float)));
+    }
     NEED(m.tok_emb = rawp(m, "token_embedding.weight", (size_t)c.vocab_size * Wt));
     NEED(m.tpos = rawp(m, "positional_embedding", (size_t)c.context_length * Wt));
     NEED(m.lnf_w = rawp(m, "ln_final.weight", Wt));  NEED(m.lnf_b = rawp(m, "ln_final.bias", Wt));
@@ -241,7 +265,8 @@ static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
     return RLCF_OK;
 }
 static int bwd_ensure(rlcf_engine* e, int T, int width) {
-    if (T <= e->bwd_T) return RLCF_OK;
+    if ((size_t)T * width <= e->bwd_elems) return RLCF_OK;
+    e->bwd_elems = (size_t)T * width;
     const size_t n = (size_t)T * width * sizeof(float);
     TRY(e->dX.ensure(n)); TRY(e->dA.ensure(n)); TRY(e->dH.ensure(n)); TRY(e->dF.ensure(4 * n)); TRY(e->dQKV.ensure(3 * n));
     e->bwd_T = T;
@@ -299,7 +324,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
 
 // dX-only backward of the above (all weights frozen: TPT/tpt_cls_rl.py:103-105); dX in/out in e->dX.
 static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_keys,
-                                long attn_pairs, int causal, int T, hipStream_t st) {
+                                long attn_pairs, int causal, int T, hipStream_t st, float* ln_grad = nullptr, int max_q_len = 0) {
     const int W = w.width, L = w.layers;
     float *dX = e->dX.as<float>(), *dA = e->dA.as<float>(), *dH = e->dH.as<float>(), *dF = e->dF.as<float>(), *dQKV = e->dQKV.as<float>();
     for (int l = L - 1; l >= 0; --l) {
@@ -307,13 +332,15 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         const SavedLayer& s = ws.sv[l];
         TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st));
         TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, nullptr, nullptr, T, W, st));
+        float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
+        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st));
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
-        TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
+        if (max_keys > 96) TRY(launch_attention_bwd_long(s.qkv, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, max_keys, W, causal, dQKV, st));
+        else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, nullptr, nullptr, T, W, st));
+        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st));
     }
     return RLCF_OK;
 }
@@ -537,6 +564,8 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
         io0.txt = e->txt0.as<float>();
         TRY(text_forward(e, s, e->lay[0], e->tt, e->ctx_init.as<float>(), io0, false, st));
     }
+    TRY(e->txt0T.ensure(cd));
+    TRY(launch_transpose(e->txt0.as<float>(), e->txt0T.as<float>(), C, D, st));
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     e->sp_max_e = 0; e->sp_groups = 0; e->b_cap = 0;   // sparse / batch layouts are (re)built lazily
     return RLCF_OK;
@@ -845,5 +874,105 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
         i += B;
     }
     e->last_flops = flops / count;
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ LayerNorm-tuning step (BASELINE configs[2])
+// Image tower forward of n views WITH saved activations (CLIPCLS_TTA.forward, custom_clip.py:423-432).
+static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st) {
+    const rlcf_clip_cfg& c = m.cfg;
+    const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
+    TRY(tower_ensure_saved(e->vt, T, Wv, c.vision_layers));
+    TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
+    TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv, n * G2, Wv, m.Kp,
+             1.f, RLCF_EPI_NONE, st));
+    TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.sv[0].x, n, tok, Wv, st));
+    TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, true, st));
+    TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
+    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), nullptr, n, Wv, st));
+    TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
+             RLCF_EPI_NONE, st));
+    TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));
+    return RLCF_OK;
+}
+// d loss / d (visual LN parameters) given dlogits [n, C] of the n views whose activations vit_forward_saved holds.
+static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int n, const float* dlogits, float* ln_grad, hipStream_t st) {
+    const rlcf_clip_cfg& c = m.cfg;
+    const int Wv = c.vision_width, tok = m.tokens, T = n * tok, D = c.embed_dim, C = e->C, L = c.vision_layers;
+    TRY(bwd_ensure(e, T, Wv));
+    TRY(e->dfeat.ensure((size_t)e->max_views * D * sizeof(float))); TRY(e->dcls.ensure((size_t)e->max_views * Wv * sizeof(float)));
+    RLCF_HIP_CHECK(hipMemsetAsync(ln_grad, 0, (size_t)e->ln_count * sizeof(float), st));
+    // d feat = scale * dlogits @ class_features  (logits = scale * feat @ class_features^T, custom_clip.py:429-430)
+    TRY(launch_dimg(dlogits, e->txt0.as<float>(), n, C, D, m.logit_scale_exp, e->dfeat.as<float>(), st));
+    TRY(launch_l2norm_bwd(feats, e->dfeat.as<float>(), e->vit_inv_norm.as<float>(), e->dfeat.as<float>(), n, D, st));
+    TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
+    float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
+    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), m.lnpost_w, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
+    TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
+    TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok));
+    TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st));
+    return RLCF_OK;
+}
+
+int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    ClipModel& r = e->model[RLCF_REWARD];
+    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim;
+    const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
+    if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
+    RLCF_ARG_CHECK(r.cfg.image_resolution == s.cfg.image_resolution && s.cfg.vision_width * 0 + s.tokens <= 320);
+    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const size_t nb = (size_t)e->ln_count * sizeof(float);
+    const rlcf_tta_out none{};
+    if (!out) out = &none;
+    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
+    e->last_flops = 0.0;
+    // model.reset() (visual.load_state_dict(initial_state_dict), custom_clip.py:456-458) + optimizer state reset
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
+    const float* cls_feat = e->txt0.as<float>();           // cached class text features (custom_clip.py:405-409)
+    for (int j = 0; j < a->tta_steps; ++j) {
+        if (j == 0) {
+            // all N views decide the selection; only the selected ones carry gradient (rows outside idx get zero grad)
+            TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
+            TRY(engine_logits(e, e->img_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
+            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
+            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st));
+            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
+            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
+            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
+            COPY_OUT(out->reward_image_features, e->rimg.p, (size_t)n_sel * Dr * sizeof(float));
+        }
+        TRY(vit_forward_saved(e, s, e->views_sel.as<float>(), n_sel, e->ln_feat.as<float>(), st));
+        TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
+        TRY(launch_reward_loss(e->sel_logits.as<float>(), C, nullptr, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
+                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
+        TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st));
+        if (j == 0) {
+            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
+            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->loss, e->loss.p, sizeof(float));
+            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
+            COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
+        }
+        TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
+                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+    }
+    // final clean-view inference with the adapted LayerNorms (tune_cls_rl.py:219-221)
+    TRY(engine_encode_image(e, RLCF_STUDENT, views, 1, e->img_feat.as<float>(), st));
+    TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
+    TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
+    COPY_OUT(out->ln_after, e->ln_params.p, nb);
+    COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
+    COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    // leave the engine in its pristine state for the prompt path (which assumes frozen, pristine LayerNorms)
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
     return RLCF_OK;
 }

@@ -71,3 +71,8 @@ int launch_final_logits_batched(const float* img, int img_row_stride, const floa
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
                             void* out_hi, void* out_lo, hipStream_t st);
+int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,
+                              int width, int causal, float* dqkv, hipStream_t st);
+int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
+                            int tokens, int width, hipStream_t st);
+int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st);

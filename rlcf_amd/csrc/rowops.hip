@@ -518,3 +518,67 @@ int launch_broadcast_rows(const float* in, float* out, int n, int B, hipStream_t
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+// ---------------------------------------------------------------- ln_pre parameter gradients
+// backward of vit_assemble w.r.t. (gamma, beta) of ln_pre: dgamma += dy * xhat, dbeta += dy, xhat recomputed.
+__global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, const float* __restrict__ dy,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int tokens,
+                                                               int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= n * tokens) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / tokens, tok = row % tokens;
+    const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
+    const float* pr = pos + (size_t)tok * width;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        v[j] = c < width ? src[c] + pr[c] : 0.f;
+        s += v[j];
+    }
+    const float mu = wave_sum(s) / width;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) { float d = v[j] - mu; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) {
+            const float g = dy[(size_t)row * width + c];
+            atomicAdd(dgamma + c, g * (v[j] - mu) * rstd);
+            atomicAdd(dbeta + c, g);
+        }
+    }
+}
+int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
+                            int tokens, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE && n > 0);
+    const int rows = n * tokens;
+    vit_assemble_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, dy, dgamma, dbeta, n,
+                                                                                                   tokens, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// d img[i,:] = scale * sum_c dlogits[i,c] * txt[c,:]    (backward of logits = scale * img @ txt^T w.r.t. img)
+__global__ void dimg_kernel(const float* __restrict__ dlogits, const float* __restrict__ txt, int C, int D, float scale, float* __restrict__ dimg) {
+    const int i = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += dlogits[(size_t)i * C + c] * txt[(size_t)c * D + d];
+        dimg[(size_t)i * D + d] = scale * s;
+    }
+}
+int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && C > 0 && D > 0);
+    dimg_kernel<<<dim3(n), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -167,6 +167,23 @@ class Engine:
         L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
         return o
 
+    def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig) -> Dict[str, torch.Tensor]:
+        """LayerNorm-tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True))."""
+        views = views.to(self.device, torch.float32).contiguous()
+        N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
+        n_sel = int(N * cfg.selection_p)
+        npar = int(self.lib.rlcf_engine_ln_param_count(self.h))
+        dev = self.device
+        o = dict(final_logits=torch.empty(1, Cn, device=dev), top5=torch.empty(5, dtype=torch.int32, device=dev),
+                 ln_after=torch.empty(npar, device=dev), ln_grad=torch.empty(npar, device=dev),
+                 logits=torch.empty(N, Cn, device=dev), selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
+                 topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n_sel * K, device=dev),
+                 rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
+        co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
+        a = cfg.c_args()
+        L.check(self.lib.rlcf_tta_sample_ln(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_ln")
+        return o
+
     def tta_batch(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):
         """views [count,N,3,R,R] -> top5 [count,5] (and final logits [count,C])."""
         views = views.to(self.device, torch.float32).contiguous()

@@ -185,6 +185,86 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4):
+    """TPT/tune_cls_rl.py harness body (:206-227) around the reference's own CLIPCLS_TTA(only_norm=True) and
+    test_time_tuning, with taps on the intermediates."""
+    s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    s_sd = synth.make_state_dict(s_geo, seed=11)
+    r_sd = synth.make_state_dict(r_geo, seed=23)
+    install_models(ref, {student: (s_geo, s_sd)})
+    bank = Bank(s_geo, n_cls, n_ctx)
+    ref.custom.tokenize = bank.tokenize
+    model = ref.custom.CLIPCLS_TTA("cpu", bank.classnames, arch=student, prompt_prefix="a_photo_of_a", only_visual=True,
+                                   momentum_update=False, only_norm=True)
+    assert torch.equal(model.tokenized_prompts, bank.tokens)
+    trainable = model.parameters()
+    names = [n for n, p in model.clip_model.visual.named_parameters() if "ln" in n or "bn" in n]
+    optimizer = torch.optim.AdamW(trainable, hp["lr"], weight_decay=hp["weight_decay"])
+    args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"], min_entropy_reg=0, min_entropy_w=0.2,
+                                 gpu=None, tpt=True)
+    install_models(ref, {reward: (r_geo, r_sd)})
+    rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True, amplify_rewards=False, sample_k=hp["sample_k"],
+                                     reward_process=True, process_batch=False)
+    rm.set_class_features(tokenized_classes=model.tokenized_prompts)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scaler = torch.cuda.amp.GradScaler(init_scale=1000)
+    views = synth.make_views(view_seed, n_views, s_geo.image_resolution)
+    taps = {}
+    orig_select = ref.tpt.select_confident_samples
+
+    def tap_select(logits, top):
+        out, idx = orig_select(logits, top)
+        if "logits" not in taps:
+            taps["logits"] = logits.detach().clone()
+            taps["selected_idx"] = idx.clone()
+        return out, idx
+
+    orig_score, orig_post = rm.CLIPScore, rm.rewards_post_process
+
+    def tap_score(*a, **k):
+        s = orig_score(*a, **k)
+        if "clip_score" not in taps:
+            taps["clip_score"] = s.detach().clone()
+            taps["topk_idx"] = k["class_index"].clone()
+        return s
+
+    def tap_post(x):
+        r = orig_post(x)
+        taps.setdefault("rewards", r.detach().clone())
+        return r
+
+    ref.tpt.select_confident_samples = tap_select
+    rm.CLIPScore, rm.rewards_post_process = tap_score, tap_post
+    pmap = dict(model.clip_model.visual.named_parameters())
+    first_grads = {}
+    for n in names:
+        pmap[n].register_hook(lambda g, n=n: first_grads.setdefault(n, g.detach().clone()))
+    model.reset()
+    model.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.tpt.test_time_tuning(model, views, optimizer, scaler, args, reward_model=rm)
+    model.eval()
+    with torch.no_grad():
+        final = model(views[:1])
+    ref.tpt.select_confident_samples = orig_select
+    out = dict(logits=taps["logits"], selected_idx=taps["selected_idx"], topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]),
+               clip_score=taps["clip_score"], rewards=taps["rewards"],
+               ln_grad=torch.cat([first_grads[n].reshape(-1) for n in names]),
+               ln_after=torch.cat([pmap[n].detach().reshape(-1) for n in names]),
+               final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0])
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+LN_CASES = {
+    "ln_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3)),
+    "ln_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3)),
+    "ln_small_s1": ("small", "small", 16, 40, dict(lr=1e-3, selection_p=0.25)),
+    "ln_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-4)),
+}
+
+
 def save(name, arrays, meta):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
@@ -290,6 +370,15 @@ def main():
             save("ops", gen_ops(ref), {})
         elif grp == "modules":
             save("modules", gen_modules(ref), {})
+        elif grp in ("ln", "lnb16"):
+            for name in ([k for k in LN_CASES if "b16" not in k] if grp == "ln" else ["ln_b16_n8"]):
+                student, reward, n, c, over = LN_CASES[name]
+                hp = dict(BASE_HP, **over)
+                arrays = run_reference_ln(ref, student, reward, n, c, hp)
+                meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23, view_seed=1000,
+                            bank_seed=7, n_ctx=4, **hp)
+                save(name, arrays, meta)
+                print(f"  {name}: idx={arrays['selected_idx']} top5={arrays['top5']} |g|={np.linalg.norm(arrays['ln_grad']):.3e}")
         else:
             for name in GROUPS[grp]:
                 student, reward, n, c, over = TTA_CASES[name]

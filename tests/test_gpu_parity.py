@@ -145,7 +145,7 @@ def test_attention_fwd_bwd(L, dev, name, seqs, T, W, causal):
     ref = _attn_ref(q64, seqs, W, causal)
     torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=3e-6, rtol=1e-5)
     mk = max(s[1] + s[3] for s in seqs)
-    if mk <= 96:
+    if mk <= 320:
         do = synth.normal(3, "att.do." + name, (T, W))
         (ref * do.double()).sum().backward()
         dq = torch.zeros(T, 3 * W, device=dev)
@@ -525,3 +525,44 @@ def test_autograd_route_matches_reference_gradient(L, dev):
     assert (og - gr).norm() / gr.norm() < 1e-3
     torch.testing.assert_close(tpt_cls_rl.avg_entropy(output.detach()).cpu(), RR.avg_entropy(output.detach().cpu()), atol=1e-5, rtol=1e-5)
     runtime.reset_session()
+
+
+# ------------------------------------------------------------------------------ LayerNorm-tuning path (BASELINE configs[2])
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("name", ["ln_tiny_s1", "ln_tiny_s3", "ln_small_s1", "ln_b16_n8"])
+def test_ln_tuning_matches_reference_fixture(L, dev, name, prec):
+    """rlcf_tta_sample_ln vs the reference's CLIPCLS_TTA(only_norm=True) + test_time_tuning run (TPT/tune_cls_rl.py)."""
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated")
+    g, meta = load_golden(name)
+    from rlcf_amd.engine import Engine
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"], device=dev)
+    rsd = synth.make_state_dict(rg, meta["reward_seed"], device=dev)
+    eng = Engine(sg, rg, meta["n_views"], meta["n_cls"], prec)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]), device=dev)].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution, device=dev)
+    o = eng.tta_sample_ln(views, _cfg_from_meta(meta))
+    torch.cuda.synchronize()
+    c = lambda k: o[k].cpu()
+    assert c("selected_idx").tolist() == g["selected_idx"].tolist()
+    assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
+    torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    multi = meta["tta_steps"] > 1
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    if not multi:
+        gr, og = g["ln_grad"], c("ln_grad")
+        assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 2e-3
+    d = (c("ln_after") - g["ln_after"]).abs()
+    assert (d > 0.1 * meta["lr"]).float().mean() < (0.05 if multi else 0.01)
+    # the prompt path still sees pristine LayerNorms afterwards
+    o2 = eng.tta_sample_ln(views, _cfg_from_meta(meta))
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
+    eng.close()
