@@ -181,10 +181,15 @@ int rlcf_tta_sample(rlcf_engine*, const float* views, int N, const rlcf_tta_args
  * custom_clip.py:364-497): the class text features are cached, the IMAGE encoder runs with grad and the tunable set is
  * every visual LayerNorm weight/bias, laid out [ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w,
  * ln_post.b].  Per call: reset LN state + optimizer, S tuning steps (backward through the n_sel selected views only:
- * the other views get zero gradient), final clean-view inference.  ctx_in / sparse_backward / skip_final are ignored. */
+ * the other views get zero gradient), final clean-view inference (unless skip_final).  The engine's live LayerNorms are
+ * restored to the pristine state on return; ctx_in / sparse_backward are ignored. */
 int rlcf_tta_sample_ln(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
                        rlcf_stream stream);
 int rlcf_engine_ln_param_count(rlcf_engine*);
+/* copy the student's visual LayerNorm parameters out of / into the engine (layout above); `pristine` selects the
+ * reset state (initial_state_dict, custom_clip.py:395-399) instead of the live one. */
+int rlcf_engine_get_ln_params(rlcf_engine*, float* out, int pristine, rlcf_stream stream);
+int rlcf_engine_set_ln_params(rlcf_engine*, const float* in, rlcf_stream stream);
 
 /* Same for `count` consecutive samples (views [count,N,3,R,R]); top5 [count,5], final_logits
  * [count,C] (optional).  One host call per batch of test images. */

@@ -76,6 +76,8 @@ SIGNATURES = {
     "rlcf_tta_batch": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_tta_sample_ln": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_engine_ln_param_count": (I, [P]),
+    "rlcf_engine_get_ln_params": (I, [P, P, I, P]),
+    "rlcf_engine_set_ln_params": (I, [P, P, P]),
     "rlcf_engine_last_flops": (D, [P]),
     "rlcf_engine_text_rows": (I, [P]),
     "rlcf_profile_gemm": (I, [I]),

@@ -229,6 +229,17 @@ int rlcf_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta
     return engine_tta_sample_ln(e, views, N, args, out, (hipStream_t)stream);
 }
 int rlcf_engine_ln_param_count(rlcf_engine* e) { return e ? e->ln_count : 0; }
+int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && out && e->ln_count > 0);
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->ln_init.p : e->ln_params.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return RLCF_OK;
+}
+int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && in && e->ln_count > 0);
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RLCF_OK;
+}
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);

@@ -157,7 +157,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     const rlcf_clip_cfg& c = m.cfg;
     for (auto& d : m.derived) d.release();
     m.derived.clear();
-    m.derived.reserve(24 * (c.vision_layers + c.text_layers) + 16);
+    m.derived.reserve(32 * (c.vision_layers + c.text_layers) + 16);
     m.split_of.clear();
     const int Wv = c.vision_width, Wt = c.text_width, ps = c.vision_patch_size, D = c.embed_dim;
     const int K = 3 * ps * ps;
@@ -181,7 +181,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     NEED(vproj);
     m.vproj = vproj;
     NEED(m.vprojT = make_transposed(m, vproj, Wv, D, st));
-    TRY(resolve_tower(m, m.vis, "visual.transformer", c.vision_layers, Wv, false, st));
+    TRY(resolve_tower(m, m.vis, "visual.transformer", c.vision_layers, Wv, which == RLCF_STUDENT, st));   // W^T: LN-tuning backward
     if (which == RLCF_STUDENT) {
         // every visual LayerNorm parameter in one tunable buffer (CLIPCLS_TTA.parameters() with only_norm,
         // custom_clip.py:477-485, in named_parameters order); the towers read LN weights from it
@@ -965,13 +965,15 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
         TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
                          a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
     }
-    // final clean-view inference with the adapted LayerNorms (tune_cls_rl.py:219-221)
-    TRY(engine_encode_image(e, RLCF_STUDENT, views, 1, e->img_feat.as<float>(), st));
-    TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
-    TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
     COPY_OUT(out->ln_after, e->ln_params.p, nb);
-    COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
-    COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    if (!a->skip_final) {
+        // final clean-view inference with the adapted LayerNorms (tune_cls_rl.py:219-221)
+        TRY(engine_encode_image(e, RLCF_STUDENT, views, 1, e->img_feat.as<float>(), st));
+        TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
+        TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
+        COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
+        COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    }
     // leave the engine in its pristine state for the prompt path (which assumes frozen, pristine LayerNorms)
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
     return RLCF_OK;

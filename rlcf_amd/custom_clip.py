@@ -142,3 +142,75 @@ def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, cl
     if classnames is None:
         classnames = ["c0"]
     return ClipTestTimeTuning(device, classnames, None, arch=clip_arch, n_ctx=n_ctx, ctx_init=ctx_init, learned_cls=learned_cls)
+
+
+class CLIPCLS_TTA(nn.Module):
+    """TPT/clip/custom_clip.py:364-497 — CLIP classification with test-time adaptation of the image encoder.
+    Built: `only_visual=True, only_norm=True` (BASELINE configs[2], the `--tune_norm 1` setting): the tunable set is every
+    visual LayerNorm weight/bias.  `parameters()` returns ONE flat tensor holding them in named_parameters order
+    ([ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w, ln_post.b]) instead of 4L+4 tensors."""
+
+    def __init__(self, device, classnames, arch="ViT-L/14", prompt_prefix=None, only_visual=True, momentum_update=False,
+                 update_freq=256, update_w=1.0, momentum=0.9999, only_norm=False):
+        super().__init__()
+        if not only_visual or not only_norm:
+            raise NotImplementedError("full image-encoder / text tuning is not built yet: only only_visual=True, only_norm=True "
+                                      "(SURVEY.md §8 a14)")
+        if momentum_update:
+            raise NotImplementedError("momentum_update (cross-sample EMA, custom_clip.py:460-475) is not built: it makes test "
+                                      "samples dependent (SURVEY.md §8e)")
+        self.clip_model, _, _ = clip_store.load(arch, device=device)
+        runtime.SESSION.set_student(self.clip_model)
+        self.device, self.prompt_prefix = device, prompt_prefix
+        self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
+        self._ln = None
+        self._set_classnames(classnames)
+
+    def _set_classnames(self, classnames):
+        sd = self.clip_model.state_dict
+        self.classnames = [name.replace("_", " ") for name in classnames]
+        self.n_cls = len(classnames)
+        prompts = [self.prompt_prefix + " " + name + "." for name in self.classnames]     # prefix used raw (custom_clip.py:377-380)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.tokenized_prompts = clip_store.tokenize(prompts).to(dev)
+        # the engine's "prompt" is the raw prefix: its first token after SOT, looked up in the embedding table, so the
+        # cached text features are exactly encode_text(tokenized_prompts) (get_class_features, custom_clip.py:405-409)
+        tok0 = self.tokenized_prompts[0]
+        emb = sd["token_embedding.weight"]
+        ctx = emb[tok0[1:2].to(emb.device)].float()
+        runtime.SESSION.set_bank(self.tokenized_prompts, 1, ctx)
+
+    @property
+    def ln(self) -> nn.Parameter:
+        if self._ln is None:
+            eng = runtime.SESSION.engine()
+            self._ln_init = eng.ln_params(pristine=True)
+            self._ln = nn.Parameter(self._ln_init.clone())
+        return self._ln
+
+    def parameters(self, recurse: bool = True):            # custom_clip.py:477-485
+        return [self.ln]
+
+    @torch.no_grad()
+    def reset(self):                                       # custom_clip.py:456-458
+        self.ln.data.copy_(self._ln_init)
+
+    @torch.no_grad()
+    def reset_classnames_and_state(self, classnames, arch):   # custom_clip.py:434-454
+        self._set_classnames(classnames)
+        if self._ln is not None:
+            self.reset()
+
+    def momentum_update_model(self):                       # no-op unless momentum_update (not built)
+        return
+
+    @torch.no_grad()
+    def forward(self, image):
+        """custom_clip.py:423-432 with the current LayerNorm parameters (inference only: the training-time forward and
+        backward are fused inside rlcf_tta_sample_ln, called by rlcf_amd.tpt_cls_rl.test_time_tuning)."""
+        eng = runtime.SESSION.engine(image.shape[0])
+        eng.set_ln_params(self.ln.data)
+        img = eng.encode_image(L.STUDENT, image)
+        out = eng.logits(img, eng.text_features(runtime.SESSION.ctx_init.to(img.device)))
+        eng.set_ln_params(self._ln_init)
+        return out

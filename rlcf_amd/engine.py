@@ -167,7 +167,16 @@ class Engine:
         L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
         return o
 
-    def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig) -> Dict[str, torch.Tensor]:
+    def ln_params(self, pristine: bool = False) -> torch.Tensor:
+        out = torch.empty(int(self.lib.rlcf_engine_ln_param_count(self.h)), device=self.device)
+        L.check(self.lib.rlcf_engine_get_ln_params(self.h, _ptr(out), 1 if pristine else 0, _stream()), "get_ln_params")
+        return out
+
+    def set_ln_params(self, p: torch.Tensor) -> None:
+        p = p.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_set_ln_params(self.h, _ptr(p), _stream()), "set_ln_params")
+
+    def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
         """LayerNorm-tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True))."""
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
@@ -180,7 +189,7 @@ class Engine:
                  topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n_sel * K, device=dev),
                  rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
-        a = cfg.c_args()
+        a = cfg.c_args(skip_final)
         L.check(self.lib.rlcf_tta_sample_ln(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_ln")
         return o
 

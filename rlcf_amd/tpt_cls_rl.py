@@ -56,6 +56,14 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
         return
     cfg = _config(args, optimizer, reward_model)
     eng = runtime.SESSION.engine(inputs.shape[0])
+    if not hasattr(model, "prompt_learner"):               # CLIPCLS_TTA: LayerNorm tuning (TPT/tune_cls_rl.py:31,217)
+        if not torch.equal(model.ln.data, model._ln_init):
+            raise NotImplementedError("LayerNorm tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
+        out = eng.tta_sample_ln(inputs, cfg, skip_final=True)
+        with torch.no_grad():
+            model.ln.data.copy_(out["ln_after"])
+        model.ln.grad = None
+        return
     pl = model.prompt_learner
     ctx_in = None if torch.equal(pl.ctx.data, pl.ctx_init_state) else pl.ctx.data
     out = eng.tta_sample(inputs, cfg, want_intermediates=False, skip_final=True, ctx_in=ctx_in)

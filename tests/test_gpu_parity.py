@@ -566,3 +566,38 @@ def test_ln_tuning_matches_reference_fixture(L, dev, name, prec):
     o2 = eng.tta_sample_ln(views, _cfg_from_meta(meta))
     torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
     eng.close()
+
+
+def test_cls_tta_harness_surface(L, dev):
+    """TPT/tune_cls_rl.py call sequence (:67-87, :206-227) with rlcf_amd.custom_clip.CLIPCLS_TTA."""
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime, tpt_cls_rl
+    g, meta = load_golden("ln_tiny_s1")
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("tiny", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=1, selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000, min_entropy_reg=0,
+                                 min_entropy_w=0.2, reward_arch="tiny-r", multiple_reward_models=0, sample_k=meta["sample_k"],
+                                 reward_amplify=False, reward_process=True, process_batch=False)
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=True, only_norm=True)
+    reward_model = clip_reward.get_reward_model(dev, args)
+    reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+    optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
+    model.reset()
+    optimizer.load_state_dict(optim_state)
+    model.train()
+    tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+    model.eval()
+    out = model(views[:1])
+    torch.testing.assert_close(out.cpu(), g["final_logits"], atol=1e-3, rtol=0)
+    d = (model.ln.detach().cpu() - g["ln_after"]).abs()
+    assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+    with pytest.raises(NotImplementedError):
+        custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_norm=False)
+    runtime.reset_session()
