@@ -114,6 +114,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
         __syncthreads();
     }
 
+    if (g.N % 4 == 0 && g.ldc % 4 == 0 && g.ldr % 4 == 0 && g.ldaux % 4 == 0 && g.ldch % 4 == 0) {
+        // epilogue through LDS (see v2): 16-byte row-wise accesses instead of 64 scalar ones per lane
+        constexpr int ELD = 68;
+        float* park = (float*)lds + wave * (64 * ELD);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r] + cor[i][j][r] * 0.00048828125f;
+        __syncthreads();
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        const int col = n0 + wn * 64 + c4;
+        if (col < g.N) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias) bv = *(const float4*)(g.bias + col);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
+                if (row >= g.M) continue;
+                const float4 a4 = *(const float4*)(park + rl * ELD + c4);
+                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                if (g.epilogue == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
+                    const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                }
+                if (g.residual) {
+                    const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.Chi) {
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)((v[q] - (float)hh[q]) * 2048.0f); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -263,29 +309,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
         cur = cur == 2 ? 0 : cur + 1;
     }
 
+    // epilogue through LDS: each wave parks its 64x64 f32 tile in its own 17 KB slice of the (now idle) stage ring and
+    // re-reads it row-wise, so bias / residual / stores are 16-byte accesses covering whole 256-B row segments
+    __syncthreads();
+    {
+        constexpr int ELD = 68;                                            // floats per parked row (64 + 4 pad)
+        float* park = (float*)smem + wave * (64 * ELD);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l32;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, h);
+                for (int r = 0; r < 16; ++r)
+                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r] + cor[i][j][r] * 0.00048828125f;
+        __syncthreads();
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        const int col = n0 + wn * 64 + c4;
+        if (col < g.N) {                                                    // N % 4 == 0 is checked by the launcher
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias) bv = *(const float4*)(g.bias + col);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
                 if (row >= g.M) continue;
-                float v = g.alpha * (acc[i][j][r] + cor[i][j][r] * 0.00048828125f) + bv;
-                if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
-                else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
-                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                if (g.C) g.C[(size_t)row * g.ldc + col] = v;
+                const float4 a4 = *(const float4*)(park + rl * ELD + c4);
+                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                if (g.epilogue == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
+                    const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                }
+                if (g.residual) {
+                    const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
-                    const _Float16 hi = (_Float16)v;
-                    g.Chi[(size_t)row * g.ldch + col] = hi;
-                    g.Clo[(size_t)row * g.ldch + col] = (_Float16)((v - (float)hi) * 2048.0f);
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)((v[q] - (float)hh[q]) * 2048.0f); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
                 }
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,7 +485,8 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
-    if (force == 2 || (force == 0 && blocks2 >= 256)) {
+    const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
+    if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;
         static bool attr2 = false;
         if (!attr2) {

@@ -1,0 +1,23 @@
+"""Times BASELINE configs[2]: ViT-L/14 student + ViT-L/14 reward, N=64 views, LayerNorm tuning (rlcf_tta_sample_ln)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rlcf_amd import _lib as L, synth
+from rlcf_amd.engine import Engine, TTAConfig
+arch = sys.argv[1] if len(sys.argv) > 1 else "ViT-L/14"
+n_cls = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+dev = torch.device("cuda:0")
+geo = synth.GEOMETRIES[arch]
+ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)
+eng = Engine(geo, geo, 64, n_cls, L.PREC_F16X3)
+eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
+tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=4)
+ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
+eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+cfg = TTAConfig(selection_p=0.1, tta_steps=1, sample_k=3, lr=1e-5, weight_decay=5e-4)
+views = [synth.make_views(1000 + i, 64, geo.image_resolution, device=dev) for i in range(6)]
+for v in views[:2]: o = eng.tta_sample_ln(v, cfg)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for v in views[2:]: o = eng.tta_sample_ln(v, cfg)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+print(f"{arch} LN-tuning: {dt*1e3:.1f} ms/image ({1/dt:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF, "
+      f"top5={o['top5'].tolist()} |ln_grad|={o['ln_grad'].norm().item():.3e} nan={bool(torch.isnan(o['final_logits']).any())}")
