@@ -601,3 +601,32 @@ def test_cls_tta_harness_surface(L, dev):
     with pytest.raises(NotImplementedError):
         custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_norm=False)
     runtime.reset_session()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("prec", [0, 2])
+def test_ragged_odd_sizes_vs_oracle(L, dev, mode, prec):
+    """Sizes that are multiples of nothing (C=37 classes, N=10 views -> n_sel=3, K=2): HIP path vs the CPU oracle,
+    prompt tuning (sparse and dense backward) and LayerNorm tuning."""
+    from rlcf_amd.engine import TTAConfig
+    n_cls, N = 37, 10
+    eng, ssd, rsd, tokens, ctx0 = make_engine(("tiny", "tiny-r"), N, n_cls, mode, prec=prec)
+    views = synth.make_views(4242, N, 32)
+    hp = RR.TTAHyper(selection_p=0.3, sample_k=2, tta_steps=2)
+    ref = RR.tta_sample(ssd, rsd, views, tokens, ctx0, hp)
+    for sparse in (True, False):
+        o = eng.tta_sample(views.to(dev), TTAConfig(selection_p=0.3, sample_k=2, tta_steps=2, sparse_backward=sparse))
+        assert o["selected_idx"].cpu().tolist() == ref["selected_idx"].tolist()
+        assert o["topk_idx"].cpu().tolist() == ref["topk_idx"].tolist()
+        assert o["top5"].cpu().tolist() == ref["top5"].tolist()
+        torch.testing.assert_close(o["logits"].cpu(), ref["logits"], atol=1e-3, rtol=0)
+        torch.testing.assert_close(o["final_logits"].cpu(), ref["final_logits"], atol=2e-3, rtol=0)
+        gr, og = ref["ctx_grad"], o["ctx_grad"].cpu()
+        assert (og - gr).norm() / gr.norm() < 1e-3
+    ln = RR.tta_sample_ln(ssd, rsd, views, tokens, RR.TTAHyper(selection_p=0.3, sample_k=2, lr=1e-3))
+    o = eng.tta_sample_ln(views.to(dev), TTAConfig(selection_p=0.3, sample_k=2, lr=1e-3))
+    assert o["selected_idx"].cpu().tolist() == ln["selected_idx"].tolist()
+    assert o["top5"].cpu().tolist() == ln["top5"].tolist()
+    torch.testing.assert_close(o["final_logits"].cpu(), ln["final_logits"], atol=1e-3, rtol=0)
+    assert (o["ln_grad"].cpu() - ln["ln_grad"]).norm() / ln["ln_grad"].norm() < 2e-3
+    eng.close()
