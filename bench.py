@@ -137,6 +137,10 @@ def main():
         # f16x3: three f16 MFMAs per algorithmic multiply-add -> at most 1/3 of the f16 pipe is algorithmic
         peak = PEAK_TFLOPS["f32"] if a.precision == "f32" else PEAK_TFLOPS["bf16"]
         passes = 1 if a.precision == "f32" else 3
+        traffic = None                       # HBM bytes per GEMM launch from the committed PMC profile (same shapes, 8 images/pass)
+        tpath = os.path.join(ROOT, "profiles", "r1_gemm_hbm_traffic.json")
+        if a.precision == "f16x3" and a.batch == 8 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"]
         out = {
             "metric": "test_images_per_sec", "value": a.steps * world / dt, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -148,7 +152,7 @@ def main():
                        "tta_steps": 1, "images_per_pass": a.batch,
                        "parallelism": f"sample-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,
+                         "traffic": traffic, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,
                          "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
                          else "gemm_nt_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product) + small-M f32 GEMMs",
                          "launches_per_image": n_l.value / nprof, "avg_launch_ms": ms.value / max(n_l.value, 1),
