@@ -49,8 +49,12 @@ def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False
         if not path or not os.path.isfile(path):
             raise RuntimeError(f"Model {name} not found; registered = {sorted(_CHECKPOINTS)}; "
                                f"looked for {path or '<RLCF_CLIP_ROOT unset>'}")
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
+        try:                                           # OpenAI releases are TorchScript archives (clip.py:119-131)
+            sd = torch.jit.load(path, map_location="cpu").state_dict()
+        except RuntimeError:
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
+        sd = {k: v.float() for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
         geo = geometry_from_state_dict(sd)
     return ClipCheckpoint(name, geo, sd), geo.embed_dim, None
 

@@ -358,103 +358,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// v3 (experiment): 256x256 block tile, 8 waves (2x4) of 128x64, ONE accumulator per MFMA tile, BK = 16,
-// 4-stage glds ring.  Half the operand bytes per MFMA of v2.  Numerically valid only for operands whose lo part is
-// stored unscaled; used here to measure the structure.
-#define V3_BM 256
-#define V3_BN 256
-#define V3_BK 16
-#define V3_STAGE 32768                  // bytes: Ahi 8K | Alo 8K | Whi 8K | Wlo 8K   (256 rows x 32 B each)
-#define V3_NST 4
-__global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int per_group = 4 * tiles_n, grp = bid / per_group, first_m = grp * 4;
-    const int gsize = min(tiles_m - first_m, 4), in_g = bid - grp * per_group;
-    const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // each operand tile: 256 rows x 2 chunks = 512 chunks = one glds per thread; chunk slot = c ^ ((row >> 3) & 1)
-    const int row = t >> 1, cs = t & 1, c = cs ^ ((row >> 3) & 1);
-    const size_t sa = (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
-    const size_t sw = (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
-    const int dd = wave * 1024;
-#define V3_ISSUE(k0, stage)                                                                                       \
-    {                                                                                                             \
-        char* sb_ = smem + (stage) * V3_STAGE;                                                                    \
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa + (k0)), (lptr_t)(sb_ + dd), 16, 0, 0);             \
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa + (k0)), (lptr_t)(sb_ + 8192 + dd), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw + (k0)), (lptr_t)(sb_ + 16384 + dd), 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw + (k0)), (lptr_t)(sb_ + 24576 + dd), 16, 0, 0);     \
-    }
-    const int nk = g.K / V3_BK;
-    V3_ISSUE(0, 0)
-    if (nk > 1) V3_ISSUE(V3_BK, 1)
-    if (nk > 2) V3_ISSUE(2 * V3_BK, 2)
-    const int co = (h ^ ((l32 >> 3) & 1)) * 16;
-    const int aoff = (wm * 128 + l32) * 32 + co, boff = (wn * 64 + l32) * 32 + co;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 3 < nk) V3_ISSUE((kt + 3) * V3_BK, (cur + 3) & 3)
-        const char* sb = smem + cur * V3_STAGE;
-        h16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *(const h16x8*)(sb + aoff + i * 1024);
-            al[i] = *(const h16x8*)(sb + 8192 + aoff + i * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            bh[j] = *(const h16x8*)(sb + 16384 + boff + j * 1024);
-            bl[j] = *(const h16x8*)(sb + 24576 + boff + j * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        cur = (cur + 1) & 3;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l32;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row2 = m0 + wm * 128 + i * 32 + mfma32_row(r, h);
-                if (row2 >= g.M) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
-                if (g.residual) v += g.residual[(size_t)row2 * g.ldr + col];
-                if (g.C) g.C[(size_t)row2 * g.ldc + col] = v;
-            }
-        }
-}
-
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st) {
@@ -473,18 +376,6 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const int blocks2 = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
     static int force = -1;                                   // RLCF_X3_KERNEL=1|2 pins a variant (benchmarks)
     if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
-    if (force == 3) {
-        const size_t sh3 = (size_t)V3_NST * V3_STAGE;
-        static bool attr3 = false;
-        if (!attr3) {
-            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
-            attr3 = true;
-        }
-        const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
-        gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
-        RLCF_LAUNCH_CHECK();
-        return RLCF_OK;
-    }
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;

@@ -257,6 +257,22 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+TOKENIZER_STRINGS = [
+    "a photo of a tench.", "a_photo_of_a great white shark.", "a photo of a hen-of-the-woods.", "itap of a toilet tissue.",
+    "a bad photo of the CD player.", "a photo of a 3D-printed #42 T-shirt's logo!", "art of the  maillot   (tank suit).",
+    "a photo of a", "X X X X goldfish.", "a origami Bernese mountain dog.", "a photo of the large jack-o'-lantern.",
+    "a photo of a café au lait, naïve façade.", "graffiti of a potter's wheel.", "a photo of a person riding a horse & cart.",
+    "a photo of 1 2 3 go-karts?", "the embroidered cock-a-doodle-doo.", "a photo of a \u4e2d\u6587 sign.", "<|startoftext|> nested <|endoftext|>",
+    "a photo of a web site, website, internet site, site.", "a tattoo of the I'll've we're it's don't'd.",
+]
+
+
+def gen_tokenizer(ref):
+    """clip.tokenize of the reference (TPT/clip/clip.py:197-233) on TOKENIZER_STRINGS."""
+    toks = ref.cc.tokenize(TOKENIZER_STRINGS)
+    return {"tokens": toks.numpy()}
+
+
 LN_CASES = {
     "ln_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3)),
     "ln_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3)),
@@ -266,6 +282,8 @@ LN_CASES = {
 
 
 def save(name, arrays, meta):
+    if "reward_class_features" in arrays and arrays["reward_class_features"].shape[0] > 64:
+        arrays["reward_class_features"] = arrays["reward_class_features"][:64]     # 64 classes pin the reward bank; keeps the file small
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
@@ -283,7 +301,8 @@ TTA_CASES = {
     "tta_tiny_k1": ("tiny", "tiny-r", 8, 16, dict(sample_k=1, view_seed=1006)),
     "tta_small_s1": ("small", "small", 16, 40, dict(selection_p=0.25)),
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
-    "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1)),
+    # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
+    "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
 GROUPS = {
     "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny")],
@@ -370,6 +389,8 @@ def main():
             save("ops", gen_ops(ref), {})
         elif grp == "modules":
             save("modules", gen_modules(ref), {})
+        elif grp == "tokenizer":
+            save("tokenizer", gen_tokenizer(ref), {})
         elif grp in ("ln", "lnb16"):
             for name in ([k for k in LN_CASES if "b16" not in k] if grp == "ln" else ["ln_b16_n8"]):
                 student, reward, n, c, over = LN_CASES[name]

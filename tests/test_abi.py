@@ -48,3 +48,24 @@ def test_struct_layouts(lib):
     import ctypes as C
     assert C.sizeof(lib.ClipCfg) == 40 and C.sizeof(lib.Seq) == 16
     assert C.sizeof(lib.TTAArgs) == 64 and C.sizeof(lib.TTAOut) == 15 * 8
+
+
+def test_bpe_tokenizer_matches_reference_fixture():
+    """rlcf_amd.bpe.ClipBPE vs clip.tokenize of the reference (tests/golden/tokenizer.npz).  Needs OpenAI's merges file,
+    which is data this repo does not ship: read from the reference checkout when present."""
+    import sys
+    import numpy as np
+    vocab = os.environ.get("RLCF_BPE_VOCAB", "/root/reference/TPT/clip/bpe_simple_vocab_16e6.txt.gz")
+    if not os.path.exists(vocab):
+        pytest.skip("BPE merges file not available")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import TOKENIZER_STRINGS
+    from rlcf_amd.bpe import ClipBPE
+    tok = ClipBPE(vocab)
+    got = tok.tokenize(TOKENIZER_STRINGS).numpy()
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "tokenizer.npz"))["tokens"]
+    assert got.shape == ref.shape and (got == ref).all()
+    assert tok.sot == 49406 and tok.eot == 49407
+    with pytest.raises(RuntimeError):
+        tok.tokenize("word " * 100)
+    assert tok.tokenize("word " * 100, truncate=True)[0, -1] == tok.eot
