@@ -27,6 +27,7 @@ struct GemmX3Args {
     _Float16 *Chi, *Clo; int ldch;     // split output (may be null)
     int M, N, K;
     float alpha; int epilogue;
+    int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
 };
 
 #define X3_BM 128
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
     const int brow = (wn * 64 + l32) * X3_LD + h * 8;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) { X3_GLOAD((kt + 1) * X3_BK) }
+        if (kt + 1 < nk) { X3_GLOAD((kt + 1) * g.kstep) }
         const _Float16* base = lds + cur * 4 * X3_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
 
     const int nk = g.K / X3_BK;
     V2_ISSUE(0, 0)
-    if (nk > 1) V2_ISSUE(X3_BK, 1)
+    if (nk > 1) V2_ISSUE(g.kstep, 1)
     const int swz = (l32 >> 2) & 3;
     const int aoff = (wm * 64 + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
     int cur = 0;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const bool pf = kt + 2 < nk;
-        const int kn = (kt + 2) * X3_BK;
+        const int kn = (kt + 2) * g.kstep;
         char* sn = smem + (cur >= 1 ? cur - 1 : 2) * V2_STAGE;             // stage (cur + 2) % 3
         const char* sb = smem + cur * V2_STAGE;
         h16x8 ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
@@ -367,6 +368,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
+    g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
     static bool attr = false;
     if (!attr) {
