@@ -160,9 +160,80 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// Same as layernorm_bwd_kernel but every wave walks LNB_ROWS consecutive rows and keeps its dgamma/dbeta partial sums in
+// registers: one atomicAdd per column per wave instead of one per column per row (LayerNorm-tuning backward).
+#define LNB_ROWS 16
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ dy, const float* __restrict__ dres,
+                                                                   float* __restrict__ dx, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int rows, int width) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LNB_ROWS;
+    float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const float* xr = x + (size_t)row * width;
+        const float* dr = dy + (size_t)row * width;
+        float v[MAX_PER_LANE], d[MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            v[j] = c < width ? xr[c] : 0.f;
+            d[j] = c < width ? dr[c] : 0.f;
+            s += v[j];
+        }
+        const float mu = wave_sum(s) / width;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) { float t = v[j] - mu; q += t * t; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                float xh = (v[j] - mu) * rstd;
+                float gd = d[j] * gamma[c];
+                ag[j] += d[j] * xh; ab[j] += d[j];
+                v[j] = xh; d[j] = gd;
+                s1 += gd; s2 += gd * xh;
+            }
+        }
+        s1 = wave_sum(s1) / width;
+        s2 = wave_sum(s2) / width;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                float o = rstd * (d[j] - s1 - v[j] * s2);
+                if (dres) o += dres[(size_t)row * width + c];
+                dx[(size_t)row * width + c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width && row0 < rows) { atomicAdd(dgamma + c, ag[j]); atomicAdd(dbeta + c, ab[j]); }
+    }
+}
+
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
                          float* dbeta, int rows, int width, hipStream_t st) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
+    if (dgamma && dbeta && rows >= 256) {
+        const int per_block = ROWS_PER_BLOCK * LNB_ROWS;
+        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width);
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
+    }
     layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -568,17 +639,20 @@ int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const floa
 }
 
 // d img[i,:] = scale * sum_c dlogits[i,c] * txt[c,:]    (backward of logits = scale * img @ txt^T w.r.t. img)
+#define DIMG_PARTS 16
 __global__ void dimg_kernel(const float* __restrict__ dlogits, const float* __restrict__ txt, int C, int D, float scale, float* __restrict__ dimg) {
-    const int i = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += dlogits[(size_t)i * C + c] * txt[(size_t)c * D + d];
-        dimg[(size_t)i * D + d] = scale * s;
-    }
+    // block = (view i, 256-wide d chunk, class partition); partial sums meet in dimg by atomicAdd (dimg pre-zeroed)
+    const int i = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x, part = blockIdx.z;
+    if (d >= D) return;
+    const int per = (C + DIMG_PARTS - 1) / DIMG_PARTS, c0 = part * per, c1 = min(C, c0 + per);
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) s += dlogits[(size_t)i * C + c] * txt[(size_t)c * D + d];
+    atomicAdd(dimg + (size_t)i * D + d, scale * s);
 }
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st) {
     RLCF_ARG_CHECK(n > 0 && C > 0 && D > 0);
-    dimg_kernel<<<dim3(n), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
+    RLCF_HIP_CHECK(hipMemsetAsync(dimg, 0, (size_t)n * D * sizeof(float), st));
+    dimg_kernel<<<dim3(n, (D + 255) / 256, DIMG_PARTS), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
