@@ -137,7 +137,10 @@ def main():
         torch.cuda.synchronize()
         import ctypes as C
         n_l, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
-        _lib.check(lib.rlcf_profile_read(C.byref(n_l), C.byref(ms), C.byref(fl)))
+        dom = 2 if a.precision == "f16x3" else 0          # the dominant kernel of the mode
+        _lib.check(lib.rlcf_profile_read(dom, C.byref(n_l), C.byref(ms), C.byref(fl)))
+        n_all, ms_all, fl_all = C.c_int(0), C.c_double(0), C.c_double(0)
+        _lib.check(lib.rlcf_profile_read(-1, C.byref(n_all), C.byref(ms_all), C.byref(fl_all)))
         lib.rlcf_profile_gemm(0)
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         # f16x3: three f16 MFMAs per algorithmic multiply-add -> at most 1/3 of the f16 pipe is algorithmic
@@ -151,7 +154,7 @@ def main():
             "metric": "test_images_per_sec", "value": a.steps * world / dt, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "f32 (split-f16 x3 MFMA: hi+lo f16 operands, f32 accumulate)", "data": "synthetic",
+            "dtype": "f32" if a.precision == "f32" else "f32 via split-f16x3 MFMA", "data": "synthetic",
             "config": {"workload": "RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + ViT-B/16 reward, N=64 views, "
                                    "1000-class bank, selection_p=0.1, K=3, 1 AdamW step (BASELINE configs[1])",
                        "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
@@ -159,8 +162,10 @@ def main():
                        "parallelism": f"sample-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,
-                         "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
-                         else "gemm_nt_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product) + small-M f32 GEMMs",
+                         "kernel": "gemm_nt_f32_kernel + gemm_nt_f32_splitk_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
+                         else "gemm_nt_f16x3_v2_kernel (3x v_mfma_f32_32x32x16_f16 per f32-grade product)",
+                         "all_gemm_kernels": {"launches_per_image": n_all.value / nprof, "ms_per_image": ms_all.value / nprof,
+                                              "achieved": fl_all.value / (ms_all.value * 1e-3) / 1e12 if ms_all.value > 0 else 0.0},
                          "launches_per_image": n_l.value / nprof, "avg_launch_ms": ms.value / max(n_l.value, 1),
                          "gemm_flops_per_image": fl.value / nprof},
             "flops_exec_per_image": flops_exec,

@@ -200,10 +200,11 @@ int rlcf_tta_batch(rlcf_engine*, const float* views, int count, int N, const rlc
 double rlcf_engine_last_flops(rlcf_engine*);
 int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
 
-/* Optional per-launch timing (HIP events on the launch stream) of the dominant GEMM kernel:
- * enable, run one sample, read {launches, total ms, total algorithmic FLOPs}. */
+/* Optional per-launch timing (HIP events on the launch stream) of the GEMM kernels: enable, run one pass, read
+ * {launches, total ms, total algorithmic FLOPs} of one kernel kind: 2 = gemm_nt_f16x3_v2_kernel (the dominant kernel),
+ * 1 = gemm_nt_f16x3_kernel, 0 = the f32-MFMA kernels, -1 = all. */
 int rlcf_profile_gemm(int enable);
-int rlcf_profile_read(int* launches, double* total_ms, double* total_flops);
+int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops);
 
 #ifdef __cplusplus
 }

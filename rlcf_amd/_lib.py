@@ -81,7 +81,7 @@ SIGNATURES = {
     "rlcf_engine_last_flops": (D, [P]),
     "rlcf_engine_text_rows": (I, [P]),
     "rlcf_profile_gemm": (I, [I]),
-    "rlcf_profile_read": (I, [C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
+    "rlcf_profile_read": (I, [I, C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
 }
 
 

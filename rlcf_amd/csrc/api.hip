@@ -254,16 +254,19 @@ int rlcf_profile_gemm(int enable) {
     g_prof.n = 0;
     return RLCF_OK;
 }
-int rlcf_profile_read(int* launches, double* total_ms, double* total_flops) {
+int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops) {
     RLCF_ARG_CHECK(launches && total_ms && total_flops);
     double ms = 0.0, fl = 0.0;
+    int cnt = 0;
     for (int i = 0; i < g_prof.n; ++i) {
+        if (kind >= 0 && g_prof.kind[i] != kind) continue;
+        ++cnt;
         RLCF_HIP_CHECK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
         float t = 0.f;
         RLCF_HIP_CHECK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
         ms += t; fl += g_prof.flops[i];
     }
-    *launches = g_prof.n; *total_ms = ms; *total_flops = fl;
+    *launches = cnt; *total_ms = ms; *total_flops = fl;
     return RLCF_OK;
 }
 

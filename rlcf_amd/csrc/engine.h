@@ -103,7 +103,9 @@ struct GemmProfile {                 // optional per-launch timing of the domina
     int n = 0;
     std::vector<hipEvent_t> ev;      // 2 per launch
     std::vector<double> flops;
+    std::vector<int> kind;           // 0 = f32 MFMA kernels, 1 = f16x3 128x128, 2 = f16x3 256x128 (the dominant kernel)
 };
+extern int g_last_x3_variant;
 extern GemmProfile g_prof;
 
 // engine internals used by api.hip

@@ -29,12 +29,15 @@ static int prof_begin(hipStream_t st, double flops) {
         g_prof.ev.push_back(a); g_prof.ev.push_back(b);
     }
     g_prof.flops.resize(g_prof.n + 1);
+    g_prof.kind.resize(g_prof.n + 1);
     g_prof.flops[g_prof.n] = flops;
+    g_prof.kind[g_prof.n] = 0;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
     return g_prof.n;
 }
-static void prof_end(int slot, hipStream_t st) {
+static void prof_end(int slot, hipStream_t st, int kind = 0) {
     if (slot < 0) return;
+    g_prof.kind[slot] = kind;
     (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
     g_prof.n = slot + 1;
 }
@@ -55,7 +58,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const int slot = prof_begin(st, 2.0 * M * N * K);
             int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->first, sp->second, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha, epi, st);
-            prof_end(slot, st);
+            prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
     }
@@ -77,7 +80,7 @@ static int gemm_pre(rlcf_engine* e, const void* Ahi, const void* Alo, int lda, c
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K);
     int rc = launch_gemm_f16x3(Ahi, Alo, lda, sp->first, sp->second, K, bias, res, ldr, nullptr, 0, C, ldc, Chi, Clo, ldch, M, N, K, 1.f, epi, st);
-    prof_end(slot, st);
+    prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
 static int x3_ensure(Tower& t, int T, int W) {

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     }
 }
 
+int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st) {
@@ -387,11 +388,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             attr2 = true;
         }
         gemm_nt_f16x3_v2_kernel<<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        g_last_x3_variant = 2;
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
     const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
     gemm_nt_f16x3_kernel<<<dim3(blocks), dim3(256), sh, st>>>(g);
+    g_last_x3_variant = 1;
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

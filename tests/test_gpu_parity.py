@@ -630,3 +630,34 @@ def test_ragged_odd_sizes_vs_oracle(L, dev, mode, prec):
     torch.testing.assert_close(o["final_logits"].cpu(), ln["final_logits"], atol=1e-3, rtol=0)
     assert (o["ln_grad"].cpu() - ln["ln_grad"]).norm() / ln["ln_grad"].norm() < 2e-3
     eng.close()
+
+
+def test_full_size_properties(L, dev):
+    """BASELINE configs[1] sizes (ViT-B/16 + ViT-B/16, N=64, C=1000), size-independent properties: (i) idempotence — the
+    per-sample reset makes a repeated sample bit-for-bit reproducible up to the float atomics of the backward; (ii) the fused
+    8-images-per-pass path gives every image the result it gets alone; (iii) the three text layouts (reference graph,
+    EOT-packed, shared prefix) agree."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    geo = synth.GEOMETRIES["ViT-B/16"]
+    ssd = synth.make_state_dict(geo, 11, device=dev)
+    rsd = synth.make_state_dict(geo, 23, device=dev)
+    tokens = synth.make_token_bank(geo, 1000, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
+    cfg = TTAConfig(selection_p=0.1)
+    vs = torch.stack([synth.make_views(s, 64, 224, device=dev) for s in (1113, 1101, 1000)])
+    results = {}
+    for mode in (L.TEXT_SHARED, L.TEXT_PACKED, L.TEXT_DENSE):
+        eng = Engine(geo, geo, 64 * 3, 1000, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
+        eng.set_class_bank(tokens, 4, ctx0, mode)
+        a = eng.tta_sample(vs[0], cfg, want_intermediates=False)
+        b = eng.tta_sample(vs[0], cfg, want_intermediates=False)
+        torch.testing.assert_close(a["final_logits"], b["final_logits"], atol=2e-4, rtol=0)          # (i)
+        assert a["top5"].tolist() == b["top5"].tolist()
+        top5, fl = eng.tta_batch(vs, cfg, want_logits=True)                                           # (ii) fused pass of 3 images
+        torch.testing.assert_close(fl[0], a["final_logits"][0], atol=2e-4, rtol=0)
+        assert top5[0].tolist() == a["top5"].tolist()
+        results[mode] = fl.cpu()
+        eng.close()
+    torch.testing.assert_close(results[L.TEXT_PACKED], results[L.TEXT_SHARED], atol=1e-3, rtol=0)    # (iii)
+    torch.testing.assert_close(results[L.TEXT_DENSE], results[L.TEXT_SHARED], atol=1e-3, rtol=0)
