@@ -66,7 +66,8 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
                  float* C, int ldc, int M, int N, int K, float alpha, int epilogue, int precision,
                  rlcf_stream stream);
 
-/* Split-f16 operand pairs (RLCF_PREC_F16X3): x = hi + lo*2^-11 with hi = f16(x), lo = f16((x-hi)*2^11);
+/* Split-f16 operand pairs (RLCF_PREC_F16X3): x = hi + lo with hi = f16(x), lo = f16(x-hi) (operands should be O(1):
+ * below |x| = 2^-3 the absolute error floor is 2^-25; the engine pre-scales weights and gradients by exact powers of two);
  * n % 8 == 0.  rlcf_gemm_f16x3 is rlcf_gemm_nt on pre-split operands (3 f16 MFMAs per product,
  * f32 accumulate); output f32 (C) and/or a split pair (Chi, Clo).  K % 32 == 0. */
 int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream stream);
@@ -201,8 +202,8 @@ double rlcf_engine_last_flops(rlcf_engine*);
 int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
 
 /* Optional per-launch timing (HIP events on the launch stream) of the GEMM kernels: enable, run one pass, read
- * {launches, total ms, total algorithmic FLOPs} of one kernel kind: 2 = gemm_nt_f16x3_v2_kernel (the dominant kernel),
- * 1 = gemm_nt_f16x3_kernel, 0 = the f32-MFMA kernels, -1 = all. */
+ * {launches, total ms, total algorithmic FLOPs} of one kernel kind: 3 = gemm_nt_f16x3_v3_kernel (the dominant kernel),
+ * 2 = gemm_nt_f16x3_v2_kernel, 1 = gemm_nt_f16x3_kernel, 0 = the f32-MFMA kernels, -1 = all. */
 int rlcf_profile_gemm(int enable);
 int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops);
 

@@ -103,8 +103,8 @@ __global__ __launch_bounds__(64) void attention_fwd_f32_kernel(const float* __re
                 h16x4 h0, l0, h1, l1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)((v0[q] - (float)h0[q]) * 2048.0f);
-                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)((v1[q] - (float)h1[q]) * 2048.0f);
+                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)(v0[q] - (float)h0[q]);
+                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)(v1[q] - (float)h1[q]);
                 }
                 *(h16x4*)(oh + obase + d) = h0; *(h16x4*)(ol + obase + d) = l0;
                 *(h16x4*)(oh + obase + 32 + d) = h1; *(h16x4*)(ol + obase + 32 + d) = l1;

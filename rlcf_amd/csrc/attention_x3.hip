@@ -1,6 +1,7 @@
 // Attention forward on the f16 matrix cores with f32-grade accuracy (split-f16, see gemm_f16x3.hip):
-// every operand of both contractions is carried as hi + lo*2^-11 and each product costs three
-// v_mfma_f32_32x32x16_f16.  Same dataflow as attention_f32.hip (one wave = 32 queries, both
+// every operand of both contractions is carried as hi + lo (two f16 numbers) and each product costs three
+// v_mfma_f32_32x32x16_f16 into ONE f32 accumulator (hi*hi + hi*lo + lo*hi; P is carried times 2^6 so that its lo
+// parts stay in f16's normal range).  Same dataflow as attention_f32.hip (one wave = 32 queries, both
 // contractions transposed so a lane owns one query, online softmax lane-local), but
 //   * NW waves (= NW query blocks of one (sequence, head)) share each converted K/V chunk in LDS;
 //   * K is stored [key][d] (rows padded to 144 B), V is stored TRANSPOSED [d][key-slot] (rows padded
@@ -17,7 +18,7 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
     for (int e = 0; e < 8; ++e) {
         const _Float16 hh = (_Float16)v[e];
         hi[e] = hh;
-        lo[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
+        lo[e] = (_Float16)(v[e] - (float)hh);
     }
 }
 
@@ -47,13 +48,13 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4 a = *(const float4*)(qp + ks * 16), b = *(const float4*)(qp + ks * 16 + 4);
-            const float v[8] = {a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f, b.x * 0.125f, b.y * 0.125f, b.z * 0.125f, b.w * 0.125f};
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};      // the 1/8 scale is applied to the scores (exact)
             split8(v, qh[ks], ql[ks]);
         }
     }
-    f32x16 o0, o1, c0, c1;
+    f32x16 o0, o1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; c0[r] = 0.f; c1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -INFINITY, lsum = 0.f;
 
     // chunk staging: thread -> (key, PER consecutive d); the key's V slot in the transposed tile is the position its
@@ -90,26 +91,26 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
             for (int j = 0; j < PER; ++j) {
                 const _Float16 hh = (_Float16)vv[j];
                 Vh[(d0 + j) * AX_VLD + slot] = hh;
-                Vl[(d0 + j) * AX_VLD + slot] = (_Float16)((vv[j] - (float)hh) * 2048.0f);
+                Vl[(d0 + j) * AX_VLD + slot] = (_Float16)(vv[j] - (float)hh);
             }
         }
         __syncthreads();
         if (active && kc < my_kend) {
-            f32x16 s, sc;
+            f32x16 s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; sc[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const h16x8 kh = *(const h16x8*)(Kh + l32 * AX_KLD + ks * 16 + h * 8);
                 const h16x8 kl = *(const h16x8*)(Kl + l32 * AX_KLD + ks * 16 + h * 8);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
             }
             float cm = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] += sc[r] * 0.00048828125f;
+                s[r] *= 0.125f;
                 const int key = kc + mfma32_row(r, h);
                 if (key >= nkeys || (causal && key > qpos)) s[r] = -INFINITY;
                 cm = fmaxf(cm, s[r]);
@@ -122,12 +123,12 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
             for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mn); ps += s[r]; }
             lsum = lsum * alpha + ps;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; c0[r] *= alpha; c1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 float pv[8];
 #pragma unroll
-                for (int e2 = 0; e2 < 8; ++e2) pv[e2] = s[8 * tt + e2];
+                for (int e2 = 0; e2 < 8; ++e2) pv[e2] = s[8 * tt + e2] * 64.0f;
                 h16x8 ph, pl;
                 split8(pv, ph, pl);
                 const h16x8 v0h = *(const h16x8*)(Vh + l32 * AX_VLD + tt * 16 + h * 8);
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
                 const h16x8 v1h = *(const h16x8*)(Vh + (32 + l32) * AX_VLD + tt * 16 + h * 8);
                 const h16x8 v1l = *(const h16x8*)(Vl + (32 + l32) * AX_VLD + tt * 16 + h * 8);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, c0, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, c0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, c1, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, c1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
             }
             m = mn;
         }
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
     if (!active) return;
     const float ltot = lsum + __shfl_xor(lsum, 32);
     if (qb * 32 + l32 < sq.q_len) {
-        const float inv = 1.0f / ltot;
+        const float inv = 0.015625f / ltot;                       // undoes the 2^6 carried by P
         const size_t obase = (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
             float v0[4], v1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                v0[q] = (o0[4 * g + q] + c0[4 * g + q] * 0.00048828125f) * inv;
-                v1[q] = (o1[4 * g + q] + c1[4 * g + q] * 0.00048828125f) * inv;
+                v0[q] = o0[4 * g + q] * inv;
+                v1[q] = o1[4 * g + q] * inv;
             }
             if (out) {
                 *(float4*)(out + obase + d) = make_float4(v0[0], v0[1], v0[2], v0[3]);
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
                 h16x4 h0, l0, h1, l1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)((v0[q] - (float)h0[q]) * 2048.0f);
-                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)((v1[q] - (float)h1[q]) * 2048.0f);
+                    h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)(v0[q] - (float)h0[q]);
+                    h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)(v1[q] - (float)h1[q]);
                 }
                 *(h16x4*)(oh + obase + d) = h0; *(h16x4*)(ol + obase + d) = l0;
                 *(h16x4*)(oh + obase + 32 + d) = h1; *(h16x4*)(ol + obase + 32 + d) = l1;

@@ -61,7 +61,8 @@ struct ClipModel {
     const float* vproj = nullptr;          // [Wv, D] as stored (backward operand)
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
-    std::unordered_map<const float*, std::pair<void*, void*>> split_of;   // f32 weight -> (hi, lo) f16 copies (F16X3 mode)
+    struct SplitW { void *hi, *lo; float inv_scale; };                    // W * 2^s = hi + lo; inv_scale = 2^-s
+    std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 mode)
 };
 
 struct rlcf_engine {

@@ -43,21 +43,25 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 }
 
 // C = epi(alpha A W^T + b) (+res): dispatch on the engine precision
+// a_scale: exact power of two applied to A before it is split into f16 pairs (undone in alpha).  Backward passes hand in
+// gradients (1e-6..1e-2), which must be lifted out of f16's subnormal range; forward activations use 1.
+#define GRAD_SCALE 256.0f
 static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
-                const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st) {
+                const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st,
+                float a_scale = 1.0f) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi; g.out_bf16 = 0;
     e->last_flops += 2.0 * M * N * K;
     if (e->precision == RLCF_PREC_F16X3 && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
         // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
-        const std::pair<void*, void*>* sp = nullptr;
+        const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
         if (sp && (size_t)M * K <= e->a_split_elems) {
-            TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st));
+            TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st, a_scale));
             const int slot = prof_begin(st, 2.0 * M * N * K);
-            int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->first, sp->second, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
-                                       nullptr, 0, M, N, K, alpha, epi, st);
+            int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
+                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -69,17 +73,17 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
 }
 
 // pre-split A operand (written by the producing kernel): C f32 and/or a split pair
-static const std::pair<void*, void*>* split_of(rlcf_engine* e, const float* W) {
+static const ClipModel::SplitW* split_of(rlcf_engine* e, const float* W) {
     for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) return &it->second; }
     return nullptr;
 }
 static int gemm_pre(rlcf_engine* e, const void* Ahi, const void* Alo, int lda, const float* W, const float* bias, const float* res, int ldr,
                     float* C, int ldc, void* Chi, void* Clo, int ldch, int M, int N, int K, int epi, hipStream_t st) {
-    const std::pair<void*, void*>* sp = split_of(e, W);
+    const ClipModel::SplitW* sp = split_of(e, W);
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K);
-    int rc = launch_gemm_f16x3(Ahi, Alo, lda, sp->first, sp->second, K, bias, res, ldr, nullptr, 0, C, ldc, Chi, Clo, ldch, M, N, K, 1.f, epi, st);
+    int rc = launch_gemm_f16x3(Ahi, Alo, lda, sp->hi, sp->lo, K, bias, res, ldr, nullptr, 0, C, ldc, Chi, Clo, ldch, M, N, K, sp->inv_scale, epi, st);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -107,8 +111,19 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     DevBuf hi, lo;
     TRY(hi.ensure(numel * 2));
     TRY(lo.ensure(numel * 2));
-    TRY(launch_split_f16x2(w, hi.p, lo.p, (int64_t)numel, st));
-    m.split_of[w] = {hi.p, lo.p};
+    // exact power-of-two pre-scale that lifts the tensor to max|w| in [2^9, 2^10): lo parts of all but negligible
+    // elements are then normal f16 numbers (full 22-bit operand), far from f16 overflow
+    static DevBuf amax;
+    TRY(amax.ensure(sizeof(float)));
+    TRY(launch_absmax(w, (int64_t)numel, amax.as<float>(), st));
+    float mx = 0.f;
+    RLCF_HIP_CHECK(hipMemcpyAsync(&mx, amax.p, sizeof(float), hipMemcpyDeviceToHost, st));
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    int sh = 0;
+    if (mx > 0.f && std::isfinite(mx)) sh = std::max(-8, std::min(12, 9 - (int)std::floor(std::log2(mx))));
+    const float scale = std::ldexp(1.0f, sh);
+    TRY(launch_split_f16x2(w, hi.p, lo.p, (int64_t)numel, st, scale));
+    m.split_of[w] = ClipModel::SplitW{hi.p, lo.p, 1.0f / scale};
     m.derived.push_back(hi);
     m.derived.push_back(lo);
     return RLCF_OK;
@@ -333,16 +348,16 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
     for (int l = L - 1; l >= 0; --l) {
         const BlockW& b = w.blk[l];
         const SavedLayer& s = ws.sv[l];
-        TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st));
-        TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st));
+        TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, GRAD_SCALE));
+        TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
         TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st));
-        TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
+        TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96) TRY(launch_attention_bwd_long(s.qkv, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
-        TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st));
+        TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st));
     }
     return RLCF_OK;

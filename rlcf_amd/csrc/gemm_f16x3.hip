@@ -1,10 +1,10 @@
 // Split-f16 GEMM: f32-grade results on the f16 matrix cores of gfx950.
 //
-// Every f32 operand x is carried as two f16 numbers  x = hi + lo * 2^-11,
-//     hi = f16(x),  lo = f16((x - hi) * 2^11)              (22 significant bits, f16 range kept)
-// and a product a*b is evaluated as  ahi*bhi + (ahi*blo + alo*bhi) * 2^-11  with THREE
-// v_mfma_f32_32x32x16_f16 instructions accumulating in f32 (each f16 x f16 product is exact in
-// f32); the dropped lo*lo term is 2^-22 relative.  Measured on the ViT-B/16 image tower the
+// Every f32 operand x is carried as two f16 numbers  x = hi + lo,  hi = f16(x),  lo = f16(x - hi)
+// (22 significant bits while lo is a normal f16, i.e. |x| >= 2^-3; below that the ABSOLUTE error is <= 2^-25 — weights
+// are therefore pre-multiplied by an exact power of two at split time, undone in alpha), and a product a*b is evaluated
+// as  ahi*bhi + ahi*blo + alo*bhi  with THREE v_mfma_f32_32x32x16_f16 into ONE f32 accumulator (each f16 x f16 product is
+// exact in f32); the dropped lo*lo term is 2^-22 relative.  Measured on the ViT-B/16 image tower the
 // feature error vs f64 is 6.9e-8 (plain f32: 6.1e-8, plain f16: 5.3e-5, bf16: 4.7e-4), i.e. the
 // 1e-3 logit tolerance of the RLCF parity contract holds with the margin of the f32 path while
 // the contraction runs on the 2.5 PF f16 MFMA pipe instead of the 157 TF f32 one.
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
 
-    f32x16 acc[2][2], cor[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // staging: each operand tile = 128 rows x 64 B = 512 16-B chunks, 2 per thread (rows r0 and r0+64)
     const int r0 = t >> 2, c8 = (t & 3) * 8;
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
         if (kt + 1 < nk) X3_LSTORE(cur ^ 1)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r] + cor[i][j][r] * 0.00048828125f;
+                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r];
         __syncthreads();
         const int c4 = (lane & 15) * 4, rsub = lane >> 4;
         const int col = n0 + wn * 64 + c4;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)((v[q] - (float)hh[q]) * 2048.0f); }
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
                     *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
                 }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, h);
                 if (row >= g.M) continue;
-                float v = g.alpha * (acc[i][j][r] + cor[i][j][r] * 0.00048828125f) + bv;
+                float v = g.alpha * acc[i][j][r] + bv;
                 if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.Chi) {
                     const _Float16 hi = (_Float16)v;
                     g.Chi[(size_t)row * g.ldch + col] = hi;
-                    g.Clo[(size_t)row * g.ldch + col] = (_Float16)((v - (float)hi) * 2048.0f);
+                    g.Clo[(size_t)row * g.ldch + col] = (_Float16)(v - (float)hi);
                 }
             }
         }
@@ -221,13 +221,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
 
-    f32x16 acc[2][2], cor[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // DMA sources: A tile = 1024 chunks (2 wave-instructions per wave per array), W tile = 512 (1 each)
     const int qa0 = (wave * 2) * 64 + lane, qa1 = qa0 + 64, qw = wave * 64 + lane;
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     }
 #define V2_MMA3(i, j, AH, AL, BH, BL)                                                                                    \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);                                \
-    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], cor[i][j], 0, 0, 0);                                \
-    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], cor[i][j], 0, 0, 0);
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);                                \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);
 #define V2_FENCE __builtin_amdgcn_sched_barrier(0);
 
     const int nk = g.K / X3_BK;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r] + cor[i][j][r] * 0.00048828125f;
+                    park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[i][j][r];
         __syncthreads();
         const int c4 = (lane & 15) * 4, rsub = lane >> 4;
         const int col = n0 + wn * 64 + c4;
@@ -350,7 +350,152 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)((v[q] - (float)hh[q]) * 2048.0f); }
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// v3: 256x256 block tile, 8 waves (2x4) of 128x64 (8 MFMA tiles = 128 accumulator registers), BK = 32, DMA into a
+// 2-stage LDS ring (64 KB per stage: 512 operand rows x 64 B x {hi, lo}).  Two thirds of v2's DMA bytes and three
+// quarters of its LDS operand reads per MFMA — the resources the round-1 ablations identified as the limiter.
+#define V3_BM 256
+#define V3_BN 256
+#define V3_STAGE 65536                  // bytes: Ahi 16K | Alo 16K | Whi 16K | Wlo 16K
+#define V3_ALO 16384
+#define V3_WHI 32768
+#define V3_WLO 49152
+__global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
+    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n, grp = bid / per_group, first_m = grp * 8;
+    const int gsize = min(tiles_m - first_m, 8), in_g = bid - grp * per_group;
+    const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA: every operand tile = 256 rows x 4 chunks = 1024 chunks = 2 pieces per wave; 8 pieces per wave per stage
+    size_t sa[2], sw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (wave * 2 + j) * 64 + lane, r = q >> 2, c = ((q & 3) ^ ((r >> 2) & 3)) * 8;
+        sa[j] = (size_t)min(m0 + r, g.M - 1) * g.lda + c;
+        sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c;
+    }
+#define V3_PIECE(idx, kk, sb_)                                                                                                         \
+    {                                                                                                                                  \
+        if ((idx) < 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 1] + (kk)), (lptr_t)((sb_) + (wave * 2 + ((idx) & 1)) * 1024), 16, 0, 0);                   \
+        else if ((idx) < 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa[(idx) & 1] + (kk)), (lptr_t)((sb_) + V3_ALO + (wave * 2 + ((idx) & 1)) * 1024), 16, 0, 0);     \
+        else if ((idx) < 6) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 1] + (kk)), (lptr_t)((sb_) + V3_WHI + (wave * 2 + ((idx) & 1)) * 1024), 16, 0, 0);     \
+        else __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw[(idx) & 1] + (kk)), (lptr_t)((sb_) + V3_WLO + (wave * 2 + ((idx) & 1)) * 1024), 16, 0, 0);                    \
+    }
+#define V3_LDA(ks, AH, AL)                                                                                               \
+    {                                                                                                                    \
+        const int co_ = (((ks) * 2 + h) ^ swz) * 16;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+            AH[i] = *(const h16x8*)(sb + aoff + i * 2048 + co_);                                                         \
+            AL[i] = *(const h16x8*)(sb + V3_ALO + aoff + i * 2048 + co_);                                                \
+        }                                                                                                                \
+    }
+#define V3_LDB(ks, BH, BL)                                                                                               \
+    {                                                                                                                    \
+        const int co_ = (((ks) * 2 + h) ^ swz) * 16;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            BH[j] = *(const h16x8*)(sb + V3_WHI + boff + j * 2048 + co_);                                                \
+            BL[j] = *(const h16x8*)(sb + V3_WLO + boff + j * 2048 + co_);                                                \
+        }                                                                                                                \
+    }
+    const int nk = g.K / X3_BK;
+    {
+        char* s0 = smem;
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, 0, s0)
+    }
+    const int swz = (l32 >> 2) & 3;
+    const int aoff = (wm * 128 + l32) * 64, boff = (wn * 64 + l32) * 64;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                             // ... everybody's have, and tile kt-1's buffer is free
+        __builtin_amdgcn_sched_barrier(0);
+        const bool pf = kt + 1 < nk;
+        const int kn = (kt + 1) * g.kstep;
+        char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
+        const char* sb = smem + (kt & 1) * V3_STAGE;
+        h16x8 ah0[4], al0[4], bh0[2], bl0[2], ah1[4], al1[4], bh1[2], bl1[2];
+        V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
+        V2_FENCE
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
+                if (pf) V3_PIECE(i * 2 + j, kn, sn)
+                if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
+                V2_FENCE
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
+    }
+    // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
+    constexpr int ELD = 68;
+    float* park = (float*)smem + wave * (64 * ELD);
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int col = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && col < g.N) bv = *(const float4*)(g.bias + col);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i][j][r];
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 4 + rsub, row = m0 + wm * 128 + half * 64 + rl;
+                if (row >= g.M) continue;
+                const float4 a4 = *(const float4*)(park + rl * ELD + c4);
+                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                if (g.epilogue == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
+                    const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                }
+                if (g.residual) {
+                    const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.Chi) {
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
                     *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
                 }
@@ -380,6 +525,19 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     static int force = -1;                                   // RLCF_X3_KERNEL=1|2 pins a variant (benchmarks)
     if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
+    const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
+    if (v2_ok && (force == 3 || (force == 0 && blocks3 >= 512))) {
+        const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
+        static bool attr3 = false;
+        if (!attr3) {
+            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
+            attr3 = true;
+        }
+        gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        g_last_x3_variant = 3;
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
+    }
     if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;
         static bool attr2 = false;
@@ -400,26 +558,26 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
 }
 
 // x -> (hi, lo): hi = f16(x), lo = f16((x - hi) * 2^11).  8 elements per thread.
-__global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8) {
+__global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
         h16x8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const _Float16 hh = (_Float16)v[e];
             vh[e] = hh;
-            vl[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
+            vl[e] = (_Float16)(v[e] - (float)hh);
         }
         ((h16x8*)hi)[i] = vh;
         ((h16x8*)lo)[i] = vl;
     }
 }
-int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st) {
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0);
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    split_f16x2_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8);
+    split_f16x2_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                     h16x4 hh, ll;
                     const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)((ov[q] - (float)hh[q]) * 2048.0f); }
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)(ov[q] - (float)hh[q]); }
                     *(h16x4*)(yh + (size_t)row * width + c) = hh;
                     *(h16x4*)(yl + (size_t)row * width + c) = ll;
                 }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 if (yh) {
                     const _Float16 hh = (_Float16)o;
                     yh[(size_t)row * width + c] = hh;
-                    yl[(size_t)row * width + c] = (_Float16)((o - (float)hh) * 2048.0f);
+                    yl[(size_t)row * width + c] = (_Float16)(o - (float)hh);
                 }
             }
         }
@@ -264,7 +264,7 @@ __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__
         if (oh) {
             h16x4 hh, ll;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)o[q]; ll[q] = (_Float16)((o[q] - (float)hh[q]) * 2048.0f); }
+            for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)o[q]; ll[q] = (_Float16)(o[q] - (float)hh[q]); }
             *(h16x4*)(oh + (size_t)p * Kp + k4) = hh;
             *(h16x4*)(ol + (size_t)p * Kp + k4) = ll;
         }
@@ -653,6 +653,22 @@ int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, flo
     RLCF_ARG_CHECK(n > 0 && C > 0 && D > 0);
     RLCF_HIP_CHECK(hipMemsetAsync(dimg, 0, (size_t)n * D * sizeof(float), st));
     dimg_kernel<<<dim3(n, (D + 255) / 256, DIMG_PARTS), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ---------------------------------------------------------------- max |x| (weight pre-scaling of the split-f16 GEMMs)
+__global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));        // non-negative floats order like their bit patterns
+}
+int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st) {
+    RLCF_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), st));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    absmax_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, n, (unsigned int*)out_dev);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
