@@ -25,9 +25,9 @@ typedef struct rlcf_engine rlcf_engine;
 
 enum rlcf_status { RLCF_OK = 0, RLCF_ERR_ARG = -1, RLCF_ERR_HIP = -2, RLCF_ERR_STATE = -3, RLCF_ERR_NOMEM = -4 };
 enum rlcf_precision {
-    RLCF_PREC_F32 = 0,   /* parity mode: f32 storage, f32-input MFMA (exact f32 FMA chains)            */
-    RLCF_PREC_BF16 = 1,  /* performance mode: bf16 GEMM/attention operands, f32 accumulate/LN/softmax */
-    RLCF_PREC_F16X3 = 2  /* split-f16 mode: each f32 operand = hi+lo f16, 3 f16 MFMAs per product      */
+    RLCF_PREC_F32 = 0,   /* f32 storage, f32-input MFMA (exact f32 FMA chains, 157 TF pipe)                       */
+    RLCF_PREC_BF16 = 1,  /* reserved, not built: plain bf16 cannot meet the 1e-3 logit contract    */
+    RLCF_PREC_F16X3 = 2  /* split-f16: each f32 operand = hi+lo f16, 3 f16 MFMAs per product, f32-grade results  */
 };
 enum rlcf_epilogue {     /* GEMM epilogues (TPT/clip/model.py:166-168,177-181,190-191) */
     RLCF_EPI_NONE = 0,

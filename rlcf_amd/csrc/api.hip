@@ -38,7 +38,7 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
     }
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
-    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.out_bf16 = 0;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
     return launch_gemm_f32(g, (hipStream_t)stream);
 }
 int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream stream) {
@@ -54,7 +54,7 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
 }
 int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, rlcf_stream stream) {
     RLCF_ARG_CHECK(x && gamma && beta && y);
-    return launch_layernorm_fwd(x, gamma, beta, y, nullptr, rows, width, (hipStream_t)stream);
+    return launch_layernorm_fwd(x, gamma, beta, y, rows, width, (hipStream_t)stream);
 }
 int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                        int width, rlcf_stream stream) {

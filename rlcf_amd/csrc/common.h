@@ -26,7 +26,6 @@ void rlcf_set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
@@ -52,25 +51,15 @@ __device__ __forceinline__ float quick_gelu_grad(float f) {
     return s * (1.0f + 1.702f * f * (1.0f - s));
 }
 
-// bf16 helpers (round-to-nearest-even)
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
-
 // ---- internal launchers shared between translation units (all async on `st`) ----
 struct GemmArgs {
-    const void* A; int lda;        // [M,K]   f32 (F32 mode) or bf16 (BF16 mode)
+    const void* A; int lda;        // [M,K] f32
     const void* W; int ldw;        // [N,K]
     const float* bias;             // [N] or null
     const float* residual; int ldr;
     const float* aux; int ldaux;
-    void* C; int ldc;              // f32, or bf16 when out_bf16
+    void* C; int ldc;              // [M,N] f32
     int M, N, K;
     float alpha; int epilogue;
-    int out_bf16;
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
-int launch_gemm_bf16(const GemmArgs& g, hipStream_t st);

@@ -18,7 +18,6 @@ struct DevBuf {
 struct BlockW {                      // one ResidualAttentionBlock (TPT/clip/model.py:171-192)
     const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b;
     const float *in_wT = nullptr, *out_wT = nullptr, *fc_wT = nullptr, *proj_wT = nullptr;   // for dX = dY.W
-    const unsigned short *in_w16 = nullptr, *out_w16 = nullptr, *fc_w16 = nullptr, *proj_w16 = nullptr;  // bf16 copies
 };
 struct TowerW {
     int layers = 0, width = 0;
@@ -37,7 +36,7 @@ struct SavedLayer { float *x, *qkv, *a, *x1, *f; };
 
 struct Tower {                       // workspace of one transformer pass over T rows
     int T = 0, width = 0;
-    DevBuf x, h, qkv, a, f;          // f32 (F32 mode); bf16 views allocated separately
+    DevBuf x, h, qkv, a, f;          // f32 activations
     DevBuf hh, hl, ah, al, fh, fl;   // split-f16 operand pairs written by the producers (F16X3 mode)
     int x3_T = 0, x3_W = 0;
     DevBuf saved;                    // per-layer saved activations for backward
@@ -52,7 +51,6 @@ struct ClipModel {
     std::vector<DevBuf> derived;           // transposed / bf16 copies
     TowerW vis, txt;
     const float *conv_w = nullptr;         // [Wv, Kp] zero padded
-    const unsigned short* conv_w16 = nullptr;
     const float *cls = nullptr, *vpos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr, *lnpost_b = nullptr;
     const float *vprojT = nullptr;         // [D, Wv]
     const float *tok_emb = nullptr, *tpos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;

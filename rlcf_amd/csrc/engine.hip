@@ -51,7 +51,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
                 float a_scale = 1.0f) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
-    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi; g.out_bf16 = 0;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi;
     e->last_flops += 2.0 * M * N * K;
     if (e->precision == RLCF_PREC_F16X3 && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
         // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
@@ -323,12 +323,12 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* a = save ? ws.sv[l].a : ws.a.as<float>();
         float* h = ws.h.as<float>();
         float* f = ws.f.as<float>();
-        TRY(launch_layernorm_fwd(xin, b.ln1_w, b.ln1_b, h, nullptr, T, W, st));
+        TRY(launch_layernorm_fwd(xin, b.ln1_w, b.ln1_b, h, T, W, st));
         TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
         TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, st));
         e->last_flops += 4.0 * attn_pairs * W;
         TRY(gemm(e, a, W, b.out_w, W, b.out_b, xin, W, nullptr, 0, x1, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_fwd(x1, b.ln2_w, b.ln2_b, h, nullptr, T, W, st));
+        TRY(launch_layernorm_fwd(x1, b.ln2_w, b.ln2_b, h, T, W, st));
         if (save) {
             TRY(gemm(e, h, W, b.fc_w, W, b.fc_b, nullptr, 0, nullptr, 0, ws.sv[l].f, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_NONE, st));
             TRY(launch_quickgelu(ws.sv[l].f, f, (int64_t)T * 4 * W, st));
@@ -385,7 +385,7 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
                             false, st));
     TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
-    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), nullptr, n, Wv, st));
+    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), n, Wv, st));
     TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
              RLCF_EPI_NONE, st));
     TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, nullptr, n, D, st));
@@ -500,7 +500,7 @@ static int text_forward(rlcf_engine* e, ClipModel& m, const TextLayout& L, Tower
     TRY(launch_text_assemble(L.E.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), ctx, x0, io.T, Wt, io.rep_rows, io.ctx_stride, st));
     TRY(transformer_forward(e, m.txt, ws, io.seqs, io.n_seq, io.max_q_len, io.attn_pairs, 1, io.T, save, st));
     TRY(launch_gather_rows(ws.x.as<float>(), Wt, io.eot_rows, io.eot_x, Wt, io.n_cls, Wt, st));
-    TRY(launch_layernorm_fwd(io.eot_x, m.lnf_w, m.lnf_b, io.eot_ln, nullptr, io.n_cls, Wt, st));
+    TRY(launch_layernorm_fwd(io.eot_x, m.lnf_w, m.lnf_b, io.eot_ln, io.n_cls, Wt, st));
     TRY(gemm(e, io.eot_ln, Wt, m.tprojT, Wt, nullptr, nullptr, 0, nullptr, 0, io.u, D, io.n_cls, D, Wt, 1.f, RLCF_EPI_NONE, st));
     TRY(launch_l2norm_rows(io.u, io.txt, io.inv_norm, io.n_cls, D, st));
     return RLCF_OK;
@@ -907,7 +907,7 @@ static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, 
     TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.sv[0].x, n, tok, Wv, st));
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, true, st));
     TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
-    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), nullptr, n, Wv, st));
+    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), n, Wv, st));
     TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
              RLCF_EPI_NONE, st));
     TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));

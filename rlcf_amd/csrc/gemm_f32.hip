@@ -169,7 +169,6 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
     RLCF_ARG_CHECK(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 16 == 0);
     RLCF_ARG_CHECK(g.lda % 4 == 0 && g.ldw % 4 == 0);
     RLCF_ARG_CHECK(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0);
-    RLCF_ARG_CHECK(!g.out_bf16);
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     if (g.M <= 512 && g.K % 64 == 0) {
         const long nb = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);

@@ -2,12 +2,11 @@
 #pragma once
 #include "common.h"
 
-// LayerNorm fwd: y f32 (y) and/or bf16 (y_bf16) — either may be null.
-int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
-                         unsigned short* y_bf16, int rows, int width, hipStream_t st);
+// LayerNorm fwd: f32 output (launch_layernorm_fwd) or a split-f16 pair for the next GEMM (launch_layernorm_fwd_split).
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                          float* dgamma, float* dbeta, int rows, int width, hipStream_t st);
-// images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 or bf16)
+// images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 and/or a split-f16 pair)
 int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st);
@@ -28,13 +27,10 @@ int launch_scatter_rows(const float* src, const int32_t* rows_idx, float* dst, i
 int launch_ctx_grad(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, float* dctx, hipStream_t st);
 // dtxt[c,:] = scale * sum_i dlogits[i,c] * img[i,:]
 int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int D, float scale, float* dtxt, hipStream_t st);
-int launch_f32_to_bf16(const float* in, unsigned short* out, int64_t n, hipStream_t st);
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);   // out[cols,rows]
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
                              int causal, float* out, float* lse, hipStream_t st, void* out_hi = nullptr, void* out_lo = nullptr);
-int launch_attention_fwd_bf16(const unsigned short* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
-                              int causal, unsigned short* out, hipStream_t st);
 int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,
                          int causal, float* dqkv, hipStream_t st);
 

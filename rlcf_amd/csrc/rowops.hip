@@ -10,7 +10,7 @@
 // TPT/clip/model.py:157-163 (fp32, eps 1e-5, biased variance about the mean)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                            unsigned short* __restrict__ yb, _Float16* __restrict__ yh,
+                                                            _Float16* __restrict__ yh,
                                                             _Float16* __restrict__ yl, int rows, int width) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -61,10 +61,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 o.z = (v[4 * j + 2] - mu) * rstd * gg.z + bb.z;
                 o.w = (v[4 * j + 3] - mu) * rstd * gg.w + bb.w;
                 if (y) *(float4*)(y + (size_t)row * width + c) = o;
-                if (yb) {
-                    ushort4 ob = make_ushort4(f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w));
-                    *(ushort4*)(yb + (size_t)row * width + c) = ob;
-                }
                 if (yh) {                               // split-f16 pair for the consuming GEMM (gemm_f16x3.hip)
                     h16x4 hh, ll;
                     const float ov[4] = {o.x, o.y, o.z, o.w};
@@ -81,7 +77,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             if (c < width) {
                 float o = (v[j] - mu) * rstd * gamma[c] + beta[c];
                 if (y) y[(size_t)row * width + c] = o;
-                if (yb) yb[(size_t)row * width + c] = f2bf(o);
                 if (yh) {
                     const _Float16 hh = (_Float16)o;
                     yh[(size_t)row * width + c] = hh;
@@ -92,14 +87,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, unsigned short* y_bf16,
-                         int rows, int width, hipStream_t st) {
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st) {
     return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st);
 }
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
-    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, nullptr, (_Float16*)yh,
+    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
                                                                                                    (_Float16*)yl, rows, width);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -461,16 +455,6 @@ int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int 
 }
 
 // ---------------------------------------------------------------- conversions
-__global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
-}
-int launch_f32_to_bf16(const float* in, unsigned short* out, int64_t n, hipStream_t st) {
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    f32_to_bf16_kernel<<<dim3(blocks), dim3(256), 0, st>>>(in, out, n);
-    RLCF_LAUNCH_CHECK();
-    return RLCF_OK;
-}
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
