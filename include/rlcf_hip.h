@@ -135,6 +135,9 @@ int rlcf_engine_set_class_bank(rlcf_engine*, const int32_t* tokens_host, int C, 
 /* encode_image + L2 normalise (TPT/clip/model.py:223-240,340-341; custom_clip.py:327-330;
  * clip_reward.py:130-137).  images [n,3,R,R]; feats [n,D]. */
 int rlcf_encode_image(rlcf_engine*, int which, const float* images, int n, float* feats, rlcf_stream stream);
+/* same for images [n,3,in_res,in_res] at another resolution than the model's: bicubic, align_corners=True resample first
+ * (nn.functional.interpolate at clip_reward.py:133-134). */
+int rlcf_encode_image_resized(rlcf_engine*, int which, const float* images, int n, int in_res, float* feats, rlcf_stream stream);
 /* ClipTestTimeTuning.get_text_features (custom_clip.py:315-323): txt [C,D] normalised. */
 int rlcf_text_features(rlcf_engine*, const float* ctx, float* txt, rlcf_stream stream);
 /* reward class bank cached by set_class_bank: copies [C,Dr] out. */

@@ -91,6 +91,16 @@ def adamw_step(p, g, m, v, step: int, hp: TTAHyper):
     return p, m, v
 
 
+def reward_image_features(reward_sd, images: torch.Tensor) -> torch.Tensor:
+    """CLIPRewards.extract_image_features, TPT/clip_reward.py:130-137: bicubic (align_corners=True) resample to the reward
+    model's input resolution when it differs, encode_image, float, L2 normalise."""
+    ps = reward_sd["visual.conv1.weight"].shape[-1]
+    res = ps * round((reward_sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    if images.shape[-1] != res:
+        images = torch.nn.functional.interpolate(images, size=res, mode="bicubic", align_corners=True)
+    return C.l2_normalize(C.encode_image(reward_sd, images).float())
+
+
 def reward_class_features(reward_sd, tokens: torch.Tensor, truncate: bool = False) -> torch.Tensor:
     """BaseRewards.set_class_features -> extract_text_features(tokenized_cap=...),
     TPT/clip_reward.py:55-57,139-150; called once per dataset (tpt_cls_rl.py:182-183)."""
@@ -117,7 +127,7 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
             logits_all = C.student_logits(student_sd, views, tokens, ctx, truncate)
             output, selected = select_confident_samples(logits_all, hp.selection_p)
             with torch.no_grad():                           # clip_reward.py:130-137
-                rimg = C.l2_normalize(C.encode_image(reward_sd, views[selected]).float())
+                rimg = reward_image_features(reward_sd, views[selected])
         else:                                               # tpt_cls_rl.py:55
             logits_all = None
             output = C.student_logits(student_sd, views[selected], tokens, ctx, truncate)
@@ -193,7 +203,7 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
             logits_all = logits_of(views, prm)
             output, selected = select_confident_samples(logits_all, hp.selection_p)
             with torch.no_grad():
-                rimg = C.l2_normalize(C.encode_image(reward_sd, views[selected]).float())
+                rimg = reward_image_features(reward_sd, views[selected])
         else:
             logits_all = None
             output = logits_of(views[selected], prm)

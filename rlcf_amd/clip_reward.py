@@ -67,9 +67,7 @@ class CLIPRewards(BaseRewards):
     @torch.no_grad()
     def extract_image_features(self, images):
         """clip_reward.py:130-137: encode_image, float, L2 normalise."""
-        if images.shape[-1] != self.resolutions:
-            raise NotImplementedError("reward models that need the bicubic resolution change (clip_reward.py:133-134) "
-                                      "are a 'next' row (SURVEY.md §8f-3)")
+        # a resolution change (bicubic, align_corners=True, clip_reward.py:133-134) happens inside the engine
         return runtime.SESSION.engine(images.shape[0]).encode_image(L.REWARD, images)
 
     @torch.no_grad()

@@ -164,7 +164,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     }
     release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
     release_layout(e->lay[0]); release_layout(e->lay[1]);
-    DevBuf* all[] = {&e->patches, &e->patch_out, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
+    DevBuf* all[] = {&e->patches, &e->patch_out, &e->resized, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
                      &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->reward_cls, &e->sp_seqs,
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
@@ -199,6 +199,10 @@ int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C
 int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && (which == 0 || which == 1) && images && feats);
     return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream);
+}
+int rlcf_encode_image_resized(rlcf_engine* e, int which, const float* images, int n, int in_res, float* feats, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && images && feats && in_res > 0);
+    return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream, in_res);
 }
 int rlcf_text_features(rlcf_engine* e, const float* ctx, float* txt, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && ctx && txt);

@@ -68,7 +68,7 @@ struct rlcf_engine {
     ClipModel model[2];
     // ViT workspace (shared by student and reward passes)
     Tower vt;
-    DevBuf patches, patch_out, vit_seqs /*[2][max_views]*/, cls_rows, cls_ln, feat_raw;
+    DevBuf patches, patch_out, vit_seqs /*[2][max_views]*/, cls_rows, cls_ln, feat_raw, resized;
     // text
     int text_mode = RLCF_TEXT_SHARED, n_ctx = 0, C = 0;
     TextLayout lay[2];               // [student], [reward]
@@ -110,7 +110,7 @@ extern GemmProfile g_prof;
 // engine internals used by api.hip
 int engine_finalize(rlcf_engine* e, int which, hipStream_t st);
 int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st);
-int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st);
+int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st, int in_res = 0);
 int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt, hipStream_t st);
 int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st);
 int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);

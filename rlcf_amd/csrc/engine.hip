@@ -366,11 +366,17 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
 // ------------------------------------------------------------------ image tower
 // VisionTransformer.forward (TPT/clip/model.py:223-240) + L2 normalise (custom_clip.py:330,
 // clip_reward.py:136).  Runs under no_grad in the reference (custom_clip.py:325-327).
-int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st) {
+int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st, int in_res) {
     ClipModel& m = e->model[which];
     if (!m.finalized) { rlcf_set_error("model %d not finalized", which); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(n > 0 && n <= e->max_views);
     const rlcf_clip_cfg& c = m.cfg;
+    if (in_res > 0 && in_res != c.image_resolution) {
+        // the model wants another input size than the views have: bicubic, align_corners=True (clip_reward.py:133-134)
+        TRY(e->resized.ensure((size_t)e->max_views * 3 * c.image_resolution * c.image_resolution * sizeof(float)));
+        TRY(launch_bicubic(images, e->resized.as<float>(), n * 3, in_res, c.image_resolution, st));
+        images = e->resized.as<float>();
+    }
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
     if (e->precision == RLCF_PREC_F16X3 && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
         TRY(launch_im2col(images, nullptr, e->a_hi.p, e->a_lo.p, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
@@ -565,7 +571,7 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     TRY(e->top5.ensure(5 * sizeof(int32_t))); TRY(e->sel_feat.ensure((size_t)N * D * sizeof(float)));
     TRY(e->sel_logits.ensure((size_t)N * C * sizeof(float)));
     if (r.present) {
-        const int Dr = r.cfg.embed_dim, R = r.cfg.image_resolution;
+        const int Dr = r.cfg.embed_dim, R = s.cfg.image_resolution;        // selected views are kept at the student's resolution
         TRY(e->rimg.ensure((size_t)N * Dr * sizeof(float)));
         TRY(e->views_sel.ensure((size_t)N * 3 * R * R * sizeof(float)));
         TRY(e->reward_cls.ensure((size_t)C * Dr * sizeof(float)));
@@ -682,7 +688,6 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     const int n_sel = (int)(N * a->selection_p);              // int() truncation, tpt_cls_rl.py:34
     RLCF_ARG_CHECK(K <= C);
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
-    RLCF_ARG_CHECK(r.cfg.image_resolution == s.cfg.image_resolution);   // bicubic resample (clip_reward.py:133-134): not built yet
     const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const rlcf_tta_out none{};
@@ -719,7 +724,7 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st));
+            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st, s.cfg.image_resolution));
             TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
             rows_logits = e->sel_logits.as<float>();
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
@@ -811,7 +816,7 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
     TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
     TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
-    TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), BS, e->rimg.as<float>(), st));
+    TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), BS, e->rimg.as<float>(), st, s.cfg.image_resolution));
     TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
     // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
     TRY(launch_reward_loss_grouped(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
@@ -874,8 +879,7 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
     const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
                            !(a->flags & RLCF_F_MIN_ENTROPY) && a->sample_k > 1;
     const int Bmax = e->max_views / N;
-    const bool fused = Bmax >= 2 && a->tta_steps == 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0 &&
-                       r.cfg.image_resolution == s.cfg.image_resolution;
+    const bool fused = Bmax >= 2 && a->tta_steps == 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0;
     double flops = 0.0;
     int i = 0;
     while (i < count) {
@@ -941,7 +945,7 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim;
     const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
-    RLCF_ARG_CHECK(r.cfg.image_resolution == s.cfg.image_resolution && s.cfg.vision_width * 0 + s.tokens <= 320);
+    RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const size_t nb = (size_t)e->ln_count * sizeof(float);
     const rlcf_tta_out none{};
@@ -960,7 +964,7 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
             TRY(engine_logits(e, e->img_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st));
+            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st, s.cfg.image_resolution));
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
             COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
             COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));

@@ -73,3 +73,4 @@ int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_se
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
                             int tokens, int width, hipStream_t st);
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st);
+int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipStream_t st);

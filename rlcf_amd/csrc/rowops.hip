@@ -656,3 +656,47 @@ int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st) {
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+// ---------------------------------------------------------------- bicubic resample, align_corners=True
+// nn.functional.interpolate(images, size=res, mode='bicubic', align_corners=True) of TPT/clip_reward.py:133-134,264-266:
+// cubic convolution kernel with A = -0.75, source index = dst * (in-1)/(out-1), taps clamped at the border.
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+    const float A = -0.75f;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = ((A * (2.f - t) - 5.f * A) * (2.f - t) + 8.f * A) * (2.f - t) - 4.f * A;
+}
+__global__ void bicubic_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int Ri, int Ro) {
+    const long total = (long)planes * Ro * Ro;
+    const float sc = Ro > 1 ? (float)(Ri - 1) / (float)(Ro - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Ro), oy = (int)((idx / Ro) % Ro);
+        const long pl = idx / ((long)Ro * Ro);
+        const float sx = ox * sc, sy = oy * sc;
+        const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+        float wx[4], wy[4];
+        cubic_w(sx - x0, wx);
+        cubic_w(sy - y0, wy);
+        const float* p = in + pl * Ri * Ri;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(y0 - 1 + i, 0), Ri - 1);
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r += wx[j] * p[(size_t)yy * Ri + min(max(x0 - 1 + j, 0), Ri - 1)];
+            acc += wy[i] * r;
+        }
+        out[idx] = acc;
+    }
+}
+int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipStream_t st) {
+    RLCF_ARG_CHECK(planes > 0 && Ri > 0 && Ro > 0);
+    const long total = (long)planes * Ro * Ro;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    bicubic_kernel<<<dim3(blocks), dim3(256), 0, st>>>(in, out, planes, Ri, Ro);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

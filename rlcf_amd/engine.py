@@ -114,8 +114,12 @@ class Engine:
         g = self.student if which == L.STUDENT else self.reward
         images = images.to(self.device, torch.float32).contiguous()
         out = torch.empty(images.shape[0], g.embed_dim, device=self.device)
-        L.check(self.lib.rlcf_encode_image(self.h, which, _ptr(images), images.shape[0], _ptr(out), _stream()),
-                "encode_image")
+        if images.shape[-1] != g.image_resolution:          # bicubic resample inside the engine
+            L.check(self.lib.rlcf_encode_image_resized(self.h, which, _ptr(images), images.shape[0], images.shape[-1], _ptr(out),
+                                                       _stream()), "encode_image_resized")
+        else:
+            L.check(self.lib.rlcf_encode_image(self.h, which, _ptr(images), images.shape[0], _ptr(out), _stream()),
+                    "encode_image")
         return out
 
     def text_features(self, ctx: torch.Tensor) -> torch.Tensor:

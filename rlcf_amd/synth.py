@@ -61,6 +61,7 @@ GEOMETRIES: Dict[str, ClipGeometry] = {
     # reduced geometries for tests (head_dim stays 64 as in every CLIP)
     "tiny": ClipGeometry(128, 32, 2, 128, 8, 77, 1024, 128, 2, 2),
     "tiny-r": ClipGeometry(64, 32, 2, 128, 8, 77, 1024, 64, 1, 2),
+    "tiny-r64": ClipGeometry(64, 64, 2, 128, 16, 77, 1024, 64, 1, 2),     # reward model at twice the view resolution (bicubic path)
     "small": ClipGeometry(256, 64, 4, 256, 16, 77, 4096, 256, 4, 4),
 }
 

@@ -300,12 +300,14 @@ TTA_CASES = {
     "tta_tiny_minent": ("tiny", "tiny-r", 8, 16, dict(min_entropy_reg=1, min_entropy_w=0.2)),
     "tta_tiny_k1": ("tiny", "tiny-r", 8, 16, dict(sample_k=1, view_seed=1006)),
     "tta_small_s1": ("small", "small", 16, 40, dict(selection_p=0.25)),
+    "tta_tiny_rres": ("tiny", "tiny-r64", 8, 16, dict(view_seed=1003)),     # reward resolution != view resolution: bicubic resample
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
 GROUPS = {
-    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny")],
+    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres"],
+    "rres": ["tta_tiny_rres"],
     "small": ["tta_small_s1"],
     "b16n8": ["tta_b16_n8"],
     "b16n64": ["tta_b16_n64"],

@@ -307,7 +307,7 @@ def test_text_features_vs_oracle(L, dev, mode, geo, n_cls):
 
 
 TTA_FIXTURES = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-                "tta_small_s1"]
+                "tta_small_s1", "tta_tiny_rres"]
 
 
 def _cfg_from_meta(meta, sparse=True):
@@ -390,6 +390,22 @@ def test_fused_sample_batch_equals_per_sample(L, dev, geo, reward, n_cls, p, mod
         assert top5[i].tolist() == ref[i]["top5"].tolist()
         torch.testing.assert_close(fl[i], ref[i]["final_logits"][0], atol=2e-4, rtol=0)
     big.close()
+
+
+@pytest.mark.parametrize("ri,ro", [(32, 64), (224, 336), (64, 32), (17, 40)])
+def test_bicubic_resample_vs_torch(L, dev, ri, ro):
+    """The engine's reward-resolution change vs nn.functional.interpolate(mode='bicubic', align_corners=True)."""
+    from rlcf_amd.engine import Engine
+    geo = synth.ClipGeometry(64, ro, 1, 64, ro // 4 if ro % 4 == 0 else ro, 77, 1024, 64, 1, 1) if ro != 336 else synth.ClipGeometry(64, 336, 1, 64, 14, 77, 1024, 64, 1, 1)
+    sd = synth.make_state_dict(geo, 3)
+    eng = Engine(geo, None, 4, 8)
+    eng.load_state_dict(L.STUDENT, sd)
+    eng.finalize()
+    x = synth.normal(12, "bic", (3, 3, ri, ri))
+    f = eng.encode_image(L.STUDENT, x.to(dev)).cpu()
+    ref = CR.l2_normalize(CR.encode_image(sd, torch.nn.functional.interpolate(x, size=ro, mode="bicubic", align_corners=True)))
+    torch.testing.assert_close(f, ref, atol=1e-5, rtol=1e-4)
+    eng.close()
 
 
 def test_errors_are_loud(L, dev):

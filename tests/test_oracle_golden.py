@@ -40,7 +40,7 @@ def run_oracle(meta, truncate=False):
 
 
 TINY = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-        "tta_small_s1"]
+        "tta_small_s1", "tta_tiny_rres"]
 
 
 @pytest.mark.parametrize("name", TINY)
