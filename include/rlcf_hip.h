@@ -39,7 +39,7 @@ enum rlcf_text_mode {
     RLCF_TEXT_PACKED = 1,  /* rows after EOT dropped (exact under the causal mask)          */
     RLCF_TEXT_SHARED = 2   /* PACKED + the class-independent [SOT|ctx] rows computed once    */
 };
-enum rlcf_which { RLCF_STUDENT = 0, RLCF_REWARD = 1 };
+enum rlcf_which { RLCF_STUDENT = 0, RLCF_REWARD = 1 /* reward slot m (0-based) is RLCF_REWARD + m */ };
 
 const char* rlcf_last_error(void);
 int rlcf_version(void);
@@ -98,6 +98,7 @@ int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* ent
                         int32_t* idx, rlcf_stream stream);
 
 /* Flags of rlcf_reward_loss (TPT/params.py:55-59,65-66). */
+#define RLCF_MAX_REWARDS 4
 enum { RLCF_F_REWARD_PROCESS = 1, RLCF_F_AMPLIFY = 2, RLCF_F_PROCESS_BATCH = 4, RLCF_F_MIN_ENTROPY = 8 };
 /* The loss section of test_time_tuning (TPT/tpt_cls_rl.py:63-74) with
  * CLIPRewards.CLIPScore / rewards_post_process (TPT/clip_reward.py:111-128,152-165):
@@ -110,6 +111,16 @@ int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int
                      int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
                      float* dlogits, rlcf_stream stream);
 
+/* The same with an ENSEMBLE of reward models (CLIPRewardsMultiple.CLIPScore, TPT/clip_reward.py:228-257): per model m the
+ * clamped score max(w*<class_feats[m][idx], reward_imgs[m][i]>, 0); final score = sum_m mix[m]*score_m (weighted_scores) or
+ * (sum_m score_m)/n_models (mean != 0).  class_feats / reward_imgs / Dr / mix are HOST arrays of n_models (<= RLCF_MAX_REWARDS)
+ * entries; the pointers in them are device pointers. */
+int rlcf_reward_loss_ensemble(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K, int n_models,
+                              const float* const* class_feats, const float* const* reward_imgs, const int* Dr, const float* mix,
+                              int mean, float clipscore_weight, int flags, float min_entropy_w,
+                              int32_t* topk_idx, float* clip_score, float* rewards, float* loss, float* dlogits,
+                              rlcf_stream stream);
+
 /* torch.optim.AdamW single step (amsgrad off), TPT/tpt_cls_rl.py:78,120. step is 1-based. */
 int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -119,6 +130,13 @@ int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int
  * Owns device copies of the weights (plus derived layouts) and all workspace. */
 rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward /*NULL: none*/,
                                 int max_views, int max_classes, int precision);
+/* Engine with n_rewards (0..RLCF_MAX_REWARDS) reward models: get_reward_model(args.multiple_reward_models=1) builds
+ * CLIPRewardsMultiple over a list of CLIP archs (TPT/clip_reward.py:29-34,180-225).  Slot m is addressed as which = RLCF_REWARD+m. */
+rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlcf_clip_cfg* rewards, int n_rewards,
+                                         int max_views, int max_classes, int precision);
+/* Ensemble scoring rule: mix[n] = the reference's round(w/sum(w),2) weights (clip_reward.py:206,250-253) or, with mean != 0,
+ * torch.mean over models (:255).  n must equal the number of reward slots.  Default: slot 0 alone, weight 1. */
+int rlcf_engine_set_reward_mix(rlcf_engine*, const float* mix, int n, int mean);
 void rlcf_engine_destroy(rlcf_engine*);
 /* Copy one OpenAI-layout state-dict tensor (TPT/clip/model.py:399-436) into the engine. */
 int rlcf_engine_load_weight(rlcf_engine*, int which, const char* key, const float* dev_ptr, int64_t numel);
@@ -140,8 +158,8 @@ int rlcf_encode_image(rlcf_engine*, int which, const float* images, int n, float
 int rlcf_encode_image_resized(rlcf_engine*, int which, const float* images, int n, int in_res, float* feats, rlcf_stream stream);
 /* ClipTestTimeTuning.get_text_features (custom_clip.py:315-323): txt [C,D] normalised. */
 int rlcf_text_features(rlcf_engine*, const float* ctx, float* txt, rlcf_stream stream);
-/* reward class bank cached by set_class_bank: copies [C,Dr] out. */
-int rlcf_reward_class_features(rlcf_engine*, float* out, rlcf_stream stream);
+/* reward class bank of slot `which` (>= RLCF_REWARD) cached by set_class_bank: copies [C,Dr] out. */
+int rlcf_reward_class_features(rlcf_engine*, int which, float* out, rlcf_stream stream);
 /* logits = exp(logit_scale) * img @ txt^T (custom_clip.py:332-333). */
 int rlcf_logits(rlcf_engine*, const float* img, int n, const float* txt, int C, float* logits, rlcf_stream stream);
 /* d loss / d ctx given dlogits[n,C] w.r.t. logits = scale*img@txt(ctx)^T — what autograd does for

@@ -37,6 +37,9 @@ class TTAHyper:
     clipscore_weight: float = 2.5
     min_entropy_reg: bool = False
     min_entropy_w: float = 0.2
+    # reward ensemble (CLIPRewardsMultiple, TPT/clip_reward.py:180-257): per-model weights round(w/sum(w),2), or the plain mean
+    reward_weights: Optional[tuple] = None
+    weighted_scores: bool = True
 
 
 def entropy_rows(logits: torch.Tensor) -> torch.Tensor:
@@ -69,6 +72,18 @@ def clip_score(class_features: torch.Tensor, image_features: torch.Tensor, class
     return torch.clamp_min(s, 0.0).squeeze()
 
 
+def clip_score_any(reward_cls, rimg, class_index, hp: "TTAHyper") -> torch.Tensor:
+    """CLIPScore of one reward model, or of the ensemble (CLIPRewardsMultiple.CLIPScore, TPT/clip_reward.py:227-257):
+    per-model clamped scores stacked, then weighted sum over models (weighted_scores) or their mean."""
+    if not isinstance(reward_cls, (list, tuple)):
+        return clip_score(reward_cls, rimg, class_index, hp.sample_k, hp.clipscore_weight)
+    scores = torch.stack([clip_score(c, i, class_index, hp.sample_k, hp.clipscore_weight) for c, i in zip(reward_cls, rimg)], dim=0)
+    if hp.weighted_scores:
+        w = torch.tensor(hp.reward_weights, dtype=scores.dtype).unsqueeze(1)
+        return torch.sum(w * scores, dim=0)
+    return torch.mean(scores, dim=0)
+
+
 def rewards_post_process(score: torch.Tensor, reward_process: bool, amplify: bool) -> torch.Tensor:
     """CLIPRewards.rewards_post_process, TPT/clip_reward.py:152-165 (torch.std is
     the unbiased estimator)."""
@@ -91,7 +106,13 @@ def adamw_step(p, g, m, v, step: int, hp: TTAHyper):
     return p, m, v
 
 
-def reward_image_features(reward_sd, images: torch.Tensor) -> torch.Tensor:
+def reward_image_features(reward_sd, images: torch.Tensor):
+    if isinstance(reward_sd, (list, tuple)):                # one feature matrix per ensemble member (clip_reward.py:259-273)
+        return [reward_image_features(sd, images) for sd in reward_sd]
+    return _reward_image_features(reward_sd, images)
+
+
+def _reward_image_features(reward_sd, images: torch.Tensor) -> torch.Tensor:
     """CLIPRewards.extract_image_features, TPT/clip_reward.py:130-137: bicubic (align_corners=True) resample to the reward
     model's input resolution when it differs, encode_image, float, L2 normalise."""
     ps = reward_sd["visual.conv1.weight"].shape[-1]
@@ -101,7 +122,13 @@ def reward_image_features(reward_sd, images: torch.Tensor) -> torch.Tensor:
     return C.l2_normalize(C.encode_image(reward_sd, images).float())
 
 
-def reward_class_features(reward_sd, tokens: torch.Tensor, truncate: bool = False) -> torch.Tensor:
+def reward_class_features(reward_sd, tokens: torch.Tensor, truncate: bool = False):
+    if isinstance(reward_sd, (list, tuple)):                # clip_reward.py:275-291
+        return [reward_class_features(sd, tokens, truncate) for sd in reward_sd]
+    return _reward_class_features(reward_sd, tokens, truncate)
+
+
+def _reward_class_features(reward_sd, tokens: torch.Tensor, truncate: bool = False) -> torch.Tensor:
     """BaseRewards.set_class_features -> extract_text_features(tokenized_cap=...),
     TPT/clip_reward.py:55-57,139-150; called once per dataset (tpt_cls_rl.py:182-183)."""
     with torch.no_grad():
@@ -134,7 +161,7 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
         bs = output.shape[0]
         _, index = torch.topk(output, hp.sample_k, dim=-1)  # :63
         flat = index.flatten()
-        score = clip_score(reward_cls, rimg, flat, hp.sample_k, hp.clipscore_weight)
+        score = clip_score_any(reward_cls, rimg, flat, hp)
         rewards = rewards_post_process(score if hp.process_batch else score.reshape(bs, -1),
                                        hp.reward_process, hp.reward_amplify)
         rep = torch.repeat_interleave(output, hp.sample_k, dim=0)
@@ -148,7 +175,7 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
                        selected_idx=selected.clone(), topk_idx=index.clone(), clip_score=score.detach().clone(),
                        rewards=rewards.detach().clone(), loss=loss.detach().clone(), ctx_grad=grad.clone(),
                        dlogits=dlogits.clone(),
-                       reward_image_features=rimg.clone())
+                       reward_image_features=rimg[0].clone() if isinstance(rimg, list) else rimg.clone())
         with torch.no_grad():
             new_ctx, m, v = adamw_step(ctx.detach(), grad, m, v, j + 1, hp)
         ctx = new_ctx
@@ -210,7 +237,7 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
         bs = output.shape[0]
         _, index = torch.topk(output, hp.sample_k, dim=-1)
         flat = index.flatten()
-        score = clip_score(reward_cls, rimg, flat, hp.sample_k, hp.clipscore_weight)
+        score = clip_score_any(reward_cls, rimg, flat, hp)
         rewards = rewards_post_process(score if hp.process_batch else score.reshape(bs, -1), hp.reward_process, hp.reward_amplify)
         rep = torch.repeat_interleave(output, hp.sample_k, dim=0)
         loss = torch.mean(rewards * torch.nn.functional.cross_entropy(rep, flat, reduction="none"))

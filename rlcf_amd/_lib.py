@@ -17,6 +17,7 @@ PREC_F32, PREC_BF16, PREC_F16X3 = 0, 1, 2
 EPI_NONE, EPI_QUICKGELU, EPI_QUICKGELU_BWD = 0, 1, 2
 TEXT_DENSE, TEXT_PACKED, TEXT_SHARED = 0, 1, 2
 STUDENT, REWARD = 0, 1
+MAX_REWARDS = 4
 F_REWARD_PROCESS, F_AMPLIFY, F_PROCESS_BATCH, F_MIN_ENTROPY = 1, 2, 4, 8
 
 
@@ -70,7 +71,10 @@ SIGNATURES = {
     "rlcf_encode_image": (I, [P, I, P, I, P, P]),
     "rlcf_encode_image_resized": (I, [P, I, P, I, I, P, P]),
     "rlcf_text_features": (I, [P, P, P, P]),
-    "rlcf_reward_class_features": (I, [P, P, P]),
+    "rlcf_reward_class_features": (I, [P, I, P, P]),
+    "rlcf_engine_create_ensemble": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I, I]),
+    "rlcf_engine_set_reward_mix": (I, [P, P, I, I]),
+    "rlcf_reward_loss_ensemble": (I, [P, I, P, I, I, I, I, P, P, P, P, I, F, I, F, P, P, P, P, P, P]),
     "rlcf_logits": (I, [P, P, I, P, I, P, P]),
     "rlcf_text_backward_dense": (I, [P, P, P, I, P, P, P]),
     "rlcf_tta_sample": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),

@@ -1,5 +1,5 @@
 """Host-side mirror of the reference reward surface (TPT/clip_reward.py): `get_reward_model` (:29-40),
-`BaseRewards` (:43-73), `CLIPRewards` (:76-177).  The frozen reward CLIP lives in the shared HIP
+`BaseRewards` (:43-73), `CLIPRewards` (:76-177), `CLIPRewardsMultiple` (:180-307).  The frozen reward CLIP lives in the shared HIP
 engine (rlcf_amd.runtime); this class carries the flags the tuning loop reads and the cached features."""
 from __future__ import annotations
 
@@ -10,11 +10,17 @@ from . import _lib as L
 from . import clip_store, runtime
 
 
+# relative confidence of each reward arch in the ensemble (TPT/clip_reward.py:21-26); add entries for other checkpoints
+CONFIDECES = {"ViT-L/14@336px": 10, "ViT-L/14": 5, "RN50x64": 3, "ViT-B/16": 1}
+ENSEMBLE_ARCHS = ["ViT-L/14@336px", "RN50x64", "ViT-L/14"]     # the fixed list of get_reward_model (:31)
+
+
 def get_reward_model(device, args):
     """TPT/clip_reward.py:29-40."""
     if getattr(args, "multiple_reward_models", 0):
-        raise NotImplementedError("CLIPRewardsMultiple (reward ensemble, clip_reward.py:180-307) is a 'next' row "
-                                  "(SURVEY.md §8f-3): not built yet")
+        return CLIPRewardsMultiple(device, arch=list(ENSEMBLE_ARCHS), classification=True, amplify_rewards=args.reward_amplify,
+                                   sample_k=args.sample_k, reward_process=args.reward_process, process_batch=args.process_batch,
+                                   weighted_scores=args.weighted_scores)
     return CLIPRewards(device, arch=args.reward_arch, classification=True, amplify_rewards=args.reward_amplify,
                        sample_k=args.sample_k, reward_process=args.reward_process, process_batch=args.process_batch)
 
@@ -111,3 +117,66 @@ class CLIPRewards(BaseRewards):
     def calulate_similarity(self):
         """clip_reward.py:167-177."""
         return self.clipscore_weight * self.image_features @ self.class_features.t()
+
+
+class CLIPRewardsMultiple(BaseRewards):
+    """TPT/clip_reward.py:180-307: CLIP reward from an ensemble of frozen CLIP models.  Every model lives in a reward slot of
+    the shared HIP engine; the fused step mixes the per-model clamped scores in the reward kernel (rlcf_reward_loss_ensemble)."""
+
+    def __init__(self, device, arch=("ViT-B/16", "RN50x64", "ViT-L/14"), clipscore_weight=2.5, classification=True,
+                 amplify_rewards=False, sample_k=5, reward_process=True, process_batch=True, weighted_scores=True,
+                 default_resolutions=224) -> None:
+        super().__init__()
+        self.default_resolutions = default_resolutions
+        self.clip_models, self.preprocess, self.resolutions, weights = [], [], [], []
+        for ar in arch:
+            ckpt, _, pre = clip_store.load(ar, device=device)
+            self.clip_models.append(ckpt)
+            self.preprocess.append(pre)
+            self.resolutions.append(ckpt.geometry.image_resolution)
+            weights.append(CONFIDECES[ar])
+        self.n_model = len(self.clip_models)
+        self.weights = [round(x / sum(weights), 2) for x in weights]          # clip_reward.py:206
+        self.clipscore_weight, self.device, self.classification = clipscore_weight, device, classification
+        self.class_features = None
+        self.image_features = None
+        self.amplify_rewards, self.sample_k = amplify_rewards, sample_k
+        self.reward_process, self.process_batch, self.weighted_scores = reward_process, process_batch, weighted_scores
+        runtime.SESSION.set_rewards(self.clip_models, self.weights, mean=not weighted_scores)
+
+    @torch.no_grad()
+    def extract_image_features(self, images):
+        """clip_reward.py:259-273: one normalised feature matrix per model (bicubic resize inside the engine)."""
+        eng = runtime.SESSION.engine(images.shape[0])
+        return [eng.encode_image(L.REWARD + i, images) for i in range(self.n_model)]
+
+    @torch.no_grad()
+    def extract_text_features(self, captions=None, tokenized_cap=None):
+        """clip_reward.py:275-291."""
+        if tokenized_cap is None:
+            tokenized_cap = clip_store.tokenize(captions, truncate=True)
+        bank = runtime.SESSION.tokens
+        if bank is None or bank.shape != tokenized_cap.shape or not torch.equal(bank, tokenized_cap.detach().cpu()):
+            raise NotImplementedError("reward class bank must be the student's tokenized_prompts (tpt_cls_rl.py:183)")
+        eng = runtime.SESSION.engine()
+        return [eng.reward_class_features(i) for i in range(self.n_model)]
+
+    @torch.no_grad()
+    def CLIPScore(self, class_index, images=None, image_features=None, captions=None, tokenized_cap=None, text_features=None,
+                  pairwise=True):
+        """clip_reward.py:227-257: per-model clamped similarity, then the weighted sum (or the mean) over models."""
+        if pairwise:
+            raise NotImplementedError               # as the reference (:240)
+        all_scores = []
+        for i in range(self.n_model):
+            t = self.class_features[i][class_index.long()]
+            im = torch.repeat_interleave(self.image_features[i], self.sample_k, dim=0)
+            sim = self.clipscore_weight * torch.sum(t * im, dim=-1)
+            all_scores.append(torch.maximum(sim, torch.zeros_like(sim)).squeeze())
+        scores = torch.stack(all_scores, dim=0)
+        if self.weighted_scores:
+            w = torch.tensor(self.weights, device=scores.device, dtype=scores.dtype).unsqueeze(1)
+            return torch.sum(w * scores, dim=0)
+        return torch.mean(scores, dim=0)
+
+    rewards_post_process = CLIPRewards.rewards_post_process

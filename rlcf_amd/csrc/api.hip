@@ -87,6 +87,20 @@ int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int
     return launch_reward_loss(logits, ld_logits, sel, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags, min_entropy_w,
                               topk_idx, clip_score, rewards, loss, dlogits, (hipStream_t)stream);
 }
+int rlcf_reward_loss_ensemble(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K, int n_models,
+                              const float* const* class_feats, const float* const* reward_imgs, const int* Dr, const float* mix, int mean,
+                              float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards,
+                              float* loss, float* dlogits, rlcf_stream stream) {
+    RLCF_ARG_CHECK(logits && class_feats && reward_imgs && Dr && (mean || mix) && n_models >= 1 && n_models <= RLCF_MAX_REWARDS);
+    RewardBank b{};
+    b.n = n_models;
+    for (int m = 0; m < n_models; ++m) {
+        b.class_feat[m] = class_feats[m]; b.reward_img[m] = reward_imgs[m]; b.Dr[m] = Dr[m]; b.mix[m] = mean ? 1.f : mix[m];
+    }
+    b.post_div = mean ? (float)n_models : 1.f;
+    return launch_reward_loss_bank(logits, ld_logits, sel, 1, n_sel, C, K, b, clipscore_weight, flags, min_entropy_w, topk_idx, clip_score,
+                                   rewards, loss, dlogits, (hipStream_t)stream);
+}
 int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2,
                     float eps, float weight_decay, rlcf_stream stream) {
     RLCF_ARG_CHECK(p && g && m && v);
@@ -101,8 +115,16 @@ static bool cfg_ok(const rlcf_clip_cfg* c) {
            c->text_heads * HEAD_DIM == c->text_width;
 }
 
+static bool which_ok(const rlcf_engine* e, int which) { return e && which >= 0 && which <= RLCF_MAX_REWARDS && e->model[which].present; }
+
 rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward, int max_views, int max_classes, int precision) {
-    if (!cfg_ok(student) || (reward && !cfg_ok(reward)) || max_views <= 0 || max_classes <= 0) {
+    return rlcf_engine_create_ensemble(student, reward, reward ? 1 : 0, max_views, max_classes, precision);
+}
+rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlcf_clip_cfg* rewards, int n_rewards, int max_views,
+                                         int max_classes, int precision) {
+    bool cfgs_ok = cfg_ok(student) && n_rewards >= 0 && n_rewards <= RLCF_MAX_REWARDS && (n_rewards == 0 || rewards);
+    for (int m = 0; cfgs_ok && m < n_rewards; ++m) cfgs_ok = cfg_ok(&rewards[m]);
+    if (!cfgs_ok || max_views <= 0 || max_classes <= 0) {
         rlcf_set_error("rlcf_engine_create: bad geometry / sizes");
         return nullptr;
     }
@@ -116,10 +138,11 @@ rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cf
     if (!e) return nullptr;
     e->precision = precision; e->max_views = max_views; e->max_classes = max_classes;
     e->model[0].cfg = *student; e->model[0].present = true;
-    if (reward) { e->model[1].cfg = *reward; e->model[1].present = true; }
+    e->n_rewards = n_rewards;
+    for (int m = 0; m < n_rewards; ++m) { e->model[1 + m].cfg = rewards[m]; e->model[1 + m].present = true; }
     int Tmax = 0, Wmax = 0, Pmax = 0, Kpmax = 0, Dmax = 0;
-    std::vector<rlcf_seq> seqs((size_t)2 * max_views);
-    for (int w = 0; w < 2; ++w) {
+    std::vector<rlcf_seq> seqs((size_t)(1 + RLCF_MAX_REWARDS) * max_views);
+    for (int w = 0; w <= RLCF_MAX_REWARDS; ++w) {
         if (!e->model[w].present) continue;
         const rlcf_clip_cfg& c = e->model[w].cfg;
         const int g = c.image_resolution / c.vision_patch_size, tok = g * g + 1;
@@ -163,12 +186,13 @@ void rlcf_engine_destroy(rlcf_engine* e) {
         for (auto& d : m.derived) d.release();
     }
     release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
-    release_layout(e->lay[0]); release_layout(e->lay[1]);
+    for (auto& L : e->lay) release_layout(L);
+    for (int m = 0; m < RLCF_MAX_REWARDS; ++m) { e->reward_cls[m].release(); e->rimg[m].release(); }
     DevBuf* all[] = {&e->patches, &e->patch_out, &e->resized, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
-                     &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->reward_cls, &e->sp_seqs,
+                     &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->sp_seqs,
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
-                     &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->rimg, &e->views_sel, &e->topk_idx,
+                     &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->views_sel, &e->topk_idx,
                      &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
                      &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat};
@@ -177,7 +201,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
 }
 
 int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const float* dev_ptr, int64_t numel) {
-    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && key && dev_ptr && numel > 0);
+    RLCF_ARG_CHECK(e && which_ok(e, which) && key && dev_ptr && numel > 0);
     if (!e->model[which].present) { rlcf_set_error("model %d not configured", which); return RLCF_ERR_STATE; }
     DevBuf& d = e->model[which].raw[key];
     if (d.bytes != (size_t)numel * sizeof(float)) { d.release(); int rc = d.ensure((size_t)numel * sizeof(float)); if (rc) return rc; }
@@ -187,7 +211,7 @@ int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const fl
 }
 int rlcf_engine_finalize(rlcf_engine* e, rlcf_stream stream) {
     RLCF_ARG_CHECK(e);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w <= RLCF_MAX_REWARDS; ++w)
         if (e->model[w].present) { int rc = engine_finalize(e, w, (hipStream_t)stream); if (rc) return rc; }
     return RLCF_OK;
 }
@@ -197,22 +221,28 @@ int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C
     return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream);
 }
 int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && images && feats);
+    RLCF_ARG_CHECK(e && which_ok(e, which) && images && feats);
     return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream);
 }
 int rlcf_encode_image_resized(rlcf_engine* e, int which, const float* images, int n, int in_res, float* feats, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && (which == 0 || which == 1) && images && feats && in_res > 0);
+    RLCF_ARG_CHECK(e && which_ok(e, which) && images && feats && in_res > 0);
     return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream, in_res);
 }
 int rlcf_text_features(rlcf_engine* e, const float* ctx, float* txt, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && ctx && txt);
     return engine_text_features(e, RLCF_STUDENT, ctx, txt, (hipStream_t)stream);
 }
-int rlcf_reward_class_features(rlcf_engine* e, float* out, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && out);
-    if (!e->model[1].present || e->C <= 0) { rlcf_set_error("reward class bank not set"); return RLCF_ERR_STATE; }
-    RLCF_HIP_CHECK(hipMemcpyAsync(out, e->reward_cls.p, (size_t)e->C * e->model[1].cfg.embed_dim * sizeof(float), hipMemcpyDeviceToDevice,
-                                  (hipStream_t)stream));
+int rlcf_reward_class_features(rlcf_engine* e, int which, float* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && out && which >= RLCF_REWARD && which_ok(e, which));
+    if (e->C <= 0) { rlcf_set_error("reward class bank not set"); return RLCF_ERR_STATE; }
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, e->reward_cls[which - RLCF_REWARD].p, (size_t)e->C * e->model[which].cfg.embed_dim * sizeof(float),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RLCF_OK;
+}
+int rlcf_engine_set_reward_mix(rlcf_engine* e, const float* mix, int n, int mean) {
+    RLCF_ARG_CHECK(e && n == e->n_rewards && (mean || mix));
+    e->reward_mean = mean ? 1 : 0;
+    for (int m = 0; m < n; ++m) e->reward_mix[m] = mix ? mix[m] : 1.f;
     return RLCF_OK;
 }
 int rlcf_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, rlcf_stream stream) {

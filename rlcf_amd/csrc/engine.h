@@ -65,17 +65,19 @@ struct ClipModel {
 
 struct rlcf_engine {
     int precision = RLCF_PREC_F32, max_views = 0, max_classes = 0;
-    ClipModel model[2];
+    ClipModel model[1 + RLCF_MAX_REWARDS];      // [0] student, [1..] reward slots (CLIPRewards: 1, CLIPRewardsMultiple: up to 4)
+    int n_rewards = 0, reward_mean = 0;
+    float reward_mix[RLCF_MAX_REWARDS] = {1.f, 0.f, 0.f, 0.f};
     // ViT workspace (shared by student and reward passes)
     Tower vt;
     DevBuf patches, patch_out, vit_seqs /*[2][max_views]*/, cls_rows, cls_ln, feat_raw, resized;
     // text
     int text_mode = RLCF_TEXT_SHARED, n_ctx = 0, C = 0;
-    TextLayout lay[2];               // [student], [reward]
+    TextLayout lay[1 + RLCF_MAX_REWARDS];   // [student], [reward slots]
     Tower tt;                        // text workspace (max of both layouts)
     DevBuf eot_x, eot_ln, u, inv_norm, txt, txt0;    // [C,*]; txt0 = text features at ctx_init
     DevBuf ctx_init, ctx, adam_m, adam_v, ctx_grad;  // [n_ctx, Wt]
-    DevBuf reward_cls;               // [C, Dr]
+    DevBuf reward_cls[RLCF_MAX_REWARDS];   // [C, Dr] per reward slot
     // sparse backward layout (n_e entries)
     int sp_max_e = 0, sp_T = 0;
     DevBuf sp_seqs, sp_eot_rows, sp_row_src, sp_ctx_rows_list, sp_dtxt, sp_txt, sp_inv_norm, sp_eot_x, sp_eot_ln, sp_u, sp_du, sp_dxe;
@@ -83,7 +85,7 @@ struct rlcf_engine {
     DevBuf dX, dA, dH, dF, dQKV;     // backward scratch (sized for the largest backward pass)
     int bwd_T = 0;
     // TTA step scratch
-    DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg, views_sel, topk_idx, clip_score, rewards, loss, dlogits,
+    DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg[RLCF_MAX_REWARDS], views_sel, topk_idx, clip_score, rewards, loss, dlogits,
         dtxt_dense, final_logits, top5;
     // sample-batched step (rlcf_tta_batch): B test images share every tower pass
     DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;

@@ -543,12 +543,12 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     const int Wt = s.cfg.text_width, D = s.cfg.embed_dim;
     TRY(build_layout(e, s, e->lay[0], tokens, C, n_ctx, true, text_mode, st));
     int Tmax = e->lay[0].T, Wmax = Wt, Dmax = D;
-    ClipModel& r = e->model[RLCF_REWARD];
-    if (r.present) {
-        if (!r.finalized) { rlcf_set_error("reward not finalized"); return RLCF_ERR_STATE; }
+    for (int m = 0; m < e->n_rewards; ++m) {
+        ClipModel& r = e->model[RLCF_REWARD + m];
+        if (!r.finalized) { rlcf_set_error("reward model %d not finalized", m); return RLCF_ERR_STATE; }
         RLCF_ARG_CHECK(r.cfg.context_length == s.cfg.context_length);
-        TRY(build_layout(e, r, e->lay[1], tokens, C, n_ctx, false, text_mode, st));
-        Tmax = std::max(Tmax, e->lay[1].T); Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim);
+        TRY(build_layout(e, r, e->lay[1 + m], tokens, C, n_ctx, false, text_mode, st));
+        Tmax = std::max(Tmax, e->lay[1 + m].T); Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim);
     }
     TRY(tower_ensure(e->tt, Tmax, Wmax));
     if (e->precision == RLCF_PREC_F16X3 && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
@@ -570,15 +570,19 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     TRY(e->dlogits.ensure((size_t)N * C * sizeof(float))); TRY(e->final_logits.ensure((size_t)C * sizeof(float)));
     TRY(e->top5.ensure(5 * sizeof(int32_t))); TRY(e->sel_feat.ensure((size_t)N * D * sizeof(float)));
     TRY(e->sel_logits.ensure((size_t)N * C * sizeof(float)));
-    if (r.present) {
-        const int Dr = r.cfg.embed_dim, R = s.cfg.image_resolution;        // selected views are kept at the student's resolution
-        TRY(e->rimg.ensure((size_t)N * Dr * sizeof(float)));
+    if (e->n_rewards > 0) {
+        const int R = s.cfg.image_resolution;                // selected views are kept at the student's resolution
         TRY(e->views_sel.ensure((size_t)N * 3 * R * R * sizeof(float)));
-        TRY(e->reward_cls.ensure((size_t)C * Dr * sizeof(float)));
-        // BaseRewards.set_class_features (clip_reward.py:55-57,139-150): once per class bank
-        TextPassIO io = full_io(e, e->lay[1]);
-        io.txt = e->reward_cls.as<float>();
-        TRY(text_forward(e, r, e->lay[1], e->tt, nullptr, io, false, st));
+    }
+    for (int m = 0; m < e->n_rewards; ++m) {
+        ClipModel& r = e->model[RLCF_REWARD + m];
+        const int Dr = r.cfg.embed_dim;
+        TRY(e->rimg[m].ensure((size_t)N * Dr * sizeof(float)));
+        TRY(e->reward_cls[m].ensure((size_t)C * Dr * sizeof(float)));
+        // BaseRewards.set_class_features (clip_reward.py:55-57,139-150,272-289): once per class bank, per reward model
+        TextPassIO io = full_io(e, e->lay[1 + m]);
+        io.txt = e->reward_cls[m].as<float>();
+        TRY(text_forward(e, r, e->lay[1 + m], e->tt, nullptr, io, false, st));
     }
     // Text features of the pristine prompt: every test sample starts from ctx_init (model.reset(),
     // tpt_cls_rl.py:251-253), so the first-step text forward is sample-independent -> computed once here.
@@ -677,14 +681,38 @@ static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_fe
 }
 
 // ------------------------------------------------------------------ one test sample
+// set_image_features of every reward model on the selected views (clip_reward.py:59-61,130-137,259-270); the optional
+// output is the per-model blocks [rows, Dr_m] one after another.
+static int reward_encode(rlcf_engine* e, int rows, int in_res, float* out_concat, hipStream_t st) {
+    for (int m = 0; m < e->n_rewards; ++m) {
+        const int Dr = e->model[RLCF_REWARD + m].cfg.embed_dim;
+        TRY(engine_encode_image(e, RLCF_REWARD + m, e->views_sel.as<float>(), rows, e->rimg[m].as<float>(), st, in_res));
+        if (out_concat) {
+            RLCF_HIP_CHECK(hipMemcpyAsync(out_concat, e->rimg[m].p, (size_t)rows * Dr * sizeof(float), hipMemcpyDeviceToDevice, st));
+            out_concat += (size_t)rows * Dr;
+        }
+    }
+    return RLCF_OK;
+}
+static RewardBank reward_bank(const rlcf_engine* e) {
+    RewardBank b{};
+    b.n = e->n_rewards;
+    for (int m = 0; m < e->n_rewards; ++m) {
+        b.class_feat[m] = e->reward_cls[m].as<float>(); b.reward_img[m] = e->rimg[m].as<float>();
+        b.Dr[m] = e->model[RLCF_REWARD + m].cfg.embed_dim;
+        b.mix[m] = e->reward_mean ? 1.f : e->reward_mix[m];
+    }
+    b.post_div = e->reward_mean ? (float)e->n_rewards : 1.f;
+    return b;
+}
+
 // Harness body TPT/tpt_cls_rl.py:251-262 around test_time_tuning (:47-79).
 #define COPY_OUT(dst, src, bytes) do { if (dst) RLCF_HIP_CHECK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, st)); } while (0)
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
-    ClipModel& r = e->model[RLCF_REWARD];
-    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16);
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
     const int n_sel = (int)(N * a->selection_p);              // int() truncation, tpt_cls_rl.py:34
     RLCF_ARG_CHECK(K <= C);
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
@@ -724,18 +752,17 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st, s.cfg.image_resolution));
+            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
             TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
             rows_logits = e->sel_logits.as<float>();
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
             COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
             COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
-            COPY_OUT(out->reward_image_features, e->rimg.p, (size_t)n_sel * Dr * sizeof(float));
         } else {        // tpt_cls_rl.py:55 — selected views only; their image features are unchanged
             TRY(engine_logits(e, e->sel_feat.as<float>(), n_sel, txt_j, C, e->sel_logits.as<float>(), st));
             rows_logits = e->sel_logits.as<float>();
         }
-        TRY(launch_reward_loss(rows_logits, C, nullptr, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+        TRY(launch_reward_loss_bank(rows_logits, C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
                                e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
         if (sparse_ok) {
@@ -801,9 +828,8 @@ static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
 static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                            hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
-    ClipModel& r = e->model[RLCF_REWARD];
     const TextLayout& L = e->lay[0];
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
     const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     TRY(batch_ensure(e, B, st));
@@ -816,10 +842,10 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
     TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
     TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
-    TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), BS, e->rimg.as<float>(), st, s.cfg.image_resolution));
+    TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
     TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
     // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
-    TRY(launch_reward_loss_grouped(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+    TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e),
                                    a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
                                    e->dlogits.as<float>(), st));
     // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
@@ -871,8 +897,7 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                      hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
-    ClipModel& r = e->model[RLCF_REWARD];
-    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const int n_sel = (int)(N * a->selection_p);
@@ -939,10 +964,9 @@ static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int
 
 int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
-    ClipModel& r = e->model[RLCF_REWARD];
-    if (e->C <= 0 || !r.present) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Dr = r.cfg.embed_dim;
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
     const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
     RLCF_ARG_CHECK(s.tokens <= 320);
@@ -964,15 +988,14 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
             TRY(engine_logits(e, e->img_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(engine_encode_image(e, RLCF_REWARD, e->views_sel.as<float>(), n_sel, e->rimg.as<float>(), st, s.cfg.image_resolution));
+            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
             COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
             COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
-            COPY_OUT(out->reward_image_features, e->rimg.p, (size_t)n_sel * Dr * sizeof(float));
         }
         TRY(vit_forward_saved(e, s, e->views_sel.as<float>(), n_sel, e->ln_feat.as<float>(), st));
         TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
-        TRY(launch_reward_loss(e->sel_logits.as<float>(), C, nullptr, n_sel, C, K, e->reward_cls.as<float>(), e->rimg.as<float>(), Dr,
+        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
                                e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
         TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st));

@@ -59,6 +59,17 @@ int launch_replicate_layout(const rlcf_seq* seqs, int n_seq, const int32_t* eot_
                             int32_t* eot_rep, hipStream_t st);
 int launch_broadcast_rows(const float* in, float* out, int n, int B, hipStream_t st);
 int launch_entropy_select_batched(const float* logits, int B, int n, int C, int n_sel, float* entropy, int32_t* idx_global, hipStream_t st);
+struct RewardBank {                  // reward models of one CLIPScore evaluation (CLIPRewards: n = 1; CLIPRewardsMultiple: n <= 4)
+    int n;
+    const float* class_feat[RLCF_MAX_REWARDS];   // [C, Dr[m]]
+    const float* reward_img[RLCF_MAX_REWARDS];   // [rows, Dr[m]]
+    int Dr[RLCF_MAX_REWARDS];
+    float mix[RLCF_MAX_REWARDS];                 // score = (sum_m mix[m] * max(w*dot_m, 0)) / post_div
+    float post_div;
+};
+int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
+                            const RewardBank& bank, float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx,
+                            float* clip_score, float* rewards, float* loss, float* dlogits, hipStream_t st);
 int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                                const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                                float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,

@@ -106,8 +106,7 @@ int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* e
 // stats[i] = {lse, ce[K], score[K]} packed as 1 + 2*MAX_K floats.
 #define STAT_LD (1 + 2 * MAX_K)
 __global__ __launch_bounds__(TTA_THREADS) void reward_stage_a_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ sel,
-                                                                     int C, int K, const float* __restrict__ class_feat,
-                                                                     const float* __restrict__ reward_img, int Dr, float weight,
+                                                                     int C, int K, RewardBank bank, float weight,
                                                                      int32_t* __restrict__ topk_idx, float* __restrict__ stats) {
     __shared__ float red[TTA_THREADS / 64];
     __shared__ float redv[TTA_THREADS / 64];
@@ -138,13 +137,18 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_a_kernel(const float
         }
         __syncthreads();
     }
-    for (int k = 0; k < K; ++k) {                      // CLIPScore: w * <class_feat[idx], img_i>, clamped at 0
-        const float* t = class_feat + (size_t)chosen[k] * Dr;
-        const float* im = reward_img + (size_t)i * Dr;
-        float d = 0.f;
-        for (int c = threadIdx.x; c < Dr; c += TTA_THREADS) d += t[c] * im[c];
-        d = block_sum(d, red);
-        if (threadIdx.x == 0) stats[i * STAT_LD + 1 + MAX_K + k] = fmaxf(weight * d, 0.f);
+    for (int k = 0; k < K; ++k) {                      // CLIPScore: w * <class_feat[idx], img_i>, clamped at 0, mixed over the reward models
+        float score = 0.f;
+        for (int m = 0; m < bank.n; ++m) {
+            const int Dr = bank.Dr[m];
+            const float* t = bank.class_feat[m] + (size_t)chosen[k] * Dr;
+            const float* im = bank.reward_img[m] + (size_t)i * Dr;
+            float d = 0.f;
+            for (int c = threadIdx.x; c < Dr; c += TTA_THREADS) d += t[c] * im[c];
+            d = block_sum(d, red);
+            score += bank.mix[m] * fmaxf(weight * d, 0.f);
+        }
+        if (threadIdx.x == 0) stats[i * STAT_LD + 1 + MAX_K + k] = bank.post_div == 1.f ? score : score / bank.post_div;
     }
     if (threadIdx.x == 0) stats[i * STAT_LD] = lse;
 }
@@ -251,25 +255,35 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
 static float* g_stats = nullptr;     // [max rows][STAT_LD] scratch owned by the library
 static int g_stats_rows = 0;
 // groups test samples of n_sel rows each (rows = groups*n_sel); loss[groups]; everything else row-major over all rows
-int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
-                               const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
-                               float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
-                               float* dlogits, hipStream_t st) {
+int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
+                            const RewardBank& bank, float clipscore_weight, int flags,
+                            float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                            float* dlogits, hipStream_t st) {
     RLCF_ARG_CHECK(groups > 0 && n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx);
+    RLCF_ARG_CHECK(bank.n >= 1 && bank.n <= RLCF_MAX_REWARDS);
+    for (int m = 0; m < bank.n; ++m) RLCF_ARG_CHECK(bank.class_feat[m] && bank.reward_img[m] && bank.Dr[m] > 0);
     const int rows = groups * n_sel;
     if (g_stats_rows < rows) {                           // grows only on a new maximum (setup time)
         if (g_stats) (void)hipFree(g_stats);
         g_stats_rows = rows < 64 ? 64 : rows;
         RLCF_HIP_CHECK(hipMalloc(&g_stats, (size_t)g_stats_rows * STAT_LD * sizeof(float)));
     }
-    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, class_feat, reward_img, Dr,
-                                                                    clipscore_weight, topk_idx, g_stats);
+    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, bank, clipscore_weight, topk_idx, g_stats);
     RLCF_LAUNCH_CHECK();
     const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
     reward_stage_b_kernel<<<dim3(rows), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
                                                                      topk_idx, g_stats, clip_score, rewards, loss, dlogits);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
+}
+int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
+                               const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
+                               float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
+                               float* dlogits, hipStream_t st) {
+    RewardBank bank{};
+    bank.n = 1; bank.class_feat[0] = class_feat; bank.reward_img[0] = reward_img; bank.Dr[0] = Dr; bank.mix[0] = 1.f; bank.post_div = 1.f;
+    return launch_reward_loss_bank(logits, ld_logits, sel, groups, n_sel, C, K, bank, clipscore_weight, flags, min_entropy_w, topk_idx,
+                                   clip_score, rewards, loss, dlogits, st);
 }
 int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                        const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,

@@ -60,19 +60,22 @@ class TTAConfig:
 
 
 class Engine:
-    """One student CLIP (+ optional frozen reward CLIP) resident on the current GPU."""
+    """One student CLIP (+ frozen reward CLIPs: one geometry, or a list of up to MAX_REWARDS for the ensemble of
+    CLIPRewardsMultiple, slot m addressed as which = REWARD + m) resident on the current GPU."""
 
-    def __init__(self, student: ClipGeometry, reward: Optional[ClipGeometry], max_views: int, max_classes: int,
-                 precision: int = L.PREC_F32):
+    def __init__(self, student: ClipGeometry, reward, max_views: int, max_classes: int, precision: int = L.PREC_F32):
         if not torch.cuda.is_available():
             raise L.RlcfError("rlcf_amd.Engine needs a GPU: the HIP path has no CPU fallback")
         self.lib = L.lib()
-        self.student, self.reward = student, reward
+        self.rewards = [] if reward is None else (list(reward) if isinstance(reward, (list, tuple)) else [reward])
+        if len(self.rewards) > L.MAX_REWARDS:
+            raise L.RlcfError(f"at most {L.MAX_REWARDS} reward models")
+        self.student, self.reward = student, (self.rewards[0] if self.rewards else None)
         self.max_views, self.max_classes, self.precision = max_views, max_classes, precision
         sc = _cfg(student)
-        rc = _cfg(reward) if reward is not None else None
-        self.h = self.lib.rlcf_engine_create(C.byref(sc), C.byref(rc) if rc is not None else None, max_views,
-                                             max_classes, precision)
+        rcs = (L.ClipCfg * max(1, len(self.rewards)))(*[_cfg(r) for r in self.rewards])
+        self.h = self.lib.rlcf_engine_create_ensemble(C.byref(sc), rcs if self.rewards else None, len(self.rewards), max_views,
+                                                      max_classes, precision)
         if not self.h:
             raise L.RlcfError("rlcf_engine_create: " + self.lib.rlcf_last_error().decode())
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -101,6 +104,11 @@ class Engine:
     def finalize(self) -> None:
         L.check(self.lib.rlcf_engine_finalize(self.h, _stream()), "finalize")
 
+    def set_reward_mix(self, weights=None, mean: bool = False) -> None:
+        """Ensemble rule of CLIPRewardsMultiple.CLIPScore (clip_reward.py:248-255): weighted sum, or the mean over models."""
+        w = (C.c_float * len(self.rewards))(*([1.0] * len(self.rewards) if weights is None else [float(x) for x in weights]))
+        L.check(self.lib.rlcf_engine_set_reward_mix(self.h, w, len(self.rewards), 1 if mean else 0), "set_reward_mix")
+
     def set_class_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor,
                        text_mode: int = L.TEXT_SHARED) -> None:
         tok = np.ascontiguousarray(tokens.detach().cpu().numpy().astype(np.int32))
@@ -111,7 +119,7 @@ class Engine:
 
     # ---- tower passes ------------------------------------------------------------
     def encode_image(self, which: int, images: torch.Tensor) -> torch.Tensor:
-        g = self.student if which == L.STUDENT else self.reward
+        g = self.student if which == L.STUDENT else self.rewards[which - L.REWARD]
         images = images.to(self.device, torch.float32).contiguous()
         out = torch.empty(images.shape[0], g.embed_dim, device=self.device)
         if images.shape[-1] != g.image_resolution:          # bicubic resample inside the engine
@@ -128,9 +136,9 @@ class Engine:
         L.check(self.lib.rlcf_text_features(self.h, _ptr(ctx), _ptr(out), _stream()), "text_features")
         return out
 
-    def reward_class_features(self) -> torch.Tensor:
-        out = torch.empty(self.n_cls, self.reward.embed_dim, device=self.device)
-        L.check(self.lib.rlcf_reward_class_features(self.h, _ptr(out), _stream()), "reward_class_features")
+    def reward_class_features(self, slot: int = 0) -> torch.Tensor:
+        out = torch.empty(self.n_cls, self.rewards[slot].embed_dim, device=self.device)
+        L.check(self.lib.rlcf_reward_class_features(self.h, L.REWARD + slot, _ptr(out), _stream()), "reward_class_features")
         return out
 
     def logits(self, img: torch.Tensor, txt: torch.Tensor) -> torch.Tensor:
@@ -151,7 +159,8 @@ class Engine:
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
         n_sel = int(N * cfg.selection_p)
-        D, Dr, Wt = self.student.embed_dim, self.reward.embed_dim, self.student.transformer_width
+        Wt = self.student.transformer_width
+        Dr = sum(r.embed_dim for r in self.rewards)     # per-model blocks [n_sel, Dr_m], one after another
         dev = self.device
         o: Dict[str, torch.Tensor] = {
             "final_logits": torch.empty(1, Cn, device=dev), "top5": torch.empty(5, dtype=torch.int32, device=dev),
@@ -163,12 +172,16 @@ class Engine:
                      clip_score=torch.empty(n_sel * K, device=dev), rewards=torch.empty(n_sel * K, device=dev),
                      loss=torch.empty(1, device=dev), dlogits=torch.empty(n_sel, Cn, device=dev),
                      ctx_grad=torch.empty(self.n_ctx, Wt, device=dev),
-                     reward_image_features=torch.empty(n_sel, Dr, device=dev))
+                     reward_image_features=torch.empty(n_sel * Dr, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
         if ctx_in is not None:
             ctx_in = ctx_in.detach().to(dev, torch.float32).contiguous()
         a = cfg.c_args(skip_final, ctx_in)
         L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
+        if "reward_image_features" in o:
+            parts = torch.split(o["reward_image_features"], [n_sel * r.embed_dim for r in self.rewards])
+            parts = [p.view(n_sel, r.embed_dim) for p, r in zip(parts, self.rewards)]
+            o["reward_image_features"] = parts[0] if len(parts) == 1 else parts
         return o
 
     def ln_params(self, pristine: bool = False) -> torch.Tensor:

@@ -19,7 +19,9 @@ TEXT_MODES = {"dense": L.TEXT_DENSE, "packed": L.TEXT_PACKED, "shared": L.TEXT_S
 class Session:
     def __init__(self):
         self.student = None          # ClipCheckpoint
-        self.reward = None           # ClipCheckpoint
+        self.rewards = []            # ClipCheckpoints: one (CLIPRewards) or several (CLIPRewardsMultiple)
+        self.reward_mix = None       # ensemble weights (None: single model)
+        self.reward_mean = False
         self.tokens: Optional[torch.Tensor] = None
         self.n_ctx = 0
         self.ctx_init: Optional[torch.Tensor] = None
@@ -33,8 +35,15 @@ class Session:
     def set_student(self, ckpt):
         self.student = ckpt
 
+    @property
+    def reward(self):
+        return self.rewards[0] if self.rewards else None
+
     def set_reward(self, ckpt):
-        self.reward = ckpt
+        self.rewards, self.reward_mix, self.reward_mean = [ckpt], None, False
+
+    def set_rewards(self, ckpts, weights, mean: bool):
+        self.rewards, self.reward_mix, self.reward_mean = list(ckpts), [float(w) for w in weights], bool(mean)
 
     def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor):
         self.tokens, self.n_ctx, self.ctx_init = tokens.detach().cpu(), n_ctx, ctx_init.detach().clone()
@@ -45,16 +54,18 @@ class Session:
         if n_views > self.max_views:
             self.max_views = n_views
         n_cls = int(self.tokens.shape[0]) if self.tokens is not None else 1
-        key = (id(self.student), id(self.reward), self.max_views, self.precision)
+        key = (id(self.student), tuple(id(r) for r in self.rewards), self.max_views, self.precision)
         if self._engine is None or key != self._key or n_cls > self._engine.max_classes:
             if self._engine is not None:
                 self._engine.close()
-            eng = Engine(self.student.geometry, self.reward.geometry if self.reward else None, self.max_views,
+            eng = Engine(self.student.geometry, [r.geometry for r in self.rewards] or None, self.max_views,
                          max(n_cls, 1), self.precision)
             eng.load_state_dict(L.STUDENT, self.student.state_dict)
-            if self.reward:
-                eng.load_state_dict(L.REWARD, self.reward.state_dict)
+            for m, r in enumerate(self.rewards):
+                eng.load_state_dict(L.REWARD + m, r.state_dict)
             eng.finalize()
+            if self.reward_mix is not None:
+                eng.set_reward_mix(self.reward_mix, self.reward_mean)
             self._engine, self._key, self._bank_key = eng, key, None
         if self.tokens is not None:
             bkey = (id(self.tokens), self.n_ctx, self.text_mode, float(self.ctx_init.float().abs().sum()))

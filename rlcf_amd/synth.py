@@ -215,3 +215,10 @@ def ctx_token_ids_default(geo: ClipGeometry, n_ctx: int) -> Tuple[int, ...]:
     base = (320, 1125, 539, 320)
     out = tuple(base[i % 4] % (geo.vocab_size - 2) for i in range(n_ctx))
     return out
+
+
+def reward_members(spec: str, seeds) -> list:
+    """'geoA+geoB+...' and '23+29+...' (or a list of ints) -> [(geometry, state dict), ...]: the members of a reward ensemble."""
+    names = spec.split("+")
+    seeds = [int(x) for x in seeds.split("+")] if isinstance(seeds, str) else list(seeds)
+    return [(GEOMETRIES[n], make_state_dict(GEOMETRIES[n], seed=s)) for n, s in zip(names, seeds)]

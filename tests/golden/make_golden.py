@@ -104,9 +104,12 @@ def install_models(ref, sds):
 def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4):
     """The harness body TPT/tpt_cls_rl.py:251-262 around the reference's own
     test_time_tuning, with taps on its intermediates."""
-    s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    ensemble = "+" in reward
+    s_geo = synth.GEOMETRIES[student]
     s_sd = synth.make_state_dict(s_geo, seed=11)
-    r_sd = synth.make_state_dict(r_geo, seed=23)
+    if not ensemble:
+        r_geo = synth.GEOMETRIES[reward]
+        r_sd = synth.make_state_dict(r_geo, seed=23)
     install_models(ref, {student: (s_geo, s_sd)})
     bank = Bank(s_geo, n_cls, n_ctx)
     ref.custom.tokenize = bank.tokenize
@@ -119,11 +122,23 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"],
                                  min_entropy_reg=hp.get("min_entropy_reg", 0),
                                  min_entropy_w=hp.get("min_entropy_w", 0.2), gpu=None, tpt=True)
-    install_models(ref, {reward: (r_geo, r_sd)})      # student and reward may share an arch name
-    rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True,
-                                     amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
-                                     reward_process=hp.get("reward_process", True),
-                                     process_batch=hp.get("process_batch", False))
+    if ensemble:
+        # CLIPRewardsMultiple (clip_reward.py:180-307) over three of the arch names its CONFIDECES table knows, each bound
+        # to a seeded synthetic CLIP
+        members = synth.reward_members(reward, hp["reward_seeds"])
+        install_models(ref, {a: m for a, m in zip(ENSEMBLE_NAMES, members)})
+        rm = ref.clip_reward.CLIPRewardsMultiple("cpu", arch=ENSEMBLE_NAMES[: len(members)], classification=True,
+                                                 amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
+                                                 reward_process=hp.get("reward_process", True),
+                                                 process_batch=hp.get("process_batch", False),
+                                                 weighted_scores=bool(hp.get("weighted_scores", 1)),
+                                                 default_resolutions=s_geo.image_resolution)
+    else:
+        install_models(ref, {reward: (r_geo, r_sd)})      # student and reward may share an arch name
+        rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True,
+                                         amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
+                                         reward_process=hp.get("reward_process", True),
+                                         process_batch=hp.get("process_batch", False))
     assert torch.equal(model.prompt_learner.tokenized_prompts, bank.tokens)
     rm.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
     with warnings.catch_warnings():
@@ -179,9 +194,15 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
         topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]), clip_score=taps["clip_score"],
         rewards=taps["rewards"], ctx_grad=grads[0], ctx_after=model.prompt_learner.ctx.detach().clone(),
         final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0],
-        reward_image_features=rm.image_features.clone(), reward_class_features=rm.class_features.clone(),
         ref_seconds=torch.tensor([t1 - t0, t2 - t1]),
     )
+    if ensemble:
+        for i in range(rm.n_model):
+            out[f"reward_image_features_{i}"] = rm.image_features[i].clone()
+            out[f"reward_class_features_{i}"] = rm.class_features[i].clone()
+        out["reward_weights"] = torch.tensor(rm.weights)
+    else:
+        out.update(reward_image_features=rm.image_features.clone(), reward_class_features=rm.class_features.clone())
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
@@ -289,8 +310,11 @@ def save(name, arrays, meta):
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
+ENSEMBLE_NAMES = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]      # CONFIDECES 10, 5, 1 -> weights [0.62, 0.31, 0.06]
+
 BASE_HP = dict(lr=7e-3, weight_decay=5e-4, sample_k=3, tta_steps=1, selection_p=0.5)
 
+ENS_SEED = int(os.environ.get("ENS_SEED", "1000"))
 TTA_CASES = {
     # name: (student, reward, N, C, hp overrides)
     "tta_tiny_s1": ("tiny", "tiny-r", 8, 16, {}),
@@ -301,13 +325,17 @@ TTA_CASES = {
     "tta_tiny_k1": ("tiny", "tiny-r", 8, 16, dict(sample_k=1, view_seed=1006)),
     "tta_small_s1": ("small", "small", 16, 40, dict(selection_p=0.25)),
     "tta_tiny_rres": ("tiny", "tiny-r64", 8, 16, dict(view_seed=1003)),     # reward resolution != view resolution: bicubic resample
+    # reward ensemble: three reward CLIPs (one at another resolution), weighted sum / plain mean of the clamped scores
+    "tta_tiny_ens": ("tiny", "tiny-r64+tiny-r+tiny-r", 8, 16, dict(reward_seeds="23+29+31", view_seed=ENS_SEED)),
+    "tta_tiny_ensmean": ("tiny", "tiny-r64+tiny-r+tiny-r", 8, 16, dict(reward_seeds="23+29+31", weighted_scores=0, view_seed=ENS_SEED)),
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
 GROUPS = {
-    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres"],
+    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k],
     "rres": ["tta_tiny_rres"],
+    "ens": ["tta_tiny_ens", "tta_tiny_ensmean"],
     "small": ["tta_small_s1"],
     "b16n8": ["tta_b16_n8"],
     "b16n64": ["tta_b16_n64"],
@@ -412,7 +440,8 @@ def main():
                 meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23,
                             view_seed=vseed, bank_seed=7, n_ctx=4, **hp)
                 save(name, arrays, meta)
-                print(f"  {name}: {time.time() - t0:.1f}s  idx={arrays['selected_idx']}  top5={arrays['top5']}")
+                print(f"  {name}: {time.time() - t0:.1f}s  idx={arrays['selected_idx']}  top5={arrays['top5']} "
+                      f"score={arrays['clip_score']} |g|={np.linalg.norm(arrays['ctx_grad']):.3e}")
 
 
 if __name__ == "__main__":

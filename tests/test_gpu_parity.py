@@ -354,6 +354,79 @@ def test_tta_sample_matches_reference_fixture(L, dev, name, sparse, mode):
     eng.close()
 
 
+def make_ensemble_engine(meta, mode, n_views=None, prec=0):
+    from rlcf_amd import _lib
+    from rlcf_amd.engine import Engine
+    sg = synth.GEOMETRIES[meta["student"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    members = synth.reward_members(meta["reward"], meta["reward_seeds"])
+    eng = Engine(sg, [g for g, _ in members], n_views or meta["n_views"], meta["n_cls"], prec)
+    eng.load_state_dict(_lib.STUDENT, ssd)
+    for m, (_, sd) in enumerate(members):
+        eng.load_state_dict(_lib.REWARD + m, sd)
+    eng.finalize()
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    eng.set_class_bank(tokens, meta["n_ctx"], CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(sg, meta["n_ctx"])), mode)
+    return eng, members, tokens
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("name", ["tta_tiny_ens", "tta_tiny_ensmean"])
+def test_reward_ensemble_matches_reference_fixture(L, dev, name, sparse, mode):
+    """CLIPRewardsMultiple (clip_reward.py:180-307): three reward CLIPs (one at another input resolution), weighted / mean."""
+    g, meta = load_golden(name)
+    eng, members, tokens = make_ensemble_engine(meta, mode)
+    eng.set_reward_mix(g["reward_weights"].tolist(), mean=not meta.get("weighted_scores", 1))
+    for m in range(len(members)):
+        torch.testing.assert_close(eng.reward_class_features(m).cpu(), g[f"reward_class_features_{m}"], atol=2e-5, rtol=1e-4)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution)
+    o = eng.tta_sample(views.to(dev), _cfg_from_meta(meta, sparse))
+    torch.cuda.synchronize()
+    for m in range(len(members)):
+        torch.testing.assert_close(o["reward_image_features"][m].cpu(), g[f"reward_image_features_{m}"], atol=2e-5, rtol=1e-4)
+    _check_against(o, g, meta)
+    # the fused sample batch mixes the same way
+    top5 = eng.tta_batch(views.to(dev)[None], _cfg_from_meta(meta, True))
+    assert top5[0].cpu().tolist() == g["top5"].tolist()
+    eng.close()
+
+
+def test_reward_loss_ensemble_abi(L, dev):
+    """rlcf_reward_loss_ensemble with one member == rlcf_reward_loss; with mix (a, b) on the same member == (a+b) * score."""
+    import ctypes as C
+    n_sel, Cn, K, Dr = 4, 50, 3, 64
+    logits = synth.normal(31, "ens.logits", (n_sel, Cn), 2.0).to(dev)
+    cf = CR.l2_normalize(synth.normal(31, "ens.cf", (Cn, Dr))).to(dev)
+    im = CR.l2_normalize(synth.normal(31, "ens.im", (n_sel, Dr))).to(dev)
+
+    def run(n, mix, mean):
+        topk = torch.empty(n_sel, K, dtype=torch.int32, device=dev)
+        sc, rw, dl = torch.empty(n_sel * K, device=dev), torch.empty(n_sel * K, device=dev), torch.empty(n_sel, Cn, device=dev)
+        loss = torch.empty(1, device=dev)
+        if n == 0:
+            rc = L.lib().rlcf_reward_loss(logits.data_ptr(), Cn, None, n_sel, Cn, K, cf.data_ptr(), im.data_ptr(), Dr, 2.5, 1, 0.0,
+                                          topk.data_ptr(), sc.data_ptr(), rw.data_ptr(), loss.data_ptr(), dl.data_ptr(), None)
+        else:
+            cfs = (C.c_void_p * n)(*[cf.data_ptr()] * n)
+            ims = (C.c_void_p * n)(*[im.data_ptr()] * n)
+            drs = (C.c_int * n)(*[Dr] * n)
+            mx = (C.c_float * n)(*mix)
+            rc = L.lib().rlcf_reward_loss_ensemble(logits.data_ptr(), Cn, None, n_sel, Cn, K, n, cfs, ims, drs, mx, mean, 2.5, 1, 0.0,
+                                                   topk.data_ptr(), sc.data_ptr(), rw.data_ptr(), loss.data_ptr(), dl.data_ptr(), None)
+        L.check(rc, "reward_loss")
+        torch.cuda.synchronize()
+        return sc.cpu(), rw.cpu(), dl.cpu()
+
+    base = run(0, None, 0)
+    one = run(1, [1.0], 0)
+    assert torch.equal(base[0], one[0]) and torch.equal(base[2], one[2])
+    two = run(2, [0.25, 0.5], 0)
+    torch.testing.assert_close(two[0], 0.75 * base[0], atol=1e-7, rtol=1e-6)
+    mean3 = run(3, [1.0, 1.0, 1.0], 1)
+    torch.testing.assert_close(mean3[0], base[0], atol=1e-7, rtol=1e-6)
+
+
 def test_tta_batch_and_reset(L, dev):
     """Per-sample reset (tpt_cls_rl.py:251-255): a batch gives the same predictions as one-by-one calls."""
     g, meta = load_golden("tta_tiny_s1")
@@ -474,14 +547,23 @@ def _harness_objects(dev, meta):
     import types
     from rlcf_amd import clip_reward, clip_store, custom_clip, runtime
     runtime.reset_session()
-    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    sg = synth.GEOMETRIES[meta["student"]]
     clip_store.register_checkpoint(meta["student"], sg, synth.make_state_dict(sg, meta["student_seed"]))
-    clip_store.register_checkpoint(meta["reward"] + "#r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    ensemble = "+" in meta["reward"]
+    if ensemble:        # get_reward_model(multiple_reward_models=1): CLIPRewardsMultiple over a fixed arch list (clip_reward.py:29-34)
+        names = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]          # the names the fixture generator bound the members to
+        for n, (geo, sd) in zip(names, synth.reward_members(meta["reward"], meta["reward_seeds"])):
+            clip_store.register_checkpoint(n, geo, sd)
+        clip_reward.ENSEMBLE_ARCHS[:] = names
+    else:
+        rg = synth.GEOMETRIES[meta["reward"]]
+        clip_store.register_checkpoint(meta["reward"] + "#r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
     bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
     clip_store.set_tokenizer(bank.tokenize)
     args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
                                  min_entropy_reg=meta.get("min_entropy_reg", 0), min_entropy_w=meta.get("min_entropy_w", 0.2),
-                                 reward_arch=meta["reward"] + "#r", multiple_reward_models=0, sample_k=meta["sample_k"],
+                                 reward_arch=meta["reward"] + "#r", multiple_reward_models=int(ensemble),
+                                 weighted_scores=meta.get("weighted_scores", 1), sample_k=meta["sample_k"],
                                  reward_amplify=meta.get("reward_amplify", False), reward_process=True,
                                  process_batch=meta.get("process_batch", False))
     model = custom_clip.get_coop(meta["student"], "I", dev, meta["n_ctx"], "a_photo_of_a", classnames=bank.classnames)
@@ -496,7 +578,7 @@ def _harness_objects(dev, meta):
     return model, optimizer, optim_state, reward_model, args
 
 
-@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1"])
+@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean"])
 def test_reference_harness_runs_on_the_hip_path(L, dev, name):
     """The reference's main_worker/test_time_adapt_eval call sequence (tpt_cls_rl.py:94-190,219-279) with this
     package's classes in place of the reference's: same ctx update and final logits as the reference run."""
@@ -516,11 +598,12 @@ def test_reference_harness_runs_on_the_hip_path(L, dev, name):
     runtime.reset_session()
 
 
-def test_autograd_route_matches_reference_gradient(L, dev):
+@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_ens"])
+def test_autograd_route_matches_reference_gradient(L, dev, name):
     """model(images) is differentiable w.r.t. ctx exactly like the reference module: an unmodified copy of the
     reference loop (torch ops for the loss, loss.backward()) yields the reference's ctx.grad."""
     from rlcf_amd import runtime, tpt_cls_rl
-    g, meta = load_golden("tta_tiny_s1")
+    g, meta = load_golden(name)
     model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
     views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
     output = model(views)

@@ -26,28 +26,35 @@ def hyper(meta):
                       reward_amplify=bool(meta.get("reward_amplify", False)),
                       process_batch=bool(meta.get("process_batch", False)),
                       min_entropy_reg=bool(meta.get("min_entropy_reg", 0)),
-                      min_entropy_w=float(meta.get("min_entropy_w", 0.2)))
+                      min_entropy_w=float(meta.get("min_entropy_w", 0.2)),
+                      weighted_scores=bool(meta.get("weighted_scores", 1)))
 
 
-def run_oracle(meta, truncate=False):
-    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+def run_oracle(meta, truncate=False, weights=None):
+    sg = synth.GEOMETRIES[meta["student"]]
     ssd = synth.make_state_dict(sg, meta["student_seed"])
-    rsd = synth.make_state_dict(rg, meta["reward_seed"])
+    if "+" in meta["reward"]:               # reward ensemble: a list of state dicts
+        rsd = [sd for _, sd in synth.reward_members(meta["reward"], meta["reward_seeds"])]
+    else:
+        rsd = synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"])
     tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
     views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
     ctx0 = C.ctx_from_tokens(ssd, synth.ctx_token_ids_default(sg, meta["n_ctx"]))
-    return R.tta_sample(ssd, rsd, views, tokens, ctx0, hyper(meta), truncate=truncate)
+    hp = hyper(meta)
+    if weights is not None:
+        hp.reward_weights = tuple(float(w) for w in weights)
+    return R.tta_sample(ssd, rsd, views, tokens, ctx0, hp, truncate=truncate)
 
 
 TINY = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-        "tta_small_s1", "tta_tiny_rres"]
+        "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean"]
 
 
 @pytest.mark.parametrize("name", TINY)
 @pytest.mark.parametrize("truncate", [False, True])
 def test_tta_matches_reference(name, truncate):
     g, meta = load(name)
-    o = run_oracle(meta, truncate)
+    o = run_oracle(meta, truncate, g.get("reward_weights"))
     assert torch.equal(o["selected_idx"], g["selected_idx"])
     assert torch.equal(o["topk_idx"], g["topk_idx"])
     assert torch.equal(o["top5"], g["top5"])
@@ -149,9 +156,12 @@ LN_CASES = ["ln_tiny_s1", "ln_tiny_s3", "ln_small_s1"]
 def test_ln_tuning_oracle_matches_reference(name):
     """CLIPCLS_TTA(only_norm=True) + test_time_tuning of the reference (TPT/tune_cls_rl.py) vs oracle.tta_sample_ln."""
     g, meta = load(name)
-    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    sg = synth.GEOMETRIES[meta["student"]]
     ssd = synth.make_state_dict(sg, meta["student_seed"])
-    rsd = synth.make_state_dict(rg, meta["reward_seed"])
+    if "+" in meta["reward"]:               # reward ensemble: a list of state dicts
+        rsd = [sd for _, sd in synth.reward_members(meta["reward"], meta["reward_seeds"])]
+    else:
+        rsd = synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"])
     tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
     views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
     o = R.tta_sample_ln(ssd, rsd, views, tokens, hyper(meta))
