@@ -32,7 +32,8 @@ enum rlcf_precision {
 enum rlcf_epilogue {     /* GEMM epilogues (TPT/clip/model.py:166-168,177-181,190-191) */
     RLCF_EPI_NONE = 0,
     RLCF_EPI_QUICKGELU = 1,      /* y = v*sigmoid(1.702 v)                                   */
-    RLCF_EPI_QUICKGELU_BWD = 2   /* y = v * d/df[f*sigmoid(1.702 f)] with f = aux            */
+    RLCF_EPI_QUICKGELU_BWD = 2,  /* y = v * d/df[f*sigmoid(1.702 f)] with f = aux            */
+    RLCF_EPI_RELU = 3            /* y = max(v (+ residual), 0): conv+bn(+identity)+relu of ModifiedResNet, model.py:24-56 */
 };
 enum rlcf_text_mode {
     RLCF_TEXT_DENSE = 0,   /* reference graph: every class runs all context_length positions */
@@ -44,10 +45,14 @@ enum rlcf_which { RLCF_STUDENT = 0, RLCF_REWARD = 1 /* reward slot m (0-based) i
 const char* rlcf_last_error(void);
 int rlcf_version(void);
 
-/* CLIP geometry: constructor arguments of the reference `CLIP` class (TPT/clip/model.py:244-257). */
+/* CLIP geometry: constructor arguments of the reference `CLIP` class (TPT/clip/model.py:244-257).  The reference passes
+ * `vision_layers` as an int for a VisionTransformer and as a 4-tuple of Bottleneck counts for a ModifiedResNet (:262-270): here
+ * vision_stages[0] > 0 selects the ModifiedResNet (inference only: reward models, frozen student image encoder of the prompt
+ * path) and vision_layers / vision_patch_size are then ignored. */
 typedef struct {
     int embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size;
     int context_length, vocab_size, text_width, text_heads, text_layers;
+    int vision_stages[4];
 } rlcf_clip_cfg;
 
 /* One attention sequence over a packed token matrix: queries are rows

@@ -81,9 +81,68 @@ def transformer(x: torch.Tensor, sd: SD, prefix: str, mask: Optional[torch.Tenso
     return x
 
 
+def _conv_bn(sd: SD, x: torch.Tensor, conv: str, bn: str, stride: int = 1, relu: bool = True) -> torch.Tensor:
+    """bias-free Conv2d (kernel 1 or 3, padding k//2) followed by eval-mode BatchNorm2d (running statistics, eps 1e-5) and
+    an optional ReLU: the conv/bn/relu triples of TPT/clip/model.py:18-31,108-116."""
+    w = sd[conv + ".weight"]
+    x = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
+    x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, 1e-5)
+    return F.relu(x) if relu else x
+
+
+def _bottleneck(sd: SD, x: torch.Tensor, p: str, stride: int) -> torch.Tensor:
+    """Bottleneck.forward, TPT/clip/model.py:42-55: 1x1 -> 3x3 -> (avgpool when stride > 1) -> 1x1 (x4), every conv at stride 1;
+    the identity branch is avgpool + 1x1 conv + bn when the block changes resolution or width; ReLU after the sum."""
+    out = _conv_bn(sd, x, p + "conv1", p + "bn1")
+    out = _conv_bn(sd, out, p + "conv2", p + "bn2")
+    if stride > 1:
+        out = F.avg_pool2d(out, stride)
+    out = _conv_bn(sd, out, p + "conv3", p + "bn3", relu=False)
+    if (p + "downsample.0.weight") in sd:
+        idn = F.avg_pool2d(x, stride) if stride > 1 else x
+        idn = _conv_bn(sd, idn, p + "downsample.0", p + "downsample.1", relu=False)
+    else:
+        idn = x
+    return F.relu(out + idn)
+
+
+def _attention_pool(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    """AttentionPool2d.forward, TPT/clip/model.py:68-91: tokens = [mean over positions; positions] + positional embedding;
+    one multi-head attention whose only query is the mean token (separate q/k/v projections with bias, head_dim 64,
+    q scaled by 1/8 after its bias); output projection c_proj."""
+    n, c, h, w = x.shape
+    t = x.flatten(2).transpose(1, 2)                                    # [n, HW, C]
+    t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1) + sd["visual.attnpool.positional_embedding"]
+    heads = c // 64
+    q = F.linear(t[:, :1], sd["visual.attnpool.q_proj.weight"], sd["visual.attnpool.q_proj.bias"]) * (64 ** -0.5)
+    k = F.linear(t, sd["visual.attnpool.k_proj.weight"], sd["visual.attnpool.k_proj.bias"])
+    v = F.linear(t, sd["visual.attnpool.v_proj.weight"], sd["visual.attnpool.v_proj.bias"])
+    q = q.view(n, 1, heads, 64).transpose(1, 2)
+    k = k.view(n, -1, heads, 64).transpose(1, 2)
+    v = v.view(n, -1, heads, 64).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(n, c)
+    return F.linear(o, sd["visual.attnpool.c_proj.weight"], sd["visual.attnpool.c_proj.bias"])
+
+
+def encode_image_resnet(sd: SD, images: torch.Tensor) -> torch.Tensor:
+    """ModifiedResNet.forward, TPT/clip/model.py:138-154 (eval mode: BatchNorm uses its running statistics)."""
+    x = _conv_bn(sd, images.float(), "visual.conv1", "visual.bn1", stride=2)
+    x = _conv_bn(sd, x, "visual.conv2", "visual.bn2")
+    x = _conv_bn(sd, x, "visual.conv3", "visual.bn3")
+    x = F.avg_pool2d(x, 2)
+    for li in (1, 2, 3, 4):
+        nb = len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")})
+        for b in range(nb):
+            x = _bottleneck(sd, x, f"visual.layer{li}.{b}.", 2 if (b == 0 and li > 1) else 1)
+    return _attention_pool(sd, x)
+
+
 def encode_image(sd: SD, images: torch.Tensor) -> torch.Tensor:
     """VisionTransformer.forward, TPT/clip/model.py:223-240 (== CLIP.encode_image
-    :340-341).  The stride==kernel convolution is written as patch gather + GEMM."""
+    :340-341).  The stride==kernel convolution is written as patch gather + GEMM.
+    A state dict without ``visual.proj`` holds a ModifiedResNet (build_model, :399-412)."""
+    if "visual.proj" not in sd:
+        return encode_image_resnet(sd, images)
     w = sd["visual.conv1.weight"]
     width, _, ps, _ = w.shape
     n = images.shape[0]

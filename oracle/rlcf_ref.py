@@ -115,8 +115,11 @@ def reward_image_features(reward_sd, images: torch.Tensor):
 def _reward_image_features(reward_sd, images: torch.Tensor) -> torch.Tensor:
     """CLIPRewards.extract_image_features, TPT/clip_reward.py:130-137: bicubic (align_corners=True) resample to the reward
     model's input resolution when it differs, encode_image, float, L2 normalise."""
-    ps = reward_sd["visual.conv1.weight"].shape[-1]
-    res = ps * round((reward_sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    if "visual.proj" in reward_sd:
+        ps = reward_sd["visual.conv1.weight"].shape[-1]
+        res = ps * round((reward_sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    else:                                                   # ModifiedResNet: build_model, TPT/clip/model.py:408-412
+        res = 32 * round((reward_sd["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
     if images.shape[-1] != res:
         images = torch.nn.functional.interpolate(images, size=res, mode="bicubic", align_corners=True)
     return C.l2_normalize(C.encode_image(reward_sd, images).float())

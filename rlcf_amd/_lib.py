@@ -24,7 +24,7 @@ F_REWARD_PROCESS, F_AMPLIFY, F_PROCESS_BATCH, F_MIN_ENTROPY = 1, 2, 4, 8
 class ClipCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("embed_dim", "image_resolution", "vision_layers", "vision_width",
                                        "vision_patch_size", "context_length", "vocab_size", "text_width",
-                                       "text_heads", "text_layers")]
+                                       "text_heads", "text_layers")] + [("vision_stages", C.c_int * 4)]
 
 
 class Seq(C.Structure):

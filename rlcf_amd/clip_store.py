@@ -26,15 +26,19 @@ def register_checkpoint(name: str, geometry: ClipGeometry, state_dict: Dict[str,
 
 
 def geometry_from_state_dict(sd: Dict[str, torch.Tensor]) -> ClipGeometry:
-    """Shape inference of build_model (TPT/clip/model.py:400-422), ViT towers only."""
-    if "visual.proj" not in sd:
-        raise NotImplementedError("ModifiedResNet image towers are not built yet (SURVEY.md §8 a-R)")
+    """Shape inference of build_model (TPT/clip/model.py:400-422)."""
+    tw = sd["ln_final.weight"].shape[0]
+    tl = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
+    if "visual.proj" not in sd:            # ModifiedResNet branch (:408-415)
+        counts = tuple(len(set(k.split(".")[2] for k in sd if k.startswith(f"visual.layer{b}"))) for b in (1, 2, 3, 4))
+        out_w = round((sd["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+        assert out_w ** 2 + 1 == sd["visual.attnpool.positional_embedding"].shape[0]
+        return ClipGeometry(sd["text_projection"].shape[1], out_w * 32, counts, sd["visual.layer1.0.conv1.weight"].shape[0], None,
+                            sd["positional_embedding"].shape[0], sd["token_embedding.weight"].shape[0], tw, tw // 64, tl)
     vw = sd["visual.conv1.weight"].shape[0]
     vl = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
     ps = sd["visual.conv1.weight"].shape[-1]
     grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
-    tw = sd["ln_final.weight"].shape[0]
-    tl = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
     return ClipGeometry(sd["text_projection"].shape[1], ps * grid, vl, vw, ps, sd["positional_embedding"].shape[0],
                         sd["token_embedding.weight"].shape[0], tw, tw // 64, tl)
 

@@ -23,7 +23,7 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
                  const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue,
                  int precision, rlcf_stream stream) {
     RLCF_ARG_CHECK(A && W && C && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3));
-    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_QUICKGELU_BWD);
+    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_RELU);
     RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
     if (precision == RLCF_PREC_F16X3) {          // op-level convenience: split both operands into library scratch
         static DevBuf ah, al, wh, wl;
@@ -48,7 +48,7 @@ int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream 
 int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                     int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {
-    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_QUICKGELU_BWD && (epilogue != RLCF_EPI_QUICKGELU_BWD || aux));
+    RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_RELU && (epilogue != RLCF_EPI_QUICKGELU_BWD || aux));
     return launch_gemm_f16x3(Ahi, Alo, lda, Whi, Wlo, ldw, bias, residual, ldr, aux, ldaux, C, ldc, Chi, Clo, ldch, M, N, K, alpha,
                              epilogue, (hipStream_t)stream);
 }
@@ -109,10 +109,14 @@ int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int
 
 // ------------------------------------------------------------------ engine
 static bool cfg_ok(const rlcf_clip_cfg* c) {
-    return c && c->embed_dim > 0 && c->vision_width % HEAD_DIM == 0 && c->text_width % HEAD_DIM == 0 && c->vision_width <= 1024 &&
-           c->text_width <= 1024 && c->vision_patch_size > 0 && c->image_resolution % c->vision_patch_size == 0 &&
-           c->vision_layers > 0 && c->text_layers > 0 && c->context_length > 3 && c->vocab_size > 2 && c->embed_dim % 4 == 0 &&
-           c->text_heads * HEAD_DIM == c->text_width;
+    if (!c) return false;
+    const bool text_ok = c->embed_dim > 0 && c->text_width % HEAD_DIM == 0 && c->text_width <= 1024 && c->text_layers > 0 &&
+                         c->context_length > 3 && c->vocab_size > 2 && c->embed_dim % 4 == 0 && c->text_heads * HEAD_DIM == c->text_width;
+    if (is_resnet(*c))        // ModifiedResNet: four stages, width/2 stem channels, /32 attention-pool map (model.py:102-127)
+        return text_ok && c->vision_stages[1] > 0 && c->vision_stages[2] > 0 && c->vision_stages[3] > 0 && c->vision_width % 16 == 0 &&
+               c->vision_width > 0 && c->image_resolution > 0 && c->image_resolution % 32 == 0;
+    return text_ok && c->vision_width % HEAD_DIM == 0 && c->vision_width <= 1024 && c->vision_patch_size > 0 &&
+           c->image_resolution % c->vision_patch_size == 0 && c->vision_layers > 0;
 }
 
 static bool which_ok(const rlcf_engine* e, int which) { return e && which >= 0 && which <= RLCF_MAX_REWARDS && e->model[which].present; }
@@ -145,6 +149,8 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     for (int w = 0; w <= RLCF_MAX_REWARDS; ++w) {
         if (!e->model[w].present) continue;
         const rlcf_clip_cfg& c = e->model[w].cfg;
+        Dmax = std::max(Dmax, c.embed_dim);
+        if (is_resnet(c)) continue;                     // its workspace is sized per image chunk (resnet.hip)
         const int g = c.image_resolution / c.vision_patch_size, tok = g * g + 1;
         Tmax = std::max(Tmax, max_views * tok); Wmax = std::max(Wmax, c.vision_width); Pmax = std::max(Pmax, max_views * g * g);
         Kpmax = std::max(Kpmax, (3 * c.vision_patch_size * c.vision_patch_size + 63) / 64 * 64); Dmax = std::max(Dmax, c.embed_dim);
@@ -197,6 +203,8 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat};
     for (DevBuf* d : all) d->release();
+    for (DevBuf& d : e->rn_buf) d.release();
+    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->dyn}) d->release();
     delete e;
 }
 

@@ -44,12 +44,24 @@ struct Tower {                       // workspace of one transformer pass over T
     int saved_T = 0, saved_layers = 0;
 };
 
+struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1, Kp = 0; };   // conv with folded BatchNorm
+struct BottleW { ConvW c1, c2, c3, down; bool has_down = false; int stride = 1; };                          // model.py:10-55
+struct ResNetW {                     // ModifiedResNet (TPT/clip/model.py:94-154), inference form
+    bool present = false;
+    ConvW stem[3];
+    std::vector<BottleW> blocks;
+    const float *pos = nullptr, *q_w = nullptr, *q_b = nullptr, *kv_w = nullptr, *kv_b = nullptr, *c_w = nullptr, *c_b = nullptr;
+    int E = 0, heads = 0, out_hw = 0;
+    size_t act_per_img = 0, col_per_img = 0;     // floats of workspace per image
+};
+
 struct ClipModel {
     rlcf_clip_cfg cfg{};
     bool present = false, finalized = false;
     std::map<std::string, DevBuf> raw;     // state-dict tensors as loaded
     std::vector<DevBuf> derived;           // transposed / bf16 copies
     TowerW vis, txt;
+    ResNetW rn;                            // image tower when cfg.vision_stages[0] > 0
     const float *conv_w = nullptr;         // [Wv, Kp] zero padded
     const float *cls = nullptr, *vpos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr, *lnpost_b = nullptr;
     const float *vprojT = nullptr;         // [D, Wv]
@@ -94,6 +106,8 @@ struct rlcf_engine {
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
     int ln_count = 0;                // (4*layers + 4) * Wv
     size_t bwd_elems = 0;
+    DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att;   // ModifiedResNet workspace (one chunk of images)
+    DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
     DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
     double last_flops = 0.0;
@@ -108,6 +122,15 @@ struct GemmProfile {                 // optional per-launch timing of the domina
 };
 extern int g_last_x3_variant;
 extern GemmProfile g_prof;
+
+static inline bool is_resnet(const rlcf_clip_cfg& c) { return c.vision_stages[0] > 0; }
+// resnet.hip
+int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
+int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
+// engine.hip services used by resnet.hip
+int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
+                int ldc, int M, int N, int K, int epi, hipStream_t st);
+int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st);
 
 // engine internals used by api.hip
 int engine_finalize(rlcf_engine* e, int which, hipStream_t st);

@@ -48,7 +48,7 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 #define GRAD_SCALE 256.0f
 static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                 const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st,
-                float a_scale = 1.0f) {
+                float a_scale = 1.0f, bool dyn_scale = false) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi;
@@ -58,10 +58,17 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
         const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
         if (sp && (size_t)M * K <= e->a_split_elems) {
-            TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st, a_scale));
+            const float* alpha_dev = nullptr;
+            if (dyn_scale) {       // operand range unknown (un-normalised ResNet activations): power-of-two scale found on the device
+                TRY(e->dyn.ensure(3 * sizeof(float)));
+                TRY(launch_split_f16x2_dyn(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>(), st));
+                alpha_dev = e->dyn.as<float>() + 2;
+            } else {
+                TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st, a_scale));
+            }
             const int slot = prof_begin(st, 2.0 * M * N * K);
             int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
-                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st);
+                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -70,6 +77,11 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
     int rc = launch_gemm_f32(g, st);
     prof_end(slot, st);
     return rc;
+}
+
+int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
+                int ldc, int M, int N, int K, int epi, hipStream_t st) {
+    return gemm(e, A, lda, W, ldw, bias, res, ldr, nullptr, 0, C, ldc, M, N, K, 1.f, epi, st, 1.0f, true);
 }
 
 // pre-split A operand (written by the producing kernel): C f32 and/or a split pair
@@ -128,6 +140,7 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     m.derived.push_back(lo);
     return RLCF_OK;
 }
+int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) { return make_split(e, m, w, numel, st); }
 static const float* make_transposed(ClipModel& m, const float* w, int rows, int cols, hipStream_t st) {
     m.derived.emplace_back();
     DevBuf& d = m.derived.back();
@@ -176,8 +189,15 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     for (auto& d : m.derived) d.release();
     m.derived.clear();
     m.derived.reserve(32 * (c.vision_layers + c.text_layers) + 16);
+    m.vis.blk.clear(); m.vis.layers = 0;
     m.split_of.clear();
-    const int Wv = c.vision_width, Wt = c.text_width, ps = c.vision_patch_size, D = c.embed_dim;
+    const int Wt = c.text_width, D = c.embed_dim;
+    const bool rn = is_resnet(c);
+    if (rn) {
+        if (which == RLCF_STUDENT) e->ln_count = 0;       // no LayerNorm to tune: the LN path refuses a ResNet student
+        TRY(resnet_finalize(e, m, st));
+    } else {
+    const int Wv = c.vision_width, ps = c.vision_patch_size;
     const int K = 3 * ps * ps;
     m.Kp = (K + 63) / 64 * 64;
     m.tokens = (c.image_resolution / ps) * (c.image_resolution / ps) + 1;
@@ -223,6 +243,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
         RLCF_HIP_CHECK(hipStreamSynchronize(st));
         TRY(e->vit_inv_norm.ensure(e->max_views * sizeof(float)));
     }
+    }
     NEED(m.tok_emb = rawp(m, "token_embedding.weight", (size_t)c.vocab_size * Wt));
     NEED(m.tpos = rawp(m, "positional_embedding", (size_t)c.context_length * Wt));
     NEED(m.lnf_w = rawp(m, "ln_final.weight", Wt));  NEED(m.lnf_b = rawp(m, "ln_final.bias", Wt));
@@ -236,8 +257,10 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     m.logit_scale_exp = expf(lsh);
     // split-f16 copies of every forward GEMM weight (F16X3 mode)
-    TRY(make_split(e, m, m.conv_w, (size_t)Wv * m.Kp, st));
-    TRY(make_split(e, m, m.vprojT, (size_t)Wv * D, st));
+    if (!rn) {
+        TRY(make_split(e, m, m.conv_w, (size_t)c.vision_width * m.Kp, st));
+        TRY(make_split(e, m, m.vprojT, (size_t)c.vision_width * D, st));
+    }
     TRY(make_split(e, m, m.tprojT, (size_t)Wt * D, st));
     for (TowerW* t : {&m.vis, &m.txt})
         for (BlockW& b : t->blk) {
@@ -377,6 +400,7 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
         TRY(launch_bicubic(images, e->resized.as<float>(), n * 3, in_res, c.image_resolution, st));
         images = e->resized.as<float>();
     }
+    if (is_resnet(c)) return resnet_encode(e, m, images, n, feats, st);
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
     if (e->precision == RLCF_PREC_F16X3 && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
         TRY(launch_im2col(images, nullptr, e->a_hi.p, e->a_lo.p, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
@@ -969,6 +993,7 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
     const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
+    if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const size_t nb = (size_t)e->ln_count * sizeof(float);

@@ -27,8 +27,11 @@ struct GemmX3Args {
     _Float16 *Chi, *Clo; int ldch;     // split output (may be null)
     int M, N, K;
     float alpha; int epilogue;
+    const float* alpha_dev;            // optional device scalar multiplied into alpha (undoes a data-dependent operand pre-scale)
     int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
 };
+
+__device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha; }
 
 #define X3_BM 128
 #define X3_BN 128
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
-                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                const float al = x3_alpha(g);
+                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
@@ -148,6 +152,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
                     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.epilogue == RLCF_EPI_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
@@ -172,10 +180,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, h);
                 if (row >= g.M) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
+                float v = x3_alpha(g) * acc[i][j][r] + bv;
                 if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
                 if (g.C) g.C[(size_t)row * g.ldc + col] = v;
                 if (g.Chi) {
                     const _Float16 hi = (_Float16)v;
@@ -334,7 +343,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
                 const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
-                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                const float al = x3_alpha(g);
+                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
@@ -345,6 +355,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
                     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.epilogue == RLCF_EPI_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
@@ -479,7 +493,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 const int rl = it * 4 + rsub, row = m0 + wm * 128 + half * 64 + rl;
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
-                float v[4] = {g.alpha * a4.x + bv.x, g.alpha * a4.y + bv.y, g.alpha * a4.z + bv.z, g.alpha * a4.w + bv.w};
+                const float al = x3_alpha(g);
+                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
@@ -490,6 +505,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
                     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.epilogue == RLCF_EPI_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
@@ -507,13 +526,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
-                      int M, int N, int K, float alpha, int epilogue, hipStream_t st) {
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && Clo)));
     GemmX3Args g{};
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
+    g.alpha_dev = alpha_dev;
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
     static bool attr = false;
@@ -576,6 +596,46 @@ __global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __rest
         ((h16x8*)hi)[i] = vh;
         ((h16x8*)lo)[i] = vl;
     }
+}
+// data-dependent pre-scale for operands without a known range (ResNet activations): s = 2^k lifting max|x| into [2^9, 2^10);
+// out[0] = s (read by the split kernel), out[1] = 1/s (folded into the GEMM's alpha)
+__global__ void dyn_scale_kernel(const float* __restrict__ amax, float* __restrict__ out) {
+    const float mx = amax[0];
+    int sh = 0;
+    if (mx > 0.f && mx < INFINITY) sh = 9 - (int)floorf(log2f(mx));
+    sh = sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+    out[0] = ldexpf(1.0f, sh);
+    out[1] = ldexpf(1.0f, -sh);
+}
+__global__ void split_f16x2_dyn_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8,
+                                       const float* __restrict__ scale_dev) {
+    const float scale = scale_dev[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+        const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+        h16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 hh = (_Float16)v[e];
+            vh[e] = hh;
+            vl[e] = (_Float16)(v[e] - (float)hh);
+        }
+        ((h16x8*)hi)[i] = vh;
+        ((h16x8*)lo)[i] = vl;
+    }
+}
+// scratch: 3 floats on the device {max|x|, s, 1/s}
+int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scratch3);
+    int rc = launch_absmax(x, n, scratch3, st);
+    if (rc != RLCF_OK) return rc;
+    dyn_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(scratch3, scratch3 + 1);
+    RLCF_LAUNCH_CHECK();
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scratch3 + 1);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
 }
 int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0);

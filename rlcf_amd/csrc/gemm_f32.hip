@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
                 if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
                 C[(size_t)row * g.ldc + col] = v;
             }
         }
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
         if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
         else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
         if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+        if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
         C[(size_t)row * g.ldc + col] = v;
     }
 }

@@ -25,6 +25,9 @@ def _stream() -> int:
 
 
 def _cfg(g: ClipGeometry) -> L.ClipCfg:
+    if g.is_resnet:          # the reference's vision_layers tuple selects ModifiedResNet (TPT/clip/model.py:262-270)
+        return L.ClipCfg(g.embed_dim, g.image_resolution, 0, g.vision_width, 0, g.context_length, g.vocab_size,
+                         g.transformer_width, g.transformer_heads, g.transformer_layers, (C.c_int * 4)(*g.vision_layers))
     return L.ClipCfg(g.embed_dim, g.image_resolution, g.vision_layers, g.vision_width, g.vision_patch_size,
                      g.context_length, g.vocab_size, g.transformer_width, g.transformer_heads, g.transformer_layers)
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 import math
 import zlib
 from dataclasses import dataclass
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Tuple, Union
 
 import torch
 
@@ -23,12 +23,13 @@ _M32 = 0xFFFFFFFF
 @dataclass(frozen=True)
 class ClipGeometry:
     """Constructor arguments of the reference ``CLIP`` class, same order
-    (TPT/clip/model.py:244-257).  ViT image towers only."""
+    (TPT/clip/model.py:244-257).  ``vision_layers`` is an int for a VisionTransformer image tower and a 4-tuple of
+    block counts for a ModifiedResNet (then ``vision_patch_size`` is None), as in the reference (:262-270)."""
     embed_dim: int
     image_resolution: int
-    vision_layers: int
+    vision_layers: Union[int, Tuple[int, int, int, int]]
     vision_width: int
-    vision_patch_size: int
+    vision_patch_size: Optional[int]
     context_length: int
     vocab_size: int
     transformer_width: int
@@ -36,12 +37,16 @@ class ClipGeometry:
     transformer_layers: int
 
     @property
+    def is_resnet(self) -> bool:
+        return isinstance(self.vision_layers, (tuple, list))
+
+    @property
     def vision_heads(self) -> int:
-        return self.vision_width // 64
+        return self.vision_width * 32 // 64 if self.is_resnet else self.vision_width // 64
 
     @property
     def grid(self) -> int:
-        return self.image_resolution // self.vision_patch_size
+        return self.image_resolution // (32 if self.is_resnet else self.vision_patch_size)
 
     @property
     def vision_tokens(self) -> int:
@@ -58,11 +63,20 @@ GEOMETRIES: Dict[str, ClipGeometry] = {
     "ViT-B/16": ClipGeometry(512, 224, 12, 768, 16, 77, 49408, 512, 8, 12),
     "ViT-B/32": ClipGeometry(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12),
     "ViT-L/14": ClipGeometry(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12),
+    "ViT-L/14@336px": ClipGeometry(768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12),
+    "RN50": ClipGeometry(1024, 224, (3, 4, 6, 3), 64, None, 77, 49408, 512, 8, 12),
+    "RN101": ClipGeometry(512, 224, (3, 4, 23, 3), 64, None, 77, 49408, 512, 8, 12),
+    "RN50x4": ClipGeometry(640, 288, (4, 6, 10, 6), 80, None, 77, 49408, 640, 10, 12),
+    "RN50x16": ClipGeometry(768, 384, (6, 8, 18, 8), 96, None, 77, 49408, 768, 12, 12),
+    "RN50x64": ClipGeometry(1024, 448, (3, 15, 36, 10), 128, None, 77, 49408, 1024, 16, 12),
     # reduced geometries for tests (head_dim stays 64 as in every CLIP)
     "tiny": ClipGeometry(128, 32, 2, 128, 8, 77, 1024, 128, 2, 2),
     "tiny-r": ClipGeometry(64, 32, 2, 128, 8, 77, 1024, 64, 1, 2),
     "tiny-r64": ClipGeometry(64, 64, 2, 128, 16, 77, 1024, 64, 1, 2),     # reward model at twice the view resolution (bicubic path)
     "small": ClipGeometry(256, 64, 4, 256, 16, 77, 4096, 256, 4, 4),
+    # ModifiedResNet image towers (attention-pool width 32*width, head_dim 64): 64x64 input -> 2x2 map -> 5 pooled tokens
+    "tiny-rn": ClipGeometry(64, 64, (1, 2, 1, 1), 16, None, 77, 1024, 64, 1, 2),
+    "tiny-rn32": ClipGeometry(128, 32, (2, 1, 1, 1), 16, None, 77, 1024, 128, 2, 2),      # as a student: 32x32 views, 1x1 map
 }
 
 
@@ -141,6 +155,10 @@ def make_state_dict(geo: ClipGeometry, seed: int, device="cpu",
     (a random-init CLIP has ln(1/0.07))."""
     sd: Dict[str, torch.Tensor] = {}
     vw, tw = geo.vision_width, geo.transformer_width
+    if geo.is_resnet:
+        _resnet(sd, seed, geo, device)
+        _text(sd, seed, geo, device, logit_scale)
+        return sd
     ps = geo.vision_patch_size
     sc = vw ** -0.5
     sd["visual.conv1.weight"] = normal(seed, "v.conv1", (vw, 3, ps, ps), (3 * ps * ps) ** -0.5, device=device)
@@ -154,7 +172,53 @@ def make_state_dict(geo: ClipGeometry, seed: int, device="cpu",
     sd["visual.ln_post.weight"] = normal(seed, "v.lnpost_w", (vw,), 0.1, 1.0, device=device)
     sd["visual.ln_post.bias"] = normal(seed, "v.lnpost_b", (vw,), 0.05, device=device)
     sd["visual.proj"] = normal(seed, "v.proj", (vw, geo.embed_dim), sc, device=device)
+    _text(sd, seed, geo, device, logit_scale)
+    return sd
 
+
+def _bn(sd, seed, key, ch, device, gain=1.0):
+    """BatchNorm2d buffers and affine in eval form: non-trivial running statistics so that the folding is exercised."""
+    sd[key + ".weight"] = normal(seed, key + ".w", (ch,), 0.1, gain, device=device)
+    sd[key + ".bias"] = normal(seed, key + ".b", (ch,), 0.05, device=device)
+    sd[key + ".running_mean"] = normal(seed, key + ".rm", (ch,), 0.1, device=device)
+    sd[key + ".running_var"] = 1.0 + 0.3 * torch.tanh(normal(seed, key + ".rv", (ch,), 1.0, device=device))
+    sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64, device=device)
+
+
+def _conv(sd, seed, key, cout, cin, k, device):
+    sd[key + ".weight"] = normal(seed, key, (cout, cin, k, k), (2.0 / (cin * k * k)) ** 0.5, device=device)
+
+
+def _resnet(sd, seed, geo, device):
+    """ModifiedResNet key layout (TPT/clip/model.py:94-154): 3-conv stem, four stages of Bottlenecks (expansion 4, the first
+    block of a stage carries the downsample branch), AttentionPool2d."""
+    w = geo.vision_width
+    _conv(sd, seed, "visual.conv1", w // 2, 3, 3, device);      _bn(sd, seed, "visual.bn1", w // 2, device)
+    _conv(sd, seed, "visual.conv2", w // 2, w // 2, 3, device); _bn(sd, seed, "visual.bn2", w // 2, device)
+    _conv(sd, seed, "visual.conv3", w, w // 2, 3, device);      _bn(sd, seed, "visual.bn3", w, device)
+    inpl = w
+    for li, (nb, mult) in enumerate(zip(geo.vision_layers, (1, 2, 4, 8)), start=1):
+        planes = w * mult
+        for b in range(nb):
+            p = f"visual.layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            _conv(sd, seed, p + "conv1", planes, inpl, 1, device);       _bn(sd, seed, p + "bn1", planes, device)
+            _conv(sd, seed, p + "conv2", planes, planes, 3, device);     _bn(sd, seed, p + "bn2", planes, device)
+            _conv(sd, seed, p + "conv3", planes * 4, planes, 1, device); _bn(sd, seed, p + "bn3", planes * 4, device, gain=0.5)
+            if stride > 1 or inpl != planes * 4:
+                _conv(sd, seed, p + "downsample.0", planes * 4, inpl, 1, device)
+                _bn(sd, seed, p + "downsample.1", planes * 4, device)
+            inpl = planes * 4
+    e = w * 32
+    hw = geo.image_resolution // 32
+    sd["visual.attnpool.positional_embedding"] = normal(seed, "v.ap.pos", (hw * hw + 1, e), e ** -0.5, device=device)
+    for nm, od in (("q_proj", e), ("k_proj", e), ("v_proj", e), ("c_proj", geo.embed_dim)):
+        sd[f"visual.attnpool.{nm}.weight"] = normal(seed, "v.ap." + nm, (od, e), e ** -0.5, device=device)
+        sd[f"visual.attnpool.{nm}.bias"] = normal(seed, "v.ap.b." + nm, (od,), 0.02, device=device)
+
+
+def _text(sd, seed, geo, device, logit_scale):
+    tw = geo.transformer_width
     sd["token_embedding.weight"] = normal(seed, "t.tok", (geo.vocab_size, tw), 0.02, device=device)
     sd["positional_embedding"] = normal(seed, "t.pos", (geo.context_length, tw), 0.01, device=device)
     t_proj_std = (tw ** -0.5) * ((2 * geo.transformer_layers) ** -0.5)

@@ -126,8 +126,9 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
         # CLIPRewardsMultiple (clip_reward.py:180-307) over three of the arch names its CONFIDECES table knows, each bound
         # to a seeded synthetic CLIP
         members = synth.reward_members(reward, hp["reward_seeds"])
-        install_models(ref, {a: m for a, m in zip(ENSEMBLE_NAMES, members)})
-        rm = ref.clip_reward.CLIPRewardsMultiple("cpu", arch=ENSEMBLE_NAMES[: len(members)], classification=True,
+        names = hp.get("reward_archs", "+".join(ENSEMBLE_NAMES)).split("+")
+        install_models(ref, {a: m for a, m in zip(names, members)})
+        rm = ref.clip_reward.CLIPRewardsMultiple("cpu", arch=names[: len(members)], classification=True,
                                                  amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
                                                  reward_process=hp.get("reward_process", True),
                                                  process_batch=hp.get("process_batch", False),
@@ -314,6 +315,7 @@ ENSEMBLE_NAMES = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]      # CONFIDECES 10
 
 BASE_HP = dict(lr=7e-3, weight_decay=5e-4, sample_k=3, tta_steps=1, selection_p=0.5)
 
+RN_SEED = int(os.environ.get("RN_SEED", "1000"))
 ENS_SEED = int(os.environ.get("ENS_SEED", "1000"))
 TTA_CASES = {
     # name: (student, reward, N, C, hp overrides)
@@ -328,12 +330,20 @@ TTA_CASES = {
     # reward ensemble: three reward CLIPs (one at another resolution), weighted sum / plain mean of the clamped scores
     "tta_tiny_ens": ("tiny", "tiny-r64+tiny-r+tiny-r", 8, 16, dict(reward_seeds="23+29+31", view_seed=ENS_SEED)),
     "tta_tiny_ensmean": ("tiny", "tiny-r64+tiny-r+tiny-r", 8, 16, dict(reward_seeds="23+29+31", weighted_scores=0, view_seed=ENS_SEED)),
+    # the arch list get_reward_model really uses (clip_reward.py:31): L/14@336px, RN50x64, L/14 -> weights [0.56, 0.17, 0.28];
+    # the middle member is a ModifiedResNet at twice the view resolution
+    "tta_tiny_ensrn": ("tiny", "tiny-r64+tiny-rn+tiny-r", 8, 16, dict(reward_seeds="23+29+31", view_seed=ENS_SEED,
+                                                                      reward_archs="ViT-L/14@336px+RN50x64+ViT-L/14")),
+    # ModifiedResNet towers: as the reward model (with the bicubic resolution change) and as the frozen student image encoder
+    "tta_tiny_rnreward": ("tiny", "tiny-rn", 8, 16, dict(view_seed=RN_SEED)),
+    "tta_tiny_rnstudent": ("tiny-rn32", "tiny-r", 8, 16, dict(view_seed=RN_SEED)),
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
 GROUPS = {
-    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k],
+    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k and "_rn" not in k],
+    "rn": ["tta_tiny_ensrn", "tta_tiny_rnreward", "tta_tiny_rnstudent"],
     "rres": ["tta_tiny_rres"],
     "ens": ["tta_tiny_ens", "tta_tiny_ensmean"],
     "small": ["tta_small_s1"],
@@ -408,6 +418,23 @@ def gen_modules(ref):
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+def gen_modules_rn(ref):
+    """encode_image of the reference CLIP class with ModifiedResNet towers (TPT/clip/model.py:94-154): a reduced geometry, RN50 at
+    224^2 and the reward model RN50x64 at 448^2."""
+    out = {}
+    for arch, tag, nv in (("tiny-rn", "tinyrn", 3), ("RN50", "rn50", 2), ("RN50x64", "rn50x64", 1)):
+        geo = synth.GEOMETRIES[arch]
+        sd = synth.make_state_dict(geo, seed=11)
+        m = ref.refmodel.CLIP(*geo.as_tuple())
+        m.load_state_dict(sd)
+        m = m.eval().float()
+        views = synth.make_views(1000, nv, geo.image_resolution)
+        with torch.no_grad():
+            out[f"{tag}_image"] = m.encode_image(views)
+        print(arch, "done", flush=True)
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="tiny,small,ops")
@@ -419,6 +446,8 @@ def main():
             save("ops", gen_ops(ref), {})
         elif grp == "modules":
             save("modules", gen_modules(ref), {})
+        elif grp == "modules_rn":
+            save("modules_rn", gen_modules_rn(ref), {})
         elif grp == "tokenizer":
             save("tokenizer", gen_tokenizer(ref), {})
         elif grp in ("ln", "lnb16"):

@@ -307,7 +307,7 @@ def test_text_features_vs_oracle(L, dev, mode, geo, n_cls):
 
 
 TTA_FIXTURES = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-                "tta_small_s1", "tta_tiny_rres"]
+                "tta_small_s1", "tta_tiny_rres", "tta_tiny_rnreward", "tta_tiny_rnstudent"]
 
 
 def _cfg_from_meta(meta, sparse=True):
@@ -372,7 +372,7 @@ def make_ensemble_engine(meta, mode, n_views=None, prec=0):
 
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("sparse", [True, False])
-@pytest.mark.parametrize("name", ["tta_tiny_ens", "tta_tiny_ensmean"])
+@pytest.mark.parametrize("name", ["tta_tiny_ens", "tta_tiny_ensmean", "tta_tiny_ensrn"])
 def test_reward_ensemble_matches_reference_fixture(L, dev, name, sparse, mode):
     """CLIPRewardsMultiple (clip_reward.py:180-307): three reward CLIPs (one at another input resolution), weighted / mean."""
     g, meta = load_golden(name)
@@ -465,6 +465,27 @@ def test_fused_sample_batch_equals_per_sample(L, dev, geo, reward, n_cls, p, mod
     big.close()
 
 
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("arch,tag,nv", [("tiny-rn", "tinyrn", 3), ("RN50", "rn50", 2), ("RN50x64", "rn50x64", 1)])
+def test_modified_resnet_matches_reference_fixture(L, dev, arch, tag, nv, prec):
+    """ModifiedResNet image tower (model.py:94-154; BatchNorm folded, NHWC GEMM convolutions) vs the reference CLIP class."""
+    from rlcf_amd.engine import Engine
+    g, _ = load_golden("modules_rn")
+    geo = synth.GEOMETRIES[arch]
+    sd = synth.make_state_dict(geo, 11, device=dev)
+    eng = Engine(geo, None, 4, 8, prec)
+    eng.load_state_dict(L.STUDENT, sd)
+    eng.finalize()
+    views = synth.make_views(1000, nv, geo.image_resolution)
+    f = eng.encode_image(L.STUDENT, views.to(dev)).cpu()
+    ref = CR.l2_normalize(g[f"{tag}_image"])
+    torch.testing.assert_close(f, ref, atol=2e-5, rtol=1e-4)
+    if nv > 1:                   # chunked == unchunked, any order
+        f2 = eng.encode_image(L.STUDENT, views.flip(0).to(dev)).cpu().flip(0)
+        torch.testing.assert_close(f2, f, atol=1e-6, rtol=0)
+    eng.close()
+
+
 @pytest.mark.parametrize("ri,ro", [(32, 64), (224, 336), (64, 32), (17, 40)])
 def test_bicubic_resample_vs_torch(L, dev, ri, ro):
     """The engine's reward-resolution change vs nn.functional.interpolate(mode='bicubic', align_corners=True)."""
@@ -551,7 +572,7 @@ def _harness_objects(dev, meta):
     clip_store.register_checkpoint(meta["student"], sg, synth.make_state_dict(sg, meta["student_seed"]))
     ensemble = "+" in meta["reward"]
     if ensemble:        # get_reward_model(multiple_reward_models=1): CLIPRewardsMultiple over a fixed arch list (clip_reward.py:29-34)
-        names = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]          # the names the fixture generator bound the members to
+        names = meta.get("reward_archs", "ViT-L/14@336px+ViT-L/14+ViT-B/16").split("+")    # the names the generator bound the members to
         for n, (geo, sd) in zip(names, synth.reward_members(meta["reward"], meta["reward_seeds"])):
             clip_store.register_checkpoint(n, geo, sd)
         clip_reward.ENSEMBLE_ARCHS[:] = names
@@ -578,7 +599,8 @@ def _harness_objects(dev, meta):
     return model, optimizer, optim_state, reward_model, args
 
 
-@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean"])
+@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean",
+                                  "tta_tiny_ensrn", "tta_tiny_rnreward", "tta_tiny_rnstudent"])
 def test_reference_harness_runs_on_the_hip_path(L, dev, name):
     """The reference's main_worker/test_time_adapt_eval call sequence (tpt_cls_rl.py:94-190,219-279) with this
     package's classes in place of the reference's: same ctx update and final logits as the reference run."""

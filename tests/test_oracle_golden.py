@@ -47,7 +47,8 @@ def run_oracle(meta, truncate=False, weights=None):
 
 
 TINY = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-        "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean"]
+        "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean", "tta_tiny_ensrn", "tta_tiny_rnreward",
+        "tta_tiny_rnstudent"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -108,6 +109,18 @@ def test_ops_fixture():
             r = R.rewards_post_process(sc.flatten() if pb else sc, True, bool(amp))
             torch.testing.assert_close(r, g[f"rewards_amp{amp}_pb{pb}"], atol=1e-6, rtol=1e-6)
     torch.testing.assert_close(R.rewards_post_process(sc[:, :1], True, True), g["rewards_k1"])
+
+
+def test_modified_resnet_fixture():
+    """oracle.clip_ref.encode_image_resnet vs the reference CLIP class with ModifiedResNet towers (model.py:94-154)."""
+    g, _ = load("modules_rn")
+    for arch, tag, nv in (("tiny-rn", "tinyrn", 3), ("RN50", "rn50", 2)):          # (RN50x64 is checked on the GPU: 420 M weights)
+        geo = synth.GEOMETRIES[arch]
+        sd = synth.make_state_dict(geo, seed=11)
+        with torch.no_grad():
+            f = C.encode_image(sd, synth.make_views(1000, nv, geo.image_resolution))
+        ref = g[f"{tag}_image"]
+        assert (f - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
 def test_synth_is_deterministic():
