@@ -23,13 +23,15 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
                                                                     _Float16* __restrict__ oh, _Float16* __restrict__ ol) {
     const rlcf_seq sq = seqs[blockIdx.y];
     const int head = blockIdx.z;
     if (blockIdx.x * NW * 32 >= sq.q_len) return;
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * AX_KLD], Kl[32 * AX_KLD], Vh[64 * AX_VLD], Vl[64 * AX_VLD];
+    // two images of the converted K / V^T chunk: chunk c+1 is fetched (registers) and written while chunk c is consumed
+    constexpr int NB = NW > 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[NB][32 * AX_KLD], Kl[NB][32 * AX_KLD], Vh[NB][64 * AX_VLD], Vl[NB][64 * AX_VLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
     const int ld = 3 * width;
     const int qb = blockIdx.x * NW + wave;
@@ -41,14 +43,14 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
     const int kend = causal ? min(nkeys, sq.pre_len + last_q) : nkeys;
     const int my_kend = causal ? min(nkeys, sq.pre_len + qb * 32 + 32) : nkeys;
 
-    // Q fragments: lane (q, h) owns d = ks*16 + h*8 + [0,8) for ks = 0..3; scaled by 1/8 (exact) then split
+    // Q fragments: lane (q, h) owns d = ks*16 + h*8 + [0,8) for ks = 0..3; the 1/8 scale is applied to the scores (exact)
     h16x8 qh[4], ql[4];
     {
         const float* qp = qkv + (size_t)(sq.q_start + qi) * ld + head * HEAD_DIM + h * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4 a = *(const float4*)(qp + ks * 16), b = *(const float4*)(qp + ks * 16 + 4);
-            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};      // the 1/8 scale is applied to the scores (exact)
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             split8(v, qh[ks], ql[ks]);
         }
     }
@@ -56,74 +58,94 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -INFINITY, lsum = 0.f;
+    constexpr float SC = 0.125f * 1.44269504088896341f;           // softmax(s/8) through v_exp_f32 (2^x)
 
     // chunk staging: thread -> (key, PER consecutive d); the key's V slot in the transposed tile is the position its
     // score occupies in the S^T accumulator: key = (e&3) + 8*(2t + (e>>2)) + 4h  <->  slot = 16t + 8h + e
-    constexpr int PER = 32 / NW, PARTS = 64 / PER;
+    constexpr int PER = 32 / NW, PARTS = 64 / PER, NV = PER / 4;
     const int lkey = t / PARTS, d0 = (t % PARTS) * PER;
     const int slot = ((lkey >> 4) << 4) | (((lkey >> 2) & 1) << 3) | (((lkey >> 3) & 1) << 2) | (lkey & 3);
-
-    for (int kc = 0; kc < kend; kc += 32) {
-        {
-            const int kap = kc + lkey;
-            float kv[PER], vv[PER];
-            if (kap < nkeys) {
-                const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
-                const float* p = qkv + (size_t)row * ld + head * HEAD_DIM + d0;
-#pragma unroll
-                for (int j = 0; j < PER / 4; ++j) {
-                    const float4 a = *(const float4*)(p + width + 4 * j), b = *(const float4*)(p + 2 * width + 4 * j);
-                    kv[4 * j] = a.x; kv[4 * j + 1] = a.y; kv[4 * j + 2] = a.z; kv[4 * j + 3] = a.w;
-                    vv[4 * j] = b.x; vv[4 * j + 1] = b.y; vv[4 * j + 2] = b.z; vv[4 * j + 3] = b.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < PER; ++j) { kv[j] = 0.f; vv[j] = 0.f; }
-            }
-#pragma unroll
-            for (int j = 0; j < PER / 8; ++j) {
-                h16x8 a, b;
-                split8(kv + 8 * j, a, b);
-                *(h16x8*)(Kh + lkey * AX_KLD + d0 + 8 * j) = a;
-                *(h16x8*)(Kl + lkey * AX_KLD + d0 + 8 * j) = b;
-            }
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const _Float16 hh = (_Float16)vv[j];
-                Vh[(d0 + j) * AX_VLD + slot] = hh;
-                Vl[(d0 + j) * AX_VLD + slot] = (_Float16)(vv[j] - (float)hh);
-            }
-        }
+    float4 kq[NV], vq[NV];
+#define AX_FETCH(kc_)                                                                                                    \
+    {                                                                                                                    \
+        const int kap = (kc_) + lkey;                                                                                    \
+        if (kap < nkeys) {                                                                                               \
+            const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;                       \
+            const float* p = qkv + (size_t)row * ld + head * HEAD_DIM + d0;                                              \
+            _Pragma("unroll") for (int j = 0; j < NV; ++j) {                                                             \
+                kq[j] = *(const float4*)(p + width + 4 * j);                                                             \
+                vq[j] = *(const float4*)(p + 2 * width + 4 * j);                                                         \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < NV; ++j) { kq[j] = make_float4(0.f, 0.f, 0.f, 0.f); vq[j] = kq[j]; }   \
+        }                                                                                                                \
+    }
+#define AX_STORE(buf_)                                                                                                   \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NV; ++j) {                                                                 \
+            const float kk[4] = {kq[j].x, kq[j].y, kq[j].z, kq[j].w}, vv[4] = {vq[j].x, vq[j].y, vq[j].z, vq[j].w};      \
+            h16x4 a, b;                                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+                a[e] = (_Float16)kk[e]; b[e] = (_Float16)(kk[e] - (float)a[e]);                                          \
+                const _Float16 hh = (_Float16)vv[e];                                                                     \
+                Vh[buf_][(d0 + 4 * j + e) * AX_VLD + slot] = hh;                                                         \
+                Vl[buf_][(d0 + 4 * j + e) * AX_VLD + slot] = (_Float16)(vv[e] - (float)hh);                             \
+            }                                                                                                            \
+            *(h16x4*)(Kh[buf_] + lkey * AX_KLD + d0 + 4 * j) = a;                                                        \
+            *(h16x4*)(Kl[buf_] + lkey * AX_KLD + d0 + 4 * j) = b;                                                        \
+        }                                                                                                                \
+    }
+    // one-wave blocks (text sequences: a single chunk of <= 32 keys) gain nothing from the prefetch and pay for its registers
+    constexpr bool PIPE = NW > 1;
+    if (PIPE) {
+        AX_FETCH(0)
+        AX_STORE(0)
         __syncthreads();
+    }
+    int buf = 0;
+    for (int kc = 0; kc < kend; kc += 32, buf ^= PIPE ? 1 : 0) {
+        const bool has_next = PIPE && kc + 32 < kend;
+        if (!PIPE) {
+            AX_FETCH(kc)
+            AX_STORE(0)
+            __syncthreads();
+        }
+        if (has_next) AX_FETCH(kc + 32)                            // in flight while this chunk is consumed
         if (active && kc < my_kend) {
+            const _Float16 *kh_ = Kh[buf], *kl_ = Kl[buf], *vh_ = Vh[buf], *vl_ = Vl[buf];
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const h16x8 kh = *(const h16x8*)(Kh + l32 * AX_KLD + ks * 16 + h * 8);
-                const h16x8 kl = *(const h16x8*)(Kl + l32 * AX_KLD + ks * 16 + h * 8);
+                const h16x8 kh = *(const h16x8*)(kh_ + l32 * AX_KLD + ks * 16 + h * 8);
+                const h16x8 kl = *(const h16x8*)(kl_ + l32 * AX_KLD + ks * 16 + h * 8);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
             }
             float cm = -INFINITY;
+            if (kc + 32 > nkeys || (causal && kc + 31 > sq.pre_len + qb * 32)) {       // chunk holds masked keys
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] *= 0.125f;
-                const int key = kc + mfma32_row(r, h);
-                if (key >= nkeys || (causal && key > qpos)) s[r] = -INFINITY;
-                cm = fmaxf(cm, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kc + mfma32_row(r, h);
+                    if (key >= nkeys || (causal && key > qpos)) s[r] = -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, s[r]);
             cm = fmaxf(cm, __shfl_xor(cm, 32));
             const float mn = fmaxf(m, cm);
-            const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+            const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m - mn) * SC);
+            const float mb = mn * SC;
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mn); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] * SC - mb); ps += s[r]; }
             lsum = lsum * alpha + ps;
+            if (alpha != 1.f) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 float pv[8];
@@ -131,10 +153,10 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
                 for (int e2 = 0; e2 < 8; ++e2) pv[e2] = s[8 * tt + e2] * 64.0f;
                 h16x8 ph, pl;
                 split8(pv, ph, pl);
-                const h16x8 v0h = *(const h16x8*)(Vh + l32 * AX_VLD + tt * 16 + h * 8);
-                const h16x8 v0l = *(const h16x8*)(Vl + l32 * AX_VLD + tt * 16 + h * 8);
-                const h16x8 v1h = *(const h16x8*)(Vh + (32 + l32) * AX_VLD + tt * 16 + h * 8);
-                const h16x8 v1l = *(const h16x8*)(Vl + (32 + l32) * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v0h = *(const h16x8*)(vh_ + l32 * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v0l = *(const h16x8*)(vl_ + l32 * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v1h = *(const h16x8*)(vh_ + (32 + l32) * AX_VLD + tt * 16 + h * 8);
+                const h16x8 v1l = *(const h16x8*)(vl_ + (32 + l32) * AX_VLD + tt * 16 + h * 8);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(64 * NW) void attention_fwd_x3_kernel(const float* 
             }
             m = mn;
         }
+        if (has_next) AX_STORE((buf ^ 1) & (NB - 1))
         __syncthreads();
     }
     if (!active) return;
@@ -182,7 +205,11 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
                             void* out_hi, void* out_lo, hipStream_t st) {
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
-    if (max_q_len > 32) {
+    if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
+        dim3 grid((max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
+        RLCF_ARG_CHECK(grid.y <= 65535);
+        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+    } else if (max_q_len > 32) {
         dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
         attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
