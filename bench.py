@@ -60,13 +60,13 @@ def cpu_baseline(ssd, rsd, geo, n_ctx=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
-    ap.add_argument("--batch", type=int, default=8, help="independent test images per tower pass (engine-internal batching)")
+    ap.add_argument("--batch", type=int, default=32, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
@@ -146,10 +146,10 @@ def main():
         # f16x3: three f16 MFMAs per algorithmic multiply-add -> at most 1/3 of the f16 pipe is algorithmic
         peak = PEAK_TFLOPS["f32"] if a.precision == "f32" else PEAK_TFLOPS["bf16"]
         passes = 1 if a.precision == "f32" else 3
-        traffic = None                       # HBM bytes per GEMM launch from the committed PMC profile (same shapes, 8 images/pass)
+        traffic = None                       # fabric bytes per GEMM launch from the committed PMC profile (same shapes, same images/pass)
         tpath = os.path.join(ROOT, "profiles", "r1_gemm_hbm_traffic.json")
-        if a.precision == "f16x3" and a.batch == 8 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["bytes_per_launch"]
+        if a.precision == "f16x3" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch_by_images_per_pass"].get(str(a.batch))
         out = {
             "metric": "test_images_per_sec", "value": a.steps * world / dt, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
