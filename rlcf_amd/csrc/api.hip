@@ -204,7 +204,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat};
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
-    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->dyn}) d->release();
+    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn}) d->release();
     delete e;
 }
 

@@ -52,6 +52,13 @@ __device__ __forceinline__ float quick_gelu_grad(float f) {
 }
 
 // ---- internal launchers shared between translation units (all async on `st`) ----
+// max|v| of a GEMM's output, folded into the epilogue (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void amax_commit(unsigned int* out, float m) {
+    if (!out) return;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 struct GemmArgs {
     const void* A; int lda;        // [M,K] f32
     const void* W; int ldw;        // [N,K]
@@ -61,5 +68,6 @@ struct GemmArgs {
     void* C; int ldc;              // [M,N] f32
     int M, N, K;
     float alpha; int epilogue;
+    unsigned int* amax_out;        // optional: atomicMax of |C| (as float bits) — the next GEMM's split-f16 operand scale
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st);

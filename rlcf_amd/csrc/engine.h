@@ -106,7 +106,7 @@ struct rlcf_engine {
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
     int ln_count = 0;                // (4*layers + 4) * Wv
     size_t bwd_elems = 0;
-    DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att;   // ModifiedResNet workspace (one chunk of images)
+    DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
     DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
@@ -129,7 +129,10 @@ int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
 int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
 // engine.hip services used by resnet.hip
 int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
-                int ldc, int M, int N, int K, int epi, hipStream_t st);
+                int ldc, int M, int N, int K, int epi, hipStream_t st, const float* amax_in = nullptr, float* amax_out = nullptr);
+int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N,
+                         int K, int epi, const float* alpha_dev, hipStream_t st, float* amax_out = nullptr);
+bool engine_has_split(const rlcf_engine* e, const float* W);
 int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st);
 
 // engine internals used by api.hip

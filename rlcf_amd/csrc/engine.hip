@@ -48,8 +48,9 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 #define GRAD_SCALE 256.0f
 static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                 const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st,
-                float a_scale = 1.0f, bool dyn_scale = false) {
+                float a_scale = 1.0f, bool dyn_scale = false, const float* amax_in = nullptr, unsigned int* amax_out = nullptr) {
     GemmArgs g{};
+    g.amax_out = amax_out;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi;
     e->last_flops += 2.0 * M * N * K;
@@ -61,14 +62,19 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const float* alpha_dev = nullptr;
             if (dyn_scale) {       // operand range unknown (un-normalised ResNet activations): power-of-two scale found on the device
                 TRY(e->dyn.ensure(3 * sizeof(float)));
-                TRY(launch_split_f16x2_dyn(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>(), st));
+                if (amax_in) {             // max|A| was produced by the GEMM that wrote A
+                    TRY(launch_dyn_scale_from(amax_in, e->dyn.as<float>() + 1, st));
+                    TRY(launch_split_f16x2_dev(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>() + 1, st));
+                } else {
+                    TRY(launch_split_f16x2_dyn(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>(), st));
+                }
                 alpha_dev = e->dyn.as<float>() + 2;
             } else {
                 TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st, a_scale));
             }
             const int slot = prof_begin(st, 2.0 * M * N * K);
             int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
-                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev);
+                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -80,8 +86,26 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
 }
 
 int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
-                int ldc, int M, int N, int K, int epi, hipStream_t st) {
-    return gemm(e, A, lda, W, ldw, bias, res, ldr, nullptr, 0, C, ldc, M, N, K, 1.f, epi, st, 1.0f, true);
+                int ldc, int M, int N, int K, int epi, hipStream_t st, const float* amax_in, float* amax_out) {
+    return gemm(e, A, lda, W, ldw, bias, res, ldr, nullptr, 0, C, ldc, M, N, K, 1.f, epi, st, 1.0f, true, amax_in, (unsigned int*)amax_out);
+}
+
+// A operand already split into e->a_hi / e->a_lo by the caller (scaled by the device scalar whose inverse is *alpha_dev)
+int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, const float* res, int ldr, float* C, int ldc, int M, int N,
+                         int K, int epi, const float* alpha_dev, hipStream_t st, float* amax_out) {
+    const ClipModel::SplitW* sp = nullptr;
+    for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
+    if (!sp) { rlcf_set_error("engine_gemm_presplit: weight has no split copy"); return RLCF_ERR_STATE; }
+    e->last_flops += 2.0 * M * N * K;
+    const int slot = prof_begin(st, 2.0 * M * N * K);
+    int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
+                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out);
+    prof_end(slot, st, g_last_x3_variant);
+    return rc;
+}
+bool engine_has_split(const rlcf_engine* e, const float* W) {
+    for (auto& m : e->model) if (m.split_of.find(W) != m.split_of.end()) return true;
+    return false;
 }
 
 // pre-split A operand (written by the producing kernel): C f32 and/or a split pair

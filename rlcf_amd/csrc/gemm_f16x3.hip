@@ -27,6 +27,7 @@ struct GemmX3Args {
     _Float16 *Chi, *Clo; int ldch;     // split output (may be null)
     int M, N, K;
     float alpha; int epilogue;
+    unsigned int* amax_out;            // optional: atomicMax of |C| (float bits), see common.h
     const float* alpha_dev;            // optional device scalar multiplied into alpha (undoes a data-dependent operand pre-scale)
     int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
 };
@@ -40,6 +41,7 @@ __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_
 #define X3_TILE (X3_BM * X3_LD)         // halves per operand tile
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
+    float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // [2][4][128][40]
     // XCD-aware tile mapping: consecutive block ids run on different XCDs (id % 8); give each XCD
     // a contiguous range of tiles so that neighbours sharing an A row-panel share one L2.
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
                     h16x4 hh, ll;
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 }
             }
         }
+        amax_commit(g.amax_out, am);
         return;
     }
 #pragma unroll
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                 if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
+                if (g.amax_out) am = fmaxf(am, fabsf(v));
                 if (g.C) g.C[(size_t)row * g.ldc + col] = v;
                 if (g.Chi) {
                     const _Float16 hi = (_Float16)v;
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 }
             }
         }
+    amax_commit(g.amax_out, am);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -213,6 +219,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
+    float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [3][V2_STAGE]
     const int tiles_n = (g.N + V2_BN - 1) / V2_BN;
     const int nwg = gridDim.x;
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
                     h16x4 hh, ll;
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
             }
         }
     }
+    amax_commit(g.amax_out, am);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
 #define V3_WHI 32768
 #define V3_WLO 49152
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) {
+    float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
     const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
     const int nwg = gridDim.x;
@@ -510,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if (g.Chi) {
                     h16x4 hh, ll;
@@ -521,19 +532,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
             }
         }
     }
+    amax_commit(g.amax_out, am);
 }
 
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
-                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev) {
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && Clo)));
     GemmX3Args g{};
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
-    g.alpha_dev = alpha_dev;
+    g.alpha_dev = alpha_dev; g.amax_out = amax_out;
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
     static bool attr = false;
@@ -625,12 +637,31 @@ __global__ void split_f16x2_dyn_kernel(const float* __restrict__ x, _Float16* __
     }
 }
 // scratch: 3 floats on the device {max|x|, s, 1/s}
-int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st) {
-    RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scratch3);
+int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && scratch3);
     int rc = launch_absmax(x, n, scratch3, st);
     if (rc != RLCF_OK) return rc;
     dyn_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(scratch3, scratch3 + 1);
     RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st) {
+    dyn_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(amax_dev, scale2);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scale_dev);
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale_dev);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scratch3);
+    int rc = launch_dyn_scale(x, n, scratch3, st);
+    if (rc != RLCF_OK) return rc;
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scratch3 + 1);

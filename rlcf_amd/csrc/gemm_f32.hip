@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
     }
 
     float* __restrict__ C = (float*)g.C;
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -115,9 +116,11 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                 if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
+                if (g.amax_out) am = fmaxf(am, fabsf(v));
                 C[(size_t)row * g.ldc + col] = v;
             }
         }
+    amax_commit(g.amax_out, am);
 }
 
 // Small-M variant (sparse backward, reward views): one 32x32 output tile per 4-wave block, the
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
     for (int r = 0; r < 16; ++r) part[wave][mfma32_row(r, h) * 33 + l32] = acc[r];
     __syncthreads();
     float* __restrict__ C = (float*)g.C;
+    float am = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int idx = t + e * 256, rr = idx >> 5, cc = idx & 31;
@@ -163,8 +167,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
         else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
         if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
         if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
+        if (g.amax_out) am = fmaxf(am, fabsf(v));
         C[(size_t)row * g.ldc + col] = v;
     }
+    amax_commit(g.amax_out, am);
 }
 
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {

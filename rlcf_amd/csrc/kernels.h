@@ -50,7 +50,11 @@ int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* im
                        float* dtxt, hipStream_t st);
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
-                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr);
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr,
+                      unsigned int* amax_out = nullptr);
+int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
+int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
+int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st);
 int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st);
 int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f);
 int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st);

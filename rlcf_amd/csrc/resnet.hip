@@ -48,6 +48,40 @@ __global__ void im2col3x3_kernel(const float* __restrict__ in, float* __restrict
     }
 }
 
+// The same gather for NHWC activations with Cin % 8 == 0, written directly as the split-f16 operand pair of the GEMM:
+// 8 channels of one tap per thread (two 16-B loads, two 16-B stores), scaled by the device scalar scale[0] (a power of two).
+__global__ void im2col3x3_split_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long total8,
+                                       int Cin, int H, int W, int Ho, int Wo, int stride, int Kp, const float* __restrict__ scale) {
+    const float sc = scale[0];
+    const int K8 = Kp / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / K8;
+        const int k = (int)(i - row * K8) * 8;
+        h16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+        if (k < 9 * Cin) {
+            const int tap = k / Cin, c = k - tap * Cin, ky = tap / 3, kx = tap - ky * 3;
+            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho);
+            const long img = row / ((long)Wo * Ho);
+            const int y = oy * stride + ky - 1, x = ox * stride + kx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const float* p = in + ((img * H + y) * W + x) * Cin + c;
+                const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+                const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 hh = (_Float16)v[e];
+                    vh[e] = hh;
+                    vl[e] = (_Float16)(v[e] - (float)hh);
+                }
+            }
+        }
+        ((h16x8*)hi)[i] = vh;
+        ((h16x8*)lo)[i] = vl;
+    }
+}
+
 // AvgPool2d(2) on an NHWC activation (model.py:25,37,117): out[img, y, x, c] = mean of the 2x2 window
 __global__ void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int C, int Ho, int Wo) {
     const int W = 2 * Wo;
@@ -229,11 +263,26 @@ static int rn_ensure(rlcf_engine* e, const ResNetW& r, int chunk, int T) {
 static inline dim3 grid_for(long total) { return dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)); }
 
 // conv (+folded bn) (+identity) (+relu) on an NHWC activation; 3x3 goes through the patch matrix
-static int conv(rlcf_engine* e, const ConvW& cw, const float* in, int n, int H, int W, int stride, bool nchw, const float* res, int epi,
-                float* out, hipStream_t st) {
+// in_amax / out_amax: device scalars holding max|in| (if known) and receiving max|out| (GEMM epilogue), so that the split-f16
+// operand scale of the next convolution needs no extra pass over the activation
+static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* in_amax, int n, int H, int W, int stride, bool nchw,
+                const float* res, int epi, float* out, float* out_amax, hipStream_t st) {
     const int Ho = H / stride, Wo = W / stride;
     const long M = (long)n * Ho * Wo;
     const float* A = in;
+    if (cw.k == 3 && !nchw && e->precision == RLCF_PREC_F16X3 && cw.cin % 8 == 0 && M > 512 && (size_t)M * cw.Kp <= e->a_split_elems &&
+        engine_has_split(e, cw.w)) {
+        // split-f16 mode: the patch matrix is written once, already as the (hi, lo) operand pair; its power-of-two scale comes
+        // from max|activation| (the patch matrix holds the same values), found on the 9x smaller activation
+        TRY(e->dyn.ensure(3 * sizeof(float)));
+        if (in_amax) TRY(launch_dyn_scale_from(in_amax, e->dyn.as<float>() + 1, st));
+        else TRY(launch_dyn_scale(in, (int64_t)n * H * W * cw.cin, e->dyn.as<float>(), st));
+        const long total8 = M * (cw.Kp / 8);
+        im2col3x3_split_kernel<<<grid_for(total8), dim3(256), 0, st>>>(in, (_Float16*)e->a_hi.p, (_Float16*)e->a_lo.p, total8, cw.cin, H, W,
+                                                                      Ho, Wo, stride, cw.Kp, e->dyn.as<float>() + 1);
+        RLCF_LAUNCH_CHECK();
+        return engine_gemm_presplit(e, cw.w, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi, e->dyn.as<float>() + 2, st, out_amax);
+    }
     if (cw.k == 3) {
         const long total = M * cw.Kp;
         const long sN = (long)cw.cin * H * W, sC = nchw ? (long)H * W : 1, sH = nchw ? W : (long)W * cw.cin, sW = nchw ? 1 : cw.cin;
@@ -242,7 +291,8 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, int n, int H, 
         RLCF_LAUNCH_CHECK();
         A = e->rn_col.as<float>();
     }
-    return engine_gemm(e, A, cw.Kp, cw.w, cw.Kp, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi, st);
+    return engine_gemm(e, A, cw.Kp, cw.w, cw.Kp, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi, st,
+                       cw.k == 1 ? in_amax : nullptr, out_amax);
 }
 
 static int avgpool2(const float* in, float* out, int n, int Ho, int Wo, int C, hipStream_t st) {
@@ -257,7 +307,7 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
     const rlcf_clip_cfg& c = m.cfg;
     const ResNetW& r = m.rn;
     const int R = c.image_resolution, w = c.vision_width, E = r.E, D = c.embed_dim, HW = r.out_hw * r.out_hw, T = HW + 1;
-    const size_t budget = (size_t)256 << 20;                                   // floats in the patch matrix of one chunk
+    const size_t budget = (size_t)1 << 30;                                     // floats in the patch matrix of one chunk (4 GB)
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_total, budget / r.col_per_img));
     TRY(rn_ensure(e, r, chunk, T));
     float *X = e->rn_buf[0].as<float>(), *A = e->rn_buf[1].as<float>(), *B = e->rn_buf[2].as<float>(), *Cb = e->rn_buf[3].as<float>(),
@@ -266,28 +316,44 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
         const int n = std::min(chunk, n_total - i0);
         const float* img = images + (size_t)i0 * 3 * R * R;
         int H = R / 2;
+        // max|.| of the five activation buffers (X, A, B, Cb, Dd), refreshed by whichever GEMM writes the buffer; an
+        // average-pooled copy inherits the scalar of its source (a valid, slightly conservative bound)
+        TRY(e->rn_amax.ensure(8 * sizeof(float)));
+        float* am = e->rn_amax.as<float>();
+        float *amX = am, *amA = am + 1, *amB = am + 2, *amD = am + 4;
+#define ZERO(p) RLCF_HIP_CHECK(hipMemsetAsync((p), 0, sizeof(float), st))
         // stem (model.py:139-145): conv 3x3 s2 -> conv 3x3 -> conv 3x3 -> avgpool 2
-        TRY(conv(e, r.stem[0], img, n, R, R, 2, true, nullptr, RLCF_EPI_RELU, A, st));
-        TRY(conv(e, r.stem[1], A, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, B, st));
-        TRY(conv(e, r.stem[2], B, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, st));
+        ZERO(amA);
+        TRY(conv(e, r.stem[0], img, nullptr, n, R, R, 2, true, nullptr, RLCF_EPI_RELU, A, amA, st));
+        ZERO(amB);
+        TRY(conv(e, r.stem[1], A, amA, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, B, amB, st));
+        ZERO(amA);
+        TRY(conv(e, r.stem[2], B, amB, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, amA, st));
         H /= 2;
         TRY(avgpool2(A, X, n, H, H, w, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(amX, amA, sizeof(float), hipMemcpyDeviceToDevice, st));
         for (const BottleW& b : r.blocks) {                                    // Bottleneck.forward, model.py:42-55
             const int planes = b.c1.cout, Ho = H / b.stride;
-            TRY(conv(e, b.c1, X, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, st));
-            TRY(conv(e, b.c2, A, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, B, st));
+            ZERO(amA);
+            TRY(conv(e, b.c1, X, amX, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, amA, st));
+            ZERO(amB);
+            TRY(conv(e, b.c2, A, amA, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, B, amB, st));
             const float* t2 = B;
-            if (b.stride > 1) { TRY(avgpool2(B, A, n, Ho, Ho, planes, st)); t2 = A; }
+            if (b.stride > 1) { TRY(avgpool2(B, A, n, Ho, Ho, planes, st)); t2 = A; }      // max|A| <= max|B|: keep using amB
             const float* idn = X;
             if (b.has_down) {
                 const float* xp = X;
                 if (b.stride > 1) { TRY(avgpool2(X, Cb, n, Ho, Ho, b.down.cin, st)); xp = Cb; }
-                TRY(conv(e, b.down, xp, n, Ho, Ho, 1, false, nullptr, RLCF_EPI_NONE, Dd, st));
+                ZERO(amD);
+                TRY(conv(e, b.down, xp, amX, n, Ho, Ho, 1, false, nullptr, RLCF_EPI_NONE, Dd, amD, st));
                 idn = Dd;
             }
-            TRY(conv(e, b.c3, t2, n, Ho, Ho, 1, false, idn, RLCF_EPI_RELU, X, st));   // in place when idn == X (elementwise)
+            // in place when idn == X (elementwise); amX is re-zeroed first: the GEMM reads X only as the residual operand
+            ZERO(amX);
+            TRY(conv(e, b.c3, t2, amB, n, Ho, Ho, 1, false, idn, RLCF_EPI_RELU, X, amX, st));
             H = Ho;
         }
+#undef ZERO
         // attention pool (model.py:68-91)
         attnpool_tokens_kernel<<<dim3((E + 255) / 256, n), dim3(256), 0, st>>>(X, r.pos, e->rn_tok.as<float>(), HW, E);
         RLCF_LAUNCH_CHECK();

@@ -782,3 +782,41 @@ def test_full_size_properties(L, dev):
         eng.close()
     torch.testing.assert_close(results[L.TEXT_PACKED], results[L.TEXT_SHARED], atol=1e-3, rtol=0)    # (iii)
     torch.testing.assert_close(results[L.TEXT_DENSE], results[L.TEXT_SHARED], atol=1e-3, rtol=0)
+
+
+def test_config5_rn50x64_student_vit_l14_reward(L, dev):
+    """BASELINE configs[4]: RN50x64 student (448^2 views, frozen ModifiedResNet image encoder, prompt tuning) + ViT-L/14 reward (the
+    selected views are resampled 448 -> 224 with the bicubic kernel), N=32.  Full geometry, 200 classes; size-independent properties:
+    per-sample reset reproducibility, f32 and split-f16 precision agree, rewards of a view sum to zero (baseline subtraction), and
+    the student features of view 0 equal the reference-generated RN50x64 fixture."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    sg, rg = synth.GEOMETRIES["RN50x64"], synth.GEOMETRIES["ViT-L/14"]
+    ssd = synth.make_state_dict(sg, 11, device=dev)
+    rsd = synth.make_state_dict(rg, 23, device=dev)
+    tokens = synth.make_token_bank(sg, 200, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, 4), device=dev)].clone()
+    views = synth.make_views(1000, 32, 448, device=dev)
+    cfg = TTAConfig(selection_p=0.1)
+    out = {}
+    for prec in (L.PREC_F32, L.PREC_F16X3):
+        eng = Engine(sg, rg, 32, 200, prec)
+        eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
+        eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+        if prec == L.PREC_F32:
+            g, _ = load_golden("modules_rn")
+            f = eng.encode_image(L.STUDENT, views[:1]).cpu()
+            torch.testing.assert_close(f, CR.l2_normalize(g["rn50x64_image"]), atol=2e-5, rtol=1e-4)
+        a = eng.tta_sample(views, cfg)
+        b = eng.tta_sample(views, cfg, want_intermediates=False)
+        torch.cuda.synchronize()
+        assert a["top5"].tolist() == b["top5"].tolist()
+        torch.testing.assert_close(a["final_logits"], b["final_logits"], atol=2e-4, rtol=0)
+        assert a["selected_idx"].numel() == 3 and a["topk_idx"].shape == (3, 3)
+        torch.testing.assert_close(a["rewards"].view(3, 3).sum(1).cpu(), torch.zeros(3), atol=1e-5, rtol=0)
+        out[prec] = {k: v.cpu() for k, v in a.items() if torch.is_tensor(v)}
+        eng.close()
+    x, y = out[L.PREC_F32], out[L.PREC_F16X3]
+    assert x["selected_idx"].tolist() == y["selected_idx"].tolist() and x["topk_idx"].tolist() == y["topk_idx"].tolist()
+    assert x["top5"].tolist() == y["top5"].tolist()
+    torch.testing.assert_close(x["logits"], y["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(x["final_logits"], y["final_logits"], atol=1e-3, rtol=0)
