@@ -131,6 +131,18 @@ int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     rlcf_stream stream);
 
+/* ------------------------------------------------------------------ views ------
+ * Device-side replacement of the reference's per-sample CPU view pipeline (TPT/data/datautils.py:76-128 AugMixAugmenter with an
+ * empty aug_list; transforms of TPT/tpt_cls_rl.py:132-150): from ONE decoded uint8 RGB image (HWC, device) write
+ * views[1 + n_crops, 3, res, res] float32: view 0 = Resize(res, bicubic) + CenterCrop(res); view 1+i = resized_crop(crops[i],
+ * bilinear) with optional horizontal flip; all followed by ToTensor and Normalize(mean, std).  Bit-exact with Pillow's 8-bit
+ * resampler.  crops, mean3, std3 are HOST arrays; the random boxes / flips are drawn by the caller (RandomResizedCrop.get_params,
+ * RandomHorizontalFlip).  scratch: device, >= rlcf_make_views_scratch_bytes(H, n_crops, res). */
+typedef struct { int top, left, h, w, flip; } rlcf_crop;
+size_t rlcf_make_views_scratch_bytes(int H, int n_crops, int res);
+int rlcf_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
+                    const float* std3, float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream);
+
 /* ------------------------------------------------------------------ engine ------
  * Owns device copies of the weights (plus derived layouts) and all workspace. */
 rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward /*NULL: none*/,

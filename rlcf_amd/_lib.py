@@ -27,6 +27,10 @@ class ClipCfg(C.Structure):
                                        "text_heads", "text_layers")] + [("vision_stages", C.c_int * 4)]
 
 
+class Crop(C.Structure):       # rlcf_crop: RandomResizedCrop box + RandomHorizontalFlip
+    _fields_ = [(n, C.c_int) for n in ("top", "left", "h", "w", "flip")]
+
+
 class Seq(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("q_start", "q_len", "pre_start", "pre_len")]
 
@@ -72,6 +76,8 @@ SIGNATURES = {
     "rlcf_encode_image_resized": (I, [P, I, P, I, I, P, P]),
     "rlcf_text_features": (I, [P, P, P, P]),
     "rlcf_reward_class_features": (I, [P, I, P, P]),
+    "rlcf_make_views_scratch_bytes": (C.c_size_t, [I, I, I]),
+    "rlcf_make_views": (I, [P, I, I, P, I, I, P, P, P, P, C.c_size_t, P]),
     "rlcf_engine_create_ensemble": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I, I]),
     "rlcf_engine_set_reward_mix": (I, [P, P, I, I]),
     "rlcf_reward_loss_ensemble": (I, [P, I, P, I, I, I, I, P, P, P, P, I, F, I, F, P, P, P, P, P, P]),

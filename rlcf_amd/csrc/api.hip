@@ -107,6 +107,12 @@ int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int
     return launch_adamw(p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
 }
 
+size_t rlcf_make_views_scratch_bytes(int H, int n_crops, int res) { return views_scratch_bytes(H, 1 + n_crops, res); }
+int rlcf_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3, const float* std3,
+                    float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream) {
+    return launch_make_views(image, H, W, crops, n_crops, res, mean3, std3, views, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ engine
 static bool cfg_ok(const rlcf_clip_cfg* c) {
     if (!c) return false;

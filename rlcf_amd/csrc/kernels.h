@@ -90,3 +90,8 @@ int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const floa
                             int tokens, int width, hipStream_t st);
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st);
 int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipStream_t st);
+
+// views.hip
+size_t views_scratch_bytes(int H, int n_views, int res);
+int launch_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
+                      const float* std3, float* views, void* scratch, size_t scratch_bytes, hipStream_t st);
