@@ -271,6 +271,12 @@ int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* s
     reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, bank, clipscore_weight, topk_idx, g_stats);
     RLCF_LAUNCH_CHECK();
     const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
+    if (sh > 160 * 1024 - 256) { rlcf_set_error("reward_loss: min-entropy regulariser over %d classes does not fit the 160 KB LDS", C); return RLCF_ERR_ARG; }
+    static size_t sh_max = 48 * 1024;
+    if (sh > sh_max) {                                   // large banks (retrieval: 5k-25k captions)
+        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)reward_stage_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        sh_max = sh;
+    }
     reward_stage_b_kernel<<<dim3(rows), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
                                                                      topk_idx, g_stats, clip_score, rewards, loss, dlogits);
     RLCF_LAUNCH_CHECK();
