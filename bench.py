@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--tta-steps", type=int, default=1, help="AdamW steps per test image (BASELINE metric: 1; rlcf-prompt.sh runs 3)")
     ap.add_argument("--batch", type=int, default=32, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -99,7 +100,7 @@ def main():
     eng.finalize()
     mode = {"dense": _lib.TEXT_DENSE, "packed": _lib.TEXT_PACKED, "shared": _lib.TEXT_SHARED}[a.text_mode]
     eng.set_class_bank(tokens, n_ctx, ctx0, mode)
-    cfg = TTAConfig(selection_p=0.1, tta_steps=1, sample_k=3, lr=7e-3, weight_decay=5e-4)
+    cfg = TTAConfig(selection_p=0.1, tta_steps=a.tta_steps, sample_k=3, lr=7e-3, weight_decay=5e-4)
 
     # independent test images: rank r takes samples r*(W+K) .. ; seeds are per sample
     total = a.warmup + a.steps
@@ -156,9 +157,9 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else "f32 via split-f16x3 MFMA", "data": "synthetic",
             "config": {"workload": "RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + ViT-B/16 reward, N=64 views, "
-                                   "1000-class bank, selection_p=0.1, K=3, 1 AdamW step (BASELINE configs[1])",
+                                   f"1000-class bank, selection_p=0.1, K=3, {a.tta_steps} AdamW step(s) (BASELINE configs[1])",
                        "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
-                       "tta_steps": 1, "images_per_pass": a.batch,
+                       "tta_steps": a.tta_steps, "images_per_pass": a.batch,
                        "parallelism": f"sample-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,

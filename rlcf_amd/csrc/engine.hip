@@ -892,48 +892,57 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
     TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
     TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
-    // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
-    TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e),
-                                   a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
-                                   e->dlogits.as<float>(), st));
-    // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
     const int gT = L.pre_rows + n_e * L.lmax, T = B * gT, nE = B * n_e;
-    TRY(launch_build_sparse_layout(e->topk_idx.as<int32_t>(), B, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(),
-                                   L.class_eot_off.as<int32_t>(), L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
-                                   e->sp_row_src.as<int32_t>(), st));
-    TextPassIO io{};
-    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = B * (n_e + (L.pre_rows > 0 ? 1 : 0)); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = nE;
-    io.attn_pairs = (long)(nE * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
-    io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
-    io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
-    io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
-    io.rep_rows = 0; io.ctx_stride = 0;                        // every group starts from ctx_init
-    TRY(text_forward(e, s, L, e->st, e->ctx_init.as<float>(), io, true, st));
-    TRY(launch_dtxt_sparse(e->dlogits.as<float>(), e->topk_idx.as<int32_t>(), e->sel_feat.as<float>(), nE, K, C, D, s.logit_scale_exp,
-                           e->sp_dtxt.as<float>(), st));
-    {   // text_backward with the per-sample (grouped) ctx-gradient reduction
-        TRY(launch_l2norm_bwd(io.txt, e->sp_dtxt.as<float>(), io.inv_norm, e->sp_du.as<float>(), nE, D, st));
-        TRY(gemm(e, e->sp_du.as<float>(), D, s.tproj, D, nullptr, nullptr, 0, nullptr, 0, e->sp_dxe.as<float>(), Wt, nE, Wt, D, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_bwd(io.eot_x, s.lnf_w, e->sp_dxe.as<float>(), nullptr, e->sp_dxe.as<float>(), nullptr, nullptr, nE, Wt, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wt * sizeof(float), st));
-        TRY(launch_scatter_rows(e->sp_dxe.as<float>(), io.eot_rows, e->dX.as<float>(), nE, Wt, st));
-        TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, L.max_keys, io.attn_pairs, 1, T, st));
-        TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
-                                    e->b_grad.as<float>(), st));
-    }
-    // 5. one AdamW step per sample from the reset state (ctx_init, m = v = 0)
     const int64_t np = (int64_t)n_ctx * Wt;
+    // reset state of every sample: ctx = ctx_init, Adam moments zero (custom_clip.py:161-164, tpt_cls_rl.py:251-255)
     TRY(launch_broadcast_rows(e->ctx_init.as<float>(), e->b_ctx.as<float>(), (int)np, B, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->b_m.p, 0, (size_t)B * np * sizeof(float), st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->b_v.p, 0, (size_t)B * np * sizeof(float), st));
-    TRY(launch_adamw(e->b_ctx.as<float>(), e->b_grad.as<float>(), e->b_m.as<float>(), e->b_v.as<float>(), B * np, 1, a->lr, a->beta1, a->beta2,
-                     a->eps, a->weight_decay, st));
-    // 6. final clean-view inference: B adapted prompts through one replicated text pass
-    TextPassIO fo{};
+    TextPassIO fo{};                 // full class bank, one replica (and one prompt) per sample
     fo.seqs = e->b_seqs_rep.as<rlcf_seq>(); fo.n_seq = B * L.n_seq; fo.max_q_len = L.max_q_len; fo.T = B * L.T; fo.n_cls = B * C;
     fo.attn_pairs = (long)B * L.attn_pairs; fo.eot_rows = e->b_eot_rep.as<int32_t>(); fo.row_src = nullptr;
     fo.eot_x = e->b_eot_x.as<float>(); fo.eot_ln = e->b_eot_ln.as<float>(); fo.u = e->b_u.as<float>(); fo.inv_norm = e->b_inv.as<float>();
     fo.txt = e->b_txt.as<float>(); fo.rep_rows = L.T; fo.ctx_stride = (int)np;
+    for (int j = 0; j < a->tta_steps; ++j) {
+        if (j > 0) {
+            // tpt_cls_rl.py:55: logits of the selected views under each sample's current prompt
+            TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
+            TRY(launch_group_logits(e->sel_feat.as<float>(), n_sel, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, e->sel_logits.as<float>(), st));
+            e->last_flops += 2.0 * BS * C * D;
+        }
+        // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
+        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e),
+                                    a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
+                                    e->dlogits.as<float>(), st));
+        // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
+        TRY(launch_build_sparse_layout(e->topk_idx.as<int32_t>(), B, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(),
+                                       L.class_eot_off.as<int32_t>(), L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
+                                       e->sp_row_src.as<int32_t>(), st));
+        TextPassIO io{};
+        io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = B * (n_e + (L.pre_rows > 0 ? 1 : 0)); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = nE;
+        io.attn_pairs = (long)(nE * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
+        io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
+        io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
+        io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
+        io.rep_rows = gT; io.ctx_stride = (int)np;                  // group b of gT rows reads prompt b
+        TRY(text_forward(e, s, L, e->st, e->b_ctx.as<float>(), io, true, st));
+        TRY(launch_dtxt_sparse(e->dlogits.as<float>(), e->topk_idx.as<int32_t>(), e->sel_feat.as<float>(), nE, K, C, D, s.logit_scale_exp,
+                               e->sp_dtxt.as<float>(), st));
+        {   // text_backward with the per-sample (grouped) ctx-gradient reduction
+            TRY(launch_l2norm_bwd(io.txt, e->sp_dtxt.as<float>(), io.inv_norm, e->sp_du.as<float>(), nE, D, st));
+            TRY(gemm(e, e->sp_du.as<float>(), D, s.tproj, D, nullptr, nullptr, 0, nullptr, 0, e->sp_dxe.as<float>(), Wt, nE, Wt, D, 1.f, RLCF_EPI_NONE, st));
+            TRY(launch_layernorm_bwd(io.eot_x, s.lnf_w, e->sp_dxe.as<float>(), nullptr, e->sp_dxe.as<float>(), nullptr, nullptr, nE, Wt, st));
+            RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wt * sizeof(float), st));
+            TRY(launch_scatter_rows(e->sp_dxe.as<float>(), io.eot_rows, e->dX.as<float>(), nE, Wt, st));
+            TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, L.max_keys, io.attn_pairs, 1, T, st));
+            TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
+                                        e->b_grad.as<float>(), st));
+        }
+        // 5. AdamW step j+1 of every sample (tpt_cls_rl.py:76-79)
+        TRY(launch_adamw(e->b_ctx.as<float>(), e->b_grad.as<float>(), e->b_m.as<float>(), e->b_v.as<float>(), B * np, j + 1, a->lr, a->beta1,
+                         a->beta2, a->eps, a->weight_decay, st));
+    }
+    // 6. final clean-view inference: B adapted prompts through one replicated text pass
     TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
     float* fl = final_logits ? final_logits : e->b_logits.as<float>();
     TRY(launch_final_logits_batched(e->img_feat.as<float>(), N, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, fl, st));
@@ -952,7 +961,7 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
     const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
                            !(a->flags & RLCF_F_MIN_ENTROPY) && a->sample_k > 1;
     const int Bmax = e->max_views / N;
-    const bool fused = Bmax >= 2 && a->tta_steps == 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0;
+    const bool fused = Bmax >= 2 && a->tta_steps >= 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0;
     double flops = 0.0;
     int i = 0;
     while (i < count) {

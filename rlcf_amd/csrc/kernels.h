@@ -81,6 +81,7 @@ int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t
                                float* dlogits, hipStream_t st);
 int launch_final_logits_batched(const float* img, int img_row_stride, const float* txt, int B, int C, int D, float scale, float* out,
                                 hipStream_t st);
+int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st);
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
                             void* out_hi, void* out_lo, hipStream_t st);

@@ -322,8 +322,9 @@ int launch_vit_assemble(const float* patch_out, const float* cls, const float* p
 // token embedding (non-ctx rows) + positional embedding; ctx rows add the learnable vectors.
 // row_src (optional): X row r is built from row row_src[r] of E / ctx_row (-1: zero row) — the
 // sparse-backward layout re-packs a few class prompts this way.
-// rep_rows > 0: the layout is replicated (row r of replica r / rep_rows is layout row r % rep_rows) and replica b
-// reads its own context block ctx + b * ctx_stride4 (one prompt per test sample).
+// rep_rows > 0: rows come in groups of rep_rows, one per test sample, and group b reads its own context block
+// ctx + b * ctx_stride4 (one prompt per sample).  Without row_src the layout itself is replicated (row r is layout row
+// r % rep_rows); a row_src table is indexed by the global row (every group has its own sampled classes).
 __global__ void text_assemble_kernel(const float* __restrict__ E, const int32_t* __restrict__ row_src, const int32_t* __restrict__ ctx_row,
                                      const float* __restrict__ ctx, float* __restrict__ X, int rows, int w4, int rep_rows, int ctx_stride4) {
     const long total = (long)rows * w4;
@@ -331,7 +332,7 @@ __global__ void text_assemble_kernel(const float* __restrict__ E, const int32_t*
         const int r = (int)(idx / w4), c = (int)(idx % w4);
         const int rep = rep_rows > 0 ? r / rep_rows : 0;
         const int rl = rep_rows > 0 ? r - rep * rep_rows : r;
-        const int sr = row_src ? row_src[rl] : rl;
+        const int sr = row_src ? row_src[r] : rl;
         if (sr < 0) { ((float4*)X)[idx] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         float4 e = ((const float4*)E)[(size_t)sr * w4 + c];
         const int cr = ctx_row[sr];

@@ -362,6 +362,24 @@ int launch_final_logits_batched(const float* img, int img_row_stride, const floa
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+// per-sample logits of a few rows: out[b*rows + i, c] = scale * <img[b*rows + i], txt[b, c]>   (one wave per class)
+__global__ __launch_bounds__(256) void group_logits_kernel(const float* __restrict__ img, int rows, const float* __restrict__ txt, int C, int D,
+                                                           float scale, float* __restrict__ out) {
+    const int gr = blockIdx.y, b = gr / rows, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const float* im = img + (size_t)gr * D;
+    const float* t = txt + ((size_t)b * C + c) * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += im[d] * t[d];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)gr * C + c] = scale * s;
+}
+int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st) {
+    RLCF_ARG_CHECK(B > 0 && rows_per_group > 0 && B * rows_per_group <= 65535);
+    group_logits_kernel<<<dim3((C + 3) / 4, B * rows_per_group), dim3(256), 0, st>>>(img, rows_per_group, txt, C, D, scale, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st) {
     top5_kernel<<<dim3(B), dim3(TTA_THREADS), 0, st>>>(logits, C, top5);
     RLCF_LAUNCH_CHECK();
