@@ -33,8 +33,9 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # /opt/skills/guides/MI355X_MIC
 def cpu_baseline(ssd, rsd, geo, n_ctx=4):
     """Times the oracle (CPU torch restatement of the reference graph: dense 77-token text tower,
     autograd backward) on the host cores.  Bounded sample: cfg-1 shape (N=8 views, selection_p=0.5)
-    on class banks of 32 and 96 prompts; the per-image cost at C=1000 is the linear extrapolation
-    (image towers are C-independent, text tower fwd+bwd is linear in C)."""
+    on class banks of 16 and 160 prompts (a warm-up pass first: the first torch CPU call pays thread-pool and allocator
+    start-up); the per-image cost at C=1000 is the linear extrapolation (image towers are C-independent, text tower fwd+bwd
+    is linear in C)."""
     from oracle import clip_ref as CR, rlcf_ref as RR
     cores = min(os.cpu_count() or 1, 32)     # torch's intra-op pool thrashes beyond ~32 threads on these op sizes
     torch.set_num_threads(cores)
@@ -42,17 +43,18 @@ def cpu_baseline(ssd, rsd, geo, n_ctx=4):
     ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(geo, n_ctx))
     hp = RR.TTAHyper(selection_p=0.5)
     times = {}
-    for c in (16, 48):
+    lo, hi = 16, 160
+    for c in (lo, lo, hi):                                  # first pass = warm-up, overwritten
         tokens = synth.make_token_bank(geo, c, seed=7, n_ctx=n_ctx)
         rc = RR.reward_class_features(rsd, tokens)          # once per dataset in the reference: not timed
         t0 = time.time()
         RR.tta_sample(ssd, rsd, views, tokens, ctx0, hp, reward_cls=rc)
         times[c] = time.time() - t0
-    per_class = (times[48] - times[16]) / 32.0
-    t_full = times[16] + per_class * (1000 - 16)
+    per_class = (times[hi] - times[lo]) / float(hi - lo)
+    t_full = times[lo] + per_class * (1000 - lo)
     return {"value": 1.0 / t_full, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle (CPU torch fp32, dense-77 reference graph), 1 image x N=8 views (selection_p=0.5), "
-                      f"timed at C=16 ({times[16]:.2f}s) and C=48 ({times[48]:.2f}s), extrapolated linearly to "
+                      f"timed at C={lo} ({times[lo]:.2f}s) and C={hi} ({times[hi]:.2f}s), extrapolated linearly to "
                       f"C=1000 ({t_full:.1f}s/image); N=64 would add only image-tower time",
             "seconds_per_image_extrapolated": t_full}
 
