@@ -229,6 +229,11 @@ int rlcf_engine_ln_param_count(rlcf_engine*);
  * reset state (initial_state_dict, custom_clip.py:395-399) instead of the live one. */
 int rlcf_engine_get_ln_params(rlcf_engine*, float* out, int pristine, rlcf_stream stream);
 int rlcf_engine_set_ln_params(rlcf_engine*, const float* in, rlcf_stream stream);
+/* CLIPCLS_TTA.momentum_update_model (custom_clip.py:460-475) for the tunable LayerNorm set: momentum_state = m*momentum_state +
+ * (1-m)*current (the tuned parameters of the sample just processed, device [ln_param_count]); with apply != 0 (the caller's
+ * update_counter reached update_freq) the reset state becomes (1-w)*checkpoint + w*momentum_state.  Makes test samples
+ * order-dependent: single replica only. */
+int rlcf_engine_momentum_update(rlcf_engine*, const float* current, double momentum, double update_w, int apply, rlcf_stream stream);
 
 /* Same for `count` consecutive samples (views [count,N,3,R,R]); top5 [count,5], final_logits
  * [count,C] (optional).  One host call per batch of test images. */

@@ -205,8 +205,15 @@ def visual_ln_keys(sd):
     return keys + ["visual.ln_post.weight", "visual.ln_post.bias"]
 
 
+def momentum_update(mom: torch.Tensor, cur: torch.Tensor, clip: torch.Tensor, momentum: float, update_w: float, apply: bool):
+    """CLIPCLS_TTA.momentum_update_model on the tunable tensors (custom_clip.py:460-475): -> (new momentum state, new reset
+    state or None).  float32 elementwise arithmetic as torch evaluates `m * a + (1.0 - m) * b`."""
+    mom = momentum * mom + (1.0 - momentum) * cur
+    return mom, ((1 - update_w) * clip + update_w * mom if apply else None)
+
+
 def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor, hp: TTAHyper,
-                  reward_cls: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                  reward_cls: Optional[torch.Tensor] = None, ln_init: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """One iteration of the harness loop TPT/tune_cls_rl.py:183-256 with model = CLIPCLS_TTA(only_visual=True,
     only_norm=True): reset visual state -> test_time_tuning (tpt_cls_rl.py:47-79; the image encoder runs WITH grad,
     custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference."""
@@ -217,6 +224,12 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
         cls_feat = C.l2_normalize(C.encode_text(student_sd, tokens))            # get_class_features, custom_clip.py:405-409
     keys = visual_ln_keys(student_sd)
     params = {k: student_sd[k].clone() for k in keys}                           # model.reset(): pristine visual state
+    if ln_init is not None:                                                     # ... or the momentum-updated initial_state_dict
+        off = 0
+        for k in keys:
+            n = params[k].numel()
+            params[k] = ln_init[off: off + n].reshape(params[k].shape).clone()
+            off += n
     m = {k: torch.zeros_like(v) for k, v in params.items()}
     v2 = {k: torch.zeros_like(v) for k, v in params.items()}
     scale = student_sd["logit_scale"].exp()

@@ -207,7 +207,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->views_sel, &e->topk_idx,
                      &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
                      &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
-                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat};
+                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom};
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn}) d->release();
@@ -286,6 +286,16 @@ int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_str
 int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && in && e->ln_count > 0);
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RLCF_OK;
+}
+int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && current && e->ln_count > 0 && momentum >= 0.0 && momentum <= 1.0);
+    int rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
+                                    update_w, apply, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    if (apply)           // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy follows
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,

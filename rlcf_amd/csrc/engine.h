@@ -103,6 +103,7 @@ struct rlcf_engine {
     DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;
     int b_cap = 0, sp_groups = 0;
     // LayerNorm-tuning path (CLIPCLS_TTA only_norm): all visual LN parameters of the student in one tunable buffer
+    DevBuf ln_clip, ln_mom;          // pristine checkpoint values / momentum state of the tunable LayerNorms (momentum_update)
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
     int ln_count = 0;                // (4*layers + 4) * Wv
     size_t bwd_elems = 0;

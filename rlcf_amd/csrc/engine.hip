@@ -260,6 +260,9 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
             *slots[i] = P + i * Wv;
         }
         RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_init.p, P, nb, hipMemcpyDeviceToDevice, st));
+        TRY(e->ln_clip.ensure(nb)); TRY(e->ln_mom.ensure(nb));       // clip_state_dict / momentum_state_dict (custom_clip.py:395-399)
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_clip.p, P, nb, hipMemcpyDeviceToDevice, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_mom.p, P, nb, hipMemcpyDeviceToDevice, st));
         std::vector<int32_t> idx(e->max_views);
         for (int i = 0; i < e->max_views; ++i) idx[i] = i * m.tokens;
         TRY(e->cls_row_idx.ensure(idx.size() * sizeof(int32_t)));

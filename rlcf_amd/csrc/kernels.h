@@ -96,3 +96,5 @@ int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipS
 size_t views_scratch_bytes(int H, int n_views, int res);
 int launch_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
                       const float* std3, float* views, void* scratch, size_t scratch_bytes, hipStream_t st);
+int launch_momentum_update(float* mom, const float* cur, const float* clip, float* init, int64_t n, double momentum, double update_w, int apply,
+                           hipStream_t st);

@@ -323,6 +323,28 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int st
     return RLCF_OK;
 }
 
+// ---------------------------------------------------------------- cross-sample momentum update (CLIPCLS_TTA.momentum_update_model)
+// mom = m*mom + (1-m)*cur; if apply: init = (1-w)*clip + w*mom   (custom_clip.py:460-475; float32, products rounded separately
+// as torch's elementwise ops do)
+__global__ void momentum_update_kernel(float* __restrict__ mom, const float* __restrict__ cur, const float* __restrict__ clip,
+                                       float* __restrict__ init, int64_t n, float m, float one_minus_m, float w, float one_minus_w, int apply) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = __fadd_rn(__fmul_rn(m, mom[i]), __fmul_rn(one_minus_m, cur[i]));
+        mom[i] = v;
+        if (apply) init[i] = __fadd_rn(__fmul_rn(one_minus_w, clip[i]), __fmul_rn(w, v));
+    }
+}
+int launch_momentum_update(float* mom, const float* cur, const float* clip, float* init, int64_t n, double momentum, double update_w, int apply,
+                           hipStream_t st) {
+    RLCF_ARG_CHECK(mom && cur && clip && init && n > 0);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    momentum_update_kernel<<<dim3(blocks), dim3(256), 0, st>>>(mom, cur, clip, init, n, (float)momentum, (float)(1.0 - momentum), (float)update_w,
+                                                               (float)(1.0 - update_w), apply);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
 // ---------------------------------------------------------------- top-5 of one logits row
 __global__ __launch_bounds__(TTA_THREADS) void top5_kernel(const float* __restrict__ x, int C, int32_t* __restrict__ top5) {
     x += (size_t)blockIdx.x * C;

@@ -156,13 +156,11 @@ class CLIPCLS_TTA(nn.Module):
         if not only_visual or not only_norm:
             raise NotImplementedError("full image-encoder / text tuning is not built yet: only only_visual=True, only_norm=True "
                                       "(SURVEY.md §8 a14)")
-        if momentum_update:
-            raise NotImplementedError("momentum_update (cross-sample EMA, custom_clip.py:460-475) is not built: it makes test "
-                                      "samples dependent (SURVEY.md §8e)")
         self.clip_model, _, _ = clip_store.load(arch, device=device)
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.prompt_prefix = device, prompt_prefix
         self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
+        self.update_freq, self.update_w, self.momentum, self.update_counter = update_freq, update_w, momentum, 0
         self._ln = None
         self._set_classnames(classnames)
 
@@ -201,8 +199,21 @@ class CLIPCLS_TTA(nn.Module):
         if self._ln is not None:
             self.reset()
 
-    def momentum_update_model(self):                       # no-op unless momentum_update (not built)
-        return
+    @torch.no_grad()
+    def momentum_update_model(self):                       # custom_clip.py:460-475
+        """EMA of the tuned LayerNorm parameters over test samples; every update_freq samples the reset state becomes
+        (1-update_w)*checkpoint + update_w*EMA.  (The frozen tensors of the visual state dict are fixed points of the EMA.)
+        Samples become order-dependent: run on one replica."""
+        if not self.momentum_update:
+            return
+        self.update_counter += 1
+        apply = self.update_counter >= self.update_freq
+        if apply:
+            self.update_counter = 0
+        eng = runtime.SESSION.engine()
+        eng.momentum_update(self.ln.data, self.momentum, self.update_w, apply)
+        if apply:
+            self._ln_init = eng.ln_params(pristine=True)
 
     @torch.no_grad()
     def forward(self, image):

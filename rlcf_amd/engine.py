@@ -196,6 +196,12 @@ class Engine:
         p = p.detach().to(self.device, torch.float32).contiguous()
         L.check(self.lib.rlcf_engine_set_ln_params(self.h, _ptr(p), _stream()), "set_ln_params")
 
+    def momentum_update(self, current: torch.Tensor, momentum: float, update_w: float, apply: bool) -> None:
+        """CLIPCLS_TTA.momentum_update_model on the tunable LayerNorm set (custom_clip.py:460-475)."""
+        cur = current.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_momentum_update(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0, _stream()),
+                "momentum_update")
+
     def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
         """LayerNorm-tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True))."""
         views = views.to(self.device, torch.float32).contiguous()

@@ -279,6 +279,50 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
+def run_reference_ln_momentum(ref, student, reward, n_views, n_cls, hp, n_samples=3, n_ctx=4):
+    """TPT/tune_cls_rl.py:206-240 over several consecutive samples with CLIPCLS_TTA(momentum_update=True): per sample reset ->
+    test_time_tuning -> clean-view logits -> momentum_update_model (custom_clip.py:460-475)."""
+    import copy
+    s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    s_sd = synth.make_state_dict(s_geo, seed=11)
+    r_sd = synth.make_state_dict(r_geo, seed=23)
+    install_models(ref, {student: (s_geo, s_sd)})
+    bank = Bank(s_geo, n_cls, n_ctx)
+    ref.custom.tokenize = bank.tokenize
+    model = ref.custom.CLIPCLS_TTA("cpu", bank.classnames, arch=student, prompt_prefix="a_photo_of_a", only_visual=True,
+                                   momentum_update=True, update_freq=hp["update_freq"], update_w=hp["update_w"],
+                                   momentum=hp["momentum"], only_norm=True)
+    names = [n for n, p in model.clip_model.visual.named_parameters() if "ln" in n or "bn" in n]
+    optimizer = torch.optim.AdamW(model.parameters(), hp["lr"], weight_decay=hp["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"], min_entropy_reg=0, min_entropy_w=0.2,
+                                 gpu=None, tpt=True)
+    install_models(ref, {reward: (r_geo, r_sd)})
+    rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True, amplify_rewards=False, sample_k=hp["sample_k"],
+                                     reward_process=True, process_batch=False)
+    rm.set_class_features(tokenized_classes=model.tokenized_prompts)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scaler = torch.cuda.amp.GradScaler(init_scale=1000)
+    out = {}
+    for i in range(n_samples):
+        views = synth.make_views(1000 + i, n_views, s_geo.image_resolution)
+        model.reset()
+        optimizer.load_state_dict(optim_state)
+        model.train()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref.tpt.test_time_tuning(model, views, optimizer, scaler, args, reward_model=rm)
+        model.eval()
+        with torch.no_grad():
+            out[f"final_logits_{i}"] = model(views[:1]).clone()
+        pmap = dict(model.clip_model.visual.named_parameters())
+        out[f"ln_after_{i}"] = torch.cat([pmap[n].detach().reshape(-1) for n in names]).clone()
+        model.momentum_update_model()
+        out[f"ln_reset_{i}"] = torch.cat([model.initial_state_dict[n].reshape(-1) for n in names]).clone()
+    return {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
 TOKENIZER_STRINGS = [
     "a photo of a tench.", "a_photo_of_a great white shark.", "a photo of a hen-of-the-woods.", "itap of a toilet tissue.",
     "a bad photo of the CD player.", "a photo of a 3D-printed #42 T-shirt's logo!", "art of the  maillot   (tank suit).",
@@ -450,6 +494,11 @@ def main():
             save("modules_rn", gen_modules_rn(ref), {})
         elif grp == "tokenizer":
             save("tokenizer", gen_tokenizer(ref), {})
+        elif grp == "lnmom":
+            hp = dict(BASE_HP, lr=1e-3, update_freq=2, update_w=0.5, momentum=0.9)
+            arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp)
+            save("ln_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
+                                                   bank_seed=7, n_ctx=4, n_samples=3, **hp))
         elif grp in ("ln", "lnb16"):
             for name in ([k for k in LN_CASES if "b16" not in k] if grp == "ln" else ["ln_b16_n8"]):
                 student, reward, n, c, over = LN_CASES[name]

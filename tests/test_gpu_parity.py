@@ -745,6 +745,47 @@ def test_cls_tta_harness_surface(L, dev):
     runtime.reset_session()
 
 
+def test_cls_tta_momentum_update_matches_reference(L, dev):
+    """TPT/tune_cls_rl.py:206-240 over three consecutive samples with CLIPCLS_TTA(momentum_update=True, update_freq=2,
+    update_w=0.5, momentum=0.9): tuned LayerNorms, the moving reset state and the clean-view logits against the reference's run."""
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime, tpt_cls_rl
+    g, meta = load_golden("ln_tiny_momentum")
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("tiny", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
+                                 min_entropy_reg=0, min_entropy_w=0.2, reward_arch="tiny-r", multiple_reward_models=0,
+                                 sample_k=meta["sample_k"], reward_amplify=False, reward_process=True, process_batch=False)
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=True, only_norm=True,
+                                    momentum_update=True, update_freq=meta["update_freq"], update_w=meta["update_w"],
+                                    momentum=meta["momentum"])
+    reward_model = clip_reward.get_reward_model(dev, args)
+    reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+    optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    for i in range(meta["n_samples"]):
+        views = synth.make_views(1000 + i, meta["n_views"], 32).to(dev)
+        model.reset()
+        optimizer.load_state_dict(optim_state)
+        model.train()
+        tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+        model.eval()
+        torch.testing.assert_close(model(views[:1]).cpu(), g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        d = (model.ln.detach().cpu() - g[f"ln_after_{i}"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+        model.momentum_update_model()
+        reset_state = runtime.SESSION.engine().ln_params(pristine=True).cpu()
+        # Adam sign flips on ~0 gradients can move single elements by 2*lr; the EMA damps them by (1-momentum)*update_w
+        torch.testing.assert_close(reset_state, g[f"ln_reset_{i}"], atol=2.5 * meta["lr"] * (1 - meta["momentum"]) * meta["update_w"], rtol=1e-6)
+    assert (reset_state - runtime.SESSION.engine().ln_params(pristine=False).cpu()).abs().max() == 0      # live copy follows the reset state
+    runtime.reset_session()
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("prec", [0, 2])
 def test_ragged_odd_sizes_vs_oracle(L, dev, mode, prec):

@@ -123,6 +123,34 @@ def test_modified_resnet_fixture():
         assert (f - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
+def test_ln_momentum_update_matches_reference():
+    """Three consecutive samples of the LayerNorm-tuning harness with CLIPCLS_TTA(momentum_update=True, update_freq=2):
+    the oracle's tuned parameters, reset states and clean-view logits against the reference's own run."""
+    g, meta = load("ln_tiny_momentum")
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    rsd = synth.make_state_dict(rg, meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    hp = R.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                    weight_decay=meta["weight_decay"])
+    keys = R.visual_ln_keys(ssd)
+    clip = torch.cat([ssd[k].reshape(-1) for k in keys])
+    mom, init, counter = clip.clone(), clip.clone(), 0
+    for i in range(meta["n_samples"]):
+        views = synth.make_views(1000 + i, meta["n_views"], sg.image_resolution)
+        o = R.tta_sample_ln(ssd, rsd, views, tokens, hp, ln_init=init)
+        d = (o["ln_after"] - g[f"ln_after_{i}"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+        torch.testing.assert_close(o["final_logits"], g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        counter += 1
+        apply = counter >= meta["update_freq"]
+        mom, new_init = R.momentum_update(mom, g[f"ln_after_{i}"], clip, meta["momentum"], meta["update_w"], apply)
+        if apply:
+            counter, init = 0, new_init
+        torch.testing.assert_close(init, g[f"ln_reset_{i}"], atol=1e-7, rtol=1e-6)
+    assert (g["ln_reset_1"] - g["ln_reset_0"]).abs().max() > 1e-5          # the reset state really moved
+
+
 def test_synth_is_deterministic():
     a = synth.normal(1, "x", (1000,))
     b = synth.normal(1, "x", (1000,))
