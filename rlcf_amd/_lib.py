@@ -78,6 +78,7 @@ SIGNATURES = {
     "rlcf_reward_class_features": (I, [P, I, P, P]),
     "rlcf_make_views_scratch_bytes": (C.c_size_t, [I, I, I]),
     "rlcf_make_views": (I, [P, I, I, P, I, I, P, P, P, P, C.c_size_t, P]),
+    "rlcf_tta_batch_ln": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_engine_momentum_update": (I, [P, P, D, D, I, P]),
     "rlcf_engine_create_ensemble": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I, I]),
     "rlcf_engine_set_reward_mix": (I, [P, P, I, I]),

@@ -207,7 +207,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->views_sel, &e->topk_idx,
                      &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
                      &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
-                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom};
+                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom, &e->b_ln, &e->b_ln_m, &e->b_ln_v, &e->b_ln_grad};
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn}) d->release();
@@ -302,6 +302,11 @@ int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const r
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
     return engine_tta_batch(e, views, count, N, args, final_logits, top5, (hipStream_t)stream);
+}
+int rlcf_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
+                      rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
+    return engine_tta_batch_ln(e, views, count, N, args, final_logits, top5, (hipStream_t)stream);
 }
 double rlcf_engine_last_flops(rlcf_engine* e) { return e ? e->last_flops : 0.0; }
 int rlcf_engine_text_rows(rlcf_engine* e) { return e ? e->lay[0].T : 0; }

@@ -103,6 +103,7 @@ struct rlcf_engine {
     DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;
     int b_cap = 0, sp_groups = 0;
     // LayerNorm-tuning path (CLIPCLS_TTA only_norm): all visual LN parameters of the student in one tunable buffer
+    DevBuf b_ln, b_ln_m, b_ln_v, b_ln_grad;   // per-sample LayerNorm sets of the batched LN-tuning path [B, ln_count]
     DevBuf ln_clip, ln_mom;          // pristine checkpoint values / momentum state of the tunable LayerNorms (momentum_update)
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
     int ln_count = 0;                // (4*layers + 4) * Wv
@@ -145,5 +146,7 @@ int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int
 int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                        hipStream_t st);
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                      hipStream_t st);

@@ -392,7 +392,8 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
 
 // dX-only backward of the above (all weights frozen: TPT/tpt_cls_rl.py:103-105); dX in/out in e->dX.
 static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_keys,
-                                long attn_pairs, int causal, int T, hipStream_t st, float* ln_grad = nullptr, int max_q_len = 0) {
+                                long attn_pairs, int causal, int T, hipStream_t st, float* ln_grad = nullptr, int max_q_len = 0,
+                                int group_rows = 0, int group_stride = 0) {
     const int W = w.width, L = w.layers;
     float *dX = e->dX.as<float>(), *dA = e->dA.as<float>(), *dH = e->dH.as<float>(), *dF = e->dF.as<float>(), *dQKV = e->dQKV.as<float>();
     for (int l = L - 1; l >= 0; --l) {
@@ -401,14 +402,14 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, GRAD_SCALE));
         TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
-        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st));
+        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride));
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96) TRY(launch_attention_bwd_long(s.qkv, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
-        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st));
+        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride));
     }
     return RLCF_OK;
 }
@@ -1003,22 +1004,104 @@ static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, 
     return RLCF_OK;
 }
 // d loss / d (visual LN parameters) given dlogits [n, C] of the n views whose activations vit_forward_saved holds.
-static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int n, const float* dlogits, float* ln_grad, hipStream_t st) {
+// groups > 1: the n views belong to `groups` test samples (n / groups consecutive views each) and ln_grad is [groups, ln_count]
+static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int n, const float* dlogits, float* ln_grad, hipStream_t st,
+                           int groups = 1) {
     const rlcf_clip_cfg& c = m.cfg;
     const int Wv = c.vision_width, tok = m.tokens, T = n * tok, D = c.embed_dim, C = e->C, L = c.vision_layers;
+    const int per = n / groups, gs = groups > 1 ? e->ln_count : 0;
     TRY(bwd_ensure(e, T, Wv));
     TRY(e->dfeat.ensure((size_t)e->max_views * D * sizeof(float))); TRY(e->dcls.ensure((size_t)e->max_views * Wv * sizeof(float)));
-    RLCF_HIP_CHECK(hipMemsetAsync(ln_grad, 0, (size_t)e->ln_count * sizeof(float), st));
+    RLCF_HIP_CHECK(hipMemsetAsync(ln_grad, 0, (size_t)groups * e->ln_count * sizeof(float), st));
     // d feat = scale * dlogits @ class_features  (logits = scale * feat @ class_features^T, custom_clip.py:429-430)
     TRY(launch_dimg(dlogits, e->txt0.as<float>(), n, C, D, m.logit_scale_exp, e->dfeat.as<float>(), st));
     TRY(launch_l2norm_bwd(feats, e->dfeat.as<float>(), e->vit_inv_norm.as<float>(), e->dfeat.as<float>(), n, D, st));
     TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
     float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
-    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), m.lnpost_w, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st));
+    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), m.lnpost_w, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st,
+                             groups > 1 ? per : 0, gs));
     RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
     TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
-    TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok));
-    TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st));
+    TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok,
+                             groups > 1 ? per * tok : 0, gs));
+    TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st,
+                                groups > 1 ? per : 0, gs));
+    return RLCF_OK;
+}
+
+// LayerNorm tuning of B test images per tower pass (one AdamW step): every sample starts from the same reset state, so the
+// selection forward, the reward pass and the saved forward of the selected views run on all B samples at once; the backward
+// keeps the LayerNorm gradients per sample (grouped reductions), AdamW updates B parameter sets, and the clean-view inference
+// runs once per sample with its own adapted LayerNorms (tune_cls_rl.py:206-227).
+static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                              hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
+    const int n_sel = (int)(N * a->selection_p), BN = B * N, BS = B * n_sel;
+    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const size_t nb = (size_t)e->ln_count * sizeof(float), np = (size_t)e->ln_count;
+    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
+    TRY(e->b_ln.ensure(B * nb)); TRY(e->b_ln_m.ensure(B * nb)); TRY(e->b_ln_v.ensure(B * nb)); TRY(e->b_ln_grad.ensure(B * nb));
+    TRY(e->b_logits.ensure((size_t)B * C * sizeof(float)));
+    e->last_flops = 0.0;
+    const float* cls_feat = e->txt0.as<float>();
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    // 1. selection on all B*N views (pristine LayerNorms), 2. reward features of the selected views
+    TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
+    TRY(engine_logits(e, e->img_feat.as<float>(), BN, cls_feat, C, e->logits.as<float>(), st));
+    TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+    TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
+    TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
+    // 3. forward with saved activations on the selected views, loss per sample, 4. backward with per-sample LayerNorm gradients
+    TRY(vit_forward_saved(e, s, e->views_sel.as<float>(), BS, e->ln_feat.as<float>(), st));
+    TRY(engine_logits(e, e->ln_feat.as<float>(), BS, cls_feat, C, e->sel_logits.as<float>(), st));
+    TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e), a->clipscore_weight, a->flags,
+                                a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr, e->dlogits.as<float>(), st));
+    TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), BS, e->dlogits.as<float>(), e->b_ln_grad.as<float>(), st, B));
+    // 5. one AdamW step per sample from the reset state
+    TRY(launch_broadcast_rows(e->ln_init.as<float>(), e->b_ln.as<float>(), (int)np, B, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_m.p, 0, B * nb, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_v.p, 0, B * nb, st));
+    TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, 1, a->lr,
+                     a->beta1, a->beta2, a->eps, a->weight_decay, st));
+    // 6. clean-view inference, one sample at a time with its adapted LayerNorms
+    float* fl = final_logits ? final_logits : e->b_logits.as<float>();
+    for (int b = 0; b < B; ++b) {
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->b_ln.as<float>() + (size_t)b * np, nb, hipMemcpyDeviceToDevice, st));
+        TRY(engine_encode_image(e, RLCF_STUDENT, views + (size_t)b * N * img_elems, 1, e->sel_feat.as<float>(), st));
+        TRY(engine_logits(e, e->sel_feat.as<float>(), 1, cls_feat, C, fl + (size_t)b * C, st));
+    }
+    TRY(launch_top5_batched(fl, B, C, top5, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    return RLCF_OK;
+}
+
+int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
+                        hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
+    RLCF_ARG_CHECK(s.tokens <= 320);
+    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const int n_sel = (int)(N * a->selection_p), Bmax = e->max_views / N;
+    const bool fused = Bmax >= 2 && a->tta_steps == 1 && !a->skip_final && n_sel > 0;
+    double flops = 0.0;
+    int i = 0;
+    while (i < count) {
+        const int B = fused ? std::min(Bmax, count - i) : 1;
+        if (fused && B >= 2) {
+            TRY(tta_batch_ln_fused(e, views + (size_t)i * per, B, N, a, final_logits ? final_logits + (size_t)i * e->C : nullptr, top5 + (size_t)i * 5, st));
+        } else {
+            rlcf_tta_out o{};
+            o.top5 = top5 + (size_t)i * 5;
+            o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
+            TRY(engine_tta_sample_ln(e, views + (size_t)i * per, N, a, &o, st));
+        }
+        flops += e->last_flops;
+        i += B;
+    }
+    e->last_flops = flops / count;
     return RLCF_OK;
 }
 

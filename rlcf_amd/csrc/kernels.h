@@ -5,7 +5,7 @@
 // LayerNorm fwd: f32 output (launch_layernorm_fwd) or a split-f16 pair for the next GEMM (launch_layernorm_fwd_split).
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
-                         float* dgamma, float* dbeta, int rows, int width, hipStream_t st);
+                         float* dgamma, float* dbeta, int rows, int width, hipStream_t st, int group_rows = 0, int group_stride = 0);
 // images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 and/or a split-f16 pair)
 int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
@@ -88,7 +88,7 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,
                               int width, int causal, float* dqkv, hipStream_t st);
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
-                            int tokens, int width, hipStream_t st);
+                            int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0);
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st);
 int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipStream_t st);
 

@@ -105,10 +105,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy, const float* __restrict__ dres,
                                                             float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int width) {
+                                                            int rows, int width, int group_rows, int group_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    if (group_rows > 0) {                // parameter gradients kept per group of rows (one test sample each)
+        const size_t go = (size_t)(row / group_rows) * group_stride;
+        if (dgamma) dgamma += go;
+        if (dbeta) dbeta += go;
+    }
     const float* xr = x + (size_t)row * width;
     const float* dr = dy + (size_t)row * width;
     float v[MAX_PER_LANE], d[MAX_PER_LANE];
@@ -160,15 +165,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                    const float* __restrict__ dy, const float* __restrict__ dres,
                                                                    float* __restrict__ dx, float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta, int rows, int width) {
+                                                                   float* __restrict__ dbeta, int rows, int width, int group_rows,
+                                                                   int group_stride) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LNB_ROWS;
     float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
 #pragma unroll
     for (int j = 0; j < MAX_PER_LANE; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    int grp = (group_rows > 0 && row0 < rows) ? row0 / group_rows : 0;
     for (int rr = 0; rr < LNB_ROWS; ++rr) {
         const int row = row0 + rr;
         if (row >= rows) break;
+        if (group_rows > 0 && row / group_rows != grp) {          // the walk crosses into the next sample: flush the partial sums
+#pragma unroll
+            for (int j = 0; j < MAX_PER_LANE; ++j) {
+                int c = j * 64 + lane;
+                if (c < width) {
+                    atomicAdd(dgamma + (size_t)grp * group_stride + c, ag[j]); atomicAdd(dbeta + (size_t)grp * group_stride + c, ab[j]);
+                    ag[j] = 0.f; ab[j] = 0.f;
+                }
+            }
+            grp = row / group_rows;
+        }
         const float* xr = x + (size_t)row * width;
         const float* dr = dy + (size_t)row * width;
         float v[MAX_PER_LANE], d[MAX_PER_LANE];
@@ -215,20 +233,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < MAX_PER_LANE; ++j) {
         int c = j * 64 + lane;
-        if (c < width && row0 < rows) { atomicAdd(dgamma + c, ag[j]); atomicAdd(dbeta + c, ab[j]); }
+        if (c < width && row0 < rows) {
+            atomicAdd(dgamma + (size_t)grp * group_stride + c, ag[j]); atomicAdd(dbeta + (size_t)grp * group_stride + c, ab[j]);
+        }
     }
 }
 
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int width, hipStream_t st) {
-    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
+                         float* dbeta, int rows, int width, hipStream_t st, int group_rows, int group_stride) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
+    if (group_rows == 0) group_stride = 0;
     if (dgamma && dbeta && rows >= 256) {
         const int per_block = ROWS_PER_BLOCK * LNB_ROWS;
-        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width);
+        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride);
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
-    layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width);
+    layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -580,11 +601,12 @@ int launch_broadcast_rows(const float* in, float* out, int n, int B, hipStream_t
 __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                                const float* __restrict__ pos, const float* __restrict__ dy,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int tokens,
-                                                               int width) {
+                                                               int width, int group_imgs, int group_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= n * tokens) return;
     const int lane = threadIdx.x & 63;
     const int b = row / tokens, tok = row % tokens;
+    if (group_imgs > 0) { dgamma += (size_t)(b / group_imgs) * group_stride; dbeta += (size_t)(b / group_imgs) * group_stride; }
     const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
     const float* pr = pos + (size_t)tok * width;
     float v[MAX_PER_LANE];
@@ -614,11 +636,11 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
     }
 }
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
-                            int tokens, int width, hipStream_t st) {
+                            int tokens, int width, hipStream_t st, int group_imgs, int group_stride) {
     RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE && n > 0);
     const int rows = n * tokens;
     vit_assemble_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, dy, dgamma, dbeta, n,
-                                                                                                   tokens, width);
+                                                                                                   tokens, width, group_imgs, group_stride);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

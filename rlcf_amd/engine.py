@@ -230,6 +230,16 @@ class Engine:
                 "tta_batch")
         return (top5, fl) if want_logits else top5
 
+    def tta_batch_ln(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):
+        """LayerNorm tuning of views [count,N,3,R,R] -> top5 [count,5] (and final logits [count,C])."""
+        views = views.to(self.device, torch.float32).contiguous()
+        count, N = views.shape[0], views.shape[1]
+        top5 = torch.empty(count, 5, dtype=torch.int32, device=self.device)
+        fl = torch.empty(count, self.n_cls, device=self.device) if want_logits else None
+        a = cfg.c_args()
+        L.check(self.lib.rlcf_tta_batch_ln(self.h, _ptr(views), count, N, C.byref(a), _ptr(fl), _ptr(top5), _stream()), "tta_batch_ln")
+        return (top5, fl) if want_logits else top5
+
     def last_flops(self) -> float:
         return float(self.lib.rlcf_engine_last_flops(self.h))
 

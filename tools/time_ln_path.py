@@ -8,7 +8,8 @@ n_cls = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda:0")
 geo = synth.GEOMETRIES[arch]
 ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)
-eng = Engine(geo, geo, 64, n_cls, L.PREC_F16X3)
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # test images per tower pass (rlcf_tta_batch_ln)
+eng = Engine(geo, geo, 64 * B, n_cls, L.PREC_F16X3)
 eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
 tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=4)
 ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
@@ -19,5 +20,12 @@ for v in views[:2]: o = eng.tta_sample_ln(v, cfg)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for v in views[2:]: o = eng.tta_sample_ln(v, cfg)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+if B > 1:
+    vs = torch.stack([synth.make_views(1000 + i, 64, geo.image_resolution, device=dev) for i in range(2 * B)])
+    eng.tta_batch_ln(vs[:B], cfg)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    top5 = eng.tta_batch_ln(vs, cfg)
+    torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / (2 * B)
+    print(f"{arch} LN-tuning, {B} images per pass: {dtb*1e3:.1f} ms/image ({1/dtb:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF")
 print(f"{arch} LN-tuning: {dt*1e3:.1f} ms/image ({1/dt:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF, "
       f"top5={o['top5'].tolist()} |ln_grad|={o['ln_grad'].norm().item():.3e} nan={bool(torch.isnan(o['final_logits']).any())}")
