@@ -344,6 +344,21 @@ static int bwd_ensure(rlcf_engine* e, int T, int width) {
 // ------------------------------------------------------------------ transformer passes
 // Transformer.forward, TPT/clip/model.py:195-203 with ResidualAttentionBlock :189-192.
 // x0: [T,W] input (ws.x, or sv[0].x when saving).  Result always lands in ws.x.
+// Per-view LayerNorm sets (batched LN-tuning inference): a tunable LayerNorm pointer is redirected into e->lng_base and the
+// kernels pick the set of the row's view; any other LayerNorm (text tower, reward models) is left alone.
+struct LnRef { const float* p; int group_rows, group_stride; };
+static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) {
+    const float* lo = e->ln_params.as<float>();
+    if (e->lng_base && lo && p >= lo && p < lo + e->ln_count) return LnRef{e->lng_base + (p - lo), view_rows, e->ln_count};
+    return LnRef{p, 0, 0};
+}
+#define LN_FWD(xp, wp, bp, yp, rows, W)                                                                                    \
+    do { const LnRef gw_ = ln_ref(e, (wp), e->lng_view_rows), gb_ = ln_ref(e, (bp), e->lng_view_rows);                      \
+         TRY(launch_layernorm_fwd((xp), gw_.p, gb_.p, (yp), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
+#define LN_FWD_SPLIT(xp, wp, bp, hh, hl, rows, W)                                                                           \
+    do { const LnRef gw_ = ln_ref(e, (wp), e->lng_view_rows), gb_ = ln_ref(e, (bp), e->lng_view_rows);                      \
+         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
+
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
                                long attn_pairs, int causal, int T, bool save, hipStream_t st) {
     const int W = w.width, L = w.layers;
@@ -353,12 +368,12 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* x = ws.x.as<float>();
         for (int l = 0; l < L; ++l) {
             const BlockW& b = w.blk[l];
-            TRY(launch_layernorm_fwd_split(x, b.ln1_w, b.ln1_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));
+            LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.hh.p, ws.hl.p, T, W);
             TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
             TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.ah.p, ws.al.p, st));
             e->last_flops += 4.0 * attn_pairs * W;
             TRY(gemm_pre(e, ws.ah.p, ws.al.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
-            TRY(launch_layernorm_fwd_split(x, b.ln2_w, b.ln2_b, nullptr, ws.hh.p, ws.hl.p, T, W, st));
+            LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.hh.p, ws.hl.p, T, W);
             TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.fh.p, ws.fl.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
             TRY(gemm_pre(e, ws.fh.p, ws.fl.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
         }
@@ -373,12 +388,12 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* a = save ? ws.sv[l].a : ws.a.as<float>();
         float* h = ws.h.as<float>();
         float* f = ws.f.as<float>();
-        TRY(launch_layernorm_fwd(xin, b.ln1_w, b.ln1_b, h, T, W, st));
+        LN_FWD(xin, b.ln1_w, b.ln1_b, h, T, W);
         TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
         TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, st));
         e->last_flops += 4.0 * attn_pairs * W;
         TRY(gemm(e, a, W, b.out_w, W, b.out_b, xin, W, nullptr, 0, x1, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_fwd(x1, b.ln2_w, b.ln2_b, h, T, W, st));
+        LN_FWD(x1, b.ln2_w, b.ln2_b, h, T, W);
         if (save) {
             TRY(gemm(e, h, W, b.fc_w, W, b.fc_b, nullptr, 0, nullptr, 0, ws.sv[l].f, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_NONE, st));
             TRY(launch_quickgelu(ws.sv[l].f, f, (int64_t)T * 4 * W, st));
@@ -439,11 +454,17 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
         TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv,
                  n * G2, Wv, m.Kp, 1.f, RLCF_EPI_NONE, st));
     }
-    TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.x.as<float>(), n, tok, Wv, st));
+    {
+        const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
+        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.x.as<float>(), n, tok, Wv, st, gw.group_stride));
+    }
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
                             false, st));
     TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
-    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), n, Wv, st));
+    {
+        const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);      // one class-token row per view
+        TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), gw.p, gb.p, e->cls_ln.as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
+    }
     TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
              RLCF_EPI_NONE, st));
     TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, nullptr, n, D, st));
@@ -1064,15 +1085,17 @@ static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, 
     RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_v.p, 0, B * nb, st));
     TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, 1, a->lr,
                      a->beta1, a->beta2, a->eps, a->weight_decay, st));
-    // 6. clean-view inference, one sample at a time with its adapted LayerNorms
+    // 6. clean-view inference of the B samples in one pass: view b reads LayerNorm set b (tune_cls_rl.py:219-221)
     float* fl = final_logits ? final_logits : e->b_logits.as<float>();
-    for (int b = 0; b < B; ++b) {
-        RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->b_ln.as<float>() + (size_t)b * np, nb, hipMemcpyDeviceToDevice, st));
-        TRY(engine_encode_image(e, RLCF_STUDENT, views + (size_t)b * N * img_elems, 1, e->sel_feat.as<float>(), st));
-        TRY(engine_logits(e, e->sel_feat.as<float>(), 1, cls_feat, C, fl + (size_t)b * C, st));
-    }
+    for (int b = 0; b < B; ++b)
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->views_sel.as<float>() + (size_t)b * img_elems, views + (size_t)b * N * img_elems,
+                                      img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+    e->lng_base = e->b_ln.as<float>(); e->lng_view_rows = s.tokens;
+    int rc = engine_encode_image(e, RLCF_STUDENT, e->views_sel.as<float>(), B, e->sel_feat.as<float>(), st);
+    e->lng_base = nullptr; e->lng_view_rows = 0;
+    TRY(rc);
+    TRY(engine_logits(e, e->sel_feat.as<float>(), B, cls_feat, C, fl, st));
     TRY(launch_top5_batched(fl, B, C, top5, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
     return RLCF_OK;
 }
 

@@ -11,10 +11,14 @@
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             _Float16* __restrict__ yh,
-                                                            _Float16* __restrict__ yl, int rows, int width) {
+                                                            _Float16* __restrict__ yl, int rows, int width, int group_rows, int group_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    if (group_rows > 0) {                // every group of rows (one test sample) has its own (gamma, beta)
+        const size_t go = (size_t)(row / group_rows) * group_stride;
+        gamma += go; beta += go;
+    }
     const float* xr = x + (size_t)row * width;
     float v[MAX_PER_LANE];
     float s = 0.f;
@@ -87,14 +91,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st) {
-    return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st);
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st, int group_rows,
+                         int group_stride) {
+    return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st, group_rows, group_stride);
 }
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
-                               hipStream_t st) {
-    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE);
+                               hipStream_t st, int group_rows, int group_stride) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
     layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
-                                                                                                   (_Float16*)yl, rows, width);
+                                                                                                   (_Float16*)yl, rows, width, group_rows,
+                                                                                                   group_rows > 0 ? group_stride : 0);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -300,11 +306,12 @@ int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, i
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ x,
-                                                           int n, int tokens, int width) {
+                                                           int n, int tokens, int width, int group_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= n * tokens) return;
     const int lane = threadIdx.x & 63;
     const int b = row / tokens, tok = row % tokens;
+    gamma += (size_t)b * group_stride; beta += (size_t)b * group_stride;      // group_stride > 0: one (gamma, beta) per image
     const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
     const float* pr = pos + (size_t)tok * width;
     float v[MAX_PER_LANE];
@@ -330,10 +337,10 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
     }
 }
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,
-                        float* x, int n, int tokens, int width, hipStream_t st) {
+                        float* x, int n, int tokens, int width, hipStream_t st, int group_stride) {
     RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE);
     const int rows = n * tokens;
-    vit_assemble_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, gamma, beta, x, n, tokens, width);
+    vit_assemble_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, gamma, beta, x, n, tokens, width, group_stride);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
