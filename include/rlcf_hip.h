@@ -96,6 +96,10 @@ int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int ma
  * (keys accumulate across query blocks / sequences).  max_keys (prefix + queries) <= 320. */
 int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys,
                        int width, int causal, float* dqkv, rlcf_stream stream);
+/* The same backward on the f32 matrix cores, any sequence length: needs the forward's output out[T,W] and log-sum-exp
+ * lse[T,H] (rlcf_attention_fwd with precision F32).  Used by the LayerNorm-tuning backward through the image tower. */
+int rlcf_attention_bwd_flash(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs,
+                             int n_seq, int max_q_len, int width, int causal, float* dqkv, rlcf_stream stream);
 
 /* Per-row entropy H = -sum softmax*log_softmax and the int(N*top) lowest-entropy rows in
  * ascending order: select_confident_samples, TPT/tpt_cls_rl.py:32-35.  idx[n_sel]. */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rlcf_gemm_f16x3": (I, [P, P, I, P, P, I, P, P, I, P, I, P, I, P, P, I, I, I, I, F, I, P]),
     "rlcf_layernorm_fwd": (I, [P, P, P, P, I, I, P]),
     "rlcf_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
+    "rlcf_attention_bwd_flash": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),
     "rlcf_attention_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "rlcf_entropy_select": (I, [P, I, I, I, P, P, P]),

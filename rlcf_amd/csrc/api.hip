@@ -76,6 +76,11 @@ int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs
     if (max_keys > 96) return launch_attention_bwd_long(qkv, dout, seqs, n_seq, max_keys, max_keys, width, causal, dqkv, (hipStream_t)stream);
     return launch_attention_bwd(qkv, dout, seqs, n_seq, max_keys, width, causal, dqkv, (hipStream_t)stream);
 }
+int rlcf_attention_bwd_flash(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
+                            int max_q_len, int width, int causal, float* dqkv, rlcf_stream stream) {
+    RLCF_ARG_CHECK(qkv && out && lse && dout && seqs && dqkv);
+    return launch_attention_bwd_mfma(qkv, out, lse, dout, seqs, n_seq, max_q_len, width, causal, dqkv, (hipStream_t)stream);
+}
 int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, rlcf_stream stream) {
     RLCF_ARG_CHECK(logits && entropy && (idx || n_sel == 0));
     return launch_entropy_select(logits, n, C, n_sel, entropy, idx, (hipStream_t)stream);

@@ -389,3 +389,162 @@ int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_se
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward (dX only) for long sequences on the f32 matrix cores (v_mfma_f32_32x32x2_f32), flash-attention style: with the
+// forward's log-sum-exp and output saved, one workgroup (4 waves) per (sequence, head, 32-query block) walks the keys in
+// chunks of 128 — wave w owns the 32-key tile w of the chunk:
+//   S = Q K^T, dP = dO V^T (two MFMA chains); P = exp(S - lse), dS = P o (dP - D) with D = rowsum(dO o O), in registers;
+//   P and dS go through LDS once to become MFMA operands: dV += P^T dO, dK += dS^T Q (atomicAdd: other query blocks and,
+//   with a shared prefix, other sequences hit the same key rows), dQ += dS K (registers, reduced over the 4 waves at the end).
+// Same contract as attention_bwd_long_kernel (which it replaces when lse / out are available): dqkv pre-zeroed, <= 320 keys not
+// required here (any length).
+#define ABM_LD 65
+#define ABM_PLD 129
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                                 const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                 const rlcf_seq* __restrict__ seqs, int width, int causal,
+                                                                 float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const rlcf_seq sq = seqs[blockIdx.y];
+    const int head = blockIdx.z, q0 = blockIdx.x * 32;
+    if (q0 >= sq.q_len) return;
+    const int nk = sq.pre_len + sq.q_len, ld = 3 * width, H = width / HEAD_DIM, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
+    float* Qs = sm;                          // [32][65]  Q / 8
+    float* Gs = Qs + 32 * ABM_LD;            // [32][65]  dO
+    float* Kc = Gs + 32 * ABM_LD;            // [128][65]
+    float* Vc = Kc + 128 * ABM_LD;           // [128][65]
+    float* Pt = Vc + 128 * ABM_LD;           // [32][129] P
+    float* St = Pt + 32 * ABM_PLD;           // [32][129] dS
+    float* Ls = St + 32 * ABM_PLD;           // [32] lse
+    float* Dr = Ls + 32;                     // [32] D
+    for (int idx = t; idx < 32 * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63, qi = q0 + i;
+        const bool ok = qi < sq.q_len;
+        Qs[i * ABM_LD + d] = ok ? qkv[(size_t)(sq.q_start + qi) * ld + head * HEAD_DIM + d] * 0.125f : 0.f;
+        Gs[i * ABM_LD + d] = ok ? dout[(size_t)(sq.q_start + qi) * width + head * HEAD_DIM + d] : 0.f;
+    }
+    if (t < 32) {
+        const int qi = q0 + t;
+        float D = 0.f, l = 0.f;
+        if (qi < sq.q_len) {
+            const float* o = out + (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
+            const float* g = dout + (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
+            for (int d = 0; d < 64; ++d) D += o[d] * g[d];
+            l = lse[(size_t)(sq.q_start + qi) * H + head];
+        }
+        Dr[t] = D; Ls[t] = l;
+    }
+    f32x16 dq0, dq1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+    for (int kc = 0; kc < nk; kc += 128) {
+        __syncthreads();
+        for (int idx = t; idx < 128 * 64; idx += 256) {
+            const int j = idx >> 6, d = idx & 63, kap = kc + j;
+            float kv = 0.f, vv = 0.f;
+            if (kap < nk) {
+                const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                const float* p = qkv + (size_t)row * ld + head * HEAD_DIM + d;
+                kv = p[width]; vv = p[2 * width];
+            }
+            Kc[j * ABM_LD + d] = kv; Vc[j * ABM_LD + d] = vv;
+        }
+        __syncthreads();
+        const int kt = kc + 32 * wave;                    // this wave's 32 keys
+        const bool live = kt < nk;                        // (wave-uniform)
+        if (live) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const float* kq = Kc + (32 * wave + l32) * ABM_LD + h;
+            const float* vq = Vc + (32 * wave + l32) * ABM_LD + h;
+            const float* qq = Qs + l32 * ABM_LD + h;
+            const float* gq = Gs + l32 * ABM_LD + h;
+#pragma unroll 8
+            for (int st = 0; st < 32; ++st) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qq[2 * st], kq[2 * st], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gq[2 * st], vq[2 * st], pacc, 0, 0, 0);
+            }
+            const int key = kt + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, h);
+                const bool ok = key < nk && q0 + row < sq.q_len && (!causal || key <= sq.pre_len + q0 + row);
+                const float p = ok ? expf(sacc[r] - Ls[row]) : 0.f;
+                Pt[row * ABM_PLD + 32 * wave + l32] = p;
+                St[row * ABM_PLD + 32 * wave + l32] = p * (pacc[r] - Dr[row]);
+            }
+        }
+        __syncthreads();
+        if (live) {
+            // dV / dK tiles [32 keys x 32 d] x 2 (contraction over the 32 queries), dQ partial [32 q x 32 d] x 2 (over these 32 keys)
+            f32x16 dv0, dv1, dk0, dk1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv0[r] = 0.f; dv1[r] = 0.f; dk0[r] = 0.f; dk1[r] = 0.f; }
+            const float* pa = Pt + h * ABM_PLD + 32 * wave + l32;          // A[m = key][k = q]
+            const float* sa = St + h * ABM_PLD + 32 * wave + l32;
+            const float* gb = Gs + h * ABM_LD + l32;                       // B[k = q][n = d]
+            const float* qb = Qs + h * ABM_LD + l32;
+#pragma unroll 8
+            for (int st = 0; st < 16; ++st) {
+                const float pv = pa[2 * st * ABM_PLD], sv = sa[2 * st * ABM_PLD];
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, gb[2 * st * ABM_LD], dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, gb[2 * st * ABM_LD + 32], dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, qb[2 * st * ABM_LD], dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, qb[2 * st * ABM_LD + 32], dk1, 0, 0, 0);
+            }
+            const float* sq_a = St + l32 * ABM_PLD + 32 * wave + h;        // A[m = q][k = key]
+            const float* kb = Kc + (32 * wave + h) * ABM_LD + l32;         // B[k = key][n = d]
+#pragma unroll 8
+            for (int st = 0; st < 16; ++st) {
+                const float a = sq_a[2 * st];
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kb[2 * st * ABM_LD], dq0, 0, 0, 0);
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, kb[2 * st * ABM_LD + 32], dq1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kap = kt + mfma32_row(r, h);
+                if (kap < nk) {
+                    const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                    float* base = dqkv + (size_t)row * ld + head * HEAD_DIM + l32;
+                    atomicAdd(base + 2 * width, dv0[r]); atomicAdd(base + 2 * width + 32, dv1[r]);
+                    atomicAdd(base + width, dk0[r]);     atomicAdd(base + width + 32, dk1[r]);
+                }
+            }
+        }
+    }
+    // dQ: sum of the four waves' partials (through the K chunk buffer), scaled by 1/8
+    __syncthreads();
+    float* red = Kc + wave * (32 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[mfma32_row(r, h) * 64 + l32] = dq0[r];
+        red[mfma32_row(r, h) * 64 + 32 + l32] = dq1[r];
+    }
+    __syncthreads();
+    for (int idx = t; idx < 32 * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63;
+        if (q0 + i < sq.q_len) {
+            const float v = (Kc[idx] + Kc[2048 + idx]) + (Kc[4096 + idx] + Kc[6144 + idx]);
+            dqkv[(size_t)(sq.q_start + q0 + i) * ld + head * HEAD_DIM + d] = v * 0.125f;
+        }
+    }
+}
+
+int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
+                              int max_q_len, int width, int causal, float* dqkv, hipStream_t st) {
+    RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_q_len > 0 && qkv && out && lse && dout && dqkv);
+    const size_t bytes = (size_t)(2 * 32 * ABM_LD + 2 * 128 * ABM_LD + 2 * 32 * ABM_PLD + 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
+    RLCF_ARG_CHECK(grid.y <= 65535);
+    attention_bwd_mfma_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, seqs, width, causal, dqkv);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

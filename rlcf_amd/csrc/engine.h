@@ -32,7 +32,7 @@ struct TextLayout {                  // packed token matrix of a class bank
     double mean_len = 0;             // mean class_len
 };
 
-struct SavedLayer { float *x, *qkv, *a, *x1, *f; };
+struct SavedLayer { float *x, *qkv, *a, *x1, *f, *lse; };      // lse [T, heads]: log-sum-exp of the attention rows (MFMA backward)
 
 struct Tower {                       // workspace of one transformer pass over T rows
     int T = 0, width = 0;

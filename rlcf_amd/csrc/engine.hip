@@ -317,7 +317,8 @@ static int tower_ensure(Tower& t, int T, int width) {
 static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
     if (T <= t.saved_T && layers <= t.saved_layers && (int)t.sv.size() == layers) return RLCF_OK;
     const size_t per = (size_t)T * width;               // floats
-    const size_t per_layer = per * (1 + 3 + 1 + 1 + 4);
+    const size_t per_lse = (size_t)T * (width / HEAD_DIM);
+    const size_t per_layer = per * (1 + 3 + 1 + 1 + 4) + per_lse;
     TRY(t.saved.ensure(per_layer * layers * sizeof(float)));
     RLCF_HIP_CHECK(hipMemset(t.saved.p, 0, per_layer * layers * sizeof(float)));
     t.sv.resize(layers);
@@ -328,6 +329,7 @@ static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
         t.sv[l].a = p; p += per;
         t.sv[l].x1 = p; p += per;
         t.sv[l].f = p; p += 4 * per;
+        t.sv[l].lse = p; p += per_lse;
     }
     t.saved_T = T; t.saved_layers = layers;
     return RLCF_OK;
@@ -390,7 +392,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* f = ws.f.as<float>();
         LN_FWD(xin, b.ln1_w, b.ln1_b, h, T, W);
         TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, st));
+        TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, save ? ws.sv[l].lse : nullptr, st));
         e->last_flops += 4.0 * attn_pairs * W;
         TRY(gemm(e, a, W, b.out_w, W, b.out_b, xin, W, nullptr, 0, x1, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
         LN_FWD(x1, b.ln2_w, b.ln2_b, h, T, W);
@@ -420,7 +422,7 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride));
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
-        if (max_keys > 96) TRY(launch_attention_bwd_long(s.qkv, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, max_keys, W, causal, dQKV, st));
+        if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
