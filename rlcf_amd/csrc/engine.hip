@@ -317,7 +317,7 @@ static int tower_ensure(Tower& t, int T, int width) {
 static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
     if (T <= t.saved_T && layers <= t.saved_layers && (int)t.sv.size() == layers) return RLCF_OK;
     const size_t per = (size_t)T * width;               // floats
-    const size_t per_lse = (size_t)T * (width / HEAD_DIM);
+    const size_t per_lse = ((size_t)T * (width / HEAD_DIM) + 63) / 64 * 64;     // keeps the following layers 256-B aligned
     const size_t per_layer = per * (1 + 3 + 1 + 1 + 4) + per_lse;
     TRY(t.saved.ensure(per_layer * layers * sizeof(float)));
     RLCF_HIP_CHECK(hipMemset(t.saved.p, 0, per_layer * layers * sizeof(float)));

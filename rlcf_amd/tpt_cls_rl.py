@@ -84,8 +84,47 @@ def accuracy(output, target, topk=(1,)):
         return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]
 
 
-def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None):
-    """TPT/tpt_cls_rl.py:219-279: per test image: reset -> tune -> clean-view inference -> top-1/top-5."""
+def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass):
+    """Throughput form of the harness: test images are independent units (per-sample reset, tpt_cls_rl.py:251-255), so
+    `images_per_pass` of them share every tower pass inside the engine (rlcf_tta_batch / rlcf_tta_batch_ln); same predictions."""
+    cfg = _config(args, optimizer, reward_model)
+    prompt = hasattr(model, "prompt_learner")
+    n, s1, s5, buf, tgt = 0, 0.0, 0.0, [], []
+
+    def flush():
+        nonlocal n, s1, s5, buf, tgt
+        if not buf:
+            return
+        views = torch.stack(buf)
+        eng = runtime.SESSION.engine(views.shape[0] * views.shape[1])
+        top5 = (eng.tta_batch if prompt else eng.tta_batch_ln)(views, cfg).long()
+        t = torch.stack(tgt).view(-1, 1).to(top5.device)
+        s1 += float((top5[:, :1] == t).any(1).float().sum()) * 100.0
+        s5 += float((top5 == t).any(1).float().sum()) * 100.0
+        n += len(buf)
+        buf, tgt = [], []
+
+    for images, target in val_loader:
+        if isinstance(images, list):
+            images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
+        else:
+            images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
+        buf.append(images)
+        tgt.append(target.reshape(-1)[0])
+        if len(buf) == images_per_pass:
+            flush()
+    flush()
+    return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
+
+
+def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1):
+    """TPT/tpt_cls_rl.py:219-279: per test image: reset -> tune -> clean-view inference -> top-1/top-5.
+    `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once."""
+    if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False):
+        model.eval()
+        with torch.no_grad():
+            model.reset()
+        return _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass)
     n, s1, s5 = 0, 0.0, 0.0
     model.eval()
     with torch.no_grad():

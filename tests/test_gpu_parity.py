@@ -651,6 +651,22 @@ def test_reference_harness_runs_on_the_hip_path(L, dev, name):
     runtime.reset_session()
 
 
+def test_harness_images_per_pass(L, dev):
+    """test_time_adapt_eval(images_per_pass=B): B test images per engine call give the accuracy of the one-by-one loop."""
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden("tta_tiny_s1")
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    samples = [synth.make_views(1000 + i, meta["n_views"], R) for i in range(5)]
+    res = {}
+    for ipp in (1, 3):
+        model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+        # targets: the reference's own prediction for sample 0, class 0 for the others (so that both top-1 and top-5 counts vary)
+        loader = [([v.unsqueeze(0) for v in s], torch.tensor([int(g["top5"][0]) if i == 0 else 0])) for i, s in enumerate(samples)]
+        res[ipp] = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model, images_per_pass=ipp)
+        runtime.reset_session()
+    assert res[1] == res[3] and res[1][0] >= 20.0
+
+
 @pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_ens"])
 def test_autograd_route_matches_reference_gradient(L, dev, name):
     """model(images) is differentiable w.r.t. ctx exactly like the reference module: an unmodified copy of the
