@@ -245,9 +245,9 @@ int rlcf_tta_batch(rlcf_engine*, const float* views, int count, int N, const rlc
                    float* final_logits, int32_t* top5, rlcf_stream stream);
 
 /* bookkeeping for bench/roofline: FLOPs actually executed by the last rlcf_tta_sample. */
-/* The LayerNorm-tuning step (rlcf_tta_sample_ln) for `count` consecutive samples, B = max_views / N of them per tower pass when
- * tta_steps == 1 (every sample starts from the same reset state; LayerNorm gradients, AdamW state and the clean-view inference
- * stay per sample).  Not combinable with rlcf_engine_momentum_update between the samples of one call. */
+/* The LayerNorm-tuning step (rlcf_tta_sample_ln) for `count` consecutive samples, B = max_views / N of them per tower pass
+ * (every sample starts from the same reset state; LayerNorm parameters, their gradients, the AdamW state and the clean-view
+ * inference stay per sample: row groups of the token matrix read their own (gamma, beta) sets).  Not combinable with rlcf_engine_momentum_update between the samples of one call. */
 int rlcf_tta_batch_ln(rlcf_engine*, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                       rlcf_stream stream);
 double rlcf_engine_last_flops(rlcf_engine*);

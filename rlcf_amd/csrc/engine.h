@@ -104,7 +104,7 @@ struct rlcf_engine {
     int b_cap = 0, sp_groups = 0;
     // LayerNorm-tuning path (CLIPCLS_TTA only_norm): all visual LN parameters of the student in one tunable buffer
     const float* lng_base = nullptr;  // when set: per-view LayerNorm sets [views, ln_count] override the student's tunable LayerNorms
-    int lng_view_rows = 0;           // rows of one view in the pass that uses them
+    int lng_views = 1;               // consecutive views that share one set (1: per view; n_sel: per test sample)
     DevBuf b_ln, b_ln_m, b_ln_v, b_ln_grad;   // per-sample LayerNorm sets of the batched LN-tuning path [B, ln_count]
     DevBuf ln_clip, ln_mom;          // pristine checkpoint values / momentum state of the tunable LayerNorms (momentum_update)
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;

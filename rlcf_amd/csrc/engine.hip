@@ -349,21 +349,22 @@ static int bwd_ensure(rlcf_engine* e, int T, int width) {
 // Per-view LayerNorm sets (batched LN-tuning inference): a tunable LayerNorm pointer is redirected into e->lng_base and the
 // kernels pick the set of the row's view; any other LayerNorm (text tower, reward models) is left alone.
 struct LnRef { const float* p; int group_rows, group_stride; };
-static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) {
+static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) {      // view_rows: rows one view has in this matrix
     const float* lo = e->ln_params.as<float>();
-    if (e->lng_base && lo && p >= lo && p < lo + e->ln_count) return LnRef{e->lng_base + (p - lo), view_rows, e->ln_count};
+    if (e->lng_base && lo && p >= lo && p < lo + e->ln_count) return LnRef{e->lng_base + (p - lo), view_rows * e->lng_views, e->ln_count};
     return LnRef{p, 0, 0};
 }
 #define LN_FWD(xp, wp, bp, yp, rows, W)                                                                                    \
-    do { const LnRef gw_ = ln_ref(e, (wp), e->lng_view_rows), gb_ = ln_ref(e, (bp), e->lng_view_rows);                      \
+    do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
          TRY(launch_layernorm_fwd((xp), gw_.p, gb_.p, (yp), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
 #define LN_FWD_SPLIT(xp, wp, bp, hh, hl, rows, W)                                                                           \
-    do { const LnRef gw_ = ln_ref(e, (wp), e->lng_view_rows), gb_ = ln_ref(e, (bp), e->lng_view_rows);                      \
+    do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
          TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
 
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
                                long attn_pairs, int causal, int T, bool save, hipStream_t st) {
     const int W = w.width, L = w.layers;
+    const int ln_view_rows = max_q_len;          // (per-view LayerNorm sets only exist for the image tower: one sequence per view)
     if (e->precision == RLCF_PREC_F16X3 && !save && T > 512 && W % 32 == 0) {
         // split-f16 pipeline: LN, attention and the QuickGELU epilogue emit (hi, lo) f16 pairs for the next GEMM
         TRY(x3_ensure(ws, T, W));
@@ -419,14 +420,17 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, GRAD_SCALE));
         TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
-        TRY(launch_layernorm_bwd(s.x1, b.ln2_w, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride));
+        const LnRef g2w = ln_ref(e, b.ln2_w, 1), g1w = ln_ref(e, b.ln1_w, 1);       // per-sample LayerNorm sets (batched LN tuning, step > 0)
+        TRY(launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride,
+                                 group_rows > 0 ? g2w.group_stride : 0));
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
-        TRY(launch_layernorm_bwd(s.x, b.ln1_w, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride));
+        TRY(launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
+                                 group_rows > 0 ? g1w.group_stride : 0));
     }
     return RLCF_OK;
 }
@@ -458,7 +462,7 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     }
     {
         const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
-        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.x.as<float>(), n, tok, Wv, st, gw.group_stride));
+        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.x.as<float>(), n, tok, Wv, st, gw.group_rows, gw.group_stride));
     }
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
                             false, st));
@@ -1017,10 +1021,16 @@ static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, 
     TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
     TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv, n * G2, Wv, m.Kp,
              1.f, RLCF_EPI_NONE, st));
-    TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, m.lnpre_w, m.lnpre_b, e->vt.sv[0].x, n, tok, Wv, st));
+    {
+        const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
+        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.sv[0].x, n, tok, Wv, st, gw.group_rows, gw.group_stride));
+    }
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, true, st));
     TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
-    TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), m.lnpost_w, m.lnpost_b, e->cls_ln.as<float>(), n, Wv, st));
+    {
+        const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);
+        TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), gw.p, gb.p, e->cls_ln.as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
+    }
     TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
              RLCF_EPI_NONE, st));
     TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));
@@ -1041,8 +1051,9 @@ static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int
     TRY(launch_l2norm_bwd(feats, e->dfeat.as<float>(), e->vit_inv_norm.as<float>(), e->dfeat.as<float>(), n, D, st));
     TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
     float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
-    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), m.lnpost_w, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st,
-                             groups > 1 ? per : 0, gs));
+    const LnRef gpw = ln_ref(e, m.lnpost_w, 1);
+    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), gpw.p, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st,
+                             groups > 1 ? per : 0, gs, groups > 1 ? gpw.group_stride : 0));
     RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
     TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
     TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok,
@@ -1075,26 +1086,33 @@ static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, 
     TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
     TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
     TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
-    // 3. forward with saved activations on the selected views, loss per sample, 4. backward with per-sample LayerNorm gradients
-    TRY(vit_forward_saved(e, s, e->views_sel.as<float>(), BS, e->ln_feat.as<float>(), st));
-    TRY(engine_logits(e, e->ln_feat.as<float>(), BS, cls_feat, C, e->sel_logits.as<float>(), st));
-    TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e), a->clipscore_weight, a->flags,
-                                a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr, e->dlogits.as<float>(), st));
-    TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), BS, e->dlogits.as<float>(), e->b_ln_grad.as<float>(), st, B));
-    // 5. one AdamW step per sample from the reset state
+    // reset state of every sample (custom_clip.py:456-458 + optimizer.load_state_dict)
     TRY(launch_broadcast_rows(e->ln_init.as<float>(), e->b_ln.as<float>(), (int)np, B, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_m.p, 0, B * nb, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_v.p, 0, B * nb, st));
-    TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, 1, a->lr,
-                     a->beta1, a->beta2, a->eps, a->weight_decay, st));
+    for (int j = 0; j < a->tta_steps; ++j) {
+        // 3. forward with saved activations on the selected views (each sample under its own LayerNorms), loss per sample,
+        // 4. backward with per-sample LayerNorm gradients, 5. AdamW step j+1 of every sample
+        e->lng_base = e->b_ln.as<float>(); e->lng_views = n_sel;
+        int rc = vit_forward_saved(e, s, e->views_sel.as<float>(), BS, e->ln_feat.as<float>(), st);
+        if (rc == RLCF_OK) rc = engine_logits(e, e->ln_feat.as<float>(), BS, cls_feat, C, e->sel_logits.as<float>(), st);
+        if (rc == RLCF_OK) rc = launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e), a->clipscore_weight,
+                                                        a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
+                                                        e->dlogits.as<float>(), st);
+        if (rc == RLCF_OK) rc = vit_backward_ln(e, s, e->ln_feat.as<float>(), BS, e->dlogits.as<float>(), e->b_ln_grad.as<float>(), st, B);
+        e->lng_base = nullptr; e->lng_views = 1;
+        TRY(rc);
+        TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, j + 1,
+                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+    }
     // 6. clean-view inference of the B samples in one pass: view b reads LayerNorm set b (tune_cls_rl.py:219-221)
     float* fl = final_logits ? final_logits : e->b_logits.as<float>();
     for (int b = 0; b < B; ++b)
         RLCF_HIP_CHECK(hipMemcpyAsync(e->views_sel.as<float>() + (size_t)b * img_elems, views + (size_t)b * N * img_elems,
                                       img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
-    e->lng_base = e->b_ln.as<float>(); e->lng_view_rows = s.tokens;
+    e->lng_base = e->b_ln.as<float>(); e->lng_views = 1;
     int rc = engine_encode_image(e, RLCF_STUDENT, e->views_sel.as<float>(), B, e->sel_feat.as<float>(), st);
-    e->lng_base = nullptr; e->lng_view_rows = 0;
+    e->lng_base = nullptr;
     TRY(rc);
     TRY(engine_logits(e, e->sel_feat.as<float>(), B, cls_feat, C, fl, st));
     TRY(launch_top5_batched(fl, B, C, top5, st));
@@ -1110,7 +1128,7 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const int n_sel = (int)(N * a->selection_p), Bmax = e->max_views / N;
-    const bool fused = Bmax >= 2 && a->tta_steps == 1 && !a->skip_final && n_sel > 0;
+    const bool fused = Bmax >= 2 && a->tta_steps >= 1 && !a->skip_final && n_sel > 0;
     double flops = 0.0;
     int i = 0;
     while (i < count) {

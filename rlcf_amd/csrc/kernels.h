@@ -6,14 +6,15 @@
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st,
                          int group_rows = 0, int group_stride = 0);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
-                         float* dgamma, float* dbeta, int rows, int width, hipStream_t st, int group_rows = 0, int group_stride = 0);
+                         float* dgamma, float* dbeta, int rows, int width, hipStream_t st, int group_rows = 0, int group_stride = 0,
+                         int gamma_stride = 0);
 // images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 and/or a split-f16 pair)
 int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st, int group_rows = 0, int group_stride = 0);
 // x[n,1+G*G,W] = ln_pre([cls | patch_out] + pos)
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma,
-                        const float* beta, float* x, int n, int tokens, int width, hipStream_t st, int group_stride = 0);
+                        const float* beta, float* x, int n, int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0);
 // X[r] = E[r] + (ctx_row[r] >= 0 ? ctx[ctx_row[r]] : 0)
 int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
                          int width, int rep_rows, int ctx_stride, hipStream_t st);

@@ -111,14 +111,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy, const float* __restrict__ dres,
                                                             float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int width, int group_rows, int group_stride) {
+                                                            int rows, int width, int group_rows, int group_stride, int gamma_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    if (group_rows > 0) {                // parameter gradients kept per group of rows (one test sample each)
+    if (group_rows > 0) {                // parameter gradients (and, with gamma_stride, the parameters) kept per group of rows
         const size_t go = (size_t)(row / group_rows) * group_stride;
         if (dgamma) dgamma += go;
         if (dbeta) dbeta += go;
+        gamma += (size_t)(row / group_rows) * gamma_stride;
     }
     const float* xr = x + (size_t)row * width;
     const float* dr = dy + (size_t)row * width;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
                                                                    const float* __restrict__ dy, const float* __restrict__ dres,
                                                                    float* __restrict__ dx, float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta, int rows, int width, int group_rows,
-                                                                   int group_stride) {
+                                                                   int group_stride, int gamma_stride) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LNB_ROWS;
     float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
             int c = j * 64 + lane;
             if (c < width) {
                 float xh = (v[j] - mu) * rstd;
-                float gd = d[j] * gamma[c];
+                float gd = d[j] * gamma[(group_rows > 0 ? (size_t)(row / group_rows) * gamma_stride : 0) + c];
                 ag[j] += d[j] * xh; ab[j] += d[j];
                 v[j] = xh; d[j] = gd;
                 s1 += gd; s2 += gd * xh;
@@ -246,16 +247,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
 }
 
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int width, hipStream_t st, int group_rows, int group_stride) {
+                         float* dbeta, int rows, int width, hipStream_t st, int group_rows, int group_stride, int gamma_stride) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
-    if (group_rows == 0) group_stride = 0;
+    if (group_rows == 0) { group_stride = 0; gamma_stride = 0; }
     if (dgamma && dbeta && rows >= 256) {
         const int per_block = ROWS_PER_BLOCK * LNB_ROWS;
-        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride);
+        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride, gamma_stride);
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
-    layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride);
+    layernorm_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride, gamma_stride);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -306,12 +307,12 @@ int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, i
 __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ x,
-                                                           int n, int tokens, int width, int group_stride) {
+                                                           int n, int tokens, int width, int group_imgs, int group_stride) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= n * tokens) return;
     const int lane = threadIdx.x & 63;
     const int b = row / tokens, tok = row % tokens;
-    gamma += (size_t)b * group_stride; beta += (size_t)b * group_stride;      // group_stride > 0: one (gamma, beta) per image
+    if (group_imgs > 0) { gamma += (size_t)(b / group_imgs) * group_stride; beta += (size_t)(b / group_imgs) * group_stride; }
     const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
     const float* pr = pos + (size_t)tok * width;
     float v[MAX_PER_LANE];
@@ -337,10 +338,10 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
     }
 }
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma, const float* beta,
-                        float* x, int n, int tokens, int width, hipStream_t st, int group_stride) {
+                        float* x, int n, int tokens, int width, hipStream_t st, int group_imgs, int group_stride) {
     RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE);
     const int rows = n * tokens;
-    vit_assemble_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, gamma, beta, x, n, tokens, width, group_stride);
+    vit_assemble_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, gamma, beta, x, n, tokens, width, group_imgs, group_stride);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
