@@ -14,7 +14,8 @@ eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.fin
 tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=4)
 ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
 eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
-cfg = TTAConfig(selection_p=0.1, tta_steps=1, sample_k=3, lr=1e-5, weight_decay=5e-4)
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+cfg = TTAConfig(selection_p=0.1, tta_steps=steps, sample_k=3, lr=1e-5, weight_decay=5e-4)
 views = [synth.make_views(1000 + i, 64, geo.image_resolution, device=dev) for i in range(6)]
 for v in views[:2]: o = eng.tta_sample_ln(v, cfg)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -26,6 +27,6 @@ if B > 1:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     top5 = eng.tta_batch_ln(vs, cfg)
     torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / (2 * B)
-    print(f"{arch} LN-tuning, {B} images per pass: {dtb*1e3:.1f} ms/image ({1/dtb:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF")
+    print(f"{arch} LN-tuning, {steps} step(s), {B} images per pass: {dtb*1e3:.1f} ms/image ({1/dtb:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF")
 print(f"{arch} LN-tuning: {dt*1e3:.1f} ms/image ({1/dt:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF, "
       f"top5={o['top5'].tolist()} |ln_grad|={o['ln_grad'].norm().item():.3e} nan={bool(torch.isnan(o['final_logits']).any())}")
