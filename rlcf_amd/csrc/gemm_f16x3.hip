@@ -384,7 +384,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
 
 // ------------------------------------------------------------------------------------------
 // v3: 256x256 block tile, 8 waves (2x4) of 128x64 (8 MFMA tiles = 128 accumulator registers), BK = 32, DMA into a
-// 2-stage LDS ring (64 KB per stage: 512 operand rows x 64 B x {hi, lo}).  Two thirds of v2's DMA bytes and three
+// 2-stage LDS ring (64 KB per stage: 512 operand rows x 64 B x {hi, lo}); the two row groups of waves run the K loop half an
+// iteration apart (ping-pong, see the loop).  Two thirds of v2's DMA bytes and three
 // quarters of its LDS operand reads per MFMA — the resources the round-1 ablations identified as the limiter.
 #define V3_BM 256
 #define V3_BN 256
@@ -455,26 +456,76 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     }
     const int swz = (l32 >> 2) & 3;
     const int aoff = (wm * 128 + l32) * 64, boff = (wn * 64 + l32) * 64;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile kt have landed
-        __builtin_amdgcn_s_barrier();                             // ... everybody's have, and tile kt-1's buffer is free
-        __builtin_amdgcn_sched_barrier(0);
-        const bool pf = kt + 1 < nk;
-        const int kn = (kt + 1) * g.kstep;
-        char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
-        const char* sb = smem + (kt & 1) * V3_STAGE;
-        h16x8 ah0[4], al0[4], bh0[2], bl0[2], ah1[4], al1[4], bh1[2], bl1[2];
-        V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
-        V2_FENCE
+    // Ping-pong: the two waves of a SIMD belong to the row groups wm = 0 / 1, which run the same K loop half an iteration apart.
+    // Two barriers per K tile (g = 2kt: tile kt has landed; g = 2kt+1); in every interval one group is in its pure-MFMA half
+    // (second k-substep, fragments already in registers) while the other waits for its first fragments, so the matrix pipe always
+    // has work.  Both groups issue their DMA pieces of tile kt+1 in the interval [2kt, 2kt+1].
+    h16x8 ah0[4], al0[4], bh0[2], bl0[2], ah1[4], al1[4], bh1[2], bl1[2];
+    if (wm == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = kt + 1 < nk;
+            const int kn = (kt + 1) * g.kstep;
+            char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
+            const char* sb = smem + (kt & 1) * V3_STAGE;
+            V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
+            V2_FENCE
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
-                if (pf) V3_PIECE(i * 2 + j, kn, sn)
-                if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
-                V2_FENCE
+                for (int j = 0; j < 2; ++j) {
+                    V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
+                    if (pf) V3_PIECE(i * 2 + j, kn, sn)
+                    if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
+                    V2_FENCE
+                }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
+        }
+        __builtin_amdgcn_s_barrier();                              // pairs with the other group's last half step
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = kt + 1 < nk;
+            const int kn = (kt + 1) * g.kstep;
+            char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
+            const char* sb = smem + (kt & 1) * V3_STAGE;
+            if (kt > 0) {                                          // second k-substep of tile kt-1 + the DMA of tile kt+1
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE
+                        if (pf) V3_PIECE(i * 2 + j, kn, sn)
+                        V2_FENCE
+                    }
+            } else if (pf) {
+#pragma unroll
+                for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, kn, sn)
             }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
+            V2_FENCE
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
+                    if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
+                    V2_FENCE
+                }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
