@@ -82,7 +82,8 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("RLCF_FORCE_DIST"))     # RLCF_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         import torch.distributed as dist
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -115,17 +116,17 @@ def main():
     if a.warmup:
         eng.tta_batch(views[: a.warmup], cfg)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     top5 = eng.tta_batch(views[a.warmup:], cfg)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev if a.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,7 +180,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo)
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
