@@ -344,6 +344,7 @@ LN_CASES = {
     "ln_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3)),
     "ln_small_s1": ("small", "small", 16, 40, dict(lr=1e-3, selection_p=0.25)),
     "ln_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-4)),
+    "ln_l14_n8": ("ViT-L/14", "ViT-L/14", 8, 1000, dict(lr=1e-4)),          # BASELINE configs[2] geometry (N=8)
 }
 
 
@@ -499,8 +500,8 @@ def main():
             arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp)
             save("ln_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
                                                    bank_seed=7, n_ctx=4, n_samples=3, **hp))
-        elif grp in ("ln", "lnb16"):
-            for name in ([k for k in LN_CASES if "b16" not in k] if grp == "ln" else ["ln_b16_n8"]):
+        elif grp in ("ln", "lnb16", "lnl14"):
+            for name in ([k for k in LN_CASES if "b16" not in k and "l14" not in k] if grp == "ln" else ["ln_b16_n8"] if grp == "lnb16" else ["ln_l14_n8"]):
                 student, reward, n, c, over = LN_CASES[name]
                 hp = dict(BASE_HP, **over)
                 arrays = run_reference_ln(ref, student, reward, n, c, hp)
