@@ -360,6 +360,7 @@ ENSEMBLE_NAMES = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]      # CONFIDECES 10
 
 BASE_HP = dict(lr=7e-3, weight_decay=5e-4, sample_k=3, tta_steps=1, selection_p=0.5)
 
+B16L14_SEED = int(os.environ.get("B16L14_SEED", "1000"))
 RN_SEED = int(os.environ.get("RN_SEED", "1000"))
 ENS_SEED = int(os.environ.get("ENS_SEED", "1000"))
 TTA_CASES = {
@@ -383,6 +384,8 @@ TTA_CASES = {
     "tta_tiny_rnreward": ("tiny", "tiny-rn", 8, 16, dict(view_seed=RN_SEED)),
     "tta_tiny_rnstudent": ("tiny-rn32", "tiny-r", 8, 16, dict(view_seed=RN_SEED)),
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
+    # the setting of TPT/scripts/rlcf-prompt.sh: ViT-B/16 student, ViT-L/14 reward model, 3 tuning steps
+    "tta_b16_rl14_s3": ("ViT-B/16", "ViT-L/14", 8, 1000, dict(tta_steps=3, view_seed=B16L14_SEED)),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
@@ -393,6 +396,7 @@ GROUPS = {
     "ens": ["tta_tiny_ens", "tta_tiny_ensmean"],
     "small": ["tta_small_s1"],
     "b16n8": ["tta_b16_n8"],
+    "b16l14": ["tta_b16_rl14_s3"],
     "b16n64": ["tta_b16_n64"],
 }
 

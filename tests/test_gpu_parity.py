@@ -545,17 +545,19 @@ def test_errors_are_loud(L, dev):
 
 
 # ------------------------------------------------------------------------------ full geometry (BASELINE configs 0/1)
-@pytest.mark.parametrize("name", ["tta_b16_n8", "tta_b16_n64"])
+@pytest.mark.parametrize("name", ["tta_b16_n8", "tta_b16_n64", "tta_b16_rl14_s3"])
 @pytest.mark.parametrize("mode,sparse,prec", [(2, True, 0), (1, True, 0), (0, False, 0), (2, True, 2), (0, False, 2)])
 def test_vit_b16_tta_matches_reference_fixture(L, dev, name, mode, sparse, prec):
     """ViT-B/16 student + ViT-B/16 reward, C=1000, outputs of the REFERENCE itself
-    (tests/golden/make_golden.py --only b16n8,b16n64): logits within 1e-3, identical top-1/top-5."""
+    (tests/golden/make_golden.py --only b16n8,b16n64): logits within 1e-3, identical top-1/top-5.  tta_b16_rl14_s3 is the
+    setting of TPT/scripts/rlcf-prompt.sh: ViT-L/14 reward model, three tuning steps."""
     g, meta = load_golden(name)
     geo = synth.GEOMETRIES[meta["student"]]
+    rgeo = synth.GEOMETRIES[meta["reward"]]
     from rlcf_amd.engine import Engine
     ssd = synth.make_state_dict(geo, meta["student_seed"], device=dev)
-    rsd = synth.make_state_dict(geo, meta["reward_seed"], device=dev)
-    eng = Engine(geo, geo, meta["n_views"], meta["n_cls"], prec)
+    rsd = synth.make_state_dict(rgeo, meta["reward_seed"], device=dev)
+    eng = Engine(geo, rgeo, meta["n_views"], meta["n_cls"], prec)
     eng.load_state_dict(L.STUDENT, ssd)
     eng.load_state_dict(L.REWARD, rsd)
     eng.finalize()
@@ -567,9 +569,16 @@ def test_vit_b16_tta_matches_reference_fixture(L, dev, name, mode, sparse, prec)
     views = synth.make_views(meta["view_seed"], meta["n_views"], geo.image_resolution, device=dev)
     o = eng.tta_sample(views, _cfg_from_meta(meta, sparse))
     torch.cuda.synchronize()
-    _check_against(o, g, meta)
+    _check_against(o, g, meta, final_atol=1e-3 if meta["tta_steps"] == 1 else 5e-3)
     assert int(o["final_logits"].argmax()) == int(g["final_logits"].argmax())
     torch.testing.assert_close(o["reward_image_features"].cpu(), g["reward_image_features"], atol=2e-5, rtol=1e-4)
+    if meta["tta_steps"] > 1 and sparse and mode == 2:        # the fused sample batch gives the same prediction
+        big = Engine(geo, rgeo, meta["n_views"] * 2, meta["n_cls"], prec)
+        big.load_state_dict(L.STUDENT, ssd); big.load_state_dict(L.REWARD, rsd); big.finalize()
+        big.set_class_bank(tokens, meta["n_ctx"], ctx0, mode)
+        top5 = big.tta_batch(torch.stack([views, synth.make_views(7, meta["n_views"], geo.image_resolution, device=dev)]), _cfg_from_meta(meta, True))
+        assert int(top5[0, 0]) == int(g["top5"][0])
+        big.close()
     eng.close()
 
 
