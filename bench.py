@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--reward-arch", default="ViT-B/16", help="reward CLIP (BASELINE configs[1]: ViT-B/16; rlcf-prompt.sh: ViT-L/14)")
     ap.add_argument("--tta-steps", type=int, default=1, help="AdamW steps per test image (BASELINE metric: 1; rlcf-prompt.sh runs 3)")
     ap.add_argument("--batch", type=int, default=32, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,11 +94,12 @@ def main():
     geo = synth.GEOMETRIES["ViT-B/16"]
     n_ctx = 4
     ssd = synth.make_state_dict(geo, 11, device=dev)
-    rsd = synth.make_state_dict(geo, 23, device=dev)
+    rgeo = synth.GEOMETRIES[a.reward_arch]
+    rsd = synth.make_state_dict(rgeo, 23, device=dev)
     tokens = synth.make_token_bank(geo, a.classes, seed=7, n_ctx=n_ctx)
     ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, n_ctx), device=dev)].clone()
     prec = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}[a.precision]
-    eng = Engine(geo, geo, a.views * max(a.batch, 1), a.classes, prec)
+    eng = Engine(geo, rgeo, a.views * max(a.batch, 1), a.classes, prec)
     eng.load_state_dict(_lib.STUDENT, ssd)
     eng.load_state_dict(_lib.REWARD, rsd)
     eng.finalize()
@@ -159,7 +161,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else "f32 via split-f16x3 MFMA", "data": "synthetic",
-            "config": {"workload": "RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + ViT-B/16 reward, N=64 views, "
+            "config": {"workload": f"RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + {a.reward_arch} reward, N=64 views, "
                                    f"1000-class bank, selection_p=0.1, K=3, {a.tta_steps} AdamW step(s) (BASELINE configs[1])",
                        "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
                        "tta_steps": a.tta_steps, "images_per_pass": a.batch,
