@@ -123,6 +123,12 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RlcfError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(the RLCF HIP path has no CPU fallback)")
+        # PyTorch-ROCm ships its own libamdhip64; the library must bind to THAT runtime (the one that owns the device context and
+        # the tensors whose pointers it receives), so torch and its HIP runtime are brought up before the dlopen.  Loaded the other
+        # way round, the system runtime from /opt/rocm is pulled in first and sees no device next to torch's.
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
