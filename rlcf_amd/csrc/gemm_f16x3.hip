@@ -609,10 +609,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
-    // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; v3 does a
-    // round's worth of flops ~15 % faster than v2 but needs enough 256x256 tiles to fill its last round
-    auto fill = [](int tiles) { return (double)tiles / ((tiles + 255) / 256 * 256); };
-    const bool pick3 = blocks3 >= 256 && 1.15 * fill(blocks3) >= fill(blocks2);
+    // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes
+    // ~0.575 of a 256x256 round (half the work at ~15 % lower efficiency).  Measured at M = 12608 (one test image): N = 768 runs
+    // 61 us as one 59 %-full 256x256 round against 70 us as two 256x128 rounds; K = 3072: 188 against 233 us.
+    const double cost3 = (double)((blocks3 + 255) / 256), cost2 = 0.575 * (double)((blocks2 + 255) / 256);
+    const bool pick3 = blocks2 >= 256 && cost3 <= cost2;
     if (v2_ok && (force == 3 || (force == 0 && pick3))) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
         static bool attr3 = false;
