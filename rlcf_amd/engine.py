@@ -109,8 +109,9 @@ class Engine:
 
     def set_reward_mix(self, weights=None, mean: bool = False) -> None:
         """Ensemble rule of CLIPRewardsMultiple.CLIPScore (clip_reward.py:248-255): weighted sum, or the mean over models."""
-        w = (C.c_float * len(self.rewards))(*([1.0] * len(self.rewards) if weights is None else [float(x) for x in weights]))
-        L.check(self.lib.rlcf_engine_set_reward_mix(self.h, w, len(self.rewards), 1 if mean else 0), "set_reward_mix")
+        ws = [1.0] * len(self.rewards) if weights is None else [float(x) for x in weights]
+        w = (C.c_float * max(len(ws), 1))(*ws)
+        L.check(self.lib.rlcf_engine_set_reward_mix(self.h, w, len(ws), 1 if mean else 0), "set_reward_mix")
 
     def set_class_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor,
                        text_mode: int = L.TEXT_SHARED) -> None:

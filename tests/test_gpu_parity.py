@@ -541,7 +541,38 @@ def test_errors_are_loud(L, dev):
         eng.tta_sample(views, TTAConfig(selection_p=0.1))
     with pytest.raises(L.RlcfError):
         eng.tta_sample(torch.cat([views, views]), TTAConfig(selection_p=0.5))   # more views than max_views
+    with pytest.raises(L.RlcfError):     # the mix must name every reward slot
+        eng.set_reward_mix([0.5, 0.5])
+    with pytest.raises(L.RlcfError):     # the momentum EMA needs momentum in [0, 1]
+        eng.momentum_update(eng.ln_params(), 1.5, 1.0, False)
     eng.close()
+    from rlcf_amd.engine import Engine
+    tiny, tr = synth.GEOMETRIES["tiny"], synth.GEOMETRIES["tiny-r"]
+    with pytest.raises(L.RlcfError):     # at most RLCF_MAX_REWARDS reward models
+        Engine(tiny, [tr] * 5, 8, 16)
+    four = Engine(tiny, [tr] * 4, 8, 16)                     # ... and four are fine
+    four.load_state_dict(L.STUDENT, synth.make_state_dict(tiny, 11))
+    for m in range(4):
+        four.load_state_dict(L.REWARD + m, synth.make_state_dict(tr, 23 + m))
+    four.finalize()
+    four.set_reward_mix([0.25] * 4)
+    tokens = synth.make_token_bank(tiny, 16, seed=7, n_ctx=4)
+    four.set_class_bank(tokens, 4, CR.ctx_from_tokens(synth.make_state_dict(tiny, 11), synth.ctx_token_ids_default(tiny, 4)), L.TEXT_SHARED)
+    o = four.tta_sample(views, TTAConfig(selection_p=0.5))
+    assert len(o["reward_image_features"]) == 4 and torch.isfinite(o["final_logits"]).all()
+    four.close()
+    # a ModifiedResNet student has no LayerNorms to tune: the LN path refuses it, the prompt path takes it
+    rn = synth.GEOMETRIES["tiny-rn32"]
+    e2 = Engine(rn, tr, 8, 16)
+    e2.load_state_dict(L.STUDENT, synth.make_state_dict(rn, 11)); e2.load_state_dict(L.REWARD, synth.make_state_dict(tr, 23))
+    e2.finalize()
+    tok2 = synth.make_token_bank(rn, 16, seed=7, n_ctx=4)
+    e2.set_class_bank(tok2, 4, CR.ctx_from_tokens(synth.make_state_dict(rn, 11), synth.ctx_token_ids_default(rn, 4)), L.TEXT_SHARED)
+    with pytest.raises(L.RlcfError):
+        e2.tta_sample_ln(views, TTAConfig(selection_p=0.5))
+    with pytest.raises(L.RlcfError):
+        e2.tta_batch_ln(views[None], TTAConfig(selection_p=0.5))
+    e2.close()
 
 
 # ------------------------------------------------------------------------------ full geometry (BASELINE configs 0/1)
