@@ -215,7 +215,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom, &e->b_ln, &e->b_ln_m, &e->b_ln_v, &e->b_ln_grad};
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
-    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn}) d->release();
+    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax}) d->release();
     delete e;
 }
 

@@ -111,6 +111,7 @@ struct rlcf_engine {
     int ln_count = 0;                // (4*layers + 4) * Wv
     size_t bwd_elems = 0;
     DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
+    DevBuf bwd_amax;                 // max|dF| handed from one backward GEMM's epilogue to the next one's operand scale
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
     DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;

@@ -43,9 +43,10 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 }
 
 // C = epi(alpha A W^T + b) (+res): dispatch on the engine precision
-// a_scale: exact power of two applied to A before it is split into f16 pairs (undone in alpha).  Backward passes hand in
-// gradients (1e-6..1e-2), which must be lifted out of f16's subnormal range; forward activations use 1.
-#define GRAD_SCALE 256.0f
+// a_scale: exact power of two applied to A before it is split into f16 pairs (undone in alpha); forward activations use 1.
+// dyn_scale: the power of two is found on the device from max|A| (operands without a known range: ResNet activations, and the
+// gradients of the backward passes, 1e-8..1e-1 depending on checkpoint, loss scale and depth, which must be lifted out of f16's
+// subnormal range without overflowing it).  amax_in: max|A| already known (written by the producing GEMM's epilogue).
 static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr,
                 const float* aux, int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epi, hipStream_t st,
                 float a_scale = 1.0f, bool dyn_scale = false, const float* amax_in = nullptr, unsigned int* amax_out = nullptr) {
@@ -417,18 +418,22 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
     for (int l = L - 1; l >= 0; --l) {
         const BlockW& b = w.blk[l];
         const SavedLayer& s = ws.sv[l];
-        TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, GRAD_SCALE));
-        TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
+        TRY(e->bwd_amax.ensure(sizeof(float)));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->bwd_amax.p, 0, sizeof(float), st));
+        TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, 1.0f, true,
+                 nullptr, (unsigned int*)e->bwd_amax.p));                 // max|dF| comes out of the epilogue ...
+        TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, 1.0f, true,
+                 e->bwd_amax.as<float>()));                               // ... and scales the next operand without another pass
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
         const LnRef g2w = ln_ref(e, b.ln2_w, 1), g1w = ln_ref(e, b.ln1_w, 1);       // per-sample LayerNorm sets (batched LN tuning, step > 0)
         TRY(launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride,
                                  group_rows > 0 ? g2w.group_stride : 0));
-        TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
+        TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
-        TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, GRAD_SCALE));
+        TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         TRY(launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
                                  group_rows > 0 ? g1w.group_stride : 0));
     }
