@@ -16,7 +16,7 @@ void rlcf_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 1; }
+int rlcf_version(void) { return 2; }   // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch
 
 // ------------------------------------------------------------------ op level
 int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
