@@ -25,6 +25,23 @@ def get_reward_model(device, args):
                        sample_k=args.sample_k, reward_process=args.reward_process, process_batch=args.process_batch)
 
 
+def _clamped_scores(bank: torch.Tensor, feats: torch.Tensor, index: torch.Tensor, k: int, weight: float, pairwise: bool) -> torch.Tensor:
+    """max(weight * <bank[index], feats>, 0): every indexed bank row against every feature row (pairwise), or entry i against
+    feature row i // k (the K sampled classes of a view)."""
+    rows = bank[index.long()]
+    sim = rows @ feats.t() if pairwise else (rows * feats.repeat_interleave(k, dim=0)).sum(-1)
+    return (weight * sim).clamp_min(0).squeeze()
+
+
+def _baseline(score: torch.Tensor, enabled: bool, amplify: bool) -> torch.Tensor:
+    """Subtract the mean over the last axis (the REINFORCE baseline), optionally divide by std + 1e-5; flat result."""
+    if enabled and score.shape[-1] > 1:
+        score = score - score.mean(dim=-1, keepdim=True)
+        if amplify:
+            score = score / (score.std(dim=-1, keepdim=True) + 1e-5)
+    return score.reshape(-1)
+
+
 class BaseRewards(nn.Module):
     """TPT/clip_reward.py:43-73."""
 
@@ -92,26 +109,13 @@ class CLIPRewards(BaseRewards):
                   pairwise=True):
         """clip_reward.py:111-128 (classification branch).  Stand-alone convenience on device tensors; the
         tuning loop gets the same numbers from the fused rlcf_reward_loss kernel."""
-        text_features = self.class_features[class_index.long()]
-        image_features = self.image_features if image_features is None else image_features
-        if pairwise:
-            similarity = self.clipscore_weight * text_features @ image_features.t()
-        else:
-            image_features = torch.repeat_interleave(image_features, self.sample_k, dim=0)
-            similarity = self.clipscore_weight * torch.sum(text_features * image_features, dim=-1)
-        return torch.maximum(similarity, torch.zeros_like(similarity)).squeeze()
+        feats = self.image_features if image_features is None else image_features
+        return _clamped_scores(self.class_features, feats, class_index, self.sample_k, self.clipscore_weight, pairwise)
 
     @torch.no_grad()
     def rewards_post_process(self, clip_score):
         """clip_reward.py:152-165."""
-        if clip_score.shape[-1] > 1 and self.reward_process:
-            mean = torch.mean(clip_score, dim=-1, keepdim=True)
-            if self.amplify_rewards:
-                std = torch.std(clip_score, dim=-1, keepdim=True) + 1e-5
-            else:
-                std = 1.0
-            clip_score = (clip_score - mean) / std
-        return clip_score.flatten()
+        return _baseline(clip_score, bool(self.reward_process), bool(self.amplify_rewards))
 
     @torch.no_grad()
     def calulate_similarity(self):
@@ -167,16 +171,11 @@ class CLIPRewardsMultiple(BaseRewards):
         """clip_reward.py:227-257: per-model clamped similarity, then the weighted sum (or the mean) over models."""
         if pairwise:
             raise NotImplementedError               # as the reference (:240)
-        all_scores = []
-        for i in range(self.n_model):
-            t = self.class_features[i][class_index.long()]
-            im = torch.repeat_interleave(self.image_features[i], self.sample_k, dim=0)
-            sim = self.clipscore_weight * torch.sum(t * im, dim=-1)
-            all_scores.append(torch.maximum(sim, torch.zeros_like(sim)).squeeze())
-        scores = torch.stack(all_scores, dim=0)
-        if self.weighted_scores:
-            w = torch.tensor(self.weights, device=scores.device, dtype=scores.dtype).unsqueeze(1)
-            return torch.sum(w * scores, dim=0)
-        return torch.mean(scores, dim=0)
+        per_model = torch.stack([_clamped_scores(c, f, class_index, self.sample_k, self.clipscore_weight, False)
+                                 for c, f in zip(self.class_features, self.image_features)])
+        if not self.weighted_scores:
+            return per_model.mean(dim=0)
+        w = per_model.new_tensor(self.weights)[:, None]
+        return (w * per_model).sum(dim=0)
 
     rewards_post_process = CLIPRewards.rewards_post_process
