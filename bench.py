@@ -169,7 +169,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "mfma_passes": passes, "frac_of_mfma_pipe": passes * achieved / peak,
                          "kernel": "gemm_nt_f32_kernel + gemm_nt_f32_splitk_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
-                         else "gemm_nt_f16x3_v3_kernel (3x v_mfma_f32_32x32x16_f16 per f32-grade product)",
+                         else "gemm_nt_f16x3_v3i_kernel (3x v_mfma_f32_32x32x16_f16 per f32-grade product)",
                          "all_gemm_kernels": {"launches_per_image": n_all.value / nprof, "ms_per_image": ms_all.value / nprof,
                                               "achieved": fl_all.value / (ms_all.value * 1e-3) / 1e12 if ms_all.value > 0 else 0.0},
                          "launches_per_image": n_l.value / nprof, "avg_launch_ms": ms.value / max(n_l.value, 1),

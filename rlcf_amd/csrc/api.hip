@@ -180,7 +180,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0;
     if (precision == RLCF_PREC_F16X3) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
-        ok = ok && e->a_hi.ensure(e->a_split_elems * 2) == 0 && e->a_lo.ensure(e->a_split_elems * 2) == 0;
+        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0;
     }
     if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { rlcf_engine_destroy(e); return nullptr; }
@@ -189,7 +189,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
 
 static void release_tower(Tower& t) {
     t.x.release(); t.h.release(); t.qkv.release(); t.a.release(); t.f.release(); t.saved.release();
-    t.hh.release(); t.hl.release(); t.ah.release(); t.al.release(); t.fh.release(); t.fl.release();
+    t.h2.release(); t.a2.release(); t.f2.release();
 }
 static void release_layout(TextLayout& L) {
     L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
@@ -210,7 +210,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
                      &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
                      &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->views_sel, &e->topk_idx,
-                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->a_lo, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
+                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
                      &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom, &e->b_ln, &e->b_ln_m, &e->b_ln_v, &e->b_ln_grad};
     for (DevBuf* d : all) d->release();

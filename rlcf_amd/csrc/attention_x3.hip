@@ -25,7 +25,7 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
-                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol) {
+                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il) {
     const rlcf_seq sq = seqs[blockIdx.y];
     const int head = blockIdx.z;
     if (blockIdx.x * NW * 32 >= sq.q_len) return;
@@ -194,29 +194,32 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
                     h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)(v0[q] - (float)h0[q]);
                     h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)(v1[q] - (float)h1[q]);
                 }
-                *(h16x4*)(oh + obase + d) = h0; *(h16x4*)(ol + obase + d) = l0;
-                *(h16x4*)(oh + obase + 32 + d) = h1; *(h16x4*)(ol + obase + 32 + d) = l1;
+                // interleaved pair layout (il): the head's two 32-column blocks sit at row*2W + head*128 (+64), lo 32 halves after hi
+                const size_t p0 = il ? (size_t)(sq.q_start + qi) * 2 * width + head * 128 + d : obase + d;
+                const size_t p1 = il ? p0 + 64 : p0 + 32;
+                *(h16x4*)(oh + p0) = h0; *(h16x4*)(ol + p0) = l0;
+                *(h16x4*)(oh + p1) = h1; *(h16x4*)(ol + p1) = l1;
             }
         }
     }
 }
 
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st) {
+                            void* out_hi, void* out_lo, hipStream_t st, int il) {
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
     if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
         dim3 grid((max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
     } else if (max_q_len > 32) {
         dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
     } else {
         dim3 grid(1, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo);
+        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
     }
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

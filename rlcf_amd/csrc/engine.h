@@ -37,7 +37,7 @@ struct SavedLayer { float *x, *qkv, *a, *x1, *f, *lse; };      // lse [T, heads]
 struct Tower {                       // workspace of one transformer pass over T rows
     int T = 0, width = 0;
     DevBuf x, h, qkv, a, f;          // f32 activations
-    DevBuf hh, hl, ah, al, fh, fl;   // split-f16 operand pairs written by the producers (F16X3 mode)
+    DevBuf h2, a2, f2;               // interleaved split-f16 operand pairs written by the producers (F16X3 mode): LN out, attention out, fc out
     int x3_T = 0, x3_W = 0;
     DevBuf saved;                    // per-layer saved activations for backward
     std::vector<SavedLayer> sv;
@@ -113,7 +113,7 @@ struct rlcf_engine {
     DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
     DevBuf bwd_amax;                 // max|dF| handed from one backward GEMM's epilogue to the next one's operand scale
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
-    DevBuf a_hi, a_lo;               // split copy of the current GEMM A operand (F16X3 mode)
+    DevBuf a_hi;                     // interleaved split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
     double last_flops = 0.0;
 };

@@ -42,6 +42,12 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
     g_prof.n = slot + 1;
 }
 
+// Split-f16 operands of the engine are INTERLEAVED pairs: per row, each block of 32 K-columns is stored as 32 hi halves followed by
+// its 32 lo halves (row stride 2K halves), so that one 128-B LDS-DMA segment brings both parts of a k-tile (a 64-B segment per
+// part reaches 25.8 B/clk/CU, a 128-B one 45.5: profiles/r1_gemm_sq_counters.txt).  The lo part of a pair therefore starts 64 B after hi.
+static inline void* lo_of(void* hi) { return (char*)hi + 64; }
+static inline const void* lo_of(const void* hi) { return (const char*)hi + 64; }
+
 // C = epi(alpha A W^T + b) (+res): dispatch on the engine precision
 // a_scale: exact power of two applied to A before it is split into f16 pairs (undone in alpha); forward activations use 1.
 // dyn_scale: the power of two is found on the device from max|A| (operands without a known range: ResNet activations, and the
@@ -65,16 +71,16 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
                 TRY(e->dyn.ensure(3 * sizeof(float)));
                 if (amax_in) {             // max|A| was produced by the GEMM that wrote A
                     TRY(launch_dyn_scale_from(amax_in, e->dyn.as<float>() + 1, st));
-                    TRY(launch_split_f16x2_dev(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>() + 1, st));
+                    TRY(launch_split_f16x2_dev(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, e->dyn.as<float>() + 1, st, 1));
                 } else {
-                    TRY(launch_split_f16x2_dyn(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, e->dyn.as<float>(), st));
+                    TRY(launch_split_f16x2_dyn(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, e->dyn.as<float>(), st, 1));
                 }
                 alpha_dev = e->dyn.as<float>() + 2;
             } else {
-                TRY(launch_split_f16x2(A, e->a_hi.p, e->a_lo.p, (int64_t)M * K, st, a_scale));
+                TRY(launch_split_f16x2(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, st, a_scale, 1));
             }
             const int slot = prof_begin(st, 2.0 * M * N * K);
-            int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
+            int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
@@ -99,7 +105,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     if (!sp) { rlcf_set_error("engine_gemm_presplit: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K);
-    int rc = launch_gemm_f16x3(e->a_hi.p, e->a_lo.p, K, sp->hi, sp->lo, K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
+    int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
                                sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
@@ -114,21 +120,23 @@ static const ClipModel::SplitW* split_of(rlcf_engine* e, const float* W) {
     for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) return &it->second; }
     return nullptr;
 }
-static int gemm_pre(rlcf_engine* e, const void* Ahi, const void* Alo, int lda, const float* W, const float* bias, const float* res, int ldr,
-                    float* C, int ldc, void* Chi, void* Clo, int ldch, int M, int N, int K, int epi, hipStream_t st) {
+// A (and the optional split output) are interleaved pairs; lda / ldch are given in logical columns
+static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, const float* bias, const float* res, int ldr,
+                    float* C, int ldc, void* C2, int ldch, int M, int N, int K, int epi, hipStream_t st) {
     const ClipModel::SplitW* sp = split_of(e, W);
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K);
-    int rc = launch_gemm_f16x3(Ahi, Alo, lda, sp->hi, sp->lo, K, bias, res, ldr, nullptr, 0, C, ldc, Chi, Clo, ldch, M, N, K, sp->inv_scale, epi, st);
+    int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
+                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
 static int x3_ensure(Tower& t, int T, int W) {
     if (T <= t.x3_T && W <= t.x3_W) return RLCF_OK;
     T = std::max(T, t.x3_T); W = std::max(W, t.x3_W);
-    const size_t n = (size_t)T * W * 2;
-    TRY(t.hh.ensure(n)); TRY(t.hl.ensure(n)); TRY(t.ah.ensure(n)); TRY(t.al.ensure(n)); TRY(t.fh.ensure(4 * n)); TRY(t.fl.ensure(4 * n));
+    const size_t n = (size_t)T * W * 4;                     // one interleaved (hi, lo) pair per element
+    TRY(t.h2.ensure(n)); TRY(t.a2.ensure(n)); TRY(t.f2.ensure(4 * n));
     t.x3_T = T; t.x3_W = W;
     return RLCF_OK;
 }
@@ -145,9 +153,10 @@ static const float* rawp(ClipModel& m, const std::string& k, size_t numel) {
 }
 static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
     if (e->precision != RLCF_PREC_F16X3 || !w) return RLCF_OK;
-    DevBuf hi, lo;
-    TRY(hi.ensure(numel * 2));
-    TRY(lo.ensure(numel * 2));
+    DevBuf hi;                                             // both parts in one allocation
+    TRY(hi.ensure(numel * 4));
+    const int il = numel % 32 == 0;                        // K % 32 == 0 (every weight the split-f16 GEMM accepts): interleaved pairs
+    void* lo = il ? lo_of(hi.p) : (void*)((char*)hi.p + numel * 2);
     // exact power-of-two pre-scale that lifts the tensor to max|w| in [2^9, 2^10): lo parts of all but negligible
     // elements are then normal f16 numbers (full 22-bit operand), far from f16 overflow
     static DevBuf amax;
@@ -159,10 +168,9 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     int sh = 0;
     if (mx > 0.f && std::isfinite(mx)) sh = std::max(-8, std::min(12, 9 - (int)std::floor(std::log2(mx))));
     const float scale = std::ldexp(1.0f, sh);
-    TRY(launch_split_f16x2(w, hi.p, lo.p, (int64_t)numel, st, scale));
-    m.split_of[w] = ClipModel::SplitW{hi.p, lo.p, 1.0f / scale};
+    TRY(launch_split_f16x2(w, hi.p, lo, (int64_t)numel, st, scale, il));
+    m.split_of[w] = ClipModel::SplitW{hi.p, lo, 1.0f / scale};
     m.derived.push_back(hi);
-    m.derived.push_back(lo);
     return RLCF_OK;
 }
 int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) { return make_split(e, m, w, numel, st); }
@@ -360,7 +368,7 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
          TRY(launch_layernorm_fwd((xp), gw_.p, gb_.p, (yp), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
 #define LN_FWD_SPLIT(xp, wp, bp, hh, hl, rows, W)                                                                           \
     do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
-         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
+         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride, 1)); } while (0)
 
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
                                long attn_pairs, int causal, int T, bool save, hipStream_t st) {
@@ -372,14 +380,14 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* x = ws.x.as<float>();
         for (int l = 0; l < L; ++l) {
             const BlockW& b = w.blk[l];
-            LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.hh.p, ws.hl.p, T, W);
-            TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
-            TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.ah.p, ws.al.p, st));
+            LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1));
             e->last_flops += 4.0 * attn_pairs * W;
-            TRY(gemm_pre(e, ws.ah.p, ws.al.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
-            LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.hh.p, ws.hl.p, T, W);
-            TRY(gemm_pre(e, ws.hh.p, ws.hl.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.fh.p, ws.fl.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
-            TRY(gemm_pre(e, ws.fh.p, ws.fl.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
+            TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
+            LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            TRY(gemm_pre(e, ws.h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.f2.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
+            TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
         }
         return RLCF_OK;
     }
@@ -457,8 +465,8 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     if (is_resnet(c)) return resnet_encode(e, m, images, n, feats, st);
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
     if (e->precision == RLCF_PREC_F16X3 && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
-        TRY(launch_im2col(images, nullptr, e->a_hi.p, e->a_lo.p, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
-        TRY(gemm_pre(e, e->a_hi.p, e->a_lo.p, m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, nullptr, 0, n * G2, Wv,
+        TRY(launch_im2col(images, nullptr, e->a_hi.p, lo_of(e->a_hi.p), n, c.image_resolution, c.vision_patch_size, m.Kp, st, 1));
+        TRY(gemm_pre(e, e->a_hi.p, m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, 0, n * G2, Wv,
                      m.Kp, RLCF_EPI_NONE, st));
     } else {
         TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
@@ -637,7 +645,7 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     TRY(tower_ensure(e->tt, Tmax, Wmax));
     if (e->precision == RLCF_PREC_F16X3 && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
         e->a_split_elems = (size_t)Tmax * Wmax * 4;
-        TRY(e->a_hi.ensure(e->a_split_elems * 2)); TRY(e->a_lo.ensure(e->a_split_elems * 2));
+        TRY(e->a_hi.ensure(e->a_split_elems * 4));
     }
     const size_t cw = (size_t)C * Wmax * sizeof(float), cd = (size_t)C * Dmax * sizeof(float);
     TRY(e->eot_x.ensure(cw)); TRY(e->eot_ln.ensure(cw)); TRY(e->u.ensure(cd)); TRY(e->inv_norm.ensure(C * sizeof(float)));
@@ -902,7 +910,7 @@ static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
     TRY(tower_ensure(e->tt, B * L.T, Wt));
     if (e->precision == RLCF_PREC_F16X3 && (size_t)B * L.T * Wt * 4 > e->a_split_elems) {
         e->a_split_elems = (size_t)B * L.T * Wt * 4;
-        TRY(e->a_hi.ensure(e->a_split_elems * 2)); TRY(e->a_lo.ensure(e->a_split_elems * 2));
+        TRY(e->a_hi.ensure(e->a_split_elems * 4));
     }
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     e->b_cap = B;

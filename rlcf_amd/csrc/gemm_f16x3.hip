@@ -28,10 +28,12 @@ struct GemmX3Args {
     int M, N, K;
     float alpha; int epilogue;
     unsigned int* amax_out;            // optional: atomicMax of |C| (float bits), see common.h
+    int c_il;                          // split output interleaved: column c of a row sits at (c/32)*64 + c%32 (hi) / +32 (lo, = Clo)
     const float* alpha_dev;            // optional device scalar multiplied into alpha (undoes a data-dependent operand pre-scale)
     int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
 };
 
+__device__ __forceinline__ int x3_ocol(const GemmX3Args& g, int col) { return g.c_il ? (((col >> 5) << 6) | (col & 31)) : col; }
 __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha; }
 
 #define X3_BM 128
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                     h16x4 hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
-                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.C) g.C[(size_t)row * g.ldc + col] = v;
                 if (g.Chi) {
                     const _Float16 hi = (_Float16)v;
-                    g.Chi[(size_t)row * g.ldch + col] = hi;
-                    g.Clo[(size_t)row * g.ldch + col] = (_Float16)(v - (float)hi);
+                    g.Chi[(size_t)row * g.ldch + x3_ocol(g, col)] = hi;
+                    g.Clo[(size_t)row * g.ldch + x3_ocol(g, col)] = (_Float16)(v - (float)hi);
                 }
             }
         }
@@ -373,8 +375,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
                     h16x4 hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
-                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -577,8 +579,206 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                     h16x4 hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
-                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + col) = ll;
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+                }
+            }
+        }
+    }
+    amax_commit(g.amax_out, am);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
+    float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
+    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n, grp = bid / per_group, first_m = grp * 8;
+    const int gsize = min(tiles_m - first_m, 8), in_g = bid - grp * per_group;
+    const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA: every operand tile = 256 rows x 4 chunks = 1024 chunks = 2 pieces per wave; 8 pieces per wave per stage
+    // Interleaved operands: row r of A (and W) holds, per K tile, one 128-byte block [32 hi | 32 lo]; a DMA instruction moves 8 rows
+    // x 128 B (whole cache lines: the 64-B row segments of the separate-array layout cost the address/tag path twice the lines per
+    // byte: 25.8 against 45.5 B/clk/CU in the delivery micro-benchmark).  LDS row = 128 B; 16-B chunk c (0-3 hi, 4-7 lo) of row r sits
+    // in slot c ^ ((r>>1)&7), so a 16-lane ds_read_b128 group (16 consecutive rows, one chunk) covers all 64 banks.
+    size_t sa[4], sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = (wave * 4 + j) * 64 + lane, r = q >> 3, c = ((q & 7) ^ ((r >> 1) & 7)) * 8;
+        sa[j] = (size_t)min(m0 + r, g.M - 1) * g.lda + c;
+        sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c;
+    }
+#undef V3_PIECE
+#define V3_PIECE(idx, kk, sb_)                                                                                                         \
+    {                                                                                                                                  \
+        if ((idx) < 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);           \
+        else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);              \
+    }
+#undef V3_LDA
+#undef V3_LDB
+#define V3_LDA(ks, AH, AL)                                                                                               \
+    {                                                                                                                    \
+        const int ch_ = (((ks) * 2 + h) ^ swz) * 16, cl_ = ((4 + (ks) * 2 + h) ^ swz) * 16;                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+            AH[i] = *(const h16x8*)(sb + aoff + i * 4096 + ch_);                                                         \
+            AL[i] = *(const h16x8*)(sb + aoff + i * 4096 + cl_);                                                         \
+        }                                                                                                                \
+    }
+#define V3_LDB(ks, BH, BL)                                                                                               \
+    {                                                                                                                    \
+        const int ch_ = (((ks) * 2 + h) ^ swz) * 16, cl_ = ((4 + (ks) * 2 + h) ^ swz) * 16;                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            BH[j] = *(const h16x8*)(sb + 32768 + boff + j * 4096 + ch_);                                                 \
+            BL[j] = *(const h16x8*)(sb + 32768 + boff + j * 4096 + cl_);                                                 \
+        }                                                                                                                \
+    }
+    const int nk = g.K / X3_BK;
+    {
+        char* s0 = smem;
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, 0, s0)
+    }
+    const int swz = (l32 >> 1) & 7;
+    const int aoff = (wm * 128 + l32) * 128, boff = (wn * 64 + l32) * 128;
+    // Ping-pong: the two waves of a SIMD belong to the row groups wm = 0 / 1, which run the same K loop half an iteration apart.
+    // Two barriers per K tile (g = 2kt: tile kt has landed; g = 2kt+1); in every interval one group is in its pure-MFMA half
+    // (second k-substep, fragments already in registers) while the other waits for its first fragments, so the matrix pipe always
+    // has work.  Both groups issue their DMA pieces of tile kt+1 in the interval [2kt, 2kt+1].
+    h16x8 ah0[4], al0[4], bh0[2], bl0[2], ah1[4], al1[4], bh1[2], bl1[2];
+    if (wm == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = kt + 1 < nk;
+            const int kn = (kt + 1) * g.kstep;
+            char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
+            const char* sb = smem + (kt & 1) * V3_STAGE;
+            V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
+            V2_FENCE
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
+                    if (pf) V3_PIECE(i * 2 + j, kn, sn)
+                    if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
+                    V2_FENCE
+                }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
+        }
+        __builtin_amdgcn_s_barrier();                              // pairs with the other group's last half step
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool pf = kt + 1 < nk;
+            const int kn = (kt + 1) * g.kstep;
+            char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
+            const char* sb = smem + (kt & 1) * V3_STAGE;
+            if (kt > 0) {                                          // second k-substep of tile kt-1 + the DMA of tile kt+1
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE
+                        if (pf) V3_PIECE(i * 2 + j, kn, sn)
+                        V2_FENCE
+                    }
+            } else if (pf) {
+#pragma unroll
+                for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, kn, sn)
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
+            V2_FENCE
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    V2_MMA3(i, j, ah0, al0, bh0, bl0) V2_FENCE
+                    if (i == 0 && j == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
+                    V2_FENCE
+                }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
+    }
+    // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
+    constexpr int ELD = 68;
+    float* park = (float*)smem + wave * (64 * ELD);
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int col = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && col < g.N) bv = *(const float4*)(g.bias + col);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i][j][r];
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 4 + rsub, row = m0 + wm * 128 + half * 64 + rl;
+                if (row >= g.M) continue;
+                const float4 a4 = *(const float4*)(park + rl * ELD + c4);
+                const float al = x3_alpha(g);
+                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+                if (g.epilogue == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
+                    const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                }
+                if (g.residual) {
+                    const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (g.epilogue == RLCF_EPI_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.Chi) {
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
+                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -589,15 +789,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
-                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out) {
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && Clo)));
     GemmX3Args g{};
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
-    g.alpha_dev = alpha_dev; g.amax_out = amax_out;
+    g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.c_il = c_il;
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
+    RLCF_ARG_CHECK((g.kstep == 64) == (Wlo == (const void*)((const _Float16*)Whi + 32)));   // both operands in the same layout
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
     static bool attr = false;
     if (!attr) {
@@ -621,6 +822,14 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
             attr3 = true;
         }
+        if (g.kstep == 64) {
+            static bool attr3i = false;
+            if (!attr3i) {
+                RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3i_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
+                attr3i = true;
+            }
+            gemm_nt_f16x3_v3i_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        } else
         gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
         g_last_x3_variant = 3;
         RLCF_LAUNCH_CHECK();
@@ -646,7 +855,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
 }
 
 // x -> (hi, lo): hi = f16(x), lo = f16((x - hi) * 2^11).  8 elements per thread.
-__global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8, float scale) {
+// il: interleaved output — 8-element group i (32-element block i/4, position i%4) lands at 8*((i/4)*8 + i%4) (hi) and 32 halves later (lo)
+__device__ __forceinline__ int64_t split_dst(int64_t i, int il) { return il ? ((i >> 2) << 3) + (i & 3) : i; }
+__global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8, float scale, int il) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
         const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
@@ -657,8 +868,8 @@ __global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __rest
             vh[e] = hh;
             vl[e] = (_Float16)(v[e] - (float)hh);
         }
-        ((h16x8*)hi)[i] = vh;
-        ((h16x8*)lo)[i] = vl;
+        ((h16x8*)hi)[split_dst(i, il)] = vh;
+        ((h16x8*)lo)[split_dst(i, il)] = vl;
     }
 }
 // data-dependent pre-scale for operands without a known range (ResNet activations): s = 2^k lifting max|x| into [2^9, 2^10);
@@ -672,7 +883,7 @@ __global__ void dyn_scale_kernel(const float* __restrict__ amax, float* __restri
     out[1] = ldexpf(1.0f, -sh);
 }
 __global__ void split_f16x2_dyn_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8,
-                                       const float* __restrict__ scale_dev) {
+                                       const float* __restrict__ scale_dev, int il) {
     const float scale = scale_dev[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
@@ -684,8 +895,8 @@ __global__ void split_f16x2_dyn_kernel(const float* __restrict__ x, _Float16* __
             vh[e] = hh;
             vl[e] = (_Float16)(v[e] - (float)hh);
         }
-        ((h16x8*)hi)[i] = vh;
-        ((h16x8*)lo)[i] = vl;
+        ((h16x8*)hi)[split_dst(i, il)] = vh;
+        ((h16x8*)lo)[split_dst(i, il)] = vl;
     }
 }
 // scratch: 3 floats on the device {max|x|, s, 1/s}
@@ -702,29 +913,29 @@ int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st) 
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
-int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st) {
+int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scale_dev);
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale_dev);
+    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale_dev, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
-int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st) {
+int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0 && scratch3);
     int rc = launch_dyn_scale(x, n, scratch3, st);
     if (rc != RLCF_OK) return rc;
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scratch3 + 1);
+    split_f16x2_dyn_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scratch3 + 1, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
-int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale) {
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale, int il) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0);
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    split_f16x2_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale);
+    split_f16x2_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

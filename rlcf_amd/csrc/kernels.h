@@ -9,9 +9,9 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
                          float* dgamma, float* dbeta, int rows, int width, hipStream_t st, int group_rows = 0, int group_stride = 0,
                          int gamma_stride = 0);
 // images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 and/or a split-f16 pair)
-int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st);
+int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st, int il = 0);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
-                               hipStream_t st, int group_rows = 0, int group_stride = 0);
+                               hipStream_t st, int group_rows = 0, int group_stride = 0, int il = 0);
 // x[n,1+G*G,W] = ln_pre([cls | patch_out] + pos)
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                         const float* beta, float* x, int n, int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0);
@@ -53,12 +53,12 @@ int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* im
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr,
-                      unsigned int* amax_out = nullptr);
+                      unsigned int* amax_out = nullptr, int c_il = 0);
 int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
-int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st);
-int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st);
-int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f);
+int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il = 0);
+int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il = 0);
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f, int il = 0);
 int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st);
 int launch_ctx_grad_grouped(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, int groups, int group_rows,
                             float* dctx, hipStream_t st);
@@ -86,7 +86,7 @@ int launch_final_logits_batched(const float* img, int img_row_stride, const floa
 int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st);
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st);
+                            void* out_hi, void* out_lo, hipStream_t st, int il = 0);
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,

@@ -77,8 +77,9 @@ __global__ void im2col3x3_split_kernel(const float* __restrict__ in, _Float16* _
                 }
             }
         }
-        ((h16x8*)hi)[i] = vh;
-        ((h16x8*)lo)[i] = vl;
+        const long dst = ((i >> 2) << 3) + (i & 3);          // interleaved pair layout (Kp % 32 == 0): lo = hi + 32 halves
+        ((h16x8*)hi)[dst] = vh;
+        ((h16x8*)lo)[dst] = vl;
     }
 }
 
@@ -253,7 +254,7 @@ static int rn_ensure(rlcf_engine* e, const ResNetW& r, int chunk, int T) {
     if (e->precision == RLCF_PREC_F16X3) {
         const size_t need = std::max((size_t)chunk * r.col_per_img, (size_t)chunk * r.act_per_img);
         if (need > e->a_split_elems) {
-            TRY(e->a_hi.ensure(need * 2)); TRY(e->a_lo.ensure(need * 2));
+            TRY(e->a_hi.ensure(need * 4));
             e->a_split_elems = need;
         }
     }
@@ -278,7 +279,7 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
         if (in_amax) TRY(launch_dyn_scale_from(in_amax, e->dyn.as<float>() + 1, st));
         else TRY(launch_dyn_scale(in, (int64_t)n * H * W * cw.cin, e->dyn.as<float>(), st));
         const long total8 = M * (cw.Kp / 8);
-        im2col3x3_split_kernel<<<grid_for(total8), dim3(256), 0, st>>>(in, (_Float16*)e->a_hi.p, (_Float16*)e->a_lo.p, total8, cw.cin, H, W,
+        im2col3x3_split_kernel<<<grid_for(total8), dim3(256), 0, st>>>(in, (_Float16*)e->a_hi.p, (_Float16*)e->a_hi.p + 32, total8, cw.cin, H, W,
                                                                       Ho, Wo, stride, cw.Kp, e->dyn.as<float>() + 1);
         RLCF_LAUNCH_CHECK();
         return engine_gemm_presplit(e, cw.w, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi, e->dyn.as<float>() + 2, st, out_amax);

@@ -4,6 +4,11 @@
 #include "kernels.h"
 
 #define ROWS_PER_BLOCK 4
+// split-f16 pair outputs may be interleaved per 32-column block: column c of a row of `width` sits at row*2*width + (c/32)*64 + c%32
+// (hi) and 32 halves later (lo, which is what the caller passes as the lo pointer)
+__device__ __forceinline__ size_t pair_off(int row, int c, int width, int il) {
+    return il ? (size_t)row * 2 * width + (((c >> 5) << 6) | (c & 31)) : (size_t)row * width + c;
+}
 #define MAX_PER_LANE 16   // width <= 1024
 
 // ---------------------------------------------------------------- LayerNorm fwd
@@ -11,7 +16,8 @@
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             _Float16* __restrict__ yh,
-                                                            _Float16* __restrict__ yl, int rows, int width, int group_rows, int group_stride) {
+                                                            _Float16* __restrict__ yl, int rows, int width, int group_rows, int group_stride,
+                                                            int il) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                     const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)(ov[q] - (float)hh[q]); }
-                    *(h16x4*)(yh + (size_t)row * width + c) = hh;
-                    *(h16x4*)(yl + (size_t)row * width + c) = ll;
+                    *(h16x4*)(yh + pair_off(row, c, width, il)) = hh;
+                    *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;
                 }
             }
     } else {
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 if (y) y[(size_t)row * width + c] = o;
                 if (yh) {
                     const _Float16 hh = (_Float16)o;
-                    yh[(size_t)row * width + c] = hh;
-                    yl[(size_t)row * width + c] = (_Float16)(o - (float)hh);
+                    yh[pair_off(row, c, width, il)] = hh;
+                    yl[pair_off(row, c, width, il)] = (_Float16)(o - (float)hh);
                 }
             }
         }
@@ -93,14 +99,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, hipStream_t st, int group_rows,
                          int group_stride) {
-    return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st, group_rows, group_stride);
+    return launch_layernorm_fwd_split(x, gamma, beta, y, nullptr, nullptr, rows, width, st, group_rows, group_stride, 0);
 }
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
-                               hipStream_t st, int group_rows, int group_stride) {
+                               hipStream_t st, int group_rows, int group_stride, int il) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
     layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
                                                                                                    (_Float16*)yl, rows, width, group_rows,
-                                                                                                   group_rows > 0 ? group_stride : 0);
+                                                                                                   group_rows > 0 ? group_stride : 0, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -264,7 +270,7 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
 // ---------------------------------------------------------------- patch gather (im2col)
 // stride==kernel convolution of TPT/clip/model.py:211,224 written as gather + GEMM.
 __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__ out, _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                              int n, int R, int ps, int Kp) {
+                              int n, int R, int ps, int Kp, int il) {
     const int G = R / ps;
     const int K = 3 * ps * ps;
     const int kq = Kp >> 2;                               // float4 groups per patch row
@@ -287,17 +293,17 @@ __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__
             h16x4 hh, ll;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)o[q]; ll[q] = (_Float16)(o[q] - (float)hh[q]); }
-            *(h16x4*)(oh + (size_t)p * Kp + k4) = hh;
-            *(h16x4*)(ol + (size_t)p * Kp + k4) = ll;
+            *(h16x4*)(oh + pair_off((int)p, k4, Kp, il)) = hh;
+            *(h16x4*)(ol + pair_off((int)p, k4, Kp, il)) = ll;
         }
     }
 }
-int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st) {
+int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st, int il) {
     RLCF_ARG_CHECK(n > 0 && R % ps == 0 && Kp % 4 == 0 && Kp >= 3 * ps * ps);
     const long total = (long)n * (R / ps) * (R / ps) * (Kp / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    im2col_kernel<<<dim3(blocks), dim3(256), 0, st>>>(images, out, (_Float16*)out_hi, (_Float16*)out_lo, n, R, ps, Kp);
+    im2col_kernel<<<dim3(blocks), dim3(256), 0, st>>>(images, out, (_Float16*)out_hi, (_Float16*)out_lo, n, R, ps, Kp, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
