@@ -214,6 +214,8 @@ typedef struct {                 /* every pointer optional (NULL = not wanted); 
     int32_t* top5;               /* [5]                                      */
     float* ln_grad;              /* [(4L+4)*Wv] first-step gradient of the visual LayerNorm parameters (rlcf_tta_sample_ln) */
     float* ln_after;             /* [(4L+4)*Wv] adapted LayerNorm parameters                                                 */
+    float* vis_grad;             /* [visual_param_count] first-step gradient of the other visual parameters (rlcf_tta_sample_visual) */
+    float* vis_after;            /* [visual_param_count] adapted values                                                      */
 } rlcf_tta_out;
 
 /* One iteration of the harness loop TPT/tpt_cls_rl.py:251-262: reset ctx and optimizer state,
@@ -238,6 +240,28 @@ int rlcf_engine_set_ln_params(rlcf_engine*, const float* in, rlcf_stream stream)
  * update_counter reached update_freq) the reset state becomes (1-w)*checkpoint + w*momentum_state.  Makes test samples
  * order-dependent: single replica only. */
 int rlcf_engine_momentum_update(rlcf_engine*, const float* current, double momentum, double update_w, int apply, rlcf_stream stream);
+
+/* Full image-encoder tuning: CLIPCLS_TTA(only_visual=True, only_norm=False) of TPT/clip/custom_clip.py:364-497, whose
+ * parameters() is then clip_model.visual.parameters() (:477-479) — the `--tune_norm 0` default (TPT/params.py:73) that
+ * scripts/rlcf-tune.sh runs.  Same per-call contract as rlcf_tta_sample_ln (reset, S steps through the n_sel selected views,
+ * clean-view inference, pristine state restored on return) with EVERY visual parameter tuned: the LayerNorm tensors as in
+ * rlcf_tta_sample_ln (out->ln_grad / ln_after), all others in one flat vector (out->vis_grad / vis_after) laid out
+ * [class_embedding, positional_embedding, proj, conv1.weight, then per block attn.in_proj_weight, attn.in_proj_bias,
+ * attn.out_proj.weight, attn.out_proj.bias, mlp.c_fc.weight, mlp.c_fc.bias, mlp.c_proj.weight, mlp.c_proj.bias], each tensor
+ * starting at a multiple of 64 floats (rlcf_engine_visual_param_layout).  VisionTransformer students only. */
+int rlcf_tta_sample_visual(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
+                           rlcf_stream stream);
+/* floats in the flat vector (padding included); 0 + error for a ModifiedResNet student */
+int64_t rlcf_engine_visual_param_count(rlcf_engine*, rlcf_stream stream);
+/* offsets / element counts of its 4 + 8*layers tensors in the order above; returns the number of tensors (or a negative error) */
+int rlcf_engine_visual_param_layout(rlcf_engine*, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream);
+/* copy the flat vector out: which = 0 live, 1 reset state (initial_state_dict), 2 checkpoint (clip_state_dict), 3 momentum state */
+int rlcf_engine_get_visual_params(rlcf_engine*, float* out, int which, rlcf_stream stream);
+/* load the live flat vector (and refresh the transposed / split copies the GEMMs read): inference with adapted weights */
+int rlcf_engine_set_visual_params(rlcf_engine*, const float* in, rlcf_stream stream);
+/* CLIPCLS_TTA.momentum_update_model (custom_clip.py:460-475) for the flat vector; `current` = out->vis_after of the sample just
+ * processed.  Call next to rlcf_engine_momentum_update (which handles the LayerNorm set) with the same arguments. */
+int rlcf_engine_momentum_update_visual(rlcf_engine*, const float* current, double momentum, double update_w, int apply, rlcf_stream stream);
 
 /* Same for `count` consecutive samples (views [count,N,3,R,R]); top5 [count,5], final_logits
  * [count,C] (optional).  One host call per batch of test images. */

@@ -205,6 +205,21 @@ def visual_ln_keys(sd):
     return keys + ["visual.ln_post.weight", "visual.ln_post.bias"]
 
 
+def visual_param_keys(sd):
+    """CLIPCLS_TTA.parameters() with only_norm=False (custom_clip.py:477-479): every parameter of clip_model.visual, in
+    named_parameters() order of VisionTransformer (model.py:206-221: direct parameters first, then conv1, ln_pre, the
+    resblocks, ln_post)."""
+    n = C.n_blocks(sd, "visual.transformer")
+    keys = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight",
+            "visual.ln_pre.weight", "visual.ln_pre.bias"]
+    for i in range(n):
+        p = f"visual.transformer.resblocks.{i}."
+        keys += [p + "attn.in_proj_weight", p + "attn.in_proj_bias", p + "attn.out_proj.weight", p + "attn.out_proj.bias",
+                 p + "ln_1.weight", p + "ln_1.bias", p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", p + "mlp.c_proj.weight",
+                 p + "mlp.c_proj.bias", p + "ln_2.weight", p + "ln_2.bias"]
+    return keys + ["visual.ln_post.weight", "visual.ln_post.bias"]
+
+
 def momentum_update(mom: torch.Tensor, cur: torch.Tensor, clip: torch.Tensor, momentum: float, update_w: float, apply: bool):
     """CLIPCLS_TTA.momentum_update_model on the tunable tensors (custom_clip.py:460-475): -> (new momentum state, new reset
     state or None).  float32 elementwise arithmetic as torch evaluates `m * a + (1.0 - m) * b`."""
@@ -213,16 +228,19 @@ def momentum_update(mom: torch.Tensor, cur: torch.Tensor, clip: torch.Tensor, mo
 
 
 def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor, hp: TTAHyper,
-                  reward_cls: Optional[torch.Tensor] = None, ln_init: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                  reward_cls: Optional[torch.Tensor] = None, ln_init: Optional[torch.Tensor] = None,
+                  only_norm: bool = True) -> Dict[str, torch.Tensor]:
     """One iteration of the harness loop TPT/tune_cls_rl.py:183-256 with model = CLIPCLS_TTA(only_visual=True,
-    only_norm=True): reset visual state -> test_time_tuning (tpt_cls_rl.py:47-79; the image encoder runs WITH grad,
-    custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference."""
+    only_norm=...): reset visual state -> test_time_tuning (tpt_cls_rl.py:47-79; the image encoder runs WITH grad,
+    custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference.
+    only_norm=False (the default of `--tune_norm`, params.py:73, what scripts/rlcf-tune.sh runs) tunes every visual parameter;
+    `ln_grad` / `ln_after` / `ln_init` then hold all of them, concatenated in visual_param_keys order."""
     out: Dict[str, torch.Tensor] = {}
     if reward_cls is None:
         reward_cls = reward_class_features(reward_sd, tokens)
     with torch.no_grad():
         cls_feat = C.l2_normalize(C.encode_text(student_sd, tokens))            # get_class_features, custom_clip.py:405-409
-    keys = visual_ln_keys(student_sd)
+    keys = visual_ln_keys(student_sd) if only_norm else visual_param_keys(student_sd)
     params = {k: student_sd[k].clone() for k in keys}                           # model.reset(): pristine visual state
     if ln_init is not None:                                                     # ... or the momentum-updated initial_state_dict
         off = 0

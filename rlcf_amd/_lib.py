@@ -44,7 +44,7 @@ class TTAArgs(C.Structure):
 
 
 TTA_OUT_FIELDS = ("logits", "entropy", "selected_idx", "topk_idx", "clip_score", "rewards", "loss", "dlogits",
-                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5", "ln_grad", "ln_after")
+                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5", "ln_grad", "ln_after", "vis_grad", "vis_after")
 
 
 class TTAOut(C.Structure):
@@ -89,6 +89,12 @@ SIGNATURES = {
     "rlcf_tta_sample": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_batch": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_tta_sample_ln": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_tta_sample_visual": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_engine_visual_param_count": (I64, [P, P]),
+    "rlcf_engine_visual_param_layout": (I, [P, P, P, I, P]),
+    "rlcf_engine_get_visual_params": (I, [P, P, I, P]),
+    "rlcf_engine_set_visual_params": (I, [P, P, P]),
+    "rlcf_engine_momentum_update_visual": (I, [P, P, D, D, I, P]),
     "rlcf_engine_ln_param_count": (I, [P]),
     "rlcf_engine_get_ln_params": (I, [P, P, I, P]),
     "rlcf_engine_set_ln_params": (I, [P, P, P]),

@@ -16,7 +16,7 @@ void rlcf_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 2; }   // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch
+int rlcf_version(void) { return 3; }   // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
 int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
@@ -215,7 +215,8 @@ void rlcf_engine_destroy(rlcf_engine* e) {
                      &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom, &e->b_ln, &e->b_ln_m, &e->b_ln_v, &e->b_ln_grad};
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
-    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax}) d->release();
+    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
+                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi}) d->release();
     delete e;
 }
 
@@ -280,6 +281,52 @@ int rlcf_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_ar
 int rlcf_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args);
     return engine_tta_sample_ln(e, views, N, args, out, (hipStream_t)stream);
+}
+int rlcf_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && views && args);
+    return engine_tta_sample_visual(e, views, N, args, out, (hipStream_t)stream);
+}
+int64_t rlcf_engine_visual_param_count(rlcf_engine* e, rlcf_stream stream) {
+    if (!e || engine_visual_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;
+    return (int64_t)e->vw_count;
+}
+int rlcf_engine_visual_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && offsets && numels);
+    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    RLCF_ARG_CHECK(max_entries >= (int)e->vw_slots.size());
+    for (size_t i = 0; i < e->vw_slots.size(); ++i) { offsets[i] = (int64_t)e->vw_slots[i].off; numels[i] = (int64_t)e->vw_slots[i].numel; }
+    return (int)e->vw_slots.size();
+}
+int rlcf_engine_get_visual_params(rlcf_engine* e, float* out, int which, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && out && which >= 0 && which <= 3);
+    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    const DevBuf* src[4] = {&e->vw, &e->vw_init, &e->vw_clip, &e->vw_mom};
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, src[which]->p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RLCF_OK;
+}
+int rlcf_engine_set_visual_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && in);
+    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, in, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    e->vw_dirty = true;                  // (a later tuning call starts with its own reset)
+    return engine_visual_refresh(e, (hipStream_t)stream);
+}
+int rlcf_engine_momentum_update_visual(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && current && momentum >= 0.0 && momentum <= 1.0);
+    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    rc = launch_momentum_update(e->vw_mom.as<float>(), current, e->vw_clip.as<float>(), e->vw_init.as<float>(), (int64_t)e->vw_count, momentum,
+                                update_w, apply, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    if (apply) {         // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy and its derived forms follow
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        e->vw_dirty = false;
+        return engine_visual_refresh(e, (hipStream_t)stream);
+    }
+    return RLCF_OK;
 }
 int rlcf_engine_ln_param_count(rlcf_engine* e) { return e ? e->ln_count : 0; }
 int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {

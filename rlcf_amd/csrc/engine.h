@@ -63,6 +63,7 @@ struct ClipModel {
     TowerW vis, txt;
     ResNetW rn;                            // image tower when cfg.vision_stages[0] > 0
     const float *conv_w = nullptr;         // [Wv, Kp] zero padded
+    const float *conv_raw = nullptr;       // visual.conv1.weight as stored [Wv, 3*ps*ps] (== conv_w when Kp == 3*ps*ps)
     const float *cls = nullptr, *vpos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr, *lnpost_b = nullptr;
     const float *vprojT = nullptr;         // [D, Wv]
     const float *tok_emb = nullptr, *tpos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
@@ -74,6 +75,12 @@ struct ClipModel {
     struct SplitW { void *hi, *lo; float inv_scale; };                    // W * 2^s = hi + lo; inv_scale = 2^-s
     std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 mode)
 };
+
+// full image-encoder tuning (CLIPCLS_TTA only_norm=False): one entry per non-LayerNorm visual tensor of the flat buffer, and the
+// derived copies (padded / transposed / split-f16) that have to follow the live weights after an optimizer step or a reset
+struct VwSlot { size_t off, numel; };
+struct VwRefresh { int kind; const float* src; float* dst; size_t rows, cols; void *hi, *lo; float scale; int il; };
+enum { VW_PAD = 0, VW_TRANSPOSE = 1, VW_SPLIT = 2 };
 
 struct rlcf_engine {
     int precision = RLCF_PREC_F32, max_views = 0, max_classes = 0;
@@ -110,6 +117,14 @@ struct rlcf_engine {
     DevBuf ln_params, ln_init, ln_grad, ln_m, ln_v, vit_inv_norm, cls_row_idx, dfeat, dcls, txt0T, ln_feat;
     int ln_count = 0;                // (4*layers + 4) * Wv
     size_t bwd_elems = 0;
+    // full image-encoder tuning: class_embedding, positional_embedding, proj, conv1.weight, then per block in_proj_weight, in_proj_bias,
+    // out_proj.weight, out_proj.bias, c_fc.weight, c_fc.bias, c_proj.weight, c_proj.bias (each slot 64-float aligned) in one flat buffer
+    DevBuf vw, vw_init, vw_grad, vw_m, vw_v, vw_clip, vw_mom;
+    size_t vw_count = 0;
+    bool vw_dirty = false;           // live weights differ from the reset state
+    std::vector<VwSlot> vw_slots;
+    std::vector<VwRefresh> vw_refresh;
+    DevBuf wg_yt, wg_xt, w_hi;       // weight-gradient GEMM operands: dY^T, X^T (token dimension padded) and the split copy of X^T
     DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
     DevBuf bwd_amax;                 // max|dF| handed from one backward GEMM's epilogue to the next one's operand scale
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
@@ -149,6 +164,9 @@ int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int
 int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx, hipStream_t st);
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int engine_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int engine_visual_enable(rlcf_engine* e, hipStream_t st);
+int engine_visual_refresh(rlcf_engine* e, hipStream_t st);
 int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                         hipStream_t st);
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,

@@ -226,6 +226,9 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     m.split_of.clear();
     const int Wt = c.text_width, D = c.embed_dim;
     const bool rn = is_resnet(c);
+    if (which == RLCF_STUDENT) {          // the flat tunable buffer pointed into the previous weights
+        e->vw_count = 0; e->vw_dirty = false; e->vw_slots.clear(); e->vw_refresh.clear();
+    }
     if (rn) {
         if (which == RLCF_STUDENT) e->ln_count = 0;       // no LayerNorm to tune: the LN path refuses a ResNet student
         TRY(resnet_finalize(e, m, st));
@@ -236,6 +239,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     m.tokens = (c.image_resolution / ps) * (c.image_resolution / ps) + 1;
     const float* conv = rawp(m, "visual.conv1.weight", (size_t)Wv * K);
     NEED(conv);
+    m.conv_raw = conv;
     if (m.Kp == K) m.conv_w = conv;
     else {
         m.derived.emplace_back();
@@ -352,6 +356,113 @@ static int bwd_ensure(rlcf_engine* e, int T, int width) {
     return RLCF_OK;
 }
 
+// ------------------------------------------------------------------ full image-encoder tuning
+// CLIPCLS_TTA(only_norm=False): parameters() = clip_model.visual.parameters() (TPT/clip/custom_clip.py:477-479), what
+// scripts/rlcf-tune.sh runs (`--tune_norm` defaults to 0, params.py:73).  The LayerNorm tensors stay in e->ln_params; every other
+// visual tensor moves into ONE flat buffer (AdamW = one launch, reset = one copy) and the towers read the weights from it.
+int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
+    if (e->vw_count) return RLCF_OK;
+    ClipModel& m = e->model[RLCF_STUDENT];
+    if (!m.finalized) { rlcf_set_error("student model not finalized"); return RLCF_ERR_STATE; }
+    if (is_resnet(m.cfg)) { rlcf_set_error("image-encoder tuning needs a VisionTransformer student (ModifiedResNet: not built)"); return RLCF_ERR_STATE; }
+    const rlcf_clip_cfg& c = m.cfg;
+    const size_t Wv = c.vision_width, D = c.embed_dim, K = (size_t)3 * c.vision_patch_size * c.vision_patch_size, W2 = Wv * Wv;
+    struct Item { const float** slot; size_t numel; };
+    std::vector<Item> items = {{&m.cls, Wv}, {&m.vpos, (size_t)m.tokens * Wv}, {&m.vproj, Wv * D}, {&m.conv_raw, Wv * K}};
+    for (BlockW& b : m.vis.blk) {
+        items.push_back({&b.in_w, 3 * W2}); items.push_back({&b.in_b, 3 * Wv}); items.push_back({&b.out_w, W2}); items.push_back({&b.out_b, Wv});
+        items.push_back({&b.fc_w, 4 * W2}); items.push_back({&b.fc_b, 4 * Wv}); items.push_back({&b.proj_w, 4 * W2}); items.push_back({&b.proj_b, Wv});
+    }
+    size_t total = 0;
+    e->vw_slots.clear();
+    for (const Item& it : items) { e->vw_slots.push_back(VwSlot{total, it.numel}); total += (it.numel + 63) / 64 * 64; }
+    const size_t nb = total * sizeof(float);
+    for (DevBuf* d : {&e->vw, &e->vw_init, &e->vw_grad, &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom}) TRY(d->ensure(nb));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->vw.p, 0, nb, st));
+    for (size_t i = 0; i < items.size(); ++i) {
+        const float* old = *items[i].slot;
+        float* dst = e->vw.as<float>() + e->vw_slots[i].off;
+        RLCF_HIP_CHECK(hipMemcpyAsync(dst, old, items[i].numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (items[i].slot == &m.conv_raw && m.conv_w == old) m.conv_w = dst;       // Kp == K: the GEMM reads conv1.weight as stored
+        auto sp = m.split_of.find(old);
+        if (sp != m.split_of.end()) { const ClipModel::SplitW s = sp->second; m.split_of.erase(sp); m.split_of[dst] = s; }
+        *items[i].slot = dst;
+    }
+    for (DevBuf* d : {&e->vw_init, &e->vw_clip, &e->vw_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->vw.p, nb, hipMemcpyDeviceToDevice, st));
+    // derived copies that must follow the live weights (the pre-scale of a split copy stays the one of the checkpoint: a tuning
+    // step moves a weight by ~lr, far inside the 2^6 headroom of the scaled f16 range)
+    e->vw_refresh.clear();
+    auto add_split = [&](const float* w, size_t numel) {
+        auto it = m.split_of.find(w);
+        if (it != m.split_of.end())
+            e->vw_refresh.push_back(VwRefresh{VW_SPLIT, w, nullptr, numel, 0, it->second.hi, it->second.lo, 1.0f / it->second.inv_scale,
+                                              it->second.lo == lo_of(it->second.hi)});
+    };
+    auto add_T = [&](const float* w, const float* wT, size_t rows, size_t cols) {
+        if (!wT) return;
+        e->vw_refresh.push_back(VwRefresh{VW_TRANSPOSE, w, (float*)wT, rows, cols, nullptr, nullptr, 1.f, 0});
+        add_split(wT, rows * cols);
+    };
+    if (m.conv_w != m.conv_raw) e->vw_refresh.push_back(VwRefresh{VW_PAD, m.conv_raw, (float*)m.conv_w, Wv, K, nullptr, nullptr, 1.f, 0});
+    add_split(m.conv_w, Wv * m.Kp);
+    add_T(m.vproj, m.vprojT, Wv, D);
+    for (BlockW& b : m.vis.blk) {
+        add_split(b.in_w, 3 * W2); add_split(b.out_w, W2); add_split(b.fc_w, 4 * W2); add_split(b.proj_w, 4 * W2);
+        add_T(b.in_w, b.in_wT, 3 * Wv, Wv); add_T(b.out_w, b.out_wT, Wv, Wv); add_T(b.fc_w, b.fc_wT, 4 * Wv, Wv); add_T(b.proj_w, b.proj_wT, Wv, 4 * Wv);
+    }
+    e->vw_count = total;
+    e->vw_dirty = false;
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    return RLCF_OK;
+}
+
+int engine_visual_refresh(rlcf_engine* e, hipStream_t st) {
+    const int Kp = e->model[RLCF_STUDENT].Kp;
+    for (const VwRefresh& r : e->vw_refresh) {
+        if (r.kind == VW_PAD) {
+            pad_rows_kernel<<<dim3(1024), dim3(256), 0, st>>>(r.src, r.dst, (int)r.rows, (int)r.cols, Kp);
+            RLCF_LAUNCH_CHECK();
+        } else if (r.kind == VW_TRANSPOSE) {
+            TRY(launch_transpose(r.src, r.dst, (int)r.rows, (int)r.cols, st));
+        } else {
+            TRY(launch_split_f16x2(r.src, r.hi, r.lo, (int64_t)r.rows, st, r.scale, r.il));
+        }
+    }
+    return RLCF_OK;
+}
+
+// Linear weight gradient dW[N,K] = dY[T,N]^T X[T,K] (+ db[N] += column sums of dY): both operands are transposed to K-major
+// [*, Tp] (token dimension zero padded to the GEMM's K granule) and go through the NT GEMM of the engine's precision; in
+// split-f16 mode dY^T is scaled by a power of two found on the device (gradients sit far below f16's normal range).
+static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X, int ldx, int K, int T, float* dW, float* db, hipStream_t st) {
+    const int Tp = (T + 31) / 32 * 32;
+    TRY(e->wg_yt.ensure((size_t)N * Tp * sizeof(float))); TRY(e->wg_xt.ensure((size_t)K * Tp * sizeof(float)));
+    float *yt = e->wg_yt.as<float>(), *xt = e->wg_xt.as<float>();
+    TRY(launch_transpose_pad(dY, ldy, yt, T, N, Tp, st));
+    TRY(launch_transpose_pad(X, ldx, xt, T, K, Tp, st));
+    e->last_flops += 2.0 * N * K * T;
+    int rc;
+    if (e->precision == RLCF_PREC_F16X3 && N >= 256 && (size_t)N * Tp <= e->a_split_elems) {
+        TRY(e->w_hi.ensure((size_t)K * Tp * 4));
+        TRY(e->dyn.ensure(3 * sizeof(float)));
+        TRY(launch_split_f16x2_dyn(yt, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)N * Tp, e->dyn.as<float>(), st, 1));
+        TRY(launch_split_f16x2(xt, e->w_hi.p, lo_of(e->w_hi.p), (int64_t)K * Tp, st, 1.0f, 1));
+        const int slot = prof_begin(st, 2.0 * N * K * Tp);
+        rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * Tp, e->w_hi.p, lo_of(e->w_hi.p), 2 * Tp, nullptr, nullptr, 0, nullptr, 0, dW, K,
+                               nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2);
+        prof_end(slot, st, g_last_x3_variant);
+    } else {
+        GemmArgs g{};
+        g.A = yt; g.lda = Tp; g.W = xt; g.ldw = Tp; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = Tp; g.alpha = 1.f; g.epilogue = RLCF_EPI_NONE;
+        const int slot = prof_begin(st, 2.0 * N * K * Tp);
+        rc = launch_gemm_f32(g, st);
+        prof_end(slot, st);
+    }
+    TRY(rc);
+    if (db) TRY(launch_colsum(dY, ldy, T, N, db, st));
+    return RLCF_OK;
+}
+
 // ------------------------------------------------------------------ transformer passes
 // Transformer.forward, TPT/clip/model.py:195-203 with ResidualAttentionBlock :189-192.
 // x0: [T,W] input (ws.x, or sv[0].x when saving).  Result always lands in ws.x.
@@ -418,29 +529,48 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
 }
 
 // dX-only backward of the above (all weights frozen: TPT/tpt_cls_rl.py:103-105); dX in/out in e->dX.
+// wgrad (full image-encoder tuning): flat gradient buffer of the engine's non-LayerNorm visual parameters (e->vw_slots layout);
+// the Linear weight / bias gradients of every block are then formed next to the dX chain, from the same saved activations.
+static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X, int ldx, int K, int T, float* dW, float* db, hipStream_t st);
 static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_keys,
                                 long attn_pairs, int causal, int T, hipStream_t st, float* ln_grad = nullptr, int max_q_len = 0,
-                                int group_rows = 0, int group_stride = 0) {
+                                int group_rows = 0, int group_stride = 0, float* wgrad_base = nullptr) {
     const int W = w.width, L = w.layers;
     float *dX = e->dX.as<float>(), *dA = e->dA.as<float>(), *dH = e->dH.as<float>(), *dF = e->dF.as<float>(), *dQKV = e->dQKV.as<float>();
     for (int l = L - 1; l >= 0; --l) {
         const BlockW& b = w.blk[l];
         const SavedLayer& s = ws.sv[l];
+        // slots of block l: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, c_fc.weight, c_fc.bias, c_proj.weight, c_proj.bias
+        float* G[8] = {};
+        if (wgrad_base) for (int i = 0; i < 8; ++i) G[i] = wgrad_base + e->vw_slots[4 + 8 * l + i].off;
+        if (wgrad_base) {                  // c_proj: y = QuickGELU(f) Wp^T + b, dY = dX (gradient at the block output)
+            TRY(launch_quickgelu(s.f, ws.f.as<float>(), (int64_t)T * 4 * W, st));
+            TRY(wgrad(e, dX, W, W, ws.f.as<float>(), 4 * W, 4 * W, T, G[6], G[7], st));
+        }
         TRY(e->bwd_amax.ensure(sizeof(float)));
         RLCF_HIP_CHECK(hipMemsetAsync(e->bwd_amax.p, 0, sizeof(float), st));
         TRY(gemm(e, dX, W, b.proj_wT, W, nullptr, nullptr, 0, s.f, 4 * W, dF, 4 * W, T, 4 * W, W, 1.f, RLCF_EPI_QUICKGELU_BWD, st, 1.0f, true,
                  nullptr, (unsigned int*)e->bwd_amax.p));                 // max|dF| comes out of the epilogue ...
+        if (wgrad_base) {                  // c_fc: pre-activation = LN2(x1) Wfc^T + b
+            TRY(launch_layernorm_fwd(s.x1, b.ln2_w, b.ln2_b, ws.h.as<float>(), T, W, st));
+            TRY(wgrad(e, dF, 4 * W, 4 * W, ws.h.as<float>(), W, W, T, G[4], G[5], st));
+        }
         TRY(gemm(e, dF, 4 * W, b.fc_wT, 4 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st, 1.0f, true,
                  e->bwd_amax.as<float>()));                               // ... and scales the next operand without another pass
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
         const LnRef g2w = ln_ref(e, b.ln2_w, 1), g1w = ln_ref(e, b.ln1_w, 1);       // per-sample LayerNorm sets (batched LN tuning, step > 0)
         TRY(launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride,
                                  group_rows > 0 ? g2w.group_stride : 0));
+        if (wgrad_base) TRY(wgrad(e, dX, W, W, s.a, W, W, T, G[2], G[3], st));      // out_proj: x1 = x + a Wo^T + b, dY = d x1
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
+        if (wgrad_base) {                  // in_proj: qkv = LN1(x) Win^T + b
+            TRY(launch_layernorm_fwd(s.x, b.ln1_w, b.ln1_b, ws.h.as<float>(), T, W, st));
+            TRY(wgrad(e, dQKV, 3 * W, 3 * W, ws.h.as<float>(), W, W, T, G[0], G[1], st));
+        }
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         TRY(launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
                                  group_rows > 0 ? g1w.group_stride : 0));
@@ -1051,8 +1181,9 @@ static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, 
 }
 // d loss / d (visual LN parameters) given dlogits [n, C] of the n views whose activations vit_forward_saved holds.
 // groups > 1: the n views belong to `groups` test samples (n / groups consecutive views each) and ln_grad is [groups, ln_count]
+// wgrad_base (single sample only): also the gradient of every other visual parameter, into the flat e->vw_slots layout
 static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int n, const float* dlogits, float* ln_grad, hipStream_t st,
-                           int groups = 1) {
+                           int groups = 1, float* wgrad_base = nullptr) {
     const rlcf_clip_cfg& c = m.cfg;
     const int Wv = c.vision_width, tok = m.tokens, T = n * tok, D = c.embed_dim, C = e->C, L = c.vision_layers;
     const int per = n / groups, gs = groups > 1 ? e->ln_count : 0;
@@ -1062,6 +1193,8 @@ static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int
     // d feat = scale * dlogits @ class_features  (logits = scale * feat @ class_features^T, custom_clip.py:429-430)
     TRY(launch_dimg(dlogits, e->txt0.as<float>(), n, C, D, m.logit_scale_exp, e->dfeat.as<float>(), st));
     TRY(launch_l2norm_bwd(feats, e->dfeat.as<float>(), e->vit_inv_norm.as<float>(), e->dfeat.as<float>(), n, D, st));
+    if (wgrad_base)                        // visual.proj [Wv, D]: feat = ln_post(cls) @ proj  (model.py:237-238)
+        TRY(wgrad(e, e->cls_ln.as<float>(), Wv, Wv, e->dfeat.as<float>(), D, D, n, wgrad_base + e->vw_slots[2].off, nullptr, st));
     TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
     float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
     const LnRef gpw = ln_ref(e, m.lnpost_w, 1);
@@ -1070,9 +1203,25 @@ static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int
     RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
     TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
     TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok,
-                             groups > 1 ? per * tok : 0, gs));
-    TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st,
-                                groups > 1 ? per : 0, gs));
+                             groups > 1 ? per * tok : 0, gs, wgrad_base));
+    if (!wgrad_base) {
+        TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st,
+                                    groups > 1 ? per : 0, gs));
+        return RLCF_OK;
+    }
+    // through ln_pre into the embedding (model.py:224-229): pre = [class_embedding | conv1(patches)] + positional_embedding
+    float *pre = e->dH.as<float>(), *dpre = e->dA.as<float>(), *dpatch = e->dF.as<float>();      // backward scratch, free by now
+    const int G2 = tok - 1, K = 3 * m.cfg.vision_patch_size * m.cfg.vision_patch_size;
+    TRY(launch_vit_preln(e->patch_out.as<float>(), m.cls, m.vpos, pre, n, tok, Wv, st));
+    TRY(launch_layernorm_bwd(pre, m.lnpre_w, e->dX.as<float>(), nullptr, dpre, ln_grad, ln_grad + Wv, T, Wv, st));
+    float* gpos = wgrad_base + e->vw_slots[1].off;
+    TRY(launch_colsum(dpre, tok * Wv, n, tok * Wv, gpos, st));                                     // d positional_embedding = sum over views
+    RLCF_HIP_CHECK(hipMemcpyAsync(wgrad_base + e->vw_slots[0].off, gpos, Wv * sizeof(float), hipMemcpyDeviceToDevice, st));   // d class_embedding = its row 0
+    for (int v = 0; v < n; ++v)
+        RLCF_HIP_CHECK(hipMemcpyAsync(dpatch + (size_t)v * G2 * Wv, dpre + ((size_t)v * tok + 1) * Wv, (size_t)G2 * Wv * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+    // conv1.weight [Wv, 3*ps*ps] (stride == kernel convolution = patches @ W^T, model.py:224): the patch matrix of vit_forward_saved is still there
+    TRY(wgrad(e, dpatch, Wv, Wv, e->patches.as<float>(), m.Kp, K, n * G2, wgrad_base + e->vw_slots[3].off, nullptr, st));
     return RLCF_OK;
 }
 
@@ -1161,7 +1310,22 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
     return RLCF_OK;
 }
 
+static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full);
 int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+    return tta_sample_backbone(e, views, N, a, out, st, false);
+}
+// every visual parameter tuned (CLIPCLS_TTA only_norm=False, custom_clip.py:477-479)
+int engine_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+    TRY(engine_visual_enable(e, st));
+    return tta_sample_backbone(e, views, N, a, out, st, true);
+}
+static int visual_reset(rlcf_engine* e, hipStream_t st) {      // visual.load_state_dict(initial_state_dict) for the flat buffer
+    if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    e->vw_dirty = false;
+    return engine_visual_refresh(e, st);
+}
+static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
@@ -1180,6 +1344,12 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
+    const size_t vb = full ? e->vw_count * sizeof(float) : 0;
+    if (full) {
+        TRY(visual_reset(e, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_m.p, 0, vb, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_v.p, 0, vb, st));
+    }
     const float* cls_feat = e->txt0.as<float>();           // cached class text features (custom_clip.py:405-409)
     for (int j = 0; j < a->tta_steps; ++j) {
         if (j == 0) {
@@ -1198,8 +1368,11 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
         TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
                                e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
-        TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st));
+        if (full) RLCF_HIP_CHECK(hipMemsetAsync(e->vw_grad.p, 0, vb, st));
+        TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st, 1,
+                            full ? e->vw_grad.as<float>() : nullptr));
         if (j == 0) {
+            if (full) COPY_OUT(out->vis_grad, e->vw_grad.p, vb);
             COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
             COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
             COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
@@ -1209,8 +1382,15 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
         }
         TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
                          a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+        if (full) {
+            TRY(launch_adamw(e->vw.as<float>(), e->vw_grad.as<float>(), e->vw_m.as<float>(), e->vw_v.as<float>(), (int64_t)e->vw_count, j + 1,
+                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+            e->vw_dirty = true;
+            TRY(engine_visual_refresh(e, st));
+        }
     }
     COPY_OUT(out->ln_after, e->ln_params.p, nb);
+    if (full) COPY_OUT(out->vis_after, e->vw.p, vb);
     if (!a->skip_final) {
         // final clean-view inference with the adapted LayerNorms (tune_cls_rl.py:219-221)
         TRY(engine_encode_image(e, RLCF_STUDENT, views, 1, e->img_feat.as<float>(), st));
@@ -1219,7 +1399,8 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
         COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
         COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
     }
-    // leave the engine in its pristine state for the prompt path (which assumes frozen, pristine LayerNorms)
+    // leave the engine in its pristine state for the prompt path (which assumes frozen, pristine weights)
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    if (full) TRY(visual_reset(e, st));
     return RLCF_OK;
 }

@@ -30,6 +30,10 @@ int launch_ctx_grad(const float* dX, const int32_t* ctx_rows, int n_copies, int 
 // dtxt[c,:] = scale * sum_i dlogits[i,c] * img[i,:]
 int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int D, float scale, float* dtxt, hipStream_t st);
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);   // out[cols,rows]
+// full image-encoder tuning (weight gradients): out[cols, ld_out] = in[rows, cols]^T zero padded; out[c] += column sums; ln_pre input
+int launch_transpose_pad(const float* in, int ld_in, float* out, int rows, int cols, int ld_out, hipStream_t st);
+int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st);
+int launch_vit_preln(const float* patch_out, const float* cls, const float* pos, float* pre, int n, int tokens, int width, hipStream_t st);
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
                              int causal, float* out, float* lse, hipStream_t st, void* out_hi = nullptr, void* out_lo = nullptr);

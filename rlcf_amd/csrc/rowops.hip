@@ -2,6 +2,7 @@
 // assembly, L2 normalisation, row gathers.  One wave (64 lanes) per row, shuffle reductions,
 // float4 accesses where the width allows.
 #include "kernels.h"
+#include <algorithm>
 
 #define ROWS_PER_BLOCK 4
 // split-f16 pair outputs may be interleaved per 32-column block: column c of a row of `width` sits at row*2*width + (c/32)*64 + c%32
@@ -506,6 +507,67 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 }
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
     transpose_kernel<<<dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st>>>(in, out, rows, cols);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// out[c, 0..ld_out) = in[0..rows, c] followed by zeros (ld_out >= rows): the K-major operands of a weight-gradient GEMM
+// dW = dY^T X, with the token dimension padded to the GEMM's K granule
+__global__ void transpose_pad_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int rows, int cols, int ld_out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int c = bx + j, r = by + threadIdx.x;
+        if (r < ld_out && c < cols) out[(size_t)c * ld_out + r] = tile[threadIdx.x][j];
+    }
+}
+int launch_transpose_pad(const float* in, int ld_in, float* out, int rows, int cols, int ld_out, hipStream_t st) {
+    RLCF_ARG_CHECK(in && out && rows > 0 && cols > 0 && ld_out >= rows && ld_in >= cols);
+    transpose_pad_kernel<<<dim3((cols + 31) / 32, (ld_out + 31) / 32), dim3(32, 8), 0, st>>>(in, ld_in, out, rows, cols, ld_out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// out[c] += sum_r in[r, c]  (bias gradients; out pre-zeroed by the caller): 64 columns x 4 row lanes per block, COLSUM_ROWS rows per block
+#define COLSUM_ROWS 64
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, int rows, int cols, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+    float s = 0.f;
+    if (c < cols) for (int r = r0 + q; r < r1; r += 4) s += in[(size_t)r * ld + c];
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st) {
+    RLCF_ARG_CHECK(in && out && rows > 0 && cols > 0 && ld >= cols);
+    colsum_kernel<<<dim3((cols + 63) / 64, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0, st>>>(in, ld, rows, cols, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// input of ln_pre: pre[b, t, :] = (t == 0 ? class_embedding : patch_out[b, t-1, :]) + positional_embedding[t, :]  (model.py:225-229)
+__global__ void vit_preln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls, const float* __restrict__ pos,
+                                 float* __restrict__ pre, long total, int tokens, int width) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % width);
+        const long row = i / width;
+        const int tok = (int)(row % tokens);
+        const long b = row / tokens;
+        const float v = tok == 0 ? cls[c] : patch_out[(b * (tokens - 1) + tok - 1) * width + c];
+        pre[i] = v + pos[(size_t)tok * width + c];
+    }
+}
+int launch_vit_preln(const float* patch_out, const float* cls, const float* pos, float* pre, int n, int tokens, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(patch_out && cls && pos && pre && n > 0);
+    const long total = (long)n * tokens * width;
+    vit_preln_kernel<<<dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st>>>(patch_out, cls, pos, pre, total, tokens, width);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

@@ -146,22 +146,23 @@ def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, cl
 
 class CLIPCLS_TTA(nn.Module):
     """TPT/clip/custom_clip.py:364-497 — CLIP classification with test-time adaptation of the image encoder.
-    Built: `only_visual=True, only_norm=True` (BASELINE configs[2], the `--tune_norm 1` setting): the tunable set is every
-    visual LayerNorm weight/bias.  `parameters()` returns ONE flat tensor holding them in named_parameters order
-    ([ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w, ln_post.b]) instead of 4L+4 tensors."""
+    `only_visual=True` only.  only_norm=True (BASELINE configs[2], the `--tune_norm 1` setting): the tunable set is every
+    visual LayerNorm weight/bias and `parameters()` returns ONE flat tensor holding them in named_parameters order
+    ([ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w, ln_post.b]) instead of 4L+4 tensors.
+    only_norm=False (the reference default, what scripts/rlcf-tune.sh runs): every visual parameter is tuned; `parameters()`
+    returns that LayerNorm tensor plus ONE flat tensor with all other visual tensors (Engine.visual_layout())."""
 
     def __init__(self, device, classnames, arch="ViT-L/14", prompt_prefix=None, only_visual=True, momentum_update=False,
                  update_freq=256, update_w=1.0, momentum=0.9999, only_norm=False):
         super().__init__()
-        if not only_visual or not only_norm:
-            raise NotImplementedError("full image-encoder / text tuning is not built yet: only only_visual=True, only_norm=True "
-                                      "(SURVEY.md §8 a14)")
+        if not only_visual:
+            raise NotImplementedError("text-encoder tuning is not built: only_visual=True only (SURVEY.md §8 a14)")
         self.clip_model, _, _ = clip_store.load(arch, device=device)
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.prompt_prefix = device, prompt_prefix
         self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
         self.update_freq, self.update_w, self.momentum, self.update_counter = update_freq, update_w, momentum, 0
-        self._ln = None
+        self._ln = self._vis = None
         self._set_classnames(classnames)
 
     def _set_classnames(self, classnames):
@@ -186,12 +187,23 @@ class CLIPCLS_TTA(nn.Module):
             self._ln = nn.Parameter(self._ln_init.clone())
         return self._ln
 
+    @property
+    def vis(self) -> nn.Parameter:
+        """every non-LayerNorm visual parameter in one flat tensor (only_norm=False)"""
+        if self._vis is None:
+            eng = runtime.SESSION.engine()
+            self._vis_init = eng.visual_params(1)
+            self._vis = nn.Parameter(self._vis_init.clone())
+        return self._vis
+
     def parameters(self, recurse: bool = True):            # custom_clip.py:477-485
-        return [self.ln]
+        return [self.ln] if self.only_norm else [self.ln, self.vis]
 
     @torch.no_grad()
     def reset(self):                                       # custom_clip.py:456-458
         self.ln.data.copy_(self._ln_init)
+        if not self.only_norm:
+            self.vis.data.copy_(self._vis_init)
 
     @torch.no_grad()
     def reset_classnames_and_state(self, classnames, arch):   # custom_clip.py:434-454
@@ -212,8 +224,12 @@ class CLIPCLS_TTA(nn.Module):
             self.update_counter = 0
         eng = runtime.SESSION.engine()
         eng.momentum_update(self.ln.data, self.momentum, self.update_w, apply)
+        if not self.only_norm:
+            eng.momentum_update_visual(self.vis.data, self.momentum, self.update_w, apply)
         if apply:
             self._ln_init = eng.ln_params(pristine=True)
+            if not self.only_norm:
+                self._vis_init = eng.visual_params(1)
 
     @torch.no_grad()
     def forward(self, image):
@@ -221,7 +237,12 @@ class CLIPCLS_TTA(nn.Module):
         backward are fused inside rlcf_tta_sample_ln, called by rlcf_amd.tpt_cls_rl.test_time_tuning)."""
         eng = runtime.SESSION.engine(image.shape[0])
         eng.set_ln_params(self.ln.data)
+        adapted = not self.only_norm and not torch.equal(self.vis.data, self._vis_init)
+        if adapted:
+            eng.set_visual_params(self.vis.data)
         img = eng.encode_image(L.STUDENT, image)
         out = eng.logits(img, eng.text_features(runtime.SESSION.ctx_init.to(img.device)))
         eng.set_ln_params(self._ln_init)
+        if adapted:
+            eng.set_visual_params(self._vis_init)
         return out

@@ -220,6 +220,74 @@ class Engine:
         L.check(self.lib.rlcf_tta_sample_ln(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_ln")
         return o
 
+    # ---- full image-encoder tuning (CLIPCLS_TTA only_norm=False, TPT/clip/custom_clip.py:477-479)
+    def visual_layout(self):
+        """[(state-dict key, offset, numel)] of the flat non-LayerNorm visual parameter vector (include/rlcf_hip.h)."""
+        layers = self.student.vision_layers if isinstance(self.student.vision_layers, int) else 0     # (ModifiedResNet: the call refuses)
+        n = 4 + 8 * layers
+        off, num = (C.c_int64 * n)(), (C.c_int64 * n)()
+        got = self.lib.rlcf_engine_visual_param_layout(self.h, off, num, n, _stream())
+        if got < 0:
+            L.check(got, "visual_param_layout")
+        names = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight"]
+        for i in range(layers):
+            b = f"visual.transformer.resblocks.{i}."
+            names += [b + "attn.in_proj_weight", b + "attn.in_proj_bias", b + "attn.out_proj.weight", b + "attn.out_proj.bias",
+                      b + "mlp.c_fc.weight", b + "mlp.c_fc.bias", b + "mlp.c_proj.weight", b + "mlp.c_proj.bias"]
+        assert got == len(names)
+        return [(k, int(off[i]), int(num[i])) for i, k in enumerate(names)]
+
+    def merge_visual(self, ln_vec: torch.Tensor, vis_vec: torch.Tensor) -> torch.Tensor:
+        """LayerNorm vector + flat vector -> one vector in clip_model.visual.named_parameters() order (what the reference's
+        optimizer sees with only_norm=False; oracle.rlcf_ref.visual_param_keys)."""
+        Wv, Lv = self.student.vision_width, self.student.vision_layers
+        ln = ln_vec.view(-1, Wv)                                   # rows: ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x L, ln_post.w/.b
+        t = {k: vis_vec[o: o + n] for k, o, n in self.visual_layout()}
+        out = [t["visual.class_embedding"], t["visual.positional_embedding"], t["visual.proj"], t["visual.conv1.weight"], ln[0], ln[1]]
+        for i in range(Lv):
+            b = f"visual.transformer.resblocks.{i}."
+            out += [t[b + "attn.in_proj_weight"], t[b + "attn.in_proj_bias"], t[b + "attn.out_proj.weight"], t[b + "attn.out_proj.bias"],
+                    ln[2 + 4 * i], ln[3 + 4 * i], t[b + "mlp.c_fc.weight"], t[b + "mlp.c_fc.bias"], t[b + "mlp.c_proj.weight"],
+                    t[b + "mlp.c_proj.bias"], ln[4 + 4 * i], ln[5 + 4 * i]]
+        out += [ln[2 + 4 * Lv], ln[3 + 4 * Lv]]
+        return torch.cat([x.reshape(-1) for x in out])
+
+    def visual_params(self, which: int = 0) -> torch.Tensor:
+        """flat vector: 0 live, 1 reset state, 2 checkpoint, 3 momentum state"""
+        out = torch.empty(int(self.lib.rlcf_engine_visual_param_count(self.h, _stream())), device=self.device)
+        L.check(self.lib.rlcf_engine_get_visual_params(self.h, _ptr(out), which, _stream()), "get_visual_params")
+        return out
+
+    def set_visual_params(self, p: torch.Tensor) -> None:
+        p = p.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_set_visual_params(self.h, _ptr(p), _stream()), "set_visual_params")
+
+    def momentum_update_visual(self, current: torch.Tensor, momentum: float, update_w: float, apply: bool) -> None:
+        cur = current.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_momentum_update_visual(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0,
+                                                            _stream()), "momentum_update_visual")
+
+    def tta_sample_visual(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
+        """Full image-encoder tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=False), scripts/rlcf-tune.sh)."""
+        views = views.to(self.device, torch.float32).contiguous()
+        N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
+        n_sel = int(N * cfg.selection_p)
+        npar = int(self.lib.rlcf_engine_ln_param_count(self.h))
+        nvis = int(self.lib.rlcf_engine_visual_param_count(self.h, _stream()))
+        if nvis <= 0:
+            L.check(-1, "tta_sample_visual (visual_param_count)")
+        dev = self.device
+        o = dict(final_logits=torch.empty(1, Cn, device=dev), top5=torch.empty(5, dtype=torch.int32, device=dev),
+                 ln_after=torch.empty(npar, device=dev), ln_grad=torch.empty(npar, device=dev),
+                 vis_after=torch.empty(nvis, device=dev), vis_grad=torch.empty(nvis, device=dev),
+                 logits=torch.empty(N, Cn, device=dev), selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
+                 topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n_sel * K, device=dev),
+                 rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
+        co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
+        a = cfg.c_args(skip_final)
+        L.check(self.lib.rlcf_tta_sample_visual(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_visual")
+        return o
+
     def tta_batch(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):
         """views [count,N,3,R,R] -> top5 [count,5] (and final logits [count,C])."""
         views = views.to(self.device, torch.float32).contiguous()

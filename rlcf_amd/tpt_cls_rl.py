@@ -56,12 +56,16 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
         return
     cfg = _config(args, optimizer, reward_model)
     eng = runtime.SESSION.engine(inputs.shape[0])
-    if not hasattr(model, "prompt_learner"):               # CLIPCLS_TTA: LayerNorm tuning (TPT/tune_cls_rl.py:31,217)
-        if not torch.equal(model.ln.data, model._ln_init):
-            raise NotImplementedError("LayerNorm tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
-        out = eng.tta_sample_ln(inputs, cfg, skip_final=True)
+    if not hasattr(model, "prompt_learner"):               # CLIPCLS_TTA: image-encoder tuning (TPT/tune_cls_rl.py:31,217)
+        full = not model.only_norm
+        if not torch.equal(model.ln.data, model._ln_init) or (full and not torch.equal(model.vis.data, model._vis_init)):
+            raise NotImplementedError("image-encoder tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
+        out = (eng.tta_sample_visual if full else eng.tta_sample_ln)(inputs, cfg, skip_final=True)
         with torch.no_grad():
             model.ln.data.copy_(out["ln_after"])
+            if full:
+                model.vis.data.copy_(out["vis_after"])
+                model.vis.grad = None
         model.ln.grad = None
         return
     pl = model.prompt_learner
@@ -120,7 +124,8 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
 def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1):
     """TPT/tpt_cls_rl.py:219-279: per test image: reset -> tune -> clean-view inference -> top-1/top-5.
     `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once."""
-    if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False):
+    full_visual = not hasattr(model, "prompt_learner") and not model.only_norm      # per-sample weights: one sample per pass
+    if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:
         model.eval()
         with torch.no_grad():
             model.reset()

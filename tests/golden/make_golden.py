@@ -29,6 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from rlcf_amd import synth  # noqa: E402
+from oracle import rlcf_ref as RR  # noqa: E402  (only for the key-order assertion of the only_norm=False cases)
 
 REF = "/root/reference/TPT"
 
@@ -207,9 +208,11 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
-def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4):
-    """TPT/tune_cls_rl.py harness body (:206-227) around the reference's own CLIPCLS_TTA(only_norm=True) and
-    test_time_tuning, with taps on the intermediates."""
+def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4, only_norm=True, full_vectors=True):
+    """TPT/tune_cls_rl.py harness body (:206-227) around the reference's own CLIPCLS_TTA(only_norm=...) and
+    test_time_tuning, with taps on the intermediates.  only_norm=False (the `--tune_norm 0` default, scripts/rlcf-tune.sh):
+    every visual parameter is tuned; the gradient / adapted-parameter vectors are then stored per tensor as L2 norms
+    (`vis_grad_l2`, `vis_delta_l2` = |after - pristine|) and, with full_vectors, as every 7th element of the concatenated vectors."""
     s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
     s_sd = synth.make_state_dict(s_geo, seed=11)
     r_sd = synth.make_state_dict(r_geo, seed=23)
@@ -217,10 +220,13 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     bank = Bank(s_geo, n_cls, n_ctx)
     ref.custom.tokenize = bank.tokenize
     model = ref.custom.CLIPCLS_TTA("cpu", bank.classnames, arch=student, prompt_prefix="a_photo_of_a", only_visual=True,
-                                   momentum_update=False, only_norm=True)
+                                   momentum_update=False, only_norm=only_norm)
     assert torch.equal(model.tokenized_prompts, bank.tokens)
     trainable = model.parameters()
-    names = [n for n, p in model.clip_model.visual.named_parameters() if "ln" in n or "bn" in n]
+    names = [n for n, p in model.clip_model.visual.named_parameters() if not only_norm or "ln" in n or "bn" in n]
+    if not only_norm:
+        assert ["visual." + n for n in names] == RR.visual_param_keys(s_sd), "oracle key order != named_parameters order"
+    pristine = {n: p.detach().clone() for n, p in model.clip_model.visual.named_parameters()}
     optimizer = torch.optim.AdamW(trainable, hp["lr"], weight_decay=hp["weight_decay"])
     args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"], min_entropy_reg=0, min_entropy_w=0.2,
                                  gpu=None, tpt=True)
@@ -260,8 +266,14 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     rm.CLIPScore, rm.rewards_post_process = tap_score, tap_post
     pmap = dict(model.clip_model.visual.named_parameters())
     first_grads = {}
+
+    def keep_first(n):
+        def hook(g):                         # must return None: a returned tensor would REPLACE the gradient
+            first_grads.setdefault(n, g.detach().clone())
+        return hook
+
     for n in names:
-        pmap[n].register_hook(lambda g, n=n: first_grads.setdefault(n, g.detach().clone()))
+        pmap[n].register_hook(keep_first(n))
     model.reset()
     model.train()
     with warnings.catch_warnings():
@@ -273,9 +285,16 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     ref.tpt.select_confident_samples = orig_select
     out = dict(logits=taps["logits"], selected_idx=taps["selected_idx"], topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]),
                clip_score=taps["clip_score"], rewards=taps["rewards"],
-               ln_grad=torch.cat([first_grads[n].reshape(-1) for n in names]),
-               ln_after=torch.cat([pmap[n].detach().reshape(-1) for n in names]),
                final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0])
+    if only_norm:
+        out.update(ln_grad=torch.cat([first_grads[n].reshape(-1) for n in names]),
+                   ln_after=torch.cat([pmap[n].detach().reshape(-1) for n in names]))
+    elif full_vectors:      # every 7th element of the concatenated vectors (keeps the fixture small)
+        out.update(vis_grad_sample=torch.cat([first_grads[n].reshape(-1) for n in names])[::7].clone(),
+                   vis_after_sample=torch.cat([pmap[n].detach().reshape(-1) for n in names])[::7].clone())
+    if not only_norm:
+        out.update(vis_grad_l2=torch.stack([first_grads[n].double().norm() for n in names]).float(),
+                   vis_delta_l2=torch.stack([(pmap[n].detach() - pristine[n]).double().norm() for n in names]).float())
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
@@ -339,6 +358,12 @@ def gen_tokenizer(ref):
     return {"tokens": toks.numpy()}
 
 
+VIS_CASES = {      # CLIPCLS_TTA(only_norm=False): name -> (student, reward, views, classes, overrides, store full vectors)
+    "vis_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-4), True),
+    "vis_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-4, tta_steps=3), False),
+    "vis_small_s1": ("small", "small", 16, 40, dict(lr=1e-4, selection_p=0.25), False),
+    "vis_b16_s3": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-5, tta_steps=3, selection_p=0.25), False),   # rlcf-tune.sh: lr 1e-5, 3 steps
+}
 LN_CASES = {
     "ln_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3)),
     "ln_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3)),
@@ -504,6 +529,17 @@ def main():
             arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp)
             save("ln_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
                                                    bank_seed=7, n_ctx=4, n_samples=3, **hp))
+        elif grp in ("vis", "visb16"):
+            for name in ([k for k in VIS_CASES if "b16" not in k] if grp == "vis" else ["vis_b16_s3"]):
+                student, reward, n, c, over, full = VIS_CASES[name]
+                hp = dict(BASE_HP, **over)
+                t0 = time.time()
+                arrays = run_reference_ln(ref, student, reward, n, c, hp, only_norm=False, full_vectors=full)
+                meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23, view_seed=1000,
+                            bank_seed=7, n_ctx=4, only_norm=0, **hp)
+                save(name, arrays, meta)
+                print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
+                      f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")
         elif grp in ("ln", "lnb16", "lnl14"):
             for name in ([k for k in LN_CASES if "b16" not in k and "l14" not in k] if grp == "ln" else ["ln_b16_n8"] if grp == "lnb16" else ["ln_l14_n8"]):
                 student, reward, n, c, over = LN_CASES[name]

@@ -47,7 +47,7 @@ def test_engine_refuses_without_gpu(lib):
 def test_struct_layouts(lib):
     import ctypes as C
     assert C.sizeof(lib.ClipCfg) == 56 and C.sizeof(lib.Seq) == 16
-    assert C.sizeof(lib.TTAArgs) == 64 and C.sizeof(lib.TTAOut) == 15 * 8
+    assert C.sizeof(lib.TTAArgs) == 64 and C.sizeof(lib.TTAOut) == 17 * 8
 
 
 def test_bpe_tokenizer_matches_reference_fixture():

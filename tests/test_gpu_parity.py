@@ -776,6 +776,86 @@ def test_ln_tuning_matches_reference_fixture(L, dev, name, prec):
     eng.close()
 
 
+# ------------------------------------------------------------------------------ full image-encoder tuning (scripts/rlcf-tune.sh)
+def _tensor_norms(sd, keys, vec, base=None):
+    out, off = [], 0
+    for k in keys:
+        n = sd[k].numel()
+        v = vec[off: off + n].double()
+        if base is not None:
+            v = v - base[k].reshape(-1).double().to(v.device)
+        out.append(v.norm())
+        off += n
+    assert off == vec.numel()
+    return torch.stack(out).float().cpu()
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("name", ["vis_tiny_s1", "vis_tiny_s3", "vis_small_s1", "vis_b16_s3"])
+def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
+    """rlcf_tta_sample_visual vs the reference's CLIPCLS_TTA(only_norm=False) + test_time_tuning run (TPT/tune_cls_rl.py, the
+    configuration of scripts/rlcf-tune.sh): every visual parameter gets a gradient and an AdamW step."""
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated")
+    g, meta = load_golden(name)
+    from rlcf_amd.engine import Engine
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"], device=dev)
+    rsd = synth.make_state_dict(rg, meta["reward_seed"], device=dev)
+    eng = Engine(sg, rg, meta["n_views"], meta["n_cls"], prec)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]), device=dev)].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution, device=dev)
+    base = eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"].clone()        # LayerNorm path before: must be unaffected after
+    o = eng.tta_sample_visual(views, _cfg_from_meta(meta))
+    torch.cuda.synchronize()
+    c = lambda k: o[k].cpu()
+    assert c("selected_idx").tolist() == g["selected_idx"].tolist()
+    assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
+    torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    multi = meta["tta_steps"] > 1
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    keys = RR.visual_param_keys(ssd)
+    grad, after = eng.merge_visual(o["ln_grad"], o["vis_grad"]), eng.merge_visual(o["ln_after"], o["vis_after"])
+    torch.testing.assert_close(_tensor_norms(ssd, keys, grad), g["vis_grad_l2"], rtol=3e-3, atol=1e-9)
+    torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g["vis_delta_l2"], rtol=0.05 if multi else 0.01, atol=1e-7)
+    if "vis_grad_sample" in g:
+        gr, og = g["vis_grad_sample"], grad[::7].cpu()
+        assert (og - gr).norm() / gr.norm() < 2e-3
+        d = (after[::7].cpu() - g["vis_after_sample"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+    # against the oracle on the same inputs (small geometries): the whole gradient vector
+    if meta["student"] in ("tiny", "small") and not multi:
+        ref = RR.tta_sample_ln({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, views.cpu(), tokens,
+                               RR.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"],
+                                           lr=meta["lr"], weight_decay=meta["weight_decay"]), only_norm=False)
+        assert (grad.cpu() - ref["ln_grad"]).norm() / ref["ln_grad"].norm() < 2e-3
+    # the engine is back in its pristine state: the same call repeats, and the LayerNorm path gives what it gave before
+    o2 = eng.tta_sample_visual(views, _cfg_from_meta(meta))
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
+    torch.testing.assert_close(eng.visual_params(0), eng.visual_params(1), atol=0, rtol=0)
+    eng.close()
+
+
+def test_visual_tuning_refuses_resnet_student(L, dev):
+    from rlcf_amd.engine import Engine
+    sg, rg = synth.GEOMETRIES["tiny-rn32"], synth.GEOMETRIES["tiny-r"]
+    eng = Engine(sg, rg, 8, 16, 0)
+    eng.load_state_dict(L.STUDENT, synth.make_state_dict(sg, 11, device=dev))
+    eng.load_state_dict(L.REWARD, synth.make_state_dict(rg, 23, device=dev))
+    eng.finalize()
+    with pytest.raises(L.RlcfError, match="VisionTransformer"):
+        eng.visual_layout()
+    eng.close()
+
+
 @pytest.mark.parametrize("steps", [1, 3])
 @pytest.mark.parametrize("prec", [0, 2])
 @pytest.mark.parametrize("geo,reward,n_cls,p", [("tiny", "tiny-r", 16, 0.5), ("small", "small", 40, 0.25)])

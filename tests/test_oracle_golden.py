@@ -220,3 +220,49 @@ def test_ln_tuning_oracle_matches_reference(name):
         assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 1e-3
     d = (o["ln_after"] - g["ln_after"]).abs()
     assert (d > 0.1 * meta["lr"]).float().mean() < (0.05 if multi else 0.01)
+
+
+VIS_CASES = ["vis_tiny_s1", "vis_tiny_s3", "vis_small_s1"]
+
+
+def vis_tensor_norms(sd, keys, vec, base=None):
+    """Per-tensor L2 norms of a vector laid out as the concatenation of sd[k] for k in keys (minus base when given)."""
+    out, off = [], 0
+    for k in keys:
+        n = sd[k].numel()
+        v = vec[off: off + n].double()
+        if base is not None:
+            v = v - base[k].reshape(-1).double()
+        out.append(v.norm())
+        off += n
+    assert off == vec.numel()
+    return torch.stack(out).float()
+
+
+@pytest.mark.parametrize("name", VIS_CASES)
+def test_visual_tuning_oracle_matches_reference(name):
+    """CLIPCLS_TTA(only_norm=False) — every visual parameter tuned, what scripts/rlcf-tune.sh runs — vs
+    oracle.tta_sample_ln(only_norm=False)."""
+    g, meta = load(name)
+    sg = synth.GEOMETRIES[meta["student"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    rsd = synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
+    o = R.tta_sample_ln(ssd, rsd, views, tokens, hyper(meta), only_norm=False)
+    keys = R.visual_param_keys(ssd)
+    assert torch.equal(o["selected_idx"], g["selected_idx"])
+    assert torch.equal(o["topk_idx"], g["topk_idx"])
+    assert torch.equal(o["top5"], g["top5"])
+    torch.testing.assert_close(o["logits"], g["logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=2e-5, rtol=1e-4)
+    multi = meta["tta_steps"] > 1
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    if not multi:
+        torch.testing.assert_close(vis_tensor_norms(ssd, keys, o["ln_grad"]), g["vis_grad_l2"], rtol=2e-3, atol=1e-9)
+    torch.testing.assert_close(vis_tensor_norms(ssd, keys, o["ln_after"], ssd), g["vis_delta_l2"], rtol=0.05 if multi else 0.01, atol=1e-7)
+    if "vis_grad_sample" in g:
+        gr, og = g["vis_grad_sample"], o["ln_grad"][::7]
+        assert (og - gr).norm() / gr.norm() < 1e-3
+        d = (o["ln_after"][::7] - g["vis_after_sample"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
