@@ -173,21 +173,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// Same as layernorm_bwd_kernel but every wave walks LNB_ROWS consecutive rows and keeps its dgamma/dbeta partial sums in
-// registers: one atomicAdd per column per wave instead of one per column per row (LayerNorm-tuning backward).
+// Same as layernorm_bwd_kernel but every wave walks rpw (<= LNB_ROWS) consecutive rows and keeps its dgamma/dbeta partial sums
+// in registers: one atomicAdd per column per wave instead of one per column per row (LayerNorm-tuning backward).  rpw is chosen
+// by the launcher so that a small token matrix (one test image: ~1200 rows) still spreads over enough waves.
 #define LNB_ROWS 16
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                    const float* __restrict__ dy, const float* __restrict__ dres,
                                                                    float* __restrict__ dx, float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta, int rows, int width, int group_rows,
-                                                                   int group_stride, int gamma_stride) {
+                                                                   int group_stride, int gamma_stride, int rpw) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LNB_ROWS;
+    const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * rpw;
     float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
 #pragma unroll
     for (int j = 0; j < MAX_PER_LANE; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
     int grp = (group_rows > 0 && row0 < rows) ? row0 / group_rows : 0;
-    for (int rr = 0; rr < LNB_ROWS; ++rr) {
+    for (int rr = 0; rr < rpw; ++rr) {
         const int row = row0 + rr;
         if (row >= rows) break;
         if (group_rows > 0 && row / group_rows != grp) {          // the walk crosses into the next sample: flush the partial sums
@@ -258,8 +259,9 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
     if (group_rows == 0) { group_stride = 0; gamma_stride = 0; }
     if (dgamma && dbeta && rows >= 256) {
-        const int per_block = ROWS_PER_BLOCK * LNB_ROWS;
-        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride, gamma_stride);
+        const int rpw = rows >= 16384 ? LNB_ROWS : rows >= 4096 ? 4 : 2;          // >= 512 waves whenever the matrix allows it
+        const int per_block = ROWS_PER_BLOCK * rpw;
+        layernorm_bwd_params_kernel<<<dim3((rows + per_block - 1) / per_block), dim3(256), 0, st>>>(x, gamma, dy, dres, dx, dgamma, dbeta, rows, width, group_rows, group_stride, gamma_stride, rpw);
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
@@ -741,16 +743,27 @@ int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, flo
 }
 
 // ---------------------------------------------------------------- max |x| (weight pre-scaling of the split-f16 GEMMs)
-__global__ void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+// one atomicMax per block: 4096 atomics on one address cost ~48 us whatever n is (measured), 256 cost ~3 us
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned int* __restrict__ out) {
+    __shared__ float part[4];
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));        // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));   // non-negative floats order like their bit patterns
 }
 int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st) {
+    RLCF_ARG_CHECK(((uintptr_t)x & 15) == 0);
     RLCF_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), st));
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = (int)((n + 4095) / 4096);                 // >= 16 elements per thread
+    if (blocks > 512) blocks = 512;
     absmax_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, n, (unsigned int*)out_dev);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

@@ -298,9 +298,10 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
-def run_reference_ln_momentum(ref, student, reward, n_views, n_cls, hp, n_samples=3, n_ctx=4):
+def run_reference_ln_momentum(ref, student, reward, n_views, n_cls, hp, n_samples=3, n_ctx=4, only_norm=True):
     """TPT/tune_cls_rl.py:206-240 over several consecutive samples with CLIPCLS_TTA(momentum_update=True): per sample reset ->
-    test_time_tuning -> clean-view logits -> momentum_update_model (custom_clip.py:460-475)."""
+    test_time_tuning -> clean-view logits -> momentum_update_model (custom_clip.py:460-475).  only_norm=False: every visual
+    parameter tuned; the per-sample vectors are stored as per-tensor L2 norms of (value - checkpoint)."""
     import copy
     s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
     s_sd = synth.make_state_dict(s_geo, seed=11)
@@ -310,8 +311,9 @@ def run_reference_ln_momentum(ref, student, reward, n_views, n_cls, hp, n_sample
     ref.custom.tokenize = bank.tokenize
     model = ref.custom.CLIPCLS_TTA("cpu", bank.classnames, arch=student, prompt_prefix="a_photo_of_a", only_visual=True,
                                    momentum_update=True, update_freq=hp["update_freq"], update_w=hp["update_w"],
-                                   momentum=hp["momentum"], only_norm=True)
-    names = [n for n, p in model.clip_model.visual.named_parameters() if "ln" in n or "bn" in n]
+                                   momentum=hp["momentum"], only_norm=only_norm)
+    names = [n for n, p in model.clip_model.visual.named_parameters() if not only_norm or "ln" in n or "bn" in n]
+    pristine = {n: p.detach().clone() for n, p in model.clip_model.visual.named_parameters()}
     optimizer = torch.optim.AdamW(model.parameters(), hp["lr"], weight_decay=hp["weight_decay"])
     optim_state = copy.deepcopy(optimizer.state_dict())
     args = types.SimpleNamespace(tta_steps=hp["tta_steps"], selection_p=hp["selection_p"], min_entropy_reg=0, min_entropy_w=0.2,
@@ -336,9 +338,15 @@ def run_reference_ln_momentum(ref, student, reward, n_views, n_cls, hp, n_sample
         with torch.no_grad():
             out[f"final_logits_{i}"] = model(views[:1]).clone()
         pmap = dict(model.clip_model.visual.named_parameters())
-        out[f"ln_after_{i}"] = torch.cat([pmap[n].detach().reshape(-1) for n in names]).clone()
+        if only_norm:
+            out[f"ln_after_{i}"] = torch.cat([pmap[n].detach().reshape(-1) for n in names]).clone()
+        else:
+            out[f"vis_delta_l2_{i}"] = torch.stack([(pmap[n].detach() - pristine[n]).double().norm() for n in names]).float()
         model.momentum_update_model()
-        out[f"ln_reset_{i}"] = torch.cat([model.initial_state_dict[n].reshape(-1) for n in names]).clone()
+        if only_norm:
+            out[f"ln_reset_{i}"] = torch.cat([model.initial_state_dict[n].reshape(-1) for n in names]).clone()
+        else:
+            out[f"vis_reset_delta_l2_{i}"] = torch.stack([(model.initial_state_dict[n] - pristine[n]).double().norm() for n in names]).float()
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
@@ -529,6 +537,11 @@ def main():
             arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp)
             save("ln_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
                                                    bank_seed=7, n_ctx=4, n_samples=3, **hp))
+        elif grp == "vismom":
+            hp = dict(BASE_HP, lr=1e-4, update_freq=2, update_w=0.5, momentum=0.9)
+            arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp, only_norm=False)
+            save("vis_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
+                                                    bank_seed=7, n_ctx=4, n_samples=3, only_norm=0, **hp))
         elif grp in ("vis", "visb16"):
             for name in ([k for k in VIS_CASES if "b16" not in k] if grp == "vis" else ["vis_b16_s3"]):
                 student, reward, n, c, over, full = VIS_CASES[name]

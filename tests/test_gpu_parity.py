@@ -919,7 +919,51 @@ def test_cls_tta_harness_surface(L, dev):
     d = (model.ln.detach().cpu() - g["ln_after"]).abs()
     assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
     with pytest.raises(NotImplementedError):
-        custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_norm=False)
+        custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=False)
+    runtime.reset_session()
+
+
+def test_cls_tta_full_visual_harness_with_momentum(L, dev):
+    """TPT/tune_cls_rl.py:206-240 over three consecutive samples with the reference's DEFAULT CLIPCLS_TTA(only_norm=False) (what
+    scripts/rlcf-tune.sh builds) and momentum_update=True, update_freq=2: clean-view logits, the adapted weights and the moving
+    reset state (per-tensor norms of their distance from the checkpoint) against the reference's run."""
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime, tpt_cls_rl
+    g, meta = load_golden("vis_tiny_momentum")
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    clip_store.register_checkpoint("tiny", sg, ssd)
+    clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
+                                 min_entropy_reg=0, min_entropy_w=0.2, reward_arch="tiny-r", multiple_reward_models=0,
+                                 sample_k=meta["sample_k"], reward_amplify=False, reward_process=True, process_batch=False)
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", momentum_update=True,
+                                    update_freq=meta["update_freq"], update_w=meta["update_w"], momentum=meta["momentum"])
+    assert not model.only_norm and len(model.parameters()) == 2
+    reward_model = clip_reward.get_reward_model(dev, args)
+    reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+    optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    keys = RR.visual_param_keys(ssd)
+    for i in range(meta["n_samples"]):
+        views = synth.make_views(1000 + i, meta["n_views"], 32).to(dev)
+        model.reset()
+        optimizer.load_state_dict(optim_state)
+        model.train()
+        tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+        model.eval()
+        torch.testing.assert_close(model(views[:1]).cpu(), g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        eng = runtime.SESSION.engine()
+        after = eng.merge_visual(model.ln.data, model.vis.data)
+        torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g[f"vis_delta_l2_{i}"], rtol=0.01, atol=1e-7)
+        model.momentum_update_model()
+        reset_state = eng.merge_visual(eng.ln_params(pristine=True), eng.visual_params(1))
+        torch.testing.assert_close(_tensor_norms(ssd, keys, reset_state, ssd), g[f"vis_reset_delta_l2_{i}"], rtol=0.01, atol=1e-7)
+    torch.testing.assert_close(eng.visual_params(0), eng.visual_params(1), atol=0, rtol=0)        # live copy follows the reset state
     runtime.reset_session()
 
 

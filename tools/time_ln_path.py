@@ -1,4 +1,5 @@
-"""Times BASELINE configs[2]: ViT-L/14 student + ViT-L/14 reward, N=64 views, LayerNorm tuning (rlcf_tta_sample_ln)."""
+"""Times BASELINE configs[2]: ViT-L/14 student + ViT-L/14 reward, N=64 views, LayerNorm tuning (rlcf_tta_sample_ln).
+args: ARCH CLASSES IMAGES_PER_PASS STEPS [full|fullonly]   (full: also rlcf_tta_sample_visual, every visual parameter tuned)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlcf_amd import _lib as L, synth
@@ -17,10 +18,12 @@ eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cfg = TTAConfig(selection_p=0.1, tta_steps=steps, sample_k=3, lr=1e-5, weight_decay=5e-4)
 views = [synth.make_views(1000 + i, 64, geo.image_resolution, device=dev) for i in range(6)]
-for v in views[:2]: o = eng.tta_sample_ln(v, cfg)
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+ln_runs = 1 if mode == "fullonly" else 4                  # (fullonly: profile runs, keep the LayerNorm path out of the kernel table)
+for v in views[:2 if ln_runs > 1 else 1]: o = eng.tta_sample_ln(v, cfg)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for v in views[2:]: o = eng.tta_sample_ln(v, cfg)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+for v in views[2:2 + ln_runs]: o = eng.tta_sample_ln(v, cfg)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ln_runs
 if B > 1:
     vs = torch.stack([synth.make_views(1000 + i, 64, geo.image_resolution, device=dev) for i in range(2 * B)])
     eng.tta_batch_ln(vs[:B], cfg)
@@ -28,5 +31,12 @@ if B > 1:
     top5 = eng.tta_batch_ln(vs, cfg)
     torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / (2 * B)
     print(f"{arch} LN-tuning, {steps} step(s), {B} images per pass: {dtb*1e3:.1f} ms/image ({1/dtb:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF")
+if mode in ("full", "fullonly"):          # every visual parameter tuned (CLIPCLS_TTA only_norm=False, scripts/rlcf-tune.sh)
+    for v in views[:2]: of = eng.tta_sample_visual(v, cfg)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for v in views[2:]: of = eng.tta_sample_visual(v, cfg)
+    torch.cuda.synchronize(); dtf = (time.perf_counter() - t0) / 4
+    print(f"{arch} full image-encoder tuning, {steps} step(s): {dtf*1e3:.1f} ms/image ({1/dtf:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF, "
+          f"top5={of['top5'].tolist()} |vis_grad|={of['vis_grad'].norm().item():.3e} nan={bool(torch.isnan(of['final_logits']).any())}")
 print(f"{arch} LN-tuning: {dt*1e3:.1f} ms/image ({1/dt:.1f} images/s), flops_exec/image={eng.last_flops()/1e12:.2f} TF, "
       f"top5={o['top5'].tolist()} |ln_grad|={o['ln_grad'].norm().item():.3e} nan={bool(torch.isnan(o['final_logits']).any())}")
