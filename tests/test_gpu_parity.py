@@ -811,6 +811,7 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
     views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution, device=dev)
     base = eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"].clone()        # LayerNorm path before: must be unaffected after
+    base_p = eng.tta_sample(views, _cfg_from_meta(meta))["final_logits"].clone()          # ... and so must the prompt path
     o = eng.tta_sample_visual(views, _cfg_from_meta(meta))
     torch.cuda.synchronize()
     c = lambda k: o[k].cpu()
@@ -840,6 +841,7 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     o2 = eng.tta_sample_visual(views, _cfg_from_meta(meta))
     torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
     torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
+    torch.testing.assert_close(eng.tta_sample(views, _cfg_from_meta(meta))["final_logits"], base_p, atol=2e-4, rtol=0)
     torch.testing.assert_close(eng.visual_params(0), eng.visual_params(1), atol=0, rtol=0)
     eng.close()
 
