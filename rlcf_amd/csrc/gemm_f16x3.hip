@@ -210,17 +210,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 // glds writes LDS lane-linearly (wave-uniform base + lane*16 B), so the bank swizzle is applied
 // to the per-lane SOURCE address and undone on the ds_read side: 16-B chunk c of row r lives at
 // chunk slot c ^ ((r>>2)&3); a 16-lane ds_read_b128 group then touches 16 distinct slots.
+// The same kernel at a 128x128 tile with 4 waves (NWM = 2, "v2s") serves grids too small for the big tiles (one test image's
+// token matrix: 60-240 blocks): same DMA ring instead of the register staging of the 128x128 kernel above, whose K tile costs
+// ~1.3 us of exposed global-load latency when one block runs per CU.
 #define V2_BM 256
 #define V2_BN 128
 #define V2_GROUP_M 4
-#define V2_STAGE 49152                  // bytes: Ahi 16K | Alo 16K | Whi 8K | Wlo 8K
-#define V2_ALO 16384
-#define V2_WHI 32768
-#define V2_WLO 40960
+#define V2_STAGE 49152                  // bytes (NWM = 4): Ahi 16K | Alo 16K | Whi 8K | Wlo 8K
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
+template <int NWM>                      // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
+__global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
+    constexpr int BM = 64 * NWM, A_BYTES = BM * 64, W_BYTES = V2_BN * 64;
+    constexpr int STAGE = 2 * A_BYTES + 2 * W_BYTES, ALO = A_BYTES, WHI = 2 * A_BYTES, WLO = WHI + W_BYTES;
+    constexpr int WPW = 4 / NWM;            // W-tile DMA instructions per wave and array (512 chunks over 2*NWM waves)
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [3][V2_STAGE]
     const int tiles_n = (g.N + V2_BN - 1) / V2_BN;
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     }
     // grouped order inside an XCD's range: V2_GROUP_M tile-rows are walked column by column, so the ~32 blocks an XCD
     // runs concurrently form a 4 x 8 patch that shares 4 A panels and 8 W panels in its L2
-    const int tiles_m = (g.M + V2_BM - 1) / V2_BM;
+    const int tiles_m = (g.M + BM - 1) / BM;
     const int per_group = V2_GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * V2_GROUP_M;
     const int gsize = min(tiles_m - first_m, V2_GROUP_M), in_g = bid - grp * per_group;
-    const int m0 = (first_m + in_g % gsize) * V2_BM, n0 = (in_g / gsize) * V2_BN;
+    const int m0 = (first_m + in_g % gsize) * BM, n0 = (in_g / gsize) * V2_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
 
@@ -248,36 +252,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // DMA sources: A tile = 1024 chunks (2 wave-instructions per wave per array), W tile = 512 (1 each)
-    const int qa0 = (wave * 2) * 64 + lane, qa1 = qa0 + 64, qw = wave * 64 + lane;
-    const int ra0 = qa0 >> 2, ra1 = qa1 >> 2, rw = qw >> 2;
+    const int qa0 = (wave * 2) * 64 + lane, qa1 = qa0 + 64, qw = (wave * WPW) * 64 + lane, qw1 = qw + 64;
+    const int ra0 = qa0 >> 2, ra1 = qa1 >> 2, rw = qw >> 2, rw1 = qw1 >> 2;
     const size_t sa0 = (size_t)min(m0 + ra0, g.M - 1) * g.lda + (((qa0 & 3) ^ ((ra0 >> 2) & 3)) * 8);
     const size_t sa1 = (size_t)min(m0 + ra1, g.M - 1) * g.lda + (((qa1 & 3) ^ ((ra1 >> 2) & 3)) * 8);
     const size_t sw = (size_t)min(n0 + rw, g.N - 1) * g.ldw + (((qw & 3) ^ ((rw >> 2) & 3)) * 8);
-    const int da0 = (wave * 2) * 1024, da1 = da0 + 1024, dw = wave * 1024;     // wave-uniform LDS byte offsets
+    const size_t sw1 = (size_t)min(n0 + rw1, g.N - 1) * g.ldw + (((qw1 & 3) ^ ((rw1 >> 2) & 3)) * 8);       // (WPW == 2 only)
+    const int da0 = (wave * 2) * 1024, da1 = da0 + 1024, dw = (wave * WPW) * 1024, dw1 = dw + 1024;     // wave-uniform LDS byte offsets
     // one DMA piece (1 KiB per wave-instruction); the six pieces of a stage are issued BETWEEN the MFMA groups of the
     // current tile so that their ~100-cycle issue cost hides under matrix work instead of delaying it
 #define V2_PIECE(idx, kk, sb_)                                                                                           \
     {                                                                                                                    \
         if ((idx) == 0) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa0 + (kk)), (lptr_t)((sb_) + da0), 16, 0, 0);            \
         if ((idx) == 1) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa1 + (kk)), (lptr_t)((sb_) + da1), 16, 0, 0);            \
-        if ((idx) == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa0 + (kk)), (lptr_t)((sb_) + V2_ALO + da0), 16, 0, 0);   \
-        if ((idx) == 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa1 + (kk)), (lptr_t)((sb_) + V2_ALO + da1), 16, 0, 0);   \
-        if ((idx) == 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw + (kk)), (lptr_t)((sb_) + V2_WHI + dw), 16, 0, 0);     \
-        if ((idx) == 5) __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw + (kk)), (lptr_t)((sb_) + V2_WLO + dw), 16, 0, 0);     \
+        if ((idx) == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa0 + (kk)), (lptr_t)((sb_) + ALO + da0), 16, 0, 0);      \
+        if ((idx) == 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa1 + (kk)), (lptr_t)((sb_) + ALO + da1), 16, 0, 0);      \
+        if ((idx) == 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw + (kk)), (lptr_t)((sb_) + WHI + dw), 16, 0, 0);        \
+        if ((idx) == 5) __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw + (kk)), (lptr_t)((sb_) + WLO + dw), 16, 0, 0);        \
+        if ((idx) == 6 && WPW == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw1 + (kk)), (lptr_t)((sb_) + WHI + dw1), 16, 0, 0); \
+        if ((idx) == 7 && WPW == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw1 + (kk)), (lptr_t)((sb_) + WLO + dw1), 16, 0, 0); \
     }
 #define V2_ISSUE(k0, stage)                                                                                              \
     {                                                                                                                    \
-        char* sbi_ = smem + (stage) * V2_STAGE;                                                                          \
+        char* sbi_ = smem + (stage) * STAGE;                                                                             \
         V2_PIECE(0, k0, sbi_) V2_PIECE(1, k0, sbi_) V2_PIECE(2, k0, sbi_) V2_PIECE(3, k0, sbi_) V2_PIECE(4, k0, sbi_) V2_PIECE(5, k0, sbi_) \
+        V2_PIECE(6, k0, sbi_) V2_PIECE(7, k0, sbi_)                                                                      \
     }
 #define V2_LDFRAG(ks, AH, AL, BH, BL)                                                                                    \
     {                                                                                                                    \
         const int co_ = (((ks) * 2 + h) ^ swz) * 16;                                                                     \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
             AH[i] = *(const h16x8*)(sb + aoff + i * 2048 + co_);                                                         \
-            AL[i] = *(const h16x8*)(sb + V2_ALO + aoff + i * 2048 + co_);                                                \
-            BH[i] = *(const h16x8*)(sb + V2_WHI + boff + i * 2048 + co_);                                                \
-            BL[i] = *(const h16x8*)(sb + V2_WLO + boff + i * 2048 + co_);                                                \
+            AL[i] = *(const h16x8*)(sb + ALO + aoff + i * 2048 + co_);                                                   \
+            BH[i] = *(const h16x8*)(sb + WHI + boff + i * 2048 + co_);                                                   \
+            BL[i] = *(const h16x8*)(sb + WLO + boff + i * 2048 + co_);                                                   \
         }                                                                                                                \
     }
 #define V2_MMA3(i, j, AH, AL, BH, BL)                                                                                    \
@@ -293,14 +301,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
     const int aoff = (wm * 64 + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < nk) {                 // the pieces of the newest stage (6, or 8 with two W instructions per wave) may stay in flight
+            if constexpr (WPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const bool pf = kt + 2 < nk;
         const int kn = (kt + 2) * g.kstep;
-        char* sn = smem + (cur >= 1 ? cur - 1 : 2) * V2_STAGE;             // stage (cur + 2) % 3
-        const char* sb = smem + cur * V2_STAGE;
+        char* sn = smem + (cur >= 1 ? cur - 1 : 2) * STAGE;                // stage (cur + 2) % 3
+        const char* sb = smem + cur * STAGE;
         h16x8 ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
         V2_LDFRAG(0, ah0, al0, bh0, bl0)
         V2_FENCE
@@ -318,10 +328,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) 
         if (pf) V2_PIECE(3, kn, sn)
         V2_FENCE
         V2_MMA3(0, 0, ah1, al1, bh1, bl1) V2_FENCE
-        if (pf) V2_PIECE(4, kn, sn)
+        if (pf) { V2_PIECE(4, kn, sn) V2_PIECE(6, kn, sn) }
         V2_FENCE
         V2_MMA3(0, 1, ah1, al1, bh1, bl1) V2_FENCE
-        if (pf) V2_PIECE(5, kn, sn)
+        if (pf) { V2_PIECE(5, kn, sn) V2_PIECE(7, kn, sn) }
         V2_FENCE
         V2_MMA3(1, 0, ah1, al1, bh1, bl1)
         V2_MMA3(1, 1, ah1, al1, bh1, bl1)
@@ -839,11 +849,27 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const size_t sh2 = (size_t)3 * V2_STAGE;
         static bool attr2 = false;
         if (!attr2) {
-            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
+            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
             attr2 = true;
         }
-        gemm_nt_f16x3_v2_kernel<<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        gemm_nt_f16x3_v2_kernel<4><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
         g_last_x3_variant = 2;
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
+    }
+    static int nov2s = -1;                                   // RLCF_X3_NOV2S=1: small grids back on the register-staged kernel
+    if (nov2s < 0) { const char* e = getenv("RLCF_X3_NOV2S"); nov2s = e ? atoi(e) : 0; }
+    if (v2_ok && !nov2s && (force == 4 || force == 0)) {
+        const int blocks2s = ((M + 127) / 128) * ((N + V2_BN - 1) / V2_BN);
+        const size_t sh2s = (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) > (size_t)4 * 64 * 68 * sizeof(float)
+                                ? (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) : (size_t)4 * 64 * 68 * sizeof(float);
+        static bool attr2s = false;
+        if (!attr2s) {
+            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2s));
+            attr2s = true;
+        }
+        gemm_nt_f16x3_v2_kernel<2><<<dim3(blocks2s), dim3(256), sh2s, st>>>(g);
+        g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
