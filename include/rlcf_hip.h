@@ -113,7 +113,10 @@ enum { RLCF_F_REWARD_PROCESS = 1, RLCF_F_AMPLIFY = 2, RLCF_F_PROCESS_BATCH = 4, 
  * CLIPRewards.CLIPScore / rewards_post_process (TPT/clip_reward.py:111-128,152-165):
  * rows = logits[sel[i]] (sel NULL: rows = logits[i]); top-K classes per row; CLIPScore
  * against class_feat[C,Dr] and reward_img[n_sel,Dr]; baseline; loss = mean(r*CE)
- * (+ w*avg_entropy); dlogits[n_sel,C] = dloss/drows (dense).  All outputs optional but dlogits. */
+ * (+ w*avg_entropy); dlogits[n_sel,C] = dloss/drows (dense).  All outputs optional but dlogits.  1 <= K <= 32.
+ * The retrieval policy of the reference (retrieval/clip_ret_policy.py:76-137: tune_image / tune_text) is the same arithmetic over a
+ * bank of 5 000 images or 25 000 captions with K = 12 / 20 (retrieval/scripts/tta_coco_ret.sh:19-20): rows = the query's logits
+ * over the bank, class_feat = the reward model's bank features, reward_img = its query features. */
 int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                      const float* class_feat, const float* reward_img, int Dr,
                      float clipscore_weight, int flags, float min_entropy_w,

@@ -787,8 +787,8 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     const int N = e->max_views;
     TRY(e->img_feat.ensure((size_t)N * D * sizeof(float))); TRY(e->logits.ensure((size_t)N * C * sizeof(float)));
     TRY(e->entropy.ensure(N * sizeof(float))); TRY(e->sel_idx.ensure(N * sizeof(int32_t)));
-    TRY(e->topk_idx.ensure((size_t)N * 16 * sizeof(int32_t))); TRY(e->clip_score.ensure((size_t)N * 16 * sizeof(float)));
-    TRY(e->rewards.ensure((size_t)N * 16 * sizeof(float))); TRY(e->loss.ensure(sizeof(float)));
+    TRY(e->topk_idx.ensure((size_t)N * 32 * sizeof(int32_t))); TRY(e->clip_score.ensure((size_t)N * 32 * sizeof(float)));
+    TRY(e->rewards.ensure((size_t)N * 32 * sizeof(float))); TRY(e->loss.ensure(sizeof(float)));
     TRY(e->dlogits.ensure((size_t)N * C * sizeof(float))); TRY(e->final_logits.ensure((size_t)C * sizeof(float)));
     TRY(e->top5.ensure(5 * sizeof(int32_t))); TRY(e->sel_feat.ensure((size_t)N * D * sizeof(float)));
     TRY(e->sel_logits.ensure((size_t)N * C * sizeof(float)));
@@ -933,7 +933,7 @@ static RewardBank reward_bank(const rlcf_engine* e) {
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16);
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32);
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
     const int n_sel = (int)(N * a->selection_p);              // int() truncation, tpt_cls_rl.py:34
     RLCF_ARG_CHECK(K <= C);
@@ -1129,7 +1129,7 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
                      hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const int n_sel = (int)(N * a->selection_p);
     const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
@@ -1285,7 +1285,7 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
                         hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
@@ -1328,7 +1328,7 @@ static int visual_reset(rlcf_engine* e, hipStream_t st) {      // visual.load_st
 static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 16 && a->sample_k <= e->C);
+    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
     const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }

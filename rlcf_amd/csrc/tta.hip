@@ -5,7 +5,7 @@
 #include "kernels.h"
 
 #define TTA_THREADS 256
-#define MAX_K 16
+#define MAX_K 32                       // retrieval scripts sample 12 (text->image) and 20 (image->text) candidates
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -185,7 +185,9 @@ def test_entropy_select(L, dev, n, Cn, p):
 @pytest.mark.parametrize("n_sel,Cn,K,Dr", [(4, 16, 3, 64), (6, 1000, 3, 512), (3, 40, 1, 128), (5, 200, 5, 768),
                                            # retrieval-shaped banks (retrieval/clip_ret_policy.py:76-137 runs the same
                                            # top-K -> CLIPScore -> baseline -> weighted-CE loss over 5k images / 25k captions)
-                                           (1, 5000, 5, 512), (2, 25000, 5, 512)])
+                                           (1, 5000, 5, 512), (2, 25000, 5, 512),
+                                           # ... with the sample counts of retrieval/scripts/tta_coco_ret.sh:19-20 (12 text->image, 20 image->text)
+                                           (1, 5000, 12, 512), (2, 25000, 20, 512)])
 def test_reward_loss(L, dev, flags_kw, n_sel, Cn, K, Dr):
     from rlcf_amd.engine import TTAConfig
     cfg = TTAConfig(sample_k=K, **flags_kw)
