@@ -150,6 +150,21 @@ size_t rlcf_make_views_scratch_bytes(int H, int n_crops, int res);
 int rlcf_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
                     const float* std3, float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream);
 
+/* The same with the AugMix op chains the reference switches on for the fine-grained sets (AugMixAugmenter(augmix=True),
+ * TPT/tpt_cls_rl.py:149-150, scripts/rlcf-prompt-fine.sh): `augmix` of TPT/data/datautils.py:94-110 with aug_list =
+ * TPT/data/augmix_ops.py:144-147.  View 1+v becomes  m[v] * pre(x) + (1 - m[v]) * sum_i w[v][i] * pre(chain_{v,i}(x))  where x is the
+ * 8-bit resized crop, pre = ToTensor + Normalize, and chain_{v,i} applies ops[(v*3 + i)*3 + 0..2] in turn (op = -1: none).
+ * op ids follow the reference's list: 0 autocontrast, 1 equalize, 2 posterize (ip = bits kept), 3 rotate, 4 solarize (ip =
+ * threshold), 5 shear_x, 6 shear_y, 7 translate_x, 8 translate_y; ops 3 and 5-8 carry the six coefficients Image.transform(AFFINE)
+ * receives in c (for rotate: the matrix Image.rotate builds).  Bit-exact with Pillow (look-up tables; bilinear affine resampling
+ * in double precision, truncated).  ops, w [n_crops,3], m [n_crops] are HOST arrays drawn by the caller with the reference's
+ * numpy calls (the call returns after the stream has consumed them). */
+typedef struct { int op; int ip; double c[6]; } rlcf_augmix_op;
+size_t rlcf_make_views_augmix_scratch_bytes(int H, int n_crops, int res);
+int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
+                           const float* std3, const rlcf_augmix_op* ops, const float* w, const float* m, float* views, void* scratch,
+                           size_t scratch_bytes, rlcf_stream stream);
+
 /* ------------------------------------------------------------------ engine ------
  * Owns device copies of the weights (plus derived layouts) and all workspace. */
 rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward /*NULL: none*/,

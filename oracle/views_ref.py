@@ -152,3 +152,178 @@ def make_views(img: np.ndarray, crops: List[Tuple[int, int, int, int, bool]], re
     for top, left, h, w, flip in crops:
         out.append(to_tensor_normalize(crop_view_u8(img, top, left, h, w, flip, res)))
     return np.stack(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# AugMix op chains (TPT/data/datautils.py:94-110 `augmix` with aug_list = TPT/data/augmix_ops.py:144-147 `augmentations`; switched
+# on for the fine-grained sets, tpt_cls_rl.py:149-150, i.e. by scripts/rlcf-prompt-fine.sh).  The ops are thin wrappers around
+# Pillow (absent from /root/reference): ImageOps.autocontrast / equalize / posterize / solarize (per-band 256-entry look-up tables,
+# ImageOps.py) and Image.rotate / Image.transform(AFFINE, BILINEAR) (libImaging/Geometry.c: affine_transform + bilinear_filter32RGB,
+# double arithmetic, result truncated to 8 bits, pixels whose source point falls outside the image filled with 0).
+# Pinned by tests/golden/augmix_*.npz, generated with Pillow through the reference's own op functions.
+AUG_OPS = ("autocontrast", "equalize", "posterize", "rotate", "solarize", "shear_x", "shear_y", "translate_x", "translate_y")
+AUG_IMAGE_SIZE = 224                     # augmix_ops.py:21
+
+
+def _apply_lut(u8: np.ndarray, lut: np.ndarray) -> np.ndarray:
+    """Image.point with a 3 x 256 table: band b of the output = lut[b][band b of the input]."""
+    out = np.empty_like(u8)
+    for b in range(3):
+        out[..., b] = lut[b][u8[..., b]]
+    return out
+
+
+def lut_autocontrast(u8: np.ndarray) -> np.ndarray:
+    """ImageOps.autocontrast(image, cutoff=0): per band, stretch [lowest, highest occupied level] to [0, 255]."""
+    lut = np.empty((3, 256), np.uint8)
+    for b in range(3):
+        h = np.bincount(u8[..., b].reshape(-1), minlength=256)
+        nz = np.nonzero(h)[0]
+        lo, hi = int(nz[0]), int(nz[-1])
+        if hi <= lo:
+            lut[b] = np.arange(256)
+        else:
+            scale = 255.0 / (hi - lo)
+            offset = -lo * scale
+            for ix in range(256):
+                v = int(ix * scale + offset)
+                lut[b, ix] = 0 if v < 0 else 255 if v > 255 else v
+    return lut
+
+
+def lut_equalize(u8: np.ndarray) -> np.ndarray:
+    """ImageOps.equalize(image): per band histogram equalisation with integer arithmetic."""
+    lut = np.empty((3, 256), np.uint8)
+    for b in range(3):
+        h = np.bincount(u8[..., b].reshape(-1), minlength=256)
+        histo = h[h > 0]
+        step = 0 if len(histo) <= 1 else (int(histo.sum()) - int(histo[-1])) // 255
+        if not step:
+            lut[b] = np.arange(256)
+        else:
+            n = step // 2
+            for i in range(256):
+                lut[b, i] = min(n // step, 255)          # (n // step <= 255 by construction)
+                n += int(h[i])
+    return lut
+
+
+def lut_posterize(bits: int) -> np.ndarray:
+    """ImageOps.posterize: keep the `bits` most significant bits."""
+    mask = ~(2 ** (8 - bits) - 1)
+    return np.tile((np.arange(256) & mask).astype(np.uint8), (3, 1))
+
+
+def lut_solarize(threshold: int) -> np.ndarray:
+    """ImageOps.solarize: invert every level >= threshold."""
+    i = np.arange(256)
+    return np.tile(np.where(i < threshold, i, 255 - i).astype(np.uint8), (3, 1))
+
+
+def rotate_coeffs(w: int, h: int, degrees: float):
+    """The affine matrix Image.rotate(degrees) hands to transform() (Image.py: rotation about the centre, no expand); None for
+    the angles it serves by transposition (0 / 180, and 90 / 270 of a square image)."""
+    angle = degrees % 360.0
+    if angle == 0:
+        return None
+    cx, cy = w / 2.0, h / 2.0
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return tuple(m)
+
+
+def affine_bilinear_u8(u8: np.ndarray, c) -> np.ndarray:
+    """Image.transform(size, AFFINE, c, BILINEAR) for an output of the input's size (Geometry.c: ImagingGenericTransform with
+    affine_transform and bilinear_filter32RGB)."""
+    H, W = u8.shape[:2]
+    a0, a1, a2, a3, a4, a5 = [float(v) for v in c]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64) + 0.5, np.arange(W, dtype=np.float64) + 0.5, indexing="ij")
+    xin = a0 * xx + a1 * yy + a2
+    yin = a3 * xx + a4 * yy + a5
+    inside = (xin >= 0.0) & (xin < W) & (yin >= 0.0) & (yin < H)
+    xs, ys = xin - 0.5, yin - 0.5
+    x, y = np.floor(xs), np.floor(ys)
+    dx, dy = xs - x, ys - y
+    x, y = x.astype(np.int64), y.astype(np.int64)
+    x0, x1 = np.clip(x, 0, W - 1), np.clip(x + 1, 0, W - 1)
+    yc = np.clip(y, 0, H - 1)
+    src = u8.astype(np.float64)
+    out = np.zeros_like(u8)
+    for b in range(3):
+        p = src[..., b]
+        v1 = p[yc, x0] + (p[yc, x1] - p[yc, x0]) * dx
+        has2 = (y + 1 >= 0) & (y + 1 < H)
+        y2 = np.clip(y + 1, 0, H - 1)
+        v2 = np.where(has2, p[y2, x0] + (p[y2, x1] - p[y2, x0]) * dx, v1)
+        v = v1 + (v2 - v1) * dy
+        out[..., b] = np.where(inside, v, 0.0).astype(np.uint8)              # (UINT8) truncation
+    return out
+
+
+def draw_augmix_op(rng, severity):
+    """One `np.random.choice(aug_list)(x_aug, severity)` call of datautils.py:106 reduced to its random draws (same calls, same
+    order, on numpy's legacy global stream when rng is np.random): -> (op name, integer parameter, affine coefficients or None)."""
+    op = AUG_OPS[int(rng.choice(len(AUG_OPS)))]
+    if op in ("autocontrast", "equalize"):
+        return op, 0, None
+    level = rng.uniform(low=0.1, high=severity)                               # sample_level, augmix_ops.py:52-53
+    S = AUG_IMAGE_SIZE
+    if op == "posterize":
+        return op, 4 - int(level * 4 / 10), None
+    if op == "solarize":
+        return op, 256 - int(level * 256 / 10), None
+    if op == "rotate":
+        deg = int(level * 30 / 10)
+        if rng.uniform() > 0.5:
+            deg = -deg
+        return op, deg, rotate_coeffs(S, S, deg)
+    if op in ("shear_x", "shear_y"):
+        lv = float(level) * 0.3 / 10.
+        if rng.uniform() > 0.5:
+            lv = -lv
+        return op, 0, ((1, lv, 0, 0, 1, 0) if op == "shear_x" else (1, 0, 0, lv, 1, 0))
+    lv = int(level * (S / 3) / 10)                                            # translate_x / translate_y
+    if rng.random_sample() > 0.5:
+        lv = -lv
+    return op, lv, ((1, 0, lv, 0, 1, 0) if op == "translate_x" else (1, 0, 0, 0, 1, lv))
+
+
+def apply_augmix_op(u8: np.ndarray, op: str, ip: int, coeffs) -> np.ndarray:
+    if op == "autocontrast":
+        return _apply_lut(u8, lut_autocontrast(u8))
+    if op == "equalize":
+        return _apply_lut(u8, lut_equalize(u8))
+    if op == "posterize":
+        return _apply_lut(u8, lut_posterize(ip))
+    if op == "solarize":
+        return _apply_lut(u8, lut_solarize(ip))
+    if coeffs is None:                                                         # rotate by 0 degrees: Image.rotate returns a copy
+        return u8.copy()
+    return affine_bilinear_u8(u8, coeffs)
+
+
+def draw_augmix_plan(rng, severity=1):
+    """The random draws of one `augmix` call (datautils.py:100-107) -> (w float32[3], m float32, 3 chains of 1-3 ops)."""
+    w = np.float32(rng.dirichlet([1.0, 1.0, 1.0]))
+    m = np.float32(rng.beta(1.0, 1.0))
+    chains = []
+    for _ in range(3):
+        chains.append([draw_augmix_op(rng, severity) for _ in range(rng.randint(1, 4))])
+    return w, m, chains
+
+
+def augmix_view(x_orig_u8: np.ndarray, plan) -> np.ndarray:
+    """datautils.py:94-110 after the pre-augmentation: float32 [3, R, R] = m * pre(x) + (1 - m) * sum_i w_i * pre(chain_i(x))."""
+    w, m, chains = plan
+    xp = to_tensor_normalize(x_orig_u8)
+    mix = np.zeros_like(xp)
+    for i, chain in enumerate(chains):
+        x = x_orig_u8
+        for op, ip, coeffs in chain:
+            x = apply_augmix_op(x, op, ip, coeffs)
+        mix = mix + w[i] * to_tensor_normalize(x)
+    return m * xp + (np.float32(1) - m) * mix

@@ -27,6 +27,10 @@ class ClipCfg(C.Structure):
                                        "text_heads", "text_layers")] + [("vision_stages", C.c_int * 4)]
 
 
+class AugmixOp(C.Structure):
+    _fields_ = [("op", C.c_int), ("ip", C.c_int), ("c", C.c_double * 6)]
+
+
 class Crop(C.Structure):       # rlcf_crop: RandomResizedCrop box + RandomHorizontalFlip
     _fields_ = [(n, C.c_int) for n in ("top", "left", "h", "w", "flip")]
 
@@ -79,6 +83,8 @@ SIGNATURES = {
     "rlcf_reward_class_features": (I, [P, I, P, P]),
     "rlcf_make_views_scratch_bytes": (C.c_size_t, [I, I, I]),
     "rlcf_make_views": (I, [P, I, I, P, I, I, P, P, P, P, C.c_size_t, P]),
+    "rlcf_make_views_augmix_scratch_bytes": (C.c_size_t, [I, I, I]),
+    "rlcf_make_views_augmix": (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, C.c_size_t, P]),
     "rlcf_tta_batch_ln": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_engine_momentum_update": (I, [P, P, D, D, I, P]),
     "rlcf_engine_create_ensemble": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I, I]),

@@ -117,6 +117,12 @@ int rlcf_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops, 
                     float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream) {
     return launch_make_views(image, H, W, crops, n_crops, res, mean3, std3, views, scratch, scratch_bytes, (hipStream_t)stream);
 }
+size_t rlcf_make_views_augmix_scratch_bytes(int H, int n_crops, int res) { return views_augmix_scratch_bytes(H, 1 + n_crops, res); }
+int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
+                           const float* std3, const rlcf_augmix_op* ops, const float* w, const float* m, float* views, void* scratch,
+                           size_t scratch_bytes, rlcf_stream stream) {
+    return launch_make_views_augmix(image, H, W, crops, n_crops, res, mean3, std3, ops, w, m, views, scratch, scratch_bytes, (hipStream_t)stream);
+}
 
 // ------------------------------------------------------------------ engine
 static bool cfg_ok(const rlcf_clip_cfg* c) {

@@ -89,7 +89,7 @@ __global__ void views_horizontal_kernel(const uint8_t* __restrict__ img, const r
 // vertical pass + flip + ToTensor + Normalize
 __global__ void views_vertical_kernel(const rlcf_crop* __restrict__ crops, int H, int W, int res, int nw, int nh, int off_x, int off_y,
                                       const int32_t* __restrict__ tab, const uint8_t* __restrict__ tmp, float m0, float m1, float m2, float d0,
-                                      float d1, float d2, float* __restrict__ out) {
+                                      float d1, float d2, float* __restrict__ out, uint8_t* __restrict__ u8_out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, v = blockIdx.z;
     if (x >= res) return;
     const ViewGeom g = view_geom(crops, v, H, W, res, nw, nh, off_x, off_y);
@@ -108,6 +108,10 @@ __global__ void views_vertical_kernel(const rlcf_crop* __restrict__ crops, int H
     o[0] = ((float)clip8(s0) / 255.0f - m0) / d0;
     o[plane] = ((float)clip8(s1) / 255.0f - m1) / d1;
     o[2 * plane] = ((float)clip8(s2) / 255.0f - m2) / d2;
+    if (u8_out) {                       // the 8-bit view itself (HWC), input of the AugMix op chains
+        uint8_t* u = u8_out + ((size_t)v * plane + (size_t)y * res + ox) * 3;
+        u[0] = (uint8_t)clip8(s0); u[1] = (uint8_t)clip8(s1); u[2] = (uint8_t)clip8(s2);
+    }
 }
 
 static void view0_geometry(int H, int W, int res, int* nw, int* nh, int* off_x, int* off_y) {
@@ -125,7 +129,7 @@ size_t views_scratch_bytes(int H, int n_views, int res) {
 }
 
 int launch_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
-                      const float* std3, float* views, void* scratch, size_t scratch_bytes, hipStream_t st) {
+                      const float* std3, float* views, void* scratch, size_t scratch_bytes, hipStream_t st, uint8_t* u8_out) {
     RLCF_ARG_CHECK(image && views && scratch && H > 0 && W > 0 && H <= 65535 && res > 0 && n_crops >= 0 && n_crops < 65535 &&
                    (n_crops == 0 || crops_host) && mean3 && std3);
     const int n_views = 1 + n_crops;
@@ -156,7 +160,196 @@ int launch_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops
     views_horizontal_kernel<<<dim3((res + 63) / 64, H, n_views), dim3(64), 0, st>>>(image, crops, H, W, res, nw, nh, off_x, off_y, tab, tmp);
     RLCF_LAUNCH_CHECK();
     views_vertical_kernel<<<dim3((res + 63) / 64, res, n_views), dim3(64), 0, st>>>(crops, H, W, res, nw, nh, off_x, off_y, tab, tmp, mean3[0],
-                                                                                  mean3[1], mean3[2], std3[0], std3[1], std3[2], views);
+                                                                                  mean3[1], mean3[2], std3[0], std3[1], std3[2], views, u8_out);
     RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// AugMix op chains (TPT/data/datautils.py:94-110 `augmix` with aug_list = TPT/data/augmix_ops.py:144-147, switched on for the
+// fine-grained sets, tpt_cls_rl.py:149-150): every augmented view is  m * pre(x) + (1 - m) * sum_i w_i * pre(chain_i(x)),  three
+// chains of 1-3 Pillow ops on the 8-bit view.  The ops are reproduced bit for bit: ImageOps.autocontrast / equalize / posterize /
+// solarize are per-band 256-entry look-up tables (built from the band histograms with Pillow's arithmetic), Image.rotate /
+// Image.transform(AFFINE, BILINEAR) are libImaging's affine_transform + bilinear_filter32RGB (double arithmetic without FMA
+// contraction, truncation to 8 bits, 0 outside the source).  Random draws (op, level, sign, Dirichlet / Beta weights) stay on the
+// host, made with the numpy calls the reference makes, in the same order.
+#define AUG_NONE (-1)
+enum { AUG_AUTOCONTRAST = 0, AUG_EQUALIZE = 1, AUG_POSTERIZE = 2, AUG_ROTATE = 3, AUG_SOLARIZE = 4, AUG_SHEAR_X = 5, AUG_SHEAR_Y = 6,
+       AUG_TRANSLATE_X = 7, AUG_TRANSLATE_Y = 8 };
+__device__ __forceinline__ bool aug_is_lut(int op) { return op == AUG_AUTOCONTRAST || op == AUG_EQUALIZE || op == AUG_POSTERIZE || op == AUG_SOLARIZE; }
+
+// source image of chain c in round r: round 0 reads the view itself, later rounds the other ping-pong buffer
+__device__ __forceinline__ const uint8_t* aug_src(const uint8_t* xo, const uint8_t* b0, const uint8_t* b1, int round, int chain, size_t img) {
+    return round == 0 ? xo + (size_t)(1 + chain / 3) * img : (round == 1 ? b0 : b1) + (size_t)chain * img;
+}
+
+// one block per chain: band histograms of the source (LDS atomics) -> the op's 3 x 256 look-up table
+__global__ __launch_bounds__(256) void augmix_lut_kernel(const uint8_t* __restrict__ xo, const uint8_t* __restrict__ b0,
+                                                         const uint8_t* __restrict__ b1, const rlcf_augmix_op* __restrict__ ops, int round,
+                                                         int res, uint8_t* __restrict__ luts) {
+#pragma clang fp contract(off)
+    const int chain = blockIdx.x;
+    const rlcf_augmix_op op = ops[chain * 3 + round];
+    if (!aug_is_lut(op.op)) return;
+    uint8_t* lut = luts + (size_t)chain * 768;
+    if (op.op == AUG_POSTERIZE || op.op == AUG_SOLARIZE) {
+        for (int i = threadIdx.x; i < 768; i += 256) {
+            const int v = i & 255;
+            lut[i] = op.op == AUG_POSTERIZE ? (uint8_t)(v & ~((1 << (8 - op.ip)) - 1)) : (uint8_t)(v < op.ip ? v : 255 - v);
+        }
+        return;
+    }
+    __shared__ int hist[768];
+    for (int i = threadIdx.x; i < 768; i += 256) hist[i] = 0;
+    __syncthreads();
+    const size_t img = (size_t)res * res * 3;
+    const uint8_t* src = aug_src(xo, b0, b1, round, chain, img);
+    for (size_t i = threadIdx.x; i < img; i += 256) atomicAdd(&hist[(int)(i % 3) * 256 + src[i]], 1);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int* h = hist + threadIdx.x * 256;
+        uint8_t* l = lut + threadIdx.x * 256;
+        if (op.op == AUG_AUTOCONTRAST) {            // ImageOps.autocontrast(cutoff=0)
+            int lo = 0, hi = 255;
+            while (lo < 256 && !h[lo]) ++lo;
+            while (hi >= 0 && !h[hi]) --hi;
+            if (hi <= lo) { for (int i = 0; i < 256; ++i) l[i] = (uint8_t)i; }
+            else {
+                const double scale = 255.0 / (double)(hi - lo), offset = -(double)lo * scale;
+                for (int i = 0; i < 256; ++i) {
+                    const double t = (double)i * scale;
+                    int v = (int)(t + offset);
+                    l[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                }
+            }
+        } else {                                      // ImageOps.equalize
+            int nz = 0, last = 0, total = 0;
+            for (int i = 0; i < 256; ++i) if (h[i]) { ++nz; last = h[i]; total += h[i]; }
+            const int step = nz <= 1 ? 0 : (total - last) / 255;
+            if (!step) { for (int i = 0; i < 256; ++i) l[i] = (uint8_t)i; }
+            else {
+                int n = step / 2;
+                for (int i = 0; i < 256; ++i) { const int q = n / step; l[i] = (uint8_t)(q > 255 ? 255 : q); n += h[i]; }
+            }
+        }
+    }
+}
+
+// one thread per (chain, pixel): look-up table, affine bilinear resample, or copy (chains shorter than the round count)
+__global__ __launch_bounds__(256) void augmix_apply_kernel(const uint8_t* __restrict__ xo, const uint8_t* __restrict__ b0,
+                                                           const uint8_t* __restrict__ b1, const rlcf_augmix_op* __restrict__ ops, int round,
+                                                           int res, const uint8_t* __restrict__ luts, uint8_t* __restrict__ dst_all) {
+#pragma clang fp contract(off)
+    const int chain = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= res * res) return;
+    const rlcf_augmix_op op = ops[chain * 3 + round];
+    const size_t img = (size_t)res * res * 3;
+    const uint8_t* src = aug_src(xo, b0, b1, round, chain, img);
+    uint8_t* dst = dst_all + (size_t)chain * img + (size_t)p * 3;
+    if (aug_is_lut(op.op)) {
+        const uint8_t* lut = luts + (size_t)chain * 768;
+        dst[0] = lut[src[(size_t)p * 3]]; dst[1] = lut[256 + src[(size_t)p * 3 + 1]]; dst[2] = lut[512 + src[(size_t)p * 3 + 2]];
+        return;
+    }
+    if (op.op == AUG_NONE) { dst[0] = src[(size_t)p * 3]; dst[1] = src[(size_t)p * 3 + 1]; dst[2] = src[(size_t)p * 3 + 2]; return; }
+    // Geometry.c: affine_transform at the pixel centre, bilinear_filter32RGB
+    const int x = p % res, y = p / res;
+    const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+    double xin = op.c[0] * xc + op.c[1] * yc + op.c[2];
+    double yin = op.c[3] * xc + op.c[4] * yc + op.c[5];
+    if (xin < 0.0 || xin >= (double)res || yin < 0.0 || yin >= (double)res) { dst[0] = 0; dst[1] = 0; dst[2] = 0; return; }
+    xin -= 0.5; yin -= 0.5;
+    const int xf = (int)floor(xin), yf = (int)floor(yin);
+    const double dx = xin - (double)xf, dy = yin - (double)yf;
+    const int x0 = min(max(xf, 0), res - 1), x1 = min(max(xf + 1, 0), res - 1), y0 = min(max(yf, 0), res - 1);
+    const bool has2 = yf + 1 >= 0 && yf + 1 < res;
+    const uint8_t* r0 = src + (size_t)y0 * res * 3;
+    const uint8_t* r1 = src + (size_t)(has2 ? yf + 1 : y0) * res * 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const double a = (double)r0[x0 * 3 + b], bb = (double)r0[x1 * 3 + b];
+        const double v1 = a + (bb - a) * dx;
+        double v2 = v1;
+        if (has2) { const double c = (double)r1[x0 * 3 + b], d = (double)r1[x1 * 3 + b]; v2 = c + (d - c) * dx; }
+        dst[b] = (uint8_t)(v1 + (v2 - v1) * dy);
+    }
+}
+
+// views[1 + v] = m * pre(x) + (1 - m) * ((0 + w0 pre(c0)) + w1 pre(c1)) + w2 pre(c2)),  float32, no FMA contraction
+__global__ __launch_bounds__(256) void augmix_mix_kernel(const uint8_t* __restrict__ xo, const uint8_t* __restrict__ fin, const float* __restrict__ w,
+                                                         const float* __restrict__ m, int res, float m0, float m1, float m2, float d0, float d1,
+                                                         float d2, float* __restrict__ views) {
+#pragma clang fp contract(off)
+    const int v = blockIdx.y;                          // augmented view index (0-based; view 1 + v of the output)
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= res * res) return;
+    const size_t plane = (size_t)res * res, img = plane * 3;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {d0, d1, d2};
+    const float mm = m[v], om = 1.0f - mm;
+    const uint8_t* x = xo + (size_t)(1 + v) * img + (size_t)p * 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float xp = ((float)x[b] / 255.0f - mean[b]) / sd[b];
+        float mix = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float pi = ((float)fin[(size_t)(v * 3 + i) * img + (size_t)p * 3 + b] / 255.0f - mean[b]) / sd[b];
+            const float t = w[v * 3 + i] * pi;
+            mix = mix + t;
+        }
+        const float a = mm * xp, c = om * mix;
+        views[(size_t)(1 + v) * img + (size_t)b * plane + p] = a + c;
+    }
+}
+
+size_t views_augmix_scratch_bytes(int H, int n_views, int res) {
+    const size_t img = (size_t)res * res * 3, chains = (size_t)(n_views - 1) * 3;
+    size_t n = (views_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255;
+    n += ((size_t)n_views * img + 255) & ~(size_t)255;                     // the 8-bit views
+    n += 2 * ((chains * img + 255) & ~(size_t)255);                        // ping-pong chain images
+    n += (chains * 768 + 255) & ~(size_t)255;                              // look-up tables
+    n += (chains * 3 * sizeof(rlcf_augmix_op) + 255) & ~(size_t)255;       // the plan
+    n += ((size_t)(n_views - 1) * 4 * sizeof(float) + 255) & ~(size_t)255; // w, m
+    return n;
+}
+
+int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
+                             const float* std3, const rlcf_augmix_op* ops_host, const float* w_host, const float* m_host, float* views,
+                             void* scratch, size_t scratch_bytes, hipStream_t st) {
+    RLCF_ARG_CHECK(n_crops > 0 && ops_host && w_host && m_host && scratch && res > 0);
+    const int n_views = 1 + n_crops, chains = n_crops * 3;
+    RLCF_ARG_CHECK(scratch_bytes >= views_augmix_scratch_bytes(H, n_views, res));
+    for (int i = 0; i < chains * 3; ++i) {
+        const rlcf_augmix_op& o = ops_host[i];
+        if (o.op < AUG_NONE || o.op > AUG_TRANSLATE_Y || (o.op == AUG_POSTERIZE && (o.ip < 0 || o.ip > 8))) {
+            rlcf_set_error("make_views_augmix: op %d of chain %d is not an AugMix op (op %d, parameter %d)", i % 3, i / 3, o.op, o.ip);
+            return RLCF_ERR_ARG;
+        }
+    }
+    const size_t img = (size_t)res * res * 3;
+    char* p = (char*)scratch + ((views_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255);
+    uint8_t* xo = (uint8_t*)p; p += ((size_t)n_views * img + 255) & ~(size_t)255;
+    uint8_t* b0 = (uint8_t*)p; p += ((size_t)chains * img + 255) & ~(size_t)255;
+    uint8_t* b1 = (uint8_t*)p; p += ((size_t)chains * img + 255) & ~(size_t)255;
+    uint8_t* luts = (uint8_t*)p; p += ((size_t)chains * 768 + 255) & ~(size_t)255;
+    rlcf_augmix_op* ops = (rlcf_augmix_op*)p; p += ((size_t)chains * 3 * sizeof(rlcf_augmix_op) + 255) & ~(size_t)255;
+    float* wm = (float*)p;
+    int rc = launch_make_views(image, H, W, crops_host, n_crops, res, mean3, std3, views, scratch, views_scratch_bytes(H, n_views, res), st, xo);
+    if (rc != RLCF_OK) return rc;
+    RLCF_HIP_CHECK(hipMemcpyAsync(ops, ops_host, (size_t)chains * 3 * sizeof(rlcf_augmix_op), hipMemcpyHostToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(wm, w_host, (size_t)n_crops * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(wm + n_crops * 3, m_host, (size_t)n_crops * sizeof(float), hipMemcpyHostToDevice, st));
+    const dim3 grid((res * res + 255) / 256, chains);
+    for (int round = 0; round < 3; ++round) {                      // round r applies op r of every chain: b0 <- x, b1 <- b0, b0 <- b1
+        augmix_lut_kernel<<<dim3(chains), dim3(256), 0, st>>>(xo, b0, b1, ops, round, res, luts);
+        RLCF_LAUNCH_CHECK();
+        augmix_apply_kernel<<<grid, dim3(256), 0, st>>>(xo, b0, b1, ops, round, res, luts, round == 1 ? b1 : b0);
+        RLCF_LAUNCH_CHECK();
+    }
+    augmix_mix_kernel<<<dim3((res * res + 255) / 256, n_crops), dim3(256), 0, st>>>(xo, b0, wm, wm + n_crops * 3, res, mean3[0], mean3[1], mean3[2],
+                                                                                   std3[0], std3[1], std3[2], views);
+    RLCF_LAUNCH_CHECK();
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));                       // the plan was read from caller-owned host memory
     return RLCF_OK;
 }

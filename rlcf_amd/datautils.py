@@ -5,8 +5,12 @@ goes up once and `rlcf_make_views` (rlcf_amd/csrc/views.hip) writes the N normal
 resampler.  The random boxes and flips are drawn on the host with the same torch generator calls torchvision makes, in the same
 order, so a seeded run reproduces the reference's crops.
 
-Not built: the AugMix op chains (`augmix=True`: only used for the fine-grained sets, tpt_cls_rl.py:149-150) and the BYOL-style
-`hard_aug` recipe — both raise.
+`augmix=True` (the fine-grained sets, tpt_cls_rl.py:149-150, scripts/rlcf-prompt-fine.sh) adds the AugMix op chains of
+datautils.py:94-110 / augmix_ops.py: the ops, levels, signs and the Dirichlet / Beta mixing weights are drawn here with the numpy
+calls the reference makes (same order, numpy's global legacy stream, so `np.random.seed` reproduces the reference's chains) and
+`rlcf_make_views_augmix` applies them on the device, bit-exact with Pillow.
+
+Not built: the BYOL-style `hard_aug` recipe — it raises.
 """
 from __future__ import annotations
 
@@ -66,6 +70,63 @@ def get_preaugment(hard_aug=False, resolution=224, crop_min=0.2):
     return RandomResizedCropParams()
 
 
+AUG_OPS = ("autocontrast", "equalize", "posterize", "rotate", "solarize", "shear_x", "shear_y", "translate_x", "translate_y")
+AUG_IMAGE_SIZE = 224                     # augmix_ops.py:21 (transform size and the scale of the translations)
+
+
+def _rotate_coeffs(w: int, h: int, degrees: float):
+    """the matrix PIL's Image.rotate(degrees) passes to transform(AFFINE) (rotation about the centre); None: no resampling"""
+    angle = degrees % 360.0
+    if angle == 0:
+        return None
+    cx, cy = w / 2.0, h / 2.0
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2] = m[0] * -cx + m[1] * -cy + m[2]
+    m[5] = m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return tuple(m)
+
+
+def draw_augmix_op(severity=1, rng=np.random):
+    """The random draws of one `np.random.choice(aug_list)(x_aug, severity)` (datautils.py:106 with the ops of
+    augmix_ops.py:56-115): -> (op id, integer parameter, six affine coefficients or None)."""
+    op = int(rng.choice(len(AUG_OPS)))
+    name = AUG_OPS[op]
+    if name in ("autocontrast", "equalize"):
+        return op, 0, None
+    level = rng.uniform(low=0.1, high=severity)                 # sample_level
+    S = AUG_IMAGE_SIZE
+    if name == "posterize":
+        return op, 4 - int(level * 4 / 10), None
+    if name == "solarize":
+        return op, 256 - int(level * 256 / 10), None
+    if name == "rotate":
+        deg = int(level * 30 / 10)
+        if rng.uniform() > 0.5:
+            deg = -deg
+        co = _rotate_coeffs(S, S, deg)
+        return (op, deg, co) if co is not None else (-1, 0, None)
+    if name in ("shear_x", "shear_y"):
+        lv = float(level) * 0.3 / 10.
+        if rng.uniform() > 0.5:
+            lv = -lv
+        return op, 0, ((1, lv, 0, 0, 1, 0) if name == "shear_x" else (1, 0, 0, lv, 1, 0))
+    lv = int(level * (S / 3) / 10)
+    if rng.random_sample() > 0.5:
+        lv = -lv
+    return op, lv, ((1, 0, lv, 0, 1, 0) if name == "translate_x" else (1, 0, 0, 0, 1, lv))
+
+
+def draw_augmix_plan(severity=1, rng=np.random):
+    """The random draws of one `augmix` call (datautils.py:100-107): (w float32[3], m float32, three chains of 1-3 ops)."""
+    w = np.float32(rng.dirichlet([1.0, 1.0, 1.0]))
+    m = np.float32(rng.beta(1.0, 1.0))
+    chains = [[draw_augmix_op(severity, rng) for _ in range(rng.randint(1, 4))] for _ in range(3)]
+    return w, m, chains
+
+
 def _as_u8_hwc(x) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
         t = x
@@ -77,9 +138,10 @@ def _as_u8_hwc(x) -> torch.Tensor:
 
 
 def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resolution: int = 224, mean=CLIP_MEAN, std=CLIP_STD,
-               device=None) -> torch.Tensor:
+               device=None, augmix_plans=None) -> torch.Tensor:
     """[1 + len(crops), 3, R, R] float32 on the GPU: view 0 = Resize(R, bicubic) + CenterCrop(R) of the image, the others its
-    resized crops (bilinear) with optional flip; ToTensor + Normalize.  No CPU fallback."""
+    resized crops (bilinear) with optional flip; ToTensor + Normalize.  augmix_plans: one draw_augmix_plan() result per crop — the
+    crop views then go through the AugMix loop.  No CPU fallback."""
     if not torch.cuda.is_available():
         raise L.RlcfError("rlcf_amd.datautils.make_views needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device(device or "cuda")
@@ -92,6 +154,31 @@ def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resoluti
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     out = torch.empty(1 + n, 3, resolution, resolution, device=dev)
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    if augmix_plans is not None:
+        if len(augmix_plans) != n or n == 0:
+            raise ValueError("augmix_plans: one plan per crop")
+        if resolution != AUG_IMAGE_SIZE:
+            raise ValueError("the AugMix ops work on 224 x 224 views (augmix_ops.py:21)")
+        ops = (L.AugmixOp * (n * 9))()
+        wv, mv = (C.c_float * (n * 3))(), (C.c_float * n)()
+        for v, (w, m, chains) in enumerate(augmix_plans):
+            mv[v] = float(m)
+            for i in range(3):
+                wv[v * 3 + i] = float(w[i])
+                for j in range(3):
+                    o = ops[(v * 3 + i) * 3 + j]
+                    if j < len(chains[i]):
+                        o.op, o.ip = int(chains[i][j][0]), int(chains[i][j][1])
+                        if chains[i][j][2] is not None:
+                            for q in range(6):
+                                o.c[q] = float(chains[i][j][2][q])
+                    else:
+                        o.op = -1
+        nbytes = int(lib.rlcf_make_views_augmix_scratch_bytes(H, n, resolution))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.rlcf_make_views_augmix(img.data_ptr(), H, W, arr, n, resolution, m3, s3, ops, wv, mv, out.data_ptr(),
+                                           scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "make_views_augmix")
+        return out
     L.check(lib.rlcf_make_views(img.data_ptr(), H, W, arr, n, resolution, m3, s3, out.data_ptr(), scratch.data_ptr(), nbytes,
                                 torch.cuda.current_stream().cuda_stream), "make_views")
     return out
@@ -105,18 +192,20 @@ class AugMixAugmenter:
 
     def __init__(self, base_transform=None, preprocess=None, n_views=2, augmix=False, severity=1, hard_aug=False, resolution=224,
                  device=None):
-        if augmix:
-            raise NotImplementedError("AugMix op chains (fine-grained sets only, tpt_cls_rl.py:149-150) are not built")
         self.n_views, self.resolution, self.device = n_views, resolution, device
-        self.aug_list: List = []
+        self.aug_list: List = list(AUG_OPS) if augmix else []          # (names: the ops themselves run on the device)
         self.severity = severity
         self.preaugment = get_preaugment(hard_aug=hard_aug, resolution=resolution, crop_min=0.2)
 
     def views(self, x) -> torch.Tensor:
         img = _as_u8_hwc(x)
         H, W = int(img.shape[0]), int(img.shape[1])
-        crops = [self.preaugment(H, W) for _ in range(self.n_views)]
-        return make_views(img, crops, self.resolution, device=self.device)
+        crops, plans = [], [] if self.aug_list else None
+        for _ in range(self.n_views):                                  # per view: crop box + flip (torch), then the AugMix draws (numpy)
+            crops.append(self.preaugment(H, W))
+            if self.aug_list:
+                plans.append(draw_augmix_plan(self.severity))
+        return make_views(img, crops, self.resolution, device=self.device, augmix_plans=plans)
 
     def __call__(self, x):
         return list(self.views(x).unbind(0))

@@ -114,4 +114,117 @@ def test_augmenter_surface_and_errors():
     with pytest.raises(_lib.RlcfError):                     # 40x downscale needs more taps than the kernel carries
         D.make_views(torch.zeros(9000, 300, 3, dtype=torch.uint8), [(0, 0, 9000, 300, False)])
     with pytest.raises(NotImplementedError):
-        D.AugMixAugmenter(None, None, n_views=3, augmix=True)
+        D.AugMixAugmenter(None, None, n_views=3, hard_aug=True)
+
+
+# ------------------------------------------------------------------------------ AugMix op chains (fine-grained sets)
+def _sha(a):
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+class _ForcedOp:
+    """numpy.random with `choice` pinned to one op: what calling that op function directly draws"""
+
+    def __init__(self, i):
+        self.i = i
+        self.uniform, self.random_sample = np.random.uniform, np.random.random_sample
+
+    def choice(self, n):
+        return self.i
+
+
+AUG_CASES = [(i, sev) for i in range(9) for sev in (1, 5, 10)]
+
+
+@pytest.mark.parametrize("i,sev", AUG_CASES)
+def test_oracle_augmix_ops_match_pillow(i, sev):
+    """Every op of augmix_ops.augmentations at three severities, against Pillow's output through the reference's own functions."""
+    g = np.load(os.path.join(GOLDEN, "augmix_ops.npz"))
+    arr = G.synth_image("augmix", 224, 224)
+    np.random.seed(100 + 10 * i + sev)
+    name, ip, co = V.draw_augmix_op(_ForcedOp(i), sev)
+    r = V.apply_augmix_op(arr, name, ip, co)
+    assert np.array_equal(r[:16, :16], g[f"{name}_s{sev}_block"])
+    assert np.array_equal(_sha(r), g[f"{name}_s{sev}_sha1"])
+
+
+MIX_CASES = [(1, 1), (2, 1), (3, 1), (4, 3), (5, 10)]
+
+
+@pytest.mark.parametrize("seed,sev", MIX_CASES)
+def test_oracle_augmix_loop_matches_reference(seed, sev):
+    """The whole augmix loop (numpy draw order, chains, float32 mixing) against the reference's ops driven by its loop."""
+    g = np.load(os.path.join(GOLDEN, "augmix_mix.npz"))
+    arr = G.synth_image("augmix", 224, 224)
+    np.random.seed(seed)
+    r = V.augmix_view(arr, V.draw_augmix_plan(np.random, sev))
+    assert r.dtype == np.float32
+    assert np.array_equal(r[:, 100:108, 100:108], g[f"seed{seed}_s{sev}_block"])
+    assert np.array_equal(_sha(r), g[f"seed{seed}_s{sev}_sha1"])
+
+
+def test_host_plan_draws_like_the_oracle():
+    from rlcf_amd import datautils as D
+    for seed in range(8):
+        np.random.seed(seed)
+        w, m, chains = D.draw_augmix_plan(1 + seed)
+        np.random.seed(seed)
+        w2, m2, chains2 = V.draw_augmix_plan(np.random, 1 + seed)
+        assert np.array_equal(w, w2) and m == m2 and [len(c) for c in chains] == [len(c) for c in chains2]
+        for c, c2 in zip(chains, chains2):
+            for (op, ip, co), (name, ip2, co2) in zip(c, c2):
+                assert (op == -1 and name == "rotate" and co2 is None) or (V.AUG_OPS[op] == name and ip == ip2 and co == co2)
+
+
+def _to_oracle_plan(plan):
+    w, m, chains = plan
+    return w, m, [[("rotate" if op < 0 else V.AUG_OPS[op], ip, co) for op, ip, co in c] for c in chains]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,sev", MIX_CASES)
+def test_hip_augmix_views_bit_exact(seed, sev):
+    """rlcf_make_views_augmix: the golden image as a full-size 'crop' (resize 224 -> 224 is the identity), so view 1 is the
+    reference's augmix output for that numpy seed, bit for bit; two more crops against the numpy oracle."""
+    from rlcf_amd import datautils as D
+    g = np.load(os.path.join(GOLDEN, "augmix_mix.npz"))
+    arr = G.synth_image("augmix", 224, 224)
+    crops = [(0, 0, 224, 224, False), (10, 20, 150, 120, True), (100, 3, 60, 200, False)]
+    np.random.seed(seed)
+    plans = [D.draw_augmix_plan(sev) for _ in crops]
+    out = D.make_views(torch.from_numpy(arr), crops, 224, augmix_plans=plans).cpu().numpy()
+    assert np.array_equal(out[1][:, 100:108, 100:108], g[f"seed{seed}_s{sev}_block"])
+    assert np.array_equal(_sha(out[1]), g[f"seed{seed}_s{sev}_sha1"])
+    assert np.array_equal(out[0], V.to_tensor_normalize(V.center_view_u8(arr, 224)))
+    for v, (t, l, h, w, f) in enumerate(crops):
+        ref = V.augmix_view(V.crop_view_u8(arr, t, l, h, w, f, 224), _to_oracle_plan(plans[v]))
+        assert np.array_equal(out[1 + v], ref), v
+
+
+@pytest.mark.gpu
+def test_hip_augmix_every_op_and_augmenter():
+    """each op alone (severity 10: the largest rotations / shears / shifts) against the oracle, then the augmenter surface"""
+    from rlcf_amd import _lib, datautils as D
+    arr = G.synth_image("augmix", 224, 224)
+    crops, plans = [], []
+    for i in range(9):
+        np.random.seed(100 + 10 * i + 10)
+        name, ip, co = V.draw_augmix_op(_ForcedOp(i), 10)
+        op = -1 if (name == "rotate" and co is None) else i
+        crops.append((0, 0, 224, 224, False))
+        plans.append((np.float32([1.0, 0.0, 0.0]), np.float32(0.25), [[(op, ip, co)], [(1, 0, None), (0, 0, None)], [(4, 100, None), (2, 3, None), (1, 0, None)]]))
+    out = D.make_views(torch.from_numpy(arr), crops, 224, augmix_plans=plans).cpu().numpy()
+    for v in range(9):
+        assert np.array_equal(out[1 + v], V.augmix_view(arr, _to_oracle_plan(plans[v]))), V.AUG_OPS[v]
+    img = torch.from_numpy(G.synth_image("views_imagenet", 375, 500))
+    torch.manual_seed(3); np.random.seed(3)
+    aug = D.AugMixAugmenter(None, None, n_views=7, augmix=True, severity=3)
+    a = aug.views(img)
+    torch.manual_seed(3); np.random.seed(3)
+    assert torch.equal(a, aug.views(img)) and a.shape == (8, 3, 224, 224) and bool(torch.isfinite(a).all())
+    torch.manual_seed(3)
+    plain = D.AugMixAugmenter(None, None, n_views=7).views(img)
+    assert torch.equal(plain[0], a[0]) and not torch.equal(plain[1:], a[1:])
+    bad = [(np.float32([1, 0, 0]), np.float32(0.5), [[(11, 0, None)], [(0, 0, None)], [(0, 0, None)]])]
+    with pytest.raises(_lib.RlcfError, match="AugMix"):
+        D.make_views(torch.from_numpy(arr), [(0, 0, 224, 224, False)], 224, augmix_plans=bad)
