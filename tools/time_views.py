@@ -17,3 +17,15 @@ for _ in range(50): [aug.preaugment(375, 500) for _ in range(63)]
 dp = (time.perf_counter() - t1) / 50
 print(f"make_views 64 x 224^2 from 375x500: {dt*1e6:.0f} us per image (GPU, incl. launch + scratch alloc); crop sampling on host {dp*1e6:.0f} us; "
       f"output {64*3*224*224*4/1e6:.1f} MB -> {64*3*224*224*4/dt/1e9:.0f} GB/s written; upload {375*500*3/1e3:.0f} KB instead of 38.5 MB")
+# the same with the AugMix op chains of the fine-grained sets (rlcf_make_views_augmix)
+import numpy as np
+np.random.seed(0)
+plans = [D.draw_augmix_plan(1) for _ in crops]
+for _ in range(3): D.make_views(img, crops, augmix_plans=plans)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): D.make_views(img, crops, augmix_plans=plans)
+torch.cuda.synchronize(); da = (time.perf_counter() - t0) / 50
+t1 = time.perf_counter()
+for _ in range(50): [D.draw_augmix_plan(1) for _ in crops]
+dq = (time.perf_counter() - t1) / 50
+print(f"make_views + AugMix chains (63 views x 3 chains x <=3 ops): {da*1e6:.0f} us per image; plan sampling on host {dq*1e6:.0f} us")
