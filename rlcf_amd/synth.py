@@ -73,6 +73,7 @@ GEOMETRIES: Dict[str, ClipGeometry] = {
     "tiny": ClipGeometry(128, 32, 2, 128, 8, 77, 1024, 128, 2, 2),
     "tiny-r": ClipGeometry(64, 32, 2, 128, 8, 77, 1024, 64, 1, 2),
     "tiny-r64": ClipGeometry(64, 64, 2, 128, 16, 77, 1024, 64, 1, 2),     # reward model at twice the view resolution (bicubic path)
+    "tiny-p6": ClipGeometry(128, 30, 2, 128, 6, 77, 1024, 128, 2, 2),     # 3*6*6 = 108 patch columns: zero-padded to the GEMM's K granule like ViT-L/14's 588
     "small": ClipGeometry(256, 64, 4, 256, 16, 77, 4096, 256, 4, 4),
     # ModifiedResNet image towers (attention-pool width 32*width, head_dim 64): 64x64 input -> 2x2 map -> 5 pooled tokens
     "tiny-rn": ClipGeometry(64, 64, (1, 2, 1, 1), 16, None, 77, 1024, 64, 1, 2),

@@ -369,6 +369,7 @@ def gen_tokenizer(ref):
 VIS_CASES = {      # CLIPCLS_TTA(only_norm=False): name -> (student, reward, views, classes, overrides, store full vectors)
     "vis_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-4), True),
     "vis_tiny_s3": ("tiny", "tiny-r", 8, 16, dict(lr=1e-4, tta_steps=3), False),
+    "vis_tinyp6_s3": ("tiny-p6", "tiny-r", 8, 16, dict(lr=1e-4, tta_steps=3), False),        # padded conv1 columns (as ViT-L/14)
     "vis_small_s1": ("small", "small", 16, 40, dict(lr=1e-4, selection_p=0.25), False),
     "vis_b16_s3": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-5, tta_steps=3, selection_p=0.25), False),   # rlcf-tune.sh: lr 1e-5, 3 steps
 }

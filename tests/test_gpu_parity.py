@@ -793,7 +793,7 @@ def _tensor_norms(sd, keys, vec, base=None):
 
 
 @pytest.mark.parametrize("prec", [0, 2])
-@pytest.mark.parametrize("name", ["vis_tiny_s1", "vis_tiny_s3", "vis_small_s1", "vis_b16_s3"])
+@pytest.mark.parametrize("name", ["vis_tiny_s1", "vis_tiny_s3", "vis_tinyp6_s3", "vis_small_s1", "vis_b16_s3"])
 def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     """rlcf_tta_sample_visual vs the reference's CLIPCLS_TTA(only_norm=False) + test_time_tuning run (TPT/tune_cls_rl.py, the
     configuration of scripts/rlcf-tune.sh): every visual parameter gets a gradient and an AdamW step."""

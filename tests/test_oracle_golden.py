@@ -222,7 +222,7 @@ def test_ln_tuning_oracle_matches_reference(name):
     assert (d > 0.1 * meta["lr"]).float().mean() < (0.05 if multi else 0.01)
 
 
-VIS_CASES = ["vis_tiny_s1", "vis_tiny_s3", "vis_small_s1"]
+VIS_CASES = ["vis_tiny_s1", "vis_tiny_s3", "vis_tinyp6_s3", "vis_small_s1"]
 
 
 def vis_tensor_norms(sd, keys, vec, base=None):
