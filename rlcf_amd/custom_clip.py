@@ -44,9 +44,22 @@ class PromptLearner(nn.Module):
             prompt_prefix = " ".join(["X"] * n_ctx)
         self.prompt_prefix, self.n_ctx, self.ctx_init = prompt_prefix, n_ctx, ctx_init
         ctx_vectors = ctx_vectors.detach().to(self.device).clone()
-        self.ctx_init_state = ctx_vectors.detach().clone()
+        self.tokenized_prompts = None
+        self._ctx_init_state = ctx_vectors.detach().clone()
         self.ctx = nn.Parameter(ctx_vectors)
         self._set_classnames(classnames)
+
+    @property
+    def ctx_init_state(self) -> torch.Tensor:
+        return self._ctx_init_state
+
+    @ctx_init_state.setter
+    def ctx_init_state(self, value: torch.Tensor) -> None:
+        """The harness assigns a pre-trained (CoOp) prompt here (`--load`, tpt_cls_rl.py:95-101): the engine's reset state and
+        its cached step-0 text features follow."""
+        self._ctx_init_state = value.detach().to(self.device, torch.float32).clone()
+        if self.tokenized_prompts is not None:
+            runtime.SESSION.set_bank(self.tokenized_prompts, self.n_ctx, self._ctx_init_state)
 
     def _set_classnames(self, classnames: List[str]) -> None:
         classnames = [name.replace("_", " ") for name in classnames]

@@ -709,6 +709,32 @@ def test_harness_images_per_pass(L, dev):
     assert res[1] == res[3] and res[1][0] >= 20.0
 
 
+def test_pretrained_prompt_load_flow(L, dev):
+    """`--load` of the reference harness (tpt_cls_rl.py:95-101): ctx.copy_(pretrained); ctx_init_state = pretrained — WITHOUT a
+    later reset_classnames.  The tuned result must be the oracle's from that starting prompt (not from the hand-written one)."""
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden("tta_tiny_s1")
+    model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+    pre = synth.normal(31, "coop.ctx", tuple(model.prompt_learner.ctx.shape), 0.02).to(dev)
+    with torch.no_grad():
+        model.prompt_learner.ctx.copy_(pre)
+        model.prompt_learner.ctx_init_state = pre
+    views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
+    model.reset()
+    optimizer.load_state_dict(optim_state)
+    tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+    out = model(views[:1]).cpu()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd, rsd = synth.make_state_dict(sg, meta["student_seed"]), synth.make_state_dict(rg, meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ref = RR.tta_sample(ssd, rsd, views.cpu(), tokens, pre.cpu(),
+                        RR.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                                    weight_decay=meta["weight_decay"]))
+    torch.testing.assert_close(out, ref["final_logits"], atol=1e-3, rtol=0)
+    assert (out - g["final_logits"]).abs().max() > 1e-2          # ... and it is not the hand-written prompt's result
+    runtime.reset_session()
+
+
 @pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_ens"])
 def test_autograd_route_matches_reference_gradient(L, dev, name):
     """model(images) is differentiable w.r.t. ctx exactly like the reference module: an unmodified copy of the
