@@ -25,21 +25,23 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
-                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il) {
+                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il, int qb0) {
+    // qb0: first 32-query block this launch covers (a 257-token ViT-L/14 sequence = one 8-wave block for queries 0..255 plus a
+    // one-wave launch for the last query, instead of a second 8-wave block that would re-stage every K/V chunk for one row)
     const rlcf_seq sq = seqs[blockIdx.y];
     const int head = blockIdx.z;
-    if (blockIdx.x * NW * 32 >= sq.q_len) return;
+    if ((qb0 + blockIdx.x * NW) * 32 >= sq.q_len) return;
     // two images of the converted K / V^T chunk: chunk c+1 is fetched (registers) and written while chunk c is consumed
     constexpr int NB = NW > 1 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 Kh[NB][32 * AX_KLD], Kl[NB][32 * AX_KLD], Vh[NB][64 * AX_VLD], Vl[NB][64 * AX_VLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
     const int ld = 3 * width;
-    const int qb = blockIdx.x * NW + wave;
+    const int qb = qb0 + blockIdx.x * NW + wave;
     const bool active = qb * 32 < sq.q_len;                      // waves past the end only help loading
     const int qi = min(qb * 32 + l32, sq.q_len - 1);
     const int nkeys = sq.pre_len + sq.q_len;
     const int qpos = sq.pre_len + qi;
-    const int last_q = min(blockIdx.x * NW * 32 + NW * 32, sq.q_len);      // one past the last query of this workgroup
+    const int last_q = min((qb0 + blockIdx.x * NW) * 32 + NW * 32, sq.q_len);      // one past the last query of this workgroup
     const int kend = causal ? min(nkeys, sq.pre_len + last_q) : nkeys;
     const int my_kend = causal ? min(nkeys, sq.pre_len + qb * 32 + 32) : nkeys;
 
@@ -209,17 +211,24 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
     if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
-        dim3 grid((max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
+        const int full = max_q_len / 256, tail = max_q_len - full * 256;
+        const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch
+        dim3 grid(split_tail ? full : (max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
+        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
+        if (split_tail) {
+            RLCF_LAUNCH_CHECK();
+            attention_fwd_x3_kernel<1><<<dim3(1, n_seq, width / HEAD_DIM), dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi,
+                                                                                           (_Float16*)out_lo, il, full * 8);
+        }
     } else if (max_q_len > 32) {
         dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
+        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
     } else {
         dim3 grid(1, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il);
+        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
     }
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
