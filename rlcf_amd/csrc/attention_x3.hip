@@ -25,7 +25,8 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
-                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il, int qb0) {
+                                                                    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il, int qb0,
+                                                                    float* __restrict__ lse) {
     // qb0: first 32-query block this launch covers (a 257-token ViT-L/14 sequence = one 8-wave block for queries 0..255 plus a
     // one-wave launch for the last query, instead of a second 8-wave block that would re-stage every K/V chunk for one row)
     const rlcf_seq sq = seqs[blockIdx.y];
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
     const float ltot = lsum + __shfl_xor(lsum, 32);
     if (qb * 32 + l32 < sq.q_len) {
         const float inv = 0.015625f / ltot;                       // undoes the 2^6 carried by P
+        // log-sum-exp of the row's scores s/8 (saved for the flash-style backward): m is the running max of the raw scores
+        if (lse && h == 0) lse[(size_t)(sq.q_start + qi) * (width / HEAD_DIM) + head] = m * 0.125f + logf(ltot);
         const size_t obase = (size_t)(sq.q_start + qi) * width + head * HEAD_DIM;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
 }
 
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st, int il) {
+                            void* out_hi, void* out_lo, hipStream_t st, int il, float* lse) {
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
     if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
@@ -215,20 +218,20 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch
         dim3 grid(split_tail ? full : (max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
+        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
         if (split_tail) {
             RLCF_LAUNCH_CHECK();
             attention_fwd_x3_kernel<1><<<dim3(1, n_seq, width / HEAD_DIM), dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi,
-                                                                                           (_Float16*)out_lo, il, full * 8);
+                                                                                           (_Float16*)out_lo, il, full * 8, lse);
         }
     } else if (max_q_len > 32) {
         dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
+        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
     } else {
         dim3 grid(1, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0);
+        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
     }
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

@@ -513,7 +513,10 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* f = ws.f.as<float>();
         LN_FWD(xin, b.ln1_w, b.ln1_b, h, T, W);
         TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, save ? ws.sv[l].lse : nullptr, st));
+        if (e->precision == RLCF_PREC_F16X3)      // (f32 output + log-sum-exp for the backward; the split-f16 kernel is ~3x the f32-MFMA one)
+            TRY(launch_attention_fwd_x3(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, nullptr, st, 0, save ? ws.sv[l].lse : nullptr));
+        else
+            TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, save ? ws.sv[l].lse : nullptr, st));
         e->last_flops += 4.0 * attn_pairs * W;
         TRY(gemm(e, a, W, b.out_w, W, b.out_b, xin, W, nullptr, 0, x1, W, T, W, W, 1.f, RLCF_EPI_NONE, st));
         LN_FWD(x1, b.ln2_w, b.ln2_b, h, T, W);
