@@ -871,6 +871,15 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
     torch.testing.assert_close(eng.tta_sample(views, _cfg_from_meta(meta))["final_logits"], base_p, atol=2e-4, rtol=0)
     torch.testing.assert_close(eng.visual_params(0), eng.visual_params(1), atol=0, rtol=0)
+    # loading the adapted parameters (rlcf_engine_set_visual_params / set_ln_params: refreshed transposes and split copies) and
+    # running plain inference on the clean view reproduces the call's own final logits; loading the checkpoint undoes it
+    eng.set_ln_params(o["ln_after"]); eng.set_visual_params(o["vis_after"])
+    lg = eng.logits(eng.encode_image(L.STUDENT, views[:1]), eng.text_features(ctx0))
+    torch.testing.assert_close(lg, o["final_logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(eng.visual_params(0), o["vis_after"], atol=0, rtol=0)
+    eng.set_ln_params(eng.ln_params(pristine=True)); eng.set_visual_params(eng.visual_params(2))
+    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
+    torch.testing.assert_close(eng.visual_params(3), eng.visual_params(2), atol=0, rtol=0)      # momentum state untouched = checkpoint
     eng.close()
 
 
