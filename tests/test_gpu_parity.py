@@ -792,12 +792,12 @@ def test_ln_tuning_matches_reference_fixture(L, dev, name, prec):
     torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
     torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
     multi = meta["tta_steps"] > 1
-    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=1e-3, rtol=0)
     if not multi:
         gr, og = g["ln_grad"], c("ln_grad")
         assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 2e-3
     d = (c("ln_after") - g["ln_after"]).abs()
-    assert (d > 0.1 * meta["lr"]).float().mean() < (0.05 if multi else 0.01)
+    assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
     # the prompt path still sees pristine LayerNorms afterwards
     o2 = eng.tta_sample_ln(views, _cfg_from_meta(meta))
     torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
@@ -849,11 +849,11 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
     torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
     multi = meta["tta_steps"] > 1
-    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=1e-3, rtol=0)
     keys = RR.visual_param_keys(ssd)
     grad, after = eng.merge_visual(o["ln_grad"], o["vis_grad"]), eng.merge_visual(o["ln_after"], o["vis_after"])
     torch.testing.assert_close(_tensor_norms(ssd, keys, grad), g["vis_grad_l2"], rtol=3e-3, atol=1e-9)
-    torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g["vis_delta_l2"], rtol=0.05 if multi else 0.01, atol=1e-7)
+    torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g["vis_delta_l2"], rtol=0.01, atol=1e-7)
     if "vis_grad_sample" in g:
         gr, og = g["vis_grad_sample"], grad[::7].cpu()
         assert (og - gr).norm() / gr.norm() < 2e-3
@@ -868,7 +868,7 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     # the engine is back in its pristine state: the same call repeats, and the LayerNorm path gives what it gave before
     o2 = eng.tta_sample_visual(views, _cfg_from_meta(meta))
     torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
-    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
+    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-4, rtol=0)      # (float atomics in the LayerNorm-gradient reductions: last-bit run-to-run differences)
     torch.testing.assert_close(eng.tta_sample(views, _cfg_from_meta(meta))["final_logits"], base_p, atol=2e-4, rtol=0)
     torch.testing.assert_close(eng.visual_params(0), eng.visual_params(1), atol=0, rtol=0)
     # loading the adapted parameters (rlcf_engine_set_visual_params / set_ln_params: refreshed transposes and split copies) and
@@ -878,7 +878,7 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     torch.testing.assert_close(lg, o["final_logits"], atol=2e-4, rtol=0)
     torch.testing.assert_close(eng.visual_params(0), o["vis_after"], atol=0, rtol=0)
     eng.set_ln_params(eng.ln_params(pristine=True)); eng.set_visual_params(eng.visual_params(2))
-    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-5, rtol=0)
+    torch.testing.assert_close(eng.tta_sample_ln(views, _cfg_from_meta(meta))["final_logits"], base, atol=1e-4, rtol=0)      # (float atomics in the LayerNorm-gradient reductions: last-bit run-to-run differences)
     torch.testing.assert_close(eng.visual_params(3), eng.visual_params(2), atol=0, rtol=0)      # momentum state untouched = checkpoint
     eng.close()
 

@@ -211,15 +211,15 @@ def test_ln_tuning_oracle_matches_reference(name):
     assert torch.equal(o["top5"], g["top5"])
     torch.testing.assert_close(o["logits"], g["logits"], atol=2e-4, rtol=0)
     torch.testing.assert_close(o["rewards"], g["rewards"], atol=2e-5, rtol=1e-4)
-    # Adam's steps are ~lr*sign(g): elements whose gradient is numerically ~0 take a coin-flip step, and over several
-    # steps those flips reach the logits -> looser bar for multi-step runs
+    # Adam's steps are ~lr*sign(g): elements whose gradient is numerically ~0 take a coin-flip step: the
+    # adapted parameters are compared as "all but <1 % of the elements within 0.1 lr"; the logits hold 1e-3 also after 3 steps
     multi = meta["tta_steps"] > 1
-    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=1e-3, rtol=0)
     if not multi:
         gr, og = g["ln_grad"], o["ln_grad"]
         assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 1e-3
     d = (o["ln_after"] - g["ln_after"]).abs()
-    assert (d > 0.1 * meta["lr"]).float().mean() < (0.05 if multi else 0.01)
+    assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
 
 
 VIS_CASES = ["vis_tiny_s1", "vis_tiny_s3", "vis_tinyp6_s3", "vis_small_s1"]
@@ -257,10 +257,10 @@ def test_visual_tuning_oracle_matches_reference(name):
     torch.testing.assert_close(o["logits"], g["logits"], atol=2e-4, rtol=0)
     torch.testing.assert_close(o["rewards"], g["rewards"], atol=2e-5, rtol=1e-4)
     multi = meta["tta_steps"] > 1
-    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=5e-3 if multi else 1e-3, rtol=0)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=1e-3, rtol=0)
     if not multi:
         torch.testing.assert_close(vis_tensor_norms(ssd, keys, o["ln_grad"]), g["vis_grad_l2"], rtol=2e-3, atol=1e-9)
-    torch.testing.assert_close(vis_tensor_norms(ssd, keys, o["ln_after"], ssd), g["vis_delta_l2"], rtol=0.05 if multi else 0.01, atol=1e-7)
+    torch.testing.assert_close(vis_tensor_norms(ssd, keys, o["ln_after"], ssd), g["vis_delta_l2"], rtol=0.01, atol=1e-7)
     if "vis_grad_sample" in g:
         gr, og = g["vis_grad_sample"], o["ln_grad"][::7]
         assert (og - gr).norm() / gr.norm() < 1e-3
