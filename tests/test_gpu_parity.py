@@ -1143,3 +1143,39 @@ def test_config5_rn50x64_student_vit_l14_reward(L, dev):
     assert x["top5"].tolist() == y["top5"].tolist()
     torch.testing.assert_close(x["logits"], y["logits"], atol=1e-3, rtol=0)
     torch.testing.assert_close(x["final_logits"], y["final_logits"], atol=1e-3, rtol=0)
+
+
+# ------------------------------------------------------------------------------ size-independent properties at BASELINE configs[1] size
+def test_full_size_properties_view_permutation_and_reward_baseline(L, dev):
+    """ViT-B/16 + ViT-B/16, N = 64 views, 1000 classes (BASELINE configs[1]), where the oracle is too slow to run in a test:
+    (1) views are independent units until the selection: permuting views 1..63 permutes the selected indices and leaves the adapted
+        prompt, the final logits and the top-5 unchanged;
+    (2) with reward_process and per-view baselines the K rewards of every selected view sum to zero (tpt_cls_rl.py:63-67,
+        clip_reward.py:152-165) and the loss gradient of a view's logits sums to zero over the classes;
+    (3) the one-image call and the sample-batched call give the same predictions."""
+    from rlcf_amd.engine import TTAConfig
+    N, C = 64, 1000
+    eng, ssd, rsd, tokens, ctx0 = make_engine(("ViT-B/16", "ViT-B/16"), 2 * N, C, L.TEXT_SHARED, prec=2)
+    cfg = TTAConfig(selection_p=0.1, sample_k=3, lr=7e-3, weight_decay=5e-4)
+    views = synth.make_views(1113, N, 224, device=dev)          # the seed of the tta_b16_n64 fixture: non-zero CLIP rewards
+    o = eng.tta_sample(views, cfg)
+    g = torch.Generator().manual_seed(5)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(N - 1, generator=g)]).to(dev)
+    o2 = eng.tta_sample(views[perm], cfg)
+    sel, sel2 = o["selected_idx"].long(), o2["selected_idx"].long()
+    assert sorted(perm[sel2].tolist()) == sorted(sel.tolist())                     # same views selected ...
+    assert perm[sel2].tolist() == sel.tolist()                                      # ... in the same (ascending-entropy) order
+    torch.testing.assert_close(o2["logits"], o["logits"][perm], atol=2e-5, rtol=0)
+    torch.testing.assert_close(o2["ctx_after"], o["ctx_after"], atol=1e-6, rtol=0)
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
+    assert o2["top5"].tolist() == o["top5"].tolist()
+    n_sel = sel.numel()
+    r = o["rewards"].view(n_sel, 3)
+    assert r.abs().max() > 0
+    torch.testing.assert_close(r.sum(1), torch.zeros(n_sel, device=dev), atol=2e-5, rtol=0)
+    torch.testing.assert_close(o["dlogits"].sum(1), torch.zeros(n_sel, device=dev), atol=1e-6, rtol=0)
+    both = torch.stack([views, views[perm]])
+    top5, fl = eng.tta_batch(both, cfg, want_logits=True)
+    assert top5[0].tolist() == o["top5"].tolist() and top5[1].tolist() == o["top5"].tolist()
+    torch.testing.assert_close(fl[0], o["final_logits"][0], atol=2e-4, rtol=0)
+    eng.close()
