@@ -1154,8 +1154,17 @@ def test_full_size_properties_view_permutation_and_reward_baseline(L, dev):
         clip_reward.py:152-165) and the loss gradient of a view's logits sums to zero over the classes;
     (3) the one-image call and the sample-batched call give the same predictions."""
     from rlcf_amd.engine import TTAConfig
+    from rlcf_amd.engine import Engine
     N, C = 64, 1000
-    eng, ssd, rsd, tokens, ctx0 = make_engine(("ViT-B/16", "ViT-B/16"), 2 * N, C, L.TEXT_SHARED, prec=2)
+    geo = synth.GEOMETRIES["ViT-B/16"]
+    ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)
+    eng = Engine(geo, geo, 2 * N, C, 2)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(geo, C, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
+    eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
     cfg = TTAConfig(selection_p=0.1, sample_k=3, lr=7e-3, weight_decay=5e-4)
     views = synth.make_views(1113, N, 224, device=dev)          # the seed of the tta_b16_n64 fixture: non-zero CLIP rewards
     o = eng.tta_sample(views, cfg)
@@ -1178,4 +1187,74 @@ def test_full_size_properties_view_permutation_and_reward_baseline(L, dev):
     top5, fl = eng.tta_batch(both, cfg, want_logits=True)
     assert top5[0].tolist() == o["top5"].tolist() and top5[1].tolist() == o["top5"].tolist()
     torch.testing.assert_close(fl[0], o["final_logits"][0], atol=2e-4, rtol=0)
+    eng.close()
+
+
+def test_full_size_properties_layernorm_tuning_l14(L, dev):
+    """BASELINE configs[2] size (ViT-L/14 + ViT-L/14, N = 64, 1000 classes, LayerNorm tuning): the sample-batched call equals the
+    one-image call, a permutation of views 1..63 leaves the result unchanged, and lr = 0 reproduces plain inference."""
+    from rlcf_amd.engine import TTAConfig
+    from rlcf_amd.engine import Engine
+    N, C = 64, 1000
+    geo = synth.GEOMETRIES["ViT-L/14"]
+    ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)      # (generated on the device: 2 x 428 M parameters)
+    eng = Engine(geo, geo, 2 * N, C, 2)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(geo, C, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
+    eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+    cfg = TTAConfig(selection_p=0.1, sample_k=3, lr=1e-4, weight_decay=5e-4)
+    views = synth.make_views(1113, N, 224, device=dev)
+    o = eng.tta_sample_ln(views, cfg)
+    g = torch.Generator().manual_seed(9)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(N - 1, generator=g)]).to(dev)
+    o2 = eng.tta_sample_ln(views[perm], cfg)
+    assert perm[o2["selected_idx"].long()].tolist() == o["selected_idx"].long().tolist()
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=1e-3, rtol=0)
+    top5, fl = eng.tta_batch_ln(torch.stack([views, views[perm]]), cfg, want_logits=True)
+    assert top5[0].tolist() == o["top5"].tolist() and top5[1].tolist() == o["top5"].tolist()
+    torch.testing.assert_close(fl[0], o["final_logits"][0], atol=1e-3, rtol=0)
+    z = eng.tta_sample_ln(views, TTAConfig(selection_p=0.1, sample_k=3, lr=0.0, weight_decay=0.0))
+    plain = eng.logits(eng.encode_image(L.STUDENT, views[:1]), eng.text_features(ctx0.to(dev)))
+    torch.testing.assert_close(z["final_logits"], plain, atol=2e-4, rtol=0)
+    assert (o["final_logits"] - plain).abs().max() > 1e-4          # ... and the tuned run did move the logits
+    eng.close()
+
+
+def test_full_size_properties_full_encoder_tuning_b16(L, dev):
+    """scripts/rlcf-tune.sh size (ViT-B/16 + ViT-B/16, N = 64, 1000 classes, every visual parameter tuned, 3 steps): permuting views
+    1..63 leaves the result unchanged, lr = 0 reproduces plain inference, the first-step gradient does not depend on the number of
+    steps, and the LayerNorm part of that gradient is the LayerNorm-only path's gradient."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    N, C = 64, 1000
+    geo = synth.GEOMETRIES["ViT-B/16"]
+    ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)
+    eng = Engine(geo, geo, N, C, 2)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(geo, C, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
+    eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+    views = synth.make_views(1113, N, 224, device=dev)
+    cfg = lambda steps, lr=1e-5: TTAConfig(selection_p=0.1, sample_k=3, lr=lr, weight_decay=5e-4 if lr else 0.0, tta_steps=steps)
+    o3, o1 = eng.tta_sample_visual(views, cfg(3)), eng.tta_sample_visual(views, cfg(1))
+    assert o1["vis_grad"].norm() > 0                                   # (float atomics in the attention backward: last-bit run-to-run differences)
+    assert (o3["vis_grad"] - o1["vis_grad"]).norm() / o1["vis_grad"].norm() < 1e-5
+    assert (o3["ln_grad"] - o1["ln_grad"]).norm() / o1["ln_grad"].norm() < 1e-5
+    ln = eng.tta_sample_ln(views, cfg(1))
+    assert (ln["ln_grad"] - o1["ln_grad"]).norm() / o1["ln_grad"].norm() < 1e-4
+    g = torch.Generator().manual_seed(3)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(N - 1, generator=g)]).to(dev)
+    p3 = eng.tta_sample_visual(views[perm], cfg(3))
+    assert perm[p3["selected_idx"].long()].tolist() == o3["selected_idx"].long().tolist()
+    torch.testing.assert_close(p3["final_logits"], o3["final_logits"], atol=1e-3, rtol=0)
+    assert p3["top5"].tolist() == o3["top5"].tolist()
+    z = eng.tta_sample_visual(views, cfg(3, lr=0.0))
+    plain = eng.logits(eng.encode_image(L.STUDENT, views[:1]), eng.text_features(ctx0))
+    torch.testing.assert_close(z["final_logits"], plain, atol=2e-4, rtol=0)
+    torch.testing.assert_close(z["vis_after"], eng.visual_params(1), atol=0, rtol=0)
+    assert (o3["final_logits"] - plain).abs().max() > 1e-4
     eng.close()
