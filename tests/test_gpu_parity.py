@@ -277,16 +277,34 @@ def make_engine(meta_or_names, n_views, n_cls, text_mode, student_seed=11, rewar
     from rlcf_amd.engine import Engine
     s_name, r_name = meta_or_names
     sg, rg = synth.GEOMETRIES[s_name], synth.GEOMETRIES[r_name]
-    ssd = synth.make_state_dict(sg, student_seed)
-    rsd = synth.make_state_dict(rg, reward_seed)
+    # weights are generated on the device (the counter-hash generator is bit-identical on CPU and GPU: test_synth_generator_bit_identical_on_gpu) and
+    # handed back as CPU copies for the oracle
+    gdev = torch.device("cuda", torch.cuda.current_device())
+    ssd_d, rsd_d = synth.make_state_dict(sg, student_seed, device=gdev), synth.make_state_dict(rg, reward_seed, device=gdev)
     eng = Engine(sg, rg, n_views, n_cls, prec)
-    eng.load_state_dict(_lib.STUDENT, ssd)
-    eng.load_state_dict(_lib.REWARD, rsd)
+    eng.load_state_dict(_lib.STUDENT, ssd_d)
+    eng.load_state_dict(_lib.REWARD, rsd_d)
     eng.finalize()
+    ssd, rsd = {k: v.cpu() for k, v in ssd_d.items()}, {k: v.cpu() for k, v in rsd_d.items()}
     tokens = synth.make_token_bank(sg, n_cls, seed=bank_seed, n_ctx=n_ctx)
     ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(sg, n_ctx))
     eng.set_class_bank(tokens, n_ctx, ctx0, text_mode)
     return eng, ssd, rsd, tokens, ctx0
+
+
+@pytest.mark.parametrize("geo", ["tiny", "small", "tiny-rn"])
+def test_synth_generator_bit_identical_on_gpu(L, dev, geo):
+    """The seeded weight / view generator gives the same bits on the CPU (oracle, fixture generation) and on the GPU (tests, bench);
+    ModifiedResNet BatchNorm statistics to within one ulp."""
+    g = synth.GEOMETRIES[geo]
+    a, b = synth.make_state_dict(g, 11), synth.make_state_dict(g, 11, device=dev)
+    assert a.keys() == b.keys()
+    for k in a:
+        if geo.endswith("rn") and not torch.equal(a[k], b[k].cpu()):     # BatchNorm statistics go through exp(): last-bit differences
+            torch.testing.assert_close(a[k], b[k].cpu(), rtol=1e-6, atol=0)
+        else:
+            assert torch.equal(a[k], b[k].cpu()), k
+    assert torch.equal(synth.make_views(1000, 5, g.image_resolution), synth.make_views(1000, 5, g.image_resolution, device=dev).cpu())
 
 
 @pytest.mark.parametrize("geo", ["tiny", "small"])
