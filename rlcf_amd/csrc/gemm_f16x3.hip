@@ -16,6 +16,7 @@
 // 16-B slots); one barrier per K tile.
 #include "kernels.h"
 #include <cstdlib>
+#include <algorithm>
 
 struct GemmX3Args {
     const _Float16 *Ahi, *Alo; int lda;
@@ -31,6 +32,8 @@ struct GemmX3Args {
     int c_il;                          // split output interleaved: column c of a row sits at (c/32)*64 + c%32 (hi) / +32 (lo, = Clo)
     const float* alpha_dev;            // optional device scalar multiplied into alpha (undoes a data-dependent operand pre-scale)
     int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
+    int ksplit;                        // 128x128 DMA-ring kernel only: blockIdx.y walks K tiles [y*per, (y+1)*per); raw partial tiles go
+    float* ws;                         // to ws[ksplit][M][N] and gemm_x3_splitk_reduce_kernel applies alpha / bias / epilogue
 };
 
 __device__ __forceinline__ int x3_ocol(const GemmX3Args& g, int col) { return g.c_il ? (((col >> 5) << 6) | (col & 31)) : col; }
@@ -294,9 +297,16 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);
 #define V2_FENCE __builtin_amdgcn_sched_barrier(0);
 
-    const int nk = g.K / X3_BK;
-    V2_ISSUE(0, 0)
-    if (nk > 1) V2_ISSUE(g.kstep, 1)
+    // split-K (a few tiles, long K loop): this block walks K tiles [kt0, kt0 + nk) and leaves its raw partial tile in g.ws
+    int nk = g.K / X3_BK, kt0 = 0;
+    if (g.ksplit > 1) {
+        const int per = (nk + g.ksplit - 1) / g.ksplit;
+        kt0 = blockIdx.y * per;
+        nk = min(nk, kt0 + per) - kt0;               // (the launcher makes every slice non-empty)
+    }
+    const int kb = kt0 * g.kstep;
+    V2_ISSUE(kb, 0)
+    if (nk > 1) V2_ISSUE(kb + g.kstep, 1)
     const int swz = (l32 >> 2) & 3;
     const int aoff = (wm * 64 + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
     int cur = 0;
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const bool pf = kt + 2 < nk;
-        const int kn = (kt + 2) * g.kstep;
+        const int kn = kb + (kt + 2) * g.kstep;
         char* sn = smem + (cur >= 1 ? cur - 1 : 2) * STAGE;                // stage (cur + 2) % 3
         const char* sb = smem + cur * STAGE;
         h16x8 ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
@@ -354,6 +364,16 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         __syncthreads();
         const int c4 = (lane & 15) * 4, rsub = lane >> 4;
         const int col = n0 + wn * 64 + c4;
+        if (g.ksplit > 1) {                                                 // raw partial sums; the reduce kernel finishes the job
+            float* wsz = g.ws + (size_t)blockIdx.y * g.M * g.N;
+            if (col < g.N)
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
+                    if (row < g.M) *(float4*)(wsz + (size_t)row * g.N + col) = *(const float4*)(park + rl * ELD + c4);
+                }
+            return;
+        }
         if (col < g.N) {                                                    // N % 4 == 0 is checked by the launcher
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
@@ -796,6 +816,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     amax_commit(g.amax_out, am);
 }
 
+// second pass of the split-K form: C = epi(alpha * sum_z ws[z] + bias) (+ residual), the epilogue of the kernels above, one thread
+// per 4 columns of a row; the slices are added in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g) {
+    float am = 0.f;
+    const int n4 = g.N >> 2;
+    const long total = (long)g.M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+        float4 a4 = *(const float4*)(g.ws + (size_t)row * g.N + col);
+        for (int z = 1; z < g.ksplit; ++z) {
+            const float4 t = *(const float4*)(g.ws + ((size_t)z * g.M + row) * g.N + col);
+            a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) bv = *(const float4*)(g.bias + col);
+        const float al = x3_alpha(g);
+        float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+        if (g.epilogue == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+        } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
+            const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+            v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+        }
+        if (g.residual) {
+            const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (g.epilogue == RLCF_EPI_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (g.C) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.Chi) {
+            h16x4 hh, ll;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+            *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
+            *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+        }
+    }
+    amax_commit(g.amax_out, am);
+}
+
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
@@ -868,9 +933,32 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2s));
             attr2s = true;
         }
-        gemm_nt_f16x3_v2_kernel<2><<<dim3(blocks2s), dim3(256), sh2s, st>>>(g);
+        // few tiles and a long K loop (one image's token matrix against a W x 4W / W x 3W weight): split the K loop over blockIdx.y
+        // and finish in a reduce + epilogue pass (RLCF_X3_NOSPLITK=1 switches it off)
+        static int nosplit = -1;
+        if (nosplit < 0) { const char* e = getenv("RLCF_X3_NOSPLITK"); nosplit = e ? atoi(e) : 0; }
+        const int nkt = K / X3_BK;
+        int ksplit = 1;
+        if (!nosplit && blocks2s <= 96 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
+        static float* ws = nullptr;
+        static size_t ws_bytes = 0;
+        if (ksplit > 1) {
+            const size_t need = (size_t)ksplit * M * N * sizeof(float);
+            if (need > ws_bytes) {
+                if (ws) (void)hipFree(ws);
+                ws = nullptr; ws_bytes = 0;
+                if (hipMalloc((void**)&ws, need) == hipSuccess) ws_bytes = need; else { (void)hipGetLastError(); ksplit = 1; }
+            }
+        }
+        g.ksplit = ksplit; g.ws = ws;
+        gemm_nt_f16x3_v2_kernel<2><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
+        if (ksplit > 1) {
+            const long groups = (long)M * (N / 4);
+            gemm_x3_splitk_reduce_kernel<<<dim3((unsigned)std::min<long>((groups + 255) / 256, 2048)), dim3(256), 0, st>>>(g);
+            RLCF_LAUNCH_CHECK();
+        }
         return RLCF_OK;
     }
     const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
