@@ -939,7 +939,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         if (nosplit < 0) { const char* e = getenv("RLCF_X3_NOSPLITK"); nosplit = e ? atoi(e) : 0; }
         const int nkt = K / X3_BK;
         int ksplit = 1;
-        if (!nosplit && blocks2s <= 96 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
+        if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
         static float* ws = nullptr;
         static size_t ws_bytes = 0;
         if (ksplit > 1) {
