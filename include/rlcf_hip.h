@@ -11,7 +11,10 @@
  *     caller-owned (torch) memory, contiguous row-major, unless marked HOST;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *   - return 0 on success, negative rlcf_status on error (rlcf_last_error() has text);
- *   - an engine is not thread-safe; no allocation happens on the per-sample path.
+ *   - an engine is not thread-safe; no allocation happens on the per-sample path: every scratch buffer of the engine calls
+ *     belongs to the engine (one engine = one device, one stream at a time; two engines never share memory).  The stateless
+ *     op-level calls that need scratch (rlcf_gemm_nt in split-f16 mode, rlcf_reward_loss*) take it from the stream-ordered
+ *     allocator of `stream` (hipMallocAsync / hipFreeAsync).
  */
 #ifndef RLCF_HIP_H
 #define RLCF_HIP_H
@@ -214,6 +217,8 @@ typedef struct {                 /* flags read on the path, TPT/params.py:13-98 
     int sparse_backward;         /* 1: back-propagate only the n_sel*K touched classes when exact */
     int skip_final;              /* 1: tuning steps only (test_time_tuning); the caller runs the final inference */
     const float* ctx_in;         /* DEVICE [n_ctx,W] starting prompt, NULL = ctx_init_state (model.reset()) */
+    int n_sel;                   /* int(N * selection_p) as the caller's Python computes it (a double product, tpt_cls_rl.py:34);
+                                    0 = derive it here from the float selection_p (can differ by one at exact boundaries) */
 } rlcf_tta_args;
 
 typedef struct {                 /* every pointer optional (NULL = not wanted); DEVICE */
@@ -234,6 +239,8 @@ typedef struct {                 /* every pointer optional (NULL = not wanted); 
     float* ln_after;             /* [(4L+4)*Wv] adapted LayerNorm parameters                                                 */
     float* vis_grad;             /* [visual_param_count] first-step gradient of the other visual parameters (rlcf_tta_sample_visual) */
     float* vis_after;            /* [visual_param_count] adapted values                                                      */
+    int32_t* step_skipped;       /* [tta_steps] 1 = the gradient of that step held an inf / NaN and the optimizer step was skipped
+                                    (GradScaler.step semantics, TPT/tpt_cls_rl.py:76-79); single-sample calls only                */
 } rlcf_tta_out;
 
 /* One iteration of the harness loop TPT/tpt_cls_rl.py:251-262: reset ctx and optimizer state,
@@ -258,6 +265,11 @@ int rlcf_engine_set_ln_params(rlcf_engine*, const float* in, rlcf_stream stream)
  * update_counter reached update_freq) the reset state becomes (1-w)*checkpoint + w*momentum_state.  Makes test samples
  * order-dependent: single replica only. */
 int rlcf_engine_momentum_update(rlcf_engine*, const float* current, double momentum, double update_w, int apply, rlcf_stream stream);
+/* The state part of CLIPCLS_TTA.reset_classnames_and_state (custom_clip.py:449-454): visual.load_state_dict(clip_state_dict), then
+ * initial_state_dict and momentum_state_dict re-initialised from it — the reset state and the EMA of the tunable LayerNorms (and of the
+ * flat visual vector, once rlcf_tta_sample_visual has been used) return to the checkpoint.  Call when the harness moves to the next
+ * dataset, so that the EMA of one set does not leak into the next. */
+int rlcf_engine_reset_visual_state(rlcf_engine*, rlcf_stream stream);
 
 /* Full image-encoder tuning: CLIPCLS_TTA(only_visual=True, only_norm=False) of TPT/clip/custom_clip.py:364-497, whose
  * parameters() is then clip_model.visual.parameters() (:477-479) — the `--tune_norm 0` default (TPT/params.py:73) that
@@ -300,6 +312,10 @@ int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
  * 2 = gemm_nt_f16x3_v2_kernel, 1 = gemm_nt_f16x3_kernel, 0 = the f32-MFMA kernels, -1 = all. */
 int rlcf_profile_gemm(int enable);
 int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops);
+/* the same records one by one (launch order): kind as above (10 = the fused attention forward of the split-f16 pipeline),
+ * HIP-event duration in ms, algorithmic FLOPs, dims3 = {M, N, K} of a GEMM / {rows, width, longest sequence} of an attention launch */
+int rlcf_profile_count(void);
+int rlcf_profile_entry(int i, int* kind, double* ms, double* flops, int* dims3);
 
 #ifdef __cplusplus
 }

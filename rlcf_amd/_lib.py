@@ -44,11 +44,11 @@ class TTAArgs(C.Structure):
                 ("lr", C.c_float), ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("flags", C.c_int), ("clipscore_weight", C.c_float),
                 ("min_entropy_w", C.c_float), ("sparse_backward", C.c_int), ("skip_final", C.c_int),
-                ("ctx_in", C.c_void_p)]
+                ("ctx_in", C.c_void_p), ("n_sel", C.c_int)]
 
 
 TTA_OUT_FIELDS = ("logits", "entropy", "selected_idx", "topk_idx", "clip_score", "rewards", "loss", "dlogits",
-                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5", "ln_grad", "ln_after", "vis_grad", "vis_after")
+                  "ctx_grad", "ctx_after", "reward_image_features", "final_logits", "top5", "ln_grad", "ln_after", "vis_grad", "vis_after", "step_skipped")
 
 
 class TTAOut(C.Structure):
@@ -87,6 +87,7 @@ SIGNATURES = {
     "rlcf_make_views_augmix": (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, C.c_size_t, P]),
     "rlcf_tta_batch_ln": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_engine_momentum_update": (I, [P, P, D, D, I, P]),
+    "rlcf_engine_reset_visual_state": (I, [P, P]),
     "rlcf_engine_create_ensemble": (P, [C.POINTER(ClipCfg), C.POINTER(ClipCfg), I, I, I, I]),
     "rlcf_engine_set_reward_mix": (I, [P, P, I, I]),
     "rlcf_reward_loss_ensemble": (I, [P, I, P, I, I, I, I, P, P, P, P, I, F, I, F, P, P, P, P, P, P]),
@@ -108,6 +109,8 @@ SIGNATURES = {
     "rlcf_engine_text_rows": (I, [P]),
     "rlcf_profile_gemm": (I, [I]),
     "rlcf_profile_read": (I, [I, C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
+    "rlcf_profile_count": (I, []),
+    "rlcf_profile_entry": (I, [I, C.POINTER(I), C.POINTER(D), C.POINTER(D), C.POINTER(I)]),
 }
 
 

@@ -25,12 +25,28 @@ def get_reward_model(device, args):
                        sample_k=args.sample_k, reward_process=args.reward_process, process_batch=args.process_batch)
 
 
+def _gemm_nt(a: torch.Tensor, w: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """alpha * a @ w^T on the HIP GEMM (rlcf_gemm_nt, f32-MFMA kernel); K is zero-padded to the kernel's granule of 16."""
+    a, w = a.float().contiguous(), w.float().contiguous()
+    k = a.shape[1]
+    if k % 16:
+        a, w = nn.functional.pad(a, (0, 16 - k % 16)), nn.functional.pad(w, (0, 16 - k % 16))
+        k = a.shape[1]
+    out = torch.empty(a.shape[0], w.shape[0], device=a.device)
+    L.check(L.lib().rlcf_gemm_nt(a.data_ptr(), k, w.data_ptr(), k, None, None, 0, None, 0, out.data_ptr(), w.shape[0], a.shape[0],
+                                 w.shape[0], k, float(alpha), L.EPI_NONE, L.PREC_F32, torch.cuda.current_stream().cuda_stream), "gemm_nt")
+    return out
+
+
 def _clamped_scores(bank: torch.Tensor, feats: torch.Tensor, index: torch.Tensor, k: int, weight: float, pairwise: bool) -> torch.Tensor:
-    """max(weight * <bank[index], feats>, 0): every indexed bank row against every feature row (pairwise), or entry i against
-    feature row i // k (the K sampled classes of a view)."""
+    """CLIPScore of the reference (clip_reward.py:118-128): text rows bank[index] [n*K, D] against the image features repeated K
+    times [n*K, D]; pairwise: the full [n*K, n*K] matrix weight * text @ image^T, else entry e against its own view e // K.
+    max(., 0), squeezed.  The products run on the HIP GEMM; torch only indexes."""
     rows = bank[index.long()]
-    sim = rows @ feats.t() if pairwise else (rows * feats.repeat_interleave(k, dim=0)).sum(-1)
-    return (weight * sim).clamp_min(0).squeeze()
+    sim = _gemm_nt(rows, feats, weight)                                   # [n*K, n]: entry e against every view
+    view_of = torch.arange(rows.shape[0], device=rows.device) // k
+    sim = sim[:, view_of] if pairwise else sim[torch.arange(rows.shape[0], device=rows.device), view_of]
+    return sim.clamp_min(0).squeeze()
 
 
 def _baseline(score: torch.Tensor, enabled: bool, amplify: bool) -> torch.Tensor:
@@ -98,7 +114,7 @@ class CLIPRewards(BaseRewards):
         """clip_reward.py:139-150.  The class bank of the reward model is the tokenised bank of the student
         (tpt_cls_rl.py:183); the engine caches its features in rlcf_engine_set_class_bank."""
         if tokenized_cap is None:
-            tokenized_cap = clip_store.tokenize(captions)
+            tokenized_cap = clip_store.tokenize(captions, truncate=True)          # clip_reward.py:142
         bank = runtime.SESSION.tokens
         if bank is None or bank.shape != tokenized_cap.shape or not torch.equal(bank, tokenized_cap.detach().cpu()):
             raise NotImplementedError("reward class bank must be the student's tokenized_prompts (tpt_cls_rl.py:183)")
@@ -119,8 +135,11 @@ class CLIPRewards(BaseRewards):
 
     @torch.no_grad()
     def calulate_similarity(self):
-        """clip_reward.py:167-177."""
-        return self.clipscore_weight * self.image_features @ self.class_features.t()
+        """clip_reward.py:167-177: (logits_per_image, logits_per_text) = (exp(logit_scale) * image @ class^T, its transpose), the
+        pair tune_cls_kd.py:46 unpacks; logit_scale is the reward checkpoint's."""
+        scale = float(self.clip_model.state_dict["logit_scale"].float().exp())
+        logits_per_image = _gemm_nt(self.image_features, self.class_features, scale)
+        return logits_per_image, logits_per_image.t()
 
 
 class CLIPRewardsMultiple(BaseRewards):

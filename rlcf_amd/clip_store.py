@@ -2,10 +2,11 @@
 
 The reference `clip.load(name, device, download_root)` (TPT/clip/clip.py:94-194) downloads /
 opens OpenAI JIT archives and returns ``(model, embed_dim, preprocess)``.  There is no network
-here and no archive reader: a checkpoint is an OpenAI-layout ``state_dict`` (the key layout
-``build_model`` accepts, TPT/clip/model.py:399-436) that is either registered in-process
-(`register_checkpoint`) or stored as ``<clip_root>/<name with / -> ->.pt`` (``torch.save`` of the
-dict).  `tokenize` is pluggable (`set_tokenizer`): the BPE vocabulary file is data the user owns.
+here: a checkpoint is an OpenAI-layout ``state_dict`` (the key layout ``build_model`` accepts,
+TPT/clip/model.py:399-436) that is either registered in-process (`register_checkpoint`) or read from
+``<clip_root>/<name with / -> ->.pt`` — a TorchScript archive as OpenAI publishes them (``torch.jit.load``,
+clip.py:119-131), a ``torch.save`` of the dict, or of ``{"state_dict": dict}``; the geometry is inferred from
+the tensor shapes exactly as ``build_model`` does (:400-422).  `tokenize` is pluggable (`set_tokenizer`): the BPE vocabulary file is data the user owns.
 """
 from __future__ import annotations
 
@@ -78,7 +79,10 @@ def tokenize(texts: Union[str, List[str]], context_length: int = 77, truncate: b
     if _TOKENIZER is None:
         raise RuntimeError("no tokenizer installed: call rlcf_amd.clip_store.set_tokenizer(fn) with a CLIP BPE tokenizer "
                            "(or a SyntheticBank.tokenize for seeded runs)")
-    return _TOKENIZER(texts, context_length)
+    try:
+        return _TOKENIZER(texts, context_length, truncate)
+    except TypeError:                      # a two-argument tokenizer: over-long texts raise in it, as with truncate=False
+        return _TOKENIZER(texts, context_length)
 
 
 class SyntheticBank:

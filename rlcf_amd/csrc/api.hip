@@ -13,10 +13,27 @@ void rlcf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+#include <mutex>
+#include <map>
+int rlcf_func_lds(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;          // (device, kernel) -> largest size granted so far
+    int dev = 0;
+    RLCF_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& cur = done[{dev, fn}];
+    if (bytes > cur) {
+        RLCF_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cur = bytes;
+    }
+    return RLCF_OK;
+}
+
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 3; }   // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
+int rlcf_version(void) { return 4; }   // 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+//    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
 int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
@@ -25,16 +42,19 @@ int rlcf_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* 
     RLCF_ARG_CHECK(A && W && C && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3));
     RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_RELU);
     RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
-    if (precision == RLCF_PREC_F16X3) {          // op-level convenience: split both operands into library scratch
-        static DevBuf ah, al, wh, wl;
-        RLCF_ARG_CHECK(lda == K && ldw == K);
-        int rc;
-        if ((rc = ah.ensure((size_t)M * K * 2)) || (rc = al.ensure((size_t)M * K * 2)) || (rc = wh.ensure((size_t)N * K * 2)) ||
-            (rc = wl.ensure((size_t)N * K * 2))) return rc;
-        if ((rc = launch_split_f16x2(A, ah.p, al.p, (int64_t)M * K, (hipStream_t)stream))) return rc;
-        if ((rc = launch_split_f16x2(W, wh.p, wl.p, (int64_t)N * K, (hipStream_t)stream))) return rc;
-        return launch_gemm_f16x3(ah.p, al.p, K, wh.p, wl.p, K, bias, residual, ldr, aux, ldaux, C, ldc, nullptr, nullptr, 0, M, N, K,
-                                 alpha, epilogue, (hipStream_t)stream);
+    if (precision == RLCF_PREC_F16X3) {          // op-level convenience: both operands split into stream-ordered scratch
+        RLCF_ARG_CHECK(lda == K && ldw == K && M > 0 && N > 0 && K > 0);
+        hipStream_t st = (hipStream_t)stream;
+        const size_t ab = (size_t)M * K * 2, wb = (size_t)N * K * 2;
+        char* buf = nullptr;
+        RLCF_HIP_CHECK(hipMallocAsync((void**)&buf, 2 * ab + 2 * wb + 1024, st));
+        void *ah = buf, *al = buf + ab, *wh = buf + 2 * ab, *wl = buf + 2 * ab + wb;
+        int rc = launch_split_f16x2(A, ah, al, (int64_t)M * K, st);
+        if (!rc) rc = launch_split_f16x2(W, wh, wl, (int64_t)N * K, st);
+        if (!rc) rc = launch_gemm_f16x3(ah, al, K, wh, wl, K, bias, residual, ldr, aux, ldaux, C, ldc, nullptr, nullptr, 0, M, N, K, alpha,
+                                        epilogue, st);
+        (void)hipFreeAsync(buf, st);
+        return rc;
     }
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
@@ -88,9 +108,13 @@ int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* ent
 int rlcf_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K, const float* class_feat,
                      const float* reward_img, int Dr, float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx,
                      float* clip_score, float* rewards, float* loss, float* dlogits, rlcf_stream stream) {
-    RLCF_ARG_CHECK(logits && class_feat && reward_img);
-    return launch_reward_loss(logits, ld_logits, sel, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags, min_entropy_w,
-                              topk_idx, clip_score, rewards, loss, dlogits, (hipStream_t)stream);
+    RLCF_ARG_CHECK(logits && class_feat && reward_img && n_sel > 0);
+    float* stats = nullptr;          // stateless call: scratch from the stream-ordered allocator (the engine path owns its own)
+    RLCF_HIP_CHECK(hipMallocAsync((void**)&stats, reward_loss_stats_floats(n_sel) * sizeof(float), (hipStream_t)stream));
+    const int rc = launch_reward_loss(logits, ld_logits, sel, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags, min_entropy_w,
+                                      topk_idx, clip_score, rewards, loss, dlogits, stats, (hipStream_t)stream);
+    (void)hipFreeAsync(stats, (hipStream_t)stream);
+    return rc;
 }
 int rlcf_reward_loss_ensemble(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K, int n_models,
                               const float* const* class_feats, const float* const* reward_imgs, const int* Dr, const float* mix, int mean,
@@ -103,8 +127,13 @@ int rlcf_reward_loss_ensemble(const float* logits, int ld_logits, const int32_t*
         b.class_feat[m] = class_feats[m]; b.reward_img[m] = reward_imgs[m]; b.Dr[m] = Dr[m]; b.mix[m] = mean ? 1.f : mix[m];
     }
     b.post_div = mean ? (float)n_models : 1.f;
-    return launch_reward_loss_bank(logits, ld_logits, sel, 1, n_sel, C, K, b, clipscore_weight, flags, min_entropy_w, topk_idx, clip_score,
-                                   rewards, loss, dlogits, (hipStream_t)stream);
+    RLCF_ARG_CHECK(n_sel > 0);
+    float* stats = nullptr;
+    RLCF_HIP_CHECK(hipMallocAsync((void**)&stats, reward_loss_stats_floats(n_sel) * sizeof(float), (hipStream_t)stream));
+    const int rc = launch_reward_loss_bank(logits, ld_logits, sel, 1, n_sel, C, K, b, clipscore_weight, flags, min_entropy_w, topk_idx,
+                                           clip_score, rewards, loss, dlogits, stats, (hipStream_t)stream);
+    (void)hipFreeAsync(stats, (hipStream_t)stream);
+    return rc;
 }
 int rlcf_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1, float beta2,
                     float eps, float weight_decay, rlcf_stream stream) {
@@ -186,7 +215,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0;
     if (precision == RLCF_PREC_F16X3) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
-        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0;
+        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0;
     }
     if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { rlcf_engine_destroy(e); return nullptr; }
@@ -222,7 +251,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
-                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi}) d->release();
+                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->rl_stats, &e->step_skip}) d->release();
     delete e;
 }
 
@@ -356,6 +385,19 @@ int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double mom
                                       (hipStream_t)stream));
     return RLCF_OK;
 }
+int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && e->ln_count > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = (size_t)e->ln_count * sizeof(float);
+    for (DevBuf* d : {&e->ln_params, &e->ln_init, &e->ln_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->ln_clip.p, nb, hipMemcpyDeviceToDevice, st));
+    if (e->vw_count) {
+        const size_t vb = e->vw_count * sizeof(float);
+        for (DevBuf* d : {&e->vw, &e->vw_init, &e->vw_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->vw_clip.p, vb, hipMemcpyDeviceToDevice, st));
+        e->vw_dirty = false;
+        return engine_visual_refresh(e, st);
+    }
+    return RLCF_OK;
+}
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
@@ -388,6 +430,17 @@ int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_f
         ms += t; fl += g_prof.flops[i];
     }
     *launches = cnt; *total_ms = ms; *total_flops = fl;
+    return RLCF_OK;
+}
+
+int rlcf_profile_count(void) { return g_prof.n; }
+int rlcf_profile_entry(int i, int* kind, double* ms, double* flops, int* dims3) {
+    RLCF_ARG_CHECK(i >= 0 && i < g_prof.n && kind && ms && flops && dims3);
+    RLCF_HIP_CHECK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    float t = 0.f;
+    RLCF_HIP_CHECK(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    *kind = g_prof.kind[i]; *ms = t; *flops = g_prof.flops[i];
+    for (int d = 0; d < 3; ++d) dims3[d] = g_prof.dims[3 * i + d];
     return RLCF_OK;
 }
 

@@ -235,11 +235,10 @@ int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* se
                          int causal, float* dqkv, hipStream_t st) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_keys > 0 && max_keys <= ABWD_MAXK);
     const size_t bytes = (size_t)(4 * max_keys * 65 + max_keys * (max_keys + 1)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const size_t cap = (size_t)(4 * ABWD_MAXK * 65 + ABWD_MAXK * (ABWD_MAXK + 1)) * sizeof(float);
-        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap));
-        attr_set = true;
+        int rc_ = rlcf_func_lds((const void*)attention_bwd_kernel, cap);
+        if (rc_ != RLCF_OK) return rc_;
     }
     attention_bwd_kernel<<<dim3(n_seq, width / HEAD_DIM), dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv);
     RLCF_LAUNCH_CHECK();
@@ -378,11 +377,7 @@ int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_se
                               int width, int causal, float* dqkv, hipStream_t st) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_keys > 0 && max_keys <= ABL_MAXK && max_q_len > 0);
     const size_t bytes = (size_t)(2 * 32 * 65 + 2 * 32 * (ABL_MAXK + 1) + 64 * 65 + 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
+    { int rc_ = rlcf_func_lds((const void*)attention_bwd_long_kernel, bytes); if (rc_ != RLCF_OK) return rc_; }
     dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
     RLCF_ARG_CHECK(grid.y <= 65535);
     attention_bwd_long_kernel<<<grid, dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv);
@@ -537,11 +532,7 @@ int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* l
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_q_len > 0 && qkv && out && lse && dout && dqkv);
     const size_t bytes = (size_t)(2 * 32 * ABM_LD + 2 * 128 * ABM_LD + 2 * 32 * ABM_PLD + 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
+    { int rc_ = rlcf_func_lds((const void*)attention_bwd_mfma_kernel, bytes); if (rc_ != RLCF_OK) return rc_; }
     dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
     RLCF_ARG_CHECK(grid.y <= 65535);
     attention_bwd_mfma_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, seqs, width, causal, dqkv);

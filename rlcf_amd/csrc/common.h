@@ -6,6 +6,9 @@
 #include "../../include/rlcf_hip.h"
 
 void rlcf_set_error(const char* fmt, ...);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the attribute belongs to the kernel ON A DEVICE, so a
+// process-wide "already set" flag would leave the second GPU of a process at the 64 KB default.  Returns an rlcf_status.
+int rlcf_func_lds(const void* fn, size_t bytes);
 
 #define RLCF_HIP_CHECK(expr)                                                              \
     do {                                                                                  \

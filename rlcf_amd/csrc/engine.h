@@ -130,6 +130,9 @@ struct rlcf_engine {
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
     DevBuf a_hi;                     // interleaved split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
+    DevBuf gemm_ws;                  // split-K workspace of the small-grid split-f16 GEMM (X3_SPLITK_WS_BYTES, sized at create)
+    DevBuf rl_stats;                 // per-row scratch of the reward / loss kernels
+    DevBuf step_skip;                // int32 per test sample: gradient held an inf / NaN -> optimizer step skipped (GradScaler semantics)
     double last_flops = 0.0;
 };
 
@@ -138,7 +141,9 @@ struct GemmProfile {                 // optional per-launch timing of the domina
     int n = 0;
     std::vector<hipEvent_t> ev;      // 2 per launch
     std::vector<double> flops;
-    std::vector<int> kind;           // 0 = f32 MFMA kernels, 1 = f16x3 128x128, 2 = f16x3 256x128 (the dominant kernel)
+    std::vector<int> kind;           // 0 = f32 MFMA kernels, 1 = f16x3 128x128, 2 = f16x3 256x128, 3 = f16x3 256x256 (the dominant kernel),
+                                     // 10 = fused attention forward (split-f16 pipeline)
+    std::vector<int> dims;           // 3 per launch: GEMM M, N, K; attention: rows, width, longest sequence
 };
 extern int g_last_x3_variant;
 extern GemmProfile g_prof;

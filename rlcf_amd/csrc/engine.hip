@@ -7,6 +7,12 @@
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != RLCF_OK) return rc_; } while (0)
 
+// int(N * selection_p) of select_confident_samples (tpt_cls_rl.py:34) is a DOUBLE product in Python; the float field of the
+// argument block can round the other way (N=10, p=0.7 -> 6), so the host passes its own value in a->n_sel (0: derive it here).
+static inline int n_selected(const rlcf_tta_args* a, int N) {
+    return a->n_sel > 0 ? a->n_sel : (int)((double)N * (double)a->selection_p);
+}
+
 int DevBuf::ensure(size_t n) {
     if (n <= bytes && p) return RLCF_OK;
     if (p) (void)hipFree(p);
@@ -21,7 +27,7 @@ void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 
 // ------------------------------------------------------------------ profiling of GEMM launches
 GemmProfile g_prof;
-static int prof_begin(hipStream_t st, double flops) {
+static int prof_begin(hipStream_t st, double flops, int M = 0, int N = 0, int K = 0) {
     if (!g_prof.enabled) return -1;
     if ((int)g_prof.ev.size() < 2 * (g_prof.n + 1)) {
         hipEvent_t a, b;
@@ -30,6 +36,8 @@ static int prof_begin(hipStream_t st, double flops) {
     }
     g_prof.flops.resize(g_prof.n + 1);
     g_prof.kind.resize(g_prof.n + 1);
+    g_prof.dims.resize(3 * (g_prof.n + 1));
+    g_prof.dims[3 * g_prof.n] = M; g_prof.dims[3 * g_prof.n + 1] = N; g_prof.dims[3 * g_prof.n + 2] = K;
     g_prof.flops[g_prof.n] = flops;
     g_prof.kind[g_prof.n] = 0;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
@@ -79,14 +87,15 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             } else {
                 TRY(launch_split_f16x2(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, st, a_scale, 1));
             }
-            const int slot = prof_begin(st, 2.0 * M * N * K);
+            const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
             int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
-                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out);
+                                       nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
+                                       e->gemm_ws.as<float>(), e->gemm_ws.bytes);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
     }
-    const int slot = prof_begin(st, 2.0 * M * N * K);
+    const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f32(g, st);
     prof_end(slot, st);
     return rc;
@@ -104,9 +113,9 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
     if (!sp) { rlcf_set_error("engine_gemm_presplit: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
-    const int slot = prof_begin(st, 2.0 * M * N * K);
+    const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
-                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out);
+                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, e->gemm_ws.as<float>(), e->gemm_ws.bytes);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -126,9 +135,9 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
     const ClipModel::SplitW* sp = split_of(e, W);
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
-    const int slot = prof_begin(st, 2.0 * M * N * K);
+    const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
-                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1);
+                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, e->gemm_ws.as<float>(), e->gemm_ws.bytes);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -159,12 +168,13 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     void* lo = il ? lo_of(hi.p) : (void*)((char*)hi.p + numel * 2);
     // exact power-of-two pre-scale that lifts the tensor to max|w| in [2^9, 2^10): lo parts of all but negligible
     // elements are then normal f16 numbers (full 22-bit operand), far from f16 overflow
-    static DevBuf amax;
+    DevBuf amax;                                           // (finalize-time scratch, released below)
     TRY(amax.ensure(sizeof(float)));
     TRY(launch_absmax(w, (int64_t)numel, amax.as<float>(), st));
     float mx = 0.f;
     RLCF_HIP_CHECK(hipMemcpyAsync(&mx, amax.p, sizeof(float), hipMemcpyDeviceToHost, st));
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    amax.release();
     int sh = 0;
     if (mx > 0.f && std::isfinite(mx)) sh = std::max(-8, std::min(12, 9 - (int)std::floor(std::log2(mx))));
     const float scale = std::ldexp(1.0f, sh);
@@ -447,14 +457,15 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
         TRY(e->dyn.ensure(3 * sizeof(float)));
         TRY(launch_split_f16x2_dyn(yt, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)N * Tp, e->dyn.as<float>(), st, 1));
         TRY(launch_split_f16x2(xt, e->w_hi.p, lo_of(e->w_hi.p), (int64_t)K * Tp, st, 1.0f, 1));
-        const int slot = prof_begin(st, 2.0 * N * K * Tp);
+        const int slot = prof_begin(st, 2.0 * N * K * Tp, N, K, Tp);
         rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * Tp, e->w_hi.p, lo_of(e->w_hi.p), 2 * Tp, nullptr, nullptr, 0, nullptr, 0, dW, K,
-                               nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2);
+                               nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2, nullptr, 0, e->gemm_ws.as<float>(),
+                               e->gemm_ws.bytes);
         prof_end(slot, st, g_last_x3_variant);
     } else {
         GemmArgs g{};
         g.A = yt; g.lda = Tp; g.W = xt; g.ldw = Tp; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = Tp; g.alpha = 1.f; g.epilogue = RLCF_EPI_NONE;
-        const int slot = prof_begin(st, 2.0 * N * K * Tp);
+        const int slot = prof_begin(st, 2.0 * N * K * Tp, N, K, Tp);
         rc = launch_gemm_f32(g, st);
         prof_end(slot, st);
     }
@@ -493,7 +504,12 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             const BlockW& b = w.blk[l];
             LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
             TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
-            TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1));
+            {
+                const int slot = prof_begin(st, 4.0 * attn_pairs * W, T, W, max_q_len);          // kind 10: fused attention forward
+                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1);
+                prof_end(slot, st, 10);
+                TRY(arc);
+            }
             e->last_flops += 4.0 * attn_pairs * W;
             TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
             LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
@@ -795,6 +811,8 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     TRY(e->dlogits.ensure((size_t)N * C * sizeof(float))); TRY(e->final_logits.ensure((size_t)C * sizeof(float)));
     TRY(e->top5.ensure(5 * sizeof(int32_t))); TRY(e->sel_feat.ensure((size_t)N * D * sizeof(float)));
     TRY(e->sel_logits.ensure((size_t)N * C * sizeof(float)));
+    TRY(e->rl_stats.ensure(reward_loss_stats_floats(N) * sizeof(float)));          // scratch of the loss kernel: at most N selected rows
+    TRY(e->step_skip.ensure((size_t)std::max(N, 64) * sizeof(int32_t)));             // non-finite-gradient flags, one per test sample of a pass
     if (e->n_rewards > 0) {
         const int R = s.cfg.image_resolution;                // selected views are kept at the student's resolution
         TRY(e->views_sel.ensure((size_t)N * 3 * R * R * sizeof(float)));
@@ -938,7 +956,7 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32);
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
-    const int n_sel = (int)(N * a->selection_p);              // int() truncation, tpt_cls_rl.py:34
+    const int n_sel = n_selected(a, N);                       // int() truncation, tpt_cls_rl.py:34
     RLCF_ARG_CHECK(K <= C);
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
     const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
@@ -989,7 +1007,7 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
         }
         TRY(launch_reward_loss_bank(rows_logits, C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
-                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
+                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
         if (sparse_ok) {
             TRY(sparse_backward(e, ctx, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(),
                                 e->ctx_grad.as<float>(), st));
@@ -1006,8 +1024,12 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
             COPY_OUT(out->ctx_grad, e->ctx_grad.p, cb);
         }
+        // scaler.step(optimizer) (tpt_cls_rl.py:78): a gradient with an inf / NaN skips the update (the same inputs give the same
+        // gradient at the following steps, so the host-side step number j + 1 never meets an applied step after a skipped one)
+        TRY(launch_grad_nonfinite(e->ctx_grad.as<float>(), (int64_t)n_ctx * Wt, 1, e->step_skip.as<int32_t>(), st));
         TRY(launch_adamw(ctx, e->ctx_grad.as<float>(), e->adam_m.as<float>(), e->adam_v.as<float>(), (int64_t)n_ctx * Wt, j + 1, a->lr,
-                         a->beta1, a->beta2, a->eps, a->weight_decay, st));
+                         a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)n_ctx * Wt));
+        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
     }
     // final inference on the clean view (views[0]) with the adapted prompt, tpt_cls_rl.py:260-262;
     // its image feature is row 0 of img_feat (frozen image tower: identical to re-encoding it).
@@ -1055,7 +1077,7 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     ClipModel& s = e->model[RLCF_STUDENT];
     const TextLayout& L = e->lay[0];
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
-    const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
+    const int n_sel = n_selected(a, N), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     TRY(batch_ensure(e, B, st));
     TRY(sparse_ensure(e, n_e, st, B));
@@ -1090,7 +1112,7 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
         // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
         TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e),
                                     a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
-                                    e->dlogits.as<float>(), st));
+                                    e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
         // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
         TRY(launch_build_sparse_layout(e->topk_idx.as<int32_t>(), B, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(),
                                        L.class_eot_off.as<int32_t>(), L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
@@ -1116,8 +1138,9 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
                                         e->b_grad.as<float>(), st));
         }
         // 5. AdamW step j+1 of every sample (tpt_cls_rl.py:76-79)
+        TRY(launch_grad_nonfinite(e->b_grad.as<float>(), np, B, e->step_skip.as<int32_t>(), st));
         TRY(launch_adamw(e->b_ctx.as<float>(), e->b_grad.as<float>(), e->b_m.as<float>(), e->b_v.as<float>(), B * np, j + 1, a->lr, a->beta1,
-                         a->beta2, a->eps, a->weight_decay, st));
+                         a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), np));
     }
     // 6. final clean-view inference: B adapted prompts through one replicated text pass
     TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
@@ -1134,7 +1157,7 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const int n_sel = (int)(N * a->selection_p);
+    const int n_sel = n_selected(a, N);
     const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
                            !(a->flags & RLCF_F_MIN_ENTROPY) && a->sample_k > 1;
     const int Bmax = e->max_views / N;
@@ -1236,7 +1259,7 @@ static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, 
                               hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
-    const int n_sel = (int)(N * a->selection_p), BN = B * N, BS = B * n_sel;
+    const int n_sel = n_selected(a, N), BN = B * N, BS = B * n_sel;
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const size_t nb = (size_t)e->ln_count * sizeof(float), np = (size_t)e->ln_count;
     TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
@@ -1263,12 +1286,13 @@ static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, 
         if (rc == RLCF_OK) rc = engine_logits(e, e->ln_feat.as<float>(), BS, cls_feat, C, e->sel_logits.as<float>(), st);
         if (rc == RLCF_OK) rc = launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e), a->clipscore_weight,
                                                         a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
-                                                        e->dlogits.as<float>(), st);
+                                                        e->dlogits.as<float>(), e->rl_stats.as<float>(), st);
         if (rc == RLCF_OK) rc = vit_backward_ln(e, s, e->ln_feat.as<float>(), BS, e->dlogits.as<float>(), e->b_ln_grad.as<float>(), st, B);
         e->lng_base = nullptr; e->lng_views = 1;
         TRY(rc);
+        TRY(launch_grad_nonfinite(e->b_ln_grad.as<float>(), (int64_t)np, B, e->step_skip.as<int32_t>(), st));
         TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, j + 1,
-                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)np));
     }
     // 6. clean-view inference of the B samples in one pass: view b reads LayerNorm set b (tune_cls_rl.py:219-221)
     float* fl = final_logits ? final_logits : e->b_logits.as<float>();
@@ -1292,7 +1316,7 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
     if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const int n_sel = (int)(N * a->selection_p), Bmax = e->max_views / N;
+    const int n_sel = n_selected(a, N), Bmax = e->max_views / N;
     const bool fused = Bmax >= 2 && a->tta_steps >= 1 && !a->skip_final && n_sel > 0;
     double flops = 0.0;
     int i = 0;
@@ -1333,7 +1357,7 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
-    const int n_sel = (int)(N * a->selection_p), n_e = n_sel * K;
+    const int n_sel = n_selected(a, N), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
     if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(s.tokens <= 320);
@@ -1370,7 +1394,7 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
         TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
         TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
-                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), st));
+                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
         if (full) RLCF_HIP_CHECK(hipMemsetAsync(e->vw_grad.p, 0, vb, st));
         TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st, 1,
                             full ? e->vw_grad.as<float>() : nullptr));
@@ -1383,11 +1407,15 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
             COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
             COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
         }
+        // one optimizer over both buffers: an inf / NaN anywhere skips the whole step (GradScaler.step, tpt_cls_rl.py:78)
+        TRY(launch_grad_nonfinite(e->ln_grad.as<float>(), e->ln_count, 1, e->step_skip.as<int32_t>(), st));
+        if (full) TRY(launch_grad_nonfinite(e->vw_grad.as<float>(), (int64_t)e->vw_count, 1, e->step_skip.as<int32_t>(), st, true));
+        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
         TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
-                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->ln_count));
         if (full) {
             TRY(launch_adamw(e->vw.as<float>(), e->vw_grad.as<float>(), e->vw_m.as<float>(), e->vw_v.as<float>(), (int64_t)e->vw_count, j + 1,
-                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st));
+                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)e->vw_count));
             e->vw_dirty = true;
             TRY(engine_visual_refresh(e, st));
         }

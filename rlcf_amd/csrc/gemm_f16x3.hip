@@ -862,9 +862,12 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
 }
 
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
+// splitk_ws / splitk_ws_bytes: caller-owned scratch for the split-K form of the small-grid kernel (the engine sizes it once at
+// create); without it those shapes run unsplit.  Nothing is allocated here.
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
-                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il) {
+                      int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
+                      float* splitk_ws, size_t splitk_ws_bytes) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && Clo)));
     GemmX3Args g{};
@@ -875,11 +878,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     RLCF_ARG_CHECK((g.kstep == 64) == (Wlo == (const void*)((const _Float16*)Whi + 32)));   // both operands in the same layout
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
-    static bool attr = false;
-    if (!attr) {
-        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr = true;
-    }
+#define X3_LDS(fn, bytes) do { int rc_ = rlcf_func_lds((const void*)(fn), (bytes)); if (rc_ != RLCF_OK) return rc_; } while (0)
     const int blocks2 = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
     static int force = -1;                                   // RLCF_X3_KERNEL=1|2 pins a variant (benchmarks)
     if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
@@ -892,31 +891,20 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const bool pick3 = blocks2 >= 256 && cost3 <= cost2;
     if (v2_ok && (force == 3 || (force == 0 && pick3))) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
-        static bool attr3 = false;
-        if (!attr3) {
-            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
-            attr3 = true;
-        }
         if (g.kstep == 64) {
-            static bool attr3i = false;
-            if (!attr3i) {
-                RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v3i_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3));
-                attr3i = true;
-            }
+            X3_LDS(gemm_nt_f16x3_v3i_kernel, sh3);
             gemm_nt_f16x3_v3i_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
-        } else
-        gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        } else {
+            X3_LDS(gemm_nt_f16x3_v3_kernel, sh3);
+            gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        }
         g_last_x3_variant = 3;
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
     if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;
-        static bool attr2 = false;
-        if (!attr2) {
-            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
-            attr2 = true;
-        }
+        X3_LDS(gemm_nt_f16x3_v2_kernel<4>, sh2);
         gemm_nt_f16x3_v2_kernel<4><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
         g_last_x3_variant = 2;
         RLCF_LAUNCH_CHECK();
@@ -928,11 +916,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int blocks2s = ((M + 127) / 128) * ((N + V2_BN - 1) / V2_BN);
         const size_t sh2s = (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) > (size_t)4 * 64 * 68 * sizeof(float)
                                 ? (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) : (size_t)4 * 64 * 68 * sizeof(float);
-        static bool attr2s = false;
-        if (!attr2s) {
-            RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_f16x3_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2s));
-            attr2s = true;
-        }
+        X3_LDS(gemm_nt_f16x3_v2_kernel<2>, sh2s);
         // few tiles and a long K loop (one image's token matrix against a W x 4W / W x 3W weight): split the K loop over blockIdx.y
         // and finish in a reduce + epilogue pass (RLCF_X3_NOSPLITK=1 switches it off)
         static int nosplit = -1;
@@ -940,17 +924,8 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int nkt = K / X3_BK;
         int ksplit = 1;
         if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
-        static float* ws = nullptr;
-        static size_t ws_bytes = 0;
-        if (ksplit > 1) {
-            const size_t need = (size_t)ksplit * M * N * sizeof(float);
-            if (need > ws_bytes) {
-                if (ws) (void)hipFree(ws);
-                ws = nullptr; ws_bytes = 0;
-                if (hipMalloc((void**)&ws, need) == hipSuccess) ws_bytes = need; else { (void)hipGetLastError(); ksplit = 1; }
-            }
-        }
-        g.ksplit = ksplit; g.ws = ws;
+        if (ksplit > 1 && (!splitk_ws || (size_t)ksplit * M * N * sizeof(float) > splitk_ws_bytes)) ksplit = 1;
+        g.ksplit = ksplit; g.ws = splitk_ws;
         gemm_nt_f16x3_v2_kernel<2><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
@@ -962,6 +937,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         return RLCF_OK;
     }
     const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
+    X3_LDS(gemm_nt_f16x3_kernel, sh);
     gemm_nt_f16x3_kernel<<<dim3(blocks), dim3(256), sh, st>>>(g);
     g_last_x3_variant = 1;
     RLCF_LAUNCH_CHECK();

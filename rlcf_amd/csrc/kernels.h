@@ -44,9 +44,12 @@ int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* e
 int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                        const float* class_feat, const float* reward_img, int Dr, float clipscore_weight,
                        int flags, float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards,
-                       float* loss, float* dlogits, hipStream_t st);
+                       float* loss, float* dlogits, float* stats, hipStream_t st);
+// skip: optional device flags, one per group of per_group consecutive parameters: a flagged group is left untouched (GradScaler's
+// inf / NaN step skip); launch_grad_nonfinite fills such flags from the gradients
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
-                 float b2, float eps, float wd, hipStream_t st);
+                 float b2, float eps, float wd, hipStream_t st, const int32_t* skip = nullptr, int64_t per_group = 0);
+int launch_grad_nonfinite(const float* g, int64_t per_group, int groups, int32_t* flag, hipStream_t st, bool accumulate = false);   // accumulate: OR into flags already set (a second gradient buffer of the same optimizer)
 int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st);
 int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st);
 int launch_build_sparse_layout(const int32_t* cls, int groups, int n_e, const int32_t* class_start, const int32_t* class_len,
@@ -57,7 +60,8 @@ int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* im
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr,
-                      unsigned int* amax_out = nullptr, int c_il = 0);
+                      unsigned int* amax_out = nullptr, int c_il = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+#define X3_SPLITK_WS_BYTES ((size_t)4 * 128 * 128 * 128 * sizeof(float))   // 4 slices x (<= 128 tiles of 128x128): the largest split-K launch
 int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
 int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il = 0);
@@ -78,13 +82,15 @@ struct RewardBank {                  // reward models of one CLIPScore evaluatio
     float mix[RLCF_MAX_REWARDS];                 // score = (sum_m mix[m] * max(w*dot_m, 0)) / post_div
     float post_div;
 };
+// stats: caller-owned scratch of reward_loss_stats_floats(groups * n_sel) floats (engine: sized at set_class_bank)
+size_t reward_loss_stats_floats(int rows);
 int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                             const RewardBank& bank, float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx,
-                            float* clip_score, float* rewards, float* loss, float* dlogits, hipStream_t st);
+                            float* clip_score, float* rewards, float* loss, float* dlogits, float* stats, hipStream_t st);
 int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                                const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                                float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
-                               float* dlogits, hipStream_t st);
+                               float* dlogits, float* stats, hipStream_t st);
 int launch_final_logits_batched(const float* img, int img_row_stride, const float* txt, int B, int C, int D, float scale, float* out,
                                 hipStream_t st);
 int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st);

@@ -252,57 +252,74 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_b_kernel(const float
     }
 }
 
-static float* g_stats = nullptr;     // [max rows][STAT_LD] scratch owned by the library
-static int g_stats_rows = 0;
+size_t reward_loss_stats_floats(int rows) { return (size_t)(rows > 0 ? rows : 1) * STAT_LD; }
 // groups test samples of n_sel rows each (rows = groups*n_sel); loss[groups]; everything else row-major over all rows
 int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                             const RewardBank& bank, float clipscore_weight, int flags,
                             float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
-                            float* dlogits, hipStream_t st) {
-    RLCF_ARG_CHECK(groups > 0 && n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx);
+                            float* dlogits, float* stats, hipStream_t st) {
+    RLCF_ARG_CHECK(groups > 0 && n_sel > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && dlogits && topk_idx && stats);
     RLCF_ARG_CHECK(bank.n >= 1 && bank.n <= RLCF_MAX_REWARDS);
     for (int m = 0; m < bank.n; ++m) RLCF_ARG_CHECK(bank.class_feat[m] && bank.reward_img[m] && bank.Dr[m] > 0);
     const int rows = groups * n_sel;
-    if (g_stats_rows < rows) {                           // grows only on a new maximum (setup time)
-        if (g_stats) (void)hipFree(g_stats);
-        g_stats_rows = rows < 64 ? 64 : rows;
-        RLCF_HIP_CHECK(hipMalloc(&g_stats, (size_t)g_stats_rows * STAT_LD * sizeof(float)));
-    }
-    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, bank, clipscore_weight, topk_idx, g_stats);
+    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, sel, C, K, bank, clipscore_weight, topk_idx, stats);
     RLCF_LAUNCH_CHECK();
     const size_t sh = (flags & RLCF_F_MIN_ENTROPY) ? (size_t)C * sizeof(float) : 0;
     if (sh > 160 * 1024 - 256) { rlcf_set_error("reward_loss: min-entropy regulariser over %d classes does not fit the 160 KB LDS", C); return RLCF_ERR_ARG; }
-    static size_t sh_max = 48 * 1024;
-    if (sh > sh_max) {                                   // large banks (retrieval: 5k-25k captions)
-        RLCF_HIP_CHECK(hipFuncSetAttribute((const void*)reward_stage_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        sh_max = sh;
+    if (sh > 48 * 1024) {                                // large banks (retrieval: 5k-25k captions)
+        int rc_ = rlcf_func_lds((const void*)reward_stage_b_kernel, sh);
+        if (rc_ != RLCF_OK) return rc_;
     }
     reward_stage_b_kernel<<<dim3(rows), dim3(TTA_THREADS), sh, st>>>(logits, ld_logits, sel, n_sel, C, K, flags, min_entropy_w,
-                                                                     topk_idx, g_stats, clip_score, rewards, loss, dlogits);
+                                                                     topk_idx, stats, clip_score, rewards, loss, dlogits);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
 int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                                const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                                float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
-                               float* dlogits, hipStream_t st) {
+                               float* dlogits, float* stats, hipStream_t st) {
     RewardBank bank{};
     bank.n = 1; bank.class_feat[0] = class_feat; bank.reward_img[0] = reward_img; bank.Dr[0] = Dr; bank.mix[0] = 1.f; bank.post_div = 1.f;
     return launch_reward_loss_bank(logits, ld_logits, sel, groups, n_sel, C, K, bank, clipscore_weight, flags, min_entropy_w, topk_idx,
-                                   clip_score, rewards, loss, dlogits, st);
+                                   clip_score, rewards, loss, dlogits, stats, st);
 }
 int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                        const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                        float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
-                       float* dlogits, hipStream_t st) {
+                       float* dlogits, float* stats, hipStream_t st) {
     return launch_reward_loss_grouped(logits, ld_logits, sel, 1, n_sel, C, K, class_feat, reward_img, Dr, clipscore_weight, flags,
-                                      min_entropy_w, topk_idx, clip_score, rewards, loss, dlogits, st);
+                                      min_entropy_w, topk_idx, clip_score, rewards, loss, dlogits, stats, st);
 }
 
 // ---------------------------------------------------------------- AdamW
+// GradScaler semantics of the reference (torch.cuda.amp.GradScaler.step at TPT/tpt_cls_rl.py:76-79): the optimizer step of a
+// sample whose gradient holds an inf / NaN is SKIPPED (parameters and moments untouched).  nonfinite_kernel raises flag[group]
+// for every parameter group (one group per test sample in the batched calls) with such a gradient; adamw_kernel leaves the
+// elements of a flagged group alone.  Device-side: no host synchronisation, the step count handed to the kernel stays the host's.
+__global__ void nonfinite_kernel(const float* __restrict__ g, int64_t per_group, int32_t* __restrict__ flag) {
+    const float* gg = g + (int64_t)blockIdx.y * per_group;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_group; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = gg[i];
+        bad |= !(fabsf(v) <= 3.4028234663852886e38f);             // inf or NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag + blockIdx.y, 1);
+}
+int launch_grad_nonfinite(const float* g, int64_t per_group, int groups, int32_t* flag, hipStream_t st, bool accumulate) {
+    RLCF_ARG_CHECK(g && flag && per_group > 0 && groups > 0 && groups <= 65535);
+    if (!accumulate) RLCF_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)groups * sizeof(int32_t), st));
+    int bx = (int)((per_group + 255) / 256);
+    if (bx > 256) bx = 256;
+    nonfinite_kernel<<<dim3(bx, groups), dim3(256), 0, st>>>(g, per_group, flag);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                             const int32_t* __restrict__ skip, int64_t per_group) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (skip && skip[i / per_group]) continue;
         const float gi = g[i];
         float pi = p[i] * (1.0f - lr * wd);
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -313,12 +330,13 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2,
-                 float eps, float wd, hipStream_t st) {
-    RLCF_ARG_CHECK(n > 0 && step >= 1);
+                 float eps, float wd, hipStream_t st, const int32_t* skip, int64_t per_group) {
+    RLCF_ARG_CHECK(n > 0 && step >= 1 && (!skip || per_group > 0));
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    adamw_kernel<<<dim3(blocks), dim3(256), 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
+    adamw_kernel<<<dim3(blocks), dim3(256), 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), skip,
+                                                     per_group > 0 ? per_group : n);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

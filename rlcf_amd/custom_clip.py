@@ -220,7 +220,15 @@ class CLIPCLS_TTA(nn.Module):
 
     @torch.no_grad()
     def reset_classnames_and_state(self, classnames, arch):   # custom_clip.py:434-454
+        """New class bank AND the visual state back to the checkpoint: visual.load_state_dict(clip_state_dict), then
+        initial_state_dict / momentum_state_dict re-initialised from it (:449-454) — the EMA of one dataset does not leak into the next."""
         self._set_classnames(classnames)
+        eng = runtime.SESSION.engine()
+        eng.reset_visual_state()
+        if self._ln is not None:
+            self._ln_init = eng.ln_params(pristine=True)
+        if self._vis is not None:
+            self._vis_init = eng.visual_params(1)
         if self._ln is not None:
             self.reset()
 

@@ -48,18 +48,23 @@ class TTAConfig:
     reward_amplify: bool = False
     clipscore_weight: float = 2.5
     min_entropy_reg: bool = False
-    min_entropy_w: float = 0.2
+    min_entropy_w: float = 0.1           # TPT/params.py:66
     sparse_backward: bool = True
 
     def flags(self) -> int:
         return ((L.F_REWARD_PROCESS if self.reward_process else 0) | (L.F_AMPLIFY if self.reward_amplify else 0) |
                 (L.F_PROCESS_BATCH if self.process_batch else 0) | (L.F_MIN_ENTROPY if self.min_entropy_reg else 0))
 
-    def c_args(self, skip_final: bool = False, ctx_in: Optional[torch.Tensor] = None) -> L.TTAArgs:
+    def n_sel(self, n_views: int) -> int:
+        """int(N * top) of select_confident_samples (TPT/tpt_cls_rl.py:34): Python's double product, truncated."""
+        return int(n_views * self.selection_p)
+
+    def c_args(self, n_views: int, skip_final: bool = False, ctx_in: Optional[torch.Tensor] = None) -> L.TTAArgs:
+        # n_sel travels as an int: the float selection_p field alone can truncate the other way (N=10, p=0.7)
         return L.TTAArgs(self.selection_p, self.tta_steps, self.sample_k, self.lr, self.weight_decay, self.beta1,
                          self.beta2, self.eps, self.flags(), self.clipscore_weight, self.min_entropy_w,
                          1 if self.sparse_backward else 0, 1 if skip_final else 0,
-                         ctx_in.data_ptr() if ctx_in is not None else None)
+                         ctx_in.data_ptr() if ctx_in is not None else None, self.n_sel(n_views))
 
 
 class Engine:
@@ -162,13 +167,14 @@ class Engine:
                    ctx_in: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
-        n_sel = int(N * cfg.selection_p)
+        n_sel = cfg.n_sel(N)
         Wt = self.student.transformer_width
         Dr = sum(r.embed_dim for r in self.rewards)     # per-model blocks [n_sel, Dr_m], one after another
         dev = self.device
         o: Dict[str, torch.Tensor] = {
             "final_logits": torch.empty(1, Cn, device=dev), "top5": torch.empty(5, dtype=torch.int32, device=dev),
-            "ctx_after": torch.empty(self.n_ctx, Wt, device=dev)}
+            "ctx_after": torch.empty(self.n_ctx, Wt, device=dev),
+            "step_skipped": torch.zeros(max(cfg.tta_steps, 1), dtype=torch.int32, device=dev)}
         if want_intermediates and cfg.tta_steps > 0:
             o.update(logits=torch.empty(N, Cn, device=dev), entropy=torch.empty(N, device=dev),
                      selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
@@ -180,7 +186,7 @@ class Engine:
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
         if ctx_in is not None:
             ctx_in = ctx_in.detach().to(dev, torch.float32).contiguous()
-        a = cfg.c_args(skip_final, ctx_in)
+        a = cfg.c_args(N, skip_final, ctx_in)
         L.check(self.lib.rlcf_tta_sample(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample")
         if "reward_image_features" in o:
             parts = torch.split(o["reward_image_features"], [n_sel * r.embed_dim for r in self.rewards])
@@ -203,20 +209,25 @@ class Engine:
         L.check(self.lib.rlcf_engine_momentum_update(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0, _stream()),
                 "momentum_update")
 
+    def reset_visual_state(self) -> None:
+        """State part of CLIPCLS_TTA.reset_classnames_and_state (custom_clip.py:449-454): reset state and EMA back to the checkpoint."""
+        L.check(self.lib.rlcf_engine_reset_visual_state(self.h, _stream()), "reset_visual_state")
+
     def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
         """LayerNorm-tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True))."""
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
-        n_sel = int(N * cfg.selection_p)
+        n_sel = cfg.n_sel(N)
         npar = int(self.lib.rlcf_engine_ln_param_count(self.h))
         dev = self.device
         o = dict(final_logits=torch.empty(1, Cn, device=dev), top5=torch.empty(5, dtype=torch.int32, device=dev),
                  ln_after=torch.empty(npar, device=dev), ln_grad=torch.empty(npar, device=dev),
+                 step_skipped=torch.zeros(max(cfg.tta_steps, 1), dtype=torch.int32, device=dev),
                  logits=torch.empty(N, Cn, device=dev), selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
                  topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n_sel * K, device=dev),
                  rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
-        a = cfg.c_args(skip_final)
+        a = cfg.c_args(N, skip_final)
         L.check(self.lib.rlcf_tta_sample_ln(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_ln")
         return o
 
@@ -271,7 +282,7 @@ class Engine:
         """Full image-encoder tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=False), scripts/rlcf-tune.sh)."""
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
-        n_sel = int(N * cfg.selection_p)
+        n_sel = cfg.n_sel(N)
         npar = int(self.lib.rlcf_engine_ln_param_count(self.h))
         nvis = int(self.lib.rlcf_engine_visual_param_count(self.h, _stream()))
         if nvis <= 0:
@@ -280,11 +291,12 @@ class Engine:
         o = dict(final_logits=torch.empty(1, Cn, device=dev), top5=torch.empty(5, dtype=torch.int32, device=dev),
                  ln_after=torch.empty(npar, device=dev), ln_grad=torch.empty(npar, device=dev),
                  vis_after=torch.empty(nvis, device=dev), vis_grad=torch.empty(nvis, device=dev),
+                 step_skipped=torch.zeros(max(cfg.tta_steps, 1), dtype=torch.int32, device=dev),
                  logits=torch.empty(N, Cn, device=dev), selected_idx=torch.empty(n_sel, dtype=torch.int32, device=dev),
                  topk_idx=torch.empty(n_sel, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n_sel * K, device=dev),
                  rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
-        a = cfg.c_args(skip_final)
+        a = cfg.c_args(N, skip_final)
         L.check(self.lib.rlcf_tta_sample_visual(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_visual")
         return o
 
@@ -294,7 +306,7 @@ class Engine:
         count, N = views.shape[0], views.shape[1]
         top5 = torch.empty(count, 5, dtype=torch.int32, device=self.device)
         fl = torch.empty(count, self.n_cls, device=self.device) if want_logits else None
-        a = cfg.c_args()
+        a = cfg.c_args(N)
         L.check(self.lib.rlcf_tta_batch(self.h, _ptr(views), count, N, C.byref(a), _ptr(fl), _ptr(top5), _stream()),
                 "tta_batch")
         return (top5, fl) if want_logits else top5
@@ -305,7 +317,7 @@ class Engine:
         count, N = views.shape[0], views.shape[1]
         top5 = torch.empty(count, 5, dtype=torch.int32, device=self.device)
         fl = torch.empty(count, self.n_cls, device=self.device) if want_logits else None
-        a = cfg.c_args()
+        a = cfg.c_args(N)
         L.check(self.lib.rlcf_tta_batch_ln(self.h, _ptr(views), count, N, C.byref(a), _ptr(fl), _ptr(top5), _stream()), "tta_batch_ln")
         return (top5, fl) if want_logits else top5
 

@@ -30,7 +30,8 @@ class Session:
         self.text_mode = TEXT_MODES[os.environ.get("RLCF_TEXT_MODE", "shared")]
         self._engine: Optional[Engine] = None
         self._key = None
-        self._bank_key = None
+        self._bank_version = 0       # bumped by set_bank: the engine re-reads the class bank when its copy is older
+        self._bank_applied = -1
 
     def set_student(self, ckpt):
         self.student = ckpt
@@ -47,6 +48,7 @@ class Session:
 
     def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor):
         self.tokens, self.n_ctx, self.ctx_init = tokens.detach().cpu(), n_ctx, ctx_init.detach().clone()
+        self._bank_version += 1
 
     def engine(self, n_views: int = 1) -> Engine:
         if self.student is None:
@@ -66,19 +68,19 @@ class Session:
             eng.finalize()
             if self.reward_mix is not None:
                 eng.set_reward_mix(self.reward_mix, self.reward_mean)
-            self._engine, self._key, self._bank_key = eng, key, None
+            self._engine, self._key, self._bank_applied = eng, key, None
         if self.tokens is not None:
-            bkey = (id(self.tokens), self.n_ctx, self.text_mode, float(self.ctx_init.float().abs().sum()))
-            if bkey != self._bank_key:
+            bkey = (self._bank_version, self.text_mode)       # a counter, not id()/checksums: no stale bank, no device sync per call
+            if bkey != self._bank_applied:
                 self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode)
-                self._bank_key = bkey
+                self._bank_applied = bkey
         return self._engine
 
     def close(self):
         if self._engine is not None:
             self._engine.close()
         self._engine = None
-        self._key = self._bank_key = None
+        self._key = self._bank_applied = None
 
 
 SESSION = Session()

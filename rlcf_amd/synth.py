@@ -112,6 +112,8 @@ def normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0,
            device="cpu") -> torch.Tensor:
     """Approximately normal fp32 tensor: Irwin-Hall sum of eight 16-bit uniforms,
     exact in integer arithmetic, then one fp64 scale and one fp32 rounding."""
+    if str(device) == "meta":            # shapes only (loader tests of the 400-600 M parameter geometries)
+        return torch.empty(*shape, dtype=torch.float32, device="meta")
     n = 1
     for s in shape:
         n *= int(s)

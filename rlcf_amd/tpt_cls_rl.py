@@ -43,7 +43,7 @@ def _config(args, optimizer, reward_model) -> TTAConfig:
                      reward_process=bool(reward_model.reward_process), process_batch=bool(reward_model.process_batch),
                      reward_amplify=bool(reward_model.amplify_rewards), clipscore_weight=reward_model.clipscore_weight,
                      min_entropy_reg=bool(getattr(args, "min_entropy_reg", 0)),
-                     min_entropy_w=float(getattr(args, "min_entropy_w", 0.2)))
+                     min_entropy_w=float(getattr(args, "min_entropy_w", 0.1)))
 
 
 def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
@@ -122,8 +122,11 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
 
 
 def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1):
-    """TPT/tpt_cls_rl.py:219-279: per test image: reset -> tune -> clean-view inference -> top-1/top-5.
+    """TPT/tpt_cls_rl.py:219-279 and its twin TPT/tune_cls_rl.py:183-256 (CLIPCLS_TTA models: model.train() / model.eval() round the
+    tuning step, :216-218, and model.momentum_update_model() after the clean-view inference, :240): per test image
+    reset -> tune -> clean-view inference -> (EMA) -> top-1/top-5.
     `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once."""
+    backbone = not hasattr(model, "prompt_learner")                 # CLIPCLS_TTA: the tune_cls_rl.py form of the loop
     full_visual = not hasattr(model, "prompt_learner") and not model.only_norm      # per-sample weights: one sample per pass
     if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:
         model.eval()
@@ -153,12 +156,18 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
             with torch.no_grad():
                 model.reset()
         optimizer.load_state_dict(optim_state)
+        if backbone:
+            model.train()                                           # tune_cls_rl.py:216
         test_time_tuning(model, images, optimizer, scaler, args, reward_model=reward_model)
+        if backbone:
+            model.eval()                                            # tune_cls_rl.py:218
         with torch.no_grad():
             output = model(image)
+        if backbone:
+            model.momentum_update_model()                           # tune_cls_rl.py:240 (no-op unless momentum_update)
         acc1, acc5 = accuracy(output, target, topk=(1, 5))
         n += image.size(0); s1 += float(acc1[0]) * image.size(0); s5 += float(acc5[0]) * image.size(0)
-        if (i + 1) % getattr(args, "print_freq", 200) == 0:
+        if (i + 1) % getattr(args, "print_freq", 500) == 0:
             print(f"Test: [{i + 1}/{len(val_loader)}] Time {time.time() - end:6.3f} Acc@1 {s1 / n:6.2f} Acc@5 {s5 / n:6.2f}")
         end = time.time()
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]

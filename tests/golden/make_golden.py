@@ -563,6 +563,21 @@ def main():
                             bank_seed=7, n_ctx=4, **hp)
                 save(name, arrays, meta)
                 print(f"  {name}: idx={arrays['selected_idx']} top5={arrays['top5']} |g|={np.linalg.norm(arrays['ln_grad']):.3e}")
+        elif grp == "b16stream":
+            # BASELINE configs[1] as a STREAM: eight consecutive test images (view seeds 1113..1120) through the harness body
+            # TPT/tpt_cls_rl.py:251-262 one at a time (reset -> test_time_tuning -> clean-view logits); pins rlcf_tta_batch at the
+            # images-per-pass counts bench.py runs (8 and 32)
+            hp = dict(BASE_HP, selection_p=0.1)
+            arrays, n_s = {}, int(os.environ.get("STREAM_N", "8"))
+            for i in range(n_s):
+                t0 = time.time()
+                a_i = run_reference_tta(ref, "ViT-B/16", "ViT-B/16", 64, 1000, dict(hp), view_seed=1113 + i)
+                for k in ("selected_idx", "topk_idx", "clip_score", "rewards", "ctx_after", "final_logits", "top5"):
+                    arrays[f"{k}_{i}"] = a_i[k]
+                print(f"  stream sample {i}: {time.time() - t0:.1f}s idx={a_i['selected_idx']} top5={a_i['top5']} "
+                      f"rewards={a_i['rewards']}", flush=True)
+            save("tta_b16_n64_stream", arrays, dict(student="ViT-B/16", reward="ViT-B/16", n_views=64, n_cls=1000, student_seed=11,
+                                                    reward_seed=23, view_seed0=1113, n_samples=n_s, bank_seed=7, n_ctx=4, **hp))
         else:
             for name in GROUPS[grp]:
                 student, reward, n, c, over = TTA_CASES[name]

@@ -47,7 +47,7 @@ def test_engine_refuses_without_gpu(lib):
 def test_struct_layouts(lib):
     import ctypes as C
     assert C.sizeof(lib.ClipCfg) == 56 and C.sizeof(lib.Seq) == 16
-    assert C.sizeof(lib.TTAArgs) == 64 and C.sizeof(lib.TTAOut) == 17 * 8
+    assert C.sizeof(lib.TTAArgs) == 72 and C.sizeof(lib.TTAOut) == 18 * 8      # + n_sel, + step_skipped (ABI version 4)
     assert C.sizeof(lib.Crop) == 20 and C.sizeof(lib.AugmixOp) == 56          # rlcf_crop, rlcf_augmix_op {int, int, double[6]}
 
 

@@ -369,17 +369,29 @@ def _check_against(o, g, meta, final_atol=1e-3):
         assert (og - gr).norm() / gr.norm() < 1e-3
         big = gr.abs() > 1e-3 * gr.abs().max()
         assert torch.equal(torch.sign(og[big]), torch.sign(gr[big]))
+    # post-AdamW prompt: Adam's first step is -lr*sign(g), so an element may differ from the reference only where
+    # the reference gradient is ~0 (its sign is noise).  Single-step fixtures carry that gradient: every differing element must be
+    # such an element; the count is reported, not rate-limited.
     d = (c("ctx_after") - g["ctx_after"]).abs()
-    assert (d > 1e-4).float().mean() < 0.01
+    differing = d > 1e-4
+    if meta["tta_steps"] == 1:
+        gr = g["ctx_grad"]
+        fragile = gr.abs() <= 1e-3 * gr.abs().max()
+        assert not (differing & ~fragile).any(), f"{int((differing & ~fragile).sum())} prompt elements with a solid gradient differ"
+    else:                                  # multi-step fixtures hold no per-step gradients: a handful of sign-fragile elements at most
+        assert int(differing.sum()) <= max(2, differing.numel() // 100)
+    if differing.any():
+        print(f"[ctx_after] {int(differing.sum())} of {differing.numel()} elements differ by > 1e-4 (all at ~zero reference gradient)")
 
 
+@pytest.mark.parametrize("prec", [0, 2])           # 2 = split-f16, the product default (runtime.Session, bench.py)
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("name", TTA_FIXTURES)
-def test_tta_sample_matches_reference_fixture(L, dev, name, sparse, mode):
+def test_tta_sample_matches_reference_fixture(L, dev, name, sparse, mode, prec):
     g, meta = load_golden(name)
     eng, ssd, rsd, tokens, ctx0 = make_engine((meta["student"], meta["reward"]), meta["n_views"], meta["n_cls"], mode,
-                                              meta["student_seed"], meta["reward_seed"], meta["bank_seed"], meta["n_ctx"])
+                                              meta["student_seed"], meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=prec)
     views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution)
     o = eng.tta_sample(views.to(dev), _cfg_from_meta(meta, sparse))
     torch.cuda.synchronize()
@@ -403,13 +415,14 @@ def make_ensemble_engine(meta, mode, n_views=None, prec=0):
     return eng, members, tokens
 
 
+@pytest.mark.parametrize("prec", [0, 2])
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("name", ["tta_tiny_ens", "tta_tiny_ensmean", "tta_tiny_ensrn"])
-def test_reward_ensemble_matches_reference_fixture(L, dev, name, sparse, mode):
+def test_reward_ensemble_matches_reference_fixture(L, dev, name, sparse, mode, prec):
     """CLIPRewardsMultiple (clip_reward.py:180-307): three reward CLIPs (one at another input resolution), weighted / mean."""
     g, meta = load_golden(name)
-    eng, members, tokens = make_ensemble_engine(meta, mode)
+    eng, members, tokens = make_ensemble_engine(meta, mode, prec=prec)
     eng.set_reward_mix(g["reward_weights"].tolist(), mean=not meta.get("weighted_scores", 1))
     for m in range(len(members)):
         torch.testing.assert_close(eng.reward_class_features(m).cpu(), g[f"reward_class_features_{m}"], atol=2e-5, rtol=1e-4)

@@ -1,0 +1,298 @@
+"""GPU parity, round-2 additions: the sample-batched call at the images-per-pass counts bench.py runs against a reference-generated
+STREAM of ViT-B/16 samples; GradScaler's non-finite step skip; the shipped harness with the cross-sample EMA; engine-owned scratch
+(two engines on two streams); the sharded eval driver on two ranks; host-side n_sel; the reward mirror's tensor contracts."""
+import copy
+import json
+import os
+import subprocess
+import sys
+import threading
+import types
+
+import pytest
+import torch
+
+from oracle import rlcf_ref as RR
+from rlcf_amd import synth
+from test_gpu_parity import _cfg_from_meta, load_golden, make_engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rlcf_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------ the benchmarked path, at the benchmarked batch sizes
+@pytest.mark.parametrize("B", [8, 32])
+def test_tta_batch_matches_reference_stream_b16_n64(L, dev, B):
+    """BASELINE configs[1] as bench.py runs it (split-f16, shared-prefix text, sparse class backward, B test images per tower
+    pass): eight consecutive ViT-B/16 N=64 C=1000 samples, each produced by the reference's own harness body one at a time
+    (tests/golden/make_golden.py --only b16stream: TPT/tpt_cls_rl.py:251-262).  Every sample's top-5 and final logits must come
+    out of rlcf_tta_batch, at 8 per pass and at 32 per pass (the stream repeated four times: all four copies must agree too)."""
+    g, meta = load_golden("tta_b16_n64_stream")
+    n = meta["n_samples"]
+    eng, *_ = make_engine((meta["student"], meta["reward"]), meta["n_views"] * B, meta["n_cls"], L.TEXT_SHARED, meta["student_seed"],
+                          meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=L.PREC_F16X3)
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    stream = torch.stack([synth.make_views(meta["view_seed0"] + i, meta["n_views"], R, device=dev) for i in range(n)])
+    views = stream.repeat(B // n, 1, 1, 1, 1) if B > n else stream[:B]
+    top5, fl = eng.tta_batch(views, _cfg_from_meta(meta, sparse=True), want_logits=True)
+    torch.cuda.synchronize()
+    top5, fl = top5.cpu(), fl.cpu()
+    worst = 0.0
+    for j in range(views.shape[0]):
+        i = j % n
+        assert top5[j].tolist() == g[f"top5_{i}"].tolist(), f"sample {i} (slot {j})"
+        err = (fl[j] - g[f"final_logits_{i}"][0]).abs().max().item()
+        worst = max(worst, err)
+        assert err < 1e-3, f"sample {i} (slot {j}): max|dlogit| {err:.2e}"
+    print(f"[stream B={B}] {views.shape[0]} samples, worst max|dlogit| = {worst:.2e}")
+    eng.close()
+
+
+def test_tta_sample_matches_reference_stream_intermediates(L, dev):
+    """The same stream one image at a time through rlcf_tta_sample: selection, sampled classes, scores, rewards and the adapted
+    prompt of every sample against the reference (split-f16)."""
+    g, meta = load_golden("tta_b16_n64_stream")
+    eng, *_ = make_engine((meta["student"], meta["reward"]), meta["n_views"], meta["n_cls"], L.TEXT_SHARED, meta["student_seed"],
+                          meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=L.PREC_F16X3)
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    cfg = _cfg_from_meta(meta, sparse=True)
+    for i in range(meta["n_samples"]):
+        o = eng.tta_sample(synth.make_views(meta["view_seed0"] + i, meta["n_views"], R, device=dev), cfg)
+        assert o["selected_idx"].cpu().tolist() == g[f"selected_idx_{i}"].tolist()
+        assert o["topk_idx"].cpu().reshape(-1).tolist() == g[f"topk_idx_{i}"].reshape(-1).tolist()
+        assert o["top5"].cpu().tolist() == g[f"top5_{i}"].tolist()
+        torch.testing.assert_close(o["clip_score"].cpu(), g[f"clip_score_{i}"].reshape(-1), atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(o["rewards"].cpu(), g[f"rewards_{i}"].reshape(-1), atol=5e-5, rtol=1e-3)
+        torch.testing.assert_close(o["final_logits"].cpu(), g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        assert int(o["step_skipped"].sum()) == 0
+    eng.close()
+
+
+# ------------------------------------------------------------------------------ GradScaler semantics: a non-finite gradient skips the step
+@pytest.mark.parametrize("prec", [0, 2])
+def test_nonfinite_gradient_skips_the_optimizer_step(L, dev, prec):
+    """scaler.step(optimizer) (TPT/tpt_cls_rl.py:76-79) does not step when the gradient holds an inf / NaN.  A NaN pixel in an
+    augmented view that gets selected makes every gradient of the sample NaN: the prompt (and the LayerNorm set on the image-encoder
+    path) must stay at the reset state, the flag must be raised, and the clean-view prediction must equal plain inference — while a
+    clean sample in the SAME batched pass still takes its step."""
+    from rlcf_amd.engine import TTAConfig
+    N, n_cls = 8, 16
+    eng, ssd, rsd, tokens, ctx0 = make_engine(("tiny", "tiny-r"), N * 2, n_cls, L.TEXT_SHARED, prec=prec)
+    cfg = TTAConfig(selection_p=1.0, tta_steps=2)                      # every view selected: the poisoned one is in the loss
+    clean = synth.make_views(1000, N, 32).to(dev)
+    bad = clean.clone()
+    bad[3, 1, 5, 7] = float("nan")
+    plain = eng.tta_sample(clean, TTAConfig(selection_p=1.0, tta_steps=0), want_intermediates=False)      # inference only
+    ok = eng.tta_sample(clean, cfg)
+    assert ok["step_skipped"].tolist() == [0, 0] and not torch.equal(ok["ctx_after"].cpu(), ctx0)
+    o = eng.tta_sample(bad, cfg)
+    assert o["step_skipped"].tolist() == [1, 1]
+    assert torch.equal(o["ctx_after"].cpu(), ctx0)                       # untouched: not even weight decay was applied
+    assert o["top5"].tolist() == plain["top5"].tolist()
+    torch.testing.assert_close(o["final_logits"], plain["final_logits"], atol=1e-6, rtol=0)
+    # batched pass: sample 0 poisoned, sample 1 clean
+    top5, fl = eng.tta_batch(torch.stack([bad, clean]), cfg, want_logits=True)
+    assert top5[0].tolist() == plain["top5"].tolist() and top5[1].tolist() == ok["top5"].tolist()
+    torch.testing.assert_close(fl[1], ok["final_logits"][0], atol=1e-3, rtol=0)
+    # image-encoder (LayerNorm) tuning: same contract
+    ln0 = eng.ln_params(pristine=True)
+    o = eng.tta_sample_ln(bad, TTAConfig(selection_p=1.0, tta_steps=1, lr=1e-3))
+    assert o["step_skipped"].tolist() == [1] and torch.equal(o["ln_after"], ln0)
+    o = eng.tta_sample_ln(clean, TTAConfig(selection_p=1.0, tta_steps=1, lr=1e-3))
+    assert o["step_skipped"].tolist() == [0] and not torch.equal(o["ln_after"], ln0)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------ the shipped harness with CLIPCLS_TTA + momentum_update
+def _cls_tta_objects(dev, meta, only_norm):
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("tiny", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
+                                 min_entropy_reg=0, min_entropy_w=0.1, reward_arch="tiny-r", multiple_reward_models=0,
+                                 sample_k=meta["sample_k"], reward_amplify=False, reward_process=True, process_batch=False)
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=True,
+                                    only_norm=only_norm, momentum_update=True, update_freq=meta["update_freq"],
+                                    update_w=meta["update_w"], momentum=meta["momentum"])
+    reward_model = clip_reward.get_reward_model(dev, args)
+    reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+    optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    return model, optimizer, copy.deepcopy(optimizer.state_dict()), reward_model, args, bank
+
+
+@pytest.mark.parametrize("fixture,only_norm", [("ln_tiny_momentum", True), ("vis_tiny_momentum", False)])
+def test_shipped_harness_applies_the_momentum_update(L, dev, fixture, only_norm):
+    """rlcf_amd.tpt_cls_rl.test_time_adapt_eval with a CLIPCLS_TTA(momentum_update=True) model is TPT/tune_cls_rl.py:183-256: after every
+    sample's clean-view inference it must call model.momentum_update_model() (:240).  Three consecutive samples THROUGH THE HARNESS:
+    the moving reset state must follow the reference's run (update_freq=2: the second sample moves it), which it cannot if the EMA
+    is dropped; then reset_classnames_and_state (custom_clip.py:449-454) must put reset state and EMA back to the checkpoint."""
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden(fixture)
+    model, optimizer, optim_state, reward_model, args, bank = _cls_tta_objects(dev, meta, only_norm)
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    n = meta["n_samples"]
+    # targets = the reference's own clean-view top-1 of every sample: the harness must score 100 %
+    loader = [([v.unsqueeze(0) for v in synth.make_views(1000 + i, meta["n_views"], R)],
+               torch.tensor([int(g[f"final_logits_{i}"][0].argmax())])) for i in range(n)]
+    calls = {"train": 0, "eval": 0}
+    orig_train, orig_eval = model.train, model.eval
+    model.train = lambda *a, **k: (calls.__setitem__("train", calls["train"] + 1), orig_train(*a, **k))[1]
+    model.eval = lambda *a, **k: (calls.__setitem__("eval", calls["eval"] + 1), orig_eval(*a, **k))[1]
+    acc = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model)
+    assert acc == [100.0, 100.0]
+    assert calls["train"] == n and calls["eval"] >= n                   # model.train() / model.eval() round every tuning step (:216-218)
+    eng = runtime.SESSION.engine()
+    last = n - 1
+    if only_norm:
+        reset_state = eng.ln_params(pristine=True).cpu()
+        torch.testing.assert_close(reset_state, g[f"ln_reset_{last}"], atol=2.5 * meta["lr"] * (1 - meta["momentum"]) * meta["update_w"], rtol=1e-6)
+        assert (reset_state - g["ln_reset_0"]).abs().max() > 0           # it moved: the EMA was applied at sample 2
+    else:
+        from test_gpu_parity import _tensor_norms
+        ssd = synth.make_state_dict(synth.GEOMETRIES[meta["student"]], meta["student_seed"])
+        keys = RR.visual_param_keys(ssd)
+        reset_state = eng.merge_visual(eng.ln_params(pristine=True), eng.visual_params(1))
+        torch.testing.assert_close(_tensor_norms(ssd, keys, reset_state, ssd), g[f"vis_reset_delta_l2_{last}"], rtol=0.01, atol=1e-7)
+        assert float(g[f"vis_reset_delta_l2_{last}"].sum()) > 0
+    # next dataset: class bank swapped, visual state back to the checkpoint (after sample 0 the reference's reset state still IS the checkpoint)
+    model.reset_classnames_and_state(bank.classnames, "tiny")
+    eng = runtime.SESSION.engine()
+    a, b = eng.ln_params(pristine=True), eng.ln_params(pristine=False)
+    assert torch.equal(a, b) and torch.equal(model.ln.data, a)
+    if only_norm:
+        assert torch.equal(a.cpu(), g["ln_reset_0"])
+    else:
+        assert torch.equal(eng.visual_params(1), eng.visual_params(2)) and torch.equal(eng.visual_params(3), eng.visual_params(2))
+        assert torch.equal(eng.visual_params(0), eng.visual_params(2)) and torch.equal(model.vis.data, eng.visual_params(2))
+    runtime.reset_session()
+
+
+# ------------------------------------------------------------------------------ engine-owned scratch
+def test_two_engines_on_two_streams_do_not_share_scratch(L, dev):
+    """Every scratch buffer of an engine call belongs to the engine (split-K workspace of the small-grid GEMM, reward / loss
+    statistics, step-skip flags): two engines driven concurrently from two host threads on two streams give the results of the
+    serial runs.  LayerNorm tuning of one image at a time exercises the split-K workspace (K >= 1536 products on < 128 tiles)."""
+    from rlcf_amd.engine import TTAConfig
+    cfgs = [TTAConfig(selection_p=0.5, tta_steps=2), TTAConfig(selection_p=0.25, tta_steps=1, lr=1e-3)]
+    engines = [make_engine(("small", "small"), 16, 40, L.TEXT_SHARED, student_seed=11 + i, reward_seed=23 + i, prec=L.PREC_F16X3)[0] for i in range(2)]
+    views = [synth.make_views(3000 + i, 16, 64).to(dev) for i in range(2)]
+
+    def work(i, out, reps):
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            res = []
+            for r in range(reps):
+                a = engines[i].tta_sample(views[i], cfgs[0], want_intermediates=False)
+                b = engines[i].tta_sample_ln(views[i], cfgs[1])
+                res.append((a["final_logits"].clone(), a["ctx_after"].clone(), b["final_logits"].clone(), b["ln_after"].clone()))
+            torch.cuda.current_stream().synchronize()
+            out[i] = res
+
+    serial = {}
+    for i in range(2):
+        work(i, serial, 1)
+    conc = {}
+    th = [threading.Thread(target=work, args=(i, conc, 6)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        for rep in conc[i]:
+            for x, y in zip(rep, serial[i][0]):
+                torch.testing.assert_close(x, y, atol=2e-4, rtol=0)      # (float atomics on shared-prefix dK/dV: last bits)
+    for e in engines:
+        e.close()
+
+
+# ------------------------------------------------------------------------------ host-side n_sel
+def test_n_sel_is_the_hosts_double_product(L, dev):
+    """int(N * selection_p) (tpt_cls_rl.py:34) in Python doubles; the float field of the C argument block rounds 10 * 0.7f down to 6.
+    The engine must select what the host (and the reference) computes: 7 — and stay inside the caller's buffers."""
+    from rlcf_amd.engine import TTAConfig
+    N, p = 10, 0.7
+    assert int(N * p) == 7
+    eng, ssd, rsd, tokens, ctx0 = make_engine(("tiny", "tiny-r"), N, 16, L.TEXT_SHARED)
+    views = synth.make_views(4250, N, 32)
+    ref = RR.tta_sample(ssd, rsd, views, tokens, ctx0, RR.TTAHyper(selection_p=p))
+    o = eng.tta_sample(views.to(dev), TTAConfig(selection_p=p))
+    assert len(ref["selected_idx"]) == 7 and o["selected_idx"].cpu().tolist() == ref["selected_idx"].tolist()
+    assert o["topk_idx"].cpu().tolist() == ref["topk_idx"].tolist()
+    torch.testing.assert_close(o["final_logits"].cpu(), ref["final_logits"], atol=1e-3, rtol=0)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------ reward mirror: tensor contracts of the reference
+def test_reward_mirror_tensor_contracts(L, dev):
+    """CLIPScore(pairwise=True) is [n*K, n*K] (text rows against the K-times repeated image rows, clip_reward.py:118-123);
+    calulate_similarity returns the (logits_per_image, logits_per_text) pair scaled by exp(logit_scale) (:167-177)."""
+    from rlcf_amd import runtime
+    from test_gpu_parity import _harness_objects
+    g, meta = load_golden("tta_tiny_s1")
+    model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
+    n, K = 4, reward_model.sample_k
+    reward_model.set_image_features(views[:n])
+    idx = torch.arange(n * K, device=dev) % meta["n_cls"]
+    img, cls = reward_model.image_features, reward_model.class_features
+    pw = reward_model.CLIPScore(class_index=idx, pairwise=True)
+    ref_pw = (reward_model.clipscore_weight * cls[idx] @ img.repeat_interleave(K, dim=0).t()).clamp_min(0)
+    assert pw.shape == (n * K, n * K)
+    torch.testing.assert_close(pw, ref_pw, atol=1e-5, rtol=1e-5)
+    rw = reward_model.CLIPScore(class_index=idx, pairwise=False)
+    torch.testing.assert_close(rw, torch.diagonal(ref_pw), atol=1e-5, rtol=1e-5)
+    per_image, per_text = reward_model.calulate_similarity()
+    scale = float(synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"])["logit_scale"].exp())
+    torch.testing.assert_close(per_image, scale * img @ cls.t(), atol=1e-3, rtol=1e-5)
+    assert per_text.shape == (meta["n_cls"], n) and torch.equal(per_text, per_image.t())
+    runtime.reset_session()
+
+
+# ------------------------------------------------------------------------------ the sharded driver: two ranks == one rank
+def test_sharded_eval_two_ranks_equal_one_rank(L, dev, tmp_path):
+    """python -m rlcf_amd.eval: BASELINE configs[3] in miniature — a 7-image stream on one rank, then on two ranks (gloo, both on
+    this one GPU, launched the way the driver launches bench.py).  No data-path collective: the gathered predictions of the two
+    shards must be the one-rank predictions, and the reduced hit counts must agree."""
+    common = ["--total-images", "7", "--arch", "tiny", "--reward-arch", "tiny-r", "--views", "8", "--classes", "16", "--selection-p", "0.5",
+              "--images-per-pass", "2"]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one, two = os.path.join(tmp_path, "one.json"), os.path.join(tmp_path, "two.json")
+    r = subprocess.run([sys.executable, "-m", "rlcf_amd.eval", "--gpus", "1", "--out", one] + common, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", "-m", "rlcf_amd.eval", "--gpus", "2", "--dist-backend", "gloo", "--out", two] + common,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = json.load(open(one)), json.load(open(two))
+    assert a["images"] == b["images"] == 7 and b["n_gpus"] == 2
+    assert a["top5"] == b["top5"] and a["predictions_sha256"] == b["predictions_sha256"]
+    assert (a["acc1"], a["acc5"]) == (b["acc1"], b["acc5"])
+
+
+def test_bench_strong_scaling_line_two_ranks(L, dev):
+    """bench.py --total-images T on two ranks (gloo on one GPU): one JSON line, scaling 'strong', T images in total."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--total-images", "6", "--warmup", "2",
+                        "--views", "8", "--classes", "64", "--batch", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["value"] > 0
+    assert rec["config"]["timed_images_per_rank"] == 3 and rec["roofline"]["check_gemm_time_within_step"] in (True, False)
