@@ -58,41 +58,53 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3):
+T_START = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """progress on stderr (stdout carries the one JSON line)"""
+    print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
     """the oracle (CPU torch fp32 restatement of the REFERENCE GRAPH: dense 77-token text tower with
     autograd tape, dense backward, AdamW, final inference) on BASELINE configs[0] — ViT-B/16 + ViT-B/16, one image -> N=8 views,
-    selection_p=0.5, the full class bank — 1 warm-up + `timed` timed samples; no extrapolation.  Threads: os.cpu_count(); when
-    the host has more than 32 hardware threads the warm-up is repeated at 32 (torch's intra-op pool can thrash beyond that on
-    these op sizes) and the faster setting is the one timed — both warm-up times are reported."""
+    selection_p=0.5, the full class bank — 1 warm-up + `timed` timed samples at the full class count; no extrapolation.
+    Threads: min(os.cpu_count(), 32) (see below).
+    `budget_s` bounds the leg: timed samples stop early (at least one is taken) once it is spent."""
     from oracle import clip_ref as CR, rlcf_ref as RR
+    t_leg = time.perf_counter()
     ncpu = os.cpu_count() or 1
-    tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=n_ctx)
     ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(geo, n_ctx))
     hp = RR.TTAHyper(selection_p=0.5)
-    torch.set_num_threads(ncpu)
-    rc = RR.reward_class_features(rsd, tokens)              # once per dataset in the reference (tpt_cls_rl.py:182-183): not timed
 
-    def one(seed):
+    def one(seed, tokens, rc):
         views = synth.make_views(seed, 8, geo.image_resolution)
         t0 = time.perf_counter()
         RR.tta_sample(ssd, rsd, views, tokens, ctx0, hp, reward_cls=rc)
         return time.perf_counter() - t0
 
-    warm = {ncpu: one(999)}
-    if ncpu > 32:
-        torch.set_num_threads(32)
-        warm[32] = one(999)
-    threads = min(warm, key=warm.get)
+    # Threads: BASELINE.md asks for os.cpu_count(); on the GPU boxes of this pool (hundreds of hardware threads) torch's intra-op pool
+    # then thrashes so badly that a 1.5 s probe sample (32 classes) did not finish in ten minutes (round-2 measurement), so the pool
+    # is capped at 32 threads — the count is reported as `cores`, the host's total as `hardware_threads`.
+    threads = min(ncpu, 32)
     torch.set_num_threads(threads)
-    n_timed = timed if warm[threads] < 75.0 else 1          # small host: scale the sample count down (BASELINE.md section 3)
-    times = [one(1000 + i) for i in range(n_timed)]
+    tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=n_ctx)
+    rc = RR.reward_class_features(rsd, tokens)              # once per dataset in the reference (tpt_cls_rl.py:182-183): not timed
+    warm = one(999, tokens, rc)
+    log(f"cpu_baseline warm-up at C={n_cls}, {threads} threads: {warm:.1f} s")
+    times = []
+    for i in range(timed):
+        times.append(one(1000 + i, tokens, rc))
+        log(f"cpu_baseline sample {i}: {times[-1]:.1f} s")
+        if time.perf_counter() - t_leg > budget_s:
+            break
     mean = sum(times) / len(times)
     return {"value": 1.0 / mean, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle (CPU torch fp32, dense-77 reference graph, no structural shortcuts) on BASELINE configs[0]: ViT-B/16 + ViT-B/16, "
-                      f"1 image x N=8 views (selection_p=0.5 -> 4 selected), C={n_cls}, K=3, 1 AdamW step; 1 warm-up + {n_timed} timed "
+                      f"1 image x N=8 views (selection_p=0.5 -> 4 selected), C={n_cls}, K=3, 1 AdamW step; 1 warm-up + {len(times)} timed "
                       f"samples, {threads} torch threads of {ncpu} hardware threads",
-            "seconds_per_image": [round(t, 3) for t in times], "seconds_per_image_mean": mean,
-            "warmup_seconds_by_threads": {str(k): round(v, 3) for k, v in warm.items()},
+            "seconds_per_image": [round(t, 3) for t in times], "seconds_per_image_mean": mean, "warmup_seconds": round(warm, 3),
             "cpu_model": cpu_model(), "hardware_threads": ncpu}
 
 
@@ -122,6 +134,7 @@ def main():
                     help="strong scaling: this many test images in total, split over the ranks (BASELINE configs[3]: 256); overrides --steps")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=300.0, help="seconds after which no further timed CPU sample is started")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch profiling leg (rocprofv3 runs: fewer launches in the trace)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
@@ -156,6 +169,7 @@ def main():
     eng.finalize()
     mode = {"dense": _lib.TEXT_DENSE, "packed": _lib.TEXT_PACKED, "shared": _lib.TEXT_SHARED}[a.text_mode]
     eng.set_class_bank(tokens, n_ctx, ctx0, mode)
+    log("engine ready")
     cfg = TTAConfig(selection_p=0.1, tta_steps=a.tta_steps, sample_k=3, lr=7e-3, weight_decay=5e-4)
 
     # which test images this rank times: weak scaling = `steps` images of its own; strong = its shard of a fixed stream
@@ -194,6 +208,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     flops_exec = eng.last_flops()
+    log(f"timed region: {total_steps} images in {dt:.3f} s")
     ms_per_step = dt / (total_steps / world) * 1e3       # per rank: every rank runs total/world images concurrently
 
     if rank == 0:
@@ -222,6 +237,7 @@ def main():
             torch.cuda.synchronize()
             ent = profile_entries(lib)
             lib.rlcf_profile_gemm(0)
+            log(f"roofline leg: {len(ent)} profiled launches")
             gemms = [e for e in ent if e[0] != 10]
             dom_kind = 3 if a.precision != "f32" else 0      # 256x256-tile split-f16 GEMM / the f32-MFMA kernels
             dom = [e for e in gemms if e[0] == dom_kind]
@@ -283,12 +299,14 @@ def main():
                     torch.cuda.synchronize()             # keeps the host at most 4 passes ahead (the loop is time-bounded)
             torch.cuda.synchronize()
             per_img = sorted(e0.elapsed_time(e1) / pass_images for e0, e1 in evs)
+            log(f"sustained leg: {len(per_img)} passes")
             out["sustained"] = {"passes": len(per_img), "images_per_pass": pass_images, "mean_ms_per_image": statistics.fmean(per_img),
                                 "p50_ms_per_image": statistics.median(per_img), "min_ms_per_image": per_img[0],
                                 "max_ms_per_image": per_img[-1], "images_per_s_mean": 1e3 / statistics.fmean(per_img),
                                 "timer": "HIP events on the launch stream, one pair per pass"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes)
+            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes,
+                                               budget_s=a.cpu_baseline_budget)
         print(json.dumps(out))
     eng.close()
     if use_dist:

@@ -34,6 +34,7 @@ struct GemmX3Args {
     int kstep;                         // halves between consecutive K tiles in A/W rows: 32 (separate hi/lo arrays) or 64 (interleaved)
     int ksplit;                        // 128x128 DMA-ring kernel only: blockIdx.y walks K tiles [y*per, (y+1)*per); raw partial tiles go
     float* ws;                         // to ws[ksplit][M][N] and gemm_x3_splitk_reduce_kernel applies alpha / bias / epilogue
+    int no_fast_epi;                   // RLCF_X3_NOFASTEPI=1: 256x256 kernel keeps the generic per-row epilogue (A/B measurements)
 };
 
 __device__ __forceinline__ int x3_ocol(const GemmX3Args& g, int col) { return g.c_il ? (((col >> 5) << 6) | (col & 31)) : col; }
@@ -618,6 +619,96 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     amax_commit(g.amax_out, am);
 }
 
+// Epilogue of the 256x256 kernels for the shapes of the forward towers, specialised at compile time (no per-row branches on the
+// epilogue kind) and written so that NOTHING waits inside the row loop: on gfx9 stores count in vmcnt like loads, so a residual load
+// issued after a store cannot be awaited without draining that store — the generic loop below (load, wait, store, per row) pays one
+// HBM round trip per row, ~12 us per tile.  Here the 16 residual rows of a half are fetched BEFORE the accumulators are parked, then
+// the rows stream out as ds_read -> math -> store with no VMEM wait in between; each wave parks and re-reads only its own LDS
+// slice, so one barrier (the ring is no longer read) is all the synchronisation there is.
+template <int EPI, bool RES, bool F32OUT, bool PAIR>
+__device__ __forceinline__ void v3_epilogue_fast(const GemmX3Args& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+    constexpr int ELD = 68;
+    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+    float* park = (float*)smem + wave * (64 * ELD);
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int col = n0 + wn * 64 + c4;
+    const bool colok = col < g.N;
+    const int colc = colok ? col : 0;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *(const float4*)(g.bias + colc);
+    const float al = g.alpha;
+    const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
+    const int rbase = m0 + wm * 128 + rsub;
+    __syncthreads();
+#define V3E_PARK(half)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[(half) * 2 + i][j][r];
+#define V3E_VALUE(it, OUT)                                                                                               \
+    {                                                                                                                    \
+        const float4 a4 = *(const float4*)(park + ((it) * 4 + rsub) * ELD + c4);                                         \
+        float v_[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};                          \
+        if constexpr (EPI == RLCF_EPI_QUICKGELU) { _Pragma("unroll") for (int q = 0; q < 4; ++q) v_[q] = quick_gelu(v_[q]); } \
+        OUT = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                                   \
+    }
+#define V3E_STORE(row, V)                                                                                                \
+    if (colok && (row) < g.M) {                                                                                          \
+        if constexpr (F32OUT) *(float4*)(g.C + (size_t)(row) * g.ldc + col) = (V);                                       \
+        if constexpr (PAIR) {                                                                                            \
+            const float v_[4] = {(V).x, (V).y, (V).z, (V).w};                                                            \
+            h16x4 hh, ll;                                                                                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v_[q]; ll[q] = (_Float16)(v_[q] - (float)hh[q]); } \
+            *(h16x4*)(g.Chi + (size_t)(row) * g.ldch + ocol) = hh;                                                       \
+            *(h16x4*)(g.Clo + (size_t)(row) * g.ldch + ocol) = ll;                                                       \
+        }                                                                                                                \
+    }
+    if constexpr (RES) {
+        // two phases per half so that no load is awaited behind a store of the same half: the 16 residual rows are fetched before the
+        // accumulators are parked and combined in registers; only then do the rows stream out (half 1's fetch drains half 0's stores once)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 rr[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) rr[it] = *(const float4*)(g.residual + (size_t)min(rbase + half * 64 + it * 4, g.M - 1) * g.ldr + colc);
+            V3E_PARK(half)
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                float4 t; V3E_VALUE(it, t) rr[it].x += t.x; rr[it].y += t.y; rr[it].z += t.z; rr[it].w += t.w;
+                asm volatile("" : "+v"(rr[it].x), "+v"(rr[it].y), "+v"(rr[it].z), "+v"(rr[it].w));     // materialise here: the sums must not sink
+            }                                                                                            // into the store loop (IR sinking re-fuses the phases)
+            asm volatile("" ::: "memory");                     // no store moves above this point, no load below it
+#pragma unroll
+            for (int it = 0; it < 16; ++it) { V3E_STORE(rbase + half * 64 + it * 4, rr[it]) }
+            asm volatile("" ::: "memory");
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            V3E_PARK(half)
+#pragma unroll
+            for (int it = 0; it < 16; ++it) { float4 t; V3E_VALUE(it, t) V3E_STORE(rbase + half * 64 + it * 4, t) }
+        }
+    }
+#undef V3E_PARK
+#undef V3E_VALUE
+#undef V3E_STORE
+}
+// wave-uniform dispatch to the specialisations above; false: the caller runs the generic epilogue
+__device__ __forceinline__ bool v3_epilogue_dispatch(const GemmX3Args& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+    if (g.amax_out || g.alpha_dev || g.aux || g.no_fast_epi) return false;
+    const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
+    if (g.epilogue == RLCF_EPI_NONE && f32o && !pair) {
+        if (res) v3_epilogue_fast<RLCF_EPI_NONE, true, true, false>(g, acc, smem, m0, n0, wave, lane);        // out_proj / c_proj + residual
+        else v3_epilogue_fast<RLCF_EPI_NONE, false, true, false>(g, acc, smem, m0, n0, wave, lane);           // in_proj (QKV), conv1
+        return true;
+    }
+    if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) {                                            // c_fc + QuickGELU -> operand pair
+        v3_epilogue_fast<RLCF_EPI_QUICKGELU, false, false, true>(g, acc, smem, m0, n0, wave, lane);
+        return true;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
@@ -761,6 +852,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
             for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
     }
+    if (v3_epilogue_dispatch(g, acc, smem, m0, n0, wave, lane)) return;
     // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
     constexpr int ELD = 68;
     float* park = (float*)smem + wave * (64 * ELD);
@@ -882,6 +974,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const int blocks2 = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
     static int force = -1;                                   // RLCF_X3_KERNEL=1|2 pins a variant (benchmarks)
     if (force < 0) { const char* e = getenv("RLCF_X3_KERNEL"); force = e ? atoi(e) : 0; }
+    static int nofast = -1;
+    if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }
+    g.no_fast_epi = nofast;
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
     // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes

@@ -25,20 +25,26 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     for (int i = 1; i < TTA_THREADS / 64; ++i) s = fmaxf(s, red[i]);
     return s;
 }
+// Total order used by every selection here: NaN ranks ABOVE +inf (torch.topk / torch.argsort treat NaN as the largest value), so a
+// non-finite logits row still yields in-range, distinct indices (the GradScaler guard then skips the step: launch_grad_nonfinite).
+__device__ __forceinline__ bool ord_gt(float a, float b) { return a > b || (a != a && b == b); }
+__device__ __forceinline__ bool ord_eq(float a, float b) { return a == b || (a != a && b != b); }
+// max(x, 0) that lets a NaN through, like torch.maximum(similarity, zeros) (clip_reward.py:126)
+__device__ __forceinline__ float relu_nan(float x) { return x > 0.f ? x : (x == x ? 0.f : x); }
 // argmax over (value, index) with lowest index winning ties
 __device__ __forceinline__ void block_argmax(float& v, int& i, float* redv, int* redi) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ov = __shfl_xor(v, o);
         int oi = __shfl_xor(i, o);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+        if (ord_gt(ov, v) || (ord_eq(ov, v) && oi < i)) { v = ov; i = oi; }
     }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = i; }
     __syncthreads();
     v = redv[0]; i = redi[0];
     for (int w = 1; w < TTA_THREADS / 64; ++w)
-        if (redv[w] > v || (redv[w] == v && redi[w] < i)) { v = redv[w]; i = redi[w]; }
+        if (ord_gt(redv[w], v) || (ord_eq(redv[w], v) && redi[w] < i)) { v = redv[w]; i = redi[w]; }
 }
 
 // ---------------------------------------------------------------- entropy per row
@@ -64,7 +70,7 @@ __global__ void select_lowest_kernel(const float* __restrict__ entropy, int n, i
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             const float f = entropy[j];
-            rank += (f < e || (f == e && j < i)) ? 1 : 0;
+            rank += (ord_gt(e, f) || (ord_eq(f, e) && j < i)) ? 1 : 0;          // NaN entropies sort last, as in torch.argsort
         }
         if (rank < n_sel) idx[rank] = i;
     }
@@ -77,7 +83,7 @@ __global__ void select_lowest_batched_kernel(const float* __restrict__ entropy, 
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             const float f = ent[j];
-            rank += (f < e || (f == e && j < i)) ? 1 : 0;
+            rank += (ord_gt(e, f) || (ord_eq(f, e) && j < i)) ? 1 : 0;          // NaN entropies sort last, as in torch.argsort
         }
         if (rank < n_sel) idx[blockIdx.x * n_sel + rank] = blockIdx.x * n + i;
     }
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_a_kernel(const float
             bool used = false;
             for (int p = 0; p < k; ++p) used |= (chosen[p] == c);
             const float v = x[c];
-            if (!used && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+            if (!used && (ord_gt(v, bv) || (ord_eq(v, bv) && c < bi))) { bv = v; bi = c; }
         }
         block_argmax(bv, bi, redv, redi);
         if (threadIdx.x == 0) {
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(TTA_THREADS) void reward_stage_a_kernel(const float
             float d = 0.f;
             for (int c = threadIdx.x; c < Dr; c += TTA_THREADS) d += t[c] * im[c];
             d = block_sum(d, red);
-            score += bank.mix[m] * fmaxf(weight * d, 0.f);
+            score += bank.mix[m] * relu_nan(weight * d);
         }
         if (threadIdx.x == 0) stats[i * STAT_LD + 1 + MAX_K + k] = bank.post_div == 1.f ? score : score / bank.post_div;
     }
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(TTA_THREADS) void top5_kernel(const float* __restri
             bool used = false;
             for (int p = 0; p < k; ++p) used |= (chosen[p] == c);
             const float v = x[c];
-            if (!used && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+            if (!used && (ord_gt(v, bv) || (ord_eq(v, bv) && c < bi))) { bv = v; bi = c; }
         }
         block_argmax(bv, bi, redv, redi);
         if (threadIdx.x == 0) { chosen[k] = bi; top5[k] = bi; }

@@ -152,9 +152,14 @@ def test_shipped_harness_applies_the_momentum_update(L, dev, fixture, only_norm)
     loader = [([v.unsqueeze(0) for v in synth.make_views(1000 + i, meta["n_views"], R)],
                torch.tensor([int(g[f"final_logits_{i}"][0].argmax())])) for i in range(n)]
     calls = {"train": 0, "eval": 0}
-    orig_train, orig_eval = model.train, model.eval
-    model.train = lambda *a, **k: (calls.__setitem__("train", calls["train"] + 1), orig_train(*a, **k))[1]
-    model.eval = lambda *a, **k: (calls.__setitem__("eval", calls["eval"] + 1), orig_eval(*a, **k))[1]
+    orig_train = model.train
+
+
+    def counted_train(mode=True):                # (nn.Module.eval() is train(False): count the two directions separately)
+        calls["train" if mode else "eval"] += 1
+        return orig_train(mode)
+
+    model.train = counted_train
     acc = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model)
     assert acc == [100.0, 100.0]
     assert calls["train"] == n and calls["eval"] >= n                   # model.train() / model.eval() round every tuning step (:216-218)
@@ -289,7 +294,7 @@ def test_bench_strong_scaling_line_two_ranks(L, dev):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29519", "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--total-images", "6", "--warmup", "2",
-                        "--views", "8", "--classes", "64", "--batch", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                        "--views", "16", "--classes", "64", "--batch", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
