@@ -191,7 +191,8 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     e->n_rewards = n_rewards;
     for (int m = 0; m < n_rewards; ++m) { e->model[1 + m].cfg = rewards[m]; e->model[1 + m].present = true; }
     int Tmax = 0, Wmax = 0, Pmax = 0, Kpmax = 0, Dmax = 0;
-    std::vector<rlcf_seq> seqs((size_t)(1 + RLCF_MAX_REWARDS) * max_views);
+    std::vector<rlcf_seq> seqs((size_t)(1 + RLCF_MAX_REWARDS) * max_views), seqs_cls(seqs.size());
+    std::vector<int32_t> cls_idx(seqs.size(), 0);
     for (int w = 0; w <= RLCF_MAX_REWARDS; ++w) {
         if (!e->model[w].present) continue;
         const rlcf_clip_cfg& c = e->model[w].cfg;
@@ -200,7 +201,11 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
         const int g = c.image_resolution / c.vision_patch_size, tok = g * g + 1;
         Tmax = std::max(Tmax, max_views * tok); Wmax = std::max(Wmax, c.vision_width); Pmax = std::max(Pmax, max_views * g * g);
         Kpmax = std::max(Kpmax, (3 * c.vision_patch_size * c.vision_patch_size + 63) / 64 * 64); Dmax = std::max(Dmax, c.embed_dim);
-        for (int i = 0; i < max_views; ++i) seqs[(size_t)w * max_views + i] = rlcf_seq{i * tok, tok, 0, 0};
+        for (int i = 0; i < max_views; ++i) {
+            seqs[(size_t)w * max_views + i] = rlcf_seq{i * tok, tok, 0, 0};
+            seqs_cls[(size_t)w * max_views + i] = rlcf_seq{i * tok, 1, i * tok + 1, tok - 1};     // query = class token, keys = all tok rows
+            cls_idx[(size_t)w * max_views + i] = i * tok;
+        }
     }
     bool ok = true;
     {
@@ -212,12 +217,15 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     ok = ok && e->patches.ensure((size_t)Pmax * Kpmax * sizeof(float)) == 0 && e->patch_out.ensure((size_t)Pmax * Wmax * sizeof(float)) == 0;
     ok = ok && e->cls_rows.ensure((size_t)max_views * Wmax * sizeof(float)) == 0 && e->cls_ln.ensure((size_t)max_views * Wmax * sizeof(float)) == 0;
     ok = ok && e->feat_raw.ensure((size_t)max_views * Dmax * sizeof(float)) == 0;
-    ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0;
+    ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0 && e->vit_seqs_cls.ensure(seqs.size() * sizeof(rlcf_seq)) == 0 &&
+         e->vit_cls_idx.ensure(cls_idx.size() * sizeof(int32_t)) == 0;
     if (precision == RLCF_PREC_F16X3) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
         ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0;
     }
-    if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(e->vit_seqs_cls.p, seqs_cls.data(), seqs_cls.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(e->vit_cls_idx.p, cls_idx.data(), cls_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { rlcf_engine_destroy(e); return nullptr; }
     return e;
 }
@@ -251,7 +259,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
-                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->rl_stats, &e->step_skip}) d->release();
+                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }
 

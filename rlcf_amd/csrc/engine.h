@@ -89,7 +89,9 @@ struct rlcf_engine {
     float reward_mix[RLCF_MAX_REWARDS] = {1.f, 0.f, 0.f, 0.f};
     // ViT workspace (shared by student and reward passes)
     Tower vt;
-    DevBuf patches, patch_out, vit_seqs /*[2][max_views]*/, cls_rows, cls_ln, feat_raw, resized;
+    DevBuf patches, patch_out, vit_seqs /*[1 + rewards][max_views]*/, cls_rows, cls_ln, feat_raw, resized;
+    DevBuf vit_seqs_cls, vit_cls_idx;   // per model: one-query descriptors of the class token (keys: the whole sequence) and its row ids
+    DevBuf cls_a2, cls_h2, cls_f2;      // operand pairs of the class-token-only last block [views, W] / [views, 4W]
     // text
     int text_mode = RLCF_TEXT_SHARED, n_ctx = 0, C = 0;
     TextLayout lay[1 + RLCF_MAX_REWARDS];   // [student], [reward slots]

@@ -492,8 +492,14 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
     do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
          TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride, 1)); } while (0)
 
+// cls_seqs / cls_idx / cls_out (image towers, split-f16 pipeline): only row `cls_idx[s]` of every sequence is consumed after the
+// last block (ln_post(x[:, 0]) @ proj, model.py:235-238), and out_proj, the MLP and the residual adds act row by row — so the LAST
+// block runs its attention for that one query per sequence (keys: the whole sequence; cls_seqs = {q_start = cls row, q_len = 1,
+// prefix = the other rows}) and everything after it on the n_seq gathered rows only; the result lands compact in cls_out [n_seq, W]
+// (ws.x then holds the input of the last block).  Exact: no other row of the last block's output is ever read.
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
-                               long attn_pairs, int causal, int T, bool save, hipStream_t st) {
+                               long attn_pairs, int causal, int T, bool save, hipStream_t st, const rlcf_seq* cls_seqs = nullptr,
+                               const int32_t* cls_idx = nullptr, float* cls_out = nullptr) {
     const int W = w.width, L = w.layers;
     const int ln_view_rows = max_q_len;          // (per-view LayerNorm sets only exist for the image tower: one sequence per view)
     if (e->precision == RLCF_PREC_F16X3 && !save && T > 512 && W % 32 == 0) {
@@ -504,6 +510,23 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             const BlockW& b = w.blk[l];
             LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
             TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            if (l == L - 1 && cls_out && cls_seqs && cls_idx && !causal) {
+                // last block, class-token rows only (see above).  Pair rows are W * 4 bytes like f32 rows: gather_rows moves both.
+                const size_t nw = (size_t)n_seq * W * sizeof(float);
+                TRY(e->cls_a2.ensure(nw)); TRY(e->cls_h2.ensure(nw)); TRY(e->cls_f2.ensure(4 * nw));
+                TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), cls_seqs, n_seq, 1, W, 0, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1));
+                e->last_flops += 4.0 * (double)n_seq * max_q_len * W;
+                TRY(launch_gather_rows((const float*)ws.a2.p, W, cls_idx, e->cls_a2.as<float>(), W, n_seq, W, st));
+                TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
+                TRY(gemm_pre(e, e->cls_a2.p, W, b.out_w, b.out_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, W, RLCF_EPI_NONE, st));
+                {   // LayerNorm sets per view (batched LN-tuning inference): one row per view here
+                    const int ln_view_rows = 1;
+                    LN_FWD_SPLIT(cls_out, b.ln2_w, b.ln2_b, e->cls_h2.p, lo_of(e->cls_h2.p), n_seq, W);
+                }
+                TRY(gemm_pre(e, e->cls_h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, e->cls_f2.p, 4 * W, n_seq, 4 * W, W, RLCF_EPI_QUICKGELU, st));
+                TRY(gemm_pre(e, e->cls_f2.p, 4 * W, b.proj_w, b.proj_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, 4 * W, RLCF_EPI_NONE, st));
+                return RLCF_OK;
+            }
             {
                 const int slot = prof_begin(st, 4.0 * attn_pairs * W, T, W, max_q_len);          // kind 10: fused attention forward
                 const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1);
@@ -516,6 +539,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             TRY(gemm_pre(e, ws.h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.f2.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
             TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
         }
+        if (cls_out && cls_idx) TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
         return RLCF_OK;
     }
     for (int l = 0; l < L; ++l) {
@@ -544,6 +568,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         }
         TRY(gemm(e, f, 4 * W, b.proj_w, 4 * W, b.proj_b, x1, W, nullptr, 0, xout, W, T, W, 4 * W, 1.f, RLCF_EPI_NONE, st));
     }
+    if (cls_out && cls_idx) TRY(launch_gather_rows(ws.x.as<float>(), W, cls_idx, cls_out, W, n_seq, W, st));
     return RLCF_OK;
 }
 
@@ -626,9 +651,10 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
         const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
         TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.x.as<float>(), n, tok, Wv, st, gw.group_rows, gw.group_stride));
     }
+    // class-token rows come out compact: the last block is evaluated for them only (transformer_forward)
     TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
-                            false, st));
-    TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
+                            false, st, e->vit_seqs_cls.as<rlcf_seq>() + (size_t)which * e->max_views,
+                            e->vit_cls_idx.as<int32_t>() + (size_t)which * e->max_views, e->cls_rows.as<float>()));
     {
         const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);      // one class-token row per view
         TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), gw.p, gb.p, e->cls_ln.as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
