@@ -41,11 +41,9 @@ from rlcf_amd import _lib, shard, synth  # noqa: E402
 from rlcf_amd.engine import Engine, TTAConfig  # noqa: E402
 
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks; f16 = bf16 rate)
-PRECISIONS = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}
-if hasattr(_lib, "PREC_F16"):
-    PRECISIONS["f16"] = _lib.PREC_F16
+PRECISIONS = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16}
 MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16": 1}
-DTYPE = {"f32": "f32", "f16x3": "f32 via split-f16x3 MFMA", "f16": "f16 (single pass, f32 accumulate)"}
+DTYPE = {"f32": "f32", "f16x3": "f32 via split-f16x3 MFMA", "f16": "f16 forward pipeline (one MFMA per product, f32 accumulate): NOT parity-grade"}
 
 
 def cpu_model() -> str:
@@ -135,6 +133,7 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=300.0, help="seconds after which no further timed CPU sample is started")
+    ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary single-pass f16 measurement (RLCF_PREC_F16, not parity-grade)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch profiling leg (rocprofv3 runs: fewer launches in the trace)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
@@ -304,6 +303,45 @@ def main():
                                 "p50_ms_per_image": statistics.median(per_img), "min_ms_per_image": per_img[0],
                                 "max_ms_per_image": per_img[-1], "images_per_s_mean": 1e3 / statistics.fmean(per_img),
                                 "timer": "HIP events on the launch stream, one pair per pass"}
+        if world == 1 and a.precision == "f16x3" and not a.no_f16_line and not use_dist:
+            # ---- secondary, clearly labelled: the reference's own GPU arithmetic (fp16 autocast, tpt_cls_rl.py:52) = RLCF_PREC_F16.
+            # Not the headline and not parity-grade: reported with its measured deviation from the split-f16 engine on this very pass.
+            top5x, flx = eng.tta_batch(views[:pass_images], cfg, want_logits=True)
+            eh = Engine(geo, rgeo, a.views * batch, a.classes, _lib.PREC_F16)
+            eh.load_state_dict(_lib.STUDENT, ssd)
+            eh.load_state_dict(_lib.REWARD, rsd)
+            eh.finalize()
+            eh.set_class_bank(tokens, n_ctx, ctx0, mode)
+            top5h, flh = eh.tta_batch(views[:pass_images], cfg, want_logits=True)         # also sizes the workspaces
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            e0.record()
+            for _ in range(reps):
+                eh.tta_batch(views[:pass_images], cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_h = e0.elapsed_time(e1) / (reps * pass_images)
+            lib.rlcf_profile_gemm(1)
+            eh.tta_batch(views[:pass_images], cfg)
+            torch.cuda.synchronize()
+            ent_h = profile_entries(lib)
+            lib.rlcf_profile_gemm(0)
+            dom_h = [e for e in ent_h if e[0] == 3]
+            ach_h = sum(e[2] for e in dom_h) / max(sum(e[1] for e in dom_h), 1e-9) / 1e9
+            Wv, tok = geo.vision_width, geo.vision_tokens
+            qkv_h = [e for e in ent_h if e[0] != 10 and e[3] == (pass_images * a.views * tok, 3 * Wv, Wv)]
+            att_h = [e for e in ent_h if e[0] == 10 and e[3][0] == pass_images * a.views * tok]
+            out["secondary_f16_single_pass"] = {
+                "what": "RLCF_PREC_F16: forward tower pipeline in plain f16, one MFMA per product (the reference's fp16-autocast arithmetic); "
+                        "NOT parity-grade, not the headline", "images_per_s": 1e3 / ms_h, "ms_per_image": ms_h, "images_per_pass": pass_images,
+                "max_abs_dlogit_vs_split_f16": float((flx - flh).abs().max().item()),
+                "top1_agreement_vs_split_f16": float((top5x[:, 0] == top5h[:, 0]).float().mean().item()),
+                "dominant_gemm_tflops": ach_h, "dominant_gemm_frac_of_f16_peak": ach_h / PEAK_TFLOPS["f16"],
+                "in_proj_qkv_gemm_frac_of_f16_peak": (sum(e[2] for e in qkv_h) / max(sum(e[1] for e in qkv_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if qkv_h else None,
+                "attention_fwd_frac_of_f16_peak": (sum(e[2] for e in att_h) / max(sum(e[1] for e in att_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if att_h else None}
+            eh.close()
+            log("secondary f16 line done")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes,
                                                budget_s=a.cpu_baseline_budget)

@@ -29,8 +29,12 @@ typedef struct rlcf_engine rlcf_engine;
 enum rlcf_status { RLCF_OK = 0, RLCF_ERR_ARG = -1, RLCF_ERR_HIP = -2, RLCF_ERR_STATE = -3, RLCF_ERR_NOMEM = -4 };
 enum rlcf_precision {
     RLCF_PREC_F32 = 0,   /* f32 storage, f32-input MFMA (exact f32 FMA chains, 157 TF pipe)                       */
-    RLCF_PREC_BF16 = 1,  /* reserved, not built: plain bf16 cannot meet the 1e-3 logit contract    */
-    RLCF_PREC_F16X3 = 2  /* split-f16: each f32 operand = hi+lo f16, 3 f16 MFMAs per product, f32-grade results  */
+    RLCF_PREC_F16 = 1,   /* PERFORMANCE mode, NOT parity-grade: the forward tower pipeline in plain f16 (one MFMA per product, f32
+                          * accumulate; LayerNorm / softmax / losses / AdamW in f32) = the arithmetic of the reference's fp16-autocast
+                          * GPU path (TPT/tpt_cls_rl.py:52).  Logits deviate from the f32 reference by ~1e-2 at logit scale 100
+                          * (measured per run by bench.py and tests: max |dlogit|, top-1 agreement); engine calls only        */
+    RLCF_PREC_F16X3 = 2  /* split-f16: each f32 operand = hi+lo f16, 3 f16 MFMAs per product, f32-grade results (the default: meets
+                          * the 1e-3 logit contract)                                                                         */
 };
 enum rlcf_epilogue {     /* GEMM epilogues (TPT/clip/model.py:166-168,177-181,190-191) */
     RLCF_EPI_NONE = 0,

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librlcf_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
-PREC_F32, PREC_BF16, PREC_F16X3 = 0, 1, 2
+PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2       # F16: single-pass performance mode (not parity-grade); F16X3: the default
 EPI_NONE, EPI_QUICKGELU, EPI_QUICKGELU_BWD = 0, 1, 2
 TEXT_DENSE, TEXT_PACKED, TEXT_SHARED = 0, 1, 2
 STUDENT, REWARD = 0, 1

@@ -178,7 +178,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
         rlcf_set_error("rlcf_engine_create: bad geometry / sizes");
         return nullptr;
     }
-    if (precision != RLCF_PREC_F32 && precision != RLCF_PREC_F16X3) {
+    if (precision != RLCF_PREC_F32 && precision != RLCF_PREC_F16X3 && precision != RLCF_PREC_F16) {
         rlcf_set_error("rlcf_engine_create: precision %d not built", precision);
         return nullptr;
     }
@@ -219,7 +219,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     ok = ok && e->feat_raw.ensure((size_t)max_views * Dmax * sizeof(float)) == 0;
     ok = ok && e->vit_seqs.ensure(seqs.size() * sizeof(rlcf_seq)) == 0 && e->vit_seqs_cls.ensure(seqs.size() * sizeof(rlcf_seq)) == 0 &&
          e->vit_cls_idx.ensure(cls_idx.size() * sizeof(int32_t)) == 0;
-    if (precision == RLCF_PREC_F16X3) {
+    if (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
         ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0;
     }

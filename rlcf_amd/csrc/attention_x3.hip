@@ -22,7 +22,9 @@ __device__ __forceinline__ void split8(const float* v, h16x8& hi, h16x8& lo) {
     }
 }
 
-template <int NW>
+// SINGLE: one MFMA per product on the hi parts only — plain f16 attention (RLCF_PREC_F16, the arithmetic of the reference's fp16
+// autocast); the lo tiles are neither written nor read, the output is a plain f16 matrix (ol null).
+template <int NW, bool SINGLE>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
                                                                     _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il, int qb0,
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
                 a[e] = (_Float16)kk[e]; b[e] = (_Float16)(kk[e] - (float)a[e]);                                          \
                 const _Float16 hh = (_Float16)vv[e];                                                                     \
                 Vh[buf_][(d0 + 4 * j + e) * AX_VLD + slot] = hh;                                                         \
-                Vl[buf_][(d0 + 4 * j + e) * AX_VLD + slot] = (_Float16)(vv[e] - (float)hh);                             \
+                if constexpr (!SINGLE) Vl[buf_][(d0 + 4 * j + e) * AX_VLD + slot] = (_Float16)(vv[e] - (float)hh);       \
             }                                                                                                            \
             *(h16x4*)(Kh[buf_] + lkey * AX_KLD + d0 + 4 * j) = a;                                                        \
-            *(h16x4*)(Kl[buf_] + lkey * AX_KLD + d0 + 4 * j) = b;                                                        \
+            if constexpr (!SINGLE) *(h16x4*)(Kl[buf_] + lkey * AX_KLD + d0 + 4 * j) = b;                                 \
         }                                                                                                                \
     }
     // one-wave blocks (text sequences: a single chunk of <= 32 keys) gain nothing from the prefetch and pay for its registers
@@ -122,10 +124,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const h16x8 kh = *(const h16x8*)(kh_ + l32 * AX_KLD + ks * 16 + h * 8);
-                const h16x8 kl = *(const h16x8*)(kl_ + l32 * AX_KLD + ks * 16 + h * 8);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                if constexpr (!SINGLE) {
+                    const h16x8 kl = *(const h16x8*)(kl_ + l32 * AX_KLD + ks * 16 + h * 8);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                }
             }
             float cm = -INFINITY;
             if (kc + 32 > nkeys || (causal && kc + 31 > sq.pre_len + qb * 32)) {       // chunk holds masked keys
@@ -157,15 +161,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
                 h16x8 ph, pl;
                 split8(pv, ph, pl);
                 const h16x8 v0h = *(const h16x8*)(vh_ + l32 * AX_VLD + tt * 16 + h * 8);
-                const h16x8 v0l = *(const h16x8*)(vl_ + l32 * AX_VLD + tt * 16 + h * 8);
                 const h16x8 v1h = *(const h16x8*)(vh_ + (32 + l32) * AX_VLD + tt * 16 + h * 8);
-                const h16x8 v1l = *(const h16x8*)(vl_ + (32 + l32) * AX_VLD + tt * 16 + h * 8);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
+                if constexpr (!SINGLE) {
+                    const h16x8 v0l = *(const h16x8*)(vl_ + l32 * AX_VLD + tt * 16 + h * 8);
+                    const h16x8 v1l = *(const h16x8*)(vl_ + (32 + l32) * AX_VLD + tt * 16 + h * 8);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
+                }
             }
             m = mn;
         }
@@ -202,36 +208,42 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
                 // interleaved pair layout (il): the head's two 32-column blocks sit at row*2W + head*128 (+64), lo 32 halves after hi
                 const size_t p0 = il ? (size_t)(sq.q_start + qi) * 2 * width + head * 128 + d : obase + d;
                 const size_t p1 = il ? p0 + 64 : p0 + 32;
-                *(h16x4*)(oh + p0) = h0; *(h16x4*)(ol + p0) = l0;
-                *(h16x4*)(oh + p1) = h1; *(h16x4*)(ol + p1) = l1;
+                *(h16x4*)(oh + p0) = h0; *(h16x4*)(oh + p1) = h1;
+                if (ol) { *(h16x4*)(ol + p0) = l0; *(h16x4*)(ol + p1) = l1; }
             }
         }
     }
 }
 
+template <int NW>
+static void attn_launch(bool single, dim3 grid, hipStream_t st, const float* qkv, const rlcf_seq* seqs, int width, int causal, float* out,
+                        _Float16* oh, _Float16* ol, int il, int qb0, float* lse) {
+    if (single) attention_fwd_x3_kernel<NW, true><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse);
+    else attention_fwd_x3_kernel<NW, false><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse);
+}
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st, int il, float* lse) {
-    RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && out_lo)));
+                            void* out_hi, void* out_lo, hipStream_t st, int il, float* lse, int single) {
+    RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && (out_lo || single))));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
     if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
         const int full = max_q_len / 256, tail = max_q_len - full * 256;
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch
         dim3 grid(split_tail ? full : (max_q_len + 255) / 256, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<8><<<grid, dim3(512), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
+        attn_launch<8>(single, grid, st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
         if (split_tail) {
             RLCF_LAUNCH_CHECK();
-            attention_fwd_x3_kernel<1><<<dim3(1, n_seq, width / HEAD_DIM), dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi,
-                                                                                           (_Float16*)out_lo, il, full * 8, lse);
+            attn_launch<1>(single, dim3(1, n_seq, width / HEAD_DIM), st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il,
+                           full * 8, lse);
         }
     } else if (max_q_len > 32) {
         dim3 grid((max_q_len + 127) / 128, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<4><<<grid, dim3(256), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
+        attn_launch<4>(single, grid, st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
     } else {
         dim3 grid(1, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attention_fwd_x3_kernel<1><<<grid, dim3(64), 0, st>>>(qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
+        attn_launch<1>(single, grid, st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
     }
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

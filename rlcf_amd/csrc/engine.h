@@ -73,7 +73,8 @@ struct ClipModel {
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
     struct SplitW { void *hi, *lo; float inv_scale; };                    // W * 2^s = hi + lo; inv_scale = 2^-s
-    std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 mode)
+    std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 / F16 modes)
+    std::unordered_map<const float*, SplitW> f16_of;                      // f32 weight -> plain f16 copy (.hi; RLCF_PREC_F16 mode only)
 };
 
 // full image-encoder tuning (CLIPCLS_TTA only_norm=False): one entry per non-LayerNorm visual tensor of the flat buffer, and the
@@ -151,6 +152,11 @@ extern int g_last_x3_variant;
 extern GemmProfile g_prof;
 
 static inline bool is_resnet(const rlcf_clip_cfg& c) { return c.vision_stages[0] > 0; }
+// RLCF_PREC_F16 is the split-f16 engine with ONE change: the forward tower pipeline (LayerNorm -> GEMM -> attention -> GEMM ... of
+// transformer_forward, the patch embedding) carries plain f16 operands and spends one MFMA per product — the arithmetic of the
+// reference's fp16-autocast GPU path (tpt_cls_rl.py:52).  Everything else (backward, small GEMMs, losses) stays f32-grade.
+static inline bool prec_x3(const rlcf_engine* e) { return e->precision == RLCF_PREC_F16X3 || e->precision == RLCF_PREC_F16; }
+static inline bool prec_single(const rlcf_engine* e) { return e->precision == RLCF_PREC_F16; }
 // resnet.hip
 int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
 int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);

@@ -69,7 +69,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi;
     e->last_flops += 2.0 * M * N * K;
-    if (e->precision == RLCF_PREC_F16X3 && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
+    if (prec_x3(e) && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
         // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
         const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
@@ -129,12 +129,23 @@ static const ClipModel::SplitW* split_of(rlcf_engine* e, const float* W) {
     for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) return &it->second; }
     return nullptr;
 }
-// A (and the optional split output) are interleaved pairs; lda / ldch are given in logical columns
+// A (and the optional split output) are interleaved pairs; lda / ldch are given in logical columns.
+// RLCF_PREC_F16: A, the weight copy and the optional output are plain f16 matrices instead (one MFMA per product).
 static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, const float* bias, const float* res, int ldr,
                     float* C, int ldc, void* C2, int ldch, int M, int N, int K, int epi, hipStream_t st) {
+    e->last_flops += 2.0 * M * N * K;
+    if (prec_single(e)) {
+        const ClipModel::SplitW* fw = nullptr;
+        for (auto& m : e->model) { auto it = m.f16_of.find(W); if (it != m.f16_of.end()) { fw = &it->second; break; } }
+        if (!fw || K % 64) { rlcf_set_error("gemm_pre: weight has no plain f16 copy (K = %d)", K); return RLCF_ERR_STATE; }
+        const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+        int rc = launch_gemm_f16x3(A2, lo_of(A2), lda, fw->hi, lo_of(fw->hi), K, bias, res, ldr, nullptr, 0, C, ldc, C2, nullptr, ldch, M, N, K,
+                                   fw->inv_scale, epi, st, nullptr, nullptr, 0, e->gemm_ws.as<float>(), e->gemm_ws.bytes, 1);
+        prof_end(slot, st, g_last_x3_variant);
+        return rc;
+    }
     const ClipModel::SplitW* sp = split_of(e, W);
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
-    e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
                                2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, e->gemm_ws.as<float>(), e->gemm_ws.bytes);
@@ -161,7 +172,7 @@ static const float* rawp(ClipModel& m, const std::string& k, size_t numel) {
     return it->second.as<float>();
 }
 static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
-    if (e->precision != RLCF_PREC_F16X3 || !w) return RLCF_OK;
+    if (!prec_x3(e) || !w) return RLCF_OK;
     DevBuf hi;                                             // both parts in one allocation
     TRY(hi.ensure(numel * 4));
     const int il = numel % 32 == 0;                        // K % 32 == 0 (every weight the split-f16 GEMM accepts): interleaved pairs
@@ -181,6 +192,13 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     TRY(launch_split_f16x2(w, hi.p, lo, (int64_t)numel, st, scale, il));
     m.split_of[w] = ClipModel::SplitW{hi.p, lo, 1.0f / scale};
     m.derived.push_back(hi);
+    if (prec_single(e) && numel % 64 == 0) {                 // plain f16 copy for the single-pass forward pipeline (same pre-scale)
+        DevBuf f;
+        TRY(f.ensure(numel * 2 + 64));
+        TRY(launch_split_f16x2(w, f.p, nullptr, (int64_t)numel, st, scale, 0));
+        m.f16_of[w] = ClipModel::SplitW{f.p, nullptr, 1.0f / scale};
+        m.derived.push_back(f);
+    }
     return RLCF_OK;
 }
 int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) { return make_split(e, m, w, numel, st); }
@@ -234,6 +252,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     m.derived.reserve(32 * (c.vision_layers + c.text_layers) + 16);
     m.vis.blk.clear(); m.vis.layers = 0;
     m.split_of.clear();
+    m.f16_of.clear();
     const int Wt = c.text_width, D = c.embed_dim;
     const bool rn = is_resnet(c);
     if (which == RLCF_STUDENT) {          // the flat tunable buffer pointed into the previous weights
@@ -452,7 +471,7 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
     TRY(launch_transpose_pad(X, ldx, xt, T, K, Tp, st));
     e->last_flops += 2.0 * N * K * T;
     int rc;
-    if (e->precision == RLCF_PREC_F16X3 && N >= 256 && (size_t)N * Tp <= e->a_split_elems) {
+    if (prec_x3(e) && N >= 256 && (size_t)N * Tp <= e->a_split_elems) {
         TRY(e->w_hi.ensure((size_t)K * Tp * 4));
         TRY(e->dyn.ensure(3 * sizeof(float)));
         TRY(launch_split_f16x2_dyn(yt, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)N * Tp, e->dyn.as<float>(), st, 1));
@@ -490,7 +509,9 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
          TRY(launch_layernorm_fwd((xp), gw_.p, gb_.p, (yp), (rows), (W), st, gw_.group_rows, gw_.group_stride)); } while (0)
 #define LN_FWD_SPLIT(xp, wp, bp, hh, hl, rows, W)                                                                           \
     do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
-         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), (hl), (rows), (W), st, gw_.group_rows, gw_.group_stride, 1)); } while (0)
+         const bool sg_ = prec_single(e);                 /* RLCF_PREC_F16: plain f16 rows, no lo part */                    \
+         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), sg_ ? nullptr : (hl), (rows), (W), st, gw_.group_rows,     \
+                                        gw_.group_stride, sg_ ? 0 : 1)); } while (0)
 
 // cls_seqs / cls_idx / cls_out (image towers, split-f16 pipeline): only row `cls_idx[s]` of every sequence is consumed after the
 // last block (ln_post(x[:, 0]) @ proj, model.py:235-238), and out_proj, the MLP and the residual adds act row by row — so the LAST
@@ -502,7 +523,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                                const int32_t* cls_idx = nullptr, float* cls_out = nullptr) {
     const int W = w.width, L = w.layers;
     const int ln_view_rows = max_q_len;          // (per-view LayerNorm sets only exist for the image tower: one sequence per view)
-    if (e->precision == RLCF_PREC_F16X3 && !save && T > 512 && W % 32 == 0) {
+    if (prec_x3(e) && !save && T > 512 && W % 32 == 0 && (!prec_single(e) || W % 64 == 0)) {
         // split-f16 pipeline: LN, attention and the QuickGELU epilogue emit (hi, lo) f16 pairs for the next GEMM
         TRY(x3_ensure(ws, T, W));
         float* x = ws.x.as<float>();
@@ -514,9 +535,16 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                 // last block, class-token rows only (see above).  Pair rows are W * 4 bytes like f32 rows: gather_rows moves both.
                 const size_t nw = (size_t)n_seq * W * sizeof(float);
                 TRY(e->cls_a2.ensure(nw)); TRY(e->cls_h2.ensure(nw)); TRY(e->cls_f2.ensure(4 * nw));
-                TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), cls_seqs, n_seq, 1, W, 0, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1));
+                {
+                    const bool sg = prec_single(e);
+                    TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), cls_seqs, n_seq, 1, W, 0, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
+                                                sg ? 0 : 1, nullptr, sg ? 1 : 0));
+                }
                 e->last_flops += 4.0 * (double)n_seq * max_q_len * W;
-                TRY(launch_gather_rows((const float*)ws.a2.p, W, cls_idx, e->cls_a2.as<float>(), W, n_seq, W, st));
+                {
+                    const int rw = prec_single(e) ? W / 2 : W;           // row length of the operand matrix in floats (plain f16: W halves)
+                    TRY(launch_gather_rows((const float*)ws.a2.p, rw, cls_idx, e->cls_a2.as<float>(), rw, n_seq, rw, st));
+                }
                 TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
                 TRY(gemm_pre(e, e->cls_a2.p, W, b.out_w, b.out_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, W, RLCF_EPI_NONE, st));
                 {   // LayerNorm sets per view (batched LN-tuning inference): one row per view here
@@ -529,7 +557,9 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             }
             {
                 const int slot = prof_begin(st, 4.0 * attn_pairs * W, T, W, max_q_len);          // kind 10: fused attention forward
-                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p, lo_of(ws.a2.p), st, 1);
+                const bool sg = prec_single(e);
+                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p,
+                                                        sg ? nullptr : lo_of(ws.a2.p), st, sg ? 0 : 1, nullptr, sg ? 1 : 0);
                 prof_end(slot, st, 10);
                 TRY(arc);
             }
@@ -553,7 +583,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         float* f = ws.f.as<float>();
         LN_FWD(xin, b.ln1_w, b.ln1_b, h, T, W);
         TRY(gemm(e, h, W, b.in_w, W, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, 1.f, RLCF_EPI_NONE, st));
-        if (e->precision == RLCF_PREC_F16X3)      // (f32 output + log-sum-exp for the backward; the split-f16 kernel is ~3x the f32-MFMA one)
+        if (prec_x3(e))      // (f32 output + log-sum-exp for the backward; the split-f16 kernel is ~3x the f32-MFMA one)
             TRY(launch_attention_fwd_x3(qkv, seqs, n_seq, max_q_len, W, causal, a, nullptr, nullptr, st, 0, save ? ws.sv[l].lse : nullptr));
         else
             TRY(launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, W, causal, a, save ? ws.sv[l].lse : nullptr, st));
@@ -638,8 +668,9 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     }
     if (is_resnet(c)) return resnet_encode(e, m, images, n, feats, st);
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
-    if (e->precision == RLCF_PREC_F16X3 && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
-        TRY(launch_im2col(images, nullptr, e->a_hi.p, lo_of(e->a_hi.p), n, c.image_resolution, c.vision_patch_size, m.Kp, st, 1));
+    if (prec_x3(e) && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
+        const bool sg = prec_single(e) && m.Kp % 64 == 0 && m.f16_of.count(m.conv_w);
+        TRY(launch_im2col(images, nullptr, e->a_hi.p, sg ? nullptr : lo_of(e->a_hi.p), n, c.image_resolution, c.vision_patch_size, m.Kp, st, sg ? 0 : 1));
         TRY(gemm_pre(e, e->a_hi.p, m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, 0, n * G2, Wv,
                      m.Kp, RLCF_EPI_NONE, st));
     } else {
@@ -818,7 +849,7 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
         Tmax = std::max(Tmax, e->lay[1 + m].T); Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim);
     }
     TRY(tower_ensure(e->tt, Tmax, Wmax));
-    if (e->precision == RLCF_PREC_F16X3 && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
+    if (prec_x3(e) && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
         e->a_split_elems = (size_t)Tmax * Wmax * 4;
         TRY(e->a_hi.ensure(e->a_split_elems * 4));
     }
@@ -1089,7 +1120,7 @@ static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
     TRY(e->b_eot_x.ensure((size_t)B * C * Wt * sizeof(float))); TRY(e->b_eot_ln.ensure((size_t)B * C * Wt * sizeof(float)));
     TRY(e->b_inv.ensure((size_t)B * C * sizeof(float))); TRY(e->b_logits.ensure((size_t)B * C * sizeof(float)));
     TRY(tower_ensure(e->tt, B * L.T, Wt));
-    if (e->precision == RLCF_PREC_F16X3 && (size_t)B * L.T * Wt * 4 > e->a_split_elems) {
+    if (prec_x3(e) && (size_t)B * L.T * Wt * 4 > e->a_split_elems) {
         e->a_split_elems = (size_t)B * L.T * Wt * 4;
         TRY(e->a_hi.ensure(e->a_split_elems * 4));
     }

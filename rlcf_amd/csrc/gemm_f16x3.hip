@@ -36,9 +36,105 @@ struct GemmX3Args {
     float* ws;                         // to ws[ksplit][M][N] and gemm_x3_splitk_reduce_kernel applies alpha / bias / epilogue
     int no_fast_epi;                   // RLCF_X3_NOFASTEPI=1: 256x256 kernel keeps the generic per-row epilogue (A/B measurements)
 };
+// SINGLE (template flag of the kernels): plain f16 operands, ONE MFMA per product (RLCF_PREC_F16 — the arithmetic of the reference's
+// own fp16-autocast GPU path, tpt_cls_rl.py:52; NOT f32-grade).  A plain f16 row of K halves has exactly the memory layout of an
+// interleaved pair row of K/2 logical columns (every 128-B block = 32 "hi" + 32 "lo" halves), so the kernels run unchanged with
+// g.K = K/2 and the MFMA triple (hi*hi, hi*lo, lo*hi) replaced by the two products of the block's own halves: "hi" x "hi" (K columns
+// 0..31 of the block) and "lo" x "lo" (columns 32..63).  Split output (Chi) is then a plain f16 matrix; Clo may be null.
 
 __device__ __forceinline__ int x3_ocol(const GemmX3Args& g, int col) { return g.c_il ? (((col >> 5) << 6) | (col & 31)) : col; }
 __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha; }
+
+// Epilogue of the DMA-ring kernels for the shapes of the forward towers, specialised at compile time (no per-row branches on the
+// epilogue kind) and written so that NOTHING waits inside the row loop: on gfx9 stores count in vmcnt like loads, so a residual load
+// issued after a store cannot be awaited without draining that store — the generic loops (load, wait, store, per row) pay one
+// HBM round trip per row, ~12 us per 256x256 tile.  Here the 16 residual rows of a 64-row slab are fetched BEFORE the accumulators
+// are parked and combined in registers (no store yet); then the 16 rows stream out back to back.  Each wave parks and re-reads only
+// its own LDS slice, so one barrier (the ring is no longer read) is all the synchronisation there is.
+// One call = the 64x64 slab of one wave: a0..a3 = accumulator tiles (i, j) = (0,0) (0,1) (1,0) (1,1); row0 / col0 = its origin.
+template <int EPI, bool RES, bool F32OUT, bool PAIR>
+__device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3,
+                                                 float* park, int row0, int col0, int lane) {
+    constexpr int ELD = 68;
+    const int l32 = lane & 31, h = lane >> 5;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int col = col0 + c4;
+    const bool colok = col < g.N;
+    const int colc = colok ? col : 0;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *(const float4*)(g.bias + colc);
+    const float al = g.alpha;
+    const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
+    const int rbase = row0 + rsub;
+    float4 rr[16];
+    if constexpr (RES) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) rr[it] = *(const float4*)(g.residual + (size_t)min(rbase + it * 4, g.M - 1) * g.ldr + colc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int pr = mfma32_row(r, h) * ELD + l32;
+        park[pr] = a0[r]; park[pr + 32] = a1[r]; park[pr + 32 * ELD] = a2[r]; park[pr + 32 * ELD + 32] = a3[r];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const float4 a4 = *(const float4*)(park + (it * 4 + rsub) * ELD + c4);
+        float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+        if constexpr (EPI == RLCF_EPI_QUICKGELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+        }
+        if constexpr (RES) {
+            rr[it].x += v[0]; rr[it].y += v[1]; rr[it].z += v[2]; rr[it].w += v[3];
+            asm volatile("" : "+v"(rr[it].x), "+v"(rr[it].y), "+v"(rr[it].z), "+v"(rr[it].w));     // materialise here: the sums must not sink
+        } else {                                                                                     // into the store loop (IR sinking re-fuses the phases)
+            const int row = rbase + it * 4;
+            if (colok && row < g.M) {
+                if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (PAIR) {
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + ocol) = hh;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + ocol) = ll;
+                }
+            }
+        }
+    }
+    if constexpr (RES) {
+        asm volatile("" ::: "memory");                     // no store moves above this point, no load below it
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = rbase + it * 4;
+            if (colok && row < g.M) {
+                if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = rr[it];
+                if constexpr (PAIR) {
+                    const float v[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    h16x4 hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    *(h16x4*)(g.Chi + (size_t)row * g.ldch + ocol) = hh;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + ocol) = ll;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+// which specialisation (wave-uniform): 0 = none (generic epilogue), 1 = f32 out, 2 = f32 out + residual, 3 = QuickGELU -> operand pair
+__device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
+    if (g.amax_out || g.alpha_dev || g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
+    const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
+    if (g.epilogue == RLCF_EPI_NONE && f32o && !pair) return res ? 2 : 1;
+    if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
+    return 0;
+}
+#define X3_EPILOGUE_SLAB(kind, ...)                                                                                      \
+    {                                                                                                                    \
+        if ((kind) == 1) x3_epilogue_slab<RLCF_EPI_NONE, false, true, false>(__VA_ARGS__);       /* in_proj (QKV), conv1 */      \
+        else if ((kind) == 2) x3_epilogue_slab<RLCF_EPI_NONE, true, true, false>(__VA_ARGS__);   /* out_proj / c_proj + residual */ \
+        else x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true>(__VA_ARGS__);              /* c_fc + QuickGELU -> pair */     \
+    }
 
 #define X3_BM 128
 #define X3_BN 128
@@ -46,6 +142,7 @@ __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_
 #define X3_LD 40                        // halves per LDS row (32 + 8 pad = 80 B)
 #define X3_TILE (X3_BM * X3_LD)         // halves per operand tile
 
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // [2][4][128][40]
@@ -118,8 +215,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if constexpr (SINGLE) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bl[j], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         if (kt + 1 < nk) X3_LSTORE(cur ^ 1)
@@ -172,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -200,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.Chi) {
                     const _Float16 hi = (_Float16)v;
                     g.Chi[(size_t)row * g.ldch + x3_ocol(g, col)] = hi;
-                    g.Clo[(size_t)row * g.ldch + x3_ocol(g, col)] = (_Float16)(v - (float)hi);
+                    if (g.Clo) g.Clo[(size_t)row * g.ldch + x3_ocol(g, col)] = (_Float16)(v - (float)hi);
                 }
             }
         }
@@ -224,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NWM>                      // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
+template <int NWM, bool SINGLE>         // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
     constexpr int BM = 64 * NWM, A_BYTES = BM * 64, W_BYTES = V2_BN * 64;
     constexpr int STAGE = 2 * A_BYTES + 2 * W_BYTES, ALO = A_BYTES, WHI = 2 * A_BYTES, WLO = WHI + W_BYTES;
@@ -294,8 +395,12 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     }
 #define V2_MMA3(i, j, AH, AL, BH, BL)                                                                                    \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);                                \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);                                \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);
+    if constexpr (SINGLE) {                                                                                              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BL[j], acc[i][j], 0, 0, 0);                            \
+    } else {                                                                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);                            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);                            \
+    }
 #define V2_FENCE __builtin_amdgcn_sched_barrier(0);
 
     // split-K (a few tiles, long K loop): this block walks K tiles [kt0, kt0 + nk) and leaves its raw partial tile in g.ws
@@ -352,6 +457,10 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     // epilogue through LDS: each wave parks its 64x64 f32 tile in its own 17 KB slice of the (now idle) stage ring and
     // re-reads it row-wise, so bias / residual / stores are 16-byte accesses covering whole 256-B row segments
     __syncthreads();
+    if (const int ek = x3_epilogue_kind(g)) {
+        X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (float*)smem + wave * (64 * 68), m0 + wm * 64, n0 + wn * 64, lane)
+        return;
+    }
     {
         constexpr int ELD = 68;                                            // floats per parked row (64 + 4 pad)
         float* park = (float*)smem + wave * (64 * ELD);
@@ -407,7 +516,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -427,6 +536,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
 #define V3_WHI 32768
 #define V3_WLO 49152
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) {
+    constexpr bool SINGLE = false;      // (separate hi / lo arrays: the plain C-ABI call, split-f16 only)
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
     const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
@@ -611,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -619,96 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     amax_commit(g.amax_out, am);
 }
 
-// Epilogue of the 256x256 kernels for the shapes of the forward towers, specialised at compile time (no per-row branches on the
-// epilogue kind) and written so that NOTHING waits inside the row loop: on gfx9 stores count in vmcnt like loads, so a residual load
-// issued after a store cannot be awaited without draining that store — the generic loop below (load, wait, store, per row) pays one
-// HBM round trip per row, ~12 us per tile.  Here the 16 residual rows of a half are fetched BEFORE the accumulators are parked, then
-// the rows stream out as ds_read -> math -> store with no VMEM wait in between; each wave parks and re-reads only its own LDS
-// slice, so one barrier (the ring is no longer read) is all the synchronisation there is.
-template <int EPI, bool RES, bool F32OUT, bool PAIR>
-__device__ __forceinline__ void v3_epilogue_fast(const GemmX3Args& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
-    constexpr int ELD = 68;
-    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
-    float* park = (float*)smem + wave * (64 * ELD);
-    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-    const int col = n0 + wn * 64 + c4;
-    const bool colok = col < g.N;
-    const int colc = colok ? col : 0;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) bv = *(const float4*)(g.bias + colc);
-    const float al = g.alpha;
-    const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
-    const int rbase = m0 + wm * 128 + rsub;
-    __syncthreads();
-#define V3E_PARK(half)                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                        \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[(half) * 2 + i][j][r];
-#define V3E_VALUE(it, OUT)                                                                                               \
-    {                                                                                                                    \
-        const float4 a4 = *(const float4*)(park + ((it) * 4 + rsub) * ELD + c4);                                         \
-        float v_[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};                          \
-        if constexpr (EPI == RLCF_EPI_QUICKGELU) { _Pragma("unroll") for (int q = 0; q < 4; ++q) v_[q] = quick_gelu(v_[q]); } \
-        OUT = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                                   \
-    }
-#define V3E_STORE(row, V)                                                                                                \
-    if (colok && (row) < g.M) {                                                                                          \
-        if constexpr (F32OUT) *(float4*)(g.C + (size_t)(row) * g.ldc + col) = (V);                                       \
-        if constexpr (PAIR) {                                                                                            \
-            const float v_[4] = {(V).x, (V).y, (V).z, (V).w};                                                            \
-            h16x4 hh, ll;                                                                                                \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v_[q]; ll[q] = (_Float16)(v_[q] - (float)hh[q]); } \
-            *(h16x4*)(g.Chi + (size_t)(row) * g.ldch + ocol) = hh;                                                       \
-            *(h16x4*)(g.Clo + (size_t)(row) * g.ldch + ocol) = ll;                                                       \
-        }                                                                                                                \
-    }
-    if constexpr (RES) {
-        // two phases per half so that no load is awaited behind a store of the same half: the 16 residual rows are fetched before the
-        // accumulators are parked and combined in registers; only then do the rows stream out (half 1's fetch drains half 0's stores once)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 rr[16];
-#pragma unroll
-            for (int it = 0; it < 16; ++it) rr[it] = *(const float4*)(g.residual + (size_t)min(rbase + half * 64 + it * 4, g.M - 1) * g.ldr + colc);
-            V3E_PARK(half)
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                float4 t; V3E_VALUE(it, t) rr[it].x += t.x; rr[it].y += t.y; rr[it].z += t.z; rr[it].w += t.w;
-                asm volatile("" : "+v"(rr[it].x), "+v"(rr[it].y), "+v"(rr[it].z), "+v"(rr[it].w));     // materialise here: the sums must not sink
-            }                                                                                            // into the store loop (IR sinking re-fuses the phases)
-            asm volatile("" ::: "memory");                     // no store moves above this point, no load below it
-#pragma unroll
-            for (int it = 0; it < 16; ++it) { V3E_STORE(rbase + half * 64 + it * 4, rr[it]) }
-            asm volatile("" ::: "memory");
-        }
-    } else {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            V3E_PARK(half)
-#pragma unroll
-            for (int it = 0; it < 16; ++it) { float4 t; V3E_VALUE(it, t) V3E_STORE(rbase + half * 64 + it * 4, t) }
-        }
-    }
-#undef V3E_PARK
-#undef V3E_VALUE
-#undef V3E_STORE
-}
-// wave-uniform dispatch to the specialisations above; false: the caller runs the generic epilogue
-__device__ __forceinline__ bool v3_epilogue_dispatch(const GemmX3Args& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
-    if (g.amax_out || g.alpha_dev || g.aux || g.no_fast_epi) return false;
-    const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
-    if (g.epilogue == RLCF_EPI_NONE && f32o && !pair) {
-        if (res) v3_epilogue_fast<RLCF_EPI_NONE, true, true, false>(g, acc, smem, m0, n0, wave, lane);        // out_proj / c_proj + residual
-        else v3_epilogue_fast<RLCF_EPI_NONE, false, true, false>(g, acc, smem, m0, n0, wave, lane);           // in_proj (QKV), conv1
-        return true;
-    }
-    if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) {                                            // c_fc + QuickGELU -> operand pair
-        v3_epilogue_fast<RLCF_EPI_QUICKGELU, false, false, true>(g, acc, smem, m0, n0, wave, lane);
-        return true;
-    }
-    return false;
-}
-
+template <bool SINGLE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
@@ -852,7 +873,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
             for (int j = 0; j < 2; ++j) { V2_MMA3(i, j, ah1, al1, bh1, bl1) V2_FENCE }
     }
-    if (v3_epilogue_dispatch(g, acc, smem, m0, n0, wave, lane)) return;
+    if (const int ek = x3_epilogue_kind(g)) {
+        float* parkf = (float*)smem + wave * (64 * 68);
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
+                             m0 + wm * 128 + half * 64, n0 + wn * 64, lane)
+        return;
+    }
     // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
     constexpr int ELD = 68;
     float* park = (float*)smem + wave * (64 * ELD);
@@ -900,7 +929,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
-                    *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+                    if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
@@ -947,7 +976,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
 #pragma unroll
             for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
             *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
-            *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
+            if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
         }
     }
     amax_commit(g.amax_out, am);
@@ -959,9 +988,13 @@ int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 2
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
-                      float* splitk_ws, size_t splitk_ws_bytes) {
+                      float* splitk_ws, size_t splitk_ws_bytes, int single) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
-    RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && Clo)));
+    RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && (Clo || single))));
+    if (single) {       // plain f16 operands: a row of K halves == an interleaved pair row of K/2 logical columns (see GemmX3Args)
+        RLCF_ARG_CHECK(K % 64 == 0 && Alo == (const void*)((const _Float16*)Ahi + 32) && Wlo == (const void*)((const _Float16*)Whi + 32));
+        K /= 2;
+    }
     GemmX3Args g{};
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
@@ -986,9 +1019,12 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const bool pick3 = blocks2 >= 256 && cost3 <= cost2;
     if (v2_ok && (force == 3 || (force == 0 && pick3))) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
-        if (g.kstep == 64) {
-            X3_LDS(gemm_nt_f16x3_v3i_kernel, sh3);
-            gemm_nt_f16x3_v3i_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        if (g.kstep == 64 && single) {
+            X3_LDS(gemm_nt_f16x3_v3i_kernel<true>, sh3);
+            gemm_nt_f16x3_v3i_kernel<true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        } else if (g.kstep == 64) {
+            X3_LDS(gemm_nt_f16x3_v3i_kernel<false>, sh3);
+            gemm_nt_f16x3_v3i_kernel<false><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
         } else {
             X3_LDS(gemm_nt_f16x3_v3_kernel, sh3);
             gemm_nt_f16x3_v3_kernel<<<dim3(blocks3), dim3(512), sh3, st>>>(g);
@@ -999,8 +1035,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     }
     if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;
-        X3_LDS(gemm_nt_f16x3_v2_kernel<4>, sh2);
-        gemm_nt_f16x3_v2_kernel<4><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        if (single) {
+            X3_LDS((gemm_nt_f16x3_v2_kernel<4, true>), sh2);
+            gemm_nt_f16x3_v2_kernel<4, true><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        } else {
+            X3_LDS((gemm_nt_f16x3_v2_kernel<4, false>), sh2);
+            gemm_nt_f16x3_v2_kernel<4, false><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+        }
         g_last_x3_variant = 2;
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
@@ -1011,7 +1052,8 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int blocks2s = ((M + 127) / 128) * ((N + V2_BN - 1) / V2_BN);
         const size_t sh2s = (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) > (size_t)4 * 64 * 68 * sizeof(float)
                                 ? (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) : (size_t)4 * 64 * 68 * sizeof(float);
-        X3_LDS(gemm_nt_f16x3_v2_kernel<2>, sh2s);
+        if (single) X3_LDS((gemm_nt_f16x3_v2_kernel<2, true>), sh2s);
+        else X3_LDS((gemm_nt_f16x3_v2_kernel<2, false>), sh2s);
         // few tiles and a long K loop (one image's token matrix against a W x 4W / W x 3W weight): split the K loop over blockIdx.y
         // and finish in a reduce + epilogue pass (RLCF_X3_NOSPLITK=1 switches it off)
         static int nosplit = -1;
@@ -1021,7 +1063,8 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
         if (ksplit > 1 && (!splitk_ws || (size_t)ksplit * M * N * sizeof(float) > splitk_ws_bytes)) ksplit = 1;
         g.ksplit = ksplit; g.ws = splitk_ws;
-        gemm_nt_f16x3_v2_kernel<2><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
+        if (single) gemm_nt_f16x3_v2_kernel<2, true><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
+        else gemm_nt_f16x3_v2_kernel<2, false><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
         if (ksplit > 1) {
@@ -1032,8 +1075,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         return RLCF_OK;
     }
     const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN);
-    X3_LDS(gemm_nt_f16x3_kernel, sh);
-    gemm_nt_f16x3_kernel<<<dim3(blocks), dim3(256), sh, st>>>(g);
+    if (single) {
+        X3_LDS(gemm_nt_f16x3_kernel<true>, sh);
+        gemm_nt_f16x3_kernel<true><<<dim3(blocks), dim3(256), sh, st>>>(g);
+    } else {
+        X3_LDS(gemm_nt_f16x3_kernel<false>, sh);
+        gemm_nt_f16x3_kernel<false><<<dim3(blocks), dim3(256), sh, st>>>(g);
+    }
     g_last_x3_variant = 1;
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -1054,7 +1102,7 @@ __global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __rest
             vl[e] = (_Float16)(v[e] - (float)hh);
         }
         ((h16x8*)hi)[split_dst(i, il)] = vh;
-        ((h16x8*)lo)[split_dst(i, il)] = vl;
+        if (lo) ((h16x8*)lo)[split_dst(i, il)] = vl;      // (lo null: plain f16 copy, RLCF_PREC_F16)
     }
 }
 // data-dependent pre-scale for operands without a known range (ResNet activations): s = 2^k lifting max|x| into [2^9, 2^10);
@@ -1081,7 +1129,7 @@ __global__ void split_f16x2_dyn_kernel(const float* __restrict__ x, _Float16* __
             vl[e] = (_Float16)(v[e] - (float)hh);
         }
         ((h16x8*)hi)[split_dst(i, il)] = vh;
-        ((h16x8*)lo)[split_dst(i, il)] = vl;
+        if (lo) ((h16x8*)lo)[split_dst(i, il)] = vl;      // (lo null: plain f16 copy, RLCF_PREC_F16)
     }
 }
 // scratch: 3 floats on the device {max|x|, s, 1/s}

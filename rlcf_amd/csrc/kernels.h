@@ -60,7 +60,8 @@ int launch_dtxt_sparse(const float* dlogits, const int32_t* cls, const float* im
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr,
-                      unsigned int* amax_out = nullptr, int c_il = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+                      unsigned int* amax_out = nullptr, int c_il = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
+                      int single = 0 /* plain f16 operands, one MFMA per product (RLCF_PREC_F16): see GemmX3Args */);
 #define X3_SPLITK_WS_BYTES ((size_t)4 * 128 * 128 * 128 * sizeof(float))   // 4 slices x (<= 128 tiles of 128x128): the largest split-K launch
 int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
@@ -96,7 +97,7 @@ int launch_final_logits_batched(const float* img, int img_row_stride, const floa
 int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st);
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr);
+                            void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr, int single = 0 /* plain f16, one MFMA per product */);
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,

@@ -251,7 +251,7 @@ static int rn_ensure(rlcf_engine* e, const ResNetW& r, int chunk, int T) {
     TRY(e->rn_kv.ensure((size_t)chunk * T * 2 * r.E * sizeof(float)));
     TRY(e->rn_q.ensure((size_t)chunk * r.E * sizeof(float)));
     TRY(e->rn_att.ensure((size_t)chunk * r.E * sizeof(float)));
-    if (e->precision == RLCF_PREC_F16X3) {
+    if (prec_x3(e)) {
         const size_t need = std::max((size_t)chunk * r.col_per_img, (size_t)chunk * r.act_per_img);
         if (need > e->a_split_elems) {
             TRY(e->a_hi.ensure(need * 4));
@@ -271,7 +271,7 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
     const int Ho = H / stride, Wo = W / stride;
     const long M = (long)n * Ho * Wo;
     const float* A = in;
-    if (cw.k == 3 && !nchw && e->precision == RLCF_PREC_F16X3 && cw.cin % 8 == 0 && M > 512 && (size_t)M * cw.Kp <= e->a_split_elems &&
+    if (cw.k == 3 && !nchw && prec_x3(e) && cw.cin % 8 == 0 && M > 512 && (size_t)M * cw.Kp <= e->a_split_elems &&
         engine_has_split(e, cw.w)) {
         // split-f16 mode: the patch matrix is written once, already as the (hi, lo) operand pair; its power-of-two scale comes
         // from max|activation| (the patch matrix holds the same values), found on the 9x smaller activation

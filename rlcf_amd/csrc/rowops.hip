@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)(ov[q] - (float)hh[q]); }
                     *(h16x4*)(yh + pair_off(row, c, width, il)) = hh;
-                    *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;
+                    if (yl) *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;       // (yl null: plain f16 output, RLCF_PREC_F16)
                 }
             }
     } else {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 if (yh) {
                     const _Float16 hh = (_Float16)o;
                     yh[pair_off(row, c, width, il)] = hh;
-                    yl[pair_off(row, c, width, il)] = (_Float16)(o - (float)hh);
+                    if (yl) yl[pair_off(row, c, width, il)] = (_Float16)(o - (float)hh);
                 }
             }
         }
@@ -297,7 +297,7 @@ __global__ void im2col_kernel(const float* __restrict__ img, float* __restrict__
 #pragma unroll
             for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)o[q]; ll[q] = (_Float16)(o[q] - (float)hh[q]); }
             *(h16x4*)(oh + pair_off((int)p, k4, Kp, il)) = hh;
-            *(h16x4*)(ol + pair_off((int)p, k4, Kp, il)) = ll;
+            if (ol) *(h16x4*)(ol + pair_off((int)p, k4, Kp, il)) = ll;
         }
     }
 }

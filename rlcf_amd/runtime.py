@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from .engine import Engine
 
-PRECISIONS = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
+PRECISIONS = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3, "f16": L.PREC_F16}
 TEXT_MODES = {"dense": L.TEXT_DENSE, "packed": L.TEXT_PACKED, "shared": L.TEXT_SHARED}
 
 

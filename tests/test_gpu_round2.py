@@ -301,3 +301,42 @@ def test_bench_strong_scaling_line_two_ranks(L, dev):
     rec = json.loads(line)
     assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["value"] > 0
     assert rec["config"]["timed_images_per_rank"] == 3 and rec["roofline"]["check_gemm_time_within_step"] in (True, False)
+
+
+# ------------------------------------------------------------------------------ RLCF_PREC_F16: the reference's own GPU arithmetic (performance mode)
+def test_f16_single_pass_mode_small(L, dev):
+    """RLCF_PREC_F16 switches the forward tower pipeline to plain f16 operands, one MFMA per product (fp16 autocast of the reference,
+    tpt_cls_rl.py:52).  Not parity-grade: image features deviate at the f16 level (and must deviate: the mode has to be active), the
+    predictions of the fused step agree with the split-f16 engine."""
+    from rlcf_amd.engine import TTAConfig
+    N, n_cls = 64, 40                                                   # 64 views x 17 tokens = 1088 rows: the pipelined path
+    ex, *_ = make_engine(("small", "small"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16X3)
+    eh, *_ = make_engine(("small", "small"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16)
+    views = synth.make_views(2000, N, 64).to(dev)
+    fx, fh = ex.encode_image(L.STUDENT, views), eh.encode_image(L.STUDENT, views)
+    d = (fx - fh).abs().max().item()
+    assert 1e-6 < d < 5e-3, d
+    cfg = TTAConfig(selection_p=0.25)
+    ox, oh = ex.tta_sample(views, cfg), eh.tta_sample(views, cfg)
+    dl = (ox["final_logits"] - oh["final_logits"]).abs().max().item()
+    print(f"[f16 small] max|dfeat| = {d:.2e}, max|dlogit| = {dl:.2e}")
+    assert dl < 0.25 and ox["top5"][0].item() == oh["top5"][0].item()
+    ex.close(); eh.close()
+
+
+def test_f16_single_pass_mode_b16_stream(L, dev):
+    """The same on BASELINE configs[1] against the REFERENCE stream: top-1 of every sample unchanged, max |dlogit| reported (SURVEY
+    section 0 fact 9 measured 0.0185 for fp16 autocast on the reference ViT-B/16; the bound asserted here is 0.1)."""
+    g, meta = load_golden("tta_b16_n64_stream")
+    n = meta["n_samples"]
+    eng, *_ = make_engine((meta["student"], meta["reward"]), meta["n_views"] * n, meta["n_cls"], L.TEXT_SHARED, meta["student_seed"],
+                          meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=L.PREC_F16)
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    views = torch.stack([synth.make_views(meta["view_seed0"] + i, meta["n_views"], R, device=dev) for i in range(n)])
+    top5, fl = eng.tta_batch(views, _cfg_from_meta(meta, sparse=True), want_logits=True)
+    top5, fl = top5.cpu(), fl.cpu()
+    worst = max((fl[i] - g[f"final_logits_{i}"][0]).abs().max().item() for i in range(n))
+    agree = sum(int(top5[i, 0]) == int(g[f"top5_{i}"][0]) for i in range(n))
+    print(f"[f16 b16 stream] top-1 agreement {agree}/{n}, max|dlogit| vs the reference = {worst:.3e}")
+    assert agree == n and worst < 0.1
+    eng.close()
