@@ -115,7 +115,8 @@ int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* ent
 
 /* Flags of rlcf_reward_loss (TPT/params.py:55-59,65-66). */
 #define RLCF_MAX_REWARDS 4
-enum { RLCF_F_REWARD_PROCESS = 1, RLCF_F_AMPLIFY = 2, RLCF_F_PROCESS_BATCH = 4, RLCF_F_MIN_ENTROPY = 8 };
+enum { RLCF_F_REWARD_PROCESS = 1, RLCF_F_AMPLIFY = 2, RLCF_F_PROCESS_BATCH = 4, RLCF_F_MIN_ENTROPY = 8,
+       RLCF_F_NO_SELECTION = 16 /* image-encoder tuning calls: rows taken in order, no confidence selection (set by rlcf_tta_retrieval_image) */ };
 /* The loss section of test_time_tuning (TPT/tpt_cls_rl.py:63-74) with
  * CLIPRewards.CLIPScore / rewards_post_process (TPT/clip_reward.py:111-128,152-165):
  * rows = logits[sel[i]] (sel NULL: rows = logits[i]); top-K classes per row; CLIPScore
@@ -285,6 +286,18 @@ int rlcf_engine_reset_visual_state(rlcf_engine*, rlcf_stream stream);
  * starting at a multiple of 64 floats (rlcf_engine_visual_param_layout).  VisionTransformer students only. */
 int rlcf_tta_sample_visual(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
                            rlcf_stream stream);
+/* Image -> text retrieval with test-time adaptation of the image encoder: `tune_image` of retrieval/clip_ret_policy.py:76-103 followed
+ * by the evaluation step of its loop (:171-176, 178-181: logits of the tuned model, reset).  The caption bank is a class bank without
+ * learnable rows (rlcf_engine_set_class_bank with n_ctx = 0: the student's caption features = CLIPRet_TTA.set_text_features, the
+ * reward model's = CLIPRewards.set_many_text_features); per call: reward features of the n query images (set_image_features), then
+ * tta_steps of  logits_per_image -> top-K captions -> CLIPScore(text_index) -> baseline -> mean(r * CE) -> backward through the
+ * image encoder -> AdamW over clip_model.visual.parameters(), and out->final_logits = logits_per_image[0] of the tuned encoder.
+ * It is rlcf_tta_sample_visual with every image selected (the classification path picks int(N * selection_p) views): same kernels,
+ * same outputs (out->topk_idx [n,K], clip_score, rewards, loss, ln_* / vis_* vectors).  K = sample_k <= 32 (scripts: 20).
+ * The text -> image direction (tune_text, :106-137) tunes the TEXT encoder, which is not built; its loss arithmetic (CLIPScore with
+ * images_index, baseline, CE over the image bank) is rlcf_reward_loss with the roles of the two banks exchanged. */
+int rlcf_tta_retrieval_image(rlcf_engine*, const float* images, int n, const rlcf_tta_args* args, const rlcf_tta_out* out,
+                             rlcf_stream stream);
 /* floats in the flat vector (padding included); 0 + error for a ModifiedResNet student */
 int64_t rlcf_engine_visual_param_count(rlcf_engine*, rlcf_stream stream);
 /* offsets / element counts of its 4 + 8*layers tensors in the order above; returns the number of tensors (or a negative error) */

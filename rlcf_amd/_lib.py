@@ -96,6 +96,7 @@ SIGNATURES = {
     "rlcf_tta_sample": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_batch": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_tta_sample_ln": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_tta_retrieval_image": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_sample_visual": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_engine_visual_param_count": (I64, [P, P]),
     "rlcf_engine_visual_param_layout": (I, [P, P, P, I, P]),

@@ -1,0 +1,168 @@
+"""Host-side mirror of the RLCF retrieval policy, image -> text direction: `tune_image` (retrieval/clip_ret_policy.py:76-103),
+`CLIPRet_TTA` with only_visual=True (retrieval/custom_models.py:29-163) and the retrieval `CLIPRewards` surface
+(retrieval/clip_reward.py:107-222: text_features / image_features, CLIPScore(text_index=..., images_index=..., pairwise=...)).
+Same signatures; the arithmetic is one call into the HIP engine (rlcf_tta_retrieval_image), whose caption bank is a class bank
+without learnable rows (rlcf_engine_set_class_bank, n_ctx = 0).
+
+The text -> image direction (`tune_text`, :106-137) tunes the TEXT encoder, which the engine does not build: `CLIPRet_TTA(only_visual=
+False)` raises; its loss arithmetic is available as `text2image_loss` (rlcf_reward_loss with the two banks exchanged)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import clip_reward as _cr
+from . import clip_store, runtime
+from .engine import TTAConfig
+
+
+class CLIPRet_TTA(nn.Module):
+    """retrieval/custom_models.py:29-163.  `parameters()` = [LayerNorm vector, flat vector of every other visual tensor]
+    (Engine.visual_layout()), as rlcf_amd.custom_clip.CLIPCLS_TTA(only_norm=False)."""
+
+    def __init__(self, device, arch="ViT-B-16", only_visual=True, momentum_update=False, update_freq=256, update_w=1.0, momentum=0.9999):
+        super().__init__()
+        if not only_visual:
+            raise NotImplementedError("text -> image retrieval tunes the text encoder (custom_models.py:148-153): not built")
+        self.clip_model, _, _ = clip_store.load(arch, device=device)
+        runtime.SESSION.set_student(self.clip_model)
+        self.device, self.only_visual, self.momentum_update = device, only_visual, momentum_update
+        self.update_freq, self.update_w, self.momentum, self.update_counter = update_freq, update_w, momentum, 0
+        self.text_features = None
+        self.image_features = None
+        self._ln = self._vis = None
+        self._tuned = None           # (ln, vis) of the last tune_image call, until reset_initial()
+
+    # the caption bank: tokens go to the engine once (model.set_text_features + reward_model.set_many_text_features, :150-156)
+    def set_text_bank(self, texts: Optional[List[str]] = None, tokenized_prompts: Optional[torch.Tensor] = None):
+        tok = clip_store.tokenize(texts) if tokenized_prompts is None else tokenized_prompts
+        self.tokenized_prompts = tok
+        runtime.SESSION.set_bank(tok, 0, torch.zeros(0))
+        self.text_features = runtime.SESSION.engine().text_features(None)
+        return self.text_features
+
+    def set_text_features(self, text=None, tokenized_prompts=None, text_features=None):
+        if text is not None or tokenized_prompts is not None:
+            self.set_text_bank(text, tokenized_prompts)
+        else:
+            self.text_features = text_features
+
+    def get_image_features(self, images):
+        return runtime.SESSION.engine(images.shape[0]).encode_image(L.STUDENT, images)
+
+    @property
+    def ln(self):
+        if self._ln is None:
+            self._ln_init = runtime.SESSION.engine().ln_params(pristine=True)
+            self._ln = nn.Parameter(self._ln_init.clone())
+        return self._ln
+
+    @property
+    def vis(self):
+        if self._vis is None:
+            self._vis_init = runtime.SESSION.engine().visual_params(1)
+            self._vis = nn.Parameter(self._vis_init.clone())
+        return self._vis
+
+    def parameters(self, recurse: bool = True):
+        return [self.ln, self.vis]
+
+    @torch.no_grad()
+    def reset_initial(self):                                # custom_models.py:124-126
+        self.ln.data.copy_(self._ln_init)
+        self.vis.data.copy_(self._vis_init)
+
+    @torch.no_grad()
+    def momentum_update_model(self):                        # custom_models.py:128-143
+        if not self.momentum_update:
+            return
+        self.update_counter += 1
+        apply = self.update_counter >= self.update_freq
+        if apply:
+            self.update_counter = 0
+        eng = runtime.SESSION.engine()
+        eng.momentum_update(self.ln.data, self.momentum, self.update_w, apply)
+        eng.momentum_update_visual(self.vis.data, self.momentum, self.update_w, apply)
+        if apply:
+            self._ln_init, self._vis_init = eng.ln_params(pristine=True), eng.visual_params(1)
+
+    @torch.no_grad()
+    def forward(self, images=None, text=None, tokenized_prompts=None):
+        """(logits_per_image, logits_per_text) with the current (possibly tuned) image encoder, custom_models.py:66-75."""
+        if text is not None or tokenized_prompts is not None:
+            self.set_text_bank(text, tokenized_prompts)
+        eng = runtime.SESSION.engine(images.shape[0])
+        adapted = not (torch.equal(self.ln.data, self._ln_init) and torch.equal(self.vis.data, self._vis_init))
+        if adapted:
+            eng.set_ln_params(self.ln.data)
+            eng.set_visual_params(self.vis.data)
+        per_image = eng.logits(eng.encode_image(L.STUDENT, images), self.text_features)
+        if adapted:
+            eng.set_ln_params(self._ln_init)
+            eng.set_visual_params(self._vis_init)
+        return per_image, per_image.t()
+
+
+class CLIPRewards(_cr.CLIPRewards):
+    """retrieval/clip_reward.py:107-222: the classification reward model with the bank called `text_features` and both index
+    directions in CLIPScore."""
+
+    @property
+    def text_features(self):
+        return self.class_features
+
+    @text_features.setter
+    def text_features(self, v):
+        self.class_features = v
+
+    @torch.no_grad()
+    def set_many_text_features(self, texts, text_bs=128):
+        self.class_features = self.extract_text_features(captions=texts)
+
+    @torch.no_grad()
+    def CLIPScore(self, text_index=None, images_index=None, pairwise=True):
+        t = self.class_features[text_index.long()] if text_index is not None else self.class_features.repeat_interleave(self.sample_k, dim=0)
+        i = self.image_features[images_index.long()] if images_index is not None else self.image_features.repeat_interleave(self.sample_k, dim=0)
+        sim = _cr._gemm_nt(t, i, self.clipscore_weight)
+        if not pairwise:
+            sim = torch.diagonal(sim)
+        return sim.clamp_min(0).squeeze()
+
+
+def tune_image(image, model, reward_model, optimizer, scaler, args=None):
+    """retrieval/clip_ret_policy.py:76-103.  `optimizer` supplies the AdamW hyper-parameters; `scaler` is accepted and unused."""
+    g = optimizer.param_groups[0]
+    b1, b2 = g.get("betas", (0.9, 0.999))
+    cfg = TTAConfig(selection_p=1.0, tta_steps=args.tta_steps, sample_k=reward_model.sample_k, lr=g["lr"], weight_decay=g.get("weight_decay", 0.0),
+                    beta1=b1, beta2=b2, eps=g.get("eps", 1e-8), reward_process=bool(reward_model.reward_process),
+                    process_batch=bool(reward_model.process_batch), reward_amplify=bool(reward_model.amplify_rewards),
+                    clipscore_weight=reward_model.clipscore_weight)
+    if not (torch.equal(model.ln.data, model._ln_init) and torch.equal(model.vis.data, model._vis_init)):
+        raise NotImplementedError("tune_image starts from the reset state (model.reset_initial(), clip_ret_policy.py:180)")
+    out = runtime.SESSION.engine(image.shape[0]).tta_retrieval_image(image, cfg, skip_final=True)
+    with torch.no_grad():
+        model.ln.data.copy_(out["ln_after"])
+        model.vis.data.copy_(out["vis_after"])
+    return out
+
+
+def text2image_loss(logits_per_text, reward_model, sample_k=None):
+    """Loss section of tune_text (clip_ret_policy.py:123-133) for one query caption on the HIP loss kernel: logits_per_text [1, n_images];
+    reward_model.text_features [1, Dr] (the query) and .image_features [n_images, Dr] (the bank).
+    -> dict(topk_idx, clip_score, rewards, loss, dlogits)."""
+    K = sample_k or reward_model.sample_k
+    lg = logits_per_text.float().contiguous()
+    n, C = lg.shape
+    bank, q = reward_model.image_features.float().contiguous(), reward_model.class_features.float().contiguous()
+    dev = lg.device
+    o = dict(topk_idx=torch.empty(n, K, dtype=torch.int32, device=dev), clip_score=torch.empty(n * K, device=dev),
+             rewards=torch.empty(n * K, device=dev), loss=torch.empty(1, device=dev), dlogits=torch.empty(n, C, device=dev))
+    flags = (L.F_REWARD_PROCESS if reward_model.reward_process else 0) | (L.F_AMPLIFY if reward_model.amplify_rewards else 0) | \
+            (L.F_PROCESS_BATCH if reward_model.process_batch else 0)
+    L.check(L.lib().rlcf_reward_loss(lg.data_ptr(), C, None, n, C, K, bank.data_ptr(), q.data_ptr(), bank.shape[1], float(reward_model.clipscore_weight),
+                                     flags, 0.0, o["topk_idx"].data_ptr(), o["clip_score"].data_ptr(), o["rewards"].data_ptr(),
+                                     o["loss"].data_ptr(), o["dlogits"].data_ptr(), torch.cuda.current_stream().cuda_stream), "reward_loss")
+    return o

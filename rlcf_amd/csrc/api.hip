@@ -280,7 +280,7 @@ int rlcf_engine_finalize(rlcf_engine* e, rlcf_stream stream) {
 }
 int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
                                rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && tokens_host && ctx_init);
+    RLCF_ARG_CHECK(e && tokens_host && (ctx_init || n_ctx == 0));
     return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream);
 }
 int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
@@ -292,7 +292,7 @@ int rlcf_encode_image_resized(rlcf_engine* e, int which, const float* images, in
     return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream, in_res);
 }
 int rlcf_text_features(rlcf_engine* e, const float* ctx, float* txt, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && ctx && txt);
+    RLCF_ARG_CHECK(e && txt && (ctx || e->n_ctx == 0));
     return engine_text_features(e, RLCF_STUDENT, ctx, txt, (hipStream_t)stream);
 }
 int rlcf_reward_class_features(rlcf_engine* e, int which, float* out, rlcf_stream stream) {
@@ -328,6 +328,12 @@ int rlcf_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta
 int rlcf_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args);
     return engine_tta_sample_visual(e, views, N, args, out, (hipStream_t)stream);
+}
+int rlcf_tta_retrieval_image(rlcf_engine* e, const float* images, int n, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && images && args && n > 0);
+    rlcf_tta_args a = *args;
+    a.selection_p = 1.0f; a.n_sel = n; a.flags |= RLCF_F_NO_SELECTION;     // every query image carries reward and gradient, in loader order
+    return engine_tta_sample_visual(e, images, n, &a, out, (hipStream_t)stream);
 }
 int64_t rlcf_engine_visual_param_count(rlcf_engine* e, rlcf_stream stream) {
     if (!e || engine_visual_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;

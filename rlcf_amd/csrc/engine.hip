@@ -835,7 +835,9 @@ static TextPassIO full_io(rlcf_engine* e, const TextLayout& L) {
 int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (!s.finalized) { rlcf_set_error("student not finalized"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(C > 0 && C <= e->max_classes && n_ctx > 0 && n_ctx + 3 <= s.cfg.context_length);
+    // n_ctx == 0: a bank of plain texts without learnable rows (the caption bank of the retrieval task, the raw class prompts of
+    // CLIPCLS_TTA): the image-encoder tuning calls use it; the prompt-tuning calls refuse it
+    RLCF_ARG_CHECK(C > 0 && C <= e->max_classes && n_ctx >= 0 && n_ctx + 3 <= s.cfg.context_length && (n_ctx == 0 || ctx_init));
     RLCF_ARG_CHECK(text_mode >= RLCF_TEXT_DENSE && text_mode <= RLCF_TEXT_SHARED);
     e->text_mode = text_mode; e->n_ctx = n_ctx; e->C = C;
     const int Wt = s.cfg.text_width, D = s.cfg.embed_dim;
@@ -857,8 +859,10 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     TRY(e->eot_x.ensure(cw)); TRY(e->eot_ln.ensure(cw)); TRY(e->u.ensure(cd)); TRY(e->inv_norm.ensure(C * sizeof(float)));
     TRY(e->txt.ensure(cd)); TRY(e->dtxt_dense.ensure(cd));
     const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
-    TRY(e->ctx_init.ensure(cb)); TRY(e->ctx.ensure(cb)); TRY(e->adam_m.ensure(cb)); TRY(e->adam_v.ensure(cb)); TRY(e->ctx_grad.ensure(cb));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ctx_init.p, ctx_init, cb, hipMemcpyDeviceToDevice, st));
+    if (cb) {
+        TRY(e->ctx_init.ensure(cb)); TRY(e->ctx.ensure(cb)); TRY(e->adam_m.ensure(cb)); TRY(e->adam_v.ensure(cb)); TRY(e->ctx_grad.ensure(cb));
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->ctx_init.p, ctx_init, cb, hipMemcpyDeviceToDevice, st));
+    }
     // TTA scratch
     const int N = e->max_views;
     TRY(e->img_feat.ensure((size_t)N * D * sizeof(float))); TRY(e->logits.ensure((size_t)N * C * sizeof(float)));
@@ -1011,6 +1015,7 @@ static RewardBank reward_bank(const rlcf_engine* e) {
 int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    if (e->n_ctx <= 0) { rlcf_set_error("prompt tuning needs a class bank with learnable context rows (n_ctx > 0)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32);
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
     const int n_sel = n_selected(a, N);                       // int() truncation, tpt_cls_rl.py:34
@@ -1212,6 +1217,7 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
                      hipStream_t st) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
+    if (e->n_ctx <= 0) { rlcf_set_error("prompt tuning needs a class bank with learnable context rows (n_ctx > 0)"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const int n_sel = n_selected(a, N);
@@ -1441,6 +1447,7 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
             TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
             TRY(engine_logits(e, e->img_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+            if (a->flags & RLCF_F_NO_SELECTION) TRY(launch_iota(e->sel_idx.as<int32_t>(), n_sel, st));     // retrieval: every row, in order
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
             TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));

@@ -41,6 +41,7 @@ int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* se
                          int causal, float* dqkv, hipStream_t st);
 
 int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, hipStream_t st);
+int launch_iota(int32_t* p, int n, hipStream_t st);
 int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, int n_sel, int C, int K,
                        const float* class_feat, const float* reward_img, int Dr, float clipscore_weight,
                        int flags, float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards,

@@ -88,6 +88,16 @@ __global__ void select_lowest_batched_kernel(const float* __restrict__ entropy, 
         if (rank < n_sel) idx[blockIdx.x * n_sel + rank] = blockIdx.x * n + i;
     }
 }
+__global__ void iota_kernel(int32_t* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+int launch_iota(int32_t* p, int n, hipStream_t st) {          // p[i] = i: "every row selected, in order" (retrieval: no view selection)
+    RLCF_ARG_CHECK(p && n > 0);
+    iota_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(p, n);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 int launch_entropy_select_batched(const float* logits, int B, int n, int C, int n_sel, float* entropy, int32_t* idx_global, hipStream_t st) {
     RLCF_ARG_CHECK(B > 0 && n > 0 && C > 0 && n_sel > 0 && n_sel <= n);
     row_entropy_kernel<<<dim3(B * n), dim3(TTA_THREADS), 0, st>>>(logits, C, entropy);

@@ -121,8 +121,8 @@ class Engine:
     def set_class_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor,
                        text_mode: int = L.TEXT_SHARED) -> None:
         tok = np.ascontiguousarray(tokens.detach().cpu().numpy().astype(np.int32))
-        ci = ctx_init.detach().to(self.device, torch.float32).contiguous()
-        L.check(self.lib.rlcf_engine_set_class_bank(self.h, tok.ctypes.data, tok.shape[0], n_ctx, ci.data_ptr(),
+        ci = ctx_init.detach().to(self.device, torch.float32).contiguous() if n_ctx > 0 else None      # n_ctx = 0: plain texts (caption bank)
+        L.check(self.lib.rlcf_engine_set_class_bank(self.h, tok.ctypes.data, tok.shape[0], n_ctx, ci.data_ptr() if ci is not None else None,
                                                     text_mode, _stream()), "set_class_bank")
         self.n_cls, self.n_ctx = tok.shape[0], n_ctx
 
@@ -139,8 +139,9 @@ class Engine:
                     "encode_image")
         return out
 
-    def text_features(self, ctx: torch.Tensor) -> torch.Tensor:
-        ctx = ctx.detach().to(self.device, torch.float32).contiguous()
+    def text_features(self, ctx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """student text features of the class bank under prompt `ctx` (None for a bank without learnable rows, n_ctx = 0)"""
+        ctx = ctx.detach().to(self.device, torch.float32).contiguous() if ctx is not None else None
         out = torch.empty(self.n_cls, self.student.embed_dim, device=self.device)
         L.check(self.lib.rlcf_text_features(self.h, _ptr(ctx), _ptr(out), _stream()), "text_features")
         return out
@@ -278,11 +279,16 @@ class Engine:
         L.check(self.lib.rlcf_engine_momentum_update_visual(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0,
                                                             _stream()), "momentum_update_visual")
 
-    def tta_sample_visual(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
+    def tta_retrieval_image(self, images: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
+        """Image -> text retrieval step: tune_image + the evaluation of its loop (retrieval/clip_ret_policy.py:76-103,171-176) over the
+        caption bank given to set_class_bank(n_ctx=0).  Every query image is 'selected'."""
+        return self.tta_sample_visual(images, cfg, skip_final, retrieval=True)
+
+    def tta_sample_visual(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False, retrieval: bool = False) -> Dict[str, torch.Tensor]:
         """Full image-encoder tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=False), scripts/rlcf-tune.sh)."""
         views = views.to(self.device, torch.float32).contiguous()
         N, Cn, K = views.shape[0], self.n_cls, cfg.sample_k
-        n_sel = cfg.n_sel(N)
+        n_sel = N if retrieval else cfg.n_sel(N)
         npar = int(self.lib.rlcf_engine_ln_param_count(self.h))
         nvis = int(self.lib.rlcf_engine_visual_param_count(self.h, _stream()))
         if nvis <= 0:
@@ -297,7 +303,8 @@ class Engine:
                  rewards=torch.empty(n_sel * K, device=dev), loss=torch.empty(1, device=dev))
         co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
         a = cfg.c_args(N, skip_final)
-        L.check(self.lib.rlcf_tta_sample_visual(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_visual")
+        fn = self.lib.rlcf_tta_retrieval_image if retrieval else self.lib.rlcf_tta_sample_visual
+        L.check(fn(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_retrieval_image" if retrieval else "tta_sample_visual")
         return o
 
     def tta_batch(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):

@@ -1,0 +1,225 @@
+"""Generate tests/golden/retrieval_*.npz by running the REFERENCE's retrieval policy (imported read-only from
+/root/reference/retrieval) on this repo's seeded synthetic weights / images / caption banks.  Build container only.
+
+    python tests/golden/make_retrieval_golden.py
+
+What is imported from the reference and exercised: `tune_image`, `tune_text` (retrieval/clip_ret_policy.py:76-137),
+`CLIPRet_TTA` (retrieval/custom_models.py:29-163) and `CLIPRewards` (retrieval/clip_reward.py:107-222).  What is stubbed: the LAVIS
+package the retrieval scripts sit on (third-party, needs omegaconf & co.) — `lavis.models.clip_models.tokenizer.tokenize` becomes a
+lookup into the synthetic token bank and `lavis.models.clip_models.model.load_openai_model` returns the reference's own OpenAI-CLIP
+class (TPT/clip/model.py, the same architecture LAVIS re-implements) with this repo's seeded weights; the DOWNLOAD_ROOT gate is
+opened as in make_golden.py.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+import warnings
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from rlcf_amd import synth  # noqa: E402
+from oracle import rlcf_ref as RR  # noqa: E402  (key order of the visual parameters only)
+
+REF = "/root/reference"
+STATE = {}          # arch name -> (geometry, state dict); the tokenizer bank
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location("ref_clip_model", os.path.join(REF, "TPT/clip/model.py"))
+    refmodel = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refmodel)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.__all__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    def tokenize(texts, context_length=77):
+        return STATE["bank"].tokenize(texts, context_length)
+
+    def load_openai_model(path, device="cpu", jit=False):
+        geo, sd = STATE[os.path.basename(path)[:-3]]
+        m = refmodel.CLIP(*geo.as_tuple())
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        m = m.eval().float()
+        m.visual.image_size = geo.image_resolution          # read by CLIPRewards.__init__ (clip_reward.py:128)
+        m.lock_image_tower = lambda unlocked_groups=0, freeze_bn_stats=True: [p.requires_grad_(False) for p in m.visual.parameters()]
+        return m
+
+    for n in ["lavis", "lavis.common", "lavis.models", "lavis.models.clip_models", "lavis.datasets", "lavis.datasets.builders", "lavis.processors",
+              "lavis.runners", "lavis.tasks"]:
+        stub(n)
+    stub("lavis.common.config", Config=object)
+    stub("lavis.common.dist_utils", get_rank=lambda: 0, init_distributed_mode=lambda *a: None)
+    stub("lavis.common.logger", setup_logger=lambda: None, MetricLogger=object)
+    stub("lavis.common.utils", now=lambda: "now")
+    stub("lavis.runners.runner_base", RunnerBase=object)
+    stub("lavis.models.clip_models.tokenizer", tokenize=tokenize)
+    stub("lavis.models.clip_models.model", load_openai_model=load_openai_model)
+    stub("lavis_evaluate", setup_seeds=lambda cfg: None)
+    _exists = os.path.exists
+    os.path.exists = lambda p: True if p == "/YOUR/PATH" else _exists(p)
+    sys.path.insert(0, os.path.join(REF, "retrieval"))
+    import clip_ret_policy
+    import clip_reward
+    import custom_models
+    os.path.exists = _exists
+    return types.SimpleNamespace(policy=clip_ret_policy, reward=clip_reward, models=custom_models)
+
+
+class Bank:
+    """captions 'c<i>.' -> row i of the synthetic token bank (make_golden.py's tokenizer)"""
+
+    def __init__(self, geo, n):
+        self.tokens = synth.make_token_bank(geo, n, seed=7, n_ctx=4)
+        self.texts = [f"c{i}." for i in range(n)]
+
+    def tokenize(self, texts, context_length=77):
+        if isinstance(texts, str):
+            texts = [texts]
+        return torch.stack([self.tokens[int(t.strip().rstrip(".").split("c")[-1])] for t in texts])
+
+
+def save(name, arrays, meta):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()},
+                        **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+def setup(ref, student, reward, n_bank, K, amplify=False):
+    s_geo, r_geo = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    s_sd, r_sd = synth.make_state_dict(s_geo, 11), synth.make_state_dict(r_geo, 23)
+    STATE.update({"student": (s_geo, s_sd), "reward": (r_geo, r_sd), "bank": Bank(s_geo, n_bank)})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scaler = torch.cuda.amp.GradScaler(init_scale=1000)
+    rm = ref.reward.CLIPRewards("cpu", arch="reward", classification=True, amplify_rewards=amplify, sample_k=K, reward_process=True,
+                                process_batch=False, default_resolutions=s_geo.image_resolution)
+    return s_geo, r_geo, s_sd, r_sd, scaler, rm
+
+
+def tap(rm, taps):
+    orig_score, orig_post = rm.CLIPScore, rm.rewards_post_process
+
+    def score(*a, **k):
+        s = orig_score(*a, **k)
+        if "clip_score" not in taps:
+            taps["clip_score"] = s.detach().clone()
+            idx = k.get("text_index")
+            taps["topk_idx"] = (idx if idx is not None else k.get("images_index")).clone()
+        return s
+
+    def post(x):
+        r = orig_post(x)
+        taps.setdefault("rewards", r.detach().clone())
+        return r
+
+    rm.CLIPScore, rm.rewards_post_process = score, post
+
+
+def gen_i2t(ref, name, n_img, K, steps, lr, n_bank=300):
+    """image -> text: test_time_tune's only_visual branch for one data-loader item (clip_ret_policy.py:150-181)."""
+    s_geo, r_geo, s_sd, r_sd, scaler, rm = setup(ref, "tiny", "tiny-r", n_bank, K)
+    bank = STATE["bank"]
+    model = ref.models.CLIPRet_TTA("cpu", arch="student", only_visual=True, momentum_update=False)
+    args = types.SimpleNamespace(tta_steps=steps)
+    with torch.no_grad():
+        text_ids = ref.policy.tokenize_all_text(bank.texts, types.SimpleNamespace(device="cpu"), 128)
+        model.set_text_features(text_features=ref.policy.get_all_text_embeds(text_ids, model, 128))
+        rm.set_many_text_features(bank.texts, text_bs=128)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, eps=1e-06, weight_decay=5e-4)            # clip_ret_policy.py:222
+    names = [n for n, _ in model.clip_model.visual.named_parameters()]
+    assert ["visual." + n for n in names] == RR.visual_param_keys(s_sd)
+    pmap = dict(model.clip_model.visual.named_parameters())
+    pristine = {n: p.detach().clone() for n, p in pmap.items()}
+    first = {}
+    def keep_first(n):
+        def hook(g):                         # must return None: a returned tensor would REPLACE the gradient
+            first.setdefault(n, g.detach().clone())
+        return hook
+
+    for n in names:
+        pmap[n].register_hook(keep_first(n))
+    taps = {}
+    tap(rm, taps)
+    image = synth.make_views(1000, n_img, s_geo.image_resolution)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.policy.tune_image(image, model, rm, optimizer, scaler, args=args)
+    model.eval()
+    with torch.no_grad():
+        logits_per_image, _ = model(image)
+    arrays = dict(topk_idx=taps["topk_idx"].reshape(n_img, K), clip_score=taps["clip_score"], rewards=taps["rewards"],
+                  final_logits=logits_per_image[:1],
+                  grad_l2=torch.stack([first[n].double().norm() for n in names]).float(),
+                  delta_l2=torch.stack([(pmap[n].detach() - pristine[n]).double().norm() for n in names]).float(),
+                  grad_sample=torch.cat([first[n].reshape(-1) for n in names])[::7].clone(),
+                  after_sample=torch.cat([pmap[n].detach().reshape(-1) for n in names])[::7].clone())
+    save(name, arrays, dict(student="tiny", reward="tiny-r", n_bank=n_bank, n_img=n_img, sample_k=K, tta_steps=steps, lr=lr, eps=1e-6,
+                            weight_decay=5e-4, student_seed=11, reward_seed=23, bank_seed=7, view_seed=1000))
+    print(f"  {name}: topk[0,:5]={taps['topk_idx'][:5].tolist()} |g|={float(arrays['grad_l2'].norm()):.3e} score>0: {int((taps['clip_score'] > 0).sum())}")
+
+
+def gen_t2i(ref, name, K, n_images=200, amplify=False):
+    """text -> image: tune_text (clip_ret_policy.py:106-137) run for ONE step on CPU; stored: the student's logits_per_text, the reward
+    model's features and the loss section's outputs (top-K image index, scores, rewards, loss, d loss / d logits_per_text)."""
+    s_geo, r_geo, s_sd, r_sd, scaler, rm = setup(ref, "tiny", "tiny-r", 64, K, amplify)
+    model = ref.models.CLIPRet_TTA("cpu", arch="student", only_visual=False, momentum_update=False)
+    images = synth.make_views(3000, n_images, s_geo.image_resolution)
+    with torch.no_grad():
+        model.set_image_features(image_features=model.get_image_features(images))
+        rm.set_image_features(images=images)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-6, eps=1e-06, weight_decay=5e-4)
+    taps, grabbed = {}, {}
+    tap(rm, taps)
+    orig_forward = model.forward
+
+    def forward(images=None, text=None, tokenized_prompts=None):
+        li, lt = orig_forward(images=images, text=text, tokenized_prompts=tokenized_prompts)
+        if "logits" not in grabbed and lt.requires_grad:
+            grabbed["logits"] = lt.detach().clone()
+            def hook(g):
+                grabbed.setdefault("dlogits", g.detach().clone())
+            lt.register_hook(hook)
+        return li, lt
+
+    model.forward = forward
+    text = "c5."
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.policy.tune_text(text, model, rm, optimizer, scaler, args=types.SimpleNamespace(tta_steps=1))
+    lt, idx = grabbed["logits"], taps["topk_idx"]
+    rewards = taps["rewards"]
+    rep = torch.repeat_interleave(lt, K, dim=0)
+    loss = torch.mean(rewards * torch.nn.functional.cross_entropy(rep, idx, reduction="none"))
+    arrays = dict(logits_per_text=lt, reward_text=rm.text_features, reward_images=rm.image_features, topk_idx=idx.reshape(1, K),
+                  clip_score=taps["clip_score"], rewards=rewards, loss=loss, dlogits=grabbed["dlogits"])
+    save(name, arrays, dict(sample_k=K, n_images=n_images, reward_amplify=int(amplify), clipscore_weight=2.5))
+    print(f"  {name}: idx[:5]={idx[:5].tolist()} loss={float(loss):.4e} score>0: {int((taps['clip_score'] > 0).sum())}")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    ref = import_reference()
+    gen_i2t(ref, "retrieval_i2t_tiny", n_img=1, K=20, steps=2, lr=1e-4)         # scripts/tta_coco_ret.sh: sample_k_i2t=20
+    gen_i2t(ref, "retrieval_i2t_tiny_b2", n_img=2, K=5, steps=1, lr=1e-4)        # a loader batch of two query images
+    gen_t2i(ref, "retrieval_t2i_loss", K=12)                                      # sample_k_t2i=12
+    gen_t2i(ref, "retrieval_t2i_loss_amp", K=12, amplify=True)
+
+
+if __name__ == "__main__":
+    main()

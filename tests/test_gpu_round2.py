@@ -340,3 +340,97 @@ def test_f16_single_pass_mode_b16_stream(L, dev):
     print(f"[f16 b16 stream] top-1 agreement {agree}/{n}, max|dlogit| vs the reference = {worst:.3e}")
     assert agree == n and worst < 0.1
     eng.close()
+
+
+# ------------------------------------------------------------------------------ retrieval policy
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("name", ["retrieval_i2t_tiny", "retrieval_i2t_tiny_b2"])
+def test_retrieval_image_to_text_matches_reference_fixture(L, dev, name, prec):
+    """rlcf_tta_retrieval_image vs the reference's tune_image (retrieval/clip_ret_policy.py:76-103) + the evaluation of its loop
+    (:171-176) with CLIPRet_TTA / CLIPRewards, over a 300-caption bank without learnable rows (n_ctx = 0), K = 20 (the script's
+    sample_k_i2t) / a loader batch of two query images."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    from test_gpu_parity import _tensor_norms
+    g, meta = load_golden(name)
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd, rsd = synth.make_state_dict(sg, meta["student_seed"], device=dev), synth.make_state_dict(rg, meta["reward_seed"], device=dev)
+    eng = Engine(sg, rg, max(meta["n_img"], 2), meta["n_bank"], prec)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    tokens = synth.make_token_bank(sg, meta["n_bank"], seed=meta["bank_seed"], n_ctx=4)
+    eng.set_class_bank(tokens, 0, None, L.TEXT_SHARED)                   # captions: no learnable rows
+    images = synth.make_views(meta["view_seed"], meta["n_img"], sg.image_resolution, device=dev)
+    cfg = TTAConfig(selection_p=1.0, tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"], weight_decay=meta["weight_decay"],
+                    eps=meta["eps"])
+    o = eng.tta_retrieval_image(images, cfg)
+    torch.cuda.synchronize()
+    c = lambda k: o[k].cpu()
+    assert c("selected_idx").tolist() == list(range(meta["n_img"]))      # every query image carries reward
+    assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(c("clip_score"), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=1e-3, rtol=0)
+    keys = RR.visual_param_keys(ssd)
+    grad, after = eng.merge_visual(o["ln_grad"], o["vis_grad"]), eng.merge_visual(o["ln_after"], o["vis_after"])
+    torch.testing.assert_close(_tensor_norms(ssd, keys, grad), g["grad_l2"], rtol=3e-3, atol=1e-9)
+    torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g["delta_l2"], rtol=0.01, atol=1e-7)
+    gs = grad[::7].cpu()
+    assert (gs - g["grad_sample"]).norm() / g["grad_sample"].norm() < 2e-3
+    # prompt tuning refuses a bank without learnable rows
+    with pytest.raises(L.RlcfError, match="learnable context"):
+        eng.tta_sample(images, cfg)
+    eng.close()
+
+
+def test_retrieval_mirror_tune_image(L, dev):
+    """The reference-shaped objects (rlcf_amd.clip_ret_policy: CLIPRet_TTA, CLIPRewards, tune_image) reproduce the fixture through the
+    loop body of test_time_tune (clip_ret_policy.py:166-181): tune, logits of the tuned model, reset."""
+    import copy
+    from rlcf_amd import clip_ret_policy as P, clip_store, runtime
+    g, meta = load_golden("retrieval_i2t_tiny")
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("student", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("reward", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    tokens = synth.make_token_bank(sg, meta["n_bank"], seed=meta["bank_seed"], n_ctx=4)
+    clip_store.set_tokenizer(lambda texts, context_length=77, truncate=False: tokens[[int(t.strip().rstrip(".").split("c")[-1]) for t in ([texts] if isinstance(texts, str) else texts)]])
+    texts = [f"c{i}." for i in range(meta["n_bank"])]
+    model = P.CLIPRet_TTA(dev, arch="student", only_visual=True)
+    reward_model = P.CLIPRewards(dev, arch="reward", sample_k=meta["sample_k"], reward_process=True, process_batch=False)
+    model.set_text_bank(texts)
+    reward_model.set_many_text_features(texts)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=meta["lr"], eps=meta["eps"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    image = synth.make_views(meta["view_seed"], 1, sg.image_resolution, device=dev)
+    reward_model.set_image_features(image)
+    P.tune_image(image, model, reward_model, optimizer, None, args=types.SimpleNamespace(tta_steps=meta["tta_steps"]))
+    logits_per_image, logits_per_text = model(image)
+    torch.testing.assert_close(logits_per_image[:1].cpu(), g["final_logits"], atol=1e-3, rtol=0)
+    assert logits_per_text.shape == (meta["n_bank"], 1)
+    sc = reward_model.CLIPScore(text_index=g["topk_idx"].reshape(-1).to(dev), pairwise=False)
+    # (scores of the PRISTINE-step sample set: the reward model is frozen, so they are the fixture's)
+    torch.testing.assert_close(sc.cpu(), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+    model.reset_initial()
+    optimizer.load_state_dict(optim_state)
+    assert torch.equal(model.ln.data, model._ln_init)
+    with pytest.raises(NotImplementedError):
+        P.CLIPRet_TTA(dev, arch="student", only_visual=False)
+    runtime.reset_session()
+
+
+@pytest.mark.parametrize("name", ["retrieval_t2i_loss", "retrieval_t2i_loss_amp"])
+def test_retrieval_text_to_image_loss_matches_reference_fixture(L, dev, name):
+    """Loss section of the reference's tune_text (clip_ret_policy.py:123-133) on the HIP loss kernel with the banks exchanged:
+    rows = logits_per_text over the image bank, class_feat = the reward model's image features, reward_img = its query text feature."""
+    from rlcf_amd import clip_ret_policy as P
+    g, meta = load_golden(name)
+    rm = types.SimpleNamespace(sample_k=meta["sample_k"], reward_process=True, amplify_rewards=bool(meta["reward_amplify"]), process_batch=False,
+                               clipscore_weight=meta["clipscore_weight"], image_features=g["reward_images"].to(dev),
+                               class_features=g["reward_text"].to(dev))
+    o = P.text2image_loss(g["logits_per_text"].to(dev), rm)
+    assert o["topk_idx"].cpu().reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(o["clip_score"].cpu(), g["clip_score"].reshape(-1), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(o["rewards"].cpu(), g["rewards"].reshape(-1), atol=1e-5, rtol=1e-3)
+    torch.testing.assert_close(o["loss"].cpu()[0], g["loss"], atol=1e-7, rtol=1e-3)
+    torch.testing.assert_close(o["dlogits"].cpu(), g["dlogits"], atol=1e-7, rtol=1e-3)

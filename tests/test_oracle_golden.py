@@ -266,3 +266,39 @@ def test_visual_tuning_oracle_matches_reference(name):
         assert (og - gr).norm() / gr.norm() < 1e-3
         d = (o["ln_after"][::7] - g["vis_after_sample"]).abs()
         assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+
+
+# ------------------------------------------------------------------------------ retrieval policy
+@pytest.mark.parametrize("name", ["retrieval_i2t_tiny", "retrieval_i2t_tiny_b2"])
+def test_retrieval_image_to_text_oracle_matches_reference(name):
+    """oracle.retrieval_ref.tune_image vs the reference's tune_image + CLIPRet_TTA + CLIPRewards run
+    (tests/golden/make_retrieval_golden.py): sampled captions, scores, rewards, gradient and post-tuning logits."""
+    from oracle import retrieval_ref as QR
+    g, meta = load(name)
+    sg, rg = synth.GEOMETRIES[str(meta["student"])], synth.GEOMETRIES[str(meta["reward"])]
+    ssd, rsd = synth.make_state_dict(sg, int(meta["student_seed"])), synth.make_state_dict(rg, int(meta["reward_seed"]))
+    tokens = synth.make_token_bank(sg, int(meta["n_bank"]), seed=int(meta["bank_seed"]), n_ctx=4)
+    images = synth.make_views(int(meta["view_seed"]), int(meta["n_img"]), sg.image_resolution)
+    hp = R.TTAHyper(selection_p=1.0, tta_steps=int(meta["tta_steps"]), sample_k=int(meta["sample_k"]), lr=float(meta["lr"]),
+                     weight_decay=float(meta["weight_decay"]), eps=float(meta["eps"]))
+    o = QR.tune_image(ssd, rsd, images, tokens, hp)
+    assert o["topk_idx"].reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(o["clip_score"], g["clip_score"], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=1e-6, rtol=1e-4)
+    gs = o["grad"][::7]
+    assert (gs - g["grad_sample"]).norm() / g["grad_sample"].norm() < 1e-4
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["retrieval_t2i_loss", "retrieval_t2i_loss_amp"])
+def test_retrieval_text_to_image_loss_oracle_matches_reference(name):
+    """Loss section of the reference's tune_text on one query caption (top-K images, CLIPScore(images_index), baseline, CE)."""
+    from oracle import retrieval_ref as QR
+    g, meta = load(name)
+    hp = R.TTAHyper(sample_k=int(meta["sample_k"]), reward_amplify=bool(meta["reward_amplify"]), clipscore_weight=float(meta["clipscore_weight"]))
+    o = QR.tune_text_loss(g["logits_per_text"], g["reward_text"], g["reward_images"], hp)
+    assert o["topk_idx"].reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(o["clip_score"], g["clip_score"], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(o["loss"], g["loss"], atol=1e-7, rtol=1e-4)
+    torch.testing.assert_close(o["dlogits"], g["dlogits"], atol=1e-7, rtol=1e-4)
