@@ -197,6 +197,15 @@ int rlcf_engine_finalize(rlcf_engine*, rlcf_stream stream);
 int rlcf_engine_set_class_bank(rlcf_engine*, const int32_t* tokens_host, int C, int n_ctx,
                                const float* ctx_init, int text_mode, rlcf_stream stream);
 
+/* The same for a PromptLearner whose class tokens do not sit at the END of the prompt (class_token_position 'front' / 'middle', or
+ * '[CLS]' inside ctx_init: custom_clip.py:92-97,239-284): ctx_pos HOST [C, n_ctx] = position of learnable vector k in prompt c
+ * ('front': 1 + name_len + k; 'middle': 1 + k for k < half, 1 + half + name_len + (k - half) after), student_tokens HOST
+ * [C, context_length] = the token ids in that re-arranged order (values at the learnable positions are ignored); tokens = the prompts
+ * as tokenised ("<prefix> <class>."): the reward models' bank and the EOT positions.  Rows common to all classes ('middle': SOS + the
+ * first half of the context) are still computed once in RLCF_TEXT_SHARED mode. */
+int rlcf_engine_set_class_bank_ex(rlcf_engine*, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
+                                  const int32_t* student_tokens_host, const int32_t* ctx_pos_host, rlcf_stream stream);
+
 /* encode_image + L2 normalise (TPT/clip/model.py:223-240,340-341; custom_clip.py:327-330;
  * clip_reward.py:130-137).  images [n,3,R,R]; feats [n,D]. */
 int rlcf_encode_image(rlcf_engine*, int which, const float* images, int n, float* feats, rlcf_stream stream);

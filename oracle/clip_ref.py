@@ -182,13 +182,24 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return x / x.norm(dim=-1, keepdim=True)
 
 
-def prompt_embeddings(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-    """PromptLearner.forward with class_token_position == 'end' and a 2-D ctx,
-    TPT/clip/custom_clip.py:198-238: [SOS | ctx | class tokens, '.', EOS, pad]."""
+def prompt_embeddings(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor, position: str = "end", split_idx=None) -> torch.Tensor:
+    """PromptLearner.forward with a 2-D ctx, TPT/clip/custom_clip.py:198-289.  'end' (:211-238): [SOS | ctx | class tokens, '.', EOS,
+    pad]; 'middle' (:239-264): [SOS | ctx[:half] | class | ctx[half:] | '.', EOS, pad] with half = split_idx (the place of '[CLS]' in
+    ctx_init, :92-97) or n_ctx // 2; 'front' (:266-284): [SOS | class | ctx | '.', EOS, pad].  name_len = the tokens between the
+    context words and the final '.' of the tokenised prompt (:127)."""
     emb = sd["token_embedding.weight"][tokens]
     n_ctx = ctx.shape[0]
     c = tokens.shape[0]
-    return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(c, -1, -1), emb[:, 1 + n_ctx:]], dim=1)
+    if position == "end":
+        return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(c, -1, -1), emb[:, 1 + n_ctx:]], dim=1)
+    half = (split_idx if split_idx is not None else n_ctx // 2) if position == "middle" else 0
+    eot = tokens.argmax(dim=-1)
+    rows = []
+    for i in range(c):
+        nl = int(eot[i]) - 1 - n_ctx - 1
+        suffix = emb[i, 1 + n_ctx:]
+        rows.append(torch.cat([emb[i, :1], ctx[:half], suffix[:nl], ctx[half:], suffix[nl:]], dim=0))
+    return torch.stack(rows)
 
 
 def ctx_from_tokens(sd: SD, ctx_token_ids) -> torch.Tensor:
@@ -197,21 +208,22 @@ def ctx_from_tokens(sd: SD, ctx_token_ids) -> torch.Tensor:
     return sd["token_embedding.weight"][ids].clone()
 
 
-def student_text_features(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor, truncate: bool = False) -> torch.Tensor:
+def student_text_features(sd: SD, tokens: torch.Tensor, ctx: torch.Tensor, truncate: bool = False, position: str = "end",
+                          split_idx=None) -> torch.Tensor:
     """ClipTestTimeTuning.get_text_features, TPT/clip/custom_clip.py:315-323
     (the stack+mean over a one-element list is the identity)."""
     eot = tokens.argmax(dim=-1)
-    x = prompt_embeddings(sd, tokens, ctx)
+    x = prompt_embeddings(sd, tokens, ctx, position, split_idx)
     if truncate:
         x = x[:, : int(eot.max()) + 1]
     return l2_normalize(text_tower(sd, x, eot))
 
 
 def student_logits(sd: SD, images: torch.Tensor, tokens: torch.Tensor, ctx: torch.Tensor,
-                   truncate: bool = False) -> torch.Tensor:
+                   truncate: bool = False, position: str = "end", split_idx=None) -> torch.Tensor:
     """ClipTestTimeTuning.inference, TPT/clip/custom_clip.py:325-335: image tower
     under no_grad, text tower differentiable w.r.t. ctx."""
     with torch.no_grad():
         img = l2_normalize(encode_image(sd, images))
-    txt = student_text_features(sd, tokens, ctx, truncate)
+    txt = student_text_features(sd, tokens, ctx, truncate, position, split_idx)
     return sd["logit_scale"].exp() * img @ txt.t()

@@ -37,6 +37,10 @@ class TTAHyper:
     clipscore_weight: float = 2.5
     min_entropy_reg: bool = False
     min_entropy_w: float = 0.2
+    # PromptLearner class-token position (custom_clip.py:198-289): 'end' (every RLCF script), 'middle' (split_idx: where '[CLS]' stood in
+    # ctx_init, None = n_ctx // 2), 'front'
+    ctx_position: str = "end"
+    split_idx: Optional[int] = None
     # reward ensemble (CLIPRewardsMultiple, TPT/clip_reward.py:180-257): per-model weights round(w/sum(w),2), or the plain mean
     reward_weights: Optional[tuple] = None
     weighted_scores: bool = True
@@ -154,13 +158,13 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
     for j in range(hp.tta_steps):
         ctx = ctx.detach().requires_grad_(True)
         if selected is None:                                # tpt_cls_rl.py:57-59
-            logits_all = C.student_logits(student_sd, views, tokens, ctx, truncate)
+            logits_all = C.student_logits(student_sd, views, tokens, ctx, truncate, hp.ctx_position, hp.split_idx)
             output, selected = select_confident_samples(logits_all, hp.selection_p)
             with torch.no_grad():                           # clip_reward.py:130-137
                 rimg = reward_image_features(reward_sd, views[selected])
         else:                                               # tpt_cls_rl.py:55
             logits_all = None
-            output = C.student_logits(student_sd, views[selected], tokens, ctx, truncate)
+            output = C.student_logits(student_sd, views[selected], tokens, ctx, truncate, hp.ctx_position, hp.split_idx)
         bs = output.shape[0]
         _, index = torch.topk(output, hp.sample_k, dim=-1)  # :63
         flat = index.flatten()
@@ -184,7 +188,7 @@ def tta_sample(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor,
         ctx = new_ctx
         out[f"ctx_after_step{j + 1}"] = ctx.detach().clone()
     with torch.no_grad():                                   # tpt_cls_rl.py:260-262
-        final = C.student_logits(student_sd, views[:1], tokens, ctx.detach(), truncate)
+        final = C.student_logits(student_sd, views[:1], tokens, ctx.detach(), truncate, hp.ctx_position, hp.split_idx)
     out["ctx_after"] = ctx.detach().clone()
     out["final_logits"] = final
     out["top5"] = torch.topk(final, min(5, final.shape[1]), dim=-1).indices[0]

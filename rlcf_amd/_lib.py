@@ -77,6 +77,7 @@ SIGNATURES = {
     "rlcf_engine_load_weight": (I, [P, I, C.c_char_p, P, I64]),
     "rlcf_engine_finalize": (I, [P, P]),
     "rlcf_engine_set_class_bank": (I, [P, P, I, I, P, I, P]),
+    "rlcf_engine_set_class_bank_ex": (I, [P, P, I, I, P, I, P, P, P]),
     "rlcf_encode_image": (I, [P, I, P, I, P, P]),
     "rlcf_encode_image_resized": (I, [P, I, P, I, I, P, P]),
     "rlcf_text_features": (I, [P, P, P, P]),

@@ -283,6 +283,12 @@ int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C
     RLCF_ARG_CHECK(e && tokens_host && (ctx_init || n_ctx == 0));
     return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream);
 }
+int rlcf_engine_set_class_bank_ex(rlcf_engine* e, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
+                                  const int32_t* student_tokens_host, const int32_t* ctx_pos_host, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && tokens_host && ctx_init && student_tokens_host && ctx_pos_host && n_ctx > 0);
+    for (int i = 0; i < C * n_ctx; ++i) RLCF_ARG_CHECK(ctx_pos_host[i] >= 1 && ctx_pos_host[i] < e->model[RLCF_STUDENT].cfg.context_length);
+    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream, student_tokens_host, ctx_pos_host);
+}
 int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && which_ok(e, which) && images && feats);
     return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream);

@@ -26,6 +26,8 @@ struct TowerW {
 
 struct TextLayout {                  // packed token matrix of a class bank
     int T = 0, C = 0, n_seq = 0, max_q_len = 0, max_keys = 0, pre_rows = 0, lmax = 0, n_copies = 0, n_ctx = 0;
+    bool ctx_general = false;        // learnable rows at class-dependent positions (class_token_position 'front' / 'middle'): the ctx
+                                     // gradient is gathered by scanning ctx_row instead of through the fixed row lists
     DevBuf seqs, eot_rows, ctx_row, E, class_start, class_len, class_eot_off, ctx_rows_list;
     long tokens_total = 0;           // sum of rows that carry real tokens (FLOP accounting)
     long attn_pairs = 0;             // visible (query,key) pairs over all sequences
@@ -170,7 +172,8 @@ int engine_make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
 
 // engine internals used by api.hip
 int engine_finalize(rlcf_engine* e, int which, hipStream_t st);
-int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st);
+int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st,
+                          const int32_t* student_tokens = nullptr, const int32_t* ctx_pos = nullptr);
 int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, hipStream_t st, int in_res = 0);
 int engine_text_features(rlcf_engine* e, int which, const float* ctx, float* txt, hipStream_t st);
 int engine_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, hipStream_t st);

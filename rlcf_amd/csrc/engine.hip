@@ -716,8 +716,11 @@ static int upload(DevBuf& d, const std::vector<T>& v, hipStream_t st) {
 // Builds the packed layout of a class bank.  tokens: HOST [C, L] as clip.tokenize produces
 // (TPT/clip/clip.py:197-233); EOT = argmax id (custom_clip.py:71).  n_ctx > 0: rows 1..n_ctx of
 // every prompt are the learnable context (custom_clip.py:198-238).
+// ctx_pos (student only, HOST [C, n_ctx]): position of learnable vector k in prompt c when the class tokens are not at the END of the
+// prompt (PromptLearner.forward with class_token_position 'front' / 'middle', custom_clip.py:239-284); `tokens` then holds the token ids
+// in that re-arranged order (anything at the learnable positions).  NULL: learnable vector k sits at position 1 + k.
 static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32_t* tokens, int C, int n_ctx, bool has_ctx, int mode,
-                        hipStream_t st) {
+                        hipStream_t st, const int32_t* ctx_pos = nullptr) {
     const int CL = m.cfg.context_length, Wt = m.cfg.text_width;
     std::vector<int> eot(C);
     for (int c = 0; c < C; ++c) {
@@ -725,8 +728,16 @@ static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32
         for (int j = 1; j < CL; ++j) if (tokens[(size_t)c * CL + j] > tokens[(size_t)c * CL + best]) best = j;
         eot[c] = best;
     }
+    // which learnable vector (or -1) sits at position j of prompt c
+    auto ctx_at = [&](int c, int j) -> int {
+        if (!has_ctx) return -1;
+        if (!ctx_pos) return (j >= 1 && j <= n_ctx) ? j - 1 : -1;
+        for (int k = 0; k < n_ctx; ++k) if (ctx_pos[(size_t)c * n_ctx + k] == j) return k;
+        return -1;
+    };
+    const bool general = has_ctx && ctx_pos != nullptr;
     int pre = 0;
-    if (mode == RLCF_TEXT_SHARED) {
+    if (mode == RLCF_TEXT_SHARED && !general) {
         pre = 1 + n_ctx;
         bool ok = true;
         for (int c = 0; c < C && ok; ++c) {
@@ -737,13 +748,25 @@ static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32
             }
         }
         if (!ok) { pre = 0; mode = RLCF_TEXT_PACKED; }
+    } else if (mode == RLCF_TEXT_SHARED) {
+        // longest run of leading positions that is the same row for every class ('front': SOS only; 'middle': SOS + the first half of ctx)
+        int min_eot = CL;
+        for (int c = 0; c < C; ++c) min_eot = std::min(min_eot, eot[c]);
+        while (pre < min_eot) {
+            const int k0 = ctx_at(0, pre);
+            bool same = true;
+            for (int c = 1; c < C && same; ++c) same = ctx_at(c, pre) == k0 && (k0 >= 0 || tokens[(size_t)c * CL + pre] == tokens[pre]);
+            if (!same) break;
+            ++pre;
+        }
+        if (pre == 0) mode = RLCF_TEXT_PACKED;
     }
     std::vector<int32_t> row_token, row_pos, ctx_row, class_start(C), class_len(C), class_eot_off(C), eot_rows(C), ctx_list;
     std::vector<rlcf_seq> seqs;
     auto push_row = [&](int token, int pos_idx, int cr) { row_token.push_back(token); row_pos.push_back(pos_idx); ctx_row.push_back(cr); };
     for (int j = 0; j < pre; ++j) {
-        const bool is_ctx = has_ctx && j >= 1;
-        push_row(is_ctx ? -1 : tokens[j], j, is_ctx ? j - 1 : -1);
+        const int k = ctx_at(0, j);
+        push_row(k >= 0 ? -1 : tokens[j], j, k);
     }
     long pairs = 0;
     int lmax = 0;
@@ -755,20 +778,21 @@ static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32
         class_eot_off[c] = eot[c] - first;
         eot_rows[c] = class_start[c] + class_eot_off[c];
         for (int j = first; j <= last; ++j) {
-            const bool is_ctx = has_ctx && j >= 1 && j <= n_ctx;
-            push_row(is_ctx ? -1 : tokens[(size_t)c * CL + j], j, is_ctx ? j - 1 : -1);
+            const int k = ctx_at(c, j);
+            push_row(k >= 0 ? -1 : tokens[(size_t)c * CL + j], j, k);
         }
         seqs.push_back(rlcf_seq{class_start[c], class_len[c], 0, pre});
         lmax = std::max(lmax, class_len[c]);
         for (int i = 0; i < class_len[c]; ++i) pairs += pre + i + 1;
         L.tokens_total += class_len[c];
-        if (has_ctx && pre == 0) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(class_start[c] + 1 + j);
+        if (has_ctx && pre == 0 && !general) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(class_start[c] + 1 + j);
     }
     if (pre > 0) {
         seqs.push_back(rlcf_seq{0, pre, 0, 0});
         for (int i = 0; i < pre; ++i) pairs += i + 1;
-        if (has_ctx) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(1 + j);
+        if (has_ctx && !general) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(1 + j);
     }
+    L.ctx_general = general;
     L.T = (int)row_token.size(); L.C = C; L.n_seq = (int)seqs.size(); L.pre_rows = pre; L.lmax = lmax;
     L.max_q_len = std::max(lmax, pre); L.max_keys = pre + lmax; L.n_ctx = has_ctx ? n_ctx : 0;
     L.n_copies = has_ctx ? (pre > 0 ? 1 : C) : 0;
@@ -796,6 +820,7 @@ struct TextPassIO {
     const int32_t* eot_rows; const int32_t* row_src;
     float *eot_x, *eot_ln, *u, *inv_norm, *txt;
     int rep_rows = 0, ctx_stride = 0;      // replicated layout: one replica (and one prompt) per test sample
+    const int32_t* ctx_row_tab = nullptr;  // set when the layout has its learnable rows at class-dependent positions (TextLayout::ctx_general)
 };
 static int text_forward(rlcf_engine* e, ClipModel& m, const TextLayout& L, Tower& ws, const float* ctx, const TextPassIO& io, bool save,
                         hipStream_t st) {
@@ -819,7 +844,8 @@ static int text_backward(rlcf_engine* e, ClipModel& m, Tower& ws, const TextPass
     RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)io.T * Wt * sizeof(float), st));
     TRY(launch_scatter_rows(dxe, io.eot_rows, e->dX.as<float>(), io.n_cls, Wt, st));
     TRY(transformer_backward(e, m.txt, ws, io.seqs, io.n_seq, max_keys, io.attn_pairs, 1, io.T, st));
-    TRY(launch_ctx_grad(e->dX.as<float>(), ctx_rows_list, n_copies, n_ctx, Wt, dctx, st));
+    if (io.ctx_row_tab) TRY(launch_ctx_grad_scan(e->dX.as<float>(), io.row_src, io.ctx_row_tab, 1, io.T, n_ctx, Wt, dctx, st));
+    else TRY(launch_ctx_grad(e->dX.as<float>(), ctx_rows_list, n_copies, n_ctx, Wt, dctx, st));
     return RLCF_OK;
 }
 
@@ -829,10 +855,12 @@ static TextPassIO full_io(rlcf_engine* e, const TextLayout& L) {
     io.attn_pairs = L.attn_pairs; io.eot_rows = L.eot_rows.as<int32_t>(); io.row_src = nullptr;
     io.eot_x = e->eot_x.as<float>(); io.eot_ln = e->eot_ln.as<float>(); io.u = e->u.as<float>();
     io.inv_norm = e->inv_norm.as<float>(); io.txt = e->txt.as<float>();
+    io.ctx_row_tab = L.ctx_general ? L.ctx_row.as<int32_t>() : nullptr;
     return io;
 }
 
-int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st) {
+int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ctx, const float* ctx_init, int text_mode, hipStream_t st,
+                          const int32_t* student_tokens, const int32_t* ctx_pos) {
     ClipModel& s = e->model[RLCF_STUDENT];
     if (!s.finalized) { rlcf_set_error("student not finalized"); return RLCF_ERR_STATE; }
     // n_ctx == 0: a bank of plain texts without learnable rows (the caption bank of the retrieval task, the raw class prompts of
@@ -841,7 +869,8 @@ int engine_set_class_bank(rlcf_engine* e, const int32_t* tokens, int C, int n_ct
     RLCF_ARG_CHECK(text_mode >= RLCF_TEXT_DENSE && text_mode <= RLCF_TEXT_SHARED);
     e->text_mode = text_mode; e->n_ctx = n_ctx; e->C = C;
     const int Wt = s.cfg.text_width, D = s.cfg.embed_dim;
-    TRY(build_layout(e, s, e->lay[0], tokens, C, n_ctx, true, text_mode, st));
+    RLCF_ARG_CHECK((ctx_pos == nullptr) == (student_tokens == nullptr) && (!ctx_pos || n_ctx > 0));
+    TRY(build_layout(e, s, e->lay[0], ctx_pos ? student_tokens : tokens, C, n_ctx, true, text_mode, st, ctx_pos));
     int Tmax = e->lay[0].T, Wmax = Wt, Dmax = D;
     for (int m = 0; m < e->n_rewards; ++m) {
         ClipModel& r = e->model[RLCF_REWARD + m];
@@ -977,6 +1006,7 @@ static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_fe
     io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
     io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
     io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
+    io.ctx_row_tab = L.ctx_general ? L.ctx_row.as<int32_t>() : nullptr;
     TRY(text_forward(e, m, L, e->st, ctx, io, true, st));
     TRY(launch_dtxt_sparse(dlogits, cls, sel_feat, n_e, K, L.C, D, m.logit_scale_exp, e->sp_dtxt.as<float>(), st));
     TRY(text_backward(e, m, e->st, io, L.max_keys, e->sp_dtxt.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
@@ -1196,8 +1226,11 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
             RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wt * sizeof(float), st));
             TRY(launch_scatter_rows(e->sp_dxe.as<float>(), io.eot_rows, e->dX.as<float>(), nE, Wt, st));
             TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, L.max_keys, io.attn_pairs, 1, T, st));
-            TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
-                                        e->b_grad.as<float>(), st));
+            if (L.ctx_general)
+                TRY(launch_ctx_grad_scan(e->dX.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), B, gT, n_ctx, Wt, e->b_grad.as<float>(), st));
+            else
+                TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
+                                            e->b_grad.as<float>(), st));
         }
         // 5. AdamW step j+1 of every sample (tpt_cls_rl.py:76-79)
         TRY(launch_grad_nonfinite(e->b_grad.as<float>(), np, B, e->step_skip.as<int32_t>(), st));

@@ -70,6 +70,9 @@ int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const 
 int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il = 0);
 int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f, int il = 0);
 int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st);
+// the same by scanning: dctx[b, j] = sum of dX rows r of group b whose source row (row_src[r], or r itself) carries learnable vector j
+int launch_ctx_grad_scan(const float* dX, const int32_t* row_src, const int32_t* ctx_row, int groups, int group_rows, int n_ctx, int width,
+                         float* dctx, hipStream_t st);
 int launch_ctx_grad_grouped(const float* dX, const int32_t* ctx_rows, int n_copies, int n_ctx, int width, int groups, int group_rows,
                             float* dctx, hipStream_t st);
 int launch_replicate_layout(const rlcf_seq* seqs, int n_seq, const int32_t* eot_rows, int C, int T, int B, rlcf_seq* seqs_rep,

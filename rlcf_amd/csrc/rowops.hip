@@ -476,6 +476,29 @@ int launch_ctx_grad_grouped(const float* dX, const int32_t* ctx_rows, int n_copi
     return RLCF_OK;
 }
 
+// learnable rows at class-dependent positions ('front' / 'middle' class-token position, custom_clip.py:239-284): no fixed row lists —
+// every row of the group is looked up in ctx_row (through row_src for re-packed layouts); fixed summation order, deterministic
+__global__ void ctx_grad_scan_kernel(const float* __restrict__ dX, const int32_t* __restrict__ row_src, const int32_t* __restrict__ ctx_row,
+                                     int group_rows, int n_ctx, int width, float* __restrict__ dctx) {
+    const int j = blockIdx.y, b = blockIdx.z;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    const size_t base = (size_t)b * group_rows;
+    float s = 0.f;
+    for (int r = 0; r < group_rows; ++r) {
+        const int src = row_src ? row_src[base + r] : r;
+        if (src >= 0 && ctx_row[src] == j) s += dX[(base + r) * width + c];
+    }
+    dctx[((size_t)b * n_ctx + j) * width + c] = s;
+}
+int launch_ctx_grad_scan(const float* dX, const int32_t* row_src, const int32_t* ctx_row, int groups, int group_rows, int n_ctx, int width,
+                         float* dctx, hipStream_t st) {
+    RLCF_ARG_CHECK(dX && ctx_row && dctx && groups > 0 && group_rows > 0 && n_ctx > 0);
+    ctx_grad_scan_kernel<<<dim3((width + 63) / 64, n_ctx, groups), dim3(64), 0, st>>>(dX, row_src, ctx_row, group_rows, n_ctx, width, dctx);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
 // ---------------------------------------------------------------- d txt from d logits (dense)
 __global__ void dtxt_dense_kernel(const float* __restrict__ dlogits, const float* __restrict__ img, int n, int C, int D, float scale,
                                   float* __restrict__ dtxt) {

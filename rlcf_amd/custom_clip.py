@@ -20,9 +20,10 @@ class PromptLearner(nn.Module):
     def __init__(self, clip_model, classnames, batch_size=None, n_ctx=16, ctx_init=None, ctx_position="end",
                  learned_cls=False):
         super().__init__()
-        if batch_size is not None or learned_cls or ctx_position != "end":
-            raise NotImplementedError("batch-wise ctx, learned_cls and ctx_position != 'end' are not on the RLCF path "
-                                      "(never set by TPT/scripts/rlcf-*.sh)")
+        if batch_size is not None or learned_cls:
+            raise NotImplementedError("batch-wise ctx and learned_cls are not built (never set by TPT/scripts/rlcf-*.sh)")
+        if ctx_position not in ("end", "middle", "front"):
+            raise ValueError(ctx_position)
         self.clip_model = clip_model
         self.learned_cls, self.batch_size, self.class_token_position = learned_cls, batch_size, ctx_position
         sd = clip_model.state_dict
@@ -31,14 +32,18 @@ class PromptLearner(nn.Module):
         self.dtype = torch.float32
         if ctx_init:                                   # custom_clip.py:90-107
             ctx_init = ctx_init.replace("_", " ")
-            if "[CLS]" in ctx_init:
-                raise NotImplementedError("'[CLS]' (middle class-token position) is not on the RLCF path")
-            self.split_idx = None
+            if "[CLS]" in ctx_init:                    # custom_clip.py:92-97: the class tokens go where [CLS] stands
+                self.split_idx = ctx_init.split(" ").index("[CLS]")
+                ctx_init = ctx_init.replace("[CLS] ", "")
+                self.class_token_position = "middle"
+            else:
+                self.split_idx = None
             n_ctx = len(ctx_init.split(" "))
             prompt = clip_store.tokenize(ctx_init)
             ctx_vectors = sd["token_embedding.weight"][prompt[0, 1:1 + n_ctx].to(sd["token_embedding.weight"].device)].float()
             prompt_prefix = ctx_init
         else:                                          # custom_clip.py:108-112
+            self.split_idx = None
             ctx_vectors = torch.empty(n_ctx, self.ctx_dim)
             nn.init.normal_(ctx_vectors, std=0.02)
             prompt_prefix = " ".join(["X"] * n_ctx)
@@ -59,14 +64,40 @@ class PromptLearner(nn.Module):
         its cached step-0 text features follow."""
         self._ctx_init_state = value.detach().to(self.device, torch.float32).clone()
         if self.tokenized_prompts is not None:
-            runtime.SESSION.set_bank(self.tokenized_prompts, self.n_ctx, self._ctx_init_state)
+            self._publish_bank()
 
     def _set_classnames(self, classnames: List[str]) -> None:
         classnames = [name.replace("_", " ") for name in classnames]
         prompts = [self.prompt_prefix + " " + name + "." for name in classnames]
         self.tokenized_prompts = clip_store.tokenize(prompts).to(self.device)      # custom_clip.py:154
         self.n_cls, self.classnames = len(classnames), classnames
-        runtime.SESSION.set_bank(self.tokenized_prompts, self.n_ctx, self.ctx_init_state)
+        # name_lens (custom_clip.py:127): tokens between the context words and the final '.', read off the tokenised prompt
+        eot = self.tokenized_prompts.argmax(dim=-1)
+        self.name_lens = [int(e) - 1 - self.n_ctx - 1 for e in eot]
+        self._publish_bank()
+
+    def _arrangement(self):
+        """-> (student_tokens [C, L], ctx_pos [C, n_ctx]) for class_token_position 'front' / 'middle' (custom_clip.py:239-284): the
+        token ids in the order PromptLearner.forward concatenates the pieces, and where each learnable vector lands; None for 'end'."""
+        if self.class_token_position == "end":
+            return None, None
+        tok = self.tokenized_prompts.cpu()
+        C, n = tok.shape[0], self.n_ctx
+        half = (self.split_idx if self.split_idx is not None else n // 2) if self.class_token_position == "middle" else 0
+        stok, pos = tok.clone(), torch.zeros(C, n, dtype=torch.int64)
+        for i in range(C):
+            nl = self.name_lens[i]
+            cls_ids = tok[i, 1 + n: 1 + n + nl]
+            stok[i, 1 + half: 1 + half + nl] = cls_ids                       # [SOS | ctx[:half] | class | ctx[half:] | rest]
+            stok[i, 1: 1 + half] = 0
+            stok[i, 1 + half + nl: 1 + n + nl] = 0
+            pos[i, :half] = torch.arange(1, 1 + half)
+            pos[i, half:] = torch.arange(1 + half + nl, 1 + n + nl)
+        return stok, pos
+
+    def _publish_bank(self) -> None:
+        stok, pos = self._arrangement()
+        runtime.SESSION.set_bank(self.tokenized_prompts, self.n_ctx, self.ctx_init_state, stok, pos)
 
     def reset(self):                                   # custom_clip.py:161-167
         self.ctx.data.copy_(self.ctx_init_state)
@@ -78,8 +109,14 @@ class PromptLearner(nn.Module):
         """Materialised prompts [C, 77, W] = [SOS | ctx | class tokens . EOS pad] (custom_clip.py:198-238).
         The HIP text tower never needs this tensor; provided for API completeness."""
         ctx = init if init is not None else self.ctx
-        emb = self.clip_model.state_dict["token_embedding.weight"].to(ctx.device)[self.tokenized_prompts]
-        return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(self.n_cls, -1, -1), emb[:, 1 + self.n_ctx:]], dim=1)
+        table = self.clip_model.state_dict["token_embedding.weight"].to(ctx.device)
+        stok, pos = self._arrangement()
+        if stok is None:
+            emb = table[self.tokenized_prompts]
+            return torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(self.n_cls, -1, -1), emb[:, 1 + self.n_ctx:]], dim=1)
+        emb = table[stok.to(ctx.device)].clone()
+        emb[torch.arange(self.n_cls)[:, None], pos.to(ctx.device)] = ctx.unsqueeze(0).expand(self.n_cls, -1, -1)
+        return emb
 
 
 class TextEncoder(nn.Module):

@@ -119,8 +119,20 @@ class Engine:
         L.check(self.lib.rlcf_engine_set_reward_mix(self.h, w, len(ws), 1 if mean else 0), "set_reward_mix")
 
     def set_class_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor,
-                       text_mode: int = L.TEXT_SHARED) -> None:
+                       text_mode: int = L.TEXT_SHARED, student_tokens: Optional[torch.Tensor] = None,
+                       ctx_pos: Optional[torch.Tensor] = None) -> None:
+        """student_tokens / ctx_pos: class tokens not at the end of the prompt (PromptLearner 'front' / 'middle'), see
+        rlcf_engine_set_class_bank_ex."""
         tok = np.ascontiguousarray(tokens.detach().cpu().numpy().astype(np.int32))
+        if ctx_pos is not None:
+            ci = ctx_init.detach().to(self.device, torch.float32).contiguous()
+            stok = np.ascontiguousarray(student_tokens.detach().cpu().numpy().astype(np.int32))
+            cp = np.ascontiguousarray(ctx_pos.detach().cpu().numpy().astype(np.int32))
+            assert stok.shape == tok.shape and cp.shape == (tok.shape[0], n_ctx)
+            L.check(self.lib.rlcf_engine_set_class_bank_ex(self.h, tok.ctypes.data, tok.shape[0], n_ctx, ci.data_ptr(), text_mode,
+                                                           stok.ctypes.data, cp.ctypes.data, _stream()), "set_class_bank_ex")
+            self.n_cls, self.n_ctx = tok.shape[0], n_ctx
+            return
         ci = ctx_init.detach().to(self.device, torch.float32).contiguous() if n_ctx > 0 else None      # n_ctx = 0: plain texts (caption bank)
         L.check(self.lib.rlcf_engine_set_class_bank(self.h, tok.ctypes.data, tok.shape[0], n_ctx, ci.data_ptr() if ci is not None else None,
                                                     text_mode, _stream()), "set_class_bank")

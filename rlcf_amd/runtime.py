@@ -23,6 +23,7 @@ class Session:
         self.reward_mix = None       # ensemble weights (None: single model)
         self.reward_mean = False
         self.tokens: Optional[torch.Tensor] = None
+        self.student_tokens = self.ctx_pos = None
         self.n_ctx = 0
         self.ctx_init: Optional[torch.Tensor] = None
         self.max_views = int(os.environ.get("RLCF_MAX_VIEWS", "64"))
@@ -46,8 +47,9 @@ class Session:
     def set_rewards(self, ckpts, weights, mean: bool):
         self.rewards, self.reward_mix, self.reward_mean = list(ckpts), [float(w) for w in weights], bool(mean)
 
-    def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor):
+    def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor, student_tokens=None, ctx_pos=None):
         self.tokens, self.n_ctx, self.ctx_init = tokens.detach().cpu(), n_ctx, ctx_init.detach().clone()
+        self.student_tokens, self.ctx_pos = student_tokens, ctx_pos       # class tokens not at the end of the prompt ('front' / 'middle')
         self._bank_version += 1
 
     def engine(self, n_views: int = 1) -> Engine:
@@ -72,7 +74,8 @@ class Session:
         if self.tokens is not None:
             bkey = (self._bank_version, self.text_mode)       # a counter, not id()/checksums: no stale bank, no device sync per call
             if bkey != self._bank_applied:
-                self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode)
+                self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode, getattr(self, "student_tokens", None),
+                                            getattr(self, "ctx_pos", None))
                 self._bank_applied = bkey
         return self._engine
 

@@ -114,8 +114,12 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     install_models(ref, {student: (s_geo, s_sd)})
     bank = Bank(s_geo, n_cls, n_ctx)
     ref.custom.tokenize = bank.tokenize
+    # name_lens of the reference come from its BPE tokenizer (custom_clip.py:127); the synthetic bank's class names have the length the
+    # token bank gives them: 'front' / 'middle' prompts split the suffix there
+    ref.custom._tokenizer = types.SimpleNamespace(
+        encode=lambda name: [0] * (int(bank.tokens[int(name.split("c")[-1])].argmax()) - 1 - n_ctx - 1))
     model = ref.custom.ClipTestTimeTuning("cpu", bank.classnames, None, arch=student, n_ctx=n_ctx,
-                                          ctx_init="a_photo_of_a")
+                                          ctx_init=hp.get("ctx_init", "a_photo_of_a"), ctx_position=hp.get("ctx_position", "end"))
     for name, p in model.named_parameters():
         if "prompt_learner" not in name:
             p.requires_grad_(False)
@@ -379,6 +383,7 @@ LN_CASES = {
     "ln_small_s1": ("small", "small", 16, 40, dict(lr=1e-3, selection_p=0.25)),
     "ln_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-4)),
     "ln_l14_n8": ("ViT-L/14", "ViT-L/14", 8, 1000, dict(lr=1e-4)),          # BASELINE configs[2] geometry (N=8)
+    "ln_l14_n64": ("ViT-L/14", "ViT-L/14", 64, 1000, dict(lr=1e-4, selection_p=0.1)),   # BASELINE configs[2] at FULL size: N=64 views, 6 selected
 }
 
 
@@ -417,6 +422,10 @@ TTA_CASES = {
     # ModifiedResNet towers: as the reward model (with the bicubic resolution change) and as the frozen student image encoder
     "tta_tiny_rnreward": ("tiny", "tiny-rn", 8, 16, dict(view_seed=RN_SEED)),
     "tta_tiny_rnstudent": ("tiny-rn32", "tiny-r", 8, 16, dict(view_seed=RN_SEED)),
+    # class tokens not at the end of the prompt (PromptLearner.forward 'front' / 'middle', '[CLS]' inside ctx_init: custom_clip.py:92-97,239-284)
+    "tta_tiny_front": ("tiny", "tiny-r", 8, 16, dict(ctx_position="front")),
+    "tta_tiny_middle": ("tiny", "tiny-r", 8, 16, dict(ctx_position="middle", tta_steps=2)),
+    "tta_tiny_cls1": ("tiny", "tiny-r", 8, 16, dict(ctx_init="a_[CLS]_photo_of_a")),
     "tta_b16_n8": ("ViT-B/16", "ViT-B/16", 8, 1000, {}),
     # the setting of TPT/scripts/rlcf-prompt.sh: ViT-B/16 student, ViT-L/14 reward model, 3 tuning steps
     "tta_b16_rl14_s3": ("ViT-B/16", "ViT-L/14", 8, 1000, dict(tta_steps=3, view_seed=B16L14_SEED)),
@@ -424,9 +433,11 @@ TTA_CASES = {
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
 }
 GROUPS = {
-    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k and "_rn" not in k],
+    "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k and "_rn" not in k
+             and k not in ("tta_tiny_front", "tta_tiny_middle", "tta_tiny_cls1")],
     "rn": ["tta_tiny_ensrn", "tta_tiny_rnreward", "tta_tiny_rnstudent"],
     "rres": ["tta_tiny_rres"],
+    "ctxpos": ["tta_tiny_front", "tta_tiny_middle", "tta_tiny_cls1"],
     "ens": ["tta_tiny_ens", "tta_tiny_ensmean"],
     "small": ["tta_small_s1"],
     "b16n8": ["tta_b16_n8"],
@@ -554,8 +565,9 @@ def main():
                 save(name, arrays, meta)
                 print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
                       f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")
-        elif grp in ("ln", "lnb16", "lnl14"):
-            for name in ([k for k in LN_CASES if "b16" not in k and "l14" not in k] if grp == "ln" else ["ln_b16_n8"] if grp == "lnb16" else ["ln_l14_n8"]):
+        elif grp in ("ln", "lnb16", "lnl14", "lnl14n64"):
+            for name in ([k for k in LN_CASES if "b16" not in k and "l14" not in k] if grp == "ln" else ["ln_b16_n8"] if grp == "lnb16" else
+                         ["ln_l14_n8"] if grp == "lnl14" else ["ln_l14_n64"]):
                 student, reward, n, c, over = LN_CASES[name]
                 hp = dict(BASE_HP, **over)
                 arrays = run_reference_ln(ref, student, reward, n, c, hp)

@@ -340,7 +340,27 @@ def test_text_features_vs_oracle(L, dev, mode, geo, n_cls):
 
 
 TTA_FIXTURES = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
-                "tta_small_s1", "tta_tiny_rres", "tta_tiny_rnreward", "tta_tiny_rnstudent"]
+                "tta_small_s1", "tta_tiny_rres", "tta_tiny_rnreward", "tta_tiny_rnstudent", "tta_tiny_front", "tta_tiny_middle", "tta_tiny_cls1"]
+
+
+def _ctx_arrangement(meta, tokens):
+    """(student_tokens, ctx_pos) of a fixture whose class tokens are not at the end of the prompt (None, None otherwise): what
+    rlcf_amd.custom_clip.PromptLearner._arrangement hands to rlcf_engine_set_class_bank_ex."""
+    ci = str(meta.get("ctx_init", "a_photo_of_a")).replace("_", " ")
+    position, split = ("middle", ci.split(" ").index("[CLS]")) if "[CLS]" in ci else (str(meta.get("ctx_position", "end")), None)
+    if position == "end":
+        return None, None
+    n = meta["n_ctx"]
+    half = (split if split is not None else n // 2) if position == "middle" else 0
+    stok, pos = tokens.clone(), torch.zeros(tokens.shape[0], n, dtype=torch.int64)
+    for i in range(tokens.shape[0]):
+        nl = int(tokens[i].argmax()) - 1 - n - 1
+        stok[i, 1 + half: 1 + half + nl] = tokens[i, 1 + n: 1 + n + nl]
+        stok[i, 1: 1 + half] = 0
+        stok[i, 1 + half + nl: 1 + n + nl] = 0
+        pos[i, :half] = torch.arange(1, 1 + half)
+        pos[i, half:] = torch.arange(1 + half + nl, 1 + n + nl)
+    return stok, pos
 
 
 def _cfg_from_meta(meta, sparse=True):
@@ -392,10 +412,22 @@ def test_tta_sample_matches_reference_fixture(L, dev, name, sparse, mode, prec):
     g, meta = load_golden(name)
     eng, ssd, rsd, tokens, ctx0 = make_engine((meta["student"], meta["reward"]), meta["n_views"], meta["n_cls"], mode,
                                               meta["student_seed"], meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=prec)
+    stok, pos = _ctx_arrangement(meta, tokens)
+    if pos is not None:                 # class tokens in front of / inside the context: rlcf_engine_set_class_bank_ex
+        eng.set_class_bank(tokens, meta["n_ctx"], ctx0, mode, stok, pos)
     views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution)
     o = eng.tta_sample(views.to(dev), _cfg_from_meta(meta, sparse))
     torch.cuda.synchronize()
     _check_against(o, g, meta)
+    if pos is not None:                 # ... and through the sample-batched call (per-sample prompt copies, scanned ctx gradient)
+        big, *_ = make_engine((meta["student"], meta["reward"]), meta["n_views"] * 2, meta["n_cls"], mode, meta["student_seed"],
+                              meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=prec)
+        big.set_class_bank(tokens, meta["n_ctx"], ctx0, mode, stok, pos)
+        top5, fl = big.tta_batch(torch.stack([views, views]).to(dev), _cfg_from_meta(meta, True), want_logits=True)
+        for b in range(2):
+            assert top5[b].cpu().tolist() == g["top5"].tolist()
+            torch.testing.assert_close(fl[b].cpu(), g["final_logits"][0], atol=1e-3, rtol=0)
+        big.close()
     eng.close()
 
 
@@ -691,7 +723,11 @@ def _harness_objects(dev, meta):
                                  weighted_scores=meta.get("weighted_scores", 1), sample_k=meta["sample_k"],
                                  reward_amplify=meta.get("reward_amplify", False), reward_process=True,
                                  process_batch=meta.get("process_batch", False))
-    model = custom_clip.get_coop(meta["student"], "I", dev, meta["n_ctx"], "a_photo_of_a", classnames=bank.classnames)
+    if str(meta.get("ctx_position", "end")) != "end":   # (get_coop has no ctx_position argument: the constructor it wraps does)
+        model = custom_clip.ClipTestTimeTuning(dev, bank.classnames, None, arch=meta["student"], n_ctx=meta["n_ctx"], ctx_init="a_photo_of_a",
+                                               ctx_position=str(meta["ctx_position"]))
+    else:
+        model = custom_clip.get_coop(meta["student"], "I", dev, meta["n_ctx"], str(meta.get("ctx_init", "a_photo_of_a")), classnames=bank.classnames)
     for name, p in model.named_parameters():            # tpt_cls_rl.py:103-105
         if "prompt_learner" not in name:
             p.requires_grad_(False)
@@ -703,7 +739,7 @@ def _harness_objects(dev, meta):
     return model, optimizer, optim_state, reward_model, args
 
 
-@pytest.mark.parametrize("name", ["tta_tiny_s1", "tta_tiny_s3", "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean",
+@pytest.mark.parametrize("name", ["tta_tiny_front", "tta_tiny_middle", "tta_tiny_cls1", "tta_tiny_s1", "tta_tiny_s3", "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean",
                                   "tta_tiny_ensrn", "tta_tiny_rnreward", "tta_tiny_rnstudent"])
 def test_reference_harness_runs_on_the_hip_path(L, dev, name):
     """The reference's main_worker/test_time_adapt_eval call sequence (tpt_cls_rl.py:94-190,219-279) with this

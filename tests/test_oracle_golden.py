@@ -27,7 +27,17 @@ def hyper(meta):
                       process_batch=bool(meta.get("process_batch", False)),
                       min_entropy_reg=bool(meta.get("min_entropy_reg", 0)),
                       min_entropy_w=float(meta.get("min_entropy_w", 0.2)),
-                      weighted_scores=bool(meta.get("weighted_scores", 1)))
+                      weighted_scores=bool(meta.get("weighted_scores", 1)),
+                      ctx_position=_ctx_position(meta)[0], split_idx=_ctx_position(meta)[1])
+
+
+def _ctx_position(meta):
+    """(class_token_position, split_idx) the reference derives from its arguments (custom_clip.py:92-97): '[CLS]' inside ctx_init
+    forces 'middle' with the split where it stood."""
+    ci = str(meta.get("ctx_init", "a_photo_of_a")).replace("_", " ")
+    if "[CLS]" in ci:
+        return "middle", ci.split(" ").index("[CLS]")
+    return str(meta.get("ctx_position", "end")), None
 
 
 def run_oracle(meta, truncate=False, weights=None):
@@ -48,7 +58,7 @@ def run_oracle(meta, truncate=False, weights=None):
 
 TINY = ["tta_tiny_s1", "tta_tiny_s3", "tta_tiny_amplify", "tta_tiny_batchproc", "tta_tiny_minent", "tta_tiny_k1",
         "tta_small_s1", "tta_tiny_rres", "tta_tiny_ens", "tta_tiny_ensmean", "tta_tiny_ensrn", "tta_tiny_rnreward",
-        "tta_tiny_rnstudent"]
+        "tta_tiny_rnstudent", "tta_tiny_front", "tta_tiny_middle", "tta_tiny_cls1"]
 
 
 @pytest.mark.parametrize("name", TINY)
