@@ -832,7 +832,7 @@ def test_autograd_route_matches_reference_gradient(L, dev, name):
 
 # ------------------------------------------------------------------------------ LayerNorm-tuning path (BASELINE configs[2])
 @pytest.mark.parametrize("prec", [0, 2])
-@pytest.mark.parametrize("name", ["ln_tiny_s1", "ln_tiny_s3", "ln_small_s1", "ln_b16_n8", "ln_l14_n8"])
+@pytest.mark.parametrize("name", ["ln_tiny_s1", "ln_tiny_s3", "ln_small_s1", "ln_b16_n8", "ln_l14_n8", "ln_l14_n64"])     # ln_l14_n64 = BASELINE configs[2] at full size
 def test_ln_tuning_matches_reference_fixture(L, dev, name, prec):
     """rlcf_tta_sample_ln vs the reference's CLIPCLS_TTA(only_norm=True) + test_time_tuning run (TPT/tune_cls_rl.py)."""
     if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):

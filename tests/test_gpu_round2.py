@@ -434,3 +434,25 @@ def test_retrieval_text_to_image_loss_matches_reference_fixture(L, dev, name):
     torch.testing.assert_close(o["rewards"].cpu(), g["rewards"].reshape(-1), atol=1e-5, rtol=1e-3)
     torch.testing.assert_close(o["loss"].cpu()[0], g["loss"], atol=1e-7, rtol=1e-3)
     torch.testing.assert_close(o["dlogits"].cpu(), g["dlogits"], atol=1e-7, rtol=1e-3)
+
+
+def test_ln_batch_matches_reference_at_full_size_l14_n64(L, dev):
+    """BASELINE configs[2] at FULL size (ViT-L/14 + ViT-L/14, N = 64 views, C = 1000, LayerNorm tuning) through the sample-batched call
+    rlcf_tta_batch_ln, two copies of the reference's sample per pass: top-5 and final logits of the reference's own run (ln_l14_n64)."""
+    from rlcf_amd.engine import Engine
+    g, meta = load_golden("ln_l14_n64")
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    eng = Engine(sg, rg, meta["n_views"] * 2, meta["n_cls"], L.PREC_F16X3)
+    eng.load_state_dict(L.STUDENT, synth.make_state_dict(sg, meta["student_seed"], device=dev))
+    eng.load_state_dict(L.REWARD, synth.make_state_dict(rg, meta["reward_seed"], device=dev))
+    eng.finalize()
+    ssd_tok = synth.make_state_dict(sg, meta["student_seed"])["token_embedding.weight"]
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd_tok[torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]))].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution, device=dev)
+    top5, fl = eng.tta_batch_ln(torch.stack([views, views]), _cfg_from_meta(meta), want_logits=True)
+    for b in range(2):
+        assert top5[b].cpu().tolist() == g["top5"].tolist()
+        torch.testing.assert_close(fl[b].cpu(), g["final_logits"][0], atol=1e-3, rtol=0)
+    eng.close()
