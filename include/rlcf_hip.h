@@ -303,10 +303,35 @@ int rlcf_tta_sample_visual(rlcf_engine*, const float* views, int N, const rlcf_t
  * image encoder -> AdamW over clip_model.visual.parameters(), and out->final_logits = logits_per_image[0] of the tuned encoder.
  * It is rlcf_tta_sample_visual with every image selected (the classification path picks int(N * selection_p) views): same kernels,
  * same outputs (out->topk_idx [n,K], clip_score, rewards, loss, ln_* / vis_* vectors).  K = sample_k <= 32 (scripts: 20).
- * The text -> image direction (tune_text, :106-137) tunes the TEXT encoder, which is not built; its loss arithmetic (CLIPScore with
- * images_index, baseline, CE over the image bank) is rlcf_reward_loss with the roles of the two banks exchanged. */
+ * The text -> image direction (tune_text, :106-137) is rlcf_tta_retrieval_text below. */
 int rlcf_tta_retrieval_image(rlcf_engine*, const float* images, int n, const rlcf_tta_args* args, const rlcf_tta_out* out,
                              rlcf_stream stream);
+/* Text -> image retrieval with test-time adaptation of the TEXT encoder: `tune_text` of retrieval/clip_ret_policy.py:106-137 with
+ * CLIPRet_TTA(only_visual=False) (retrieval/custom_models.py:139-147: parameters() = every parameter whose name has no 'visual' —
+ * token_embedding.weight, positional_embedding, the text transformer, ln_final, text_projection, logit_scale), followed by the
+ * evaluation step of its loop (:193-196: logits_per_text of the tuned model, reset).
+ * rlcf_engine_set_image_bank: the bank of n images — their L2-normalised features under the student [n, D]
+ * (CLIPRet_TTA.set_image_features, custom_models.py:91-95) and under every reward model, blocks [n, Dr_m] one after another
+ * (CLIPRewards.set_image_features, retrieval/clip_reward.py:130-137); device pointers, copied.  It replaces the class / caption bank
+ * (the prompt, LayerNorm and image-encoder calls then refuse until rlcf_engine_set_class_bank is called again).
+ * rlcf_tta_retrieval_text: tokens_host = HOST [context_length], ONE query caption (bs = 1 in the reference).  Per step:
+ * logits_per_text [1, n] = exp(logit_scale) * text_features @ bank^T -> top-K images -> CLIPScore(images_index) of the reward models
+ * -> baseline -> mean(r * CE) -> backward through the text encoder -> AdamW (inf / NaN gradients skip the step).
+ * Outputs: out->logits [n], topk_idx [K], clip_score [K], rewards [K], loss, dlogits [n], reward_image_features [Dr_0] (= the
+ * reward model's features of the QUERY TEXT) of the first step; out->vis_grad / vis_after = the flat text parameter vector
+ * (rlcf_engine_text_param_layout: token_embedding.weight, positional_embedding, text_projection, per block in_proj_weight,
+ * in_proj_bias, out_proj.weight, out_proj.bias, c_fc.weight, c_fc.bias, c_proj.weight, c_proj.bias, then logit_scale; slots
+ * 64-float aligned), out->ln_grad / ln_after = [ln_final.weight | ln_final.bias | per block ln_1.weight ln_1.bias ln_2.weight
+ * ln_2.bias]; out->final_logits [n]; out->step_skipped [tta_steps].  The engine is left in its pristine state. */
+int rlcf_engine_set_image_bank(rlcf_engine*, const float* student_feats, const float* reward_feats, int n, rlcf_stream stream);
+int rlcf_tta_retrieval_text(rlcf_engine*, const int32_t* tokens_host, const rlcf_tta_args* args, const rlcf_tta_out* out,
+                            rlcf_stream stream);
+/* floats in the flat text vector (padding included; 0 + error on failure); *ln_count (optional) = floats of the LayerNorm vector */
+int64_t rlcf_engine_text_param_count(rlcf_engine*, int* ln_count, rlcf_stream stream);
+/* offsets / element counts of its 3 + 8*layers + 1 tensors in the order above; returns the number of tensors (or a negative error) */
+int rlcf_engine_text_param_layout(rlcf_engine*, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream);
+/* copy the flat vector and / or the LayerNorm vector out (either pointer may be NULL): which = 0 live, 1 reset state */
+int rlcf_engine_get_text_params(rlcf_engine*, float* flat, float* ln, int which, rlcf_stream stream);
 /* floats in the flat vector (padding included); 0 + error for a ModifiedResNet student */
 int64_t rlcf_engine_visual_param_count(rlcf_engine*, rlcf_stream stream);
 /* offsets / element counts of its 4 + 8*layers tensors in the order above; returns the number of tensors (or a negative error) */

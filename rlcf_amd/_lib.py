@@ -99,6 +99,11 @@ SIGNATURES = {
     "rlcf_tta_sample_ln": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_retrieval_image": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
     "rlcf_tta_sample_visual": (I, [P, P, I, C.POINTER(TTAArgs), C.POINTER(TTAOut), P]),
+    "rlcf_engine_set_image_bank": (I, [P, P, P, I, P]),
+    "rlcf_tta_retrieval_text": (I, [P, P, P, P, P]),
+    "rlcf_engine_text_param_count": (I64, [P, P, P]),
+    "rlcf_engine_text_param_layout": (I, [P, P, P, I, P]),
+    "rlcf_engine_get_text_params": (I, [P, P, P, I, P]),
     "rlcf_engine_visual_param_count": (I64, [P, P]),
     "rlcf_engine_visual_param_layout": (I, [P, P, P, I, P]),
     "rlcf_engine_get_visual_params": (I, [P, P, I, P]),

@@ -1,11 +1,12 @@
-"""Host-side mirror of the RLCF retrieval policy, image -> text direction: `tune_image` (retrieval/clip_ret_policy.py:76-103),
-`CLIPRet_TTA` with only_visual=True (retrieval/custom_models.py:29-163) and the retrieval `CLIPRewards` surface
-(retrieval/clip_reward.py:107-222: text_features / image_features, CLIPScore(text_index=..., images_index=..., pairwise=...)).
-Same signatures; the arithmetic is one call into the HIP engine (rlcf_tta_retrieval_image), whose caption bank is a class bank
-without learnable rows (rlcf_engine_set_class_bank, n_ctx = 0).
-
-The text -> image direction (`tune_text`, :106-137) tunes the TEXT encoder, which the engine does not build: `CLIPRet_TTA(only_visual=
-False)` raises; its loss arithmetic is available as `text2image_loss` (rlcf_reward_loss with the two banks exchanged)."""
+"""Host-side mirror of the RLCF retrieval policy: `tune_image` / `tune_text` (retrieval/clip_ret_policy.py:76-137), `CLIPRet_TTA`
+(retrieval/custom_models.py:29-163) and the retrieval `CLIPRewards` surface (retrieval/clip_reward.py:107-222: text_features /
+image_features, CLIPScore(text_index=..., images_index=..., pairwise=...)).  Same signatures; the arithmetic is one call into the HIP
+engine per query:
+  image -> text  (only_visual=True):  rlcf_tta_retrieval_image over a caption bank = a class bank without learnable rows
+                                       (rlcf_engine_set_class_bank, n_ctx = 0); the image encoder is tuned;
+  text -> image  (only_visual=False): rlcf_tta_retrieval_text over an image bank (rlcf_engine_set_image_bank); every non-visual
+                                       parameter (embeddings, text transformer, ln_final, text_projection, logit_scale) is tuned.
+`text2image_loss` is the loss section of tune_text alone (rlcf_reward_loss with the two banks exchanged)."""
 from __future__ import annotations
 
 from typing import List, Optional
@@ -20,13 +21,14 @@ from .engine import TTAConfig
 
 
 class CLIPRet_TTA(nn.Module):
-    """retrieval/custom_models.py:29-163.  `parameters()` = [LayerNorm vector, flat vector of every other visual tensor]
-    (Engine.visual_layout()), as rlcf_amd.custom_clip.CLIPCLS_TTA(only_norm=False)."""
+    """retrieval/custom_models.py:29-163.  only_visual=True: `parameters()` = [LayerNorm vector, flat vector of every other visual
+    tensor] (Engine.visual_layout()), as rlcf_amd.custom_clip.CLIPCLS_TTA(only_norm=False).  only_visual=False: [text LayerNorm vector,
+    flat vector of every other non-visual tensor] (Engine.text_layout())."""
 
     def __init__(self, device, arch="ViT-B-16", only_visual=True, momentum_update=False, update_freq=256, update_w=1.0, momentum=0.9999):
         super().__init__()
-        if not only_visual:
-            raise NotImplementedError("text -> image retrieval tunes the text encoder (custom_models.py:148-153): not built")
+        if not only_visual and momentum_update:
+            raise NotImplementedError("momentum_update of the text side (custom_models.py:128-143): not built")
         self.clip_model, _, _ = clip_store.load(arch, device=device)
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.only_visual, self.momentum_update = device, only_visual, momentum_update
@@ -34,7 +36,7 @@ class CLIPRet_TTA(nn.Module):
         self.text_features = None
         self.image_features = None
         self._ln = self._vis = None
-        self._tuned = None           # (ln, vis) of the last tune_image call, until reset_initial()
+        self._tuned_query = None     # (tokens, logits_per_text of the tuned text encoder) of the last tune_text call, until reset_initial()
 
     # the caption bank: tokens go to the engine once (model.set_text_features + reward_model.set_many_text_features, :150-156)
     def set_text_bank(self, texts: Optional[List[str]] = None, tokenized_prompts: Optional[torch.Tensor] = None):
@@ -53,18 +55,30 @@ class CLIPRet_TTA(nn.Module):
     def get_image_features(self, images):
         return runtime.SESSION.engine(images.shape[0]).encode_image(L.STUDENT, images)
 
+    def set_image_features(self, images=None, image_features=None):              # custom_models.py:91-95
+        if images is not None:
+            step = runtime.SESSION.max_views
+            image_features = torch.cat([self.get_image_features(images[i: i + step]) for i in range(0, images.shape[0], step)])
+        self.image_features = image_features
+
+    def _fetch(self):
+        eng = runtime.SESSION.engine()
+        if self.only_visual:
+            self._ln_init, self._vis_init = eng.ln_params(pristine=True), eng.visual_params(1)
+        else:
+            self._vis_init, self._ln_init = eng.text_params(1)
+        self._ln, self._vis = nn.Parameter(self._ln_init.clone()), nn.Parameter(self._vis_init.clone())
+
     @property
-    def ln(self):
+    def ln(self):                # LayerNorm vector of the tuned side
         if self._ln is None:
-            self._ln_init = runtime.SESSION.engine().ln_params(pristine=True)
-            self._ln = nn.Parameter(self._ln_init.clone())
+            self._fetch()
         return self._ln
 
     @property
-    def vis(self):
+    def vis(self):               # flat vector of every other tuned tensor (visual tensors, or the non-visual ones with only_visual=False)
         if self._vis is None:
-            self._vis_init = runtime.SESSION.engine().visual_params(1)
-            self._vis = nn.Parameter(self._vis_init.clone())
+            self._fetch()
         return self._vis
 
     def parameters(self, recurse: bool = True):
@@ -74,6 +88,7 @@ class CLIPRet_TTA(nn.Module):
     def reset_initial(self):                                # custom_models.py:124-126
         self.ln.data.copy_(self._ln_init)
         self.vis.data.copy_(self._vis_init)
+        self._tuned_query = None
 
     @torch.no_grad()
     def momentum_update_model(self):                        # custom_models.py:128-143
@@ -91,7 +106,9 @@ class CLIPRet_TTA(nn.Module):
 
     @torch.no_grad()
     def forward(self, images=None, text=None, tokenized_prompts=None):
-        """(logits_per_image, logits_per_text) with the current (possibly tuned) image encoder, custom_models.py:66-75."""
+        """(logits_per_image, logits_per_text) with the current (possibly tuned) encoder, custom_models.py:66-75."""
+        if not self.only_visual:
+            return self._forward_text(text, tokenized_prompts)
         if text is not None or tokenized_prompts is not None:
             self.set_text_bank(text, tokenized_prompts)
         eng = runtime.SESSION.engine(images.shape[0])
@@ -104,6 +121,22 @@ class CLIPRet_TTA(nn.Module):
             eng.set_ln_params(self._ln_init)
             eng.set_visual_params(self._vis_init)
         return per_image, per_image.t()
+
+    def _forward_text(self, text, tokenized_prompts):
+        """text -> image: logits of ONE query caption against the image bank given to set_image_features (the reference's call shape
+        `model(images=None, text=text)`, clip_ret_policy.py:122,194).  With tuned parameters only the query they were tuned on can
+        be scored (the engine holds tuned text weights only inside rlcf_tta_retrieval_text)."""
+        tok = (clip_store.tokenize(text) if tokenized_prompts is None else tokenized_prompts).reshape(-1, self.clip_model.geometry.context_length)
+        if tok.shape[0] != 1:
+            raise NotImplementedError("text -> image scoring takes one query caption per call (bs = 1, clip_ret_policy.py:112)")
+        adapted = not (torch.equal(self.ln.data, self._ln_init) and torch.equal(self.vis.data, self._vis_init))
+        if adapted:
+            if self._tuned_query is None or not torch.equal(self._tuned_query[0], tok.cpu()):
+                raise NotImplementedError("tuned text parameters score the caption they were tuned on; call reset_initial() first")
+            per_text = self._tuned_query[1]
+        else:
+            per_text = runtime.SESSION.engine().tta_retrieval_text(tok[0], TTAConfig(tta_steps=0, sample_k=1))["final_logits"]
+        return per_text.t(), per_text
 
 
 class CLIPRewards(_cr.CLIPRewards):
@@ -121,6 +154,21 @@ class CLIPRewards(_cr.CLIPRewards):
     @torch.no_grad()
     def set_many_text_features(self, texts, text_bs=128):
         self.class_features = self.extract_text_features(captions=texts)
+
+    @torch.no_grad()
+    def set_text_features(self, captions=None, tokenized_cap=None, text_features=None):           # retrieval/clip_reward.py:64-68
+        self.class_features = self.extract_text_features(captions=captions, tokenized_cap=tokenized_cap) if text_features is None else text_features
+
+    @torch.no_grad()
+    def set_image_features(self, images=None, image_features=None):                               # retrieval/clip_reward.py:71-76
+        if image_features is None:
+            step = runtime.SESSION.max_views
+            image_features = torch.cat([self.extract_image_features(images[i: i + step]) for i in range(0, images.shape[0], step)])
+        self.image_features = image_features
+
+    @torch.no_grad()
+    def set_image_features_with_dataloder(self, data_loader):                                     # retrieval/clip_reward.py:208-215
+        self.image_features = torch.cat([self.extract_image_features(s["image"].to(self.device)) for s in data_loader], dim=0)
 
     @torch.no_grad()
     def CLIPScore(self, text_index=None, images_index=None, pairwise=True):
@@ -146,6 +194,37 @@ def tune_image(image, model, reward_model, optimizer, scaler, args=None):
     with torch.no_grad():
         model.ln.data.copy_(out["ln_after"])
         model.vis.data.copy_(out["vis_after"])
+    return out
+
+
+def tune_text(text, model, reward_model, optimizer, scaler, args=None):
+    """retrieval/clip_ret_policy.py:106-137: `text` = one caption (bs = 1).  The image bank is model.image_features (student) and
+    reward_model.image_features (set by the loop before the queries, :184-185); `optimizer` supplies the AdamW hyper-parameters;
+    `scaler` is accepted and unused (its inf / NaN step skip is built into the engine)."""
+    g = optimizer.param_groups[0]
+    b1, b2 = g.get("betas", (0.9, 0.999))
+    cfg = TTAConfig(selection_p=1.0, tta_steps=args.tta_steps, sample_k=reward_model.sample_k, lr=g["lr"], weight_decay=g.get("weight_decay", 0.0),
+                    beta1=b1, beta2=b2, eps=g.get("eps", 1e-8), reward_process=bool(reward_model.reward_process),
+                    process_batch=bool(reward_model.process_batch), reward_amplify=bool(reward_model.amplify_rewards),
+                    clipscore_weight=reward_model.clipscore_weight)
+    if model.only_visual:
+        raise ValueError("tune_text needs CLIPRet_TTA(only_visual=False)")
+    if model.image_features is None or reward_model.image_features is None:
+        raise L.RlcfError("tune_text: set_image_features of the model and of the reward model first (clip_ret_policy.py:184-185)")
+    if not (torch.equal(model.ln.data, model._ln_init) and torch.equal(model.vis.data, model._vis_init)):
+        raise NotImplementedError("tune_text starts from the reset state (model.reset_initial(), clip_ret_policy.py:196)")
+    tok = clip_store.tokenize(text).reshape(1, -1)
+    bank = runtime.SESSION.image_bank       # the engine's bank follows the two feature tensors the loop set (:184-185)
+    if bank is None or getattr(runtime.SESSION, "_image_bank_src", None) != (id(model.image_features), id(reward_model.image_features)):
+        runtime.SESSION.set_image_bank(model.image_features, reward_model.image_features)
+        runtime.SESSION._image_bank_src = (id(model.image_features), id(reward_model.image_features))
+        model._bank_refs = (model.image_features, reward_model.image_features)       # keeps the ids alive
+    out = runtime.SESSION.engine().tta_retrieval_text(tok[0], cfg)
+    reward_model.class_features = out["reward_text_features"]             # reward_model.set_text_features(captions=text), :117
+    with torch.no_grad():
+        model.ln.data.copy_(out["ln_after"])
+        model.vis.data.copy_(out["text_after"])
+    model._tuned_query = (tok.cpu(), out["final_logits"])
     return out
 
 

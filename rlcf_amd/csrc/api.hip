@@ -32,7 +32,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 4; }   // 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 5; }   // 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -340,6 +340,35 @@ int rlcf_tta_retrieval_image(rlcf_engine* e, const float* images, int n, const r
     rlcf_tta_args a = *args;
     a.selection_p = 1.0f; a.n_sel = n; a.flags |= RLCF_F_NO_SELECTION;     // every query image carries reward and gradient, in loader order
     return engine_tta_sample_visual(e, images, n, &a, out, (hipStream_t)stream);
+}
+int rlcf_engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e);
+    return engine_set_image_bank(e, student_feats, reward_feats, n, (hipStream_t)stream);
+}
+int rlcf_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens_host, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && tokens_host && args);
+    return engine_tta_retrieval_text(e, tokens_host, args, out, (hipStream_t)stream);
+}
+int64_t rlcf_engine_text_param_count(rlcf_engine* e, int* ln_count, rlcf_stream stream) {
+    if (!e || engine_text_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;
+    if (ln_count) *ln_count = e->tln_count;
+    return (int64_t)e->tw_count;
+}
+int rlcf_engine_text_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && offsets && numels);
+    int rc = engine_text_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    RLCF_ARG_CHECK(max_entries >= (int)e->tw_slots.size());
+    for (size_t i = 0; i < e->tw_slots.size(); ++i) { offsets[i] = (int64_t)e->tw_slots[i].off; numels[i] = (int64_t)e->tw_slots[i].numel; }
+    return (int)e->tw_slots.size();
+}
+int rlcf_engine_get_text_params(rlcf_engine* e, float* flat, float* ln, int which, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && (flat || ln) && which >= 0 && which <= 1);
+    int rc = engine_text_enable(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    if (flat) RLCF_HIP_CHECK(hipMemcpyAsync(flat, (which ? e->tw_init : e->tw).p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ln) RLCF_HIP_CHECK(hipMemcpyAsync(ln, (which ? e->tln_init : e->tln).p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RLCF_OK;
 }
 int64_t rlcf_engine_visual_param_count(rlcf_engine* e, rlcf_stream stream) {
     if (!e || engine_visual_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;

@@ -29,6 +29,8 @@ struct TextLayout {                  // packed token matrix of a class bank
     bool ctx_general = false;        // learnable rows at class-dependent positions (class_token_position 'front' / 'middle'): the ctx
                                      // gradient is gathered by scanning ctx_row instead of through the fixed row lists
     DevBuf seqs, eot_rows, ctx_row, E, class_start, class_len, class_eot_off, ctx_rows_list;
+    DevBuf row_token, row_pos;       // per row: token id (-1 = learnable row) and position index — E is rebuilt from them when the
+                                     // token / positional embeddings are tuned (text-encoder tuning)
     long tokens_total = 0;           // sum of rows that carry real tokens (FLOP accounting)
     long attn_pairs = 0;             // visible (query,key) pairs over all sequences
     double mean_len = 0;             // mean class_len
@@ -129,6 +131,18 @@ struct rlcf_engine {
     bool vw_dirty = false;           // live weights differ from the reset state
     std::vector<VwSlot> vw_slots;
     std::vector<VwRefresh> vw_refresh;
+    // text-encoder tuning (retrieval text -> image, CLIPRet_TTA only_visual=False: every non-visual parameter, custom_models.py:139-147):
+    // token_embedding.weight, positional_embedding, text_projection, per block the 8 Linear tensors (order of vw), logit_scale — one
+    // flat buffer; the text LayerNorms [ln_final.w | ln_final.b | per block ln_1.w ln_1.b ln_2.w ln_2.b] in a second one
+    DevBuf tw, tw_init, tw_grad, tw_m, tw_v, tln, tln_init, tln_grad, tln_m, tln_v;
+    size_t tw_count = 0;
+    int tln_count = 0;
+    bool tw_dirty = false;
+    std::vector<VwSlot> tw_slots;
+    std::vector<VwRefresh> tw_refresh;
+    TextLayout qlay[1 + RLCF_MAX_REWARDS];   // the query caption: [student], [reward slots]
+    bool image_bank = false;         // the bank of e->C entries holds IMAGE features (rlcf_engine_set_image_bank), not texts
+    DevBuf q_feat, q_dfeat, q_ls;    // query text features / their gradient [D]; {d logit_scale} scratch
     DevBuf wg_yt, wg_xt, w_hi;       // weight-gradient GEMM operands: dY^T, X^T (token dimension padded) and the split copy of X^T
     DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
     DevBuf bwd_amax;                 // max|dF| handed from one backward GEMM's epilogue to the next one's operand scale
@@ -182,6 +196,9 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
 int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_visual_enable(rlcf_engine* e, hipStream_t st);
+int engine_text_enable(rlcf_engine* e, hipStream_t st);
+int engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, hipStream_t st);
+int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_visual_refresh(rlcf_engine* e, hipStream_t st);
 int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                         hipStream_t st);

@@ -319,6 +319,82 @@ class Engine:
         L.check(fn(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_retrieval_image" if retrieval else "tta_sample_visual")
         return o
 
+    # ---- text-encoder tuning (retrieval text -> image, CLIPRet_TTA only_visual=False, retrieval/custom_models.py:139-147)
+    def text_layout(self):
+        """[(state-dict key, offset, numel)] of the flat non-LayerNorm text parameter vector (include/rlcf_hip.h)."""
+        layers = self.student.transformer_layers
+        n = 3 + 8 * layers + 1
+        off, num = (C.c_int64 * n)(), (C.c_int64 * n)()
+        got = self.lib.rlcf_engine_text_param_layout(self.h, off, num, n, _stream())
+        if got < 0:
+            L.check(got, "text_param_layout")
+        names = ["token_embedding.weight", "positional_embedding", "text_projection"]
+        for i in range(layers):
+            b = f"transformer.resblocks.{i}."
+            names += [b + "attn.in_proj_weight", b + "attn.in_proj_bias", b + "attn.out_proj.weight", b + "attn.out_proj.bias",
+                      b + "mlp.c_fc.weight", b + "mlp.c_fc.bias", b + "mlp.c_proj.weight", b + "mlp.c_proj.bias"]
+        names.append("logit_scale")
+        assert got == len(names)
+        return [(k, int(off[i]), int(num[i])) for i, k in enumerate(names)]
+
+    def merge_text(self, ln_vec: torch.Tensor, flat_vec: torch.Tensor) -> torch.Tensor:
+        """text LayerNorm vector + flat vector -> one vector in the order the reference's optimizer sees them: the named_parameters()
+        of the CLIP module without the 'visual' ones (oracle.retrieval_ref.text_param_keys)."""
+        Wt, Lt = self.student.transformer_width, self.student.transformer_layers
+        ln = ln_vec.view(-1, Wt)                                   # rows: ln_final.w, ln_final.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x L
+        t = {k: flat_vec[o: o + n] for k, o, n in self.text_layout()}
+        out = [t["positional_embedding"], t["text_projection"], t["logit_scale"]]
+        for i in range(Lt):
+            b = f"transformer.resblocks.{i}."
+            out += [t[b + "attn.in_proj_weight"], t[b + "attn.in_proj_bias"], t[b + "attn.out_proj.weight"], t[b + "attn.out_proj.bias"],
+                    ln[2 + 4 * i], ln[3 + 4 * i], t[b + "mlp.c_fc.weight"], t[b + "mlp.c_fc.bias"], t[b + "mlp.c_proj.weight"],
+                    t[b + "mlp.c_proj.bias"], ln[4 + 4 * i], ln[5 + 4 * i]]
+        out += [t["token_embedding.weight"], ln[0], ln[1]]
+        return torch.cat([x.reshape(-1) for x in out])
+
+    def text_params(self, which: int = 1):
+        """(flat vector, LayerNorm vector) of the tunable text side: which = 0 live, 1 reset state"""
+        ln_count = C.c_int(0)
+        nflat = int(self.lib.rlcf_engine_text_param_count(self.h, C.byref(ln_count), _stream()))
+        if nflat <= 0:
+            L.check(-1, "text_params (text_param_count)")
+        flat, ln = torch.empty(nflat, device=self.device), torch.empty(ln_count.value, device=self.device)
+        L.check(self.lib.rlcf_engine_get_text_params(self.h, _ptr(flat), _ptr(ln), which, _stream()), "get_text_params")
+        return flat, ln
+
+    def set_image_bank(self, student_feats: torch.Tensor, reward_feats) -> None:
+        """The bank of the text -> image direction: L2-normalised image features under the student [n, D] and under every reward model
+        (a tensor [n, Dr], or a list of them).  Replaces the class / caption bank."""
+        sf = student_feats.detach().to(self.device, torch.float32).contiguous()
+        rf = reward_feats if isinstance(reward_feats, (list, tuple)) else [reward_feats]
+        rf = torch.cat([r.detach().to(self.device, torch.float32).contiguous().reshape(-1) for r in rf])
+        L.check(self.lib.rlcf_engine_set_image_bank(self.h, _ptr(sf), _ptr(rf), sf.shape[0], _stream()), "set_image_bank")
+        self.n_cls = sf.shape[0]
+
+    def tta_retrieval_text(self, tokens: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
+        """Text -> image retrieval step: tune_text + the evaluation of its loop (retrieval/clip_ret_policy.py:106-137,193-196) for ONE
+        query caption (tokens [context_length]) over the image bank given to set_image_bank."""
+        tok = tokens.reshape(-1).to("cpu", torch.int32).contiguous()
+        assert tok.numel() == self.student.context_length
+        ln_count = C.c_int(0)
+        nflat = int(self.lib.rlcf_engine_text_param_count(self.h, C.byref(ln_count), _stream()))
+        if nflat <= 0:
+            L.check(-1, "tta_retrieval_text (text_param_count)")
+        dev, n, K = self.device, self.n_cls, cfg.sample_k
+        Dr = self.rewards[0].embed_dim
+        o = dict(final_logits=torch.empty(1, n, device=dev), logits=torch.empty(1, n, device=dev), dlogits=torch.empty(1, n, device=dev),
+                 ln_after=torch.empty(ln_count.value, device=dev), ln_grad=torch.empty(ln_count.value, device=dev),
+                 vis_after=torch.empty(nflat, device=dev), vis_grad=torch.empty(nflat, device=dev),
+                 step_skipped=torch.zeros(max(cfg.tta_steps, 1), dtype=torch.int32, device=dev),
+                 reward_image_features=torch.empty(1, Dr, device=dev),
+                 topk_idx=torch.empty(1, K, dtype=torch.int32, device=dev), clip_score=torch.empty(K, device=dev),
+                 rewards=torch.empty(K, device=dev), loss=torch.empty(1, device=dev))
+        co = L.TTAOut(**{k: _ptr(o[k]) if k in o else None for k in L.TTA_OUT_FIELDS})
+        a = cfg.c_args(1, skip_final)
+        L.check(self.lib.rlcf_tta_retrieval_text(self.h, tok.data_ptr(), C.byref(a), C.byref(co), _stream()), "tta_retrieval_text")
+        o["text_after"], o["text_grad"], o["reward_text_features"] = o.pop("vis_after"), o.pop("vis_grad"), o.pop("reward_image_features")
+        return o
+
     def tta_batch(self, views: torch.Tensor, cfg: TTAConfig, want_logits: bool = False):
         """views [count,N,3,R,R] -> top5 [count,5] (and final logits [count,C])."""
         views = views.to(self.device, torch.float32).contiguous()

@@ -31,6 +31,7 @@ class Session:
         self.text_mode = TEXT_MODES[os.environ.get("RLCF_TEXT_MODE", "shared")]
         self._engine: Optional[Engine] = None
         self._key = None
+        self.image_bank = None       # (student features [n, D], [reward features [n, Dr]]): the bank of the text -> image retrieval direction
         self._bank_version = 0       # bumped by set_bank: the engine re-reads the class bank when its copy is older
         self._bank_applied = -1
 
@@ -50,6 +51,14 @@ class Session:
     def set_bank(self, tokens: torch.Tensor, n_ctx: int, ctx_init: torch.Tensor, student_tokens=None, ctx_pos=None):
         self.tokens, self.n_ctx, self.ctx_init = tokens.detach().cpu(), n_ctx, ctx_init.detach().clone()
         self.student_tokens, self.ctx_pos = student_tokens, ctx_pos       # class tokens not at the end of the prompt ('front' / 'middle')
+        self.image_bank = None
+        self._bank_version += 1
+
+    def set_image_bank(self, student_feats: torch.Tensor, reward_feats):
+        """text -> image retrieval: a bank of image features replaces the class / caption bank"""
+        rf = list(reward_feats) if isinstance(reward_feats, (list, tuple)) else [reward_feats]
+        self.image_bank = (student_feats.detach().clone(), [r.detach().clone() for r in rf])
+        self.tokens = None
         self._bank_version += 1
 
     def engine(self, n_views: int = 1) -> Engine:
@@ -57,7 +66,7 @@ class Session:
             raise L.RlcfError("no student CLIP bound: construct ClipTestTimeTuning / get_coop first")
         if n_views > self.max_views:
             self.max_views = n_views
-        n_cls = int(self.tokens.shape[0]) if self.tokens is not None else 1
+        n_cls = int(self.tokens.shape[0]) if self.tokens is not None else (int(self.image_bank[0].shape[0]) if self.image_bank is not None else 1)
         key = (id(self.student), tuple(id(r) for r in self.rewards), self.max_views, self.precision)
         if self._engine is None or key != self._key or n_cls > self._engine.max_classes:
             if self._engine is not None:
@@ -76,6 +85,11 @@ class Session:
             if bkey != self._bank_applied:
                 self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode, getattr(self, "student_tokens", None),
                                             getattr(self, "ctx_pos", None))
+                self._bank_applied = bkey
+        elif self.image_bank is not None:
+            bkey = (self._bank_version, "images")
+            if bkey != self._bank_applied:
+                self._engine.set_image_bank(*self.image_bank)
                 self._bank_applied = bkey
         return self._engine
 

@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from rlcf_amd import synth  # noqa: E402
 from oracle import rlcf_ref as RR  # noqa: E402  (key order of the visual parameters only)
+from oracle import retrieval_ref as RT  # noqa: E402  (key order of the text parameters only)
 
 REF = "/root/reference"
 STATE = {}          # arch name -> (geometry, state dict); the tokenizer bank
@@ -212,6 +213,63 @@ def gen_t2i(ref, name, K, n_images=200, amplify=False):
     print(f"  {name}: idx[:5]={idx[:5].tolist()} loss={float(loss):.4e} score>0: {int((taps['clip_score'] > 0).sum())}")
 
 
+def gen_t2i_tune(ref, name, K, steps, lr, n_images=200, query="c5."):
+    """text -> image with the text encoder tuned: test_time_tune's second loop for one caption (clip_ret_policy.py:183-196):
+    tune_text (tta_steps AdamW steps over every non-visual parameter), then logits_per_text of the tuned model."""
+    s_geo, r_geo, s_sd, r_sd, scaler, rm = setup(ref, "tiny", "tiny-r", 64, K)
+    model = ref.models.CLIPRet_TTA("cpu", arch="student", only_visual=False, momentum_update=False)
+    images = synth.make_views(3000, n_images, s_geo.image_resolution)
+    with torch.no_grad():
+        model.set_image_features(image_features=model.get_image_features(images))
+        rm.set_image_features(images=images)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=lr, eps=1e-06, weight_decay=5e-4)                # clip_ret_policy.py:222
+    pmap = {n: p for n, p in model.clip_model.named_parameters() if "visual" not in n}
+    names = list(pmap)
+    assert names == RT.text_param_keys(s_sd), names
+    assert [id(p) for p in model.parameters()] == [id(pmap[n]) for n in names]
+    pristine = {n: p.detach().clone() for n, p in pmap.items()}
+    first, taps, grabbed = {}, {}, {}
+
+    def keep_first(n):
+        def hook(g):
+            first.setdefault(n, g.detach().clone())
+        return hook
+
+    for n in names:
+        pmap[n].register_hook(keep_first(n))
+    tap(rm, taps)
+    orig_forward = model.forward
+
+    def forward(images=None, text=None, tokenized_prompts=None):
+        li, lt = orig_forward(images=images, text=text, tokenized_prompts=tokenized_prompts)
+        if "logits" not in grabbed and lt.requires_grad:
+            grabbed["logits"] = lt.detach().clone()
+
+            def hook(g):
+                grabbed.setdefault("dlogits", g.detach().clone())
+            lt.register_hook(hook)
+        return li, lt
+
+    model.forward = forward
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.policy.tune_text(query, model, rm, optimizer, scaler, args=types.SimpleNamespace(tta_steps=steps))
+    model.eval()
+    with torch.no_grad():
+        _, final = orig_forward(images=None, text=query)
+    zero = torch.zeros(())
+    arrays = dict(logits=grabbed["logits"], dlogits=grabbed["dlogits"], topk_idx=taps["topk_idx"].reshape(1, K), clip_score=taps["clip_score"],
+                  rewards=taps["rewards"], final_logits=final, reward_text=rm.text_features,
+                  grad_l2=torch.stack([first.get(n, zero).double().norm() for n in names]).float(),
+                  delta_l2=torch.stack([(pmap[n].detach() - pristine[n]).double().norm() for n in names]).float(),
+                  grad_sample=torch.cat([first[n].reshape(-1) for n in names])[::7].clone(),
+                  after_sample=torch.cat([pmap[n].detach().reshape(-1) for n in names])[::7].clone())
+    save(name, arrays, dict(student="tiny", reward="tiny-r", n_images=n_images, sample_k=K, tta_steps=steps, lr=lr, eps=1e-6, weight_decay=5e-4,
+                            student_seed=11, reward_seed=23, bank_seed=7, bank_size=64, image_seed=3000, query_row=int(query[1:-1])))
+    print(f"  {name}: idx[:5]={taps['topk_idx'][:5].tolist()} |g|={float(arrays['grad_l2'].norm()):.3e} "
+          f"max|dlogit final-first|={float((final - grabbed['logits']).abs().max()):.3e}")
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     ref = import_reference()
@@ -219,6 +277,7 @@ def main():
     gen_i2t(ref, "retrieval_i2t_tiny_b2", n_img=2, K=5, steps=1, lr=1e-4)        # a loader batch of two query images
     gen_t2i(ref, "retrieval_t2i_loss", K=12)                                      # sample_k_t2i=12
     gen_t2i(ref, "retrieval_t2i_loss_amp", K=12, amplify=True)
+    gen_t2i_tune(ref, "retrieval_t2i_tiny", K=12, steps=2, lr=1e-4)
 
 
 if __name__ == "__main__":

@@ -414,8 +414,83 @@ def test_retrieval_mirror_tune_image(L, dev):
     model.reset_initial()
     optimizer.load_state_dict(optim_state)
     assert torch.equal(model.ln.data, model._ln_init)
-    with pytest.raises(NotImplementedError):
-        P.CLIPRet_TTA(dev, arch="student", only_visual=False)
+    runtime.reset_session()
+
+
+def test_retrieval_text_tuning_full_size_matches_oracle(L, dev):
+    """rlcf_tta_retrieval_text at the size the retrieval scripts run (CLIP ViT-B/16 text tower: 12 x 512, vocabulary 49408; a 5000-image
+    bank as the COCO 5k test split, K = 12, 2 steps) against the CPU oracle (oracle.retrieval_ref.tune_text, itself pinned to the
+    reference's tune_text by retrieval_t2i_tiny).  The bank features are seeded unit vectors (no image tower needed on the CPU)."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    from oracle import retrieval_ref as QR, rlcf_ref as RR2
+    sg = synth.GEOMETRIES["ViT-B/16"]
+    ssd, rsd = synth.make_state_dict(sg, 11), synth.make_state_dict(sg, 23)
+    n, K, steps, lr = 5000, 12, 2, 1e-5
+    gen = torch.Generator().manual_seed(5)
+    sbank = torch.nn.functional.normalize(torch.randn(n, sg.embed_dim, generator=gen), dim=-1)
+    rbank = torch.nn.functional.normalize(torch.randn(n, sg.embed_dim, generator=gen), dim=-1)
+    query = synth.make_token_bank(sg, 8, seed=7, n_ctx=4)[3]
+    hp = RR2.TTAHyper(selection_p=1.0, tta_steps=steps, sample_k=K, lr=lr, weight_decay=5e-4, eps=1e-6)
+    ref = QR.tune_text(ssd, rsd, query[None], None, hp, student_bank=sbank, reward_bank=rbank)
+    eng = Engine(sg, sg, 8, n, L.PREC_F16X3)
+    eng.load_state_dict(L.STUDENT, {k: v.to(dev) for k, v in ssd.items()})
+    eng.load_state_dict(L.REWARD, {k: v.to(dev) for k, v in rsd.items()})
+    eng.finalize()
+    eng.set_image_bank(sbank.to(dev), rbank.to(dev))
+    o = eng.tta_retrieval_text(query, TTAConfig(selection_p=1.0, tta_steps=steps, sample_k=K, lr=lr, weight_decay=5e-4, eps=1e-6))
+    torch.cuda.synchronize()
+    c = lambda k: o[k].cpu()
+    assert c("topk_idx").reshape(-1).tolist() == ref["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(c("logits"), ref["logits"], atol=1e-3, rtol=0)
+    torch.testing.assert_close(c("clip_score"), ref["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(c("rewards"), ref["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    grad = eng.merge_text(o["ln_grad"], o["text_grad"]).cpu()
+    assert (grad - ref["grad"]).norm() / ref["grad"].norm() < 2e-3
+    after = eng.merge_text(o["ln_after"], o["text_after"]).cpu()
+    d = (after - ref["after"]).abs()
+    print(f"[text tuning, ViT-B/16] {int((d > 0.1 * lr).sum())} of {d.numel()} tuned elements differ by > 0.1 lr")
+    assert (d > 0.1 * lr).float().mean() < 0.01                          # Adam's sign on ~zero gradients
+    torch.testing.assert_close(c("final_logits"), ref["final_logits"], atol=5e-3, rtol=0)
+    eng.close()
+
+
+def test_retrieval_mirror_tune_text(L, dev):
+    """The reference-shaped objects (rlcf_amd.clip_ret_policy: CLIPRet_TTA(only_visual=False), CLIPRewards, tune_text) reproduce the
+    fixture through the loop body of test_time_tune's text -> image part (clip_ret_policy.py:183-196): image features of both models
+    set once, then per caption: tune, logits_per_text of the tuned model, reset."""
+    import copy
+    from rlcf_amd import clip_ret_policy as P, clip_store, runtime
+    g, meta = load_golden("retrieval_t2i_tiny")
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("student", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("reward", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    tokens = synth.make_token_bank(sg, meta["bank_size"], seed=meta["bank_seed"], n_ctx=4)
+    clip_store.set_tokenizer(lambda texts, context_length=77, truncate=False: tokens[[int(t.strip().rstrip(".").split("c")[-1]) for t in ([texts] if isinstance(texts, str) else texts)]])
+    model = P.CLIPRet_TTA(dev, arch="student", only_visual=False)
+    reward_model = P.CLIPRewards(dev, arch="reward", sample_k=meta["sample_k"], reward_process=True, process_batch=False)
+    images = synth.make_views(meta["image_seed"], meta["n_images"], sg.image_resolution, device=dev)
+    model.set_image_features(images=images)
+    reward_model.set_image_features(images=images)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=meta["lr"], eps=meta["eps"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    text = f"c{meta['query_row']}."
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"])
+    for rep in range(2):
+        out = P.tune_text(text, model, reward_model, optimizer, None, args=args)
+        assert out["topk_idx"].cpu().reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+        torch.testing.assert_close(reward_model.text_features.cpu(), g["reward_text"], atol=1e-5, rtol=0)
+        logits_per_image, logits_per_text = model(images=None, text=text)
+        torch.testing.assert_close(logits_per_text.cpu(), g["final_logits"], atol=5e-3, rtol=0)
+        assert logits_per_image.shape == (meta["n_images"], 1)
+        sc = reward_model.CLIPScore(text_index=None, images_index=g["topk_idx"].reshape(-1).to(dev), pairwise=False)
+        torch.testing.assert_close(sc.cpu(), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+        with pytest.raises(NotImplementedError, match="tuned on"):
+            model(images=None, text="c6.")
+        model.reset_initial()
+        optimizer.load_state_dict(optim_state)
+        _, pristine = model(images=None, text=text)
+        torch.testing.assert_close(pristine.cpu(), g["logits"], atol=1e-3, rtol=0)
     runtime.reset_session()
 
 
@@ -434,6 +509,55 @@ def test_retrieval_text_to_image_loss_matches_reference_fixture(L, dev, name):
     torch.testing.assert_close(o["rewards"].cpu(), g["rewards"].reshape(-1), atol=1e-5, rtol=1e-3)
     torch.testing.assert_close(o["loss"].cpu()[0], g["loss"], atol=1e-7, rtol=1e-3)
     torch.testing.assert_close(o["dlogits"].cpu(), g["dlogits"], atol=1e-7, rtol=1e-3)
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+def test_retrieval_text_to_image_tuning_matches_reference_fixture(L, dev, prec):
+    """rlcf_tta_retrieval_text vs the reference's tune_text (retrieval/clip_ret_policy.py:106-137) with CLIPRet_TTA(only_visual=False)
+    + the evaluation of its loop (:193-196): one query caption against a 200-image bank, K = 12 (the script's sample_k_t2i), two AdamW
+    steps over every non-visual parameter (embeddings, text transformer, ln_final, text_projection, logit_scale)."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    from oracle import retrieval_ref as QR
+    from test_gpu_parity import _tensor_norms
+    g, meta = load_golden("retrieval_t2i_tiny")
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd, rsd = synth.make_state_dict(sg, meta["student_seed"], device=dev), synth.make_state_dict(rg, meta["reward_seed"], device=dev)
+    eng = Engine(sg, rg, 64, max(meta["n_images"], 64), prec)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    images = synth.make_views(meta["image_seed"], meta["n_images"], sg.image_resolution, device=dev)
+    sfeat = torch.cat([eng.encode_image(L.STUDENT, images[i: i + 64]) for i in range(0, meta["n_images"], 64)])
+    rfeat = torch.cat([eng.encode_image(L.REWARD, images[i: i + 64]) for i in range(0, meta["n_images"], 64)])
+    eng.set_image_bank(sfeat, rfeat)
+    bank = synth.make_token_bank(sg, meta["bank_size"], seed=meta["bank_seed"], n_ctx=4)
+    query = bank[meta["query_row"]]
+    cfg = TTAConfig(selection_p=1.0, tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"], weight_decay=meta["weight_decay"],
+                    eps=meta["eps"])
+    for rep in range(2):                                                  # the second call starts from the reset state: same results
+        o = eng.tta_retrieval_text(query, cfg)
+        torch.cuda.synchronize()
+        c = lambda k: o[k].cpu()
+        assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+        torch.testing.assert_close(c("logits"), g["logits"], atol=1e-3, rtol=0)
+        torch.testing.assert_close(c("reward_text_features"), g["reward_text"], atol=1e-5, rtol=0)
+        torch.testing.assert_close(c("clip_score"), g["clip_score"].reshape(-1), atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+        torch.testing.assert_close(c("dlogits"), g["dlogits"], atol=1e-6, rtol=2e-3)
+        torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3, rtol=0)
+        assert c("step_skipped").tolist() == [0] * meta["tta_steps"]
+        keys = QR.text_param_keys(ssd)
+        grad, after = eng.merge_text(o["ln_grad"], o["text_grad"]), eng.merge_text(o["ln_after"], o["text_after"])
+        torch.testing.assert_close(_tensor_norms(ssd, keys, grad), g["grad_l2"], rtol=3e-3, atol=1e-9)
+        torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd), g["delta_l2"], rtol=0.01, atol=1e-7)
+        gs = grad[::7].cpu()
+        assert (gs - g["grad_sample"]).norm() / g["grad_sample"].norm() < 2e-3
+        d = (after[::7].cpu() - g["after_sample"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01              # Adam's sign on ~zero gradients
+    # the image bank replaced the class bank: calls that need texts refuse
+    with pytest.raises(L.RlcfError, match="class bank"):
+        eng.tta_sample(images[:8], cfg)
+    eng.close()
 
 
 def test_ln_batch_matches_reference_at_full_size_l14_n64(L, dev):

@@ -312,3 +312,29 @@ def test_retrieval_text_to_image_loss_oracle_matches_reference(name):
     torch.testing.assert_close(o["rewards"], g["rewards"], atol=1e-5, rtol=1e-4)
     torch.testing.assert_close(o["loss"], g["loss"], atol=1e-7, rtol=1e-4)
     torch.testing.assert_close(o["dlogits"], g["dlogits"], atol=1e-7, rtol=1e-4)
+
+
+def test_retrieval_text_to_image_tuning_oracle_matches_reference():
+    """oracle.retrieval_ref.tune_text vs the reference's tune_text + CLIPRet_TTA(only_visual=False) + CLIPRewards run
+    (tests/golden/make_retrieval_golden.py): sampled images, scores, rewards, gradient of every non-visual parameter, the tuned
+    parameters and logits_per_text of the tuned text encoder."""
+    from oracle import retrieval_ref as QR
+    g, meta = load("retrieval_t2i_tiny")
+    sg, rg = synth.GEOMETRIES[str(meta["student"])], synth.GEOMETRIES[str(meta["reward"])]
+    ssd, rsd = synth.make_state_dict(sg, int(meta["student_seed"])), synth.make_state_dict(rg, int(meta["reward_seed"]))
+    bank = synth.make_token_bank(sg, int(meta["bank_size"]), seed=int(meta["bank_seed"]), n_ctx=4)
+    query = bank[int(meta["query_row"])][None]
+    images = synth.make_views(int(meta["image_seed"]), int(meta["n_images"]), sg.image_resolution)
+    hp = R.TTAHyper(selection_p=1.0, tta_steps=int(meta["tta_steps"]), sample_k=int(meta["sample_k"]), lr=float(meta["lr"]),
+                     weight_decay=float(meta["weight_decay"]), eps=float(meta["eps"]))
+    o = QR.tune_text(ssd, rsd, query, images, hp)
+    assert o["topk_idx"].reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    torch.testing.assert_close(o["logits"], g["logits"], atol=1e-4, rtol=0)
+    torch.testing.assert_close(o["clip_score"], g["clip_score"], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(o["dlogits"], g["dlogits"], atol=1e-7, rtol=1e-4)
+    torch.testing.assert_close(o["reward_text"], g["reward_text"], atol=1e-6, rtol=0)
+    assert (o["grad"][::7] - g["grad_sample"]).norm() / g["grad_sample"].norm() < 1e-4
+    d = (o["after"][::7] - g["after_sample"]).abs()
+    assert (d > 0.1 * float(meta["lr"])).float().mean() < 0.01          # Adam's sign on ~zero gradients (SURVEY fact 6)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=2e-3, rtol=0)
