@@ -10,7 +10,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librlcf_hip.so")
+LIB_PATH = os.environ.get("RLCF_LIB_PATH") or os.path.join(HERE, "librlcf_hip.so")     # (override: kernel experiments)
 CSRC = os.path.join(HERE, "csrc")
 
 PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2       # F16: single-pass performance mode (not parity-grade); F16X3: the default

@@ -83,10 +83,11 @@ int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, floa
 }
 int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
                        float* lse, int precision, rlcf_stream stream) {
-    RLCF_ARG_CHECK(qkv && seqs && out && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3));
-    if (precision == RLCF_PREC_F16X3) {
+    RLCF_ARG_CHECK(qkv && seqs && out && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16));
+    if (precision != RLCF_PREC_F32) {
         RLCF_ARG_CHECK(!lse);
-        return launch_attention_fwd_x3(qkv, seqs, n_seq, max_q_len, width, causal, out, nullptr, nullptr, (hipStream_t)stream);
+        return launch_attention_fwd_x3(qkv, seqs, n_seq, max_q_len, width, causal, out, nullptr, nullptr, (hipStream_t)stream, 0, nullptr,
+                                       precision == RLCF_PREC_F16);
     }
     return launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, width, causal, out, lse, (hipStream_t)stream);
 }

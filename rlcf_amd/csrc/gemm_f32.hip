@@ -128,8 +128,12 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmArgs g) {
 // MFMA registers: lane (row, half) owns 32 consecutive k of its row) and the four partial tiles
 // are summed through LDS in a fixed order (deterministic).  Latency of a K=2048 GEMM: ~7 us
 // instead of ~110 us for the 64x64-per-wave tiling, and M=239 fills 128+ CUs instead of 32.
-__global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
-    __shared__ float part[4][32 * 33];
+// NWV waves split K; the operand loads of a wave's next chunk are in flight while the MFMAs of the current one run (the kernel is
+// latency-bound: 16 float4 loads per lane and chunk, then 32 MFMAs).  Eight waves for K >= 512 (one test image's sparse text passes
+// are ~100 such launches: 20 -> ~8 us each).
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
+    __shared__ float part[NWV][32 * 33];
     const int tiles_n = (g.N + 31) / 32;
     const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, h = lane >> 5;
@@ -139,16 +143,27 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nchunk = g.K / 64;
-    for (int c = wave; c < nchunk; c += 4) {
-        float4 a[8], b[8];
+    float4 a[8], b[8], a2[8], b2[8];
+    if (wave < nchunk) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] = *(const float4*)(ap + c * 64 + j * 4); b[j] = *(const float4*)(wp + c * 64 + j * 4); }
+        for (int j = 0; j < 8; ++j) { a[j] = *(const float4*)(ap + wave * 64 + j * 4); b[j] = *(const float4*)(wp + wave * 64 + j * 4); }
+    }
+    for (int c = wave; c < nchunk; c += NWV) {
+        const bool more = c + NWV < nchunk;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a2[j] = *(const float4*)(ap + (c + NWV) * 64 + j * 4); b2[j] = *(const float4*)(wp + (c + NWV) * 64 + j * 4); }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = a2[j]; b[j] = b2[j]; }
         }
     }
 #pragma unroll
@@ -157,11 +172,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_splitk_kernel(GemmArgs g) {
     float* __restrict__ C = (float*)g.C;
     float am = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = t + e * 256, rr = idx >> 5, cc = idx & 31;
+    for (int e = 0; e < 1024 / (64 * NWV); ++e) {
+        const int idx = t + e * 64 * NWV, rr = idx >> 5, cc = idx & 31;
         const int row = m0 + rr, col = n0 + cc;
         if (row >= g.M || col >= g.N) continue;
-        float v = ((part[0][rr * 33 + cc] + part[1][rr * 33 + cc]) + part[2][rr * 33 + cc]) + part[3][rr * 33 + cc];
+        float v = part[0][rr * 33 + cc];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) v += part[w][rr * 33 + cc];
         v = g.alpha * v + (g.bias ? g.bias[col] : 0.f);
         if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
         else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
@@ -180,7 +197,8 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     if (g.M <= 512 && g.K % 64 == 0) {
         const long nb = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
-        gemm_nt_f32_splitk_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(g);
+        if (g.K >= 512) gemm_nt_f32_splitk_kernel<8><<<dim3((unsigned)nb), dim3(512), 0, st>>>(g);
+        else gemm_nt_f32_splitk_kernel<4><<<dim3((unsigned)nb), dim3(256), 0, st>>>(g);
     } else if (big >= 192) {
         gemm_nt_f32_kernel<128, 128><<<dim3((unsigned)big), dim3(256), 0, st>>>(g);
     } else {

@@ -1,5 +1,5 @@
 """Micro-benchmark of the attention forward kernels through the C ABI (GPU only): ViT-B/16 (197 tokens, 12 heads) and
-ViT-L/14 (257 tokens, 16 heads) image-tower shapes, plus packed text sequences; precision 0 (f32 MFMA) and 2 (split-f16)."""
+ViT-L/14 (257 tokens, 16 heads) image-tower shapes, plus packed text sequences; precision 0 (f32 MFMA), 2 (split-f16) and 1 (single-pass f16)."""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlcf_amd import _lib as L
@@ -12,7 +12,7 @@ for name, n_seq, tok, W, causal in cases:
     qkv = torch.randn(T, 3 * W, device=dev)
     seqs = torch.tensor([[i * tok, tok, 0, 0] for i in range(n_seq)], dtype=torch.int32, device=dev)
     outs = {}
-    for prec in (0, 2):
+    for prec in (0, 2, 1):
         out = torch.empty(T, W, device=dev)
         run = lambda: L.check(lib.rlcf_attention_fwd(qkv.data_ptr(), seqs.data_ptr(), n_seq, tok, W, causal, out.data_ptr(), None, prec, st()))
         for _ in range(3): run()
@@ -34,5 +34,5 @@ for name, n_seq, tok, W, causal in cases:
             sc = q[sl, cs] @ k[sl, cs].t() / 8
             if causal: sc = sc.masked_fill(torch.ones(tok, tok, device=dev).triu(1).bool(), float("-inf"))
             ref[sl, cs] = torch.softmax(sc, -1) @ v[sl, cs]
-    for prec in (0, 2):
+    for prec in (0, 2, 1):
         print(f"   maxerr prec={prec}: {(outs[prec][:2 * tok].double() - ref).abs().max().item():.2e}")
