@@ -222,8 +222,12 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
          e->vit_cls_idx.ensure(cls_idx.size() * sizeof(int32_t)) == 0;
     if (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
-        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0;
+        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0 &&
+             e->gemm_ws2.ensure(X3_SPLITK_WS_BYTES) == 0;
     }
+    ok = ok && hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipMemcpy(e->vit_seqs.p, seqs.data(), seqs.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(e->vit_seqs_cls.p, seqs_cls.data(), seqs_cls.size() * sizeof(rlcf_seq), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(e->vit_cls_idx.p, cls_idx.data(), cls_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
@@ -237,7 +241,7 @@ static void release_tower(Tower& t) {
 }
 static void release_layout(TextLayout& L) {
     L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
-    L.class_eot_off.release(); L.ctx_rows_list.release();
+    L.class_eot_off.release(); L.ctx_rows_list.release(); L.row_token.release(); L.row_pos.release();
 }
 void rlcf_engine_destroy(rlcf_engine* e) {
     if (!e) return;
@@ -248,6 +252,10 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     }
     release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
     for (auto& L : e->lay) release_layout(L);
+    for (auto& L : e->qlay) release_layout(L);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (int m = 0; m < RLCF_MAX_REWARDS; ++m) { e->reward_cls[m].release(); e->rimg[m].release(); }
     DevBuf* all[] = {&e->patches, &e->patch_out, &e->resized, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
                      &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->sp_seqs,
@@ -260,7 +268,8 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
-                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
+                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
+                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }
 

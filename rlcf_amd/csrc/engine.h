@@ -150,6 +150,12 @@ struct rlcf_engine {
     DevBuf a_hi;                     // interleaved split copy of the current GEMM A operand (F16X3 mode)
     size_t a_split_elems = 0;
     DevBuf gemm_ws;                  // split-K workspace of the small-grid split-f16 GEMM (X3_SPLITK_WS_BYTES, sized at create)
+    // one-image calls: the reward models' tower pass of the selected views runs on a second stream next to the student's sparse text
+    // forward (both leave most of the 256 CUs idle at one image's sizes); fork / join by events, its own split-K workspace
+    DevBuf gemm_ws2;
+    int ws_sel = 0;                  // which workspace the GEMM launchers hand out (1 while the side stream's launches are enqueued)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf rl_stats;                 // per-row scratch of the reward / loss kernels
     DevBuf step_skip;                // int32 per test sample: gradient held an inf / NaN -> optimizer step skipped (GradScaler semantics)
     double last_flops = 0.0;

@@ -53,6 +53,8 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 // Split-f16 operands of the engine are INTERLEAVED pairs: per row, each block of 32 K-columns is stored as 32 hi halves followed by
 // its 32 lo halves (row stride 2K halves), so that one 128-B LDS-DMA segment brings both parts of a k-tile (a 64-B segment per
 // part reaches 25.8 B/clk/CU, a 128-B one 45.5: profiles/r1_gemm_sq_counters.txt).  The lo part of a pair therefore starts 64 B after hi.
+static inline float* ws_ptr(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).as<float>(); }
+static inline size_t ws_bytes(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).bytes; }
 static inline void* lo_of(void* hi) { return (char*)hi + 64; }
 static inline const void* lo_of(const void* hi) { return (const char*)hi + 64; }
 
@@ -90,7 +92,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
             int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
-                                       e->gemm_ws.as<float>(), e->gemm_ws.bytes);
+                                       ws_ptr(e), ws_bytes(e));
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -115,7 +117,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
-                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, e->gemm_ws.as<float>(), e->gemm_ws.bytes);
+                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -140,7 +142,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
         if (!fw || K % 64) { rlcf_set_error("gemm_pre: weight has no plain f16 copy (K = %d)", K); return RLCF_ERR_STATE; }
         const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
         int rc = launch_gemm_f16x3(A2, lo_of(A2), lda, fw->hi, lo_of(fw->hi), K, bias, res, ldr, nullptr, 0, C, ldc, C2, nullptr, ldch, M, N, K,
-                                   fw->inv_scale, epi, st, nullptr, nullptr, 0, e->gemm_ws.as<float>(), e->gemm_ws.bytes, 1);
+                                   fw->inv_scale, epi, st, nullptr, nullptr, 0, ws_ptr(e), ws_bytes(e), 1);
         prof_end(slot, st, g_last_x3_variant);
         return rc;
     }
@@ -148,7 +150,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
-                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, e->gemm_ws.as<float>(), e->gemm_ws.bytes);
+                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -480,8 +482,8 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
         TRY(launch_split_f16x2(xt, e->w_hi.p, lo_of(e->w_hi.p), (int64_t)K * Tp, st, 1.0f, 1));
         const int slot = prof_begin(st, 2.0 * N * K * Tp, N, K, Tp);
         rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * Tp, e->w_hi.p, lo_of(e->w_hi.p), 2 * Tp, nullptr, nullptr, 0, nullptr, 0, dW, K,
-                               nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2, nullptr, 0, e->gemm_ws.as<float>(),
-                               e->gemm_ws.bytes);
+                               nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2, nullptr, 0, ws_ptr(e),
+                               ws_bytes(e));
         prof_end(slot, st, g_last_x3_variant);
     } else {
         GemmArgs g{};
@@ -1000,27 +1002,41 @@ static int sparse_ensure(rlcf_engine* e, int n_e_per_group, hipStream_t st, int 
     return RLCF_OK;
 }
 
-static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_feat, const int32_t* cls, int n_e, int K,
-                           const float* dlogits, float* dctx, hipStream_t st) {
-    ClipModel& m = e->model[RLCF_STUDENT];
+// the two halves of the sparse pass: the forward over the sampled (view, class) pairs needs only their class indices (top-K of the
+// student's own logits) — the one-image call runs it next to the reward models' tower pass —, the backward needs the rewards
+static TextPassIO sparse_io(rlcf_engine* e, int n_e) {
     const TextLayout& L = e->lay[0];
-    const int D = m.cfg.embed_dim;
-    const int T = L.pre_rows + n_e * L.lmax;
-    TRY(launch_build_sparse_layout(cls, 1, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
-                                   L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
-                                   e->sp_row_src.as<int32_t>(), st));
     TextPassIO io{};
-    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = n_e + (L.pre_rows > 0 ? 1 : 0); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = n_e;
+    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = n_e + (L.pre_rows > 0 ? 1 : 0); io.max_q_len = L.max_q_len; io.T = L.pre_rows + n_e * L.lmax;
+    io.n_cls = n_e;
     io.attn_pairs = (long)(n_e * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
     io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
     io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
     io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
     io.ctx_row_tab = L.ctx_general ? L.ctx_row.as<int32_t>() : nullptr;
-    TRY(text_forward(e, m, L, e->st, ctx, io, true, st));
+    return io;
+}
+static int sparse_forward(rlcf_engine* e, const float* ctx, const int32_t* cls, int n_e, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    TRY(launch_build_sparse_layout(cls, 1, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
+                                   L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
+                                   e->sp_row_src.as<int32_t>(), st));
+    return text_forward(e, m, L, e->st, ctx, sparse_io(e, n_e), true, st);
+}
+static int sparse_backward_only(rlcf_engine* e, const float* sel_feat, const int32_t* cls, int n_e, int K, const float* dlogits, float* dctx,
+                                hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    const TextLayout& L = e->lay[0];
+    const int D = m.cfg.embed_dim;
     TRY(launch_dtxt_sparse(dlogits, cls, sel_feat, n_e, K, L.C, D, m.logit_scale_exp, e->sp_dtxt.as<float>(), st));
-    TRY(text_backward(e, m, e->st, io, L.max_keys, e->sp_dtxt.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
-                      e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, L.n_ctx, dctx, st));
-    return RLCF_OK;
+    return text_backward(e, m, e->st, sparse_io(e, n_e), L.max_keys, e->sp_dtxt.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
+                         e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, L.n_ctx, dctx, st);
+}
+static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_feat, const int32_t* cls, int n_e, int K,
+                           const float* dlogits, float* dctx, hipStream_t st) {
+    TRY(sparse_forward(e, ctx, cls, n_e, st));
+    return sparse_backward_only(e, sel_feat, cls, n_e, K, dlogits, dctx, st);
 }
 
 // ------------------------------------------------------------------ one test sample
@@ -1084,6 +1100,12 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     // student image features of all N views: computed once (the image tower is frozen, custom_clip.py:325-327)
     TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
     TextPassIO io = full_io(e, e->lay[0]);
+    static int no_overlap = -1;                              // RLCF_NO_OVERLAP=1: everything on the caller's stream (benchmarks)
+    if (no_overlap < 0) { const char* ev = getenv("RLCF_NO_OVERLAP"); no_overlap = ev ? atoi(ev) : 0; }
+    bool vit_rewards = true;
+    for (int m = 0; m < e->n_rewards; ++m) vit_rewards = vit_rewards && !is_resnet(e->model[RLCF_REWARD + m].cfg);
+    const bool overlap = sparse_ok && vit_rewards && !no_overlap && !g_prof.enabled && e->side && prec_x3(e) && !prec_single(e);
+    bool fwd_done = false;
     for (int j = 0; j < a->tta_steps; ++j) {
         // step 0 runs on ctx == ctx_init: its text features are the cached txt0 (the dense-backward
         // path still needs this pass for its saved activations)
@@ -1096,9 +1118,27 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
             TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
             TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
+            // the reward models' pass over the selected views depends on nothing the student does from here to the loss, and at one
+            // image's sizes neither it nor the sparse text forward fills the chip: second stream, joined before the loss kernel
+            if (overlap) {
+                RLCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+                RLCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                e->ws_sel = 1;
+                const int rc_side = reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, e->side);
+                e->ws_sel = 0;
+                RLCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));       // (recorded even after an error: the main stream must not hang)
+                if (rc_side != RLCF_OK) { RLCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0)); return rc_side; }
+            } else {
+                TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
+            }
             TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
             rows_logits = e->sel_logits.as<float>();
+            if (overlap) {
+                TRY(launch_topk_rows(rows_logits, C, n_sel, C, K, e->topk_idx.as<int32_t>(), e->rl_stats.as<float>(), st));
+                TRY(sparse_forward(e, ctx, e->topk_idx.as<int32_t>(), n_e, st));
+                fwd_done = true;
+                RLCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
             COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
             COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
@@ -1109,7 +1149,10 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
         TRY(launch_reward_loss_bank(rows_logits, C, nullptr, 1, n_sel, C, K, reward_bank(e),
                                a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
                                e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        if (sparse_ok) {
+        if (sparse_ok && fwd_done) {
+            TRY(sparse_backward_only(e, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(), e->ctx_grad.as<float>(), st));
+            fwd_done = false;
+        } else if (sparse_ok) {
             TRY(sparse_backward(e, ctx, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(),
                                 e->ctx_grad.as<float>(), st));
         } else {

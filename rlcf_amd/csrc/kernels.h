@@ -89,6 +89,7 @@ struct RewardBank {                  // reward models of one CLIPScore evaluatio
 };
 // stats: caller-owned scratch of reward_loss_stats_floats(groups * n_sel) floats (engine: sized at set_class_bank)
 size_t reward_loss_stats_floats(int rows);
+int launch_topk_rows(const float* logits, int ld_logits, int rows, int C, int K, int32_t* topk_idx, float* stats, hipStream_t st);
 int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                             const RewardBank& bank, float clipscore_weight, int flags, float min_entropy_w, int32_t* topk_idx,
                             float* clip_score, float* rewards, float* loss, float* dlogits, float* stats, hipStream_t st);

@@ -291,6 +291,16 @@ int launch_reward_loss_bank(const float* logits, int ld_logits, const int32_t* s
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+// top-K classes of every row (torch.topk order) and their cross entropies only: stage A without a reward bank.  The scores it leaves
+// in `stats` are zeros; launch_reward_loss_bank on the same rows later recomputes the identical indices and fills the scores in.
+int launch_topk_rows(const float* logits, int ld_logits, int rows, int C, int K, int32_t* topk_idx, float* stats, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && C > 0 && K > 0 && K <= MAX_K && K <= C && topk_idx && stats);
+    RewardBank none{};
+    none.post_div = 1.f;
+    reward_stage_a_kernel<<<dim3(rows), dim3(TTA_THREADS), 0, st>>>(logits, ld_logits, nullptr, C, K, none, 0.f, topk_idx, stats);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 int launch_reward_loss_grouped(const float* logits, int ld_logits, const int32_t* sel, int groups, int n_sel, int C, int K,
                                const float* class_feat, const float* reward_img, int Dr, float clipscore_weight, int flags,
                                float min_entropy_w, int32_t* topk_idx, float* clip_score, float* rewards, float* loss,
