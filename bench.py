@@ -41,6 +41,7 @@ from rlcf_amd import _lib, shard, synth  # noqa: E402
 from rlcf_amd.engine import Engine, TTAConfig  # noqa: E402
 
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA peaks; f16 = bf16 rate)
+HBM_PEAK_GBS = 8000.0                              # HBM3E, same guide
 PRECISIONS = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16": _lib.PREC_F16}
 MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16": 1}
 DTYPE = {"f32": "f32", "f16x3": "f32 via split-f16x3 MFMA", "f16": "f16 forward pipeline (one MFMA per product, f32 accumulate): NOT parity-grade"}
@@ -237,7 +238,7 @@ def main():
             ent = profile_entries(lib)
             lib.rlcf_profile_gemm(0)
             log(f"roofline leg: {len(ent)} profiled launches")
-            gemms = [e for e in ent if e[0] != 10]
+            gemms = [e for e in ent if e[0] not in (10, 11)]
             dom_kind = 3 if a.precision != "f32" else 0      # 256x256-tile split-f16 GEMM / the f32-MFMA kernels
             dom = [e for e in gemms if e[0] == dom_kind]
             d_ms, d_fl = sum(e[1] for e in dom), sum(e[2] for e in dom)
@@ -256,6 +257,11 @@ def main():
                     ms_, fl_ = sum(e[1] for e in sel), sum(e[2] for e in sel)
                     table.append({"kernel": nm, "M": M_student, "N": n_, "K": k_, "launches": len(sel), "avg_ms": ms_ / len(sel),
                                   "tflops": fl_ / ms_ / 1e9, "frac_of_peak": fl_ / ms_ / 1e9 / peak})
+            ln = [e for e in ent if e[0] == 11 and e[3][0] == M_student]
+            if ln:      # HBM GB/s for the bandwidth-bound kernels — K3 LayerNorm, algorithmic bytes = f32 row in + pair row out
+                ms_, by_ = sum(e[1] for e in ln), sum(e[2] for e in ln)
+                table.append({"kernel": "K3 LayerNorm forward -> operand pairs (HBM-bound)", "rows": M_student, "launches": len(ln),
+                              "avg_ms": ms_ / len(ln), "gb_per_s": by_ / ms_ / 1e6, "frac_of_hbm_peak": by_ / ms_ / 1e6 / HBM_PEAK_GBS})
             att = [e for e in ent if e[0] == 10 and e[3][0] == M_student]
             if att:
                 ms_, fl_ = sum(e[1] for e in att), sum(e[2] for e in att)

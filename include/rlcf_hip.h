@@ -363,7 +363,8 @@ int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
  * 2 = gemm_nt_f16x3_v2_kernel, 1 = gemm_nt_f16x3_kernel, 0 = the f32-MFMA kernels, -1 = all. */
 int rlcf_profile_gemm(int enable);
 int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops);
-/* the same records one by one (launch order): kind as above (10 = the fused attention forward of the split-f16 pipeline),
+/* the same records one by one (launch order): kind as above (10 = the fused attention forward of the split-f16 pipeline; 11 = the LayerNorm forward that writes
+ * operand pairs, an HBM-bound kernel: its `flops` value is its ALGORITHMIC BYTES, dims3 = {rows, width, 0}),
  * HIP-event duration in ms, algorithmic FLOPs, dims3 = {M, N, K} of a GEMM / {rows, width, longest sequence} of an attention launch */
 int rlcf_profile_count(void);
 int rlcf_profile_entry(int i, int* kind, double* ms, double* flops, int* dims3);

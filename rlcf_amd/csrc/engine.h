@@ -167,7 +167,8 @@ struct GemmProfile {                 // optional per-launch timing of the domina
     std::vector<hipEvent_t> ev;      // 2 per launch
     std::vector<double> flops;
     std::vector<int> kind;           // 0 = f32 MFMA kernels, 1 = f16x3 128x128, 2 = f16x3 256x128, 3 = f16x3 256x256 (the dominant kernel),
-                                     // 10 = fused attention forward (split-f16 pipeline)
+                                     // 10 = fused attention forward (split-f16 pipeline), 11 = LayerNorm forward with pair output (HBM-bound:
+                                     // `flops` holds its algorithmic bytes)
     std::vector<int> dims;           // 3 per launch: GEMM M, N, K; attention: rows, width, longest sequence
 };
 extern int g_last_x3_variant;

@@ -514,8 +514,12 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
 #define LN_FWD_SPLIT(xp, wp, bp, hh, hl, rows, W)                                                                           \
     do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
          const bool sg_ = prec_single(e);                 /* RLCF_PREC_F16: plain f16 rows, no lo part */                    \
-         TRY(launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), sg_ ? nullptr : (hl), (rows), (W), st, gw_.group_rows,     \
-                                        gw_.group_stride, sg_ ? 0 : 1)); } while (0)
+         /* profile record of kind 11: an HBM-bound kernel, the `flops` field carries its ALGORITHMIC BYTES (f32 row in, pair row out) */ \
+         const int ps_ = prof_begin(st, (double)(rows) * (W) * (sg_ ? 6.0 : 8.0), (rows), (W), 0);                             \
+         int rc_ln_ = launch_layernorm_fwd_split((xp), gw_.p, gb_.p, nullptr, (hh), sg_ ? nullptr : (hl), (rows), (W), st, gw_.group_rows, \
+                                                 gw_.group_stride, sg_ ? 0 : 1);                                              \
+         prof_end(ps_, st, 11);                                                                                                \
+         TRY(rc_ln_); } while (0)
 
 // cls_seqs / cls_idx / cls_out (image towers, split-f16 pipeline): only row `cls_idx[s]` of every sequence is consumed after the
 // last block (ln_post(x[:, 0]) @ proj, model.py:235-238), and out_proj, the MLP and the residual adds act row by row — so the LAST
