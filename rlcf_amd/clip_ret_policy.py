@@ -19,6 +19,13 @@ from . import clip_reward as _cr
 from . import clip_store, runtime
 from .engine import TTAConfig
 
+_VERSION = [0]       # bumped whenever a model or a reward model takes new image features (tune_text re-sends the bank to the engine then)
+
+
+def _next_version() -> int:
+    _VERSION[0] += 1
+    return _VERSION[0]
+
 
 class CLIPRet_TTA(nn.Module):
     """retrieval/custom_models.py:29-163.  only_visual=True: `parameters()` = [LayerNorm vector, flat vector of every other visual
@@ -59,7 +66,7 @@ class CLIPRet_TTA(nn.Module):
         if images is not None:
             step = runtime.SESSION.max_views
             image_features = torch.cat([self.get_image_features(images[i: i + step]) for i in range(0, images.shape[0], step)])
-        self.image_features = image_features
+        self.image_features, self._img_version = image_features, _next_version()
 
     def _fetch(self):
         eng = runtime.SESSION.engine()
@@ -164,11 +171,12 @@ class CLIPRewards(_cr.CLIPRewards):
         if image_features is None:
             step = runtime.SESSION.max_views
             image_features = torch.cat([self.extract_image_features(images[i: i + step]) for i in range(0, images.shape[0], step)])
-        self.image_features = image_features
+        self.image_features, self._img_version = image_features, _next_version()
 
     @torch.no_grad()
     def set_image_features_with_dataloder(self, data_loader):                                     # retrieval/clip_reward.py:208-215
         self.image_features = torch.cat([self.extract_image_features(s["image"].to(self.device)) for s in data_loader], dim=0)
+        self._img_version = _next_version()
 
     @torch.no_grad()
     def CLIPScore(self, text_index=None, images_index=None, pairwise=True):
@@ -214,11 +222,12 @@ def tune_text(text, model, reward_model, optimizer, scaler, args=None):
     if not (torch.equal(model.ln.data, model._ln_init) and torch.equal(model.vis.data, model._vis_init)):
         raise NotImplementedError("tune_text starts from the reset state (model.reset_initial(), clip_ret_policy.py:196)")
     tok = clip_store.tokenize(text).reshape(1, -1)
-    bank = runtime.SESSION.image_bank       # the engine's bank follows the two feature tensors the loop set (:184-185)
-    if bank is None or getattr(runtime.SESSION, "_image_bank_src", None) != (id(model.image_features), id(reward_model.image_features)):
+    # the engine's bank follows the two feature tensors the loop set (:184-185): version counters bumped by the setters, not id()s
+    src = (getattr(model, "_img_version", None), getattr(reward_model, "_img_version", None), model.image_features.data_ptr(),
+           reward_model.image_features.data_ptr(), tuple(model.image_features.shape))       # (a tensor assigned past the setters has no version: re-sent)
+    if runtime.SESSION.image_bank is None or None in src or getattr(runtime.SESSION, "_image_bank_src", None) != src:
         runtime.SESSION.set_image_bank(model.image_features, reward_model.image_features)
-        runtime.SESSION._image_bank_src = (id(model.image_features), id(reward_model.image_features))
-        model._bank_refs = (model.image_features, reward_model.image_features)       # keeps the ids alive
+        runtime.SESSION._image_bank_src = src
     out = runtime.SESSION.engine().tta_retrieval_text(tok[0], cfg)
     reward_model.class_features = out["reward_text_features"]             # reward_model.set_text_features(captions=text), :117
     with torch.no_grad():

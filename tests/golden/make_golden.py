@@ -144,7 +144,9 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
         rm = ref.clip_reward.CLIPRewards("cpu", arch=reward, classification=True,
                                          amplify_rewards=hp.get("reward_amplify", False), sample_k=hp["sample_k"],
                                          reward_process=hp.get("reward_process", True),
-                                         process_batch=hp.get("process_batch", False))
+                                         process_batch=hp.get("process_batch", False),
+                                         **({"default_resolutions": s_geo.image_resolution} if s_geo.image_resolution != 224 and
+                                            r_geo.image_resolution == 224 else {}))     # views at 448 (RN50x64 student), reward model at 224
     assert torch.equal(model.prompt_learner.tokenized_prompts, bank.tokens)
     rm.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
     with warnings.catch_warnings():
@@ -431,6 +433,9 @@ TTA_CASES = {
     "tta_b16_rl14_s3": ("ViT-B/16", "ViT-L/14", 8, 1000, dict(tta_steps=3, view_seed=B16L14_SEED)),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
+    # BASELINE configs[4] at FULL geometry: RN50x64 student (448^2 views) + ViT-L/14 reward (bicubic 448 -> 224), N=32; 200 classes (the
+    # reference's autograd tape over the 1024-wide text tower of 1000 x 77 tokens does not fit the build container's 62 GB)
+    "tta_rn50x64_l14_n32": ("RN50x64", "ViT-L/14", 32, 200, dict(selection_p=0.1)),
 }
 GROUPS = {
     "tiny": [k for k in TTA_CASES if k.startswith("tta_tiny") and k != "tta_tiny_rres" and "ens" not in k and "_rn" not in k
@@ -443,6 +448,7 @@ GROUPS = {
     "b16n8": ["tta_b16_n8"],
     "b16l14": ["tta_b16_rl14_s3"],
     "b16n64": ["tta_b16_n64"],
+    "cfg5": ["tta_rn50x64_l14_n32"],
 }
 
 

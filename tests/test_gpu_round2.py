@@ -565,6 +565,27 @@ def test_retrieval_text_to_image_tuning_matches_reference_fixture(L, dev, prec):
     eng.close()
 
 
+@pytest.mark.parametrize("prec", [0, 2])
+def test_config5_full_geometry_matches_reference_fixture(L, dev, prec):
+    """BASELINE configs[4] at FULL geometry against the reference's own run (tta_rn50x64_l14_n32: RN50x64 student on 448^2 views,
+    ViT-L/14 reward model behind the bicubic 448 -> 224 resample, N = 32 views, 200 classes, prompt tuning): selected views, sampled
+    classes, scores, rewards, prompt gradient / update, final logits and top-5 — through rlcf_tta_sample and, two copies per pass,
+    through rlcf_tta_batch."""
+    from test_gpu_parity import make_engine, _check_against, _cfg_from_meta as cfgm
+    g, meta = load_golden("tta_rn50x64_l14_n32")
+    eng, ssd, rsd, tokens, ctx0 = make_engine((meta["student"], meta["reward"]), meta["n_views"] * 2, meta["n_cls"], L.TEXT_SHARED,
+                                              meta["student_seed"], meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=prec)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution, device=dev)
+    o = eng.tta_sample(views, cfgm(meta, True))
+    torch.cuda.synchronize()
+    _check_against(o, g, meta)
+    top5, fl = eng.tta_batch(torch.stack([views, views]), cfgm(meta, True), want_logits=True)
+    for b in range(2):
+        assert top5[b].cpu().tolist() == g["top5"].tolist()
+        torch.testing.assert_close(fl[b].cpu(), g["final_logits"][0], atol=1e-3, rtol=0)
+    eng.close()
+
+
 def test_ln_batch_matches_reference_at_full_size_l14_n64(L, dev):
     """BASELINE configs[2] at FULL size (ViT-L/14 + ViT-L/14, N = 64 views, C = 1000, LayerNorm tuning) through the sample-batched call
     rlcf_tta_batch_ln, two copies of the reference's sample per pass: top-5 and final logits of the reference's own run (ln_l14_n64)."""
