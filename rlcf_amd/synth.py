@@ -284,8 +284,10 @@ def ctx_token_ids_default(geo: ClipGeometry, n_ctx: int) -> Tuple[int, ...]:
     return out
 
 
-def reward_members(spec: str, seeds) -> list:
-    """'geoA+geoB+...' and '23+29+...' (or a list of ints) -> [(geometry, state dict), ...]: the members of a reward ensemble."""
+def reward_members(spec: str, seeds, device=None) -> list:
+    """'geoA+geoB+...' and '23+29+...' (or a list of ints) -> [(geometry, state dict), ...]: the members of a reward ensemble
+    (device: where the weights are generated — the generator is bit-identical on CPU and GPU up to the last bit of BatchNorm statistics)."""
     names = spec.split("+")
     seeds = [int(x) for x in seeds.split("+")] if isinstance(seeds, str) else list(seeds)
-    return [(GEOMETRIES[n], make_state_dict(GEOMETRIES[n], seed=s)) for n, s in zip(names, seeds)]
+    kw = {} if device is None else {"device": device}
+    return [(GEOMETRIES[n], make_state_dict(GEOMETRIES[n], seed=s, **kw)) for n, s in zip(names, seeds)]

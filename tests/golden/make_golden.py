@@ -207,7 +207,8 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     if ensemble:
         for i in range(rm.n_model):
             out[f"reward_image_features_{i}"] = rm.image_features[i].clone()
-            out[f"reward_class_features_{i}"] = rm.class_features[i].clone()
+            # (large banks: every 25th class row — the fixture stays small; the test compares the same rows)
+            out[f"reward_class_features_{i}"] = rm.class_features[i].clone() if n_cls <= 64 else rm.class_features[i][::25].clone()
         out["reward_weights"] = torch.tensor(rm.weights)
     else:
         out.update(reward_image_features=rm.image_features.clone(), reward_class_features=rm.class_features.clone())
@@ -433,6 +434,10 @@ TTA_CASES = {
     "tta_b16_rl14_s3": ("ViT-B/16", "ViT-L/14", 8, 1000, dict(tta_steps=3, view_seed=B16L14_SEED)),
     # view seed chosen (tools/find_seed.py) so that two views get non-zero CLIP rewards: a non-trivial gradient
     "tta_b16_n64": ("ViT-B/16", "ViT-B/16", 64, 1000, dict(selection_p=0.1, view_seed=1113)),
+    # the paper's strongest reward setting at full size: the arch list get_reward_model really uses (clip_reward.py:31) — ViT-L/14@336px,
+    # RN50x64 (448^2), ViT-L/14 — scoring the 224^2 views of a ViT-B/16 student through the bicubic align_corners=True upsample
+    "tta_b16_ensfull_n64": ("ViT-B/16", "ViT-L/14@336px+RN50x64+ViT-L/14", 64, 1000,
+                            dict(selection_p=0.1, reward_seeds="23+29+31", reward_archs="ViT-L/14@336px+RN50x64+ViT-L/14", view_seed=1113)),
     # BASELINE configs[4] at FULL geometry: RN50x64 student (448^2 views) + ViT-L/14 reward (bicubic 448 -> 224), N=32; 200 classes (the
     # reference's autograd tape over the 1024-wide text tower of 1000 x 77 tokens does not fit the build container's 62 GB)
     "tta_rn50x64_l14_n32": ("RN50x64", "ViT-L/14", 32, 200, dict(selection_p=0.1)),
@@ -449,6 +454,7 @@ GROUPS = {
     "b16l14": ["tta_b16_rl14_s3"],
     "b16n64": ["tta_b16_n64"],
     "cfg5": ["tta_rn50x64_l14_n32"],
+    "ensfull": ["tta_b16_ensfull_n64"],
 }
 
 

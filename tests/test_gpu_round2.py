@@ -586,6 +586,28 @@ def test_config5_full_geometry_matches_reference_fixture(L, dev, prec):
     eng.close()
 
 
+def test_reward_ensemble_full_size_matches_reference_fixture(L, dev):
+    """The reward ensemble at FULL size against the reference's own run (tta_b16_ensfull_n64: ViT-B/16 student, N = 64 views, 1000 classes,
+    CLIPRewardsMultiple over the arch list get_reward_model really uses — ViT-L/14@336px, RN50x64 @448^2, ViT-L/14, weights
+    [0.56, 0.17, 0.28] — each scoring the selected 224^2 views through its own bicubic align_corners=True resample), product-default
+    split-f16 precision, through rlcf_tta_sample and rlcf_tta_batch."""
+    from test_gpu_parity import make_ensemble_engine, _check_against, _cfg_from_meta as cfgm
+    g, meta = load_golden("tta_b16_ensfull_n64")
+    eng, members, tokens = make_ensemble_engine(meta, L.TEXT_SHARED, prec=L.PREC_F16X3, device=dev)
+    eng.set_reward_mix(g["reward_weights"].tolist(), mean=not meta.get("weighted_scores", 1))
+    for m in range(len(members)):
+        torch.testing.assert_close(eng.reward_class_features(m).cpu()[::25], g[f"reward_class_features_{m}"], atol=2e-5, rtol=1e-4)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], synth.GEOMETRIES[meta["student"]].image_resolution, device=dev)
+    o = eng.tta_sample(views, cfgm(meta, True))
+    torch.cuda.synchronize()
+    for m in range(len(members)):
+        torch.testing.assert_close(o["reward_image_features"][m].cpu(), g[f"reward_image_features_{m}"], atol=3e-5, rtol=1e-4)
+    _check_against(o, g, meta)
+    top5 = eng.tta_batch(views[None], cfgm(meta, True))
+    assert top5[0].cpu().tolist() == g["top5"].tolist()
+    eng.close()
+
+
 def test_ln_batch_matches_reference_at_full_size_l14_n64(L, dev):
     """BASELINE configs[2] at FULL size (ViT-L/14 + ViT-L/14, N = 64 views, C = 1000, LayerNorm tuning) through the sample-batched call
     rlcf_tta_batch_ln, two copies of the reference's sample per pass: top-5 and final logits of the reference's own run (ln_l14_n64)."""
