@@ -14,7 +14,10 @@
  *   - an engine is not thread-safe; no allocation happens on the per-sample path: every scratch buffer of the engine calls
  *     belongs to the engine (one engine = one device, one stream at a time; two engines never share memory).  The stateless
  *     op-level calls that need scratch (rlcf_gemm_nt in split-f16 mode, rlcf_reward_loss*) take it from the stream-ordered
- *     allocator of `stream` (hipMallocAsync / hipFreeAsync).
+ *     allocator of `stream` (hipMallocAsync / hipFreeAsync);
+ *   - an engine owns one side stream: rlcf_tta_sample (one test image per call) forks the reward models' tower pass onto it behind
+ *     an event recorded on `stream` and joins it back with a second event before the loss kernel, so the call stays ordered on
+ *     `stream` as a whole (work enqueued on `stream` afterwards sees all its results).  No host thread, no host synchronisation.
  */
 #ifndef RLCF_HIP_H
 #define RLCF_HIP_H
