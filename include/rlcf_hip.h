@@ -113,6 +113,11 @@ int rlcf_attention_bwd_flash(const float* qkv, const float* out, const float* ls
 
 /* Per-row entropy H = -sum softmax*log_softmax and the int(N*top) lowest-entropy rows in
  * ascending order: select_confident_samples, TPT/tpt_cls_rl.py:32-35.  idx[n_sel]. */
+/* the same with the arithmetic chosen: RLCF_PREC_F32 = rlcf_attention_bwd_flash; RLCF_PREC_F16X3 = the split-f16 kernel the engine's
+ * backward passes use in that mode (attention_bwd_x3.hip: three f16 MFMAs per product, dout lifted by a power of two found on the
+ * device).  The op-level call reads the sequence descriptors back once to find the extent of dout (engine calls do not). */
+int rlcf_attention_bwd_flash_prec(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
+                                  int max_q_len, int width, int causal, float* dqkv, int precision, rlcf_stream stream);
 int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy,
                         int32_t* idx, rlcf_stream stream);
 

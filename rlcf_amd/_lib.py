@@ -67,6 +67,7 @@ SIGNATURES = {
     "rlcf_layernorm_fwd": (I, [P, P, P, P, I, I, P]),
     "rlcf_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "rlcf_attention_bwd_flash": (I, [P, P, P, P, P, I, I, I, I, P, P]),
+    "rlcf_attention_bwd_flash_prec": (I, [P, P, P, P, P, I, I, I, I, P, I, P]),
     "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),
     "rlcf_attention_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "rlcf_entropy_select": (I, [P, I, I, I, P, P, P]),

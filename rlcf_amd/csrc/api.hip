@@ -102,6 +102,24 @@ int rlcf_attention_bwd_flash(const float* qkv, const float* out, const float* ls
     RLCF_ARG_CHECK(qkv && out && lse && dout && seqs && dqkv);
     return launch_attention_bwd_mfma(qkv, out, lse, dout, seqs, n_seq, max_q_len, width, causal, dqkv, (hipStream_t)stream);
 }
+int rlcf_attention_bwd_flash_prec(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
+                                  int max_q_len, int width, int causal, float* dqkv, int precision, rlcf_stream stream) {
+    RLCF_ARG_CHECK(qkv && out && lse && dout && seqs && dqkv && (precision == RLCF_PREC_F32 || precision == RLCF_PREC_F16X3));
+    if (precision == RLCF_PREC_F32)
+        return launch_attention_bwd_mfma(qkv, out, lse, dout, seqs, n_seq, max_q_len, width, causal, dqkv, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    int rows = 0;                               // rows of dout: one past the last query row any sequence names (HOST copy of the descriptors)
+    std::vector<rlcf_seq> hs(n_seq);
+    RLCF_HIP_CHECK(hipMemcpyAsync(hs.data(), seqs, (size_t)n_seq * sizeof(rlcf_seq), hipMemcpyDeviceToHost, st));
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    for (const rlcf_seq& q : hs) rows = std::max(rows, q.q_start + q.q_len);
+    float* amax = nullptr;
+    RLCF_HIP_CHECK(hipMallocAsync((void**)&amax, sizeof(float), st));
+    int rc = launch_absmax(dout, (int64_t)rows * width, amax, st);
+    if (rc == RLCF_OK) rc = launch_attention_bwd_x3(qkv, out, lse, dout, amax, seqs, n_seq, max_q_len, width, causal, dqkv, st);
+    (void)hipFreeAsync(amax, st);
+    return rc;
+}
 int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, rlcf_stream stream) {
     RLCF_ARG_CHECK(logits && entropy && (idx || n_sel == 0));
     return launch_entropy_select(logits, n, C, n_sel, entropy, idx, (hipStream_t)stream);

@@ -647,7 +647,13 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         if (wgrad_base) TRY(wgrad(e, dX, W, W, s.a, W, W, T, G[2], G[3], st));      // out_proj: x1 = x + a Wo^T + b, dY = d x1
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
-        if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
+        static int bwd_f32 = -1;                                // RLCF_ATTN_BWD_F32=1: the f32-MFMA backward also in split-f16 mode (benchmarks)
+        if (bwd_f32 < 0) { const char* ev = getenv("RLCF_ATTN_BWD_F32"); bwd_f32 = ev ? atoi(ev) : 0; }
+        if (max_keys > 96 && prec_x3(e) && !bwd_f32) {
+            TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));       // range of dO for the f16 pairs
+            TRY(launch_attention_bwd_x3(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal,
+                                        dQKV, st));
+        } else if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
         e->last_flops += 10.0 * attn_pairs * W;
         if (wgrad_base) {                  // in_proj: qkv = LN1(x) Win^T + b

@@ -105,6 +105,9 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
                             void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr, int single = 0 /* plain f16, one MFMA per product */);
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
+// split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)
+int launch_attention_bwd_x3(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,
+                            int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,
                               int width, int causal, float* dqkv, hipStream_t st);
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,

@@ -162,6 +162,19 @@ def test_attention_fwd_bwd(L, dev, name, seqs, T, W, causal):
     L.check(L.lib().rlcf_attention_bwd_flash(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), do.to(dev).data_ptr(), sbuf.data_ptr(), len(seqs),
                                              mq, W, causal, dq2.data_ptr(), st()))
     torch.testing.assert_close(dq2.cpu().double(), q64.grad, atol=2e-5, rtol=1e-4)
+    # ... and its split-f16 form (attention_bwd_x3.hip: what the engine's backward passes run in RLCF_PREC_F16X3), on a gradient of
+    # the magnitude the tuning paths see (1e-4: far below f16's normal range without the device-side power-of-two lift)
+    for gs in (1.0, 1e-4):
+        dq3 = torch.zeros(T, 3 * W, device=dev)
+        dos = (do * gs).to(dev)
+        L.check(L.lib().rlcf_attention_bwd_flash_prec(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), dos.data_ptr(), sbuf.data_ptr(), len(seqs),
+                                                      mq, W, causal, dq3.data_ptr(), L.PREC_F16X3, st()))
+        # accuracy of the split-f16 products: every operand carries 22 bits, so a sum of products is off by ~2.4e-7 x the sum of the
+        # |terms| — invisible in dK / dV here, visible (1e-4 of the largest gradient) in the rare dQ row whose dS entries are large
+        # and cancel.  Asserted: 99.9 % of the elements as tight as the f32-MFMA kernel's check, none beyond 2e-4 of the largest gradient.
+        err, gref = (dq3.cpu().double() / gs - q64.grad).abs(), q64.grad.abs()
+        assert float((err > 3e-5 + 2e-4 * gref).double().mean()) < 1e-3
+        assert float(err.max()) <= 2e-4 * float(gref.max())
 
 
 @pytest.mark.parametrize("n,Cn,p", [(16, 50, 0.25), (64, 1000, 0.1), (8, 16, 0.5), (16, 50, 0.05)])
