@@ -340,6 +340,10 @@ int64_t rlcf_engine_text_param_count(rlcf_engine*, int* ln_count, rlcf_stream st
 int rlcf_engine_text_param_layout(rlcf_engine*, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream);
 /* copy the flat vector and / or the LayerNorm vector out (either pointer may be NULL): which = 0 live, 1 reset state */
 int rlcf_engine_get_text_params(rlcf_engine*, float* flat, float* ln, int which, rlcf_stream stream);
+/* CLIPRet_TTA.momentum_update_model (retrieval/custom_models.py:128-143) for the text side: cur_* = out->vis_after / ln_after of the
+ * caption just processed; mom = m * mom + (1 - m) * cur; apply != 0: reset state = (1 - update_w) * checkpoint + update_w * mom */
+int rlcf_engine_momentum_update_text(rlcf_engine*, const float* cur_flat, const float* cur_ln, double momentum, double update_w, int apply,
+                                     rlcf_stream stream);
 /* floats in the flat vector (padding included); 0 + error for a ModifiedResNet student */
 int64_t rlcf_engine_visual_param_count(rlcf_engine*, rlcf_stream stream);
 /* offsets / element counts of its 4 + 8*layers tensors in the order above; returns the number of tensors (or a negative error) */

@@ -105,6 +105,7 @@ SIGNATURES = {
     "rlcf_engine_text_param_count": (I64, [P, P, P]),
     "rlcf_engine_text_param_layout": (I, [P, P, P, I, P]),
     "rlcf_engine_get_text_params": (I, [P, P, P, I, P]),
+    "rlcf_engine_momentum_update_text": (I, [P, P, P, D, D, I, P]),
     "rlcf_engine_visual_param_count": (I64, [P, P]),
     "rlcf_engine_visual_param_layout": (I, [P, P, P, I, P]),
     "rlcf_engine_get_visual_params": (I, [P, P, I, P]),

@@ -34,8 +34,6 @@ class CLIPRet_TTA(nn.Module):
 
     def __init__(self, device, arch="ViT-B-16", only_visual=True, momentum_update=False, update_freq=256, update_w=1.0, momentum=0.9999):
         super().__init__()
-        if not only_visual and momentum_update:
-            raise NotImplementedError("momentum_update of the text side (custom_models.py:128-143): not built")
         self.clip_model, _, _ = clip_store.load(arch, device=device)
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.only_visual, self.momentum_update = device, only_visual, momentum_update
@@ -106,10 +104,15 @@ class CLIPRet_TTA(nn.Module):
         if apply:
             self.update_counter = 0
         eng = runtime.SESSION.engine()
-        eng.momentum_update(self.ln.data, self.momentum, self.update_w, apply)
-        eng.momentum_update_visual(self.vis.data, self.momentum, self.update_w, apply)
-        if apply:
-            self._ln_init, self._vis_init = eng.ln_params(pristine=True), eng.visual_params(1)
+        if self.only_visual:
+            eng.momentum_update(self.ln.data, self.momentum, self.update_w, apply)
+            eng.momentum_update_visual(self.vis.data, self.momentum, self.update_w, apply)
+            if apply:
+                self._ln_init, self._vis_init = eng.ln_params(pristine=True), eng.visual_params(1)
+        else:
+            eng.momentum_update_text(self.vis.data, self.ln.data, self.momentum, self.update_w, apply)
+            if apply:
+                self._vis_init, self._ln_init = eng.text_params(1)
 
     @torch.no_grad()
     def forward(self, images=None, text=None, tokenized_prompts=None):

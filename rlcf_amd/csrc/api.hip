@@ -287,7 +287,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
                      &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
-                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
+                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }
 
@@ -397,6 +397,20 @@ int rlcf_engine_get_text_params(rlcf_engine* e, float* flat, float* ln, int whic
     if (flat) RLCF_HIP_CHECK(hipMemcpyAsync(flat, (which ? e->tw_init : e->tw).p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (ln) RLCF_HIP_CHECK(hipMemcpyAsync(ln, (which ? e->tln_init : e->tln).p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return RLCF_OK;
+}
+int rlcf_engine_momentum_update_text(rlcf_engine* e, const float* cur_flat, const float* cur_ln, double momentum, double update_w, int apply,
+                                     rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && cur_flat && cur_ln && momentum >= 0.0 && momentum <= 1.0);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = engine_text_enable(e, st);
+    if (rc != RLCF_OK) return rc;
+    rc = launch_momentum_update(e->tw_mom.as<float>(), cur_flat, e->tw_clip.as<float>(), e->tw_init.as<float>(), (int64_t)e->tw_count, momentum,
+                                update_w, apply, st);
+    if (rc != RLCF_OK) return rc;
+    rc = launch_momentum_update(e->tln_mom.as<float>(), cur_ln, e->tln_clip.as<float>(), e->tln_init.as<float>(), (int64_t)e->tln_count, momentum,
+                                update_w, apply, st);
+    if (rc != RLCF_OK) return rc;
+    return apply ? engine_text_reset(e, st, true) : RLCF_OK;      // reset_initial() loads the new initial_state_dict: live copy + derived forms follow
 }
 int64_t rlcf_engine_visual_param_count(rlcf_engine* e, rlcf_stream stream) {
     if (!e || engine_visual_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;

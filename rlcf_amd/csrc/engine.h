@@ -135,6 +135,7 @@ struct rlcf_engine {
     // token_embedding.weight, positional_embedding, text_projection, per block the 8 Linear tensors (order of vw), logit_scale — one
     // flat buffer; the text LayerNorms [ln_final.w | ln_final.b | per block ln_1.w ln_1.b ln_2.w ln_2.b] in a second one
     DevBuf tw, tw_init, tw_grad, tw_m, tw_v, tln, tln_init, tln_grad, tln_m, tln_v;
+    DevBuf tw_clip, tw_mom, tln_clip, tln_mom;       // pristine checkpoint values / momentum state (CLIPRet_TTA.momentum_update_model)
     size_t tw_count = 0;
     int tln_count = 0;
     bool tw_dirty = false;
@@ -204,6 +205,7 @@ int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_t
 int engine_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_visual_enable(rlcf_engine* e, hipStream_t st);
 int engine_text_enable(rlcf_engine* e, hipStream_t st);
+int engine_text_reset(rlcf_engine* e, hipStream_t st, bool force);
 int engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, hipStream_t st);
 int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 int engine_visual_refresh(rlcf_engine* e, hipStream_t st);

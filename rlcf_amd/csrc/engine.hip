@@ -1635,6 +1635,7 @@ int engine_text_enable(rlcf_engine* e, hipStream_t st) {
     NEED(ls);
     RLCF_HIP_CHECK(hipMemcpyAsync(e->tw.as<float>() + e->tw_slots.back().off, ls, sizeof(float), hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(e->tw_init.p, e->tw.p, nb, hipMemcpyDeviceToDevice, st));
+    for (DevBuf* d : {&e->tw_clip, &e->tw_mom}) { TRY(d->ensure(nb)); RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->tw.p, nb, hipMemcpyDeviceToDevice, st)); }
     // LayerNorms: [ln_final.weight | ln_final.bias | per block ln_1.weight ln_1.bias ln_2.weight ln_2.bias] (transformer_backward's layout)
     const int L = c.text_layers;
     e->tln_count = (int)((4 * L + 2) * Wt);
@@ -1649,6 +1650,7 @@ int engine_text_enable(rlcf_engine* e, hipStream_t st) {
             *slots[i] = P + i * Wt;
         }
         RLCF_HIP_CHECK(hipMemcpyAsync(e->tln_init.p, P, lb, hipMemcpyDeviceToDevice, st));
+        for (DevBuf* d : {&e->tln_clip, &e->tln_mom}) { TRY(d->ensure(lb)); RLCF_HIP_CHECK(hipMemcpyAsync(d->p, P, lb, hipMemcpyDeviceToDevice, st)); }
     }
     e->tw_refresh.clear();
     auto add_split = [&](const float* w, size_t numel) {
@@ -1732,7 +1734,7 @@ int engine_set_image_bank(rlcf_engine* e, const float* student_feats, const floa
     return RLCF_OK;
 }
 
-static int text_reset(rlcf_engine* e, hipStream_t st, bool force = false) {      // clip_model.load_state_dict(initial_state_dict) for the text side
+int engine_text_reset(rlcf_engine* e, hipStream_t st, bool force) {      // clip_model.load_state_dict(initial_state_dict) for the text side
     if (!e->tw_count || (!e->tw_dirty && !force)) return RLCF_OK;
     RLCF_HIP_CHECK(hipMemcpyAsync(e->tw.p, e->tw_init.p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(e->tln.p, e->tln_init.p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1761,7 +1763,7 @@ int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_
     if (!out) out = &none;
     e->last_flops = 0.0;
     // model.reset_initial() + a fresh optimizer state (clip_ret_policy.py:186-190)
-    TRY(text_reset(e, st));
+    TRY(engine_text_reset(e, st, false));
     const size_t wb = e->tw_count * sizeof(float), lb = (size_t)e->tln_count * sizeof(float);
     for (DevBuf* d : {&e->tw_m, &e->tw_v}) RLCF_HIP_CHECK(hipMemsetAsync(d->p, 0, wb, st));
     for (DevBuf* d : {&e->tln_m, &e->tln_v}) RLCF_HIP_CHECK(hipMemsetAsync(d->p, 0, lb, st));
@@ -1863,6 +1865,6 @@ int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_
         TRY(logits_per_text(e->final_logits.as<float>()));
         COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
     }
-    TRY(text_reset(e, st));
+    TRY(engine_text_reset(e, st, false));
     return RLCF_OK;
 }

@@ -362,6 +362,11 @@ class Engine:
         L.check(self.lib.rlcf_engine_get_text_params(self.h, _ptr(flat), _ptr(ln), which, _stream()), "get_text_params")
         return flat, ln
 
+    def momentum_update_text(self, cur_flat: torch.Tensor, cur_ln: torch.Tensor, momentum: float, update_w: float, apply: bool) -> None:
+        f, l = cur_flat.detach().to(self.device, torch.float32).contiguous(), cur_ln.detach().to(self.device, torch.float32).contiguous()
+        L.check(self.lib.rlcf_engine_momentum_update_text(self.h, _ptr(f), _ptr(l), float(momentum), float(update_w), 1 if apply else 0,
+                                                          _stream()), "momentum_update_text")
+
     def set_image_bank(self, student_feats: torch.Tensor, reward_feats) -> None:
         """The bank of the text -> image direction: L2-normalised image features under the student [n, D] and under every reward model
         (a tensor [n, Dr], or a list of them).  Replaces the class / caption bank."""

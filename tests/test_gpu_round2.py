@@ -459,6 +459,55 @@ def test_retrieval_text_tuning_full_size_matches_oracle(L, dev):
     eng.close()
 
 
+def test_retrieval_text_tuning_momentum_matches_oracle(L, dev):
+    """CLIPRet_TTA.momentum_update_model on the text side (retrieval/custom_models.py:128-143, scripts/tta_coco_ret.sh setting 03): an
+    EMA of the tuned text parameters across captions, folded into the reset state every update_freq captions.  Three captions,
+    update_freq = 2: rlcf_tta_retrieval_text + rlcf_engine_momentum_update_text against the oracle's tune_text run from the oracle's
+    own evolving reset state (oracle.rlcf_ref.momentum_update)."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    from oracle import retrieval_ref as QR, rlcf_ref as RR2
+    sg, rg = synth.GEOMETRIES["tiny"], synth.GEOMETRIES["tiny-r"]
+    ssd, rsd = synth.make_state_dict(sg, 11), synth.make_state_dict(rg, 23)
+    n, K, lr, m, w = 120, 6, 1e-3, 0.9, 0.5
+    gen = torch.Generator().manual_seed(9)
+    sbank = torch.nn.functional.normalize(torch.randn(n, sg.embed_dim, generator=gen), dim=-1)
+    rbank = torch.nn.functional.normalize(torch.randn(n, rg.embed_dim, generator=gen), dim=-1)
+    bank = synth.make_token_bank(sg, 16, seed=7, n_ctx=4)
+    hp = RR2.TTAHyper(selection_p=1.0, tta_steps=1, sample_k=K, lr=lr, weight_decay=5e-4, eps=1e-6)
+    cfg = TTAConfig(selection_p=1.0, tta_steps=1, sample_k=K, lr=lr, weight_decay=5e-4, eps=1e-6)
+    eng = Engine(sg, rg, 8, n, L.PREC_F32)
+    eng.load_state_dict(L.STUDENT, {k: v.to(dev) for k, v in ssd.items()})
+    eng.load_state_dict(L.REWARD, {k: v.to(dev) for k, v in rsd.items()})
+    eng.finalize()
+    eng.set_image_bank(sbank.to(dev), rbank.to(dev))
+    keys = QR.text_param_keys(ssd)
+    vec = lambda d: torch.cat([d[k].reshape(-1) for k in keys])
+    def unvec(v):
+        out, off = {}, 0
+        for k in keys:
+            out[k] = v[off: off + ssd[k].numel()].reshape(ssd[k].shape).clone(); off += ssd[k].numel()
+        return out
+    clip = vec(ssd)
+    init, mom = clip.clone(), clip.clone()
+    for i, row in enumerate([5, 9, 12]):
+        sd_i = dict(ssd); sd_i.update(unvec(init))
+        ref = QR.tune_text(sd_i, rsd, bank[row][None], None, hp, student_bank=sbank, reward_bank=rbank)
+        o = eng.tta_retrieval_text(bank[row], cfg)
+        torch.cuda.synchronize()
+        assert o["topk_idx"].cpu().reshape(-1).tolist() == ref["topk_idx"].reshape(-1).tolist()
+        torch.testing.assert_close(o["logits"].cpu(), ref["logits"], atol=1e-3, rtol=0)             # (the reset state of caption i)
+        torch.testing.assert_close(o["final_logits"].cpu(), ref["final_logits"], atol=3e-3, rtol=0)
+        apply = (i + 1) % 2 == 0
+        mom, new_init = RR2.momentum_update(mom, ref["after"], clip, m, w, apply)
+        if new_init is not None:
+            init = new_init
+        eng.momentum_update_text(o["text_after"], o["ln_after"], m, w, apply)
+        flat1, ln1 = eng.text_params(1)
+        d = (eng.merge_text(ln1, flat1).cpu() - init).abs()
+        assert float(d.max()) < 2e-4, f"reset state after caption {i}: max |delta| {float(d.max()):.3e}"
+    eng.close()
+
+
 def test_retrieval_mirror_tune_text(L, dev):
     """The reference-shaped objects (rlcf_amd.clip_ret_policy: CLIPRet_TTA(only_visual=False), CLIPRewards, tune_text) reproduce the
     fixture through the loop body of test_time_tune's text -> image part (clip_ret_policy.py:183-196): image features of both models
