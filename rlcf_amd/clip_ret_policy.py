@@ -191,6 +191,55 @@ class CLIPRewards(_cr.CLIPRewards):
         return sim.clamp_min(0).squeeze()
 
 
+class CLIPRewardsMultiple(_cr.CLIPRewardsMultiple):
+    """retrieval/clip_reward.py:230-400: the reward ensemble with the banks called `text_features` / `image_features` (one matrix per
+    model) and both index directions in CLIPScore.  tune_image / tune_text hand the per-model banks to the engine, whose loss kernel
+    mixes the clamped scores with the same weights."""
+
+    @property
+    def text_features(self):
+        return self.class_features
+
+    @text_features.setter
+    def text_features(self, v):
+        self.class_features = v
+
+    @torch.no_grad()
+    def set_many_text_features(self, texts, text_bs=128):
+        self.class_features = self.extract_text_features(captions=texts)
+
+    @torch.no_grad()
+    def set_text_features(self, captions=None, tokenized_cap=None, text_features=None):
+        self.class_features = self.extract_text_features(captions=captions, tokenized_cap=tokenized_cap) if text_features is None else text_features
+
+    @torch.no_grad()
+    def set_image_features(self, images=None, image_features=None):
+        if image_features is None:
+            step = runtime.SESSION.max_views
+            chunks = [self.extract_image_features(images[i: i + step]) for i in range(0, images.shape[0], step)]
+            image_features = [torch.cat([c[m] for c in chunks]) for m in range(self.n_model)]
+        self.image_features, self._img_version = image_features, _next_version()
+
+    @torch.no_grad()
+    def set_image_features_with_dataloder(self, data_loader):
+        chunks = [self.extract_image_features(s["image"].to(self.device)) for s in data_loader]
+        self.image_features = [torch.cat([c[m] for c in chunks]) for m in range(self.n_model)]
+        self._img_version = _next_version()
+
+    @torch.no_grad()
+    def CLIPScore(self, text_index=None, images_index=None, pairwise=True):
+        per_model = []
+        for t_all, i_all in zip(self.class_features, self.image_features):
+            t = t_all[text_index.long()] if text_index is not None else t_all.repeat_interleave(self.sample_k, dim=0)
+            i = i_all[images_index.long()] if images_index is not None else i_all.repeat_interleave(self.sample_k, dim=0)
+            sim = _cr._gemm_nt(t, i, self.clipscore_weight)
+            per_model.append((sim if pairwise else torch.diagonal(sim)).clamp_min(0).squeeze())
+        per_model = torch.stack(per_model)
+        if not self.weighted_scores:
+            return per_model.mean(dim=0)
+        return (per_model.new_tensor(self.weights).reshape(-1, *([1] * (per_model.dim() - 1))) * per_model).sum(dim=0)
+
+
 def tune_image(image, model, reward_model, optimizer, scaler, args=None):
     """retrieval/clip_ret_policy.py:76-103.  `optimizer` supplies the AdamW hyper-parameters; `scaler` is accepted and unused."""
     g = optimizer.param_groups[0]
@@ -226,13 +275,16 @@ def tune_text(text, model, reward_model, optimizer, scaler, args=None):
         raise NotImplementedError("tune_text starts from the reset state (model.reset_initial(), clip_ret_policy.py:196)")
     tok = clip_store.tokenize(text).reshape(1, -1)
     # the engine's bank follows the two feature tensors the loop set (:184-185): version counters bumped by the setters, not id()s
+    rf = reward_model.image_features
     src = (getattr(model, "_img_version", None), getattr(reward_model, "_img_version", None), model.image_features.data_ptr(),
-           reward_model.image_features.data_ptr(), tuple(model.image_features.shape))       # (a tensor assigned past the setters has no version: re-sent)
+           tuple(r.data_ptr() for r in rf) if isinstance(rf, (list, tuple)) else rf.data_ptr(),
+           tuple(model.image_features.shape))                                                 # (a tensor assigned past the setters has no version: re-sent)
     if runtime.SESSION.image_bank is None or None in src or getattr(runtime.SESSION, "_image_bank_src", None) != src:
         runtime.SESSION.set_image_bank(model.image_features, reward_model.image_features)
         runtime.SESSION._image_bank_src = src
     out = runtime.SESSION.engine().tta_retrieval_text(tok[0], cfg)
-    reward_model.class_features = out["reward_text_features"]             # reward_model.set_text_features(captions=text), :117
+    if not isinstance(reward_model.image_features, (list, tuple)):
+        reward_model.class_features = out["reward_text_features"]         # reward_model.set_text_features(captions=text), :117
     with torch.no_grad():
         model.ln.data.copy_(out["ln_after"])
         model.vis.data.copy_(out["text_after"])

@@ -508,6 +508,44 @@ def test_retrieval_text_tuning_momentum_matches_oracle(L, dev):
     eng.close()
 
 
+def test_retrieval_ensemble_text_to_image(L, dev):
+    """scripts/tta_coco_ret.sh settings 02 / 03 (multiple_reward_models = 1) in the text -> image direction: the retrieval
+    CLIPRewardsMultiple mirror hands one image bank per reward model to the engine; the scores of the sampled images are the weighted
+    sum of the per-model clamped similarities (retrieval/clip_reward.py:286-310) — checked against the oracle's per-model features."""
+    from rlcf_amd import clip_ret_policy as P, clip_store, runtime
+    from oracle import rlcf_ref as RR2
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES["tiny"], synth.GEOMETRIES["tiny-r"]
+    rsds = [synth.make_state_dict(rg, 23), synth.make_state_dict(rg, 29)]
+    clip_store.register_checkpoint("student", sg, synth.make_state_dict(sg, 11))
+    clip_store.register_checkpoint("ViT-L/14", rg, rsds[0])               # (names the CONFIDECES table knows: weights 5 : 1)
+    clip_store.register_checkpoint("ViT-B/16", rg, rsds[1])
+    tokens = synth.make_token_bank(sg, 16, seed=7, n_ctx=4)
+    clip_store.set_tokenizer(lambda texts, context_length=77, truncate=False: tokens[[int(t.strip().rstrip(".").split("c")[-1]) for t in ([texts] if isinstance(texts, str) else texts)]])
+    K = 6
+    model = P.CLIPRet_TTA(dev, arch="student", only_visual=False)
+    reward_model = P.CLIPRewardsMultiple(dev, arch=["ViT-L/14", "ViT-B/16"], sample_k=K, reward_process=True, process_batch=False)
+    images = synth.make_views(3000, 96, sg.image_resolution, device=dev)
+    model.set_image_features(images=images)
+    reward_model.set_image_features(images=images)
+    assert len(reward_model.image_features) == 2 and reward_model.image_features[0].shape == (96, rg.embed_dim)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-6, weight_decay=5e-4)
+    out = P.tune_text("c5.", model, reward_model, optimizer, None, args=types.SimpleNamespace(tta_steps=1))
+    idx = out["topk_idx"].cpu().reshape(-1).long()
+    assert idx.tolist() == torch.topk(out["logits"].cpu()[0], K).indices.tolist()
+    w = torch.tensor(reward_model.weights)
+    per = []
+    for m in range(2):
+        t = RR2.reward_class_features(rsds[m], tokens[5][None])                                        # [1, Dr]
+        per.append((2.5 * reward_model.image_features[m].cpu()[idx] @ t[0]).clamp_min(0))
+    want = (w[:, None] * torch.stack(per)).sum(0)
+    torch.testing.assert_close(out["clip_score"].cpu(), want, atol=2e-5, rtol=1e-4)
+    r = out["rewards"].cpu()
+    torch.testing.assert_close(r, want - want.mean(), atol=2e-5, rtol=1e-3)
+    model.reset_initial()
+    runtime.reset_session()
+
+
 def test_retrieval_mirror_tune_text(L, dev):
     """The reference-shaped objects (rlcf_amd.clip_ret_policy: CLIPRet_TTA(only_visual=False), CLIPRewards, tune_text) reproduce the
     fixture through the loop body of test_time_tune's text -> image part (clip_ret_policy.py:183-196): image features of both models
