@@ -287,7 +287,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
                      &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
-                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
+                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->attn_pre_ws, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }
 

@@ -134,7 +134,7 @@ int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, 
 #define ABWD_MAXK 96
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                             const rlcf_seq* __restrict__ seqs, int width, int causal,
-                                                            float* __restrict__ dqkv) {
+                                                            float* __restrict__ dqkv, float* __restrict__ pre_ws, int max_pre) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const rlcf_seq sq = seqs[blockIdx.x];
     const int head = blockIdx.y;
@@ -184,8 +184,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         const int j = idx >> 6, d = idx & 63;
         float s = 0.f;
         for (int i = 0; i < nq; ++i) s += Ps[i * LDP + j] * Gs[i * LDQ + d];
-        const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
-        atomicAdd(dqkv + (size_t)row * ld + 2 * width + head * HEAD_DIM + d, s);
+        // own rows: this workgroup is their only writer.  Prefix rows are shared by sequences: with a workspace every sequence parks
+        // its contribution in its own slot and attention_bwd_prefix_reduce_kernel adds them in sequence order (deterministic)
+        if (j < sq.pre_len && pre_ws) pre_ws[((size_t)blockIdx.x * max_pre + j) * 2 * width + width + head * HEAD_DIM + d] = s;
+        else {
+            const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
+            atomicAdd(dqkv + (size_t)row * ld + 2 * width + head * HEAD_DIM + d, s);
+        }
     }
     __syncthreads();
     // dS = P * (dP - D), D_i = sum_j P_ij dP_ij, dP_ij = dO_i . V_j
@@ -226,13 +231,34 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         const int j = idx >> 6, d = idx & 63;
         float s = 0.f;
         for (int i = 0; i < nq; ++i) s += Ps[i * LDP + j] * Qs[i * LDQ + d];
-        const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
-        atomicAdd(dqkv + (size_t)row * ld + width + head * HEAD_DIM + d, s);
+        if (j < sq.pre_len && pre_ws) pre_ws[((size_t)blockIdx.x * max_pre + j) * 2 * width + head * HEAD_DIM + d] = s;
+        else {
+            const int row = j < sq.pre_len ? sq.pre_start + j : sq.q_start + j - sq.pre_len;
+            atomicAdd(dqkv + (size_t)row * ld + width + head * HEAD_DIM + d, s);
+        }
+    }
+}
+// dK / dV of the shared prefix rows: one workgroup per RUN of consecutive sequences with the same prefix (a class bank's prompts, or
+// one test sample's group of them) adds the parked contributions in sequence order on top of what the prefix sequence itself wrote
+__global__ __launch_bounds__(256) void attention_bwd_prefix_reduce_kernel(const rlcf_seq* __restrict__ seqs, int n_seq, int max_pre, int width,
+                                                                          const float* __restrict__ pre_ws, float* __restrict__ dqkv) {
+    const int s0 = blockIdx.x;
+    const rlcf_seq a = seqs[s0];
+    if (a.pre_len <= 0) return;
+    if (s0 > 0) { const rlcf_seq b = seqs[s0 - 1]; if (b.pre_len == a.pre_len && b.pre_start == a.pre_start) return; }     // not the head of its run
+    int s1 = s0 + 1;
+    while (s1 < n_seq && seqs[s1].pre_len == a.pre_len && seqs[s1].pre_start == a.pre_start) ++s1;
+    const int ld = 3 * width, per = 2 * width;
+    for (int idx = threadIdx.x; idx < a.pre_len * per; idx += 256) {
+        const int j = idx / per, c = idx % per;
+        float acc = dqkv[(size_t)(a.pre_start + j) * ld + width + c];
+        for (int s = s0; s < s1; ++s) acc += pre_ws[((size_t)s * max_pre + j) * per + c];
+        dqkv[(size_t)(a.pre_start + j) * ld + width + c] = acc;
     }
 }
 
 int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,
-                         int causal, float* dqkv, hipStream_t st) {
+                         int causal, float* dqkv, hipStream_t st, float* pre_ws, size_t pre_ws_floats, int max_pre) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_keys > 0 && max_keys <= ABWD_MAXK);
     const size_t bytes = (size_t)(4 * max_keys * 65 + max_keys * (max_keys + 1)) * sizeof(float);
     {
@@ -240,8 +266,13 @@ int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* se
         int rc_ = rlcf_func_lds((const void*)attention_bwd_kernel, cap);
         if (rc_ != RLCF_OK) return rc_;
     }
-    attention_bwd_kernel<<<dim3(n_seq, width / HEAD_DIM), dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv);
+    if (max_pre <= 0 || !pre_ws || (size_t)n_seq * max_pre * 2 * width > pre_ws_floats) { pre_ws = nullptr; max_pre = 0; }     // (atomics: order-dependent sums)
+    attention_bwd_kernel<<<dim3(n_seq, width / HEAD_DIM), dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv, pre_ws, max_pre);
     RLCF_LAUNCH_CHECK();
+    if (pre_ws) {
+        attention_bwd_prefix_reduce_kernel<<<dim3(n_seq), dim3(256), 0, st>>>(seqs, n_seq, max_pre, width, pre_ws, dqkv);
+        RLCF_LAUNCH_CHECK();
+    }
     return RLCF_OK;
 }
 

@@ -109,6 +109,7 @@ struct rlcf_engine {
     DevBuf sp_seqs, sp_eot_rows, sp_row_src, sp_ctx_rows_list, sp_dtxt, sp_txt, sp_inv_norm, sp_eot_x, sp_eot_ln, sp_u, sp_du, sp_dxe;
     Tower st;                        // sparse pass workspace (with saved activations)
     DevBuf dX, dA, dH, dF, dQKV;     // backward scratch (sized for the largest backward pass)
+    DevBuf attn_pre_ws;              // per-sequence dK / dV contributions to shared prefix rows (ordered reduction, text attention backward)
     int bwd_T = 0;
     // TTA step scratch
     DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg[RLCF_MAX_REWARDS], views_sel, topk_idx, clip_score, rewards, loss, dlogits,

@@ -654,7 +654,14 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
             TRY(launch_attention_bwd_x3(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal,
                                         dQKV, st));
         } else if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
-        else TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st));
+        else {
+            // shared-prefix layouts: the prefix rows' dK / dV are summed in sequence order through a per-sequence workspace (reproducible
+            // bit for bit); sized on first use like the other lazily grown scratch, atomics beyond 512 MB (dense backward of a huge bank)
+            const size_t need = (size_t)n_seq * max_keys * 2 * W;
+            float* pws = nullptr;
+            if (need * sizeof(float) <= ((size_t)512 << 20)) { TRY(e->attn_pre_ws.ensure(need * sizeof(float))); pws = e->attn_pre_ws.as<float>(); }
+            TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st, pws, pws ? need : 0, max_keys));
+        }
         e->last_flops += 10.0 * attn_pairs * W;
         if (wgrad_base) {                  // in_proj: qkv = LN1(x) Win^T + b
             TRY(launch_layernorm_fwd(s.x, b.ln1_w, b.ln1_b, ws.h.as<float>(), T, W, st));

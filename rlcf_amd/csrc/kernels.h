@@ -37,8 +37,10 @@ int launch_vit_preln(const float* patch_out, const float* cls, const float* pos,
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
                              int causal, float* out, float* lse, hipStream_t st, void* out_hi = nullptr, void* out_lo = nullptr);
+// pre_ws (optional, n_seq * max_pre * 2 * width floats): the contributions to the dK / dV rows of a SHARED prefix are parked per
+// sequence and added in sequence order (bit-reproducible); without it they go through atomicAdd
 int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width,
-                         int causal, float* dqkv, hipStream_t st);
+                         int causal, float* dqkv, hipStream_t st, float* pre_ws = nullptr, size_t pre_ws_floats = 0, int max_pre = 0);
 
 int launch_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy, int32_t* idx, hipStream_t st);
 int launch_iota(int32_t* p, int n, hipStream_t st);

@@ -459,6 +459,28 @@ def test_retrieval_text_tuning_full_size_matches_oracle(L, dev):
     eng.close()
 
 
+@pytest.mark.parametrize("geo,n_views,n_cls", [("tiny", 8, 16), ("ViT-B/16", 64, 1000)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_prompt_step_bit_reproducible(L, dev, geo, n_views, n_cls, mode):
+    """The prompt-tuning step gives the same BITS on every run: the only order-dependent sums of the path were the float atomics of
+    the shared prefix rows' dK / dV in the text attention backward, now parked per sequence and added in sequence order
+    (attention_bwd_prefix_reduce_kernel).  One-image calls and the sample-batched call, all three text layouts."""
+    from rlcf_amd.engine import TTAConfig
+    from test_gpu_parity import make_engine
+    eng, *_ = make_engine((geo, geo if geo != "tiny" else "tiny-r"), n_views * 2, n_cls, mode, prec=L.PREC_F16X3)
+    cfg = TTAConfig(selection_p=0.5 if geo == "tiny" else 0.1, tta_steps=2)
+    R = synth.GEOMETRIES[geo].image_resolution
+    vs = torch.stack([synth.make_views(1113 + i, n_views, R, device=dev) for i in range(2)])
+    runs = [eng.tta_sample(vs[0], cfg) for _ in range(3)]
+    for o in runs[1:]:
+        for k in ("ctx_grad", "ctx_after", "final_logits", "dlogits"):
+            assert torch.equal(o[k], runs[0][k]), k
+    b0 = eng.tta_batch(vs, cfg, want_logits=True)[1].clone()
+    for _ in range(2):
+        assert torch.equal(eng.tta_batch(vs, cfg, want_logits=True)[1], b0)
+    eng.close()
+
+
 def test_retrieval_text_tuning_momentum_matches_oracle(L, dev):
     """CLIPRet_TTA.momentum_update_model on the text side (retrieval/custom_models.py:128-143, scripts/tta_coco_ret.sh setting 03): an
     EMA of the tuned text parameters across captions, folded into the reset state every update_freq captions.  Three captions,
