@@ -259,7 +259,7 @@ static void release_tower(Tower& t) {
 }
 static void release_layout(TextLayout& L) {
     L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
-    L.class_eot_off.release(); L.ctx_rows_list.release(); L.row_token.release(); L.row_pos.release();
+    L.class_eot_off.release(); L.ctx_rows_list.release(); L.row_token.release(); L.row_pos.release(); L.pk_seqs.release(); L.pk_rss.release();
 }
 void rlcf_engine_destroy(rlcf_engine* e) {
     if (!e) return;
@@ -287,7 +287,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
                      &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
-                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->attn_pre_ws, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
+                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->attn_pre_ws, &e->b_pk_rep, &e->b_rss_rep, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }
 

@@ -28,7 +28,10 @@ template <int NW, bool SINGLE>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_kernel(const float* __restrict__ qkv, const rlcf_seq* __restrict__ seqs,
                                                                     int width, int causal, float* __restrict__ out,
                                                                     _Float16* __restrict__ oh, _Float16* __restrict__ ol, int il, int qb0,
-                                                                    float* __restrict__ lse) {
+                                                                    float* __restrict__ lse, const int32_t* __restrict__ rss) {
+    // rss (one-wave blocks only): PACKED short sequences — the descriptor names a run of up to 32 - pre_len consecutive rows that holds
+    // several whole sequences sharing one prefix; rss[row] = first row of the sequence `row` belongs to, and a query sees the prefix
+    // keys plus the keys of its own sequence up to itself.  One MFMA tile then serves ~7 class prompts instead of one.
     // qb0: first 32-query block this launch covers (a 257-token ViT-L/14 sequence = one 8-wave block for queries 0..255 plus a
     // one-wave launch for the last query, instead of a second 8-wave block that would re-stage every K/V chunk for one row)
     const rlcf_seq sq = seqs[blockIdx.y];
@@ -139,7 +142,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
                 }
             }
             float cm = -INFINITY;
-            if (kc + 32 > nkeys || (causal && kc + 31 > sq.pre_len + qb * 32)) {       // chunk holds masked keys
+            if (rss) {
+                const int first = rss[sq.q_start + qi] - sq.q_start + sq.pre_len;       // key index of the query's own sequence start
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kc + mfma32_row(r, h);
+                    if (key >= nkeys || key > qpos || (key >= sq.pre_len && key < first)) s[r] = -INFINITY;
+                }
+            } else if (kc + 32 > nkeys || (causal && kc + 31 > sq.pre_len + qb * 32)) {       // chunk holds masked keys
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kc + mfma32_row(r, h);
@@ -223,12 +233,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attention_fwd_x3_ker
 
 template <int NW>
 static void attn_launch(bool single, dim3 grid, hipStream_t st, const float* qkv, const rlcf_seq* seqs, int width, int causal, float* out,
-                        _Float16* oh, _Float16* ol, int il, int qb0, float* lse) {
-    if (single) attention_fwd_x3_kernel<NW, true><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse);
-    else attention_fwd_x3_kernel<NW, false><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse);
+                        _Float16* oh, _Float16* ol, int il, int qb0, float* lse, const int32_t* rss = nullptr) {
+    if (single) attention_fwd_x3_kernel<NW, true><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse, rss);
+    else attention_fwd_x3_kernel<NW, false><<<grid, dim3(64 * NW), 0, st>>>(qkv, seqs, width, causal, out, oh, ol, il, qb0, lse, rss);
 }
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st, int il, float* lse, int single) {
+                            void* out_hi, void* out_lo, hipStream_t st, int il, float* lse, int single, const int32_t* row_seq_start) {
+    RLCF_ARG_CHECK(!row_seq_start || (max_q_len <= 32 && causal));
     RLCF_ARG_CHECK(n_seq > 0 && max_q_len > 0 && width % HEAD_DIM == 0 && (out || (out_hi && (out_lo || single))));
     RLCF_ARG_CHECK(n_seq <= 65535 * 16);
     if (max_q_len > 128) {         // ViT sequences (197 / 257 tokens): 8 query blocks share every converted K/V chunk
@@ -249,7 +260,7 @@ int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, i
     } else {
         dim3 grid(1, n_seq, width / HEAD_DIM);
         RLCF_ARG_CHECK(grid.y <= 65535);
-        attn_launch<1>(single, grid, st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse);
+        attn_launch<1>(single, grid, st, qkv, seqs, width, causal, out, (_Float16*)out_hi, (_Float16*)out_lo, il, 0, lse, row_seq_start);
     }
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

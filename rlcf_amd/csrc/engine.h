@@ -29,6 +29,10 @@ struct TextLayout {                  // packed token matrix of a class bank
     bool ctx_general = false;        // learnable rows at class-dependent positions (class_token_position 'front' / 'middle'): the ctx
                                      // gradient is gathered by scanning ctx_row instead of through the fixed row lists
     DevBuf seqs, eot_rows, ctx_row, E, class_start, class_len, class_eot_off, ctx_rows_list;
+    // packed form of the class sequences for the no-grad text passes (shared-prefix layouts): runs of consecutive rows holding several
+    // whole sequences, at most 32 - pre_rows rows each, + per row the first row of its sequence (attention_x3.hip, `rss`)
+    DevBuf pk_seqs, pk_rss;
+    int n_pk = 0;
     DevBuf row_token, row_pos;       // per row: token id (-1 = learnable row) and position index — E is rebuilt from them when the
                                      // token / positional embeddings are tuned (text-encoder tuning)
     long tokens_total = 0;           // sum of rows that carry real tokens (FLOP accounting)
@@ -115,6 +119,7 @@ struct rlcf_engine {
     DevBuf img_feat, sel_feat, logits, sel_logits, entropy, sel_idx, rimg[RLCF_MAX_REWARDS], views_sel, topk_idx, clip_score, rewards, loss, dlogits,
         dtxt_dense, final_logits, top5;
     // sample-batched step (rlcf_tta_batch): B test images share every tower pass
+    DevBuf b_pk_rep, b_rss_rep;      // the packed sequence runs replicated per test sample
     DevBuf b_seqs_rep, b_eot_rep, b_ctx, b_m, b_v, b_grad, b_txt, b_eot_x, b_eot_ln, b_u, b_inv, b_logits;
     int b_cap = 0, sp_groups = 0;
     // LayerNorm-tuning path (CLIPCLS_TTA only_norm): all visual LN parameters of the student in one tunable buffer
@@ -160,6 +165,8 @@ struct rlcf_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf rl_stats;                 // per-row scratch of the reward / loss kernels
     DevBuf step_skip;                // int32 per test sample: gradient held an inf / NaN -> optimizer step skipped (GradScaler semantics)
+    // packed class-sequence runs of the text pass being enqueued (set by text_forward around transformer_forward)
+    const rlcf_seq* pk_cur = nullptr; int n_pk_cur = 0; const int32_t* rss_cur = nullptr;
     double last_flops = 0.0;
 };
 

@@ -566,8 +566,12 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             {
                 const int slot = prof_begin(st, 4.0 * attn_pairs * W, T, W, max_q_len);          // kind 10: fused attention forward
                 const bool sg = prec_single(e);
-                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), seqs, n_seq, max_q_len, W, causal, nullptr, ws.a2.p,
-                                                        sg ? nullptr : lo_of(ws.a2.p), st, sg ? 0 : 1, nullptr, sg ? 1 : 0);
+                static int nopack = -1;                       // RLCF_TEXT_NOPACK=1: one MFMA tile per class sequence (benchmarks)
+                if (nopack < 0) { const char* ev = getenv("RLCF_TEXT_NOPACK"); nopack = ev ? atoi(ev) : 0; }
+                const bool packed = causal && e->pk_cur && e->n_pk_cur > 0 && !nopack;      // several class prompts per tile (attention_x3.hip)
+                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), packed ? e->pk_cur : seqs, packed ? e->n_pk_cur : n_seq,
+                                                        packed ? 32 : max_q_len, W, causal, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
+                                                        sg ? 0 : 1, nullptr, sg ? 1 : 0, packed ? e->rss_cur : nullptr);
                 prof_end(slot, st, 10);
                 TRY(arc);
             }
@@ -814,6 +818,27 @@ static int build_layout(rlcf_engine* e, ClipModel& m, TextLayout& L, const int32
         for (int i = 0; i < pre; ++i) pairs += i + 1;
         if (has_ctx && !general) for (int j = 0; j < n_ctx; ++j) ctx_list.push_back(1 + j);
     }
+    // packed runs (shared-prefix layouts only): consecutive class sequences, whole, while the run stays within 32 - pre rows
+    {
+        std::vector<rlcf_seq> pk;
+        std::vector<int32_t> rss(row_token.size(), 0);
+        if (pre > 0 && pre < 24) {
+            const int cap = 32 - pre;
+            int c = 0;
+            while (c < C) {
+                const int r0 = class_start[c];
+                int rows = 0, c1 = c;
+                while (c1 < C && class_len[c1] <= cap && rows + class_len[c1] <= cap && class_start[c1] == r0 + rows) { rows += class_len[c1]; ++c1; }
+                if (c1 == c) { pk.clear(); break; }                       // a sequence longer than the cap: no packing for this bank
+                for (int k = c; k < c1; ++k) for (int i = 0; i < class_len[k]; ++i) rss[class_start[k] + i] = class_start[k];
+                pk.push_back(rlcf_seq{r0, rows, 0, pre});
+                c = c1;
+            }
+            if (!pk.empty()) pk.push_back(rlcf_seq{0, pre, 0, 0});       // the prefix itself (rss = 0: one sequence starting at row 0)
+        }
+        L.n_pk = (int)pk.size();
+        TRY(upload(L.pk_seqs, pk, st)); TRY(upload(L.pk_rss, rss, st));
+    }
     L.ctx_general = general;
     L.T = (int)row_token.size(); L.C = C; L.n_seq = (int)seqs.size(); L.pre_rows = pre; L.lmax = lmax;
     L.max_q_len = std::max(lmax, pre); L.max_keys = pre + lmax; L.n_ctx = has_ctx ? n_ctx : 0;
@@ -841,13 +866,17 @@ struct TextPassIO {
     float *eot_x, *eot_ln, *u, *inv_norm, *txt;
     int rep_rows = 0, ctx_stride = 0;      // replicated layout: one replica (and one prompt) per test sample
     const int32_t* ctx_row_tab = nullptr;  // set when the layout has its learnable rows at class-dependent positions (TextLayout::ctx_general)
+    const rlcf_seq* pk_seqs = nullptr; int n_pk = 0; const int32_t* pk_rss = nullptr;      // packed runs of the same sequences (no-grad passes)
 };
 static int text_forward(rlcf_engine* e, ClipModel& m, const TextLayout& L, Tower& ws, const float* ctx, const TextPassIO& io, bool save,
                         hipStream_t st) {
     const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
     float* x0 = save ? ws.sv[0].x : ws.x.as<float>();
     TRY(launch_text_assemble(L.E.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), ctx, x0, io.T, Wt, io.rep_rows, io.ctx_stride, st));
-    TRY(transformer_forward(e, m.txt, ws, io.seqs, io.n_seq, io.max_q_len, io.attn_pairs, 1, io.T, save, st));
+    if (!save) { e->pk_cur = io.pk_seqs; e->n_pk_cur = io.n_pk; e->rss_cur = io.pk_rss; }
+    const int rc_tf = transformer_forward(e, m.txt, ws, io.seqs, io.n_seq, io.max_q_len, io.attn_pairs, 1, io.T, save, st);
+    e->pk_cur = nullptr; e->n_pk_cur = 0; e->rss_cur = nullptr;
+    TRY(rc_tf);
     TRY(launch_gather_rows(ws.x.as<float>(), Wt, io.eot_rows, io.eot_x, Wt, io.n_cls, Wt, st));
     TRY(launch_layernorm_fwd(io.eot_x, m.lnf_w, m.lnf_b, io.eot_ln, io.n_cls, Wt, st));
     TRY(gemm(e, io.eot_ln, Wt, m.tprojT, Wt, nullptr, nullptr, 0, nullptr, 0, io.u, D, io.n_cls, D, Wt, 1.f, RLCF_EPI_NONE, st));
@@ -876,6 +905,7 @@ static TextPassIO full_io(rlcf_engine* e, const TextLayout& L) {
     io.eot_x = e->eot_x.as<float>(); io.eot_ln = e->eot_ln.as<float>(); io.u = e->u.as<float>();
     io.inv_norm = e->inv_norm.as<float>(); io.txt = e->txt.as<float>();
     io.ctx_row_tab = L.ctx_general ? L.ctx_row.as<int32_t>() : nullptr;
+    if (L.n_pk > 0) { io.pk_seqs = L.pk_seqs.as<rlcf_seq>(); io.n_pk = L.n_pk; io.pk_rss = L.pk_rss.as<int32_t>(); }
     return io;
 }
 
@@ -1218,6 +1248,11 @@ static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
     TRY(e->b_seqs_rep.ensure((size_t)B * L.n_seq * sizeof(rlcf_seq))); TRY(e->b_eot_rep.ensure((size_t)B * C * sizeof(int32_t)));
     TRY(launch_replicate_layout(L.seqs.as<rlcf_seq>(), L.n_seq, L.eot_rows.as<int32_t>(), C, L.T, B, e->b_seqs_rep.as<rlcf_seq>(),
                                 e->b_eot_rep.as<int32_t>(), st));
+    if (L.n_pk > 0) {        // packed runs: the descriptors shift like the sequences, the per-row sequence starts like row ids
+        TRY(e->b_pk_rep.ensure((size_t)B * L.n_pk * sizeof(rlcf_seq))); TRY(e->b_rss_rep.ensure((size_t)B * L.T * sizeof(int32_t)));
+        TRY(launch_replicate_layout(L.pk_seqs.as<rlcf_seq>(), L.n_pk, L.pk_rss.as<int32_t>(), L.T, L.T, B, e->b_pk_rep.as<rlcf_seq>(),
+                                    e->b_rss_rep.as<int32_t>(), st));
+    }
     const size_t cb = (size_t)B * e->n_ctx * Wt * sizeof(float);
     TRY(e->b_ctx.ensure(cb)); TRY(e->b_m.ensure(cb)); TRY(e->b_v.ensure(cb)); TRY(e->b_grad.ensure(cb));
     TRY(e->b_txt.ensure((size_t)B * C * D * sizeof(float))); TRY(e->b_u.ensure((size_t)B * C * D * sizeof(float)));
@@ -1263,6 +1298,7 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     fo.attn_pairs = (long)B * L.attn_pairs; fo.eot_rows = e->b_eot_rep.as<int32_t>(); fo.row_src = nullptr;
     fo.eot_x = e->b_eot_x.as<float>(); fo.eot_ln = e->b_eot_ln.as<float>(); fo.u = e->b_u.as<float>(); fo.inv_norm = e->b_inv.as<float>();
     fo.txt = e->b_txt.as<float>(); fo.rep_rows = L.T; fo.ctx_stride = (int)np;
+    if (L.n_pk > 0) { fo.pk_seqs = e->b_pk_rep.as<rlcf_seq>(); fo.n_pk = B * L.n_pk; fo.pk_rss = e->b_rss_rep.as<int32_t>(); }
     for (int j = 0; j < a->tta_steps; ++j) {
         if (j > 0) {
             // tpt_cls_rl.py:55: logits of the selected views under each sample's current prompt

@@ -104,7 +104,8 @@ int launch_final_logits_batched(const float* img, int img_row_stride, const floa
 int launch_group_logits(const float* img, int rows_per_group, const float* txt, int B, int C, int D, float scale, float* out, hipStream_t st);
 int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStream_t st);
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
-                            void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr, int single = 0 /* plain f16, one MFMA per product */);
+                            void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr, int single = 0 /* plain f16, one MFMA per product */,
+                            const int32_t* row_seq_start = nullptr /* packed short sequences: see attention_x3.hip */);
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 // split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)
