@@ -242,18 +242,28 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
 // one test sample's group of them) adds the parked contributions in sequence order on top of what the prefix sequence itself wrote
 __global__ __launch_bounds__(256) void attention_bwd_prefix_reduce_kernel(const rlcf_seq* __restrict__ seqs, int n_seq, int max_pre, int width,
                                                                           const float* __restrict__ pre_ws, float* __restrict__ dqkv) {
-    const int s0 = blockIdx.x;
+    const int s0 = blockIdx.x, j = blockIdx.y;              // (sequence, prefix row)
     const rlcf_seq a = seqs[s0];
-    if (a.pre_len <= 0) return;
+    if (j >= a.pre_len) return;
     if (s0 > 0) { const rlcf_seq b = seqs[s0 - 1]; if (b.pre_len == a.pre_len && b.pre_start == a.pre_start) return; }     // not the head of its run
     int s1 = s0 + 1;
     while (s1 < n_seq && seqs[s1].pre_len == a.pre_len && seqs[s1].pre_start == a.pre_start) ++s1;
     const int ld = 3 * width, per = 2 * width;
-    for (int idx = threadIdx.x; idx < a.pre_len * per; idx += 256) {
-        const int j = idx / per, c = idx % per;
-        float acc = dqkv[(size_t)(a.pre_start + j) * ld + width + c];
-        for (int s = s0; s < s1; ++s) acc += pre_ws[((size_t)s * max_pre + j) * per + c];
-        dqkv[(size_t)(a.pre_start + j) * ld + width + c] = acc;
+    for (int c = threadIdx.x; c < per; c += 256) {
+        float* dst = dqkv + (size_t)(a.pre_start + j) * ld + width + c;
+        const float* src = pre_ws + ((size_t)s0 * max_pre + j) * per + c;
+        const size_t step = (size_t)max_pre * per;
+        float acc = *dst;
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {                        // eight loads in flight, added in sequence order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s - s0 + u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < s1; ++s) acc += src[(size_t)(s - s0) * step];
+        *dst = acc;
     }
 }
 
@@ -270,7 +280,7 @@ int launch_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* se
     attention_bwd_kernel<<<dim3(n_seq, width / HEAD_DIM), dim3(256), bytes, st>>>(qkv, dout, seqs, width, causal, dqkv, pre_ws, max_pre);
     RLCF_LAUNCH_CHECK();
     if (pre_ws) {
-        attention_bwd_prefix_reduce_kernel<<<dim3(n_seq), dim3(256), 0, st>>>(seqs, n_seq, max_pre, width, pre_ws, dqkv);
+        attention_bwd_prefix_reduce_kernel<<<dim3(n_seq, max_pre), dim3(256), 0, st>>>(seqs, n_seq, max_pre, width, pre_ws, dqkv);
         RLCF_LAUNCH_CHECK();
     }
     return RLCF_OK;
