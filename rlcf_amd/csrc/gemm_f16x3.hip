@@ -82,7 +82,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
         if constexpr (EPI == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
         }
         if constexpr (RES) {
             rr[it].x += v[0]; rr[it].y += v[1]; rr[it].z += v[2]; rr[it].w += v[3];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
                     v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 const int row = m0 + wm * 64 + i * 32 + mfma32_row(r, h);
                 if (row >= g.M) continue;
                 float v = x3_alpha(g) * acc[i][j][r] + bv;
-                if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu(v);
+                if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
                 else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                 if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
                 float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
                     v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
                     v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                 float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+                    for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
                     v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
         float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
         if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
         } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
             const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
             v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
