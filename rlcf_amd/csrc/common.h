@@ -54,6 +54,10 @@ __device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + expf(-
 __device__ __forceinline__ float quick_gelu_fast(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * v));
 }
+__device__ __forceinline__ float quick_gelu_grad_fast(float f) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896341f * f));
+    return s * (1.0f + 1.702f * f * (1.0f - s));
+}
 __device__ __forceinline__ float quick_gelu_grad(float f) {
     float s = 1.0f / (1.0f + expf(-1.702f * f));
     return s * (1.0f + 1.702f * f * (1.0f - s));

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
-                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                    v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
                 }
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (row >= g.M) continue;
                 float v = x3_alpha(g) * acc[i][j][r] + bv;
                 if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
-                else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad(g.aux[(size_t)row * g.ldaux + col]);
+                else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad_fast(g.aux[(size_t)row * g.ldaux + col]);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                 if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
                 if (g.amax_out) am = fmaxf(am, fabsf(v));
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
-                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                    v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
                 }
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
-                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                    v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
                 }
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
                 } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
                     const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
-                    v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+                    v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
                 }
                 if (g.residual) {
                     const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
             for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
         } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
             const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
-            v[0] *= quick_gelu_grad(x4.x); v[1] *= quick_gelu_grad(x4.y); v[2] *= quick_gelu_grad(x4.z); v[3] *= quick_gelu_grad(x4.w);
+            v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
         }
         if (g.residual) {
             const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
