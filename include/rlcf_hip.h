@@ -102,6 +102,21 @@ int rlcf_layernorm_bwd(const float* x, const float* gamma, const float* dy, floa
  * seqs: DEVICE array of n_seq descriptors; max_q_len bounds q_len; lse[T,H] optional. */
 int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len,
                        int width, int causal, float* out, float* lse, int precision, rlcf_stream stream);
+/* The same forward on PRODUCER-EMITTED operands (attention_pair.hip; what the engine's image towers run since round 3): qkv_pairs is
+ * the in_proj output [T,3W] already written as interleaved f16 pairs (RLCF_PREC_F16X3: per row, every block of 32 columns = its 32 hi
+ * halves followed by its 32 lo halves, row = 12W bytes — rlcf_split_pairs / the GEMM's pair epilogue) or as a plain f16 matrix
+ * (RLCF_PREC_F16).  K / V stages move by LDS-DMA, V^T comes out of ds_read_b64_tr_b16: no f32 re-read, no in-kernel split.
+ * Non-causal sequences (optional prefix).  out (f32 [T,W]) and / or out_pairs ([T,W] in the operand layout of the precision);
+ * lse[T,H] optional.  TPT/clip/model.py:175,185-187. */
+int rlcf_attention_fwd_pairs(const void* qkv_pairs, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, float* out,
+                             void* out_pairs, float* lse, int precision, rlcf_stream stream);
+/* measurement switch of the call above (tools/attn_ab.py): variant = the build mask of attention_pair.hip (1 = the shipped arithmetic,
+ * 0 = eager softmax rescale; 8 / 32 / 40 / 64 = ablation builds of the 8-wave launch that give WRONG numbers by design; 16 = s_memtime
+ * trace).  The first argument is reserved (0). */
+int rlcf_attention_debug(int reserved, int variant);
+/* x[n] f32 -> the operand layout above: interleaved (hi | lo) pairs per 32-element block (RLCF_PREC_F16X3, 4n bytes) or plain f16
+ * (RLCF_PREC_F16, 2n bytes); n % 32 == 0 and rows that are multiples of 32 columns keep their row structure. */
+int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream);
 /* Backward (dX only): dqkv[T,3W] from dout[T,W]; dqkv must be zero-filled by the caller
  * (keys accumulate across query blocks / sequences).  max_keys (prefix + queries) <= 320. */
 int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys,

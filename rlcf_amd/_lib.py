@@ -69,6 +69,9 @@ SIGNATURES = {
     "rlcf_attention_bwd_flash": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "rlcf_attention_bwd_flash_prec": (I, [P, P, P, P, P, I, I, I, I, P, I, P]),
     "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),
+    "rlcf_attention_fwd_pairs": (I, [P, P, I, I, I, P, P, P, I, P]),
+    "rlcf_split_pairs": (I, [P, P, C.c_int64, I, P]),
+    "rlcf_attention_debug": (I, [I, I]),
     "rlcf_attention_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "rlcf_entropy_select": (I, [P, I, I, I, P, P, P]),
     "rlcf_reward_loss": (I, [P, I, P, I, I, I, P, P, I, F, I, F, P, P, P, P, P, P]),

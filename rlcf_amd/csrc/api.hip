@@ -91,6 +91,18 @@ int rlcf_attention_fwd(const float* qkv, const rlcf_seq* seqs, int n_seq, int ma
     }
     return launch_attention_fwd_f32(qkv, seqs, n_seq, max_q_len, width, causal, out, lse, (hipStream_t)stream);
 }
+int rlcf_attention_fwd_pairs(const void* qkv_pairs, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, float* out, void* out_pairs,
+                             float* lse, int precision, rlcf_stream stream) {
+    RLCF_ARG_CHECK(qkv_pairs && seqs && (out || out_pairs) && (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16));
+    return launch_attention_fwd_pair(qkv_pairs, seqs, n_seq, max_q_len, width, out, out_pairs, (hipStream_t)stream, lse,
+                                     precision == RLCF_PREC_F16);
+}
+int rlcf_attention_debug(int oneshot, int variant) { attention_pair_debug(oneshot, variant); return RLCF_OK; }
+int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream) {
+    RLCF_ARG_CHECK(x && pairs && n > 0 && n % 32 == 0 && (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16));
+    if (precision == RLCF_PREC_F16) return launch_split_f16x2(x, pairs, nullptr, n, (hipStream_t)stream, 1.0f, 0);
+    return launch_split_f16x2(x, pairs, (char*)pairs + 64, n, (hipStream_t)stream, 1.0f, 1);
+}
 int rlcf_attention_bwd(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_keys, int width, int causal,
                        float* dqkv, rlcf_stream stream) {
     RLCF_ARG_CHECK(qkv && dout && seqs && dqkv);
@@ -286,7 +298,7 @@ void rlcf_engine_destroy(rlcf_engine* e) {
     for (DevBuf* d : all) d->release();
     for (DevBuf& d : e->rn_buf) d.release();
     for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
-                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
+                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->a_hi2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
                      &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->attn_pre_ws, &e->b_pk_rep, &e->b_rss_rep, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
     delete e;
 }

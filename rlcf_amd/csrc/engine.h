@@ -160,6 +160,8 @@ struct rlcf_engine {
     // one-image calls: the reward models' tower pass of the selected views runs on a second stream next to the student's sparse text
     // forward (both leave most of the 256 CUs idle at one image's sizes); fork / join by events, its own split-K workspace
     DevBuf gemm_ws2;
+    DevBuf a_hi2;                    // ... and its own A-operand split buffer: the main stream's text passes re-split into a_hi (M > 512:
+    size_t a_split2_elems = 0;       // dense text mode, large sample_k / selection_p) while the side stream's reward towers read theirs
     int ws_sel = 0;                  // which workspace the GEMM launchers hand out (1 while the side stream's launches are enqueued)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

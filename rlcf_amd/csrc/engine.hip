@@ -55,6 +55,9 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 // part reaches 25.8 B/clk/CU, a 128-B one 45.5: profiles/r1_gemm_sq_counters.txt).  The lo part of a pair therefore starts 64 B after hi.
 static inline float* ws_ptr(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).as<float>(); }
 static inline size_t ws_bytes(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).bytes; }
+// A-operand split buffer of the stream whose launches are being enqueued (see ws_sel)
+static inline void* a_ptr(rlcf_engine* e) { return e->ws_sel ? e->a_hi2.p : e->a_hi.p; }
+static inline size_t a_cap(const rlcf_engine* e) { return e->ws_sel ? e->a_split2_elems : e->a_split_elems; }
 static inline void* lo_of(void* hi) { return (char*)hi + 64; }
 static inline const void* lo_of(const void* hi) { return (const char*)hi + 64; }
 
@@ -75,22 +78,22 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
         // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
         const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
-        if (sp && (size_t)M * K <= e->a_split_elems) {
+        if (sp && (size_t)M * K <= a_cap(e)) {
             const float* alpha_dev = nullptr;
             if (dyn_scale) {       // operand range unknown (un-normalised ResNet activations): power-of-two scale found on the device
                 TRY(e->dyn.ensure(3 * sizeof(float)));
                 if (amax_in) {             // max|A| was produced by the GEMM that wrote A
                     TRY(launch_dyn_scale_from(amax_in, e->dyn.as<float>() + 1, st));
-                    TRY(launch_split_f16x2_dev(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, e->dyn.as<float>() + 1, st, 1));
+                    TRY(launch_split_f16x2_dev(A, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * K, e->dyn.as<float>() + 1, st, 1));
                 } else {
-                    TRY(launch_split_f16x2_dyn(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, e->dyn.as<float>(), st, 1));
+                    TRY(launch_split_f16x2_dyn(A, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * K, e->dyn.as<float>(), st, 1));
                 }
                 alpha_dev = e->dyn.as<float>() + 2;
             } else {
-                TRY(launch_split_f16x2(A, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)M * K, st, a_scale, 1));
+                TRY(launch_split_f16x2(A, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * K, st, a_scale, 1));
             }
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
-            int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
+            int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
                                        ws_ptr(e), ws_bytes(e));
             prof_end(slot, st, g_last_x3_variant);
@@ -116,7 +119,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     if (!sp) { rlcf_set_error("engine_gemm_presplit: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
-    int rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
+    int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
                                sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
@@ -538,15 +541,22 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         for (int l = 0; l < L; ++l) {
             const BlockW& b = w.blk[l];
             LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
-            TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            // image towers (non-causal): in_proj writes Q / K / V as the f16 operand pairs the attention kernel DMAs into LDS
+            // (attention_pair.hip; a pair row is as long as an f32 row, so the same buffer serves); RLCF_ATTN_OLD=1 keeps the f32 hand-over
+            static int attn_old = -1;
+            if (attn_old < 0) { const char* ev = getenv("RLCF_ATTN_OLD"); attn_old = ev ? atoi(ev) : 0; }
+            const bool pair_attn = !causal && !attn_old;
+            if (pair_attn) TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, nullptr, 0, ws.qkv.p, 3 * W, T, 3 * W, W, RLCF_EPI_NONE, st));
+            else TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
             if (l == L - 1 && cls_out && cls_seqs && cls_idx && !causal) {
                 // last block, class-token rows only (see above).  Pair rows are W * 4 bytes like f32 rows: gather_rows moves both.
                 const size_t nw = (size_t)n_seq * W * sizeof(float);
                 TRY(e->cls_a2.ensure(nw)); TRY(e->cls_h2.ensure(nw)); TRY(e->cls_f2.ensure(4 * nw));
                 {
                     const bool sg = prec_single(e);
-                    TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), cls_seqs, n_seq, 1, W, 0, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
-                                                sg ? 0 : 1, nullptr, sg ? 1 : 0));
+                    if (pair_attn) TRY(launch_attention_fwd_pair(ws.qkv.p, cls_seqs, n_seq, 1, W, nullptr, ws.a2.p, st, nullptr, sg ? 1 : 0));
+                    else TRY(launch_attention_fwd_x3(ws.qkv.as<float>(), cls_seqs, n_seq, 1, W, 0, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
+                                                     sg ? 0 : 1, nullptr, sg ? 1 : 0));
                 }
                 e->last_flops += 4.0 * (double)n_seq * max_q_len * W;
                 {
@@ -569,9 +579,10 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                 static int nopack = -1;                       // RLCF_TEXT_NOPACK=1: one MFMA tile per class sequence (benchmarks)
                 if (nopack < 0) { const char* ev = getenv("RLCF_TEXT_NOPACK"); nopack = ev ? atoi(ev) : 0; }
                 const bool packed = causal && e->pk_cur && e->n_pk_cur > 0 && !nopack;      // several class prompts per tile (attention_x3.hip)
-                const int arc = launch_attention_fwd_x3(ws.qkv.as<float>(), packed ? e->pk_cur : seqs, packed ? e->n_pk_cur : n_seq,
-                                                        packed ? 32 : max_q_len, W, causal, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
-                                                        sg ? 0 : 1, nullptr, sg ? 1 : 0, packed ? e->rss_cur : nullptr);
+                const int arc = pair_attn ? launch_attention_fwd_pair(ws.qkv.p, seqs, n_seq, max_q_len, W, nullptr, ws.a2.p, st, nullptr, sg ? 1 : 0)
+                                          : launch_attention_fwd_x3(ws.qkv.as<float>(), packed ? e->pk_cur : seqs, packed ? e->n_pk_cur : n_seq,
+                                                                    packed ? 32 : max_q_len, W, causal, nullptr, ws.a2.p, sg ? nullptr : lo_of(ws.a2.p), st,
+                                                                    sg ? 0 : 1, nullptr, sg ? 1 : 0, packed ? e->rss_cur : nullptr);
                 prof_end(slot, st, 10);
                 TRY(arc);
             }
@@ -694,10 +705,10 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     }
     if (is_resnet(c)) return resnet_encode(e, m, images, n, feats, st);
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
-    if (prec_x3(e) && n * G2 > 512 && (size_t)n * G2 * m.Kp <= e->a_split_elems) {
+    if (prec_x3(e) && n * G2 > 512 && (size_t)n * G2 * m.Kp <= a_cap(e)) {
         const bool sg = prec_single(e) && m.Kp % 64 == 0 && m.f16_of.count(m.conv_w);
-        TRY(launch_im2col(images, nullptr, e->a_hi.p, sg ? nullptr : lo_of(e->a_hi.p), n, c.image_resolution, c.vision_patch_size, m.Kp, st, sg ? 0 : 1));
-        TRY(gemm_pre(e, e->a_hi.p, m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, 0, n * G2, Wv,
+        TRY(launch_im2col(images, nullptr, a_ptr(e), sg ? nullptr : lo_of(a_ptr(e)), n, c.image_resolution, c.vision_patch_size, m.Kp, st, sg ? 0 : 1));
+        TRY(gemm_pre(e, a_ptr(e), m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, 0, n * G2, Wv,
                      m.Kp, RLCF_EPI_NONE, st));
     } else {
         TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
@@ -1168,23 +1179,39 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
             // the reward models' pass over the selected views depends on nothing the student does from here to the loss, and at one
             // image's sizes neither it nor the sparse text forward fills the chip: second stream, joined before the loss kernel
             if (overlap) {
+                // the side stream's own A-operand buffer: the patch matrix of the selected views or a <= 512-row token matrix against a
+                // W x 4W weight, whichever reward model needs more (the main stream keeps a_hi for the text passes it runs meanwhile)
+                size_t need2 = 0;
+                for (int m = 0; m < e->n_rewards; ++m) {
+                    const ClipModel& rm = e->model[RLCF_REWARD + m];
+                    need2 = std::max(need2, (size_t)n_sel * rm.tokens * std::max(rm.Kp, 4 * rm.cfg.vision_width));
+                }
+                if (need2 > e->a_split2_elems) { TRY(e->a_hi2.ensure(need2 * 4)); e->a_split2_elems = need2; }
                 RLCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
                 RLCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
                 e->ws_sel = 1;
                 const int rc_side = reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, e->side);
                 e->ws_sel = 0;
-                RLCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));       // (recorded even after an error: the main stream must not hang)
-                if (rc_side != RLCF_OK) { RLCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0)); return rc_side; }
+                const hipError_t er = hipEventRecord(e->ev_join, e->side);      // (recorded even after an error: the main stream must not run ahead)
+                if (rc_side != RLCF_OK || er != hipSuccess) {
+                    (void)hipStreamWaitEvent(st, e->ev_join, 0);
+                    if (er != hipSuccess) { (void)hipStreamSynchronize(e->side); rlcf_set_error("hipEventRecord(ev_join): %s", hipGetErrorString(er)); return RLCF_ERR_HIP; }
+                    return rc_side;
+                }
             } else {
                 TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
             }
             TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
             rows_logits = e->sel_logits.as<float>();
             if (overlap) {
-                TRY(launch_topk_rows(rows_logits, C, n_sel, C, K, e->topk_idx.as<int32_t>(), e->rl_stats.as<float>(), st));
-                TRY(sparse_forward(e, ctx, e->topk_idx.as<int32_t>(), n_e, st));
+                // whatever happens on the main stream, it joins the side stream before this call returns: the side stream writes
+                // e->vt, e->rimg and the caller's reward_image_features
+                int rc_main = launch_topk_rows(rows_logits, C, n_sel, C, K, e->topk_idx.as<int32_t>(), e->rl_stats.as<float>(), st);
+                if (rc_main == RLCF_OK) rc_main = sparse_forward(e, ctx, e->topk_idx.as<int32_t>(), n_e, st);
                 fwd_done = true;
-                RLCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+                const hipError_t ej = hipStreamWaitEvent(st, e->ev_join, 0);
+                if (rc_main != RLCF_OK) { if (ej != hipSuccess) (void)hipStreamSynchronize(e->side); return rc_main; }
+                if (ej != hipSuccess) { (void)hipStreamSynchronize(e->side); rlcf_set_error("hipStreamWaitEvent(ev_join): %s", hipGetErrorString(ej)); return RLCF_ERR_HIP; }
             }
             COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
             COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));

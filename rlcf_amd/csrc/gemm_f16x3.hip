@@ -121,19 +121,22 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         asm volatile("" ::: "memory");
     }
 }
-// which specialisation (wave-uniform): 0 = none (generic epilogue), 1 = f32 out, 2 = f32 out + residual, 3 = QuickGELU -> operand pair
+// which specialisation (wave-uniform): 0 = none (generic epilogue), 1 = f32 out, 2 = f32 out + residual, 3 = QuickGELU -> operand pair,
+// 4 = operand pair only (in_proj of the image towers: Q / K / V go to the attention kernel as f16 pairs, attention_pair.hip)
 __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
     if (g.amax_out || g.alpha_dev || g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
     const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
     if (g.epilogue == RLCF_EPI_NONE && f32o && !pair) return res ? 2 : 1;
     if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
+    if (g.epilogue == RLCF_EPI_NONE && !f32o && pair && !res) return 4;
     return 0;
 }
 #define X3_EPILOGUE_SLAB(kind, ...)                                                                                      \
     {                                                                                                                    \
         if ((kind) == 1) x3_epilogue_slab<RLCF_EPI_NONE, false, true, false>(__VA_ARGS__);       /* in_proj (QKV), conv1 */      \
         else if ((kind) == 2) x3_epilogue_slab<RLCF_EPI_NONE, true, true, false>(__VA_ARGS__);   /* out_proj / c_proj + residual */ \
-        else x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true>(__VA_ARGS__);              /* c_fc + QuickGELU -> pair */     \
+        else if ((kind) == 3) x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true>(__VA_ARGS__);   /* c_fc + QuickGELU -> pair */ \
+        else x3_epilogue_slab<RLCF_EPI_NONE, false, false, true>(__VA_ARGS__);                   /* in_proj -> Q / K / V pairs */    \
     }
 
 #define X3_BM 128

@@ -106,6 +106,11 @@ int launch_top5_batched(const float* logits, int B, int C, int32_t* top5, hipStr
 int launch_attention_fwd_x3(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, int causal, float* out,
                             void* out_hi, void* out_lo, hipStream_t st, int il = 0, float* lse = nullptr, int single = 0 /* plain f16, one MFMA per product */,
                             const int32_t* row_seq_start = nullptr /* packed short sequences: see attention_x3.hip */);
+// attention_pair.hip: the same forward on producer-emitted operands — qkv2 = the in_proj output as interleaved f16 pairs (single: plain
+// f16), K / V staged by LDS-DMA, V^T through ds_read_b64_tr_b16; non-causal sequences (optional prefix) only
+int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq, int max_q_len, int width, float* out, void* out_pairs,
+                              hipStream_t st, float* lse = nullptr, int single = 0);
+void attention_pair_debug(int oneshot, int var);      // measurement switches of attention_pair.hip
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 // split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)

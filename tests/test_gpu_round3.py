@@ -1,0 +1,249 @@
+"""GPU parity, round-3 additions: the attention forward on producer-emitted operand pairs (attention_pair.hip: LDS-DMA staging,
+ds_read_b64_tr_b16) against the f64 reference and against the round-2 kernel it replaces; the in_proj pair epilogue; the engine's
+image tower with the old and the new hand-over; one-rank RCCL runs of bench.py and the eval driver."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from rlcf_amd import synth
+from test_gpu_parity import _attn_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from rlcf_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _seq_buf(L, seqs, dev):
+    sq = (L.Seq * len(seqs))(*[L.Seq(*s) for s in seqs])
+    return torch.frombuffer(bytearray(bytes(sq)), dtype=torch.int32).to(dev)
+
+
+def _unpack_pairs(buf, T, W):
+    """interleaved pair matrix [T, W] (per 32 columns: 32 hi halves, 32 lo halves) -> float64 hi + lo"""
+    h = buf.view(torch.float16).reshape(T, W // 32, 2, 32).double()
+    return (h[:, :, 0] + h[:, :, 1]).reshape(T, W)
+
+
+# non-causal sequence sets: ViT-B/16 (197 = 6 x 32 + 5), ViT-L/14 (257 = 8 blocks + the odd query -> one-wave tail launch),
+# ViT-L/14@336 (577 = three 8-wave blocks), 50 / 17 tokens (4-wave and one-wave workgroups), the class-token-only last block
+# (one query, prefix = the other 196 rows), ragged lengths, and a prefix in front of a multi-block sequence
+PAIR_CASES = [
+    ("vit197", [(i * 197, 197, 0, 0) for i in range(3)], 591, 128),
+    ("vit257", [(i * 257, 257, 0, 0) for i in range(2)], 514, 128),
+    ("vit577", [(0, 577, 0, 0)], 577, 64),
+    ("vit50", [(0, 50, 0, 0), (50, 50, 0, 0), (100, 50, 0, 0)], 150, 128),
+    ("tiny17", [(i * 17, 17, 0, 0) for i in range(4)], 68, 64),
+    ("cls_only", [(i * 197, 1, i * 197 + 1, 196) for i in range(3)], 591, 128),
+    ("ragged", [(0, 33, 0, 0), (33, 1, 0, 0), (34, 64, 0, 0), (98, 65, 0, 0), (163, 129, 0, 0)], 292, 64),
+    ("prefix_multi", [(40, 130, 0, 40), (170, 37, 0, 40), (0, 40, 0, 0)], 207, 64),
+    ("keys64", [(0, 64, 0, 0), (64, 128, 0, 0), (192, 32, 0, 0)], 224, 64),
+]
+
+
+@pytest.mark.parametrize("name,seqs,T,W", PAIR_CASES)
+def test_attention_pairs_split_f16(L, dev, name, seqs, T, W):
+    """attention_fwd_pair_kernel (3 f16 MFMAs per product on operands split by the PRODUCER) against the f64 reference: f32-grade,
+    the same bar as the round-2 kernel; f32 output, pair output and log-sum-exp."""
+    qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5)
+    qd = qkv.to(dev)
+    pairs = torch.empty(T, 3 * W, device=dev)                     # a pair row is as long as an f32 row
+    L.check(L.lib().rlcf_split_pairs(qd.data_ptr(), pairs.data_ptr(), T * 3 * W, L.PREC_F16X3, st()))
+    sbuf = _seq_buf(L, seqs, dev)
+    mq = max(s[1] for s in seqs)
+    out = torch.zeros(T, W, device=dev)
+    op = torch.zeros(T, W, device=dev)
+    lse = torch.zeros(T, W // 64, device=dev)
+    L.check(L.lib().rlcf_attention_fwd_pairs(pairs.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, out.data_ptr(), op.data_ptr(),
+                                             lse.data_ptr(), L.PREC_F16X3, st()))
+    torch.cuda.synchronize()
+    # the operands ARE the rounded pairs: reference on hi + lo (22-bit operands) and on the f32 values
+    q22 = _unpack_pairs(pairs.cpu(), T, 3 * W)
+    ref = _attn_ref(qkv.double(), seqs, W, 0)
+    torch.testing.assert_close(out.cpu().double(), ref, atol=5e-6, rtol=1e-5)
+    torch.testing.assert_close(out.cpu().double(), _attn_ref(q22, seqs, W, 0), atol=5e-6, rtol=1e-5)
+    rows = sorted({r for (qs, ql, _, _) in seqs for r in range(qs, qs + ql)})
+    torch.testing.assert_close(_unpack_pairs(op.cpu(), T, W)[rows], out.cpu().double()[rows], atol=2e-6, rtol=1e-6)
+    # log-sum-exp of the scaled scores
+    H = W // 64
+    for (qs, ql, ps, pl) in seqs[:2]:
+        kr = list(range(ps, ps + pl)) + list(range(qs, qs + ql))
+        q = qkv[qs:qs + ql, :W].double().reshape(ql, H, 64).transpose(0, 1)
+        k = qkv[kr, W:2 * W].double().reshape(len(kr), H, 64).transpose(0, 1)
+        want = torch.logsumexp((q * 0.125) @ k.transpose(-1, -2), -1).transpose(0, 1)
+        torch.testing.assert_close(lse[qs:qs + ql].cpu().double(), want, atol=2e-5, rtol=1e-5)
+    # ... and the kernel it replaces, on the same values
+    old = torch.zeros(T, W, device=dev)
+    L.check(L.lib().rlcf_attention_fwd(qd.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, 0, old.data_ptr(), None, L.PREC_F16X3, st()))
+    torch.testing.assert_close(out.cpu()[rows], old.cpu()[rows], atol=3e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,seqs,T,W", PAIR_CASES[:6])
+def test_attention_pairs_single_f16(L, dev, name, seqs, T, W):
+    """RLCF_PREC_F16 form (plain f16 operands, one MFMA per product): exact against a reference on the SAME f16-rounded operands up to
+    the f16 rounding of P (carried times 2^6) — the bar of the round-2 single-pass kernel."""
+    qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5)
+    qd = qkv.to(dev)
+    q16 = torch.empty(T, 3 * W, dtype=torch.float16, device=dev)
+    L.check(L.lib().rlcf_split_pairs(qd.data_ptr(), q16.data_ptr(), T * 3 * W, L.PREC_F16, st()))
+    assert torch.equal(q16.cpu(), qkv.half())
+    sbuf = _seq_buf(L, seqs, dev)
+    mq = max(s[1] for s in seqs)
+    out = torch.zeros(T, W, device=dev)
+    o16 = torch.zeros(T, W, dtype=torch.float16, device=dev)
+    L.check(L.lib().rlcf_attention_fwd_pairs(q16.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, out.data_ptr(), o16.data_ptr(), None,
+                                             L.PREC_F16, st()))
+    ref = _attn_ref(qkv.half().double(), seqs, W, 0)
+    torch.testing.assert_close(out.cpu().double(), ref, atol=4e-3, rtol=2e-3)
+    rows = sorted({r for (qs, ql, _, _) in seqs for r in range(qs, qs + ql)})
+    torch.testing.assert_close(o16.cpu().float()[rows], out.cpu()[rows], atol=2e-3, rtol=2e-3)
+    old = torch.zeros(T, W, device=dev)
+    L.check(L.lib().rlcf_attention_fwd(qd.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, 0, old.data_ptr(), None, L.PREC_F16, st()))
+    # (the two kernels round P to f16 against different exponent references — the round-3 kernel moves it lazily — so they agree to
+    # the f16 rounding of P, not to the last bit)
+    torch.testing.assert_close(out.cpu()[rows], old.cpu()[rows], atol=3e-3, rtol=2e-3)
+
+
+def test_attention_pairs_spiked_scores(L, dev):
+    """a key whose score towers over the rest in a LATE chunk (the online-softmax rescale path with a large jump) and a row of
+    identical scores: against the f64 reference."""
+    T, W = 197, 64
+    qkv = synth.normal(5, "att.spike", (T, 3 * W), 1.0)
+    qkv[150, W:2 * W] = qkv[7, :W] * 6.0          # key 150 aligned with query 7: score ~ 6 |q|^2 / 8
+    qkv[100, :W] = 0.0                            # query 100: all scores equal
+    seqs = [(0, 197, 0, 0)]
+    qd = qkv.to(dev)
+    pairs = torch.empty(T, 3 * W, device=dev)
+    L.check(L.lib().rlcf_split_pairs(qd.data_ptr(), pairs.data_ptr(), T * 3 * W, L.PREC_F16X3, st()))
+    out = torch.zeros(T, W, device=dev)
+    L.check(L.lib().rlcf_attention_fwd_pairs(pairs.data_ptr(), _seq_buf(L, seqs, dev).data_ptr(), 1, 197, W, out.data_ptr(), None, None,
+                                             L.PREC_F16X3, st()))
+    torch.testing.assert_close(out.cpu().double(), _attn_ref(qkv.double(), seqs, W, 0), atol=5e-6, rtol=1e-5)
+
+
+def test_gemm_pair_epilogue_matches_split_of_f32_output(L, dev):
+    """in_proj shape through rlcf_gemm_f16x3 with the pair-only output (epilogue kind 4 of the DMA-ring kernels): the pairs are the
+    split of exactly the f32 values the f32-output epilogue writes."""
+    M, N, K = 1182, 384, 128
+    a = synth.normal(7, "pe.a", (M, K), 1.0).to(dev)
+    w = synth.normal(7, "pe.w", (N, K), 1.0).to(dev)
+    bias = synth.normal(7, "pe.b", (N,), 0.5).to(dev)
+    a2 = torch.empty(M, K, device=dev); w2 = torch.empty(N, K, device=dev)
+    L.check(L.lib().rlcf_split_pairs(a.data_ptr(), a2.data_ptr(), M * K, L.PREC_F16X3, st()))
+    L.check(L.lib().rlcf_split_pairs(w.data_ptr(), w2.data_ptr(), N * K, L.PREC_F16X3, st()))
+    c = torch.zeros(M, N, device=dev)
+    chi = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    clo = torch.zeros(M, N, dtype=torch.float16, device=dev)
+    lo = lambda t: t.data_ptr() + 64
+    L.check(L.lib().rlcf_gemm_f16x3(a2.data_ptr(), lo(a2), 2 * K, w2.data_ptr(), lo(w2), 2 * K, bias.data_ptr(), None, 0, None, 0, c.data_ptr(), N,
+                                    None, None, 0, M, N, K, 1.0, 0, st()))
+    # (the C ABI writes the pair as two arrays; the engine asks the same epilogue for the interleaved layout — covered by
+    # test_image_tower_old_and_new_attention_agree)
+    L.check(L.lib().rlcf_gemm_f16x3(a2.data_ptr(), lo(a2), 2 * K, w2.data_ptr(), lo(w2), 2 * K, bias.data_ptr(), None, 0, None, 0, None, 0,
+                                    chi.data_ptr(), clo.data_ptr(), N, M, N, K, 1.0, 0, st()))
+    whi = torch.empty(M, N, dtype=torch.float16, device=dev)
+    wlo = torch.empty(M, N, dtype=torch.float16, device=dev)
+    L.check(L.lib().rlcf_split_f16x2(c.data_ptr(), whi.data_ptr(), wlo.data_ptr(), M * N, st()))
+    assert torch.equal(chi.cpu().view(torch.int16), whi.cpu().view(torch.int16))
+    assert torch.equal(clo.cpu().view(torch.int16), wlo.cpu().view(torch.int16))
+    ref = a.cpu().double() @ w.cpu().double().t() + bias.cpu().double()
+    torch.testing.assert_close(c.cpu().double(), ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("geo", ["ViT-B/16", "ViT-L/14"])
+def test_image_tower_old_and_new_attention_agree(L, dev, geo):
+    """engine image tower (split-f16 pipeline) with the producer-emitted pairs against the same tower with the round-2 f32 hand-over
+    (RLCF_ATTN_OLD=1, a fresh process: the switch is read once): features agree to f32 round-off, and both agree with the fixture
+    tests' bar against the reference (checked elsewhere).  8 views so the 256x256 / 256x128 GEMM tiles with the pair epilogue run."""
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from rlcf_amd import synth, _lib\nfrom rlcf_amd.engine import Engine\n"
+        "g = synth.GEOMETRIES[%r]\n"
+        "e = Engine(g, None, 8, 16, _lib.PREC_F16X3)\n"
+        "e.load_state_dict(_lib.STUDENT, synth.make_state_dict(g, 11, device='cuda'))\n"
+        "e.finalize()\n"
+        "v = synth.make_views(1003, 8, g.image_resolution, device='cuda')\n"
+        "f = e.encode_image(_lib.STUDENT, v)\n"
+        "torch.cuda.synchronize()\n"
+        "torch.save(f.cpu(), sys.argv[1])\n" % (ROOT, geo))
+    import tempfile
+    outs = []
+    for old in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as tf:
+            env = dict(os.environ, RLCF_ATTN_OLD=old)
+            r = subprocess.run([sys.executable, "-c", code, tf.name], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(tf.name))
+    torch.testing.assert_close(outs[0], outs[1], atol=2e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------ two-stream overlap of the one-image call
+_OVERLAP_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from rlcf_amd import synth, _lib
+from rlcf_amd.engine import Engine, TTAConfig
+from oracle import clip_ref as CR
+g = synth.GEOMETRIES["ViT-B/16"]
+rewards = [g] * %(n_rewards)d
+eng = Engine(g, rewards if len(rewards) > 1 else g, 16, 24, _lib.PREC_F16X3)
+eng.load_state_dict(_lib.STUDENT, synth.make_state_dict(g, 11, device="cuda"))
+for m in range(len(rewards)):
+    eng.load_state_dict(_lib.REWARD + m, synth.make_state_dict(g, 23 + m, device="cuda"))
+eng.finalize()
+if len(rewards) > 1: eng.set_reward_mix([0.5, 0.2, 0.3][:len(rewards)])
+tokens = synth.make_token_bank(g, 24, seed=7, n_ctx=4)
+ssd = synth.make_state_dict(g, 11)
+ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(g, 4))
+eng.set_class_bank(tokens, 4, ctx0, %(text_mode)s)
+cfg = TTAConfig(selection_p=0.4, sample_k=3)          # 6 views x 3 classes: 18 prompts x 77 rows = 1386 > 512 in the dense layout
+outs = []
+for rep in range(3):
+    v = synth.make_views(1000 + rep, 16, g.image_resolution, device="cuda")
+    o = eng.tta_sample(v, cfg)
+    torch.cuda.synchronize()
+    rif = o["reward_image_features"]
+    rif = torch.cat([r.flatten() for r in rif]) if isinstance(rif, list) else rif.flatten()
+    outs.append({k: o[k].cpu() for k in ("final_logits", "ctx_after", "rewards", "clip_score", "topk_idx", "ctx_grad")} | {"rif": rif.cpu()})
+torch.save(outs, sys.argv[1])
+"""
+
+
+@pytest.mark.parametrize("text_mode,n_rewards", [("_lib.TEXT_DENSE", 1), ("_lib.TEXT_SHARED", 3)])
+def test_one_image_call_overlap_is_bitwise_the_single_stream_result(L, dev, text_mode, n_rewards):
+    """engine_tta_sample runs the reward towers of the selected views on a second stream beside the student's sparse text forward.  In
+    the dense text layout the main stream's GEMMs re-split their A operand (1 386 rows > 512) while the side stream's reward tower
+    reads ITS split operand: since round 3 the side stream owns a second buffer (round-2 advisory: both used e->a_hi).  Bitwise
+    equality with RLCF_NO_OVERLAP=1 over three samples, also with a 3-member reward ensemble (the side stream rewrites its buffer
+    once per member)."""
+    import tempfile
+    code = _OVERLAP_SNIPPET % dict(root=ROOT, n_rewards=n_rewards, text_mode=text_mode)
+    res = []
+    for no in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as tf:
+            env = dict(os.environ, RLCF_NO_OVERLAP=no)
+            r = subprocess.run([sys.executable, "-c", code, tf.name], env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res.append(torch.load(tf.name))
+    for a, b in zip(*res):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
