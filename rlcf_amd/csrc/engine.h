@@ -160,6 +160,10 @@ struct rlcf_engine {
     // one-image calls: the reward models' tower pass of the selected views runs on a second stream next to the student's sparse text
     // forward (both leave most of the 256 CUs idle at one image's sizes); fork / join by events, its own split-K workspace
     DevBuf gemm_ws2;
+    // ... its own copies of the image-tower scratch (engine_encode_image on the side stream: the reward models' pass of one part of a
+    // sample batch runs beside the student tower of the next part, tta_batch_pipelined) ...
+    struct ImgSide { DevBuf patch_out, patches, cls_rows, cls_ln, feat_raw, cls_a2, cls_h2, cls_f2, resized; Tower vt; } side_img;
+    hipEvent_t ev_part[8] = {};      // "student tower of part k done" (created on first use)
     DevBuf a_hi2;                    // ... and its own A-operand split buffer: the main stream's text passes re-split into a_hi (M > 512:
     size_t a_split2_elems = 0;       // dense text mode, large sample_k / selection_p) while the side stream's reward towers read theirs
     int ws_sel = 0;                  // which workspace the GEMM launchers hand out (1 while the side stream's launches are enqueued)

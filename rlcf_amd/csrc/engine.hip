@@ -55,7 +55,8 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 // part reaches 25.8 B/clk/CU, a 128-B one 45.5: profiles/r1_gemm_sq_counters.txt).  The lo part of a pair therefore starts 64 B after hi.
 static inline float* ws_ptr(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).as<float>(); }
 static inline size_t ws_bytes(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).bytes; }
-// A-operand split buffer of the stream whose launches are being enqueued (see ws_sel)
+// image-tower scratch / A-operand split buffer of the stream whose launches are being enqueued (see ws_sel)
+#define IMG_BUF(e, name) ((e)->ws_sel ? (e)->side_img.name : (e)->name)
 static inline void* a_ptr(rlcf_engine* e) { return e->ws_sel ? e->a_hi2.p : e->a_hi.p; }
 static inline size_t a_cap(const rlcf_engine* e) { return e->ws_sel ? e->a_split2_elems : e->a_split_elems; }
 static inline void* lo_of(void* hi) { return (char*)hi + 64; }
@@ -551,7 +552,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             if (l == L - 1 && cls_out && cls_seqs && cls_idx && !causal) {
                 // last block, class-token rows only (see above).  Pair rows are W * 4 bytes like f32 rows: gather_rows moves both.
                 const size_t nw = (size_t)n_seq * W * sizeof(float);
-                TRY(e->cls_a2.ensure(nw)); TRY(e->cls_h2.ensure(nw)); TRY(e->cls_f2.ensure(4 * nw));
+                TRY(IMG_BUF(e, cls_a2).ensure(nw)); TRY(IMG_BUF(e, cls_h2).ensure(nw)); TRY(IMG_BUF(e, cls_f2).ensure(4 * nw));
                 {
                     const bool sg = prec_single(e);
                     if (pair_attn) TRY(launch_attention_fwd_pair(ws.qkv.p, cls_seqs, n_seq, 1, W, nullptr, ws.a2.p, st, nullptr, sg ? 1 : 0));
@@ -561,16 +562,16 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                 e->last_flops += 4.0 * (double)n_seq * max_q_len * W;
                 {
                     const int rw = prec_single(e) ? W / 2 : W;           // row length of the operand matrix in floats (plain f16: W halves)
-                    TRY(launch_gather_rows((const float*)ws.a2.p, rw, cls_idx, e->cls_a2.as<float>(), rw, n_seq, rw, st));
+                    TRY(launch_gather_rows((const float*)ws.a2.p, rw, cls_idx, IMG_BUF(e, cls_a2).as<float>(), rw, n_seq, rw, st));
                 }
                 TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
-                TRY(gemm_pre(e, e->cls_a2.p, W, b.out_w, b.out_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, W, RLCF_EPI_NONE, st));
+                TRY(gemm_pre(e, IMG_BUF(e, cls_a2).p, W, b.out_w, b.out_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, W, RLCF_EPI_NONE, st));
                 {   // LayerNorm sets per view (batched LN-tuning inference): one row per view here
                     const int ln_view_rows = 1;
-                    LN_FWD_SPLIT(cls_out, b.ln2_w, b.ln2_b, e->cls_h2.p, lo_of(e->cls_h2.p), n_seq, W);
+                    LN_FWD_SPLIT(cls_out, b.ln2_w, b.ln2_b, IMG_BUF(e, cls_h2).p, lo_of(IMG_BUF(e, cls_h2).p), n_seq, W);
                 }
-                TRY(gemm_pre(e, e->cls_h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, e->cls_f2.p, 4 * W, n_seq, 4 * W, W, RLCF_EPI_QUICKGELU, st));
-                TRY(gemm_pre(e, e->cls_f2.p, 4 * W, b.proj_w, b.proj_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, 4 * W, RLCF_EPI_NONE, st));
+                TRY(gemm_pre(e, IMG_BUF(e, cls_h2).p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, IMG_BUF(e, cls_f2).p, 4 * W, n_seq, 4 * W, W, RLCF_EPI_QUICKGELU, st));
+                TRY(gemm_pre(e, IMG_BUF(e, cls_f2).p, 4 * W, b.proj_w, b.proj_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, 4 * W, RLCF_EPI_NONE, st));
                 return RLCF_OK;
             }
             {
@@ -699,37 +700,44 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
     const rlcf_clip_cfg& c = m.cfg;
     if (in_res > 0 && in_res != c.image_resolution) {
         // the model wants another input size than the views have: bicubic, align_corners=True (clip_reward.py:133-134)
-        TRY(e->resized.ensure((size_t)e->max_views * 3 * c.image_resolution * c.image_resolution * sizeof(float)));
-        TRY(launch_bicubic(images, e->resized.as<float>(), n * 3, in_res, c.image_resolution, st));
-        images = e->resized.as<float>();
+        TRY(IMG_BUF(e, resized).ensure((size_t)e->max_views * 3 * c.image_resolution * c.image_resolution * sizeof(float)));
+        TRY(launch_bicubic(images, IMG_BUF(e, resized).as<float>(), n * 3, in_res, c.image_resolution, st));
+        images = IMG_BUF(e, resized).as<float>();
     }
     if (is_resnet(c)) return resnet_encode(e, m, images, n, feats, st);
     const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
+    if (e->ws_sel) {               // side-stream scratch grows on demand (first call of a size only)
+        auto& sb = e->side_img;
+        TRY(sb.patch_out.ensure((size_t)n * G2 * Wv * sizeof(float))); TRY(sb.patches.ensure((size_t)n * G2 * m.Kp * sizeof(float)));
+        TRY(sb.cls_rows.ensure((size_t)n * Wv * sizeof(float))); TRY(sb.cls_ln.ensure((size_t)n * Wv * sizeof(float)));
+        TRY(sb.feat_raw.ensure((size_t)n * D * sizeof(float)));
+        TRY(tower_ensure(sb.vt, T, Wv));
+    }
     if (prec_x3(e) && n * G2 > 512 && (size_t)n * G2 * m.Kp <= a_cap(e)) {
         const bool sg = prec_single(e) && m.Kp % 64 == 0 && m.f16_of.count(m.conv_w);
         TRY(launch_im2col(images, nullptr, a_ptr(e), sg ? nullptr : lo_of(a_ptr(e)), n, c.image_resolution, c.vision_patch_size, m.Kp, st, sg ? 0 : 1));
-        TRY(gemm_pre(e, a_ptr(e), m.Kp, m.conv_w, nullptr, nullptr, 0, e->patch_out.as<float>(), Wv, nullptr, 0, n * G2, Wv,
+        TRY(gemm_pre(e, a_ptr(e), m.Kp, m.conv_w, nullptr, nullptr, 0, IMG_BUF(e, patch_out).as<float>(), Wv, nullptr, 0, n * G2, Wv,
                      m.Kp, RLCF_EPI_NONE, st));
     } else {
-        TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
-        TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv,
+        TRY(launch_im2col(images, IMG_BUF(e, patches).as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
+        TRY(gemm(e, IMG_BUF(e, patches).as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, IMG_BUF(e, patch_out).as<float>(), Wv,
                  n * G2, Wv, m.Kp, 1.f, RLCF_EPI_NONE, st));
     }
     {
         const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
-        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.x.as<float>(), n, tok, Wv, st, gw.group_rows, gw.group_stride));
+        TRY(launch_vit_assemble(IMG_BUF(e, patch_out).as<float>(), m.cls, m.vpos, gw.p, gb.p, IMG_BUF(e, vt).x.as<float>(), n, tok, Wv, st, gw.group_rows, gw.group_stride));
     }
     // class-token rows come out compact: the last block is evaluated for them only (transformer_forward)
-    TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
+    TRY(transformer_forward(e, m.vis, IMG_BUF(e, vt), e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
                             false, st, e->vit_seqs_cls.as<rlcf_seq>() + (size_t)which * e->max_views,
-                            e->vit_cls_idx.as<int32_t>() + (size_t)which * e->max_views, e->cls_rows.as<float>()));
+                            e->vit_cls_idx.as<int32_t>() + (size_t)which * e->max_views, IMG_BUF(e, cls_rows).as<float>()));
     {
         const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);      // one class-token row per view
-        TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), gw.p, gb.p, e->cls_ln.as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
+        TRY(launch_layernorm_fwd(IMG_BUF(e, cls_rows).as<float>(), gw.p, gb.p, IMG_BUF(e, cls_ln).as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
     }
-    TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
+    TRY(gemm(e, IMG_BUF(e, cls_ln).as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, IMG_BUF(e, feat_raw).as<float>(), D, n, D, Wv, 1.f,
              RLCF_EPI_NONE, st));
-    TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, nullptr, n, D, st));
+    TRY(launch_l2norm_rows(IMG_BUF(e, feat_raw).as<float>(), feats, nullptr, n, D, st));
     return RLCF_OK;
 }
 
@@ -1295,22 +1303,28 @@ static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
     return RLCF_OK;
 }
 
+// img_feat: the student image features [B*N, D] of these views — nullptr: computed here (the whole pass on one stream); else they
+// were produced by the caller (tta_batch_pipelined: the tower of this part ran on the other stream) and only the rest of the pass runs
 static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
-                           hipStream_t st) {
+                           hipStream_t st, const float* img_feat = nullptr) {
     ClipModel& s = e->model[RLCF_STUDENT];
     const TextLayout& L = e->lay[0];
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
     const int n_sel = n_selected(a, N), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    TRY(batch_ensure(e, B, st));
-    TRY(sparse_ensure(e, n_e, st, B));
-    e->last_flops = 0.0;
-    // 1. student image features of all B*N views; first-step logits against the cached pristine-prompt text features
-    TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
-    TRY(engine_logits(e, e->img_feat.as<float>(), BN, e->txt0.as<float>(), C, e->logits.as<float>(), st));
+    if (!img_feat) {
+        TRY(batch_ensure(e, B, st));
+        TRY(sparse_ensure(e, n_e, st, B));
+        e->last_flops = 0.0;
+        // 1. student image features of all B*N views
+        TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
+        img_feat = e->img_feat.as<float>();
+    }
+    // first-step logits against the cached pristine-prompt text features
+    TRY(engine_logits(e, img_feat, BN, e->txt0.as<float>(), C, e->logits.as<float>(), st));
     // 2. per-sample confidence selection (global row ids), gathers, reward features of the selected views
     TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-    TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
+    TRY(launch_gather_rows(img_feat, D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
     TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
     TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
     TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
@@ -1372,10 +1386,58 @@ static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, con
     // 6. final clean-view inference: B adapted prompts through one replicated text pass
     TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
     float* fl = final_logits ? final_logits : e->b_logits.as<float>();
-    TRY(launch_final_logits_batched(e->img_feat.as<float>(), N, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, fl, st));
+    TRY(launch_final_logits_batched(img_feat, N, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, fl, st));
     e->last_flops += 2.0 * B * C * D;
     TRY(launch_top5_batched(fl, B, C, top5, st));
     return RLCF_OK;
+}
+
+// One pass of B test images in `parts` parts on TWO streams: the student image tower of part k+1 (chip-filling GEMMs) runs on the
+// caller's stream while everything behind the tower of part k — reward models' pass over the selected views, loss, sparse text
+// forward / backward, AdamW, the replicated final text pass: small launch-bound kernels, ~20 % of a pass — runs on the side stream
+// with the side stream's own scratch (ws_sel: A-operand buffer, split-K workspace, image-tower scratch).  Samples are independent, so
+// the per-sample results are those of the one-stream pass up to the round-off of the GEMM forms the part sizes select
+// (test_batch_pipeline_equals_single_stream).  MEASURED SLOWER than the one-stream pass on BASELINE configs[1] (115.7 images/s
+// against 114.1 / 109.3 in 2 / 4 parts: a workgroup of the small kernels blocks a CU for the 139-KB GEMM workgroups of the tower just as
+// it does alone, so the two-stream form hides nothing) — built only when RLCF_BATCH_PARTS=n asks for it.
+static int tta_batch_pipelined(rlcf_engine* e, const float* views, int B, int N, int parts, const rlcf_tta_args* a, float* final_logits,
+                               int32_t* top5, hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    const int D = s.cfg.embed_dim, n_sel = n_selected(a, N), n_e = n_sel * a->sample_k;
+    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const int Bp = (B + parts - 1) / parts;
+    TRY(batch_ensure(e, Bp, st));
+    TRY(sparse_ensure(e, n_e, st, Bp));
+    {   // side-stream operand buffer: the text passes of a part and the reward models' patch matrices
+        size_t need2 = (size_t)Bp * e->lay[0].T * s.cfg.text_width * 4;
+        for (int m = 0; m < e->n_rewards; ++m) {
+            const ClipModel& rm = e->model[RLCF_REWARD + m];
+            need2 = std::max(need2, (size_t)Bp * n_sel * rm.tokens * std::max(rm.Kp, 4 * rm.cfg.vision_width));
+        }
+        if (need2 > e->a_split2_elems) { TRY(e->a_hi2.ensure(need2 * 4)); e->a_split2_elems = need2; }
+    }
+    for (int k = 0; k < parts && k < 8; ++k)
+        if (!e->ev_part[k]) RLCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_part[k], hipEventDisableTiming));
+    e->last_flops = 0.0;
+    RLCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+    RLCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    int rc = RLCF_OK;
+    for (int k = 0, b0 = 0; k < parts && b0 < B && rc == RLCF_OK; ++k, b0 += Bp) {
+        const int Bk = std::min(Bp, B - b0);
+        float* feat_k = e->img_feat.as<float>() + (size_t)b0 * N * D;
+        rc = engine_encode_image(e, RLCF_STUDENT, views + (size_t)b0 * per, Bk * N, feat_k, st);
+        if (rc != RLCF_OK) break;
+        if (hipEventRecord(e->ev_part[k], st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_part[k], 0) != hipSuccess) { rc = RLCF_ERR_HIP; break; }
+        e->ws_sel = 1;
+        rc = tta_batch_fused(e, views + (size_t)b0 * per, Bk, N, a, final_logits ? final_logits + (size_t)b0 * e->C : nullptr, top5 + (size_t)b0 * 5,
+                             e->side, feat_k);
+        e->ws_sel = 0;
+    }
+    // the caller's stream joins the side stream whatever happened
+    const hipError_t e1 = hipEventRecord(e->ev_join, e->side);
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, e->ev_join, 0) : e1;
+    if (e2 != hipSuccess) { (void)hipStreamSynchronize(e->side); if (rc == RLCF_OK) { rlcf_set_error("tta_batch_pipelined: join: %s", hipGetErrorString(e2)); rc = RLCF_ERR_HIP; } }
+    return rc;
 }
 
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
@@ -1395,6 +1457,18 @@ int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const
     while (i < count) {
         const int B = fused ? std::min(Bmax, count - i) : 1;
         if (fused && B >= 2) {
+            // parts of a pass on two streams (tta_batch_pipelined): needs the side stream, ViT towers everywhere (the ModifiedResNet
+            // pass keeps its scratch in the engine), no per-launch profile (its event pairs serialise), one tuning step
+            static int parts_env = -1;
+            if (parts_env < 0) { const char* ev = getenv("RLCF_BATCH_PARTS"); parts_env = ev ? atoi(ev) : 0; }
+            bool vit_all = !is_resnet(s.cfg);
+            for (int m = 0; m < e->n_rewards; ++m) vit_all = vit_all && !is_resnet(e->model[RLCF_REWARD + m].cfg);
+            int parts = parts_env > 0 ? parts_env : 1;          // (measured slower than one stream on BASELINE configs[1]: off unless asked for)
+            parts = std::min(std::min(parts, 8), B / 2);
+            if (parts >= 2 && vit_all && e->side && !g_prof.enabled && prec_x3(e)) {
+                TRY(tta_batch_pipelined(e, views + (size_t)i * per, B, N, parts, a, final_logits ? final_logits + (size_t)i * e->C : nullptr,
+                                        top5 + (size_t)i * 5, st));
+            } else
             TRY(tta_batch_fused(e, views + (size_t)i * per, B, N, a, final_logits ? final_logits + (size_t)i * e->C : nullptr, top5 + (size_t)i * 5, st));
         } else {
             rlcf_tta_out o{};
