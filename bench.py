@@ -22,8 +22,22 @@ Legs, in order (all on the launch stream of the engine = torch's current stream)
   4. cpu_baseline: the oracle (CPU restatement of the reference graph) on BASELINE configs[0] — N=8 views,
      selection_p=0.5, C=`--classes` — 1 warm-up + 3 timed samples on the host cores.
 
+`--config {0,1,2,4}` selects the BASELINE.json configuration (default 1 = the one `metric` is quoted on; 3 is config 1 sharded
+over 8 GPUs: `--gpus 8 --total-images 256`):
+  0  ViT-B/16 + ViT-B/16, N = 8 views, selection_p = 0.5, prompt tuning      (the reference's CPU-runnable case)
+  1  ViT-B/16 + ViT-B/16, N = 64, prompt tuning                               (rlcf_tta_batch)
+  2  ViT-L/14 + ViT-L/14, N = 64, LayerNorm tuning of the image encoder        (rlcf_tta_batch_ln, TPT/tune_cls_rl.py:183-256)
+  4  RN50x64 student @448 + ViT-L/14 reward, N = 32, prompt tuning             (one image per pass)
+Every config prints the same JSON shape: whole-step TF/s, F_exec per image, the dominant kernel's roofline and a per-kernel table
+built from ALL profiled launches of one pass (GEMMs by kernel kind and shape incl. the weight-gradient / dX GEMMs, attention forward
+and backward, LayerNorm forward and backward).
+
 Prints ONE JSON line on rank 0.
 """
+import os as _os
+if int(_os.environ.get("WORLD_SIZE", "1")) == 1:         # one rank: the CPU-oracle leg pins one thread per core (read at OpenMP start-up)
+    _os.environ.setdefault("OMP_PROC_BIND", "close")
+    _os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import ctypes as C
 import json
@@ -69,7 +83,7 @@ def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
     """the oracle (CPU torch fp32 restatement of the REFERENCE GRAPH: dense 77-token text tower with
     autograd tape, dense backward, AdamW, final inference) on BASELINE configs[0] — ViT-B/16 + ViT-B/16, one image -> N=8 views,
     selection_p=0.5, the full class bank — 1 warm-up + `timed` timed samples at the full class count; no extrapolation.
-    Threads: min(os.cpu_count(), 32) (see below).
+    Threads: the fastest of a 32 / 64 / 128 sweep (see below).
     `budget_s` bounds the leg: timed samples stop early (at least one is taken) once it is spent."""
     from oracle import clip_ref as CR, rlcf_ref as RR
     t_leg = time.perf_counter()
@@ -86,7 +100,20 @@ def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
     # Threads: BASELINE.md asks for os.cpu_count(); on the GPU boxes of this pool (hundreds of hardware threads) torch's intra-op pool
     # then thrashes so badly that a 1.5 s probe sample (32 classes) did not finish in ten minutes (round-2 measurement), so the pool
     # is capped at 32 threads — the count is reported as `cores`, the host's total as `hardware_threads`.
-    threads = min(ncpu, 32)
+    # Round 3: the thread count is SWEPT — one probe sample at a 64-class bank per candidate (32 / 64 / 128 threads, never more than the
+    # host has; OMP_PROC_BIND=close, OMP_PLACES=cores set at the top of this file) — and the fastest runs the timed samples.
+    cands = sorted({t for t in (32, 64, 128) if t <= ncpu} or {ncpu})
+    probe_tokens = synth.make_token_bank(geo, 64, seed=7, n_ctx=n_ctx)
+    probe_rc = RR.reward_class_features(rsd, probe_tokens)
+    sweep = {}
+    for t_ in cands:
+        torch.set_num_threads(t_)
+        one(998, probe_tokens, probe_rc)                        # (first call at a thread count: pool start-up)
+        sweep[t_] = one(997, probe_tokens, probe_rc)
+        log(f"cpu_baseline thread sweep: {t_} threads -> {sweep[t_]:.2f} s per image at C=64")
+        if time.perf_counter() - t_leg > 0.3 * budget_s:
+            break
+    threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=n_ctx)
     rc = RR.reward_class_features(rsd, tokens)              # once per dataset in the reference (tpt_cls_rl.py:182-183): not timed
@@ -104,7 +131,8 @@ def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
                       f"1 image x N=8 views (selection_p=0.5 -> 4 selected), C={n_cls}, K=3, 1 AdamW step; 1 warm-up + {len(times)} timed "
                       f"samples, {threads} torch threads of {ncpu} hardware threads",
             "seconds_per_image": [round(t, 3) for t in times], "seconds_per_image_mean": mean, "warmup_seconds": round(warm, 3),
-            "cpu_model": cpu_model(), "hardware_threads": ncpu}
+            "cpu_model": cpu_model(), "hardware_threads": ncpu,
+            "thread_sweep_seconds_at_64_classes": {str(k): round(v, 3) for k, v in sweep.items()}}
 
 
 def profile_entries(lib):
@@ -117,18 +145,35 @@ def profile_entries(lib):
     return out
 
 
+KIND_NAMES = {0: "gemm_nt_f32 (f32 MFMA)", 1: "gemm_nt_f16x3 128x128 (DMA ring / split-K / register-staged)", 2: "gemm_nt_f16x3_v2 256x128",
+              3: "gemm_nt_f16x3_v3i 256x256", 10: "attention forward (QK^T, softmax, PV)", 11: "LayerNorm forward -> operand pairs (HBM-bound)",
+              12: "attention backward (dQ, dK, dV)", 13: "LayerNorm backward (HBM-bound)"}
+HBM_KINDS = (11, 13)
+CONFIGS = {
+    0: dict(student="ViT-B/16", reward="ViT-B/16", views=8, selection_p=0.5, mode="prompt", lr=7e-3, batch=32,
+            what="BASELINE configs[0]: ViT-B/16, 1 image x N=8 views, 1000-class bank, 1 AdamW step on the prompt"),
+    1: dict(student="ViT-B/16", reward="ViT-B/16", views=64, selection_p=0.1, mode="prompt", lr=7e-3, batch=32,
+            what="BASELINE configs[1]: ViT-B/16 student + ViT-B/16 reward, N=64, prompt-tuning RLCF"),
+    2: dict(student="ViT-L/14", reward="ViT-L/14", views=64, selection_p=0.1, mode="ln", lr=1e-5, batch=16,
+            what="BASELINE configs[2]: ViT-L/14 student + ViT-L/14 reward, N=64, LayerNorm tuning of the image encoder"),
+    4: dict(student="RN50x64", reward="ViT-L/14", views=32, selection_p=0.1, mode="prompt", lr=7e-3, batch=1,
+            what="BASELINE configs[4]: RN50x64 image encoder student @448 + ViT-L/14 reward, N=32, prompt tuning"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i] (3 = config 1 with --gpus 8 --total-images 256)")
+    ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=sorted(PRECISIONS))
-    ap.add_argument("--reward-arch", default="ViT-B/16", help="reward CLIP (BASELINE configs[1]: ViT-B/16; rlcf-prompt.sh: ViT-L/14)")
+    ap.add_argument("--reward-arch", default=None, help="reward CLIP (BASELINE configs[1]: ViT-B/16; rlcf-prompt.sh: ViT-L/14)")
     ap.add_argument("--tta-steps", type=int, default=1, help="AdamW steps per test image (BASELINE metric: 1; rlcf-prompt.sh runs 3)")
-    ap.add_argument("--batch", type=int, default=32, help="independent test images per tower pass (engine-internal batching)")
+    ap.add_argument("--batch", type=int, default=None, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--total-images", type=int, default=0,
                     help="strong scaling: this many test images in total, split over the ranks (BASELINE configs[3]: 256); overrides --steps")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained leg (0 = skip)")
@@ -139,6 +184,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
     a = ap.parse_args()
+    wl = CONFIGS[a.config]
+    a.views = a.views if a.views is not None else wl["views"]
+    a.reward_arch = a.reward_arch or wl["reward"]
+    student_arch, mode_ln = wl["student"], wl["mode"] == "ln"
+    is_default_wl = (a.views, a.reward_arch, a.classes, a.tta_steps) == (wl["views"], wl["reward"], 1000, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,21 +198,39 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or bool(os.environ.get("RLCF_FORCE_DIST"))     # RLCF_FORCE_DIST: exercise the RCCL path with one rank
+    dist_info = None
+    if world > 1:
+        # one process per GPU on one host: each rank keeps to its own slice of the host cores (view generation and launches are
+        # host work: 8 ranks with the default intra-op pool of 256 threads each would thrash)
+        ncpu = os.cpu_count() or 1
+        per = max(1, ncpu // world)
+        torch.set_num_threads(min(per, 16))
+        try:
+            os.sched_setaffinity(0, set(range(local * per, (local + 1) * per)))
+        except (AttributeError, OSError):
+            pass
     if use_dist:
         import torch.distributed as dist
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        try:
+            ver = torch.cuda.nccl.version() if a.dist_backend == "nccl" else None
+        except Exception:           # (not every build exposes it)
+            ver = None
+        dist_info = {"backend": a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else ""), "rccl_ranks": dist.get_world_size(),
+                     "rccl_version": ".".join(str(v) for v in ver) if ver else None,
+                     "collectives": "barrier x2 + all_reduce(MAX) of the elapsed time; none on the data path"}
 
-    geo = synth.GEOMETRIES["ViT-B/16"]
+    geo = synth.GEOMETRIES[student_arch]
     n_ctx = 4
     ssd = synth.make_state_dict(geo, 11, device=dev)
     rgeo = synth.GEOMETRIES[a.reward_arch]
     rsd = synth.make_state_dict(rgeo, 23, device=dev)
     tokens = synth.make_token_bank(geo, a.classes, seed=7, n_ctx=n_ctx)
     ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, n_ctx), device=dev)].clone()
-    batch = max(a.batch, 1)
+    batch = max(a.batch if a.batch is not None else wl["batch"], 1)
     eng = Engine(geo, rgeo, a.views * batch, a.classes, PRECISIONS[a.precision])
     eng.load_state_dict(_lib.STUDENT, ssd)
     eng.load_state_dict(_lib.REWARD, rsd)
@@ -170,7 +238,8 @@ def main():
     mode = {"dense": _lib.TEXT_DENSE, "packed": _lib.TEXT_PACKED, "shared": _lib.TEXT_SHARED}[a.text_mode]
     eng.set_class_bank(tokens, n_ctx, ctx0, mode)
     log("engine ready")
-    cfg = TTAConfig(selection_p=0.1, tta_steps=a.tta_steps, sample_k=3, lr=7e-3, weight_decay=5e-4)
+    cfg = TTAConfig(selection_p=wl["selection_p"], tta_steps=a.tta_steps, sample_k=3, lr=wl["lr"], weight_decay=5e-4)
+    run_pass = (lambda v: eng.tta_batch_ln(v, cfg)) if mode_ln else (lambda v: eng.tta_batch(v, cfg))
 
     # which test images this rank times: weak scaling = `steps` images of its own; strong = its shard of a fixed stream
     if a.total_images > 0:
@@ -188,16 +257,16 @@ def main():
     views = make(first, steps)
     torch.cuda.synchronize()
 
-    eng.tta_batch(wviews[:pass_images], cfg)             # engine setup: sizes the batch workspaces once (not a step)
+    run_pass(wviews[:pass_images])                       # engine setup: sizes the batch workspaces once (not a step)
     torch.cuda.synchronize()
     if a.warmup:
-        eng.tta_batch(wviews[: a.warmup], cfg)
+        run_pass(wviews[: a.warmup])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    top5 = eng.tta_batch(views, cfg)
+    top5 = run_pass(views)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -215,14 +284,15 @@ def main():
         lib = _lib.lib()
         peak = PEAK_TFLOPS["f32"] if a.precision == "f32" else PEAK_TFLOPS["f16"]
         passes = MFMA_PASSES[a.precision]
+        tuned = "LayerNorm parameters of the image encoder" if mode_ln else "prompt"
         out = {
             "metric": "test_images_per_sec", "value": total_steps / dt, "unit": "images/s", "n_gpus": world,
             "steps": a.steps if scaling == "weak" else total_steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
-            "config": {"workload": f"RLCF prompt-tuning TTA step, CLIP ViT-B/16 student + {a.reward_arch} reward, N={a.views} views, "
-                                   f"{a.classes}-class bank, selection_p=0.1, K=3, {a.tta_steps} AdamW step(s)"
-                                   + (" (BASELINE configs[1])" if (a.views, a.classes, a.reward_arch, a.tta_steps) == (64, 1000, "ViT-B/16", 1)
-                                      else ""),
+            "config": {"workload": f"RLCF test-time-adaptation step ({tuned} tuned), CLIP {student_arch} student + {a.reward_arch} reward, "
+                                   f"N={a.views} views, {a.classes}-class bank, selection_p={wl['selection_p']}, K=3, {a.tta_steps} AdamW step(s)"
+                                   + (f" ({wl['what'].split(':')[0]})" if is_default_wl else ""),
+                       "baseline_config": a.config if is_default_wl else None,
                        "views": a.views, "classes": a.classes, "text_mode": a.text_mode, "text_rows": eng.text_rows(),
                        "tta_steps": a.tta_steps, "images_per_pass": pass_images, "timed_images_per_rank": steps,
                        "parallelism": f"sample-sharded x{world}, no data-path collective"},
@@ -230,63 +300,88 @@ def main():
             "whole_step_tflops": flops_exec * total_steps / dt / 1e12,
             "top1_first": int(top5[0, 0].item()),
         }
+        if dist_info:
+            out["distributed"] = dist_info
         if not a.no_roofline:
-            # ---- roofline leg: one pass of exactly the timed pass size, HIP event pair per GEMM / attention launch
+            # ---- roofline leg: one pass of exactly the timed pass size, HIP event pair per GEMM / attention / LayerNorm launch
             lib.rlcf_profile_gemm(1)
-            eng.tta_batch(views[:pass_images], cfg)
+            run_pass(views[:pass_images])
             torch.cuda.synchronize()
             ent = profile_entries(lib)
             lib.rlcf_profile_gemm(0)
             log(f"roofline leg: {len(ent)} profiled launches")
-            gemms = [e for e in ent if e[0] not in (10, 11)]
-            dom_kind = 3 if a.precision != "f32" else 0      # 256x256-tile split-f16 GEMM / the f32-MFMA kernels
+            gemms = [e for e in ent if e[0] < 10]
+            # dominant kernel = the GEMM kernel kind with the most time in the pass (configs[1]: the 256x256 split-f16 kernel)
+            by_kind = {}
+            for e in gemms:
+                by_kind[e[0]] = by_kind.get(e[0], 0.0) + e[1]
+            dom_kind = max(by_kind, key=by_kind.get) if by_kind else 3
             dom = [e for e in gemms if e[0] == dom_kind]
             d_ms, d_fl = sum(e[1] for e in dom), sum(e[2] for e in dom)
             g_ms, g_fl = sum(e[1] for e in gemms), sum(e[2] for e in gemms)
             achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
-            # per-shape table of the student image tower's layer kernels (K4 in_proj, K5 attention, K6 out_proj,
-            # K7 c_fc / c_proj) at the token-matrix size of this pass
-            Wv, tok = geo.vision_width, geo.vision_tokens
-            M_student = pass_images * a.views * tok
-            names = {(3 * Wv, Wv): "K4 in_proj (QKV)", (Wv, Wv): "K6 out_proj + residual", (4 * Wv, Wv): "K7 c_fc + QuickGELU",
-                     (Wv, 4 * Wv): "K7 c_proj + residual"}
             table = []
-            for (n_, k_), nm in names.items():
-                sel = [e for e in gemms if e[3] == (M_student, n_, k_)]
-                if sel:
-                    ms_, fl_ = sum(e[1] for e in sel), sum(e[2] for e in sel)
-                    table.append({"kernel": nm, "M": M_student, "N": n_, "K": k_, "launches": len(sel), "avg_ms": ms_ / len(sel),
-                                  "tflops": fl_ / ms_ / 1e9, "frac_of_peak": fl_ / ms_ / 1e9 / peak})
-            ln = [e for e in ent if e[0] == 11 and e[3][0] == M_student]
-            if ln:      # HBM GB/s for the bandwidth-bound kernels — K3 LayerNorm, algorithmic bytes = f32 row in + pair row out
-                ms_, by_ = sum(e[1] for e in ln), sum(e[2] for e in ln)
-                table.append({"kernel": "K3 LayerNorm forward -> operand pairs (HBM-bound)", "rows": M_student, "launches": len(ln),
-                              "avg_ms": ms_ / len(ln), "gb_per_s": by_ / ms_ / 1e6, "frac_of_hbm_peak": by_ / ms_ / 1e6 / HBM_PEAK_GBS})
-            att = [e for e in ent if e[0] == 10 and e[3][0] == M_student]
-            if att:
-                ms_, fl_ = sum(e[1] for e in att), sum(e[2] for e in att)
-                table.append({"kernel": "K5 attention forward (QK^T, softmax, PV)", "rows": M_student, "launches": len(att),
-                              "avg_ms": ms_ / len(att), "tflops": fl_ / ms_ / 1e9, "frac_of_peak": fl_ / ms_ / 1e9 / peak})
+            if not geo.is_resnet:
+                # named rows: the student image tower's layer kernels (K4 in_proj, K5 attention, K6 out_proj,
+                # K7 c_fc / c_proj, K3 LayerNorm) at the token-matrix size of this pass
+                Wv, tok = geo.vision_width, geo.vision_tokens
+                M_student = pass_images * a.views * tok
+                names = {(3 * Wv, Wv): "K4 in_proj (QKV)", (Wv, Wv): "K6 out_proj + residual", (4 * Wv, Wv): "K7 c_fc + QuickGELU",
+                         (Wv, 4 * Wv): "K7 c_proj + residual"}
+                for (n_, k_), nm in names.items():
+                    sel = [e for e in gemms if e[3] == (M_student, n_, k_)]
+                    if sel:
+                        ms_, fl_ = sum(e[1] for e in sel), sum(e[2] for e in sel)
+                        table.append({"kernel": nm, "M": M_student, "N": n_, "K": k_, "launches": len(sel), "avg_ms": ms_ / len(sel),
+                                      "tflops": fl_ / ms_ / 1e9, "frac_of_peak": fl_ / ms_ / 1e9 / peak})
+                ln = [e for e in ent if e[0] == 11 and e[3][0] == M_student]
+                if ln:      # HBM GB/s for the bandwidth-bound kernels — K3 LayerNorm, algorithmic bytes = f32 row in + pair row out
+                    ms_, by_ = sum(e[1] for e in ln), sum(e[2] for e in ln)
+                    table.append({"kernel": "K3 LayerNorm forward -> operand pairs (HBM-bound)", "rows": M_student, "launches": len(ln),
+                                  "avg_ms": ms_ / len(ln), "gb_per_s": by_ / ms_ / 1e6, "frac_of_hbm_peak": by_ / ms_ / 1e6 / HBM_PEAK_GBS})
+                att = [e for e in ent if e[0] == 10 and e[3][0] == M_student]
+                if att:
+                    ms_, fl_ = sum(e[1] for e in att), sum(e[2] for e in att)
+                    # HBM roofline of this kernel: Q, K, V operand pairs in + O pairs out = 16 B per token and column
+                    hbm_ms = M_student * Wv * 16.0 / (HBM_PEAK_GBS * 1e6)
+                    table.append({"kernel": "K5 attention forward (QK^T, softmax, PV)", "rows": M_student, "launches": len(att),
+                                  "avg_ms": ms_ / len(att), "tflops": fl_ / ms_ / 1e9, "frac_of_peak": fl_ / ms_ / 1e9 / peak,
+                                  "hbm_roofline_ms": hbm_ms, "frac_of_hbm_roofline": hbm_ms / (ms_ / len(att))})
+            # every profiled launch of the pass, grouped by kernel kind and shape, longest first (forward AND backward kernels: the
+            # dX / weight-gradient GEMMs, the attention backward and the LayerNorm backward of the encoder-tuning configs)
+            groups = {}
+            for e in ent:
+                g = groups.setdefault((e[0], e[3]), [0, 0.0, 0.0])
+                g[0] += 1; g[1] += e[1]; g[2] += e[2]
+            all_ms = sum(g[1] for g in groups.values())
+            by_shape = []
+            for (kind, dims), (n_l, ms_, w_) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:24]:
+                row = {"kernel": KIND_NAMES.get(kind, f"kind {kind}"), "dims": list(dims), "launches": n_l, "total_ms_per_image": ms_ / pass_images,
+                       "share_of_profiled_time": ms_ / all_ms if all_ms > 0 else 0.0}
+                if kind in HBM_KINDS:
+                    row.update(gb_per_s=w_ / ms_ / 1e6, frac_of_hbm_peak=w_ / ms_ / 1e6 / HBM_PEAK_GBS)
+                else:
+                    row.update(tflops=w_ / ms_ / 1e9, frac_of_peak=w_ / ms_ / 1e9 / peak)
+                by_shape.append(row)
             # HBM/fabric bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters perturb timing
-            # and cannot be read in-process); they are quoted only from THIS round's committed profile of this exact pass size
+            # and cannot be read in-process); they are quoted only from a committed profile of this exact pass size
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "r2_gemm_hbm_traffic.json")
-            if a.precision == "f16x3" and os.path.exists(tpath) and (a.views, a.classes) == (64, 1000):
+            if a.precision == "f16x3" and os.path.exists(tpath) and a.config == 1 and is_default_wl:
                 rec = json.load(open(tpath)).get("bytes_per_launch_by_images_per_pass", {}).get(str(pass_images))
                 if rec:
-                    traffic, tsrc = rec, f"profiles/r2_gemm_hbm_traffic.json (rocprofv3 --pmc pass of bench.py at {pass_images} images per pass)"
+                    traffic, tsrc = rec, (f"profiles/r2_gemm_hbm_traffic.json (rocprofv3 --pmc pass of this GEMM at {pass_images} images per pass; the kernel's "
+                                          "main loop is unchanged since; Infinity-Cache hits are inside the counter: profiles/r3_gemm_experiments.txt)")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_source": tsrc, "mfma_passes": passes,
                 "frac_of_mfma_pipe": passes * achieved / peak,     # issued MFMA flops / peak (computed: passes x achieved, not a counter)
-                "kernel": "gemm_nt_f32_kernel + gemm_nt_f32_splitk_kernel (v_mfma_f32_32x32x2_f32)" if a.precision == "f32"
-                else ("gemm_nt_f16x3_v3i_kernel (3x v_mfma_f32_32x32x16_f16 per f32-grade product)" if a.precision == "f16x3"
-                      else "gemm_nt_f16_kernel (v_mfma_f32_32x32x16_f16, one pass)"),
+                "kernel": KIND_NAMES.get(dom_kind, str(dom_kind)) + (" (3x v_mfma_f32_32x32x16_f16 per f32-grade product)" if a.precision == "f16x3" else ""),
                 "profiled_images_per_pass": pass_images, "launches": len(dom), "avg_launch_ms": d_ms / max(len(dom), 1),
                 "launches_per_image": len(dom) / pass_images, "gemm_flops_per_image": d_fl / pass_images,
                 "all_gemm_kernels": {"launches_per_image": len(gemms) / pass_images, "ms_per_image": g_ms / pass_images,
                                      "achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0},
-                "per_kernel": table,
+                "per_kernel": table, "per_kernel_all_launches": by_shape,
                 # the profiled pass is the timed pass: its GEMM time cannot exceed the step time (5 % for event overhead / clock drift)
                 "check_gemm_time_within_step": bool(g_ms / pass_images <= 1.05 * ms_per_step),
             }
@@ -297,7 +392,7 @@ def main():
             while time.perf_counter() < t_end or len(evs) < 8:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                eng.tta_batch(pv, cfg)
+                run_pass(pv)
                 e1.record()
                 evs.append((e0, e1))
                 if len(evs) % 4 == 0:
@@ -309,7 +404,7 @@ def main():
                                 "p50_ms_per_image": statistics.median(per_img), "min_ms_per_image": per_img[0],
                                 "max_ms_per_image": per_img[-1], "images_per_s_mean": 1e3 / statistics.fmean(per_img),
                                 "timer": "HIP events on the launch stream, one pair per pass"}
-        if world == 1 and a.precision == "f16x3" and not a.no_f16_line and not use_dist:
+        if world == 1 and a.precision == "f16x3" and a.config == 1 and not a.no_f16_line and not use_dist:
             # ---- secondary, clearly labelled: the reference's own GPU arithmetic (fp16 autocast, tpt_cls_rl.py:52) = RLCF_PREC_F16.
             # Not the headline and not parity-grade: reported with its measured deviation from the split-f16 engine on this very pass.
             top5x, flx = eng.tta_batch(views[:pass_images], cfg, want_logits=True)
@@ -348,9 +443,15 @@ def main():
                 "attention_fwd_frac_of_f16_peak": (sum(e[2] for e in att_h) / max(sum(e[1] for e in att_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if att_h else None}
             eh.close()
             log("secondary f16 line done")
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes,
-                                               budget_s=a.cpu_baseline_budget)
+        if world == 1 and not a.no_cpu_baseline and not use_dist:
+            # the reference's CPU path runs BASELINE configs[0] (ViT-B/16, N = 8): timed for configs 0 / 1; the ViT-L/14 and RN50x64
+            # configurations would take minutes per image on the host and get the same oracle leg only when asked for with a budget
+            if a.config in (0, 1):
+                out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes,
+                                                   budget_s=a.cpu_baseline_budget)
+            else:
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                                       "sample": "not timed for this configuration (the oracle's CPU leg is BASELINE configs[0]: run --config 0 or 1)"}
         print(json.dumps(out))
     eng.close()
     if use_dist:

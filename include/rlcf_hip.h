@@ -391,7 +391,9 @@ int rlcf_engine_text_rows(rlcf_engine*);   /* rows of the packed text layout */
 int rlcf_profile_gemm(int enable);
 int rlcf_profile_read(int kind, int* launches, double* total_ms, double* total_flops);
 /* the same records one by one (launch order): kind as above (10 = the fused attention forward of the split-f16 pipeline; 11 = the LayerNorm forward that writes
- * operand pairs, an HBM-bound kernel: its `flops` value is its ALGORITHMIC BYTES, dims3 = {rows, width, 0}),
+ * operand pairs, an HBM-bound kernel: its `flops` value is its ALGORITHMIC BYTES, dims3 = {rows, width, 0}; round 3: 12 = the
+ * attention backward of the image tower (flops = 10 * pairs * width), 13 = the LayerNorm backward of a transformer block, HBM-bound
+ * like 11: `flops` = bytes of x, dy and the residual gradient in + dx out),
  * HIP-event duration in ms, algorithmic FLOPs, dims3 = {M, N, K} of a GEMM / {rows, width, longest sequence} of an attention launch */
 int rlcf_profile_count(void);
 int rlcf_profile_entry(int i, int* kind, double* ms, double* flops, int* dims3);

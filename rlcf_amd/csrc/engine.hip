@@ -658,13 +658,20 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
                  e->bwd_amax.as<float>()));                               // ... and scales the next operand without another pass
         float* g1 = ln_grad ? ln_grad + (size_t)(2 + 4 * l) * W : nullptr;        // [ln_1.w | ln_1.b | ln_2.w | ln_2.b] of layer l
         const LnRef g2w = ln_ref(e, b.ln2_w, 1), g1w = ln_ref(e, b.ln1_w, 1);       // per-sample LayerNorm sets (batched LN tuning, step > 0)
-        TRY(launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows, group_stride,
-                                 group_rows > 0 ? g2w.group_stride : 0));
+        {   // profile record of kind 13: LayerNorm backward, HBM-bound — `flops` carries its ALGORITHMIC BYTES (x, dy, residual gradient in, dx out)
+            const int ls = prof_begin(st, (double)T * W * 16.0, T, W, 0);
+            const int lrc = launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows,
+                                                 group_stride, group_rows > 0 ? g2w.group_stride : 0);
+            prof_end(ls, st, 13);
+            TRY(lrc);
+        }
         if (wgrad_base) TRY(wgrad(e, dX, W, W, s.a, W, W, T, G[2], G[3], st));      // out_proj: x1 = x + a Wo^T + b, dY = d x1
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
         RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         static int bwd_f32 = -1;                                // RLCF_ATTN_BWD_F32=1: the f32-MFMA backward also in split-f16 mode (benchmarks)
         if (bwd_f32 < 0) { const char* ev = getenv("RLCF_ATTN_BWD_F32"); bwd_f32 = ev ? atoi(ev) : 0; }
+        // profile record of kind 12: the attention backward (flops = 10 * pairs * W; dims = rows, width, longest sequence)
+        const int pslot = prof_begin(st, 10.0 * attn_pairs * W, T, W, max_q_len > 0 ? max_q_len : max_keys);
         if (max_keys > 96 && prec_x3(e) && !bwd_f32) {
             TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));       // range of dO for the f16 pairs
             TRY(launch_attention_bwd_x3(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal,
@@ -678,14 +685,20 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
             if (need * sizeof(float) <= ((size_t)512 << 20)) { TRY(e->attn_pre_ws.ensure(need * sizeof(float))); pws = e->attn_pre_ws.as<float>(); }
             TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st, pws, pws ? need : 0, max_keys));
         }
+        prof_end(pslot, st, 12);
         e->last_flops += 10.0 * attn_pairs * W;
         if (wgrad_base) {                  // in_proj: qkv = LN1(x) Win^T + b
             TRY(launch_layernorm_fwd(s.x, b.ln1_w, b.ln1_b, ws.h.as<float>(), T, W, st));
             TRY(wgrad(e, dQKV, 3 * W, 3 * W, ws.h.as<float>(), W, W, T, G[0], G[1], st));
         }
         TRY(gemm(e, dQKV, 3 * W, b.in_wT, 3 * W, nullptr, nullptr, 0, nullptr, 0, dH, W, T, W, 3 * W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
-        TRY(launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
-                                 group_rows > 0 ? g1w.group_stride : 0));
+        {
+            const int ls = prof_begin(st, (double)T * W * 16.0, T, W, 0);
+            const int lrc = launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
+                                                 group_rows > 0 ? g1w.group_stride : 0);
+            prof_end(ls, st, 13);
+            TRY(lrc);
+        }
     }
     return RLCF_OK;
 }

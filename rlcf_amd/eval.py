@@ -41,7 +41,15 @@ def run(args) -> dict:
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1
+    use_dist = world > 1 or bool(os.environ.get("RLCF_FORCE_DIST"))     # RLCF_FORCE_DIST: the RCCL path with one rank (tests)
+    if world > 1:                   # one process per GPU: keep each rank on its own slice of the host cores
+        ncpu = os.cpu_count() or 1
+        per = max(1, ncpu // world)
+        torch.set_num_threads(min(per, 16))
+        try:
+            os.sched_setaffinity(0, set(range(local * per, (local + 1) * per)))
+        except (AttributeError, OSError):
+            pass
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group(args.dist_backend, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
@@ -90,6 +98,9 @@ def run(args) -> dict:
         dt = float(t.item())
     out = {"images": n, "acc1": round(acc1, 3), "acc5": round(acc5, 3), "n_gpus": world, "seconds": dt, "images_per_s": n / dt,
            "predictions_sha256": hashlib.sha256(all_pred.numpy().tobytes()).hexdigest(), "top5": all_pred.tolist(),
+           "distributed": ({"backend": args.dist_backend, "ranks": dist.get_world_size(),
+                            "collectives": "all_reduce(SUM) of 3 hit counters, all_gather of the top-5 block, all_reduce(MAX) of the time"}
+                           if use_dist else None),
            "config": {"arch": args.arch, "reward_arch": args.reward_arch, "views": args.views, "classes": args.classes,
                       "tta_steps": args.tta_steps, "images_per_pass": args.images_per_pass, "precision": args.precision,
                       "sharding": f"contiguous blocks over {world} rank(s), no data-path collective"}}

@@ -296,5 +296,48 @@ def test_batch_pipeline_equals_single_stream(L, dev, geo, B, N, C, p, prec, part
             res.append(torch.load(tf.name))
     for (t_a, f_a), (t_b, f_b) in zip(*res):
         assert torch.equal(t_a[:, 0], t_b[:, 0])
-        tol = 5e-4 if "X3" in prec else 2e-2
+        # Adam's first step is -lr * sign(g): a gradient element at round-off level flips with the GEMM form and moves one prompt
+        # element by 2 lr, i.e. a sample's logits by ~2e-3 — the bar the reference fixtures use as well
+        tol = 5e-3 if "X3" in prec else 5e-2
         torch.testing.assert_close(f_a, f_b, atol=tol, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------ the RCCL code path, executed with one rank
+def _run_json(cmd, env=None, timeout=900):
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def _torchrun(port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+
+
+def test_bench_runs_the_rccl_path_with_one_rank(L, dev):
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run, one rank per GPU) with the RCCL backend and ONE rank:
+    init_process_group("nccl", device_id=...), both barriers and the CUDA-tensor all_reduce(MAX) of the elapsed time execute; the line
+    reports the rank count RCCL saw and is otherwise the line of the plain single-process run (same first prediction, same executed
+    FLOPs, same configuration)."""
+    small = ["--steps", "4", "--warmup", "2", "--batch", "2", "--classes", "50", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-f16-line"]
+    plain = _run_json([sys.executable, "bench.py"] + small)
+    rccl = _run_json(_torchrun(29541) + ["bench.py", "--gpus", "1", "--dist-backend", "nccl"] + small, env={"RLCF_FORCE_DIST": "1"})
+    assert rccl["distributed"]["rccl_ranks"] == 1 and "RCCL" in rccl["distributed"]["backend"]
+    assert "distributed" not in plain
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "top1_first", "config"):
+        assert rccl[k] == plain[k], k
+    assert abs(rccl["flops_exec_per_image"] - plain["flops_exec_per_image"]) <= 1e-6 * plain["flops_exec_per_image"]
+    assert rccl["value"] > 0 and rccl["roofline"]["frac"] > 0
+
+
+def test_eval_driver_runs_the_rccl_path_with_one_rank(L, dev):
+    """python -m rlcf_amd.eval under torch.distributed.run with backend nccl and one rank: the end-of-dataset all_reduce of the hit
+    counters, the all_gather of the int64 top-5 block and the all_reduce(MAX) of the time run on RCCL with CUDA tensors; predictions are
+    those of the plain run."""
+    args = ["--total-images", "6", "--images-per-pass", "3", "--views", "8", "--classes", "40", "--selection-p", "0.5"]
+    plain = _run_json([sys.executable, "-m", "rlcf_amd.eval"] + args)
+    rccl = _run_json(_torchrun(29542) + ["-m", "rlcf_amd.eval", "--gpus", "1", "--dist-backend", "nccl"] + args, env={"RLCF_FORCE_DIST": "1"})
+    assert rccl["distributed"] == {"backend": "nccl", "ranks": 1, "collectives": rccl["distributed"]["collectives"]}
+    assert plain["distributed"] is None
+    assert rccl["predictions_sha256"] == plain["predictions_sha256"] and rccl["top5"] == plain["top5"]
+    assert (rccl["images"], rccl["acc1"], rccl["acc5"]) == (plain["images"], plain["acc1"], plain["acc5"])
