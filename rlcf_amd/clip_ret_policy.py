@@ -185,10 +185,9 @@ class CLIPRewards(_cr.CLIPRewards):
     def CLIPScore(self, text_index=None, images_index=None, pairwise=True):
         t = self.class_features[text_index.long()] if text_index is not None else self.class_features.repeat_interleave(self.sample_k, dim=0)
         i = self.image_features[images_index.long()] if images_index is not None else self.image_features.repeat_interleave(self.sample_k, dim=0)
-        sim = _cr._gemm_nt(t, i, self.clipscore_weight)
-        if not pairwise:
-            sim = torch.diagonal(sim)
-        return sim.clamp_min(0).squeeze()
+        if not pairwise:               # row-wise scores (retrieval/clip_reward.py:124-126): n*K dot products, not an [nK, nK] matrix and its diagonal
+            return (self.clipscore_weight * (t * i).sum(-1)).clamp_min(0).squeeze()
+        return _cr._gemm_nt(t, i, self.clipscore_weight).clamp_min(0).squeeze()
 
 
 class CLIPRewardsMultiple(_cr.CLIPRewardsMultiple):

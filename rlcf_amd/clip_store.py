@@ -19,6 +19,7 @@ from .synth import GEOMETRIES, ClipGeometry
 
 _CHECKPOINTS: Dict[str, Tuple[ClipGeometry, Dict[str, torch.Tensor]]] = {}
 _TOKENIZER: Optional[Callable] = None
+_TOKENIZER_TRUNCATES = True
 CLIP_ROOT = os.environ.get("RLCF_CLIP_ROOT", "")
 
 
@@ -70,8 +71,17 @@ class ClipCheckpoint:
 
 
 def set_tokenizer(fn: Callable) -> None:
-    """fn(texts: str | list[str], context_length=77) -> int64 [n, context_length] (clip.tokenize contract)."""
-    global _TOKENIZER
+    """fn(texts: str | list[str], context_length=77[, truncate=False]) -> int64 [n, context_length] (clip.tokenize contract).  Whether
+    the tokenizer takes `truncate` is decided HERE, once, from its signature — not by catching TypeError round the call, which would
+    also swallow a TypeError raised inside a three-argument tokenizer and silently repeat the call without truncation."""
+    global _TOKENIZER, _TOKENIZER_TRUNCATES
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters
+        _TOKENIZER_TRUNCATES = ("truncate" in ps or len([p for p in ps.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]) >= 3
+                                or any(p.kind == p.VAR_POSITIONAL for p in ps.values()))
+    except (TypeError, ValueError):        # builtins without a signature: the clip.tokenize contract has three arguments
+        _TOKENIZER_TRUNCATES = True
     _TOKENIZER = fn
 
 
@@ -79,10 +89,9 @@ def tokenize(texts: Union[str, List[str]], context_length: int = 77, truncate: b
     if _TOKENIZER is None:
         raise RuntimeError("no tokenizer installed: call rlcf_amd.clip_store.set_tokenizer(fn) with a CLIP BPE tokenizer "
                            "(or a SyntheticBank.tokenize for seeded runs)")
-    try:
+    if _TOKENIZER_TRUNCATES:
         return _TOKENIZER(texts, context_length, truncate)
-    except TypeError:                      # a two-argument tokenizer: over-long texts raise in it, as with truncate=False
-        return _TOKENIZER(texts, context_length)
+    return _TOKENIZER(texts, context_length)       # a two-argument tokenizer: over-long texts raise in it, as with truncate=False
 
 
 class SyntheticBank:

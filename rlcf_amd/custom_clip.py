@@ -71,9 +71,15 @@ class PromptLearner(nn.Module):
         prompts = [self.prompt_prefix + " " + name + "." for name in classnames]
         self.tokenized_prompts = clip_store.tokenize(prompts).to(self.device)      # custom_clip.py:154
         self.n_cls, self.classnames = len(classnames), classnames
-        # name_lens (custom_clip.py:127): tokens between the context words and the final '.', read off the tokenised prompt
+        # name_lens (custom_clip.py:127): tokens between the context words and the final '.', read off the tokenised prompt ...
         eot = self.tokenized_prompts.argmax(dim=-1)
         self.name_lens = [int(e) - 1 - self.n_ctx - 1 for e in eot]
+        # ... and, when the installed tokenizer is a BPE with an `encode` (rlcf_amd.bpe.ClipBPE, the reference's SimpleTokenizer), as the
+        # reference counts them: len(_tokenizer.encode(name)).  The two differ when BPE merges the trailing '.' into the name ("St.") or
+        # a prompt is truncated at 77 tokens; the bare-name count is what places the class rows in the 'front' / 'middle' layouts.
+        enc = getattr(getattr(clip_store._TOKENIZER, "__self__", None), "encode", None)
+        if callable(enc):
+            self.name_lens = [len(enc(name)) for name in classnames]
         self._publish_bank()
 
     def _arrangement(self):

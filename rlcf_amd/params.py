@@ -1,6 +1,12 @@
-"""Flags of the RLCF classification entry points, same names and defaults as the reference
-(TPT/params.py:13-98); only the flags read on the hot path or by its harness are kept."""
+"""Flags of the RLCF classification entry points: same names, types and defaults as the reference (TPT/params.py:13-98), so the command
+lines of TPT/scripts/*.sh parse identically.  Flags the HIP path has no use for (--workers, --dataset_mode, --cocoop, --corruption,
+--level, --kd_loss, --confidence_gap*) are accepted and ignored; --hard_aug 1 reaches the view pipeline, which refuses it."""
 import argparse
+
+
+def none_or_str(value):
+    """TPT/params.py:8-11"""
+    return None if value == "None" else value
 
 
 def get_args(argv=None):
@@ -9,7 +15,7 @@ def get_args(argv=None):
     p.add_argument("--test_sets", type=str, default="A/R/V/K/I")
     p.add_argument("-a", "--arch", default="RN50")
     p.add_argument("--resolution", default=224, type=int)
-    p.add_argument("-b", "--batch-size", "--batch_size", dest="batch_size", default=64, type=int)
+    p.add_argument("-b", "--batch-size", "--batch_size", dest="batch_size", default=64, type=int)     # (the scripts write -b)
     p.add_argument("--lr", "--learning-rate", default=5e-3, type=float, dest="lr")
     p.add_argument("--weight_decay", default=5e-4, type=float)
     p.add_argument("-p", "--print-freq", "--print_freq", dest="print_freq", default=500, type=int)
@@ -19,9 +25,18 @@ def get_args(argv=None):
     p.add_argument("--tta_steps", default=1, type=int)
     p.add_argument("--n_ctx", default=4, type=int)
     p.add_argument("--ctx_init", default=None, type=str)
-    p.add_argument("--load", default=None, type=str)
+    p.add_argument("--cocoop", action="store_true", default=False, help="accepted for script compatibility (CoCoOp initialisation is not on the RLCF path)")
+    p.add_argument("--load", default=None, type=none_or_str)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--output", type=str, default="output")
+    p.add_argument("--output", type=str, default="exp_01")
+    p.add_argument("--dataset_mode", type=str, default="test", help="accepted (the HIP path ships a synthetic stream only)")
+    p.add_argument("--workers", default=8, type=int, help="accepted (views are generated on the device: no loader workers)")
+    p.add_argument("--hard_aug", type=int, default=0, help="BYOL-style recipe of the view pipeline (datautils.py:77-87): not built, 1 raises there")
+    p.add_argument("--confidence_gap", type=int, default=0, help="experimental in the reference, never read by its loop: accepted, ignored")
+    p.add_argument("--confidence_gap_w", type=float, default=0.5)
+    p.add_argument("--corruption", type=str, default="defocus_blur")
+    p.add_argument("--level", type=str, default="5")
+    p.add_argument("--kd_loss", type=str, default="KD", choices=["KD", "DKD", "ATKD"])
     p.add_argument("--sample_k", type=int, default=5)
     p.add_argument("--multiple_reward_models", type=int, default=0)
     p.add_argument("--reward_arch", type=str, default="ViT-L/14")
@@ -36,7 +51,8 @@ def get_args(argv=None):
     p.add_argument("--update_w", type=float, default=1.0)
     p.add_argument("--tta_momentum", type=float, default=0.9999)
     p.add_argument("--tune_norm", type=int, default=0)
-    p.add_argument("--augmix", action="store_true", default=False, help="AugMix op chains in the view pipeline (fine-grained sets)")
+    p.add_argument("--augmix", type=int, default=1,
+                   help="AugMix op chains in the view pipeline; as in the reference (tpt_cls_rl.py:150) only for the fine-grained sets (len(set_id) > 1)")
     p.add_argument("--prior_strength", type=int, default=-1, help="BN-statistics adaptation of a ResNet student (not built: raises)")
     p.add_argument("--clip_root", type=str, default="", help="directory of OpenAI-layout state dicts (<arch>.pt)")
     return p.parse_args(argv)

@@ -105,3 +105,44 @@ def test_tokenize_forwards_truncate():
         assert int(clip_store.tokenize("x", truncate=True).sum()) == 77       # two-argument tokenizers still work
     finally:
         clip_store._TOKENIZER = old
+
+
+def test_params_mirror_has_every_reference_flag_with_its_default():
+    """rlcf_amd.params.get_args against the reference's parser (TPT/params.py:13-98), read in the build container only: every option
+    string of the reference parses here, with the same default (so the command lines of TPT/scripts/*.sh parse identically)."""
+    import argparse
+    import importlib.util
+    import os
+    import sys
+    import pytest
+    ref = "/root/reference/TPT/params.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    captured = {}
+    real_parse = argparse.ArgumentParser.parse_args
+
+    def fake_parse(self, args=None, namespace=None):
+        captured["parser"] = self
+        return real_parse(self, ["/data", "--output", "/tmp/rlcf_params_test"], namespace)
+    spec = importlib.util.spec_from_file_location("ref_params", ref)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    argparse.ArgumentParser.parse_args = fake_parse
+    try:
+        spec.loader.exec_module(mod)
+        mod.save_hp_to_json = lambda *a, **k: None
+        ref_ns = mod.get_args()
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    from rlcf_amd.params import get_args
+    mine = get_args(["/data", "--output", "/tmp/rlcf_params_test"])
+    for act in captured["parser"]._actions:
+        if act.dest in ("help",):
+            continue
+        assert hasattr(mine, act.dest), f"flag {act.option_strings or act.dest} of the reference is missing"
+        assert getattr(mine, act.dest) == getattr(ref_ns, act.dest), (act.dest, getattr(mine, act.dest), getattr(ref_ns, act.dest))
+    # the command line of scripts/rlcf-prompt.sh
+    a = get_args(["/data", "--test_sets", "A", "-a", "ViT-B/16", "-b", "64", "--gpu", "0", "--tpt", "--ctx_init", "a_photo_of_a", "--lr", "7e-3",
+                  "--tta_steps", "3", "--sample_k", "3", "--reward_arch", "ViT-L/14", "--reward_amplify", "0", "--reward_process", "1",
+                  "--process_batch", "0", "--weight_decay", "5e-4", "--selection_p", "0.1", "--output", "/tmp/x", "--multiple_reward_models", "0"])
+    assert (a.arch, a.batch_size, a.tta_steps, a.sample_k, a.augmix, a.hard_aug) == ("ViT-B/16", 64, 3, 3, 1, 0)
