@@ -293,6 +293,24 @@ int rlcf_tta_sample(rlcf_engine*, const float* views, int N, const rlcf_tta_args
 int rlcf_tta_sample_ln(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
                        rlcf_stream stream);
 int rlcf_engine_ln_param_count(rlcf_engine*);
+/* A ModifiedResNet student (arch RN50 .. RN50x64) has BatchNorms where the ViT has LayerNorms: CLIPCLS_TTA(only_norm=True) tunes the
+ * weight / bias of every BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485; downsample.1 stays frozen) and
+ * rlcf_tta_sample_ln / rlcf_tta_batch_ln / rlcf_engine_{ln_param_count,get_ln_params,set_ln_params,momentum_update} serve them
+ * unchanged: layout [bn.weight, bn.bias] per layer in named_parameters order (visual.bn1..3, then layerS.B.bn1..3).  The tuning
+ * passes AND the final clean-view inference run the BatchNorms on batch statistics (the reference's CLIPCLS_TTA.train() keeps the
+ * norm layers in train mode whatever the mode, custom_clip.py:487-497).
+ * prior_strength (TPT/params.py:91, tune_cls_rl.py:35-44,73-76): < 0 (the default) = nn.BatchNorm2d train mode (running statistics
+ * updated with momentum 0.1); >= 0 = `_modified_bn_forward`, prior = s / (s + 1) blends running and (unbiased) batch statistics. */
+int rlcf_engine_set_bn_prior_strength(rlcf_engine*, int prior_strength);
+/* running statistics [running_mean, running_var] per BatchNorm in execution order (visual.bn1..3, then per Bottleneck bn1, bn2, bn3,
+ * downsample.1): as the last rlcf_tta_sample_ln left them (what its final inference saw), or the checkpoint's (pristine). */
+/* L2-normalised image features [n, embed_dim] of the ResNet student with its BatchNorms in the form the tuning passes use (batch
+ * statistics over these n images / the prior blend) and the LIVE tunable parameters (rlcf_engine_set_ln_params): what model(image)
+ * computes after tune_cls_rl.py:218's model.eval(), which leaves CLIPCLS_TTA's norm layers in train mode (custom_clip.py:487-497).
+ * In train mode it updates the running statistics like any other pass. */
+int rlcf_engine_encode_image_bn(rlcf_engine*, const float* images, int n, float* out, rlcf_stream stream);
+int rlcf_engine_bn_stats_count(rlcf_engine*);
+int rlcf_engine_get_bn_stats(rlcf_engine*, float* out, int pristine, rlcf_stream stream);
 /* copy the student's visual LayerNorm parameters out of / into the engine (layout above); `pristine` selects the
  * reset state (initial_state_dict, custom_clip.py:395-399) instead of the live one. */
 int rlcf_engine_get_ln_params(rlcf_engine*, float* out, int pristine, rlcf_stream stream);

@@ -81,12 +81,54 @@ def transformer(x: torch.Tensor, sd: SD, prefix: str, mask: Optional[torch.Tenso
     return x
 
 
+class BNMode:
+    """How the BatchNorm2d layers of a ModifiedResNet normalise (a ResNet STUDENT whose norm layers are tuned,
+    TPT/tune_cls_rl.py:35-44,73-76 + CLIPCLS_TTA.train, custom_clip.py:487-497):
+      mode 'eval'   running statistics (inference; the only mode of reward models and of a frozen student);
+      mode 'train'  torch's train-mode BatchNorm (`--prior_strength` < 0, the parser default): batch statistics over (N, H, W) with
+                    the gradient flowing through them, running statistics updated in place with momentum 0.1 (unbiased variance);
+      mode 'prior'  `_modified_bn_forward` (`--prior_strength` s >= 0, prior = s / (s + 1)): batch mean and UNBIASED batch variance
+                    are blended into the running statistics, prior * running + (1 - prior) * batch, as detached constants; the
+                    module's running statistics stay untouched.
+    `stats` collects {bn name: (running_mean, running_var)} as they stand after the pass (mode 'train' only changes them)."""
+
+    def __init__(self, mode: str = "eval", prior: float = 0.0):
+        self.mode, self.prior, self.stats = mode, prior, {}
+
+
+_BN = BNMode()
+
+
+def set_bn_mode(m: Optional["BNMode"]) -> "BNMode":
+    """install a BatchNorm mode for the following encode_image_resnet calls; returns the previous one"""
+    global _BN
+    prev, _BN = _BN, (m if m is not None else BNMode())
+    return prev
+
+
+def _batch_norm(sd: SD, x: torch.Tensor, bn: str) -> torch.Tensor:
+    rm, rv, w, b = sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"]
+    rm, rv = _BN.stats.get(bn, (rm, rv))
+    if _BN.mode == "train":                                   # nn.BatchNorm2d.forward in training mode, momentum 0.1
+        rm, rv = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5)
+        _BN.stats[bn] = (rm, rv)
+        return y
+    if _BN.mode == "prior":                                   # tune_cls_rl.py:35-44
+        est_mean, est_var = torch.zeros_like(rm), torch.ones_like(rv)
+        F.batch_norm(x, est_mean, est_var, None, None, True, 1.0, 1e-5)
+        rm2 = _BN.prior * rm + (1 - _BN.prior) * est_mean
+        rv2 = _BN.prior * rv + (1 - _BN.prior) * est_var
+        return F.batch_norm(x, rm2, rv2, w, b, False, 0, 1e-5)
+    return F.batch_norm(x, rm, rv, w, b, False, 0.0, 1e-5)
+
+
 def _conv_bn(sd: SD, x: torch.Tensor, conv: str, bn: str, stride: int = 1, relu: bool = True) -> torch.Tensor:
-    """bias-free Conv2d (kernel 1 or 3, padding k//2) followed by eval-mode BatchNorm2d (running statistics, eps 1e-5) and
-    an optional ReLU: the conv/bn/relu triples of TPT/clip/model.py:18-31,108-116."""
+    """bias-free Conv2d (kernel 1 or 3, padding k//2) followed by BatchNorm2d (eps 1e-5; eval mode = running statistics unless a
+    BNMode is installed) and an optional ReLU: the conv/bn/relu triples of TPT/clip/model.py:18-31,108-116."""
     w = sd[conv + ".weight"]
     x = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
-    x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, 1e-5)
+    x = _batch_norm(sd, x, bn)
     return F.relu(x) if relu else x
 
 

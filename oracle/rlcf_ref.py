@@ -209,6 +209,39 @@ def visual_ln_keys(sd):
     return keys + ["visual.ln_post.weight", "visual.ln_post.bias"]
 
 
+def is_resnet_sd(sd) -> bool:
+    return "visual.layer1.0.conv1.weight" in sd
+
+
+def visual_bn_keys(sd):
+    """CLIPCLS_TTA.parameters() with only_norm for a ModifiedResNet (custom_clip.py:481-485): visual parameters whose name contains
+    'bn', in named_parameters() order (stem bn1..3, then bn1, bn2, bn3 of every Bottleneck).  `downsample.1` — a BatchNorm too — is
+    MISSED by the substring test and stays frozen, as in the reference."""
+    keys = []
+    for i in (1, 2, 3):
+        keys += [f"visual.bn{i}.weight", f"visual.bn{i}.bias"]
+    for li in (1, 2, 3, 4):
+        nb = len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")})
+        for b in range(nb):
+            for i in (1, 2, 3):
+                keys += [f"visual.layer{li}.{b}.bn{i}.weight", f"visual.layer{li}.{b}.bn{i}.bias"]
+    return keys
+
+
+def visual_bn_stat_keys(sd):
+    """every BatchNorm2d of the image tower in execution order (stem bn1..3; per Bottleneck bn1, bn2, bn3 and, where the block has
+    one, downsample.1): the layers whose running statistics a train-mode pass updates"""
+    names = [f"visual.bn{i}" for i in (1, 2, 3)]
+    for li in (1, 2, 3, 4):
+        nb = len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")})
+        for b in range(nb):
+            p = f"visual.layer{li}.{b}."
+            names += [p + "bn1", p + "bn2", p + "bn3"]
+            if (p + "downsample.1.running_mean") in sd:
+                names.append(p + "downsample.1")
+    return names
+
+
 def visual_param_keys(sd):
     """CLIPCLS_TTA.parameters() with only_norm=False (custom_clip.py:477-479): every parameter of clip_model.visual, in
     named_parameters() order of VisionTransformer (model.py:206-221: direct parameters first, then conv1, ln_pre, the
@@ -233,18 +266,26 @@ def momentum_update(mom: torch.Tensor, cur: torch.Tensor, clip: torch.Tensor, mo
 
 def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tensor, hp: TTAHyper,
                   reward_cls: Optional[torch.Tensor] = None, ln_init: Optional[torch.Tensor] = None,
-                  only_norm: bool = True) -> Dict[str, torch.Tensor]:
+                  only_norm: bool = True, prior_strength: int = -1) -> Dict[str, torch.Tensor]:
     """One iteration of the harness loop TPT/tune_cls_rl.py:183-256 with model = CLIPCLS_TTA(only_visual=True,
     only_norm=...): reset visual state -> test_time_tuning (tpt_cls_rl.py:47-79; the image encoder runs WITH grad,
     custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference.
     only_norm=False (the default of `--tune_norm`, params.py:73, what scripts/rlcf-tune.sh runs) tunes every visual parameter;
-    `ln_grad` / `ln_after` / `ln_init` then hold all of them, concatenated in visual_param_keys order."""
+    `ln_grad` / `ln_after` / `ln_init` then hold all of them, concatenated in visual_param_keys order.
+    A ModifiedResNet student (only_norm): the tuned tensors are the BatchNorm weights / biases of visual_bn_keys; the tuning passes run
+    the BatchNorm layers in train mode (prior_strength < 0, the parser default: batch statistics, running statistics updated in place
+    and USED by the final clean-view inference) or through `_modified_bn_forward` (prior_strength >= 0, tune_cls_rl.py:35-44,73-76);
+    `bn_stats_after` = the running statistics (mean | var per layer, visual_bn_stat_keys order) the final inference used."""
     out: Dict[str, torch.Tensor] = {}
+    rn = is_resnet_sd(student_sd)
+    if rn and not only_norm:
+        raise NotImplementedError("ModifiedResNet student: only the norm-layer tuning (only_norm) is restated")
     if reward_cls is None:
         reward_cls = reward_class_features(reward_sd, tokens)
     with torch.no_grad():
         cls_feat = C.l2_normalize(C.encode_text(student_sd, tokens))            # get_class_features, custom_clip.py:405-409
-    keys = visual_ln_keys(student_sd) if only_norm else visual_param_keys(student_sd)
+    keys = (visual_bn_keys(student_sd) if rn else visual_ln_keys(student_sd)) if only_norm else visual_param_keys(student_sd)
+    bn_train = C.BNMode("prior", prior_strength / (prior_strength + 1.0)) if prior_strength >= 0 else C.BNMode("train")
     params = {k: student_sd[k].clone() for k in keys}                           # model.reset(): pristine visual state
     if ln_init is not None:                                                     # ... or the momentum-updated initial_state_dict
         off = 0
@@ -256,10 +297,20 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
     v2 = {k: torch.zeros_like(v) for k, v in params.items()}
     scale = student_sd["logit_scale"].exp()
 
-    def logits_of(x, prm):
+    def logits_of(x, prm, train=True):
         sd = dict(student_sd)
         sd.update(prm)
-        return scale * C.l2_normalize(C.encode_image(sd, x)) @ cls_feat.t()
+        if not rn:
+            return scale * C.l2_normalize(C.encode_image(sd, x)) @ cls_feat.t()
+        # model.train() around test_time_tuning, model.eval() for the final inference (tune_cls_rl.py:216-218); the running statistics
+        # a train-mode pass leaves behind carry over to the following passes
+        mode = bn_train if train else C.BNMode("eval")
+        mode.stats = bn_train.stats
+        prev = C.set_bn_mode(mode)
+        try:
+            return scale * C.l2_normalize(C.encode_image(sd, x)) @ cls_feat.t()
+        finally:
+            C.set_bn_mode(prev)
 
     selected = None
     for j in range(hp.tta_steps):
@@ -290,7 +341,14 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
             for k, g in zip(keys, grads):
                 params[k], m[k], v2[k] = adamw_step(prm[k].detach(), g, m[k], v2[k], j + 1, hp)
     with torch.no_grad():
-        final = logits_of(views[:1], params)
+        # QUIRK of the reference, reproduced: CLIPCLS_TTA.train(mode) with only_norm (custom_clip.py:487-497) calls m.train() on every
+        # LayerNorm / BatchNorm2d whatever `mode` is, so model.eval() leaves the BatchNorm layers of a ResNet student in TRAINING
+        # mode: the final clean-view inference normalises with the statistics of that ONE image (train mode; blended into the running
+        # statistics under `--prior_strength`) and, in train mode, updates the running statistics once more.
+        final = logits_of(views[:1], params, train=only_norm)
+    if rn:
+        st = [bn_train.stats.get(b, (student_sd[b + ".running_mean"], student_sd[b + ".running_var"])) for b in visual_bn_stat_keys(student_sd)]
+        out["bn_stats_after"] = torch.cat([torch.cat([a.reshape(-1), b.reshape(-1)]) for a, b in st])
     out["ln_after"] = torch.cat([params[k].reshape(-1) for k in keys])
     out["final_logits"] = final
     out["top5"] = torch.topk(final, min(5, final.shape[1]), dim=-1).indices[0]

@@ -466,7 +466,38 @@ int rlcf_engine_momentum_update_visual(rlcf_engine* e, const float* current, dou
     }
     return RLCF_OK;
 }
-int rlcf_engine_ln_param_count(rlcf_engine* e) { return e ? e->ln_count : 0; }
+int rlcf_engine_ln_param_count(rlcf_engine* e) {
+    if (!e) return 0;
+    // a ModifiedResNet student's norm layers are BatchNorms: their train-form state is built on first use
+    ClipModel& s = e->model[RLCF_STUDENT];
+    if (s.finalized && is_resnet(s.cfg) && !s.rn.bn_enabled && engine_bn_enable(e, nullptr) != RLCF_OK) return 0;
+    return e->ln_count;
+}
+int rlcf_engine_set_bn_prior_strength(rlcf_engine* e, int prior_strength) {
+    RLCF_ARG_CHECK(e);
+    e->bn_prior_strength = prior_strength < 0 ? -1 : prior_strength;
+    return RLCF_OK;
+}
+int rlcf_engine_encode_image_bn(rlcf_engine* e, const float* images, int n, float* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && images && out && n > 0);
+    ClipModel& s = e->model[RLCF_STUDENT];
+    if (!s.finalized || !is_resnet(s.cfg)) { rlcf_set_error("rlcf_engine_encode_image_bn needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
+    const int rc = engine_bn_enable(e, (hipStream_t)stream);
+    return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, (hipStream_t)stream);
+}
+int rlcf_engine_bn_stats_count(rlcf_engine* e) {
+    if (!e || rlcf_engine_ln_param_count(e) <= 0) return 0;
+    ClipModel& s = e->model[RLCF_STUDENT];
+    return is_resnet(s.cfg) ? s.rn.n_stats : 0;
+}
+int rlcf_engine_get_bn_stats(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && out);
+    const int n = rlcf_engine_bn_stats_count(e);
+    if (n <= 0) { rlcf_set_error("the student has no BatchNorm statistics (VisionTransformer, or not finalized)"); return RLCF_ERR_STATE; }
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->bn_stats_init.p : e->bn_stats.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return RLCF_OK;
+}
 int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && out && e->ln_count > 0);
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->ln_init.p : e->ln_params.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,

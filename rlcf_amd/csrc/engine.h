@@ -54,8 +54,24 @@ struct Tower {                       // workspace of one transformer pass over T
 
 struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1, Kp = 0; };   // conv with folded BatchNorm
 struct BottleW { ConvW c1, c2, c3, down; bool has_down = false; int stride = 1; };                          // model.py:10-55
+// train-form view of one Conv2d(bias=False) + BatchNorm2d pair of a ModifiedResNet STUDENT whose norm layers are tuned
+// (CLIPCLS_TTA(only_norm=True) on a ResNet, TPT/clip/custom_clip.py:481-497; BatchNorm forward of TPT/tune_cls_rl.py:35-44,73-76)
+struct BnUnit {
+    ConvW raw;                       // the UNFOLDED weight in the GEMM layout [cout, Kp] ((ky,kx,ci) order, zero padded); raw.b = nullptr
+    const float* wT = nullptr;       // operand of dX = dZ . W: [cin, cout] (1x1) or [cin, KpT] with the taps flipped (3x3); nullptr: no dX (stem conv1)
+    int KpT = 0;
+    int pofs = -1;                   // offset of (gamma | beta) in the tunable vector (e->ln_params); -1: frozen (downsample.1)
+    int sofs = 0;                    // offset of (running_mean | running_var) in the statistics vector (e->bn_stats)
+    const float *gamma0 = nullptr, *beta0 = nullptr;     // checkpoint tensors (what a frozen unit reads)
+};
 struct ResNetW {                     // ModifiedResNet (TPT/clip/model.py:94-154), inference form
     bool present = false;
+    // train form (engine_bn_enable): stem conv1..3, then per Bottleneck conv1, conv2, conv3 (, downsample) in execution order
+    bool bn_enabled = false;
+    std::vector<BnUnit> units;
+    std::vector<int> block_unit;     // index of a block's first unit
+    const float *q_wT = nullptr, *kv_wT = nullptr, *c_wT = nullptr;      // transposes for the attention pool's backward
+    int n_stats = 0;                 // floats of the statistics vector
     ConvW stem[3];
     std::vector<BottleW> blocks;
     const float *pos = nullptr, *q_w = nullptr, *q_b = nullptr, *kv_w = nullptr, *kv_b = nullptr, *c_w = nullptr, *c_b = nullptr;
@@ -162,6 +178,14 @@ struct rlcf_engine {
     DevBuf gemm_ws2;
     // ... its own copies of the image-tower scratch (engine_encode_image on the side stream: the reward models' pass of one part of a
     // sample batch runs beside the student tower of the next part, tta_batch_pipelined) ...
+    // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode
+    // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
+    DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog;
+    int bn_prior_strength = -1;
+    std::vector<float*> bn_z, bn_y;  // per unit: pre-BatchNorm GEMM output and the unit's output, inside bn_saved
+    std::vector<float*> bn_ms;       // per unit: (mean | rstd) used by the pass, inside bn_scratch
+    int bn_saved_n = 0;
+    float *bn_q = nullptr, *bn_kv = nullptr;     // attention pool: projected query [n, E] and keys|values [n*T, 2E] of the saved pass
     struct ImgSide { DevBuf patch_out, patches, cls_rows, cls_ln, feat_raw, cls_a2, cls_h2, cls_f2, resized; Tower vt; } side_img;
     hipEvent_t ev_part[8] = {};      // "student tower of part k done" (created on first use)
     DevBuf a_hi2;                    // ... and its own A-operand split buffer: the main stream's text passes re-split into a_hi (M > 512:
@@ -198,6 +222,11 @@ static inline bool prec_single(const rlcf_engine* e) { return e->precision == RL
 // resnet.hip
 int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
 int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
+// norm-layer tuning of a ResNet student (resnet.hip): build the train-form weights / flat buffers once; one tuning sample
+int engine_bn_enable(rlcf_engine* e, hipStream_t st);
+int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
+int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st);
+int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
 // engine.hip services used by resnet.hip
 int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
                 int ldc, int M, int N, int K, int epi, hipStream_t st, const float* amax_in = nullptr, float* amax_out = nullptr);

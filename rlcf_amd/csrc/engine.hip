@@ -400,7 +400,7 @@ int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
     if (e->vw_count) return RLCF_OK;
     ClipModel& m = e->model[RLCF_STUDENT];
     if (!m.finalized) { rlcf_set_error("student model not finalized"); return RLCF_ERR_STATE; }
-    if (is_resnet(m.cfg)) { rlcf_set_error("image-encoder tuning needs a VisionTransformer student (ModifiedResNet: not built)"); return RLCF_ERR_STATE; }
+    if (is_resnet(m.cfg)) { rlcf_set_error("every-parameter image-encoder tuning needs a VisionTransformer student; a ModifiedResNet student tunes its BatchNorm weights / biases (rlcf_tta_sample_ln)"); return RLCF_ERR_STATE; }
     if (prec_single(e)) { rlcf_set_error("encoder tuning runs in RLCF_PREC_F32 / RLCF_PREC_F16X3 (RLCF_PREC_F16 is the prompt path's performance mode)"); return RLCF_ERR_STATE; }
     const rlcf_clip_cfg& c = m.cfg;
     const size_t Wv = c.vision_width, D = c.embed_dim, K = (size_t)3 * c.vision_patch_size * c.vision_patch_size, W2 = Wv * Wv;
@@ -1628,11 +1628,11 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
     ClipModel& s = e->model[RLCF_STUDENT];
     if (e->C <= 0 || e->image_bank || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
     RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
-    if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(s.tokens <= 320);
+    const bool rn = is_resnet(s.cfg);         // BatchNorm tuning: the batch statistics couple one sample's views, samples run one by one
+    RLCF_ARG_CHECK(rn || s.tokens <= 320);
     const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const int n_sel = n_selected(a, N), Bmax = e->max_views / N;
-    const bool fused = Bmax >= 2 && a->tta_steps >= 1 && !a->skip_final && n_sel > 0;
+    const bool fused = !rn && Bmax >= 2 && a->tta_steps >= 1 && !a->skip_final && n_sel > 0;
     double flops = 0.0;
     int i = 0;
     while (i < count) {
@@ -1649,6 +1649,86 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
         i += B;
     }
     e->last_flops = flops / count;
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm tuning of a ModifiedResNet student
+// One iteration of tune_cls_rl.py:183-256 with CLIPCLS_TTA(arch=RN*, only_norm=True): the tuned tensors are the weight / bias of every
+// BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485: the downsample BatchNorms stay frozen).  The tuning passes run the
+// BatchNorms on BATCH statistics (nn.BatchNorm2d in train mode, running statistics updated, or `_modified_bn_forward` under
+// --prior_strength >= 0, tune_cls_rl.py:35-44), step 0 over all N views (the selection reads its logits; the statistics couple the
+// views, so the backward covers all N with zero logit gradients outside the selection), later steps over the selected views.
+// CLIPCLS_TTA.train() (custom_clip.py:487-497) puts the norm layers in train mode whatever `mode` is, so the final clean-view
+// inference ALSO normalises with batch statistics (of that one image): reproduced.  The running statistics the sample leaves behind
+// stay in e->bn_stats (rlcf_engine_get_bn_stats) until the next sample resets them.
+int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+    ClipModel& s = e->model[RLCF_STUDENT];
+    TRY(engine_bn_enable(e, st));
+    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
+    const int n_sel = n_selected(a, N), n_e = n_sel * K;
+    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
+    const size_t nb = (size_t)e->ln_count * sizeof(float);
+    const rlcf_tta_out none{};
+    if (!out) out = &none;
+    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
+    TRY(e->dfeat.ensure((size_t)e->max_views * D * sizeof(float)));
+    TRY(e->bn_dlog.ensure((size_t)N * C * sizeof(float)));
+    e->last_flops = 0.0;
+    // model.reset(): visual.load_state_dict(initial_state_dict) restores parameters AND buffers (running statistics)
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats.p, e->bn_stats_init.p, (size_t)s.rn.n_stats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
+    const float* cls_feat = e->txt0.as<float>();
+    for (int j = 0; j < a->tta_steps; ++j) {
+        const int n = j == 0 ? N : n_sel;
+        TRY(rn_forward_train(e, s, j == 0 ? views : e->views_sel.as<float>(), n, e->ln_feat.as<float>(), st));
+        const float* dlog = e->dlogits.as<float>();
+        if (j == 0) {
+            TRY(engine_logits(e, e->ln_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
+            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
+            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
+            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
+            TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
+            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
+            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
+            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
+        } else {
+            TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
+        }
+        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
+                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
+                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
+        if (j == 0) {
+            RLCF_HIP_CHECK(hipMemsetAsync(e->bn_dlog.p, 0, (size_t)N * C * sizeof(float), st));
+            TRY(launch_scatter_rows(e->dlogits.as<float>(), e->sel_idx.as<int32_t>(), e->bn_dlog.as<float>(), n_sel, C, st));
+            dlog = e->bn_dlog.as<float>();
+        }
+        // d feat = scale * dlogits @ class_features (custom_clip.py:429-430), then the tower's backward down to the stem's first BatchNorm
+        TRY(launch_dimg(dlog, cls_feat, n, C, D, s.logit_scale_exp, e->dfeat.as<float>(), st));
+        TRY(rn_backward_bn(e, s, n, e->ln_feat.as<float>(), e->dfeat.as<float>(), e->ln_grad.as<float>(), st));
+        if (j == 0) {
+            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
+            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
+            COPY_OUT(out->loss, e->loss.p, sizeof(float));
+            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
+            COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
+        }
+        TRY(launch_grad_nonfinite(e->ln_grad.as<float>(), e->ln_count, 1, e->step_skip.as<int32_t>(), st));
+        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
+        TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
+                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->ln_count));
+    }
+    COPY_OUT(out->ln_after, e->ln_params.p, nb);
+    if (!a->skip_final) {
+        TRY(rn_forward_train(e, s, views, 1, e->img_feat.as<float>(), st));          // (train-form: see the header comment)
+        TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
+        TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
+        COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
+        COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
+    }
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
     return RLCF_OK;
 }
 
@@ -1674,7 +1754,10 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
     const int n_sel = n_selected(a, N), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
-    if (is_resnet(s.cfg)) { rlcf_set_error("LayerNorm tuning needs a VisionTransformer student (ModifiedResNet has BatchNorms: not built)"); return RLCF_ERR_STATE; }
+    if (is_resnet(s.cfg)) {
+        if (full) { rlcf_set_error("a ModifiedResNet student tunes its BatchNorm weights / biases (--tune_norm 1); every-parameter tuning of it is not built"); return RLCF_ERR_STATE; }
+        return engine_tta_sample_bn(e, views, N, a, out, st);
+    }
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
     const size_t nb = (size_t)e->ln_count * sizeof(float);

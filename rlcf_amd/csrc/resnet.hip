@@ -199,6 +199,7 @@ int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st) {
     ResNetW& r = m.rn;
     const int w = c.vision_width;
     r.blocks.clear();
+    r.bn_enabled = false; r.units.clear(); r.block_unit.clear();
     TRY(fold(e, m, "visual.conv1", "visual.bn1", w / 2, 3, 3, r.stem[0], st));
     TRY(fold(e, m, "visual.conv2", "visual.bn2", w / 2, w / 2, 3, r.stem[1], st));
     TRY(fold(e, m, "visual.conv3", "visual.bn3", w, w / 2, 3, r.stem[2], st));
@@ -367,5 +368,627 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
         TRY(engine_gemm(e, e->rn_att.as<float>(), E, r.c_w, E, r.c_b, nullptr, 0, e->feat_raw.as<float>(), D, n, D, E, RLCF_EPI_NONE, st));
         TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats + (size_t)i0 * D, nullptr, n, D, st));
     }
+    return RLCF_OK;
+}
+
+// ====================================================================================================================================
+// Norm-layer tuning of a ModifiedResNet STUDENT: CLIPCLS_TTA(arch = RN*, only_norm = True) of TPT/tune_cls_rl.py — parameters() are
+// the BatchNorm2d weights / biases whose name contains 'bn' (custom_clip.py:481-485; `downsample.1` is missed by that test and stays
+// frozen), and CLIPCLS_TTA.train (custom_clip.py:487-497) keeps EVERY BatchNorm2d in training mode, also under model.eval().  So every
+// pass of the student — the N views of the first step, the selected views of later steps and the final clean-view inference — runs
+// the TRAIN-FORM tower below: convolution as a GEMM on the UNFOLDED weights, per-channel batch statistics over (n, H, W), then
+//   `--prior_strength` < 0 (parser default): y = gamma (z - mu_B) / sqrt(var_B + eps) + beta, running statistics updated in place
+//                                            (momentum 0.1, unbiased variance), gradient THROUGH the statistics (views coupled);
+//   `--prior_strength` s >= 0 (tune_cls_rl.py:35-44,73-76): statistics = prior * running + (1 - prior) * batch (unbiased variance),
+//                                            prior = s / (s + 1), as constants of the backward; running statistics untouched.
+// Only BatchNorm parameters receive gradients (weights are frozen): the backward is the dX chain through the convolutions
+// (dX = dZ . W as a GEMM on the transposed / tap-flipped weights), average pools, ReLUs, the attention pool, and per BatchNorm the
+// two column sums d beta = sum g, d gamma = sum g x_hat (fixed-order two-stage reductions: bit-reproducible).
+// ====================================================================================================================================
+#define BN_EPS 1e-5f
+#define BN_ROWS 256                  // rows per partial sum of the column reductions
+
+// W[co, ci, ky, kx] -> [co, (ky,kx,ci)] zero padded to Kp (conv_fold_kernel without the BatchNorm scale)
+__global__ void conv_permute_kernel(const float* __restrict__ w, float* __restrict__ wout, int Cin, int kk, int Kp) {
+    const int co = blockIdx.x;
+    for (int i = threadIdx.x; i < Kp; i += blockDim.x) {
+        float v = 0.f;
+        if (i < kk * Cin) { const int tap = i / Cin, ci = i - tap * Cin; v = w[((size_t)co * Cin + ci) * kk + tap]; }
+        wout[(size_t)co * Kp + i] = v;
+    }
+}
+// operand of the 3x3 convolution's dX: wT[ci, (ky,kx,co)] = W[co, ci, 2-ky, 2-kx], zero padded to KpT (a stride-1, pad-1 correlation's
+// input gradient is the correlation of dZ with the flipped, channel-transposed kernel)
+__global__ void conv_flip_kernel(const float* __restrict__ w, float* __restrict__ wT, int Cin, int Cout, int KpT) {
+    const int ci = blockIdx.x;
+    for (int i = threadIdx.x; i < KpT; i += blockDim.x) {
+        float v = 0.f;
+        if (i < 9 * Cout) {
+            const int tap = i / Cout, co = i - tap * Cout, ky = tap / 3, kx = tap - ky * 3;
+            v = w[((size_t)co * Cin + ci) * 9 + (2 - ky) * 3 + (2 - kx)];
+        }
+        wT[(size_t)ci * KpT + i] = v;
+    }
+}
+// stage 1 of a column reduction over M rows: part[chunk, 0, c] = sum z, part[chunk, 1, c] = sum z^2 over the chunk's BN_ROWS rows
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, float* __restrict__ part, long M, int C) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float s1[4][64], s2[4][64];
+    const long r0 = (long)blockIdx.y * BN_ROWS, r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (long r = r0 + q; r < r1; r += 4) { const float v = z[r * C + c]; a += v; b += v * v; }
+    s1[q][threadIdx.x & 63] = a; s2[q][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+    }
+}
+// stage 2: batch mean / variance (double, chunks in order), the statistics the pass normalises with, running-statistics update.
+//   mode 0: eval (running statistics)   1: train (batch statistics, running <- 0.9 running + 0.1 batch, unbiased variance)
+//   2: prior blend (prior * running + (1 - prior) * batch with the UNBIASED batch variance; running untouched)
+// ms[c] = mean used, ms[C + c] = 1 / sqrt(var used + eps)
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int chunks, long M, int C, float* __restrict__ rmean, float* __restrict__ rvar,
+                                      float* __restrict__ ms, int mode, float prior) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu_u = rmean[c], var_u = rvar[c];
+    if (mode != 0) {
+        double s = 0.0, s2 = 0.0;
+        for (int k = 0; k < chunks; ++k) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+        const double mu = s / (double)M;
+        double var = s2 / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const double varu = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        if (mode == 1) {
+            mu_u = (float)mu; var_u = (float)var;
+            rmean[c] = 0.9f * rmean[c] + 0.1f * (float)mu;
+            rvar[c] = 0.9f * rvar[c] + 0.1f * (float)varu;
+        } else {
+            mu_u = prior * rmean[c] + (1.f - prior) * (float)mu;
+            var_u = prior * rvar[c] + (1.f - prior) * (float)varu;
+        }
+    }
+    ms[c] = mu_u;
+    ms[C + c] = 1.0f / sqrtf(var_u + BN_EPS);
+}
+// y = gamma (z - mean) rstd + beta (+ identity) (ReLU); 4 channels per thread
+__global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ ms, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ idn, float* __restrict__ y, long total4, int C, int relu) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 v = ((const float4*)z)[i];
+        const float4 mu = *(const float4*)(ms + c), rs = *(const float4*)(ms + C + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+        float o[4] = {(v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z, (v.w - mu.w) * rs.w * g.w + b.w};
+        if (idn) { const float4 r = ((const float4*)idn)[i]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+        if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        ((float4*)y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+// backward stage 1: g = dy (* [y > 0] when the unit ends in a ReLU); part[chunk, 0, c] = sum g, part[chunk, 1, c] = sum g x_hat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                                             const float* __restrict__ ms, float* __restrict__ part, long M, int C, int relu) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float s1[4][64], s2[4][64];
+    const long r0 = (long)blockIdx.y * BN_ROWS, r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const float mu = ms[c], rs = ms[C + c];
+        for (long r = r0 + q; r < r1; r += 4) {
+            float g = dy[r * C + c];
+            if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+            a += g; b += g * ((z[r * C + c] - mu) * rs);
+        }
+    }
+    s1[q][threadIdx.x & 63] = a; s2[q][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = (s1[0][l] + s1[1][l]) + (s1[2][l] + s1[3][l]);
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
+    }
+}
+// backward stage 2: sums[c] = d beta, sums[C + c] = d gamma (chunks added in order); grads written when the unit is tuned
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, s2 = 0.f;
+    for (int k = 0; k < chunks; ++k) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+    sums[c] = s; sums[C + c] = s2;
+    if (dgamma) { dgamma[c] = s2; dbeta[c] = s; }
+}
+// backward stage 3: dz = gamma rstd (g - [train mode: (sum g + x_hat sum g x_hat) / M]); gout (optional) = g, the gradient that also
+// flows into the identity branch of a block's last unit
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                    const float* __restrict__ ms, const float* __restrict__ gamma, const float* __restrict__ sums,
+                                    float* __restrict__ dz, float* __restrict__ gout, long total, long M, int C, int relu, int through_stats) {
+    const float invM = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float g = dy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        if (gout) gout[i] = g;
+        const float rs = ms[C + c];
+        float t = g;
+        if (through_stats) t -= (sums[c] + (z[i] - ms[c]) * rs * sums[C + c]) * invM;
+        dz[i] = gamma[c] * rs * t;
+    }
+}
+// AvgPool2d(2) backward on NHWC: din[img, 2y+a, 2x+b, c] = dout[img, y, x, c] / 4
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long total_in, int C, int Ho, int Wo) {
+    const int W = 2 * Wo, H = 2 * Ho;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_in; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const long img = p / ((long)W * H);
+        din[i] = 0.25f * dout[((img * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+    }
+}
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] += b[i];
+}
+// attention pool, forward with the probabilities kept: as attnpool_attend_kernel, plus prob[img, head, t]
+__global__ __launch_bounds__(256) void attnpool_attend_save_kernel(const float* __restrict__ q, const float* __restrict__ kv, float* __restrict__ out,
+                                                                  float* __restrict__ prob, int T, int E) {
+    extern __shared__ float sc[];
+    float* part = sc + T;
+    __shared__ float red[4];
+    const int head = blockIdx.x, img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float qd = q[(size_t)img * E + head * 64 + lane] * 0.125f;
+    const float* kbase = kv + (size_t)img * T * 2 * E + head * 64 + lane;
+    for (int t = wave; t < T; t += 4) { const float d = wave_sum(qd * kbase[(size_t)t * 2 * E]); if (lane == 0) sc[t] = d; }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256) mx = fmaxf(mx, sc[t]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { const float p = expf(sc[t] - mx); sc[t] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int t = threadIdx.x; t < T; t += 256) prob[((size_t)img * gridDim.x + head) * T + t] = sc[t] * inv;
+    float acc = 0.f;
+    const float* vbase = kbase + E;
+    for (int t = wave; t < T; t += 4) acc += sc[t] * vbase[(size_t)t * 2 * E];
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0) out[(size_t)img * E + head * 64 + lane] = ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) * inv;
+}
+// ... and its backward: datt [n, E] -> dq [n, E] (gradient of the projected, unscaled query), dkv [n*T, 2E]
+//   dv_t = p_t datt;  dp_t = <datt, v_t>;  ds = p (dp - sum p dp);  dq = sum_t ds_t k_t / 8;  dk_t = ds_t q / 8
+__global__ __launch_bounds__(256) void attnpool_attend_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ prob,
+                                                                 const float* __restrict__ datt, float* __restrict__ dq, float* __restrict__ dkv,
+                                                                 int T, int E) {
+    extern __shared__ float sc[];                 // [T] dp, then ds; [4*64] partial dq
+    float* part = sc + T;
+    __shared__ float red[4];
+    const int head = blockIdx.x, img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pr = prob + ((size_t)img * gridDim.x + head) * T;
+    const float da = datt[(size_t)img * E + head * 64 + lane];
+    const float qd = q[(size_t)img * E + head * 64 + lane];
+    const float* kbase = kv + (size_t)img * T * 2 * E + head * 64 + lane;
+    float* dkbase = dkv + (size_t)img * T * 2 * E + head * 64 + lane;
+    for (int t = wave; t < T; t += 4) {
+        const float d = wave_sum(da * kbase[(size_t)t * 2 * E + E]);
+        if (lane == 0) sc[t] = d;
+        dkbase[(size_t)t * 2 * E + E] = pr[t] * da;                  // dv
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) s += pr[t] * sc[t];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) sc[t] = pr[t] * (sc[t] - tot);
+    __syncthreads();
+    float acc = 0.f;
+    for (int t = wave; t < T; t += 4) {
+        const float ds = sc[t];
+        acc += ds * kbase[(size_t)t * 2 * E];
+        dkbase[(size_t)t * 2 * E] = ds * qd * 0.125f;              // dk
+    }
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0) dq[(size_t)img * E + head * 64 + lane] = ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) * 0.125f;
+}
+// tokens backward: dx[img, p, c] = dtok[img, 1 + p, c] + dtok[img, 0, c] / HW  (the mean token reads every position)
+__global__ void attnpool_tokens_bwd_kernel(const float* __restrict__ dtok, float* __restrict__ dx, int HW, int E, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % E);
+        const long p = (i / E) % HW, img = i / ((long)E * HW);
+        dx[i] = dtok[((size_t)img * (HW + 1) + 1 + p) * E + c] + dtok[(size_t)img * (HW + 1) * E + c] / (float)HW;
+    }
+}
+// dtok[img, 0, :] += dq0[img, :]
+__global__ void attnpool_add_row0_kernel(float* __restrict__ dtok, const float* __restrict__ dq0, int T, int E, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        dtok[(size_t)(i / E) * T * E + (i % E)] += dq0[i];
+}
+
+static const float* derived_buf(ClipModel& m, size_t floats, float** out) {
+    m.derived.emplace_back();
+    if (m.derived.back().ensure(floats * sizeof(float)) != RLCF_OK) return nullptr;
+    *out = m.derived.back().as<float>();
+    return *out;
+}
+static const float* transposed_of(ClipModel& m, const float* w, int rows, int cols, hipStream_t st) {
+    float* d = nullptr;
+    if (!derived_buf(m, (size_t)rows * cols, &d)) return nullptr;
+    if (launch_transpose(w, d, rows, cols, st) != RLCF_OK) return nullptr;
+    return d;
+}
+
+// build the train-form weights, the flat tunable vector (e->ln_params & co: the ABI of the LayerNorm path serves the BatchNorm
+// parameters of a ResNet student unchanged) and the statistics vector; once per finalize
+int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    if (!m.finalized || !is_resnet(m.cfg)) { rlcf_set_error("BatchNorm tuning needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
+    ResNetW& r = m.rn;
+    if (r.bn_enabled) return RLCF_OK;
+    m.derived.reserve(m.derived.size() + 8 * (r.blocks.size() * 4 + 3) + 16);
+    const rlcf_clip_cfg& c = m.cfg;
+    const int w = c.vision_width;
+    r.units.clear(); r.block_unit.clear();
+    int pofs = 0, sofs = 0;
+    auto add = [&](const std::string& conv, const std::string& bn, int cout, int cin, int k, bool tuned, bool need_dx) -> int {
+        BnUnit u;
+        const int kk = k * k;
+        const float* wr = raw_of(m, conv + ".weight", (size_t)cout * cin * kk);
+        u.gamma0 = raw_of(m, bn + ".weight", cout); u.beta0 = raw_of(m, bn + ".bias", cout);
+        NEED(wr); NEED(u.gamma0); NEED(u.beta0);
+        u.raw.cin = cin; u.raw.cout = cout; u.raw.k = k;
+        u.raw.Kp = k == 1 ? cin : (kk * cin + 31) / 32 * 32;
+        float* wp = nullptr;
+        NEED(derived_buf(m, (size_t)cout * u.raw.Kp, &wp));
+        conv_permute_kernel<<<dim3(cout), dim3(256), 0, st>>>(wr, wp, cin, kk, u.raw.Kp);
+        RLCF_LAUNCH_CHECK();
+        u.raw.w = wp; u.raw.b = nullptr;
+        TRY(engine_make_split(e, m, u.raw.w, (size_t)cout * u.raw.Kp, st));
+        if (need_dx) {
+            if (k == 1) {
+                u.KpT = cout;
+                NEED(u.wT = transposed_of(m, wr, cout, cin, st));                 // [cout, cin] -> [cin, cout]
+            } else {
+                u.KpT = (9 * cout + 31) / 32 * 32;
+                float* wt = nullptr;
+                NEED(derived_buf(m, (size_t)cin * u.KpT, &wt));
+                conv_flip_kernel<<<dim3(cin), dim3(256), 0, st>>>(wr, wt, cin, cout, u.KpT);
+                RLCF_LAUNCH_CHECK();
+                u.wT = wt;
+            }
+            if (u.KpT % 32 == 0) TRY(engine_make_split(e, m, u.wT, (size_t)cin * u.KpT, st));
+        }
+        if (tuned) { u.pofs = pofs; pofs += 2 * cout; }
+        u.sofs = sofs; sofs += 2 * cout;
+        r.units.push_back(u);
+        return RLCF_OK;
+    };
+    TRY(add("visual.conv1", "visual.bn1", w / 2, 3, 3, true, false));
+    TRY(add("visual.conv2", "visual.bn2", w / 2, w / 2, 3, true, true));
+    TRY(add("visual.conv3", "visual.bn3", w, w / 2, 3, true, true));
+    int inpl = w;
+    for (int s = 0; s < 4; ++s) {
+        const int planes = w << s;
+        for (int b = 0; b < c.vision_stages[s]; ++b) {
+            const std::string p = "visual.layer" + std::to_string(s + 1) + "." + std::to_string(b) + ".";
+            r.block_unit.push_back((int)r.units.size());
+            TRY(add(p + "conv1", p + "bn1", planes, inpl, 1, true, true));
+            TRY(add(p + "conv2", p + "bn2", planes, planes, 3, true, true));
+            TRY(add(p + "conv3", p + "bn3", planes * 4, planes, 1, true, true));
+            if (r.blocks[r.block_unit.size() - 1].has_down) TRY(add(p + "downsample.0", p + "downsample.1", planes * 4, inpl, 1, false, true));
+            inpl = planes * 4;
+        }
+    }
+    const int E = r.E, D = c.embed_dim;
+    NEED(r.q_wT = transposed_of(m, r.q_w, E, E, st));
+    NEED(r.kv_wT = transposed_of(m, r.kv_w, 2 * E, E, st));
+    NEED(r.c_wT = transposed_of(m, r.c_w, D, E, st));
+    TRY(engine_make_split(e, m, r.q_wT, (size_t)E * E, st));
+    TRY(engine_make_split(e, m, r.kv_wT, (size_t)2 * E * E, st));
+    TRY(engine_make_split(e, m, r.c_wT, (size_t)D * E, st));
+    // flat vectors: tunable (gamma | beta per tuned unit, named_parameters order = execution order) and statistics (mean | var per unit)
+    e->ln_count = pofs;
+    r.n_stats = sofs;
+    const size_t nb = (size_t)pofs * sizeof(float), sb = (size_t)sofs * sizeof(float);
+    for (DevBuf* d : {&e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v, &e->ln_clip, &e->ln_mom}) TRY(d->ensure(nb));
+    TRY(e->bn_stats.ensure(sb)); TRY(e->bn_stats_init.ensure(sb));
+    size_t ui = 0;
+    auto stat_names = [&](size_t i) -> std::string {
+        if (i < 3) return "visual.bn" + std::to_string(i + 1);
+        size_t k = 3;
+        for (size_t bi = 0; bi < r.blocks.size(); ++bi) {
+            const size_t nu = r.blocks[bi].has_down ? 4 : 3;
+            if (i < k + nu) {
+                int s = 0, b = (int)bi;
+                while (b >= c.vision_stages[s]) { b -= c.vision_stages[s]; ++s; }
+                const std::string p = "visual.layer" + std::to_string(s + 1) + "." + std::to_string(b) + ".";
+                const size_t j = i - k;
+                return j < 3 ? p + "bn" + std::to_string(j + 1) : p + "downsample.1";
+            }
+            k += nu;
+        }
+        return "";
+    };
+    for (; ui < r.units.size(); ++ui) {
+        const BnUnit& u = r.units[ui];
+        const int co = u.raw.cout;
+        if (u.pofs >= 0) {
+            RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.as<float>() + u.pofs, u.gamma0, co * sizeof(float), hipMemcpyDeviceToDevice, st));
+            RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.as<float>() + u.pofs + co, u.beta0, co * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        const std::string bn = stat_names(ui);
+        const float *rm = raw_of(m, bn + ".running_mean", co), *rv = raw_of(m, bn + ".running_var", co);
+        NEED(rm); NEED(rv);
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats.as<float>() + u.sofs, rm, co * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats.as<float>() + u.sofs + co, rv, co * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (DevBuf* d : {&e->ln_init, &e->ln_clip, &e->ln_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->ln_params.p, nb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats_init.p, e->bn_stats.p, sb, hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
+    r.bn_enabled = true;
+    return RLCF_OK;
+}
+
+// ---- train-form pass -----------------------------------------------------------------------------------------------------------
+struct BnPass {
+    rlcf_engine* e; ClipModel* m; hipStream_t st; int n; int mode; float prior; bool save;
+};
+static inline const float* bn_gamma(const rlcf_engine* e, const BnUnit& u) { return u.pofs >= 0 ? e->ln_params.as<float>() + u.pofs : u.gamma0; }
+static inline const float* bn_beta(const rlcf_engine* e, const BnUnit& u) { return u.pofs >= 0 ? e->ln_params.as<float>() + u.pofs + u.raw.cout : u.beta0; }
+
+// conv (unfolded) -> batch statistics -> normalise (+ identity) (+ ReLU).  z / y: where the GEMM output and the unit's output go
+static int bn_unit_fwd(const BnPass& P, int ui, const float* in, int H, int W, int stride, bool nchw, const float* idn, bool relu, float* z, float* y) {
+    rlcf_engine* e = P.e;
+    const BnUnit& u = P.m->rn.units[ui];
+    const int Ho = H / stride, Wo = W / stride, C = u.raw.cout;
+    const long M = (long)P.n * Ho * Wo;
+    TRY(conv(e, u.raw, in, nullptr, P.n, H, W, stride, nchw, nullptr, RLCF_EPI_NONE, z, nullptr, P.st));
+    const int chunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    TRY(e->bn_grad_c.ensure((size_t)chunks * 2 * C * sizeof(float)));
+    float* ms = e->bn_ms[ui];
+    float* st_ = e->bn_stats.as<float>() + u.sofs;
+    if (P.mode != 0) {
+        bn_stats_partial_kernel<<<dim3((C + 63) / 64, chunks), dim3(256), 0, P.st>>>(z, e->bn_grad_c.as<float>(), M, C);
+        RLCF_LAUNCH_CHECK();
+    }
+    bn_stats_final_kernel<<<dim3((C + 127) / 128), dim3(128), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, M, C, st_, st_ + C, ms, P.mode, P.prior);
+    RLCF_LAUNCH_CHECK();
+    const long total4 = M * C / 4;
+    bn_apply_kernel<<<grid_for(total4), dim3(256), 0, P.st>>>(z, ms, bn_gamma(e, u), bn_beta(e, u), idn, y, total4, C, relu ? 1 : 0);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// activation sizes of unit outputs for n images (floats), in unit order; also the spatial size every unit's OUTPUT has
+static void bn_plan(const ClipModel& m, std::vector<size_t>& out_elems, std::vector<int>& out_hw) {
+    const ResNetW& r = m.rn;
+    const int R = m.cfg.image_resolution;
+    out_elems.clear(); out_hw.clear();
+    int H = R / 2;
+    for (int i = 0; i < 3; ++i) { out_elems.push_back((size_t)H * H * r.units[i].raw.cout); out_hw.push_back(H); }
+    H /= 2;
+    for (size_t b = 0; b < r.blocks.size(); ++b) {
+        const BottleW& bw = r.blocks[b];
+        const int u0 = r.block_unit[b], Ho = H / bw.stride;
+        out_elems.push_back((size_t)H * H * r.units[u0].raw.cout); out_hw.push_back(H);
+        out_elems.push_back((size_t)H * H * r.units[u0 + 1].raw.cout); out_hw.push_back(H);
+        out_elems.push_back((size_t)Ho * Ho * r.units[u0 + 2].raw.cout); out_hw.push_back(Ho);
+        if (bw.has_down) { out_elems.push_back((size_t)Ho * Ho * r.units[u0 + 3].raw.cout); out_hw.push_back(Ho); }
+        H = Ho;
+    }
+}
+
+// ModifiedResNet.forward in train form over n images (ALL of them in one pass: the batch statistics couple them) + L2 normalisation.
+// z / y of every unit, the pooled intermediates and the attention pool's tensors are kept for rn_backward_bn (every unit writes its
+// own slots: no in-place reuse to reason about; RN50 at 64 views of 224^2: 5 GB, RN50x64 at 32 views of 448^2: ~55 GB of the 288).
+int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st) {
+    const bool save = true;
+    const rlcf_clip_cfg& c = m.cfg;
+    ResNetW& r = m.rn;
+    const int R = c.image_resolution, w = c.vision_width, E = r.E, D = c.embed_dim, HW = r.out_hw * r.out_hw, T = HW + 1;
+    const int nu = (int)r.units.size();
+    TRY(rn_ensure(e, r, n, T));
+    // statistics scratch (mean | rstd per unit) and, when saving, z / y of every unit
+    std::vector<size_t> oe; std::vector<int> ohw;
+    bn_plan(m, oe, ohw);
+    size_t ms_total = 0, act_total = 0;
+    for (int i = 0; i < nu; ++i) { ms_total += 2 * (size_t)r.units[i].raw.cout; act_total += oe[i]; }
+    TRY(e->bn_scratch.ensure(ms_total * sizeof(float)));
+    e->bn_ms.resize(nu); e->bn_z.resize(nu); e->bn_y.resize(nu);
+    { float* p = e->bn_scratch.as<float>(); for (int i = 0; i < nu; ++i) { e->bn_ms[i] = p; p += 2 * (size_t)r.units[i].raw.cout; } }
+    {
+        // + pooled copies: stem pool, per strided block the pooled conv2 output and the pooled block input
+        size_t extra = (size_t)(R / 4) * (R / 4) * w + (size_t)T * 2 * E + E;        // (+ the attention pool's k|v and q)
+        { int H = R / 4; for (const BottleW& b : r.blocks) { if (b.stride > 1) extra += (size_t)(H / 2) * (H / 2) * (b.c2.cout + b.down.cin); H /= b.stride; } }
+        TRY(e->bn_saved.ensure(((size_t)n * (2 * act_total + extra)) * sizeof(float)));
+        float* p = e->bn_saved.as<float>();
+        for (int i = 0; i < nu; ++i) { e->bn_z[i] = p; p += (size_t)n * oe[i]; e->bn_y[i] = p; p += (size_t)n * oe[i]; }
+        e->bn_saved_n = n;
+    }
+    const int mode = e->bn_prior_strength >= 0 ? 2 : 1;
+    const float prior = e->bn_prior_strength >= 0 ? (float)e->bn_prior_strength / (float)(e->bn_prior_strength + 1) : 0.f;
+    BnPass P{e, &m, st, n, mode, prior, save};
+    float* pooled = e->bn_saved.as<float>() + (size_t)n * 2 * act_total;
+    int H = R / 2;
+    auto Z = [&](int ui) { return e->bn_z[ui]; };
+    auto Y = [&](int ui) { return e->bn_y[ui]; };
+    TRY(bn_unit_fwd(P, 0, images, R, R, 2, true, nullptr, true, Z(0), Y(0)));
+    TRY(bn_unit_fwd(P, 1, Y(0), H, H, 1, false, nullptr, true, Z(1), Y(1)));
+    TRY(bn_unit_fwd(P, 2, Y(1), H, H, 1, false, nullptr, true, Z(2), Y(2)));
+    H /= 2;
+    float* xin = pooled;
+    pooled += (size_t)n * H * H * w;
+    TRY(avgpool2(Y(2), xin, n, H, H, w, st));
+    const float* x = xin;                                          // block input
+    for (size_t bi = 0; bi < r.blocks.size(); ++bi) {
+        const BottleW& b = r.blocks[bi];
+        const int u0 = r.block_unit[bi], planes = b.c1.cout, Ho = H / b.stride;
+        TRY(bn_unit_fwd(P, u0, x, H, H, 1, false, nullptr, true, Z(u0), Y(u0)));
+        TRY(bn_unit_fwd(P, u0 + 1, Y(u0), H, H, 1, false, nullptr, true, Z(u0 + 1), Y(u0 + 1)));
+        const float* t2 = Y(u0 + 1);
+        const float* xp = x;
+        if (b.stride > 1) {
+            float* t2p = pooled;
+            pooled += (size_t)n * Ho * Ho * planes;
+            TRY(avgpool2(t2, t2p, n, Ho, Ho, planes, st));
+            t2 = t2p;
+            float* xpp = pooled;
+            pooled += (size_t)n * Ho * Ho * b.down.cin;
+            TRY(avgpool2(x, xpp, n, Ho, Ho, b.down.cin, st));
+            xp = xpp;
+        }
+        const float* idn = x;
+        if (b.has_down) {
+            TRY(bn_unit_fwd(P, u0 + 3, xp, Ho, Ho, 1, false, nullptr, false, Z(u0 + 3), Y(u0 + 3)));
+            idn = Y(u0 + 3);
+        }
+        TRY(bn_unit_fwd(P, u0 + 2, t2, Ho, Ho, 1, false, idn, true, Z(u0 + 2), Y(u0 + 2)));
+        x = Y(u0 + 2);
+        H = Ho;
+    }
+    // attention pool (model.py:68-91), probabilities kept for the backward
+    attnpool_tokens_kernel<<<dim3((E + 255) / 256, n), dim3(256), 0, st>>>(x, r.pos, e->rn_tok.as<float>(), HW, E);
+    RLCF_LAUNCH_CHECK();
+    // q / k|v / probabilities stay with the saved pass (a ModifiedResNet reward model's encode, between this pass and its backward,
+    // reuses e->rn_q / e->rn_kv)
+    e->bn_kv = pooled; pooled += (size_t)n * T * 2 * E;
+    e->bn_q = pooled;
+    TRY(engine_gemm(e, e->rn_tok.as<float>(), T * E, r.q_w, E, r.q_b, nullptr, 0, e->bn_q, E, n, E, E, RLCF_EPI_NONE, st));
+    TRY(engine_gemm(e, e->rn_tok.as<float>(), E, r.kv_w, E, r.kv_b, nullptr, 0, e->bn_kv, 2 * E, n * T, 2 * E, E, RLCF_EPI_NONE, st));
+    TRY(e->bn_grad_b.ensure((size_t)n * r.heads * T * sizeof(float)));
+    attnpool_attend_save_kernel<<<dim3(r.heads, n), dim3(256), (T + 256) * sizeof(float), st>>>(e->bn_q, e->bn_kv, e->rn_att.as<float>(),
+                                                                                                e->bn_grad_b.as<float>(), T, E);
+    RLCF_LAUNCH_CHECK();
+    TRY(engine_gemm(e, e->rn_att.as<float>(), E, r.c_w, E, r.c_b, nullptr, 0, e->feat_raw.as<float>(), D, n, D, E, RLCF_EPI_NONE, st));
+    TRY(e->vit_inv_norm.ensure((size_t)std::max(n, e->max_views) * sizeof(float)));
+    TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));
+    return RLCF_OK;
+}
+
+// one BatchNorm's backward: dy = gradient at the unit's output (before its ReLU mask), -> dz (gradient at the GEMM output), the
+// parameter gradients (tuned units) and, optionally, gout = the masked gradient (what also flows into a block's identity branch)
+static int bn_unit_bwd(const BnPass& P, int ui, const float* dy, long M, bool relu, float* dz, float* gout, float* bn_grad) {
+    rlcf_engine* e = P.e;
+    const BnUnit& u = P.m->rn.units[ui];
+    const int C = u.raw.cout;
+    const int chunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    TRY(e->bn_grad_c.ensure((size_t)chunks * 2 * C * sizeof(float)));
+    TRY(e->bn_grad_a.ensure((size_t)2 * C * sizeof(float)));
+    const float *z = e->bn_z[ui], *y = e->bn_y[ui], *ms = e->bn_ms[ui];
+    bn_bwd_partial_kernel<<<dim3((C + 63) / 64, chunks), dim3(256), 0, P.st>>>(dy, y, z, ms, e->bn_grad_c.as<float>(), M, C, relu ? 1 : 0);
+    RLCF_LAUNCH_CHECK();
+    float* dg = (bn_grad && u.pofs >= 0) ? bn_grad + u.pofs : nullptr;
+    bn_bwd_final_kernel<<<dim3((C + 127) / 128), dim3(128), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, C, e->bn_grad_a.as<float>(), dg, dg ? dg + C : nullptr);
+    RLCF_LAUNCH_CHECK();
+    if (dz) {
+        const long total = M * C;
+        bn_bwd_apply_kernel<<<grid_for(total), dim3(256), 0, P.st>>>(dy, y, z, ms, bn_gamma(e, u), e->bn_grad_a.as<float>(), dz, gout, total, M, C,
+                                                                     relu ? 1 : 0, P.mode == 1 ? 1 : 0);
+        RLCF_LAUNCH_CHECK();
+    }
+    return RLCF_OK;
+}
+// dX of a convolution unit: dz [M, cout] -> dx [M_in, cin] (stride-1 units only); res (optional) is added
+static int bn_conv_dx(const BnPass& P, int ui, const float* dz, int H, int W, const float* res, float* dx) {
+    rlcf_engine* e = P.e;
+    const BnUnit& u = P.m->rn.units[ui];
+    const long M = (long)P.n * H * W;
+    if (u.raw.k == 1)
+        return engine_gemm(e, dz, u.raw.cout, u.wT, u.KpT, nullptr, res, u.raw.cin, dx, u.raw.cin, (int)M, u.raw.cin, u.raw.cout, RLCF_EPI_NONE, P.st);
+    const long total = M * u.KpT;
+    TRY(e->rn_col.ensure((size_t)total * sizeof(float)));
+    if (prec_x3(e) && (size_t)total > e->a_split_elems) { TRY(e->a_hi.ensure((size_t)total * 4)); e->a_split_elems = (size_t)total; }
+    const int Co = u.raw.cout;
+    im2col3x3_kernel<<<grid_for(total), dim3(256), 0, P.st>>>(dz, e->rn_col.as<float>(), total, Co, H, W, H, W, 1, u.KpT, (long)Co * H * W, 1,
+                                                             (long)W * Co, Co);
+    RLCF_LAUNCH_CHECK();
+    return engine_gemm(e, e->rn_col.as<float>(), u.KpT, u.wT, u.KpT, nullptr, res, u.raw.cin, dx, u.raw.cin, (int)M, u.raw.cin, u.KpT, RLCF_EPI_NONE, P.st);
+}
+static int avgpool2_bwd(const float* dout, float* din, int n, int Ho, int Wo, int C, hipStream_t st) {
+    const long total = (long)n * 4 * Ho * Wo * C;
+    avgpool2_bwd_kernel<<<grid_for(total), dim3(256), 0, st>>>(dout, din, total, C, Ho, Wo);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// d loss / d (BatchNorm weights, biases) of the pass rn_forward_train just ran over n images, from dfeat [n, D] = d loss / d (the
+// L2-normalised features).  bn_grad: [e->ln_count] in the tunable vector's layout.
+int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st) {
+    const rlcf_clip_cfg& c = m.cfg;
+    ResNetW& r = m.rn;
+    const int R = c.image_resolution, E = r.E, D = c.embed_dim, HW = r.out_hw * r.out_hw, T = HW + 1;
+    if (e->bn_saved_n != n) { rlcf_set_error("rn_backward_bn: the saved pass holds %d images, not %d", e->bn_saved_n, n); return RLCF_ERR_STATE; }
+    const int mode = e->bn_prior_strength >= 0 ? 2 : 1;
+    BnPass P{e, &m, st, n, mode, 0.f, true};
+    float *G0 = e->rn_buf[0].as<float>(), *G1 = e->rn_buf[1].as<float>(), *G2 = e->rn_buf[2].as<float>(), *G3 = e->rn_buf[3].as<float>(),
+          *G4 = e->rn_buf[4].as<float>();
+    // features -> attention pool
+    TRY(launch_l2norm_bwd(feats, dfeat, e->vit_inv_norm.as<float>(), dfeat, n, D, st));
+    TRY(engine_gemm(e, dfeat, D, r.c_wT, D, nullptr, nullptr, 0, G0, E, n, E, D, RLCF_EPI_NONE, st));                 // d att [n, E]
+    float *dq = G1, *dkv = G2;
+    attnpool_attend_bwd_kernel<<<dim3(r.heads, n), dim3(256), (T + 256) * sizeof(float), st>>>(e->bn_q, e->bn_kv, e->bn_grad_b.as<float>(), G0, dq,
+                                                                                               dkv, T, E);
+    RLCF_LAUNCH_CHECK();
+    float* dtok = G3;
+    TRY(engine_gemm(e, dkv, 2 * E, r.kv_wT, 2 * E, nullptr, nullptr, 0, dtok, E, n * T, E, 2 * E, RLCF_EPI_NONE, st));
+    TRY(engine_gemm(e, dq, E, r.q_wT, E, nullptr, nullptr, 0, G0, E, n, E, E, RLCF_EPI_NONE, st));                    // d tok0 through q_proj
+    { const long tot = (long)n * E; attnpool_add_row0_kernel<<<grid_for(tot), dim3(256), 0, st>>>(dtok, G0, T, E, tot); RLCF_LAUNCH_CHECK(); }
+    float* dOut = G4;                                                  // gradient at the last block's output [n*HW, E]
+    { const long tot = (long)n * HW * E; attnpool_tokens_bwd_kernel<<<grid_for(tot), dim3(256), 0, st>>>(dtok, dOut, HW, E, tot); RLCF_LAUNCH_CHECK(); }
+    // spatial size of every block's input
+    std::vector<int> Hin(r.blocks.size());
+    { int H = R / 4; for (size_t b = 0; b < r.blocks.size(); ++b) { Hin[b] = H; H /= r.blocks[b].stride; } }
+    // buffers rotate: dOut lives in G4 at entry of every block iteration
+    for (int bi = (int)r.blocks.size() - 1; bi >= 0; --bi) {
+        const BottleW& b = r.blocks[bi];
+        const int u0 = r.block_unit[bi], H = Hin[bi], Ho = H / b.stride, planes = b.c1.cout, inpl = b.c1.cin;
+        const long Mo = (long)n * Ho * Ho, Mi = (long)n * H * H;
+        // conv3 + bn3 (+ identity) + ReLU: dz3 -> G0, masked gradient g -> G1 (identity branch)
+        TRY(bn_unit_bwd(P, u0 + 2, dOut, Mo, true, G0, G1, bn_grad));
+        TRY(bn_conv_dx(P, u0 + 2, G0, Ho, Ho, nullptr, G2));                                   // d t2 [Mo, planes]
+        const float* dB = G2;
+        if (b.stride > 1) { TRY(avgpool2_bwd(G2, G0, n, Ho, Ho, planes, st)); dB = G0; }       // -> [Mi, planes]
+        // conv2 + bn2 + ReLU
+        float* dz2 = dB == G0 ? G2 : G0;
+        TRY(bn_unit_bwd(P, u0 + 1, dB, Mi, true, dz2, nullptr, bn_grad));
+        float* dA = dz2 == G0 ? G2 : G0;
+        TRY(bn_conv_dx(P, u0 + 1, dz2, H, H, nullptr, dA));                                   // [Mi, planes]
+        // conv1 + bn1 + ReLU
+        float* dz1 = dA == G0 ? G2 : G0;
+        TRY(bn_unit_bwd(P, u0, dA, Mi, true, dz1, nullptr, bn_grad));
+        // identity branch into G3 [Mi, inpl], then the main branch adds onto it (GEMM residual) -> new dOut in G4
+        const float* idg = G1;                                      // g [Mo, 4 planes]
+        if (b.has_down) {
+            float* dzd = dz1 == G0 ? G2 : G0;                       // (the buffer dz1 does not use)
+            TRY(bn_unit_bwd(P, u0 + 3, G1, Mo, false, dzd, nullptr, nullptr));
+            if (b.stride > 1) {
+                TRY(bn_conv_dx(P, u0 + 3, dzd, Ho, Ho, nullptr, G1));                         // [Mo, inpl] (G1's g is consumed)
+                TRY(avgpool2_bwd(G1, G3, n, Ho, Ho, inpl, st));                               // [Mi, inpl]
+            } else TRY(bn_conv_dx(P, u0 + 3, dzd, Ho, Ho, nullptr, G3));
+            idg = G3;
+        }
+        TRY(bn_conv_dx(P, u0, dz1, H, H, idg, G4));                                           // d x = main + identity
+        dOut = G4;
+    }
+    // stem: avgpool <- conv3/bn3/relu <- conv2/bn2/relu <- conv1/bn1/relu (no dX beyond conv1's BatchNorm)
+    const int w = c.vision_width, Hs = R / 2;
+    const long Ms = (long)n * Hs * Hs;
+    TRY(avgpool2_bwd(dOut, G0, n, R / 4, R / 4, w, st));
+    TRY(bn_unit_bwd(P, 2, G0, Ms, true, G1, nullptr, bn_grad));
+    TRY(bn_conv_dx(P, 2, G1, Hs, Hs, nullptr, G2));
+    TRY(bn_unit_bwd(P, 1, G2, Ms, true, G0, nullptr, bn_grad));
+    TRY(bn_conv_dx(P, 1, G0, Hs, Hs, nullptr, G1));
+    TRY(bn_unit_bwd(P, 0, G1, Ms, true, nullptr, nullptr, bn_grad));
     return RLCF_OK;
 }

@@ -747,20 +747,22 @@ int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const floa
 }
 
 // d img[i,:] = scale * sum_c dlogits[i,c] * txt[c,:]    (backward of logits = scale * img @ txt^T w.r.t. img)
-#define DIMG_PARTS 16
-__global__ void dimg_kernel(const float* __restrict__ dlogits, const float* __restrict__ txt, int C, int D, float scale, float* __restrict__ dimg) {
-    // block = (view i, 256-wide d chunk, class partition); partial sums meet in dimg by atomicAdd (dimg pre-zeroed)
-    const int i = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x, part = blockIdx.z;
-    if (d >= D) return;
-    const int per = (C + DIMG_PARTS - 1) / DIMG_PARTS, c0 = part * per, c1 = min(C, c0 + per);
+// block = (view i, 64-wide d chunk); its 4 waves take the classes c = q, q + 4, ... and meet in LDS in a fixed order: bit-reproducible
+// (the 16-way atomicAdd version this replaces made every backward pass depend on the arrival order of its partial sums)
+__global__ __launch_bounds__(256) void dimg_kernel(const float* __restrict__ dlogits, const float* __restrict__ txt, int C, int D, float scale,
+                                                   float* __restrict__ dimg) {
+    __shared__ float part[4][64];
+    const int i = blockIdx.x, l = threadIdx.x & 63, q = threadIdx.x >> 6, d = blockIdx.y * 64 + l;
     float s = 0.f;
-    for (int c = c0; c < c1; ++c) s += dlogits[(size_t)i * C + c] * txt[(size_t)c * D + d];
-    atomicAdd(dimg + (size_t)i * D + d, scale * s);
+    if (d < D)
+        for (int c = q; c < C; c += 4) s += dlogits[(size_t)i * C + c] * txt[(size_t)c * D + d];
+    part[q][l] = s;
+    __syncthreads();
+    if (q == 0 && d < D) dimg[(size_t)i * D + d] = scale * ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l]));
 }
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st) {
     RLCF_ARG_CHECK(n > 0 && C > 0 && D > 0);
-    RLCF_HIP_CHECK(hipMemsetAsync(dimg, 0, (size_t)n * D * sizeof(float), st));
-    dimg_kernel<<<dim3(n, (D + 255) / 256, DIMG_PARTS), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
+    dimg_kernel<<<dim3(n, (D + 63) / 64), dim3(256), 0, st>>>(dlogits, txt, C, D, scale, dimg);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

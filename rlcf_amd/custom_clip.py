@@ -214,6 +214,12 @@ class CLIPCLS_TTA(nn.Module):
         if not only_visual:
             raise NotImplementedError("text-encoder tuning is not built: only_visual=True only (SURVEY.md §8 a14)")
         self.clip_model, _, _ = clip_store.load(arch, device=device)
+        # a ModifiedResNet student (RN50 .. RN50x64): the norm layers are BatchNorms; `ln` then holds their weights / biases and the
+        # forward runs them on batch statistics, as the reference's does even after model.eval() (custom_clip.py:481-497)
+        self.resnet = "visual.layer1.0.conv1.weight" in self.clip_model.state_dict
+        if self.resnet and not only_norm:
+            raise NotImplementedError("a ModifiedResNet student tunes its BatchNorm weights / biases (--tune_norm 1): every-parameter "
+                                      "tuning of it is not built")
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.prompt_prefix = device, prompt_prefix
         self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
@@ -251,6 +257,11 @@ class CLIPCLS_TTA(nn.Module):
             self._vis_init = eng.visual_params(1)
             self._vis = nn.Parameter(self._vis_init.clone())
         return self._vis
+
+    def set_prior_strength(self, prior_strength: int):
+        """`--prior_strength` of tune_cls_rl.py (:73-76 swaps nn.BatchNorm2d.forward for `_modified_bn_forward` when >= 0); ResNet students only."""
+        if self.resnet:
+            runtime.SESSION.set_bn_prior_strength(prior_strength)
 
     def parameters(self, recurse: bool = True):            # custom_clip.py:477-485
         return [self.ln] if self.only_norm else [self.ln, self.vis]
@@ -301,6 +312,11 @@ class CLIPCLS_TTA(nn.Module):
         backward are fused inside rlcf_tta_sample_ln, called by rlcf_amd.tpt_cls_rl.test_time_tuning)."""
         eng = runtime.SESSION.engine(image.shape[0])
         eng.set_ln_params(self.ln.data)
+        if self.resnet:
+            img = eng.encode_image_bn(image)
+            out = eng.logits(img, eng.text_features(runtime.SESSION.ctx_init.to(img.device)))
+            eng.set_ln_params(self._ln_init)
+            return out
         adapted = not self.only_norm and not torch.equal(self.vis.data, self._vis_init)
         if adapted:
             eng.set_visual_params(self.vis.data)

@@ -244,6 +244,25 @@ class Engine:
         L.check(self.lib.rlcf_tta_sample_ln(self.h, _ptr(views), N, C.byref(a), C.byref(co), _stream()), "tta_sample_ln")
         return o
 
+    # ---- ModifiedResNet student: BatchNorm tuning (tta_sample_ln / tta_batch_ln serve it; include/rlcf_hip.h)
+    def set_bn_prior_strength(self, prior_strength: int):
+        """`--prior_strength` (TPT/params.py:91): < 0 = nn.BatchNorm2d train mode, >= 0 = `_modified_bn_forward` (tune_cls_rl.py:35-44)."""
+        L.check(self.lib.rlcf_engine_set_bn_prior_strength(self.h, int(prior_strength)), "set_bn_prior_strength")
+
+    def encode_image_bn(self, images: torch.Tensor) -> torch.Tensor:
+        """ResNet student, BatchNorms on batch statistics, live tunable parameters (what CLIPCLS_TTA's forward computes: include/rlcf_hip.h)."""
+        images = images.to(self.device, torch.float32).contiguous()
+        out = torch.empty(images.shape[0], self.student.embed_dim, device=self.device)
+        L.check(self.lib.rlcf_engine_encode_image_bn(self.h, _ptr(images), images.shape[0], _ptr(out), _stream()), "encode_image_bn")
+        return out
+
+    def bn_stats(self, pristine: bool = False) -> torch.Tensor:
+        """[running_mean | running_var] per BatchNorm in execution order, as the last tta_sample_ln left them (or the checkpoint's)."""
+        n = int(self.lib.rlcf_engine_bn_stats_count(self.h))
+        out = torch.empty(n, device=self.device)
+        L.check(self.lib.rlcf_engine_get_bn_stats(self.h, _ptr(out), 1 if pristine else 0, _stream()), "get_bn_stats")
+        return out
+
     # ---- full image-encoder tuning (CLIPCLS_TTA only_norm=False, TPT/clip/custom_clip.py:477-479)
     def visual_layout(self):
         """[(state-dict key, offset, numel)] of the flat non-LayerNorm visual parameter vector (include/rlcf_hip.h)."""

@@ -53,6 +53,6 @@ def get_args(argv=None):
     p.add_argument("--tune_norm", type=int, default=0)
     p.add_argument("--augmix", type=int, default=1,
                    help="AugMix op chains in the view pipeline; as in the reference (tpt_cls_rl.py:150) only for the fine-grained sets (len(set_id) > 1)")
-    p.add_argument("--prior_strength", type=int, default=-1, help="BN-statistics adaptation of a ResNet student (not built: raises)")
+    p.add_argument("--prior_strength", type=int, default=-1, help="ResNet student: >= 0 blends running and batch BatchNorm statistics with prior s/(s+1) (tune_cls_rl.py:35-44); -1: train-mode BatchNorm")
     p.add_argument("--clip_root", type=str, default="", help="directory of OpenAI-layout state dicts (<arch>.pt)")
     return p.parse_args(argv)

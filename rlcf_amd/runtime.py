@@ -34,9 +34,15 @@ class Session:
         self.image_bank = None       # (student features [n, D], [reward features [n, Dr]]): the bank of the text -> image retrieval direction
         self._bank_version = 0       # bumped by set_bank: the engine re-reads the class bank when its copy is older
         self._bank_applied = -1
+        self.bn_prior_strength = -1  # `--prior_strength` (ResNet students, tune_cls_rl.py:73-76): re-applied whenever the engine is rebuilt
 
     def set_student(self, ckpt):
         self.student = ckpt
+
+    def set_bn_prior_strength(self, prior_strength: int):
+        self.bn_prior_strength = int(prior_strength)
+        if self._engine is not None and self.student is not None and self.student.geometry.is_resnet:
+            self._engine.set_bn_prior_strength(self.bn_prior_strength)
 
     @property
     def reward(self):
@@ -79,6 +85,8 @@ class Session:
             eng.finalize()
             if self.reward_mix is not None:
                 eng.set_reward_mix(self.reward_mix, self.reward_mean)
+            if self.student.geometry.is_resnet:
+                eng.set_bn_prior_strength(self.bn_prior_strength)
             self._engine, self._key, self._bank_applied = eng, key, None
         if self.tokens is not None:
             bkey = (self._bank_version, self.text_mode)       # a counter, not id()/checksums: no stale bank, no device sync per call

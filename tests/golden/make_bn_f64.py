@@ -1,0 +1,49 @@
+"""float64 companion of the bn_* reference fixtures: the ORACLE (oracle/rlcf_ref.py, pinned to the reference's float32 runs by
+tests/test_oracle_golden.py::test_bn_tuning_oracle_matches_reference) re-run in double precision on the same seeded inputs.
+
+Why: with train-mode BatchNorms the float32 gradient of the reference itself is only good to ~1e-3 .. 1e-2 of its norm (channels whose
+batch variance is small against eps amplify the rounding noise of z - mean by 1/sqrt(var + eps), and the noise then rides down the whole
+backward pass).  A float32 implementation with another summation order lands somewhere else inside that noise band, so the HIP path's
+BatchNorm gradient is judged against the float64 value, next to the reference's own distance from it (`ref_err`), and against the
+float32 fixture at the band's width.  Writes tests/golden/<case>_f64.npz: ln_grad, final_logits, bn_stats_after (as float64).
+
+    python tests/golden/make_bn_f64.py [case ...]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import rlcf_ref as R          # noqa: E402
+from rlcf_amd import synth               # noqa: E402
+
+CASES = ["bn_tiny_train", "bn_tiny_train_s3", "bn_tiny_prior0", "bn_tiny_prior16_s3", "bn_rn50_train", "bn_rn50_prior16"]
+
+
+def main(names):
+    torch.Tensor.float = lambda self, *a, **k: self.double()        # the oracle's explicit .float() casts follow the run's precision
+    dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for name in names:
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+        sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+        ssd, rsd = synth.make_state_dict(sg, meta["student_seed"]), synth.make_state_dict(rg, meta["reward_seed"])
+        tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+        views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
+        hp = R.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                        weight_decay=meta["weight_decay"])
+        o = R.tta_sample_ln(dbl(ssd), dbl(rsd), views.double(), tokens, hp, prior_strength=meta["prior_strength"])
+        assert o["selected_idx"].tolist() == z["selected_idx"].tolist() and o["topk_idx"].reshape(-1).tolist() == z["topk_idx"].reshape(-1).tolist()
+        g64, g32 = o["ln_grad"].numpy(), z["ln_grad"].astype(np.float64)
+        ref_err = float(np.linalg.norm(g32 - g64) / np.linalg.norm(g64))
+        np.savez_compressed(os.path.join(HERE, name + "_f64.npz"), ln_grad=g64, final_logits=o["final_logits"].numpy(),
+                            bn_stats_after=o["bn_stats_after"].numpy(), ref_err=np.float64(ref_err))
+        print(f"{name}: |reference f32 - f64| / |f64| = {ref_err:.3e}   final logits {np.abs(z['final_logits'] - o['final_logits'].numpy()).max():.2e}",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or CASES)

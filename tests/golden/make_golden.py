@@ -58,9 +58,10 @@ def import_reference():
     import clip_reward
     from clip import model as refmodel
     import tpt_cls_rl
+    import tune_cls_rl                      # (_modified_bn_forward, the BatchNorm forward `--prior_strength` installs)
     os.path.exists = _exists
     return types.SimpleNamespace(clip=clip, cc=cc, custom=custom, clip_reward=clip_reward,
-                                 refmodel=refmodel, tpt=tpt_cls_rl)
+                                 refmodel=refmodel, tpt=tpt_cls_rl, tune=tune_cls_rl)
 
 
 class Bank:
@@ -215,7 +216,8 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 
-def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4, only_norm=True, full_vectors=True):
+def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n_ctx=4, only_norm=True, full_vectors=True,
+                     prior_strength=None):
     """TPT/tune_cls_rl.py harness body (:206-227) around the reference's own CLIPCLS_TTA(only_norm=...) and
     test_time_tuning, with taps on the intermediates.  only_norm=False (the `--tune_norm 0` default, scripts/rlcf-tune.sh):
     every visual parameter is tuned; the gradient / adapted-parameter vectors are then stored per tensor as L2 norms
@@ -229,6 +231,12 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     model = ref.custom.CLIPCLS_TTA("cpu", bank.classnames, arch=student, prompt_prefix="a_photo_of_a", only_visual=True,
                                    momentum_update=False, only_norm=only_norm)
     assert torch.equal(model.tokenized_prompts, bank.tokens)
+    # ModifiedResNet student: `--prior_strength s` (s >= 0) swaps the BatchNorm forward exactly as tune_cls_rl.py:73-76 does
+    bn_cls = torch.nn.BatchNorm2d
+    bn_forward_orig = bn_cls.forward
+    if prior_strength is not None and prior_strength >= 0:
+        bn_cls.prior = float(prior_strength) / float(prior_strength + 1)
+        bn_cls.forward = ref.tune._modified_bn_forward
     trainable = model.parameters()
     names = [n for n, p in model.clip_model.visual.named_parameters() if not only_norm or "ln" in n or "bn" in n]
     if not only_norm:
@@ -290,9 +298,18 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
     with torch.no_grad():
         final = model(views[:1])
     ref.tpt.select_confident_samples = orig_select
+    bn_cls.forward = bn_forward_orig
+    bn_stats = None
+    if s_geo.is_resnet:            # the running statistics the final inference used (train-mode passes update them in place)
+        vsd = model.clip_model.visual.state_dict()
+        bns = RR.visual_bn_stat_keys({"visual." + k: v for k, v in vsd.items()})
+        bn_stats = torch.cat([torch.cat([vsd[b[len("visual."):] + ".running_mean"].reshape(-1), vsd[b[len("visual."):] + ".running_var"].reshape(-1)]) for b in bns])
+        assert ["visual." + n for n in names] == RR.visual_bn_keys(s_sd), "oracle key order != named_parameters order"
     out = dict(logits=taps["logits"], selected_idx=taps["selected_idx"], topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]),
                clip_score=taps["clip_score"], rewards=taps["rewards"],
                final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0])
+    if bn_stats is not None:
+        out["bn_stats_after"] = bn_stats
     if only_norm:
         out.update(ln_grad=torch.cat([first_grads[n].reshape(-1) for n in names]),
                    ln_after=torch.cat([pmap[n].detach().reshape(-1) for n in names]))
@@ -400,6 +417,15 @@ def save(name, arrays, meta):
 
 ENSEMBLE_NAMES = ["ViT-L/14@336px", "ViT-L/14", "ViT-B/16"]      # CONFIDECES 10, 5, 1 -> weights [0.62, 0.31, 0.06]
 
+BN_CASES = {       # ModifiedResNet student, CLIPCLS_TTA(only_norm=True): name -> (student, reward, views, classes, overrides, prior_strength)
+    "bn_tiny_train": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-3), -1),
+    "bn_tiny_train_s3": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3), -1),
+    "bn_tiny_prior0": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-3), 0),
+    "bn_tiny_prior16_s3": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-3, tta_steps=3), 16),
+    # (RN50 geometry; K = 6 of 8 selected views: ~a quarter of the synthetic reward's scores are positive, the rest clamp to zero)
+    "bn_rn50_train": ("RN50", "ViT-B/16", 16, 40, dict(lr=1e-4, selection_p=0.5, sample_k=6), -1),
+    "bn_rn50_prior16": ("RN50", "ViT-B/16", 16, 40, dict(lr=1e-4, selection_p=0.5, sample_k=6), 16),
+}
 BASE_HP = dict(lr=7e-3, weight_decay=5e-4, sample_k=3, tta_steps=1, selection_p=0.5)
 
 B16L14_SEED = int(os.environ.get("B16L14_SEED", "1000"))
@@ -577,6 +603,16 @@ def main():
                 save(name, arrays, meta)
                 print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
                       f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")
+        elif grp in ("bn", "bnrn50"):
+            for name in [k for k in BN_CASES if ("rn50" in k) == (grp == "bnrn50")]:
+                student, reward, n, c, over, ps = BN_CASES[name]
+                hp = dict(BASE_HP, **over)
+                t0 = time.time()
+                arrays = run_reference_ln(ref, student, reward, n, c, hp, prior_strength=ps)
+                meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23, view_seed=1000,
+                            bank_seed=7, n_ctx=4, prior_strength=ps, **hp)
+                save(name, arrays, meta)
+                print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} |g|={np.linalg.norm(arrays['ln_grad']):.3e}")
         elif grp in ("ln", "lnb16", "lnl14", "lnl14n64"):
             for name in ([k for k in LN_CASES if "b16" not in k and "l14" not in k] if grp == "ln" else ["ln_b16_n8"] if grp == "lnb16" else
                          ["ln_l14_n8"] if grp == "lnl14" else ["ln_l14_n64"]):

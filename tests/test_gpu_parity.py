@@ -639,17 +639,17 @@ def test_errors_are_loud(L, dev):
     o = four.tta_sample(views, TTAConfig(selection_p=0.5))
     assert len(o["reward_image_features"]) == 4 and torch.isfinite(o["final_logits"]).all()
     four.close()
-    # a ModifiedResNet student has no LayerNorms to tune: the LN path refuses it, the prompt path takes it
+    # a ModifiedResNet student: the norm-layer path tunes its BatchNorms (row a-R); every-parameter tuning of it is refused
     rn = synth.GEOMETRIES["tiny-rn32"]
     e2 = Engine(rn, tr, 8, 16)
     e2.load_state_dict(L.STUDENT, synth.make_state_dict(rn, 11)); e2.load_state_dict(L.REWARD, synth.make_state_dict(tr, 23))
     e2.finalize()
     tok2 = synth.make_token_bank(rn, 16, seed=7, n_ctx=4)
     e2.set_class_bank(tok2, 4, CR.ctx_from_tokens(synth.make_state_dict(rn, 11), synth.ctx_token_ids_default(rn, 4)), L.TEXT_SHARED)
-    with pytest.raises(L.RlcfError):
-        e2.tta_sample_ln(views, TTAConfig(selection_p=0.5))
-    with pytest.raises(L.RlcfError):
-        e2.tta_batch_ln(views[None], TTAConfig(selection_p=0.5))
+    o = e2.tta_sample_ln(views, TTAConfig(selection_p=0.5))
+    assert torch.isfinite(o["final_logits"]).all() and torch.isfinite(o["ln_grad"]).all() and o["ln_grad"].abs().max() > 0
+    with pytest.raises(L.RlcfError, match="BatchNorm"):
+        e2.tta_sample_visual(views, TTAConfig(selection_p=0.5))
     e2.close()
 
 
@@ -963,14 +963,83 @@ def test_visual_tuning_matches_reference_fixture(L, dev, name, prec):
     eng.close()
 
 
-def test_visual_tuning_refuses_resnet_student(L, dev):
+BN_NAMES = ["bn_tiny_train", "bn_tiny_train_s3", "bn_tiny_prior0", "bn_tiny_prior16_s3", "bn_rn50_train", "bn_rn50_prior16"]
+
+
+@pytest.mark.parametrize("prec", [0, 2])
+@pytest.mark.parametrize("name", BN_NAMES)
+def test_bn_tuning_matches_reference_fixture(L, dev, name, prec):
+    """Row a-R: a ModifiedResNet student under CLIPCLS_TTA(only_norm=True) -- rlcf_tta_sample_ln tunes its BatchNorm weights / biases --
+    vs the reference's own run (tune_cls_rl.py harness body, nn.BatchNorm2d train mode or `_modified_bn_forward` under --prior_strength;
+    tests/golden/make_golden.py groups bn / bnrn50): selection, sampled classes, rewards, the BatchNorm gradient, the adapted parameters,
+    the running statistics the final inference saw and its logits (taken, as the reference takes them, with the norm layers still in
+    train mode)."""
+    g, meta = load_golden(name)
     from rlcf_amd.engine import Engine
-    sg, rg = synth.GEOMETRIES["tiny-rn32"], synth.GEOMETRIES["tiny-r"]
-    eng = Engine(sg, rg, 8, 16, 0)
-    eng.load_state_dict(L.STUDENT, synth.make_state_dict(sg, 11, device=dev))
-    eng.load_state_dict(L.REWARD, synth.make_state_dict(rg, 23, device=dev))
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"], device=dev)
+    rsd = synth.make_state_dict(rg, meta["reward_seed"], device=dev)
+    eng = Engine(sg, rg, meta["n_views"], meta["n_cls"], prec)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
     eng.finalize()
-    with pytest.raises(L.RlcfError, match="VisionTransformer"):
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]), device=dev)].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
+    eng.set_bn_prior_strength(meta["prior_strength"])
+    keys = RR.visual_bn_keys({k: v for k, v in ssd.items()})
+    assert int(eng.lib.rlcf_engine_ln_param_count(eng.h)) == sum(ssd[k].numel() for k in keys) == g["ln_grad"].numel()
+    torch.testing.assert_close(eng.ln_params(pristine=True).cpu(), torch.cat([ssd[k].reshape(-1) for k in keys]).cpu(), atol=0, rtol=0)
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution, device=dev)
+    o = eng.tta_sample_ln(views, _cfg_from_meta(meta))
+    torch.cuda.synchronize()
+    c = lambda k: o[k].cpu()
+    assert c("selected_idx").tolist() == g["selected_idx"].tolist()
+    assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
+    assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
+    torch.testing.assert_close(c("logits"), g["logits"], atol=2e-3, rtol=0)
+    torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
+    # The float32 gradient of the REFERENCE is itself only good to `ref_err` of its norm here (2e-6 on the tiny towers, 1e-4 .. 7e-3 at
+    # RN50: tests/golden/make_bn_f64.py has the why), so the HIP gradient is judged against the float64 value of the (reference-pinned)
+    # oracle -- no further from it than twice the reference is -- and against the float32 fixture at the width of that noise band.
+    z64 = np.load(os.path.join(GOLDEN, name + "_f64.npz"))
+    g64, ref_err = torch.from_numpy(z64["ln_grad"]), float(z64["ref_err"])
+    gr, og = g["ln_grad"], c("ln_grad")
+    assert gr.norm() > 0
+    assert (og.double() - g64).norm() / g64.norm() < max(2e-3, 2 * ref_err)
+    assert (og - gr).norm() / gr.norm() < max(3e-3, 3 * ref_err)
+    if meta["tta_steps"] == 1:          # Adam's first step is -lr sign(g): all but the elements whose gradient is ~0 move alike
+        d = (c("ln_after") - g["ln_after"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < (0.01 if ref_err < 1e-4 else 0.05)
+    st, gs = eng.bn_stats().cpu(), g["bn_stats_after"]
+    assert st.numel() == gs.numel()
+    torch.testing.assert_close(st, gs, atol=2e-4, rtol=2e-3)
+    if meta["prior_strength"] >= 0:                       # `_modified_bn_forward` never writes the running statistics
+        torch.testing.assert_close(st, eng.bn_stats(pristine=True).cpu(), atol=0, rtol=0)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3, rtol=0)
+    # every sample starts from the checkpoint's parameters AND running statistics; the frozen-student prompt path is untouched
+    o2 = eng.tta_sample_ln(views, _cfg_from_meta(meta))
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(eng.ln_params().cpu(), eng.ln_params(pristine=True).cpu(), atol=0, rtol=0)
+    eng.close()
+
+
+def test_bn_tuning_batch_and_refusals(L, dev):
+    """rlcf_tta_batch_ln with a ResNet student runs the samples one by one (the batch statistics couple one sample's views);
+    every-parameter tuning of a ResNet student is refused loudly."""
+    from rlcf_amd.engine import TTAConfig
+    N, n_cls = 8, 16
+    cfg = TTAConfig(selection_p=0.5, lr=1e-3, tta_steps=1)
+    eng, *_ = make_engine(("tiny-rn", "tiny-r"), N, n_cls, L.TEXT_SHARED, prec=2)
+    vs = torch.stack([synth.make_views(1000 + i, N, synth.GEOMETRIES["tiny-rn"].image_resolution) for i in range(3)]).to(dev)
+    ref = [eng.tta_sample_ln(vs[i], cfg) for i in range(3)]
+    top5, fl = eng.tta_batch_ln(vs, cfg, want_logits=True)
+    for i in range(3):
+        assert top5[i].tolist() == ref[i]["top5"].tolist()
+        torch.testing.assert_close(fl[i], ref[i]["final_logits"][0], atol=1e-5, rtol=0)
+    g, meta = load_golden("bn_tiny_train")
+    torch.testing.assert_close(fl[0].cpu(), g["final_logits"][0], atol=5e-3, rtol=0)
+    with pytest.raises(L.RlcfError, match="VisionTransformer|BatchNorm"):
         eng.visual_layout()
     eng.close()
 
@@ -1039,6 +1108,46 @@ def test_cls_tta_harness_surface(L, dev):
     assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
     with pytest.raises(NotImplementedError):
         custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=False)
+    runtime.reset_session()
+
+
+@pytest.mark.parametrize("name", ["bn_tiny_train", "bn_tiny_prior16_s3"])
+def test_cls_tta_harness_resnet_student(L, dev, name):
+    """TPT/tune_cls_rl.py call sequence with rlcf_amd.custom_clip.CLIPCLS_TTA(arch = a ModifiedResNet, only_norm=True) and
+    --prior_strength: model.train() -> test_time_tuning -> model.eval() -> model(image), against the reference's own run of it."""
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime, tpt_cls_rl
+    g, meta = load_golden(name)
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    clip_store.register_checkpoint("tiny-rn", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+    bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
+                                 min_entropy_reg=0, min_entropy_w=0.2, reward_arch="tiny-r", multiple_reward_models=0,
+                                 sample_k=meta["sample_k"], reward_amplify=False, reward_process=True, process_batch=False,
+                                 prior_strength=meta["prior_strength"])
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny-rn", prompt_prefix="a_photo_of_a", only_visual=True, only_norm=True)
+    assert model.resnet and model.ln.numel() == g["ln_after"].numel()
+    model.set_prior_strength(args.prior_strength)                      # tune_cls_rl.py:73-76
+    reward_model = clip_reward.get_reward_model(dev, args)
+    reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+    optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution).to(dev)
+    for _ in range(2):                                                 # the second pass starts from the same reset state
+        model.reset()
+        optimizer.load_state_dict(optim_state)
+        model.train()
+        tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+        model.eval()
+        out = model(views[:1])
+        torch.testing.assert_close(out.cpu(), g["final_logits"], atol=2e-3, rtol=0)
+        assert out.topk(5).indices[0].tolist() == g["top5"].tolist()
+    with pytest.raises(NotImplementedError, match="BatchNorm"):
+        custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny-rn", prompt_prefix="a_photo_of_a", only_visual=True, only_norm=False)
     runtime.reset_session()
 
 

@@ -232,6 +232,34 @@ def test_ln_tuning_oracle_matches_reference(name):
     assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
 
 
+BN_CASES = ["bn_tiny_train", "bn_tiny_train_s3", "bn_tiny_prior0", "bn_tiny_prior16_s3", "bn_rn50_prior16"]
+
+
+@pytest.mark.parametrize("name", BN_CASES)
+def test_bn_tuning_oracle_matches_reference(name):
+    """ModifiedResNet student under CLIPCLS_TTA(only_norm=True) (tune_cls_rl.py; BatchNorm weights / biases tuned, nn.BatchNorm2d train
+    mode or `_modified_bn_forward` under --prior_strength) vs oracle.tta_sample_ln: also the running statistics the reference's final
+    inference saw, and its logits taken with the norm layers still in train mode (custom_clip.py:487-497)."""
+    g, meta = load(name)
+    sg = synth.GEOMETRIES[meta["student"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    rsd = synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
+    o = R.tta_sample_ln(ssd, rsd, views, tokens, hyper(meta), prior_strength=meta["prior_strength"])
+    assert torch.equal(o["selected_idx"], g["selected_idx"])
+    assert torch.equal(o["topk_idx"], g["topk_idx"])
+    assert torch.equal(o["top5"], g["top5"])
+    torch.testing.assert_close(o["logits"], g["logits"], atol=2e-4, rtol=0)
+    torch.testing.assert_close(o["rewards"], g["rewards"], atol=2e-5, rtol=1e-4)
+    gr, og = g["ln_grad"], o["ln_grad"]
+    assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 1e-3
+    d = (o["ln_after"] - g["ln_after"]).abs()
+    assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+    torch.testing.assert_close(o["bn_stats_after"], g["bn_stats_after"], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(o["final_logits"], g["final_logits"], atol=1e-3, rtol=0)
+
+
 VIS_CASES = ["vis_tiny_s1", "vis_tiny_s3", "vis_tinyp6_s3", "vis_small_s1"]
 
 
