@@ -180,7 +180,7 @@ struct rlcf_engine {
     // sample batch runs beside the student tower of the next part, tta_batch_pipelined) ...
     // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
-    DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog;
+    DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
     int bn_prior_strength = -1;
     std::vector<float*> bn_z, bn_y;  // per unit: pre-BatchNorm GEMM output and the unit's output, inside bn_saved
     std::vector<float*> bn_ms;       // per unit: (mean | rstd) used by the pass, inside bn_scratch

@@ -262,6 +262,8 @@ static int rn_ensure(rlcf_engine* e, const ResNetW& r, int chunk, int T) {
     return RLCF_OK;
 }
 
+// kernels that end in one atomicMax per block: few, fat blocks (thousands of atomics on one address cost more than the pass itself)
+static inline dim3 grid_amax(long total) { return dim3((unsigned)std::min<long>((total + 255) / 256, 2048)); }
 static inline dim3 grid_for(long total) { return dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)); }
 
 // conv (+folded bn) (+identity) (+relu) on an NHWC activation; 3x3 goes through the patch matrix
@@ -426,18 +428,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
     }
 }
-// stage 2: batch mean / variance (double, chunks in order), the statistics the pass normalises with, running-statistics update.
+// stage 2: batch mean / variance (double; block = 64 channels x 16 chunk groups meeting in LDS in a fixed order), the statistics the
+// pass normalises with, running-statistics update.
 //   mode 0: eval (running statistics)   1: train (batch statistics, running <- 0.9 running + 0.1 batch, unbiased variance)
 //   2: prior blend (prior * running + (1 - prior) * batch with the UNBIASED batch variance; running untouched)
 // ms[c] = mean used, ms[C + c] = 1 / sqrt(var used + eps)
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int chunks, long M, int C, float* __restrict__ rmean, float* __restrict__ rvar,
-                                      float* __restrict__ ms, int mode, float prior) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part, int chunks, long M, int C, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, float* __restrict__ ms, int mode, float prior) {
+    __shared__ double r1[16][64], r2[16][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+    double s = 0.0, s2 = 0.0;
+    if (mode != 0 && c < C)
+        for (int k = q; k < chunks; k += 16) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+    r1[q][l] = s; r2[q][l] = s2;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
     float mu_u = rmean[c], var_u = rvar[c];
     if (mode != 0) {
-        double s = 0.0, s2 = 0.0;
-        for (int k = 0; k < chunks; ++k) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+        s = 0.0; s2 = 0.0;
+        for (int k = 0; k < 16; ++k) { s += r1[k][l]; s2 += r2[k][l]; }
         const double mu = s / (double)M;
         double var = s2 / (double)M - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -454,9 +463,23 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int chunks
     ms[c] = mu_u;
     ms[C + c] = 1.0f / sqrtf(var_u + BN_EPS);
 }
+// block-wide max of non-negative floats -> one atomicMax (their bit patterns order like the values)
+__device__ __forceinline__ void block_amax(float m, unsigned int* __restrict__ out) {
+    __shared__ float red[16];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        atomicMax(out, __float_as_uint(m));
+    }
+}
 // y = gamma (z - mean) rstd + beta (+ identity) (ReLU); 4 channels per thread
-__global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ ms, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ idn, float* __restrict__ y, long total4, int C, int relu) {
+// amax (optional): receives max|y| (the split-f16 operand scale of the convolution that reads y needs no pass of its own)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ ms, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ idn, float* __restrict__ y,
+                                                       long total4, int C, int relu, unsigned int* __restrict__ amax) {
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         const float4 v = ((const float4*)z)[i];
@@ -465,7 +488,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __rest
         if (idn) { const float4 r = ((const float4*)idn)[i]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
         if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
         ((float4*)y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
+    if (amax) block_amax(am, amax);
 }
 // backward stage 1: g = dy (* [y > 0] when the unit ends in a ReLU); part[chunk, 0, c] = sum g, part[chunk, 1, c] = sum g x_hat
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
@@ -490,13 +515,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         part[((size_t)blockIdx.y * 2 + 1) * C + c] = (s2[0][l] + s2[1][l]) + (s2[2][l] + s2[3][l]);
     }
 }
-// backward stage 2: sums[c] = d beta, sums[C + c] = d gamma (chunks added in order); grads written when the unit is tuned
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// backward stage 2: sums[c] = d beta, sums[C + c] = d gamma (block = 64 channels x 16 chunk groups, fixed order); grads written when
+// the unit is tuned
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float r1[16][64], r2[16][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
     float s = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int k = q; k < chunks; k += 16) { s += part[((size_t)k * 2) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+    r1[q][l] = s; r2[q][l] = s2;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+    s = 0.f; s2 = 0.f;
+    for (int k = 0; k < 16; ++k) { s += r1[k][l]; s2 += r2[k][l]; }
     sums[c] = s; sums[C + c] = s2;
     if (dgamma) { dgamma[c] = s2; dbeta[c] = s; }
 }
@@ -504,8 +536,10 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ part, int chunks, 
 // flows into the identity branch of a block's last unit
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
                                     const float* __restrict__ ms, const float* __restrict__ gamma, const float* __restrict__ sums,
-                                    float* __restrict__ dz, float* __restrict__ gout, long total, long M, int C, int relu, int through_stats) {
+                                    float* __restrict__ dz, float* __restrict__ gout, long total, long M, int C, int relu, int through_stats,
+                                    unsigned int* __restrict__ amax) {
     const float invM = 1.0f / (float)M;
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float g = dy[i];
@@ -514,8 +548,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         const float rs = ms[C + c];
         float t = g;
         if (through_stats) t -= (sums[c] + (z[i] - ms[c]) * rs * sums[C + c]) * invM;
-        dz[i] = gamma[c] * rs * t;
+        const float o = gamma[c] * rs * t;
+        dz[i] = o;
+        am = fmaxf(am, fabsf(o));
     }
+    if (amax) block_amax(am, amax);
 }
 // AvgPool2d(2) backward on NHWC: din[img, 2y+a, 2x+b, c] = dout[img, y, x, c] / 4
 __global__ void avgpool2_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long total_in, int C, int Ho, int Wo) {
@@ -748,12 +785,14 @@ static inline const float* bn_gamma(const rlcf_engine* e, const BnUnit& u) { ret
 static inline const float* bn_beta(const rlcf_engine* e, const BnUnit& u) { return u.pofs >= 0 ? e->ln_params.as<float>() + u.pofs + u.raw.cout : u.beta0; }
 
 // conv (unfolded) -> batch statistics -> normalise (+ identity) (+ ReLU).  z / y: where the GEMM output and the unit's output go
-static int bn_unit_fwd(const BnPass& P, int ui, const float* in, int H, int W, int stride, bool nchw, const float* idn, bool relu, float* z, float* y) {
+// in_unit: the unit whose output (or an average pool of it: same bound) `in` is, -1 = unknown range (the images)
+static int bn_unit_fwd(const BnPass& P, int ui, const float* in, int in_unit, int H, int W, int stride, bool nchw, const float* idn, bool relu,
+                       float* z, float* y) {
     rlcf_engine* e = P.e;
     const BnUnit& u = P.m->rn.units[ui];
     const int Ho = H / stride, Wo = W / stride, C = u.raw.cout;
     const long M = (long)P.n * Ho * Wo;
-    TRY(conv(e, u.raw, in, nullptr, P.n, H, W, stride, nchw, nullptr, RLCF_EPI_NONE, z, nullptr, P.st));
+    TRY(conv(e, u.raw, in, in_unit >= 0 ? e->bn_amax.as<float>() + in_unit : nullptr, P.n, H, W, stride, nchw, nullptr, RLCF_EPI_NONE, z, nullptr, P.st));
     const int chunks = (int)((M + BN_ROWS - 1) / BN_ROWS);
     TRY(e->bn_grad_c.ensure((size_t)chunks * 2 * C * sizeof(float)));
     float* ms = e->bn_ms[ui];
@@ -762,10 +801,11 @@ static int bn_unit_fwd(const BnPass& P, int ui, const float* in, int H, int W, i
         bn_stats_partial_kernel<<<dim3((C + 63) / 64, chunks), dim3(256), 0, P.st>>>(z, e->bn_grad_c.as<float>(), M, C);
         RLCF_LAUNCH_CHECK();
     }
-    bn_stats_final_kernel<<<dim3((C + 127) / 128), dim3(128), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, M, C, st_, st_ + C, ms, P.mode, P.prior);
+    bn_stats_final_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, M, C, st_, st_ + C, ms, P.mode, P.prior);
     RLCF_LAUNCH_CHECK();
     const long total4 = M * C / 4;
-    bn_apply_kernel<<<grid_for(total4), dim3(256), 0, P.st>>>(z, ms, bn_gamma(e, u), bn_beta(e, u), idn, y, total4, C, relu ? 1 : 0);
+    bn_apply_kernel<<<grid_amax(total4), dim3(256), 0, P.st>>>(z, ms, bn_gamma(e, u), bn_beta(e, u), idn, y, total4, C, relu ? 1 : 0,
+                                                              e->bn_amax.as<unsigned int>() + ui);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
@@ -823,19 +863,22 @@ int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, f
     int H = R / 2;
     auto Z = [&](int ui) { return e->bn_z[ui]; };
     auto Y = [&](int ui) { return e->bn_y[ui]; };
-    TRY(bn_unit_fwd(P, 0, images, R, R, 2, true, nullptr, true, Z(0), Y(0)));
-    TRY(bn_unit_fwd(P, 1, Y(0), H, H, 1, false, nullptr, true, Z(1), Y(1)));
-    TRY(bn_unit_fwd(P, 2, Y(1), H, H, 1, false, nullptr, true, Z(2), Y(2)));
+    TRY(e->bn_amax.ensure((size_t)2 * nu * sizeof(float)));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->bn_amax.p, 0, (size_t)nu * sizeof(float), st));
+    TRY(bn_unit_fwd(P, 0, images, -1, R, R, 2, true, nullptr, true, Z(0), Y(0)));
+    TRY(bn_unit_fwd(P, 1, Y(0), 0, H, H, 1, false, nullptr, true, Z(1), Y(1)));
+    TRY(bn_unit_fwd(P, 2, Y(1), 1, H, H, 1, false, nullptr, true, Z(2), Y(2)));
     H /= 2;
     float* xin = pooled;
     pooled += (size_t)n * H * H * w;
     TRY(avgpool2(Y(2), xin, n, H, H, w, st));
     const float* x = xin;                                          // block input
+    int xu = 2;                                                    // ... and the unit it came from
     for (size_t bi = 0; bi < r.blocks.size(); ++bi) {
         const BottleW& b = r.blocks[bi];
         const int u0 = r.block_unit[bi], planes = b.c1.cout, Ho = H / b.stride;
-        TRY(bn_unit_fwd(P, u0, x, H, H, 1, false, nullptr, true, Z(u0), Y(u0)));
-        TRY(bn_unit_fwd(P, u0 + 1, Y(u0), H, H, 1, false, nullptr, true, Z(u0 + 1), Y(u0 + 1)));
+        TRY(bn_unit_fwd(P, u0, x, xu, H, H, 1, false, nullptr, true, Z(u0), Y(u0)));
+        TRY(bn_unit_fwd(P, u0 + 1, Y(u0), u0, H, H, 1, false, nullptr, true, Z(u0 + 1), Y(u0 + 1)));
         const float* t2 = Y(u0 + 1);
         const float* xp = x;
         if (b.stride > 1) {
@@ -850,11 +893,12 @@ int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, f
         }
         const float* idn = x;
         if (b.has_down) {
-            TRY(bn_unit_fwd(P, u0 + 3, xp, Ho, Ho, 1, false, nullptr, false, Z(u0 + 3), Y(u0 + 3)));
+            TRY(bn_unit_fwd(P, u0 + 3, xp, xu, Ho, Ho, 1, false, nullptr, false, Z(u0 + 3), Y(u0 + 3)));
             idn = Y(u0 + 3);
         }
-        TRY(bn_unit_fwd(P, u0 + 2, t2, Ho, Ho, 1, false, idn, true, Z(u0 + 2), Y(u0 + 2)));
+        TRY(bn_unit_fwd(P, u0 + 2, t2, u0 + 1, Ho, Ho, 1, false, idn, true, Z(u0 + 2), Y(u0 + 2)));
         x = Y(u0 + 2);
+        xu = u0 + 2;
         H = Ho;
     }
     // attention pool (model.py:68-91), probabilities kept for the backward
@@ -889,31 +933,31 @@ static int bn_unit_bwd(const BnPass& P, int ui, const float* dy, long M, bool re
     bn_bwd_partial_kernel<<<dim3((C + 63) / 64, chunks), dim3(256), 0, P.st>>>(dy, y, z, ms, e->bn_grad_c.as<float>(), M, C, relu ? 1 : 0);
     RLCF_LAUNCH_CHECK();
     float* dg = (bn_grad && u.pofs >= 0) ? bn_grad + u.pofs : nullptr;
-    bn_bwd_final_kernel<<<dim3((C + 127) / 128), dim3(128), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, C, e->bn_grad_a.as<float>(), dg, dg ? dg + C : nullptr);
+    bn_bwd_final_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, C, e->bn_grad_a.as<float>(), dg, dg ? dg + C : nullptr);
     RLCF_LAUNCH_CHECK();
     if (dz) {
         const long total = M * C;
-        bn_bwd_apply_kernel<<<grid_for(total), dim3(256), 0, P.st>>>(dy, y, z, ms, bn_gamma(e, u), e->bn_grad_a.as<float>(), dz, gout, total, M, C,
-                                                                     relu ? 1 : 0, P.mode == 1 ? 1 : 0);
+        bn_bwd_apply_kernel<<<grid_amax(total), dim3(256), 0, P.st>>>(dy, y, z, ms, bn_gamma(e, u), e->bn_grad_a.as<float>(), dz, gout, total, M, C,
+                                                                     relu ? 1 : 0, P.mode == 1 ? 1 : 0,
+                                                                     e->bn_amax.as<unsigned int>() + P.m->rn.units.size() + ui);
         RLCF_LAUNCH_CHECK();
     }
     return RLCF_OK;
 }
-// dX of a convolution unit: dz [M, cout] -> dx [M_in, cin] (stride-1 units only); res (optional) is added
+// dX of a convolution unit: dz [M, cout] -> dx [M, cin] (stride-1 units only); res (optional) is added.  A 1x1 convolution's dX is
+// the 1x1 convolution with the transposed weight, a 3x3 (pad 1) one's the 3x3 convolution with the flipped, channel-transposed kernel:
+// both go through conv(), the operand scale from max|dz| (bn_bwd_apply_kernel left it in the unit's slot)
 static int bn_conv_dx(const BnPass& P, int ui, const float* dz, int H, int W, const float* res, float* dx) {
     rlcf_engine* e = P.e;
     const BnUnit& u = P.m->rn.units[ui];
-    const long M = (long)P.n * H * W;
-    if (u.raw.k == 1)
-        return engine_gemm(e, dz, u.raw.cout, u.wT, u.KpT, nullptr, res, u.raw.cin, dx, u.raw.cin, (int)M, u.raw.cin, u.raw.cout, RLCF_EPI_NONE, P.st);
-    const long total = M * u.KpT;
-    TRY(e->rn_col.ensure((size_t)total * sizeof(float)));
-    if (prec_x3(e) && (size_t)total > e->a_split_elems) { TRY(e->a_hi.ensure((size_t)total * 4)); e->a_split_elems = (size_t)total; }
-    const int Co = u.raw.cout;
-    im2col3x3_kernel<<<grid_for(total), dim3(256), 0, P.st>>>(dz, e->rn_col.as<float>(), total, Co, H, W, H, W, 1, u.KpT, (long)Co * H * W, 1,
-                                                             (long)W * Co, Co);
-    RLCF_LAUNCH_CHECK();
-    return engine_gemm(e, e->rn_col.as<float>(), u.KpT, u.wT, u.KpT, nullptr, res, u.raw.cin, dx, u.raw.cin, (int)M, u.raw.cin, u.KpT, RLCF_EPI_NONE, P.st);
+    ConvW t{};
+    t.w = u.wT; t.b = nullptr; t.cin = u.raw.cout; t.cout = u.raw.cin; t.k = u.raw.k; t.Kp = u.KpT;
+    if (t.k == 3) {
+        const size_t total = (size_t)P.n * H * W * t.Kp;
+        TRY(e->rn_col.ensure(total * sizeof(float)));
+        if (prec_x3(e) && total > e->a_split_elems) { TRY(e->a_hi.ensure(total * 4)); e->a_split_elems = total; }
+    }
+    return conv(e, t, dz, e->bn_amax.as<float>() + P.m->rn.units.size() + ui, P.n, H, W, 1, false, res, RLCF_EPI_NONE, dx, nullptr, P.st);
 }
 static int avgpool2_bwd(const float* dout, float* din, int n, int Ho, int Wo, int C, hipStream_t st) {
     const long total = (long)n * 4 * Ho * Wo * C;
@@ -931,6 +975,7 @@ int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, floa
     if (e->bn_saved_n != n) { rlcf_set_error("rn_backward_bn: the saved pass holds %d images, not %d", e->bn_saved_n, n); return RLCF_ERR_STATE; }
     const int mode = e->bn_prior_strength >= 0 ? 2 : 1;
     BnPass P{e, &m, st, n, mode, 0.f, true};
+    RLCF_HIP_CHECK(hipMemsetAsync(e->bn_amax.as<float>() + r.units.size(), 0, r.units.size() * sizeof(float), st));
     float *G0 = e->rn_buf[0].as<float>(), *G1 = e->rn_buf[1].as<float>(), *G2 = e->rn_buf[2].as<float>(), *G3 = e->rn_buf[3].as<float>(),
           *G4 = e->rn_buf[4].as<float>();
     // features -> attention pool

@@ -8,9 +8,10 @@ arch = sys.argv[1] if len(sys.argv) > 1 else "ViT-L/14"
 n_cls = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda:0")
 geo = synth.GEOMETRIES[arch]
-ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(geo, 23, device=dev)
+rgeo = synth.GEOMETRIES[os.environ.get("REWARD_ARCH", arch)]             # (a ResNet ARCH: BatchNorm tuning, row a-R)
+ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(rgeo, 23, device=dev)
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # test images per tower pass (rlcf_tta_batch_ln)
-eng = Engine(geo, geo, 64 * B, n_cls, L.PREC_F16X3)
+eng = Engine(geo, rgeo, 64 * B, n_cls, L.PREC_F16X3)
 eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
 tokens = synth.make_token_bank(geo, n_cls, seed=7, n_ctx=4)
 ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(geo, 4), device=dev)].clone()
