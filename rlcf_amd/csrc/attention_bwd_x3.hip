@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const float* _
                                                                   const float* __restrict__ lse, const float* __restrict__ dout,
                                                                   const unsigned int* __restrict__ amax_dout,
                                                                   const rlcf_seq* __restrict__ seqs, int width, int causal,
-                                                                  float* __restrict__ dqkv) {
+                                                                  float* __restrict__ dqkv, float* __restrict__ park, int park_rows) {
     extern __shared__ __attribute__((aligned(16))) char bx_smem[];
     const rlcf_seq sq = seqs[blockIdx.y];
     const int head = blockIdx.z, q0 = blockIdx.x * 32;
@@ -217,10 +217,16 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const float* _
             for (int r = 0; r < 16; ++r) {
                 const int kap = k0 + mfma32_row(r, h);
                 if (kap < nk) {
-                    const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
-                    float* base = dqkv + (size_t)row * ld + head * HEAD_DIM + l32;
-                    atomicAdd(base + 2 * width, dv0[r] * fv); atomicAdd(base + 2 * width + 32, dv1[r] * fv);
-                    atomicAdd(base + width, dk0[r] * fk);     atomicAdd(base + width + 32, dk1[r] * fk);
+                    if (park) {        // (no shared prefix) this query block's contribution to key kap, parked: [seq][q block][key][K | V]
+                        float* base = park + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * park_rows + kap) * (2 * width) + head * HEAD_DIM + l32;
+                        base[width] = dv0[r] * fv; base[width + 32] = dv1[r] * fv;
+                        base[0] = dk0[r] * fk;     base[32] = dk1[r] * fk;
+                    } else {
+                        const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                        float* base = dqkv + (size_t)row * ld + head * HEAD_DIM + l32;
+                        atomicAdd(base + 2 * width, dv0[r] * fv); atomicAdd(base + 2 * width + 32, dv1[r] * fv);
+                        atomicAdd(base + width, dk0[r] * fk);     atomicAdd(base + width + 32, dk1[r] * fk);
+                    }
                 }
             }
     }
@@ -312,15 +318,40 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_x3_kernel(const float* _
     }
 }
 
+// dK / dV of sequences without a shared prefix: the contributions of a sequence's query blocks, parked by the kernel, added in block order
+__global__ __launch_bounds__(256) void attention_bwd_park_reduce_kernel(const float* __restrict__ park, const rlcf_seq* __restrict__ seqs,
+                                                                        int park_rows, int n_qb, int width, float* __restrict__ dqkv) {
+    const rlcf_seq sq = seqs[blockIdx.y];
+    const int key = blockIdx.x;
+    if (key >= sq.q_len) return;
+    const int nqb = (sq.q_len + 31) / 32, w4 = 2 * width / 4;
+    float4* dst = (float4*)(dqkv + (size_t)(sq.q_start + key) * 3 * width + width);
+    for (int c = threadIdx.x; c < w4; c += 256) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < nqb; ++b) {
+            const float4 v = ((const float4*)(park + (((size_t)blockIdx.y * n_qb + b) * park_rows + key) * (2 * width)))[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        dst[c] = a;
+    }
+}
+
 // amax_dout: device scalar (bit pattern of a non-negative float), max |dout| over the whole matrix (launch_absmax)
+// park (optional; sequences WITHOUT a shared prefix only: the image towers): n_seq * ceil(max_q_len / 32) * max_q_len * 2 * width floats;
+// with it dK / dV are bit-reproducible (parked per query block, added in block order) and dqkv needs no zero fill
 int launch_attention_bwd_x3(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,
-                            int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st) {
+                            int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st, float* park) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_q_len > 0 && qkv && out && lse && dout && dqkv && amax_dout);
     const size_t bytes = (size_t)(4 * 64 * BX_TLD + 4 * BX_CHUNK * BX_KLD + 2 * 2 * 64 * BX_TLD) * sizeof(_Float16) + 64 * sizeof(float);
     { int rc_ = rlcf_func_lds((const void*)attention_bwd_x3_kernel, bytes); if (rc_ != RLCF_OK) return rc_; }
     dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
     RLCF_ARG_CHECK(grid.y <= 65535);
-    attention_bwd_x3_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, (const unsigned int*)amax_dout, seqs, width, causal, dqkv);
+    attention_bwd_x3_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, (const unsigned int*)amax_dout, seqs, width, causal, dqkv, park,
+                                                            max_q_len);
     RLCF_LAUNCH_CHECK();
+    if (park) {
+        attention_bwd_park_reduce_kernel<<<dim3(max_q_len, n_seq), dim3(256), 0, st>>>(park, seqs, max_q_len, (int)grid.x, width, dqkv);
+        RLCF_LAUNCH_CHECK();
+    }
     return RLCF_OK;
 }

@@ -181,6 +181,7 @@ struct rlcf_engine {
     // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
     DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
+    DevBuf parts_ws, attn_park;      // scratch of the bit-reproducible reductions: parameter-gradient partial sums; dK / dV per query block
     int bn_prior_strength = -1;
     std::vector<float*> bn_z, bn_y;  // per unit: pre-BatchNorm GEMM output and the unit's output, inside bn_saved
     std::vector<float*> bn_ms;       // per unit: (mean | rstd) used by the pass, inside bn_scratch

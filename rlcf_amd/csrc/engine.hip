@@ -58,6 +58,8 @@ static inline size_t ws_bytes(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 
 // image-tower scratch / A-operand split buffer of the stream whose launches are being enqueued (see ws_sel)
 #define IMG_BUF(e, name) ((e)->ws_sel ? (e)->side_img.name : (e)->name)
 static inline void* a_ptr(rlcf_engine* e) { return e->ws_sel ? e->a_hi2.p : e->a_hi.p; }
+// scratch of the bit-reproducible parameter-gradient reductions (rowops.hip: per-wave partial sums added in a fixed order)
+#define PARTS_WS(e) (e)->parts_ws.as<float>(), ((e)->parts_ws.p ? RLCF_PARTS_WS_FLOATS : (size_t)0)
 static inline size_t a_cap(const rlcf_engine* e) { return e->ws_sel ? e->a_split2_elems : e->a_split_elems; }
 static inline void* lo_of(void* hi) { return (char*)hi + 64; }
 static inline const void* lo_of(const void* hi) { return (const char*)hi + 64; }
@@ -497,7 +499,7 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
         prof_end(slot, st);
     }
     TRY(rc);
-    if (db) TRY(launch_colsum(dY, ldy, T, N, db, st));
+    if (db) TRY(launch_colsum(dY, ldy, T, N, db, st, PARTS_WS(e)));
     return RLCF_OK;
 }
 
@@ -636,6 +638,7 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
     const int W = w.width, L = w.layers;
     if (wgrad_base && !wslots) wslots = e->vw_slots.data() + 4;      // image encoder: class_embedding, positional_embedding, proj, conv1 come first
     float *dX = e->dX.as<float>(), *dA = e->dA.as<float>(), *dH = e->dH.as<float>(), *dF = e->dF.as<float>(), *dQKV = e->dQKV.as<float>();
+    if (ln_grad || wgrad_base) TRY(e->parts_ws.ensure(RLCF_PARTS_WS_FLOATS * sizeof(float)));
     for (int l = L - 1; l >= 0; --l) {
         const BlockW& b = w.blk[l];
         const SavedLayer& s = ws.sv[l];
@@ -661,21 +664,30 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         {   // profile record of kind 13: LayerNorm backward, HBM-bound — `flops` carries its ALGORITHMIC BYTES (x, dy, residual gradient in, dx out)
             const int ls = prof_begin(st, (double)T * W * 16.0, T, W, 0);
             const int lrc = launch_layernorm_bwd(s.x1, g2w.p, dH, dX, dX, g1 ? g1 + 2 * W : nullptr, g1 ? g1 + 3 * W : nullptr, T, W, st, group_rows,
-                                                 group_stride, group_rows > 0 ? g2w.group_stride : 0);
+                                                 group_stride, group_rows > 0 ? g2w.group_stride : 0, PARTS_WS(e));
             prof_end(ls, st, 13);
             TRY(lrc);
         }
         if (wgrad_base) TRY(wgrad(e, dX, W, W, s.a, W, W, T, G[2], G[3], st));      // out_proj: x1 = x + a Wo^T + b, dY = d x1
         TRY(gemm(e, dX, W, b.out_wT, W, nullptr, nullptr, 0, nullptr, 0, dA, W, T, W, W, 1.f, RLCF_EPI_NONE, st, 1.0f, true));
-        RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         static int bwd_f32 = -1;                                // RLCF_ATTN_BWD_F32=1: the f32-MFMA backward also in split-f16 mode (benchmarks)
         if (bwd_f32 < 0) { const char* ev = getenv("RLCF_ATTN_BWD_F32"); bwd_f32 = ev ? atoi(ev) : 0; }
         // profile record of kind 12: the attention backward (flops = 10 * pairs * W; dims = rows, width, longest sequence)
         const int pslot = prof_begin(st, 10.0 * attn_pairs * W, T, W, max_q_len > 0 ? max_q_len : max_keys);
+        // image towers (no shared prefix, max_q_len given): dK / dV parked per query block and added in block order (bit-reproducible,
+        // and dQKV needs no zero fill); beyond 16 GB of parking space (or RLCF_ATTN_BWD_ATOMIC=1) they meet by atomicAdd
+        static int bwd_atomic = -1;
+        if (bwd_atomic < 0) { const char* ev = getenv("RLCF_ATTN_BWD_ATOMIC"); bwd_atomic = ev ? atoi(ev) : 0; }
+        float* park = nullptr;
+        if (max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
+            const size_t need = (size_t)n_seq * ((max_q_len + 31) / 32) * max_q_len * 2 * W * sizeof(float);
+            if (need <= ((size_t)16 << 30)) { TRY(e->attn_park.ensure(need)); park = e->attn_park.as<float>(); }
+        }
+        if (!park) RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96 && prec_x3(e) && !bwd_f32) {
             TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));       // range of dO for the f16 pairs
             TRY(launch_attention_bwd_x3(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal,
-                                        dQKV, st));
+                                        dQKV, st, park));
         } else if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
         else {
             // shared-prefix layouts: the prefix rows' dK / dV are summed in sequence order through a per-sequence workspace (reproducible
@@ -695,7 +707,7 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         {
             const int ls = prof_begin(st, (double)T * W * 16.0, T, W, 0);
             const int lrc = launch_layernorm_bwd(s.x, g1w.p, dH, dX, dX, g1, g1 ? g1 + W : nullptr, T, W, st, group_rows, group_stride,
-                                                 group_rows > 0 ? g1w.group_stride : 0);
+                                                 group_rows > 0 ? g1w.group_stride : 0, PARTS_WS(e));
             prof_end(ls, st, 13);
             TRY(lrc);
         }
@@ -1539,24 +1551,25 @@ static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int
     TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
     float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
     const LnRef gpw = ln_ref(e, m.lnpost_w, 1);
+    TRY(e->parts_ws.ensure(RLCF_PARTS_WS_FLOATS * sizeof(float)));
     TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), gpw.p, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st,
-                             groups > 1 ? per : 0, gs, groups > 1 ? gpw.group_stride : 0));
+                             groups > 1 ? per : 0, gs, groups > 1 ? gpw.group_stride : 0, PARTS_WS(e)));
     RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
     TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
     TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok,
                              groups > 1 ? per * tok : 0, gs, wgrad_base));
     if (!wgrad_base) {
         TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st,
-                                    groups > 1 ? per : 0, gs));
+                                    groups > 1 ? per : 0, gs, PARTS_WS(e)));
         return RLCF_OK;
     }
     // through ln_pre into the embedding (model.py:224-229): pre = [class_embedding | conv1(patches)] + positional_embedding
     float *pre = e->dH.as<float>(), *dpre = e->dA.as<float>(), *dpatch = e->dF.as<float>();      // backward scratch, free by now
     const int G2 = tok - 1, K = 3 * m.cfg.vision_patch_size * m.cfg.vision_patch_size;
     TRY(launch_vit_preln(e->patch_out.as<float>(), m.cls, m.vpos, pre, n, tok, Wv, st));
-    TRY(launch_layernorm_bwd(pre, m.lnpre_w, e->dX.as<float>(), nullptr, dpre, ln_grad, ln_grad + Wv, T, Wv, st));
+    TRY(launch_layernorm_bwd(pre, m.lnpre_w, e->dX.as<float>(), nullptr, dpre, ln_grad, ln_grad + Wv, T, Wv, st, 0, 0, 0, PARTS_WS(e)));
     float* gpos = wgrad_base + e->vw_slots[1].off;
-    TRY(launch_colsum(dpre, tok * Wv, n, tok * Wv, gpos, st));                                     // d positional_embedding = sum over views
+    TRY(launch_colsum(dpre, tok * Wv, n, tok * Wv, gpos, st, PARTS_WS(e)));                                     // d positional_embedding = sum over views
     RLCF_HIP_CHECK(hipMemcpyAsync(wgrad_base + e->vw_slots[0].off, gpos, Wv * sizeof(float), hipMemcpyDeviceToDevice, st));   // d class_embedding = its row 0
     for (int v = 0; v < n; ++v)
         RLCF_HIP_CHECK(hipMemcpyAsync(dpatch + (size_t)v * G2 * Wv, dpre + ((size_t)v * tok + 1) * Wv, (size_t)G2 * Wv * sizeof(float),

@@ -7,7 +7,10 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
                          int group_rows = 0, int group_stride = 0);
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx,
                          float* dgamma, float* dbeta, int rows, int width, hipStream_t st, int group_rows = 0, int group_stride = 0,
-                         int gamma_stride = 0);
+                         int gamma_stride = 0, float* part_ws = nullptr, size_t part_ws_floats = 0);
+// part_ws (launch_layernorm_bwd, launch_colsum, launch_vit_assemble_bwd): caller-owned scratch; with it the parameter / column sums are
+// parked per wave (row block) and added in a fixed order (bit-reproducible), without it they meet by atomicAdd
+#define RLCF_PARTS_WS_FLOATS ((size_t)4224 * 2 * 1024)      // 4096 (+ group round-up) walks x (gamma, beta) x width <= 1024
 // images [n,3,R,R] -> patches [n*G*G, Kp] in (c,i,j) order, zero padded to Kp (f32 and/or a split-f16 pair)
 int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st, int il = 0);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
@@ -32,7 +35,7 @@ int launch_dtxt_dense(const float* dlogits, const float* img, int n, int C, int 
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st);   // out[cols,rows]
 // full image-encoder tuning (weight gradients): out[cols, ld_out] = in[rows, cols]^T zero padded; out[c] += column sums; ln_pre input
 int launch_transpose_pad(const float* in, int ld_in, float* out, int rows, int cols, int ld_out, hipStream_t st);
-int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st);
+int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st, float* part_ws = nullptr, size_t part_ws_floats = 0);
 int launch_vit_preln(const float* patch_out, const float* cls, const float* pos, float* pre, int n, int tokens, int width, hipStream_t st);
 
 int launch_attention_fwd_f32(const float* qkv, const rlcf_seq* seqs, int n_seq, int max_q_len, int width,
@@ -115,11 +118,12 @@ int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* l
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 // split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)
 int launch_attention_bwd_x3(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,
-                            int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
+                            int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st, float* park = nullptr);
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,
                               int width, int causal, float* dqkv, hipStream_t st);
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
-                            int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0);
+                            int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0, float* part_ws = nullptr,
+                            size_t part_ws_floats = 0);
 int launch_dimg(const float* dlogits, const float* txt, int n, int C, int D, float scale, float* dimg, hipStream_t st);
 int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipStream_t st);
 

@@ -254,10 +254,118 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
     }
 }
 
+// ---- bit-reproducible parameter gradients: per-wave partial sums, parked, then added in a fixed order ------------------------------
+// The atomicAdd forms above make dgamma / dbeta depend on the arrival order of ~10^4 partial sums.  Here wave w of group g walks rows
+// [g * group_rows + k * rpw, ... + rpw) (k = w % wpg: a walk never leaves its group) and parks its two column sums in part[w][2][width];
+// colparts_reduce_kernel then adds the wpg partials of a group in order k = 0, 1, ... (16 interleaved sub-sums met in a fixed order).
+__global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ dy, const float* __restrict__ dres,
+                                                                  float* __restrict__ dx, float* __restrict__ part, int rows, int width,
+                                                                  int group_rows, int gamma_stride, int rpw, int wpg, int n_groups) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int g = w / wpg, k = w - g * wpg;
+    if (g >= n_groups) return;
+    const int gend = min(rows, (g + 1) * group_rows), row0 = g * group_rows + k * rpw, row1 = min(gend, row0 + rpw);
+    const float* gm = gamma + (size_t)g * gamma_stride;
+    float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    for (int row = row0; row < row1; ++row) {
+        const float* xr = x + (size_t)row * width;
+        const float* dr = dy + (size_t)row * width;
+        float v[MAX_PER_LANE], d[MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            v[j] = c < width ? xr[c] : 0.f;
+            d[j] = c < width ? dr[c] : 0.f;
+            s += v[j];
+        }
+        const float mu = wave_sum(s) / width;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) { float t = v[j] - mu; q += t * t; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                float xh = (v[j] - mu) * rstd;
+                float gd = d[j] * gm[c];
+                ag[j] += d[j] * xh; ab[j] += d[j];
+                v[j] = xh; d[j] = gd;
+                s1 += gd; s2 += gd * xh;
+            }
+        }
+        s1 = wave_sum(s1) / width;
+        s2 = wave_sum(s2) / width;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                float o = rstd * (d[j] - s1 - v[j] * s2);
+                if (dres) o += dres[(size_t)row * width + c];
+                dx[(size_t)row * width + c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) { part[((size_t)w * 2) * width + c] = ag[j]; part[((size_t)w * 2 + 1) * width + c] = ab[j]; }
+    }
+}
+// out_a[g * stride + c] += sum_k part[g * wpg + k][0][c], out_b likewise from [1]: block = 64 columns x 16 sub-sums (k = q, q + 16, ...)
+__global__ __launch_bounds__(1024) void colparts_reduce_kernel(const float* __restrict__ part, int wpg, int width, float* __restrict__ out_a,
+                                                              float* __restrict__ out_b, int stride) {
+    __shared__ float r1[16][64], r2[16][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + l, g = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    if (c < width)
+        for (int k = q; k < wpg; k += 16) {
+            const size_t w = (size_t)g * wpg + k;
+            a += part[(w * 2) * width + c]; b += part[(w * 2 + 1) * width + c];
+        }
+    r1[q][l] = a; r2[q][l] = b;
+    __syncthreads();
+    if (q != 0 || c >= width) return;
+    a = 0.f; b = 0.f;
+    for (int k = 0; k < 16; ++k) { a += r1[k][l]; b += r2[k][l]; }
+    out_a[(size_t)g * stride + c] += a;
+    if (out_b) out_b[(size_t)g * stride + c] += b;
+}
+// walk plan of the partial-sum kernels: ~4096 waves over all groups, at least 2 rows per wave
+static void parts_plan(int rows, int group_rows, int& rpw, int& wpg, int& n_groups) {
+    n_groups = (rows + group_rows - 1) / group_rows;
+    const int wpg_target = std::max(1, 4096 / n_groups);
+    rpw = std::max(2, (group_rows + wpg_target - 1) / wpg_target);
+    wpg = (group_rows + rpw - 1) / rpw;
+}
+
 int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int width, hipStream_t st, int group_rows, int group_stride, int gamma_stride) {
+                         float* dbeta, int rows, int width, hipStream_t st, int group_rows, int group_stride, int gamma_stride,
+                         float* part_ws, size_t part_ws_floats) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
     if (group_rows == 0) { group_stride = 0; gamma_stride = 0; }
+    if (dgamma && dbeta && part_ws) {                         // bit-reproducible form (the engine's backward passes)
+        int rpw, wpg, ng;
+        parts_plan(rows, group_rows > 0 ? group_rows : rows, rpw, wpg, ng);
+        const size_t waves = (size_t)wpg * ng;
+        if (waves * 2 * width <= part_ws_floats) {
+            layernorm_bwd_parts_kernel<<<dim3((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, st>>>(
+                x, gamma, dy, dres, dx, part_ws, rows, width, group_rows > 0 ? group_rows : rows, gamma_stride, rpw, wpg, ng);
+            RLCF_LAUNCH_CHECK();
+            colparts_reduce_kernel<<<dim3((width + 63) / 64, ng), dim3(1024), 0, st>>>(part_ws, wpg, width, dgamma, dbeta, group_stride);
+            RLCF_LAUNCH_CHECK();
+            return RLCF_OK;
+        }
+    }
     if (dgamma && dbeta && rows >= 256) {
         const int rpw = rows >= 16384 ? LNB_ROWS : rows >= 4096 ? 4 : 2;          // >= 512 waves whenever the matrix allows it
         const int per_block = ROWS_PER_BLOCK * rpw;
@@ -570,8 +678,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     __syncthreads();
     if (q == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st) {
+// ... bit-reproducible: the row blocks park their sums in part[by][cols], colparts_reduce_kernel adds them in order
+__global__ __launch_bounds__(256) void colsum_parts_kernel(const float* __restrict__ in, int ld, int rows, int cols, int rows_per_block,
+                                                           float* __restrict__ part) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < cols) for (int r = r0 + q; r < r1; r += 4) s += in[(size_t)r * ld + c];
+    sm[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        const int l = threadIdx.x;
+        part[((size_t)blockIdx.y * 2) * cols + c] = (sm[0][l] + sm[1][l]) + (sm[2][l] + sm[3][l]);
+    }
+}
+int launch_colsum(const float* in, int ld, int rows, int cols, float* out, hipStream_t st, float* part_ws, size_t part_ws_floats) {
     RLCF_ARG_CHECK(in && out && rows > 0 && cols > 0 && ld >= cols);
+    if (part_ws) {
+        const int rpb = std::max(COLSUM_ROWS, (rows + 1023) / 1024), nb = (rows + rpb - 1) / rpb;
+        if ((size_t)nb * 2 * cols <= part_ws_floats) {
+            colsum_parts_kernel<<<dim3((cols + 63) / 64, nb), dim3(256), 0, st>>>(in, ld, rows, cols, rpb, part_ws);
+            RLCF_LAUNCH_CHECK();
+            colparts_reduce_kernel<<<dim3((cols + 63) / 64, 1), dim3(1024), 0, st>>>(part_ws, nb, cols, out, nullptr, 0);
+            RLCF_LAUNCH_CHECK();
+            return RLCF_OK;
+        }
+    }
     colsum_kernel<<<dim3((cols + 63) / 64, (rows + COLSUM_ROWS - 1) / COLSUM_ROWS), dim3(256), 0, st>>>(in, ld, rows, cols, out);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -736,10 +869,72 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const float* __re
         }
     }
 }
+// ... bit-reproducible form (see layernorm_bwd_parts_kernel): waves walk rpw rows inside their group and park their column sums
+__global__ __launch_bounds__(256) void vit_assemble_bwd_parts_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                                     const float* __restrict__ pos, const float* __restrict__ dy,
+                                                                     float* __restrict__ part, int rows, int tokens, int width,
+                                                                     int group_rows, int rpw, int wpg, int n_groups) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int g = w / wpg, k = w - g * wpg;
+    if (g >= n_groups) return;
+    const int gend = min(rows, (g + 1) * group_rows), row0 = g * group_rows + k * rpw, row1 = min(gend, row0 + rpw);
+    float ag[MAX_PER_LANE], ab[MAX_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / tokens, tok = row % tokens;
+        const float* src = tok == 0 ? cls : patch_out + ((size_t)b * (tokens - 1) + tok - 1) * width;
+        const float* pr = pos + (size_t)tok * width;
+        float v[MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            v[j] = c < width ? src[c] + pr[c] : 0.f;
+            s += v[j];
+        }
+        const float mu = wave_sum(s) / width;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) { float d = v[j] - mu; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < MAX_PER_LANE; ++j) {
+            int c = j * 64 + lane;
+            if (c < width) {
+                const float gg = dy[(size_t)row * width + c];
+                ag[j] += gg * (v[j] - mu) * rstd; ab[j] += gg;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_PER_LANE; ++j) {
+        int c = j * 64 + lane;
+        if (c < width) { part[((size_t)w * 2) * width + c] = ag[j]; part[((size_t)w * 2 + 1) * width + c] = ab[j]; }
+    }
+}
 int launch_vit_assemble_bwd(const float* patch_out, const float* cls, const float* pos, const float* dy, float* dgamma, float* dbeta, int n,
-                            int tokens, int width, hipStream_t st, int group_imgs, int group_stride) {
+                            int tokens, int width, hipStream_t st, int group_imgs, int group_stride, float* part_ws, size_t part_ws_floats) {
     RLCF_ARG_CHECK(width <= 64 * MAX_PER_LANE && n > 0);
     const int rows = n * tokens;
+    if (part_ws) {
+        int rpw, wpg, ng;
+        const int grows = group_imgs > 0 ? group_imgs * tokens : rows;
+        parts_plan(rows, grows, rpw, wpg, ng);
+        const size_t waves = (size_t)wpg * ng;
+        if (waves * 2 * width <= part_ws_floats) {
+            vit_assemble_bwd_parts_kernel<<<dim3((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, st>>>(
+                patch_out, cls, pos, dy, part_ws, rows, tokens, width, grows, rpw, wpg, ng);
+            RLCF_LAUNCH_CHECK();
+            colparts_reduce_kernel<<<dim3((width + 63) / 64, ng), dim3(1024), 0, st>>>(part_ws, wpg, width, dgamma, dbeta, group_imgs > 0 ? group_stride : 0);
+            RLCF_LAUNCH_CHECK();
+            return RLCF_OK;
+        }
+    }
     vit_assemble_bwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(patch_out, cls, pos, dy, dgamma, dbeta, n,
                                                                                                    tokens, width, group_imgs, group_stride);
     RLCF_LAUNCH_CHECK();

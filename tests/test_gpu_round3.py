@@ -341,3 +341,33 @@ def test_eval_driver_runs_the_rccl_path_with_one_rank(L, dev):
     assert plain["distributed"] is None
     assert rccl["predictions_sha256"] == plain["predictions_sha256"] and rccl["top5"] == plain["top5"]
     assert (rccl["images"], rccl["acc1"], rccl["acc5"]) == (plain["images"], plain["acc1"], plain["acc5"])
+
+
+# ------------------------------------------------------------------------------ bit-reproducible image-tower backward
+@pytest.mark.parametrize("geo,n_cls", [("tiny", 16), ("ViT-B/16", 1000)])
+def test_backbone_tuning_bit_reproducible(L, dev, geo, n_cls):
+    """LayerNorm tuning (one image and the sample-batched call) and every-parameter tuning of the image encoder give the same BITS on
+    every run: dK / dV of the attention backward are parked per query block and added in block order, the LayerNorm / ln_pre parameter
+    gradients and the bias column sums are per-wave partial sums added in a fixed order, d feat is a fixed-order reduction (no float
+    atomics left on the path in RLCF_PREC_F16X3)."""
+    from rlcf_amd.engine import TTAConfig
+    from test_gpu_parity import make_engine
+    N = 8
+    eng, *_ = make_engine((geo, geo if geo != "tiny" else "tiny-r"), N * 2, n_cls, L.TEXT_SHARED, prec=L.PREC_F16X3)
+    cfg = TTAConfig(selection_p=0.5, tta_steps=2, lr=1e-4)
+    R = synth.GEOMETRIES[geo].image_resolution
+    vs = torch.stack([synth.make_views(1000 + i, N, R, device=dev) for i in range(2)])      # (seed 1000: the ln_b16_n8 fixture's views, non-zero rewards)
+    runs = [eng.tta_sample_ln(vs[0], cfg) for _ in range(3)]
+    assert runs[0]["ln_grad"].abs().max() > 0
+    for o in runs[1:]:
+        for k in ("ln_grad", "ln_after", "final_logits"):
+            assert torch.equal(o[k], runs[0][k]), k
+    b0 = eng.tta_batch_ln(vs, cfg, want_logits=True)[1].clone()
+    for _ in range(2):
+        assert torch.equal(eng.tta_batch_ln(vs, cfg, want_logits=True)[1], b0)
+    full = [eng.tta_sample_visual(vs[0], cfg) for _ in range(3)]
+    assert full[0]["vis_grad"].abs().max() > 0
+    for o in full[1:]:
+        for k in ("ln_grad", "vis_grad", "vis_after", "final_logits"):
+            assert torch.equal(o[k], full[0][k]), k
+    eng.close()
