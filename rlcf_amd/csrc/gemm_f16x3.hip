@@ -979,6 +979,141 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
     amax_commit(g.amax_out, am);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// 256x256 tile on FOUR waves (one per SIMD, 492 registers each: 256 accumulators in AGPRs), wave tile 128x128 = 4x4 MFMA tiles.
+// EXPERIMENTAL, off by default (RLCF_X3_V4=1; 2 / 3 = the no-DMA / no-MFMA ablations): per K tile a wave reads 32 fragments for 96
+// MFMAs where the 8-wave kernel reads 24 for 48 (a third less LDS -> register traffic per flop) and there is ONE barrier per K tile.
+// With a single wave per SIMD nothing else covers its latencies, so the wave pipelines itself: one memory instruction behind each
+// MFMA, the fragments of a k-substep read during the MFMAs of the previous one, the barrier in the MIDDLE of the second substep
+// (everyone has read the tile's slots by then) and the first fragments of tile kt+1 read behind the remaining MFMAs of tile kt.
+// Measured (profiles/r3_gemm_experiments.txt): the main loop runs at the SAME 2.45 us per K tile as the 8-wave kernel, the four-slab
+// epilogue of a wave costs the K = 768 shapes 4-9 %, and under sustained load both kernels sit on the 1400 W socket power limit
+// (8-wave: 1506 MHz, 386 TF; this one: 1575 MHz, 381 TF; without its DMA 1775 MHz, 458 TF): what bounds the product is energy per
+// flop, not a latency the schedule leaves exposed.  Interleaved operands (kstep 64), compile-time epilogues (x3_epilogue_kind != 0).
+template <int ABL>          // ABL (measurements only): 1 = no DMA after the prologue, 2 = no MFMAs
+__global__ __launch_bounds__(256, 1) void gemm_nt_f16x3_v4_kernel(GemmX3Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE]
+    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int per_group = 8 * tiles_n, grp = bid / per_group, first_m = grp * 8;
+    const int gsize = min(tiles_m - first_m, 8), in_g = bid - grp * per_group;
+    const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA: a stage = 256 A rows + 256 W rows x 128 B = 64 pieces of 8 rows; wave w moves A pieces 8w..8w+7 and W pieces 8w..8w+7
+    size_t sa[8], sw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = (wave * 8 + j) * 64 + lane, r = q >> 3, c = ((q & 7) ^ ((r >> 1) & 7)) * 8;
+        sa[j] = (size_t)min(m0 + r, g.M - 1) * g.lda + c;
+        sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c;
+    }
+    // LDS: A ring of THREE 32-KB slots at [0, 96 KB), W ring of two at [96 KB, 160 KB).  The A tiles are unique to the workgroup and
+    // come from HBM / the MALL, the W tiles are hot in every L2: A pieces go out two K tiles ahead, W pieces one -- a K tile's worth of
+    // operands (64 KB) in flight per CU does not cover the loaded memory latency at this request rate (64 KB per ~1.8 us).
+#define V4_WBASE 98304
+#define V4_PA(j, kk, slot) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[j] + (kk)), (lptr_t)(smem + (slot) * 32768 + (wave * 8 + (j)) * 1024), 16, 0, 0);
+#define V4_PW(j, kk, slot) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[j] + (kk)), (lptr_t)(smem + V4_WBASE + (slot) * 32768 + (wave * 8 + (j)) * 1024), 16, 0, 0);
+    const int swz = (l32 >> 1) & 7;
+    const int aoff = (wm * 128 + l32) * 128, boff = V4_WBASE + (wn * 128 + l32) * 128;
+#define V4_M(n, i, AH, AL, BH, BL)                                                                                       \
+    if (ABL != 2) acc[i][(n) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16((n) < 8 ? AH[i] : AL[i], ((n) >> 2) == 1 ? BL[(n) & 3] : BH[(n) & 3], acc[i][(n) & 3], 0, 0, 0);
+    // read q (0..3) of row tile i of a k-substep: A hi, A lo, W hi, W lo (sa_ / sw_: byte offsets of the A / W slots)
+#define V4_RD(ks, i, q, AH, AL, BH, BL, sa_, sw_)                                                                       \
+    {                                                                                                                    \
+        const int ch_ = (((ks) * 2 + h) ^ swz) * 16, cl_ = ((4 + (ks) * 2 + h) ^ swz) * 16;                              \
+        if ((q) == 0) AH[i] = *(const h16x8*)(smem + (sa_) + aoff + (i) * 4096 + ch_);                                   \
+        else if ((q) == 1) AL[i] = *(const h16x8*)(smem + (sa_) + aoff + (i) * 4096 + cl_);                              \
+        else if ((q) == 2) BH[i] = *(const h16x8*)(smem + (sw_) + boff + (i) * 4096 + ch_);                              \
+        else BL[i] = *(const h16x8*)(smem + (sw_) + boff + (i) * 4096 + cl_);                                            \
+    }
+    const int nk = g.K / X3_BK;
+    h16x8 ah0[4], al0[4], bh0[4], bl0[4], ah1[4], al1[4], bh1[4], bl1[4];
+    // prologue: A(0), W(0), then A(1), W(1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) V4_PA(j, 0, 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) V4_PW(j, 0, 0)
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) V4_PA(j, g.kstep, 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) V4_PW(j, g.kstep, 1)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) V4_RD(0, i, q, ah0, al0, bh0, bl0, 0, 0)
+    int as_cur = 0;                                       // A slot of tile kt (kt % 3)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int as_nxt = as_cur == 2 ? 0 : as_cur + 1, as_nn = as_nxt == 2 ? 0 : as_nxt + 1;    // slots of tiles kt+1, kt+2
+        const int ao = as_cur * 32768, an = as_nxt * 32768, wo = (kt & 1) * 32768, wn_ = ((kt + 1) & 1) * 32768;
+        const bool pf1 = kt + 1 < nk, pf2 = kt + 2 < nk && ABL != 1;
+        const int k2 = (kt + 2) * g.kstep;
+        // substep 0: MFMAs on F0; behind them the fragments of substep 1 and the A pieces of tile kt+2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                V4_M(n, i, ah0, al0, bh0, bl0) V2_FENCE
+                if (n < 4) V4_RD(1, i, n, ah1, al1, bh1, bl1, ao, wo)
+                if (pf2 && i < 2 && n >= 4 && (n & 1) == 0) V4_PA(i * 4 + ((n - 4) >> 1), k2, as_nn)
+                V2_FENCE
+            }
+        }
+        // substep 1, first half
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) V4_M(n, i, ah1, al1, bh1, bl1)
+            V2_FENCE
+        }
+        // every wave has read the slots of tile kt; A(kt+1) and W(kt+1) have landed (the 8 pieces of A(kt+2) may still be in flight)
+        if (pf2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // second half: behind the MFMAs the first fragments of tile kt+1 and the W pieces of tile kt+2 (into the W slot of tile kt)
+#pragma unroll
+        for (int i = 2; i < 4; ++i) {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                V4_M(n, i, ah1, al1, bh1, bl1) V2_FENCE
+                if (pf1 && n < 8) V4_RD(0, (i - 2) * 2 + (n >> 2), n & 3, ah0, al0, bh0, bl0, an, wn_)
+                if (pf2 && n >= 8) V4_PW((i - 2) * 4 + (n - 8), k2, kt & 1)
+                V2_FENCE
+            }
+        }
+        as_cur = as_nxt;
+    }
+    const int ek = x3_epilogue_kind(g);
+    float* parkf = (float*)smem + wave * (64 * 68);
+    __syncthreads();
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc)
+            X3_EPILOGUE_SLAB(ek, g, acc[hr * 2][hc * 2], acc[hr * 2][hc * 2 + 1], acc[hr * 2 + 1][hc * 2], acc[hr * 2 + 1][hc * 2 + 1], parkf,
+                             m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane)
+}
+
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 // splitk_ws / splitk_ws_bytes: caller-owned scratch for the split-K form of the small-grid kernel (the engine sizes it once at
 // create); without it those shapes run unsplit.  Nothing is allocated here.
@@ -1014,6 +1149,27 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     // 61 us as one 59 %-full 256x256 round against 70 us as two 256x128 rounds; K = 3072: 188 against 233 us.
     const double cost3 = (double)((blocks3 + 255) / 256), cost2 = 0.575 * (double)((blocks2 + 255) / 256);
     const bool pick3 = blocks2 >= 256 && cost3 <= cost2;
+    // RLCF_X3_V4=1: the 4-wave form of the 256x256 tile where it applies (interleaved pairs, compile-time epilogues)
+    static int v4 = -1;
+    if (v4 < 0) { const char* e = getenv("RLCF_X3_V4"); v4 = e ? atoi(e) : 0; }
+    {
+        const bool f32o = C != nullptr, pair = Chi != nullptr, res = residual != nullptr;
+        const bool fast = !amax_out && !alpha_dev && !aux && !nofast &&
+                          ((epilogue == RLCF_EPI_NONE && f32o && !pair) || (epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) ||
+                           (epilogue == RLCF_EPI_NONE && !f32o && pair && !res));
+        if (v4 && v2_ok && !single && g.kstep == 64 && fast && (force == 3 || (force == 0 && pick3))) {
+            const size_t sh4 = (size_t)5 * 32768;
+            X3_LDS(gemm_nt_f16x3_v4_kernel<0>, sh4);
+            X3_LDS(gemm_nt_f16x3_v4_kernel<1>, sh4);
+            X3_LDS(gemm_nt_f16x3_v4_kernel<2>, sh4);
+            if (v4 == 2) gemm_nt_f16x3_v4_kernel<1><<<dim3(blocks3), dim3(256), sh4, st>>>(g);
+            else if (v4 == 3) gemm_nt_f16x3_v4_kernel<2><<<dim3(blocks3), dim3(256), sh4, st>>>(g);
+            else gemm_nt_f16x3_v4_kernel<0><<<dim3(blocks3), dim3(256), sh4, st>>>(g);
+            g_last_x3_variant = 3;
+            RLCF_LAUNCH_CHECK();
+            return RLCF_OK;
+        }
+    }
     if (v2_ok && (force == 3 || (force == 0 && pick3))) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
         if (g.kstep == 64 && single) {
