@@ -44,6 +44,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 import torch
@@ -388,6 +389,26 @@ def main():
         if world == 1 and a.sustain_seconds > 0 and not use_dist:
             # ---- sustained leg: full passes for >= sustain_seconds, a HIP event pair per pass (p50 / mean)
             pv = views[:pass_images]
+            # shader clock / socket power while the passes run (rocm-smi at ~3 Hz from a host thread): under this load the package sits
+            # on its power limit and the clock settles well below the 2.4 GHz the dense peaks are quoted at (profiles/r3_gemm_experiments.txt)
+            smp, smp_stop = [], threading.Event()
+
+            def _poll():
+                import re
+                import subprocess
+                while not smp_stop.is_set():
+                    try:
+                        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                        card = next(iter(json.loads(o).values()))
+                        sclk = next((float(re.sub(r"[^0-9.]", "", v)) for k, v in card.items() if "sclk clock speed" in k.lower()), None)
+                        pw = next((float(v) for k, v in card.items() if "power (w)" in k.lower()), None)
+                        if sclk:
+                            smp.append((sclk, pw))
+                    except Exception:
+                        pass
+                    smp_stop.wait(0.3)
+            th = threading.Thread(target=_poll, daemon=True)
+            th.start()
             evs, t_end = [], time.perf_counter() + a.sustain_seconds
             while time.perf_counter() < t_end or len(evs) < 8:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -398,12 +419,26 @@ def main():
                 if len(evs) % 4 == 0:
                     torch.cuda.synchronize()             # keeps the host at most 4 passes ahead (the loop is time-bounded)
             torch.cuda.synchronize()
+            smp_stop.set()
+            th.join(timeout=6)
             per_img = sorted(e0.elapsed_time(e1) / pass_images for e0, e1 in evs)
             log(f"sustained leg: {len(per_img)} passes")
             out["sustained"] = {"passes": len(per_img), "images_per_pass": pass_images, "mean_ms_per_image": statistics.fmean(per_img),
                                 "p50_ms_per_image": statistics.median(per_img), "min_ms_per_image": per_img[0],
                                 "max_ms_per_image": per_img[-1], "images_per_s_mean": 1e3 / statistics.fmean(per_img),
                                 "timer": "HIP events on the launch stream, one pair per pass"}
+            body = smp[len(smp) // 3:] if len(smp) >= 3 else smp          # (skip the ramp at the start of the leg)
+            if body:
+                sclk = statistics.median(x[0] for x in body)
+                pws = [x[1] for x in body if x[1] is not None]
+                out["sustained"]["clocks"] = {"sclk_mhz_median": sclk, "socket_power_w_median": statistics.median(pws) if pws else None,
+                                              "samples": len(body), "nominal_sclk_mhz": 2400.0,
+                                              "source": "rocm-smi --showclocks --showpower, sampled by a host thread during this leg"}
+                if "roofline" in out and out["roofline"].get("bound") == "mfma":
+                    # the same achieved rate against the matrix-pipe peak AT THE CLOCK THE PART SUSTAINS under this load (dense peak x sclk / 2.4 GHz)
+                    out["roofline"]["peak_at_sustained_clock"] = out["roofline"]["peak"] * sclk / 2400.0
+                    out["roofline"]["frac_at_sustained_clock"] = out["roofline"]["achieved"] / out["roofline"]["peak_at_sustained_clock"]
+                    out["roofline"]["frac_of_mfma_pipe_at_sustained_clock"] = out["roofline"]["frac_of_mfma_pipe"] * 2400.0 / sclk
         if world == 1 and a.precision == "f16x3" and a.config == 1 and not a.no_f16_line and not use_dist:
             # ---- secondary, clearly labelled: the reference's own GPU arithmetic (fp16 autocast, tpt_cls_rl.py:52) = RLCF_PREC_F16.
             # Not the headline and not parity-grade: reported with its measured deviation from the split-f16 engine on this very pass.
