@@ -77,7 +77,9 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epi;
     e->last_flops += 2.0 * M * N * K;
-    if (prec_x3(e) && M > 512 && K % 32 == 0 && lda == K && ldw == K) {
+    static int x3_min_m = -1;                             // RLCF_X3_MIN_M: smallest M that takes the split-f16 kernels (benchmarks)
+    if (x3_min_m < 0) { const char* ev = getenv("RLCF_X3_MIN_M"); x3_min_m = ev ? atoi(ev) : 512; }
+    if (prec_x3(e) && M > x3_min_m && K % 32 == 0 && lda == K && ldw == K) {
         // split-f16 path: W was split at finalize; A is split here (producers will emit pairs directly)
         const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }

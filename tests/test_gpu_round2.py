@@ -34,19 +34,19 @@ def dev():
 
 
 # ------------------------------------------------------------------------------ the benchmarked path, at the benchmarked batch sizes
-@pytest.mark.parametrize("B", [8, 32])
+@pytest.mark.parametrize("B", [8, 20, 32])          # 20 = the pass size of the driver's `bench.py --steps 20`
 def test_tta_batch_matches_reference_stream_b16_n64(L, dev, B):
     """BASELINE configs[1] as bench.py runs it (split-f16, shared-prefix text, sparse class backward, B test images per tower
     pass): eight consecutive ViT-B/16 N=64 C=1000 samples, each produced by the reference's own harness body one at a time
     (tests/golden/make_golden.py --only b16stream: TPT/tpt_cls_rl.py:251-262).  Every sample's top-5 and final logits must come
-    out of rlcf_tta_batch, at 8 per pass and at 32 per pass (the stream repeated four times: all four copies must agree too)."""
+    out of rlcf_tta_batch, at 8, 20 and 32 per pass (the stream repeated until the pass is full: all copies must agree too)."""
     g, meta = load_golden("tta_b16_n64_stream")
     n = meta["n_samples"]
     eng, *_ = make_engine((meta["student"], meta["reward"]), meta["n_views"] * B, meta["n_cls"], L.TEXT_SHARED, meta["student_seed"],
                           meta["reward_seed"], meta["bank_seed"], meta["n_ctx"], prec=L.PREC_F16X3)
     R = synth.GEOMETRIES[meta["student"]].image_resolution
     stream = torch.stack([synth.make_views(meta["view_seed0"] + i, meta["n_views"], R, device=dev) for i in range(n)])
-    views = stream.repeat(B // n, 1, 1, 1, 1) if B > n else stream[:B]
+    views = stream[torch.arange(B) % n]                   # the stream, repeated until the pass is full
     top5, fl = eng.tta_batch(views, _cfg_from_meta(meta, sparse=True), want_logits=True)
     torch.cuda.synchronize()
     top5, fl = top5.cpu(), fl.cpu()
