@@ -10,8 +10,12 @@ run bench_c2 --config 2
 run bench_c4 --config 4
 run bench_batch1 --batch 1 --no-cpu-baseline
 export TMPDIR=/tmp
-prof() { name=$1; shift; timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$name -- python bench.py "$@" > $O/prof_$name.log 2>&1; db=$(find $O/prof_$name -name "*_results.db" | head -1); echo "prof $name db=$db"; }
-prof c1 --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line
-prof c2 --config 2 --no-cpu-baseline --sustain-seconds 0
-prof c4 --config 4 --no-cpu-baseline --sustain-seconds 0
+# (the rocpd databases are tens of MB each and gpurun_out/ travels back only below 64 MiB: summarise on the box, drop the database)
+prof() { name=$1; nimg=$2; title=$3; shift 3; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- python bench.py "$@" > $O/prof_$name.log 2>&1
+         db=$(find /tmp/prof_$name -name "*_results.db" | head -1)
+         if [ -n "$db" ]; then python tools/prof_summary.py "$db" "$title" $nimg > $O/kernel_stats_$name.txt; else echo "prof $name: no database"; fi
+         tail -c 1500 $O/prof_$name.log > $O/prof_$name.tail; rm -f $O/prof_$name.log; rm -rf /tmp/prof_$name; }
+prof c1 45 "round 3 final build: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line (BASELINE configs[1]; 5 warm-up + 20 timed + 20 profiled images)" --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line
+prof c2 112 "round 3 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 2 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[2]: ViT-L/14 + ViT-L/14, LayerNorm tuning, N = 64, 16 images per pass; warm-up + timed + profiled passes)" --config 2 --no-cpu-baseline --sustain-seconds 0
+prof c4 97 "round 3 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 4 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[4]: RN50x64 @448 student + ViT-L/14 reward, N = 32, one image per pass; warm-up + timed + profiled images)" --config 4 --no-cpu-baseline --sustain-seconds 0
 ls -la $O | head -40
