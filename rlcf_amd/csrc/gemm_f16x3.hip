@@ -54,7 +54,7 @@ __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_
 // One call = the 64x64 slab of one wave: a0..a3 = accumulator tiles (i, j) = (0,0) (0,1) (1,0) (1,1); row0 / col0 = its origin.
 template <int EPI, bool RES, bool F32OUT, bool PAIR>
 __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3,
-                                                 float* park, int row0, int col0, int lane) {
+                                                 float* park, int row0, int col0, int lane, float& am) {
     constexpr int ELD = 68;
     const int l32 = lane & 31, h = lane >> 5;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
@@ -63,7 +63,8 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     const int colc = colok ? col : 0;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) bv = *(const float4*)(g.bias + colc);
-    const float al = g.alpha;
+    const float al = x3_alpha(g);                          // (alpha_dev: the device-side undo of a data-dependent operand scale)
+    const bool relu = g.epilogue == RLCF_EPI_RELU;         // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
     const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
     const int rbase = row0 + rsub;
     float4 rr[16];
@@ -86,10 +87,13 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         }
         if constexpr (RES) {
             rr[it].x += v[0]; rr[it].y += v[1]; rr[it].z += v[2]; rr[it].w += v[3];
+            if (relu) { rr[it].x = fmaxf(rr[it].x, 0.f); rr[it].y = fmaxf(rr[it].y, 0.f); rr[it].z = fmaxf(rr[it].z, 0.f); rr[it].w = fmaxf(rr[it].w, 0.f); }
             asm volatile("" : "+v"(rr[it].x), "+v"(rr[it].y), "+v"(rr[it].z), "+v"(rr[it].w));     // materialise here: the sums must not sink
         } else {                                                                                     // into the store loop (IR sinking re-fuses the phases)
             const int row = rbase + it * 4;
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (colok && row < g.M) {
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if constexpr (PAIR) {
                     h16x4 hh, ll;
@@ -107,6 +111,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         for (int it = 0; it < 16; ++it) {
             const int row = rbase + it * 4;
             if (colok && row < g.M) {
+                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
                 if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = rr[it];
                 if constexpr (PAIR) {
                     const float v[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
@@ -124,9 +129,11 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
 // which specialisation (wave-uniform): 0 = none (generic epilogue), 1 = f32 out, 2 = f32 out + residual, 3 = QuickGELU -> operand pair,
 // 4 = operand pair only (in_proj of the image towers: Q / K / V go to the attention kernel as f16 pairs, attention_pair.hip)
 __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
-    if (g.amax_out || g.alpha_dev || g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
+    if (g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
     const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
-    if (g.epilogue == RLCF_EPI_NONE && f32o && !pair) return res ? 2 : 1;
+    // kinds 1 / 2 also carry the ResNet convolutions' epilogue: device-side alpha, ReLU after the identity add, max|C| for the next scale
+    if ((g.epilogue == RLCF_EPI_NONE || g.epilogue == RLCF_EPI_RELU) && f32o && !pair) return res ? 2 : 1;
+    if (g.amax_out || g.alpha_dev) return 0;
     if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
     if (g.epilogue == RLCF_EPI_NONE && !f32o && pair && !res) return 4;
     return 0;
@@ -475,7 +482,8 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     // re-reads it row-wise, so bias / residual / stores are 16-byte accesses covering whole 256-B row segments
     __syncthreads();
     if (const int ek = x3_epilogue_kind(g)) {
-        X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (float*)smem + wave * (64 * 68), m0 + wm * 64, n0 + wn * 64, lane)
+        X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (float*)smem + wave * (64 * 68), m0 + wm * 64, n0 + wn * 64, lane, am)
+        amax_commit(g.amax_out, am);
         return;
     }
     {
@@ -876,7 +884,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
         for (int half = 0; half < 2; ++half)
             X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
-                             m0 + wm * 128 + half * 64, n0 + wn * 64, lane)
+                             m0 + wm * 128 + half * 64, n0 + wn * 64, lane, am)
+        amax_commit(g.amax_out, am);
         return;
     }
     // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
@@ -1105,13 +1114,15 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_f16x3_v4_kernel(GemmX3Args g) 
     }
     const int ek = x3_epilogue_kind(g);
     float* parkf = (float*)smem + wave * (64 * 68);
+    float am = 0.f;
     __syncthreads();
 #pragma unroll
     for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
         for (int hc = 0; hc < 2; ++hc)
             X3_EPILOGUE_SLAB(ek, g, acc[hr * 2][hc * 2], acc[hr * 2][hc * 2 + 1], acc[hr * 2 + 1][hc * 2], acc[hr * 2 + 1][hc * 2 + 1], parkf,
-                             m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane)
+                             m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane, am)
+    amax_commit(g.amax_out, am);
 }
 
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
