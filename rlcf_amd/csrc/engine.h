@@ -181,6 +181,7 @@ struct rlcf_engine {
     // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
     DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
+    DevBuf zpage;                    // 4 KB of zeros: what the implicit 3x3 convolution reads outside the image
     DevBuf parts_ws, attn_park;      // scratch of the bit-reproducible reductions: parameter-gradient partial sums; dK / dV per query block
     int bn_prior_strength = -1;
     std::vector<float*> bn_z, bn_y;  // per unit: pre-BatchNorm GEMM output and the unit's output, inside bn_saved
@@ -224,6 +225,8 @@ static inline bool prec_single(const rlcf_engine* e) { return e->precision == RL
 int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
 int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
 // norm-layer tuning of a ResNet student (resnet.hip): build the train-form weights / flat buffers once; one tuning sample
+int engine_gemm_conv3x3(rlcf_engine* e, const float* in, const float* scale2_dev, const float* W, const float* bias, const float* res, int ldr,
+                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out);
 int engine_bn_enable(rlcf_engine* e, hipStream_t st);
 int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
 int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st);

@@ -129,6 +129,25 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
+// implicit 3x3 convolution: the activation [n*H*W, cin] was split into e->a_hi / a_lo by the caller (interleaved pairs, scaled by
+// the device scalar whose inverse is *alpha_dev); W = the folded / raw convolution weight [cout, 9*cin] with a split copy
+int engine_gemm_conv3x3(rlcf_engine* e, const float* in, const float* scale2_dev, const float* W, const float* bias, const float* res, int ldr,
+                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out) {
+    const ClipModel::SplitW* sp = nullptr;
+    for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
+    if (!sp) { rlcf_set_error("engine_gemm_conv3x3: weight has no split copy"); return RLCF_ERR_STATE; }
+    if (!e->zpage.p) { TRY(e->zpage.ensure(4096)); RLCF_HIP_CHECK(hipMemsetAsync(e->zpage.p, 0, 4096, st)); }
+    const int M = n * H * Wd;
+    if ((size_t)M * cin > a_cap(e)) { rlcf_set_error("engine_gemm_conv3x3: operand scratch too small"); return RLCF_ERR_STATE; }
+    TRY(launch_split_f16x2_dev(in, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * cin, scale2_dev, st, 1));      // scale2_dev = {s, 1/s}
+    const float* alpha_dev = scale2_dev + 1;
+    e->last_flops += 2.0 * M * cout * 9.0 * cin;
+    const int slot = prof_begin(st, 2.0 * M * cout * 9.0 * cin, M, cout, 9 * cin);
+    int rc = launch_gemm_f16x3_conv3x3(a_ptr(e), n, H, Wd, cin, sp->hi, cout, bias, res, ldr, C, ldc, sp->inv_scale, epi, alpha_dev,
+                                       (unsigned int*)amax_out, e->zpage.p, st);
+    prof_end(slot, st, g_last_x3_variant);
+    return rc;
+}
 bool engine_has_split(const rlcf_engine* e, const float* W) {
     for (auto& m : e->model) if (m.split_of.find(W) != m.split_of.end()) return true;
     return false;

@@ -35,6 +35,11 @@ struct GemmX3Args {
     int ksplit;                        // 128x128 DMA-ring kernel only: blockIdx.y walks K tiles [y*per, (y+1)*per); raw partial tiles go
     float* ws;                         // to ws[ksplit][M][N] and gemm_x3_splitk_reduce_kernel applies alpha / bias / epilogue
     int no_fast_epi;                   // RLCF_X3_NOFASTEPI=1: 256x256 kernel keeps the generic per-row epilogue (A/B measurements)
+    // implicit 3x3 convolution (stride 1, pad 1; 256x256 kernel only): A is the NHWC activation as operand pairs [n*H*W, 2*conv_C]
+    // (lda = 2*conv_C), K = 9*conv_C in (ky, kx, c) order; row r's K tile of tap (ky, kx) is pixel r + (ky-1)*W + (kx-1)'s channel block,
+    // or 128 B of zeros (zpage) outside the image.  conv_C = 0: plain GEMM
+    int conv_C, conv_H, conv_W;
+    const _Float16* zpage;
 };
 // SINGLE (template flag of the kernels): plain f16 operands, ONE MFMA per product (RLCF_PREC_F16 — the arithmetic of the reference's
 // own fp16-autocast GPU path, tpt_cls_rl.py:52; NOT f32-grade).  A plain f16 row of K halves has exactly the memory layout of an
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     amax_commit(g.amax_out, am);
 }
 
-template <bool SINGLE>
+template <bool SINGLE, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
@@ -775,17 +780,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     // byte: 25.8 against 45.5 B/clk/CU in the delivery micro-benchmark).  LDS row = 128 B; 16-B chunk c (0-3 hi, 4-7 lo) of row r sits
     // in slot c ^ ((r>>1)&7), so a 16-lane ds_read_b128 group (16 consecutive rows, one chunk) covers all 64 banks.
     size_t sa[4], sw[4];
+    unsigned vm[4] = {0x1ffu, 0x1ffu, 0x1ffu, 0x1ffu};      // CONV: bit t = tap t of this lane's row lies inside the image
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane, r = q >> 3, c = ((q & 7) ^ ((r >> 1) & 7)) * 8;
-        sa[j] = (size_t)min(m0 + r, g.M - 1) * g.lda + c;
+        const int row = min(m0 + r, g.M - 1);
+        sa[j] = (size_t)row * g.lda + c;
         sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c;
+        if constexpr (CONV) {
+            const int ox = row % g.conv_W, oy = (row / g.conv_W) % g.conv_H;
+            unsigned m = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int iy = oy + tp / 3 - 1, ix = ox + tp % 3 - 1;
+                if (iy >= 0 && iy < g.conv_H && ix >= 0 && ix < g.conv_W) m |= 1u << tp;
+            }
+            vm[j] = m;
+        }
     }
+    const _Float16* zlane = CONV ? g.zpage + lane * 8 : nullptr;       // 16 B of zeros per lane
+    // CONV: element offset of K tile kt in the activation rows = ((ky-1) W + (kx-1)) lda + 64 (kt % (C/32)), and its tap
+    const int cblocks = CONV ? g.conv_C / 32 : 1;
+    auto conv_off = [&](int kt, int& tap) -> long {
+        tap = kt / cblocks;
+        const int cb = kt - tap * cblocks, ky = tap / 3, kx = tap - ky * 3;
+        return ((long)(ky - 1) * g.conv_W + (kx - 1)) * (long)g.lda + (long)cb * 64;
+    };
 #undef V3_PIECE
 #define V3_PIECE(idx, kk, sb_)                                                                                                         \
     {                                                                                                                                  \
-        if ((idx) < 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);           \
-        else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);              \
+        if ((idx) < 4) {                                                                                                               \
+            if constexpr (CONV) {                                                                                                      \
+                const _Float16* pa_ = ((vm[(idx) & 3] >> ctap_) & 1u) ? g.Ahi + (long)sa[(idx) & 3] + coff_ : zlane;                     \
+                __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);            \
+            } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);           \
+        } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);              \
     }
 #undef V3_LDA
 #undef V3_LDB
@@ -806,6 +835,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         }                                                                                                                \
     }
     const int nk = g.K / X3_BK;
+    int ctap_ = 0;
+    long coff_ = 0;
+    if constexpr (CONV) coff_ = conv_off(0, ctap_);
     {
         char* s0 = smem;
 #pragma unroll
@@ -825,6 +857,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = kt + 1 < nk;
             const int kn = (kt + 1) * g.kstep;
+            if constexpr (CONV) { if (pf) coff_ = conv_off(kt + 1, ctap_); }
             char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
             const char* sb = smem + (kt & 1) * V3_STAGE;
             V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
@@ -849,6 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = kt + 1 < nk;
             const int kn = (kt + 1) * g.kstep;
+            if constexpr (CONV) { if (pf) coff_ = conv_off(kt + 1, ctap_); }
             char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
             const char* sb = smem + (kt & 1) * V3_STAGE;
             if (kt > 0) {                                          // second k-substep of tile kt-1 + the DMA of tile kt+1
@@ -1247,6 +1281,37 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         gemm_nt_f16x3_kernel<false><<<dim3(blocks), dim3(256), sh, st>>>(g);
     }
     g_last_x3_variant = 1;
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// Implicit 3x3 convolution (stride 1, pad 1) on the 256x256 kernel: act = the NHWC activation [n*H*W, Cin] as interleaved operand
+// pairs (row stride 2*Cin halves), W = the convolution weight in the GEMM layout [Cout, 9*Cin] ((ky, kx, c) order) as interleaved pairs.
+// No patch matrix exists: a workgroup's DMA reads the K tile of tap (ky, kx) straight from pixel (y + ky - 1, x + kx - 1) of the
+// activation, or from `zpage` (>= 1 KB of zeros) outside the image.  Same products in the same order as the patch-matrix form.
+bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin) {
+    const long tiles = (long)((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
+    return Cin % 32 == 0 && N % 4 == 0 && tiles >= 192;
+}
+int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
+                              const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
+                              unsigned int* amax_out, const void* zpage, hipStream_t st) {
+    const int M = n * H * W, K = 9 * Cin;
+    RLCF_ARG_CHECK(act_pairs && Wpairs && C && zpage && gemm_f16x3_conv3x3_ok(M, Cout, Cin) && ldc % 4 == 0 && ldr % 4 == 0);
+    GemmX3Args g{};
+    g.Ahi = (const _Float16*)act_pairs; g.Alo = g.Ahi + 32; g.lda = 2 * Cin;
+    g.Whi = (const _Float16*)Wpairs; g.Wlo = g.Whi + 32; g.ldw = 2 * K;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = Cout; g.K = K; g.alpha = alpha;
+    g.epilogue = epilogue; g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.kstep = 64;
+    g.conv_C = Cin; g.conv_H = H; g.conv_W = W; g.zpage = (const _Float16*)zpage;
+    static int nofast = -1;
+    if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }
+    g.no_fast_epi = nofast;
+    const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((Cout + V3_BN - 1) / V3_BN);
+    const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
+    { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true>), sh3); if (rc_ != RLCF_OK) return rc_; }
+    gemm_nt_f16x3_v3i_kernel<false, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+    g_last_x3_variant = 3;
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

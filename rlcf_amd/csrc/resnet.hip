@@ -274,6 +274,17 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
     const int Ho = H / stride, Wo = W / stride;
     const long M = (long)n * Ho * Wo;
     const float* A = in;
+    static int no_implicit = -1;                          // RLCF_CONV_IM2COL=1: 3x3 convolutions back on the patch matrix (A/B measurements)
+    if (no_implicit < 0) { const char* ev = getenv("RLCF_CONV_IM2COL"); no_implicit = ev ? atoi(ev) : 0; }
+    if (cw.k == 3 && !nchw && stride == 1 && prec_x3(e) && !no_implicit && cw.Kp == 9 * cw.cin && gemm_f16x3_conv3x3_ok((int)M, cw.cout, cw.cin) &&
+        (size_t)M * cw.cin <= e->a_split_elems && engine_has_split(e, cw.w) && !prec_single(e)) {
+        // implicit GEMM: the activation is split ONCE into operand pairs (M x cin, not the 9x larger patch matrix) and the 256x256
+        // kernel's DMA gathers every tap's K tiles from it directly
+        TRY(e->dyn.ensure(3 * sizeof(float)));
+        if (in_amax) TRY(launch_dyn_scale_from(in_amax, e->dyn.as<float>() + 1, st));
+        else TRY(launch_dyn_scale(in, (int64_t)M * cw.cin, e->dyn.as<float>(), st));
+        return engine_gemm_conv3x3(e, in, e->dyn.as<float>() + 1, cw.w, cw.b, res, cw.cout, out, cw.cout, n, H, W, cw.cin, cw.cout, epi, st, out_amax);
+    }
     if (cw.k == 3 && !nchw && prec_x3(e) && cw.cin % 8 == 0 && M > 512 && (size_t)M * cw.Kp <= e->a_split_elems &&
         engine_has_split(e, cw.w)) {
         // split-f16 mode: the patch matrix is written once, already as the (hi, lo) operand pair; its power-of-two scale comes
