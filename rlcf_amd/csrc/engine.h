@@ -52,7 +52,10 @@ struct Tower {                       // workspace of one transformer pass over T
     int saved_T = 0, saved_layers = 0;
 };
 
-struct ConvW { const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1, Kp = 0; };   // conv with folded BatchNorm
+struct ConvW {                       // conv with folded BatchNorm
+    const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1, Kp = 0;
+    float gain = 0.f, bmax = 0.f;    // max_row sum_k |w[row, k]| and max |b|: |conv(x)| <= gain max|x| + bmax, the bound the scale of a
+};                                   // pair-emitting epilogue is chosen from BEFORE the launch (resnet.hip)
 struct BottleW { ConvW c1, c2, c3, down; bool has_down = false; int stride = 1; };                          // model.py:10-55
 // train-form view of one Conv2d(bias=False) + BatchNorm2d pair of a ModifiedResNet STUDENT whose norm layers are tuned
 // (CLIPCLS_TTA(only_norm=True) on a ResNet, TPT/clip/custom_clip.py:481-497; BatchNorm forward of TPT/tune_cls_rl.py:35-44,73-76)
@@ -167,7 +170,7 @@ struct rlcf_engine {
     bool image_bank = false;         // the bank of e->C entries holds IMAGE features (rlcf_engine_set_image_bank), not texts
     DevBuf q_feat, q_dfeat, q_ls;    // query text features / their gradient [D]; {d logit_scale} scratch
     DevBuf wg_yt, wg_xt, w_hi;       // weight-gradient GEMM operands: dY^T, X^T (token dimension padded) and the split copy of X^T
-    DevBuf rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
+    DevBuf rn_pairs[3] /*block input / conv1 / conv2 outputs as operand pairs*/, rn_scale, rn_buf[5], rn_col, rn_tok, rn_q, rn_kv, rn_att, rn_amax /*max|activation| per buffer, written by GEMM epilogues*/;   // ModifiedResNet workspace (one chunk of images)
     DevBuf bwd_amax;                 // max|dF| handed from one backward GEMM's epilogue to the next one's operand scale
     DevBuf dyn;                      // {max|A|, s, 1/s} of a dynamically scaled split (ResNet activations)
     DevBuf a_hi;                     // interleaved split copy of the current GEMM A operand (F16X3 mode)
@@ -226,7 +229,11 @@ int resnet_finalize(rlcf_engine* e, ClipModel& m, hipStream_t st);
 int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
 // norm-layer tuning of a ResNet student (resnet.hip): build the train-form weights / flat buffers once; one tuning sample
 int engine_gemm_conv3x3(rlcf_engine* e, const float* in, const float* scale2_dev, const float* W, const float* bias, const float* res, int ldr,
-                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out);
+                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out,
+                        const void* in_pairs = nullptr, void* Cpairs = nullptr, const float* out_scale_dev = nullptr);
+int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* alpha_dev, const float* W, const float* bias, const float* res, int ldr,
+                      float* C, int ldc, void* Cpairs, const float* out_scale_dev, int M, int N, int epi, hipStream_t st, float* amax_out);
+int engine_split_operand(rlcf_engine* e, const float* in, int64_t n, const float* amax_in, void** pairs, const float** scale2, hipStream_t st);
 int engine_bn_enable(rlcf_engine* e, hipStream_t st);
 int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
 int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st);

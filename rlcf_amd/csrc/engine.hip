@@ -131,20 +131,48 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
 }
 // implicit 3x3 convolution: the activation [n*H*W, cin] was split into e->a_hi / a_lo by the caller (interleaved pairs, scaled by
 // the device scalar whose inverse is *alpha_dev); W = the folded / raw convolution weight [cout, 9*cin] with a split copy
+// C = epi(A W^T + b) (+res) with A already an interleaved operand pair matrix [M, K] scaled by 1 / *alpha_dev; output f32 and / or pairs
+// (Cpairs [M, N], scaled by *out_scale_dev)
+int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* alpha_dev, const float* W, const float* bias, const float* res, int ldr,
+                      float* C, int ldc, void* Cpairs, const float* out_scale_dev, int M, int N, int epi, hipStream_t st, float* amax_out) {
+    const ClipModel::SplitW* sp = nullptr;
+    for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
+    if (!sp) { rlcf_set_error("engine_gemm_pairs: weight has no split copy"); return RLCF_ERR_STATE; }
+    e->last_flops += 2.0 * M * N * K;
+    const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+    int rc = launch_gemm_f16x3(Apairs, lo_of(Apairs), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, Cpairs, Cpairs ? lo_of(Cpairs) : nullptr,
+                               2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), 0, out_scale_dev);
+    prof_end(slot, st, g_last_x3_variant);
+    return rc;
+}
+// f32 matrix -> operand pairs in the engine's A scratch, scaled by the power of two found from max|in| (amax_in if known); *scale2 = {s, 1/s}
+int engine_split_operand(rlcf_engine* e, const float* in, int64_t n, const float* amax_in, void** pairs, const float** scale2, hipStream_t st) {
+    if ((size_t)n > a_cap(e)) { rlcf_set_error("engine_split_operand: operand scratch too small"); return RLCF_ERR_STATE; }
+    TRY(e->dyn.ensure(3 * sizeof(float)));
+    if (amax_in) TRY(launch_dyn_scale_from(amax_in, e->dyn.as<float>() + 1, st));
+    else TRY(launch_dyn_scale(in, n, e->dyn.as<float>(), st));
+    TRY(launch_split_f16x2_dev(in, a_ptr(e), lo_of(a_ptr(e)), n, e->dyn.as<float>() + 1, st, 1));
+    *pairs = a_ptr(e); *scale2 = e->dyn.as<float>() + 1;
+    return RLCF_OK;
+}
 int engine_gemm_conv3x3(rlcf_engine* e, const float* in, const float* scale2_dev, const float* W, const float* bias, const float* res, int ldr,
-                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out) {
+                        float* C, int ldc, int n, int H, int Wd, int cin, int cout, int epi, hipStream_t st, float* amax_out,
+                        const void* in_pairs, void* Cpairs, const float* out_scale_dev) {
     const ClipModel::SplitW* sp = nullptr;
     for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
     if (!sp) { rlcf_set_error("engine_gemm_conv3x3: weight has no split copy"); return RLCF_ERR_STATE; }
     if (!e->zpage.p) { TRY(e->zpage.ensure(4096)); RLCF_HIP_CHECK(hipMemsetAsync(e->zpage.p, 0, 4096, st)); }
     const int M = n * H * Wd;
-    if ((size_t)M * cin > a_cap(e)) { rlcf_set_error("engine_gemm_conv3x3: operand scratch too small"); return RLCF_ERR_STATE; }
-    TRY(launch_split_f16x2_dev(in, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * cin, scale2_dev, st, 1));      // scale2_dev = {s, 1/s}
+    if (!in_pairs) {
+        if ((size_t)M * cin > a_cap(e)) { rlcf_set_error("engine_gemm_conv3x3: operand scratch too small"); return RLCF_ERR_STATE; }
+        TRY(launch_split_f16x2_dev(in, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * cin, scale2_dev, st, 1));      // scale2_dev = {s, 1/s}
+        in_pairs = a_ptr(e);
+    }
     const float* alpha_dev = scale2_dev + 1;
     e->last_flops += 2.0 * M * cout * 9.0 * cin;
     const int slot = prof_begin(st, 2.0 * M * cout * 9.0 * cin, M, cout, 9 * cin);
-    int rc = launch_gemm_f16x3_conv3x3(a_ptr(e), n, H, Wd, cin, sp->hi, cout, bias, res, ldr, C, ldc, sp->inv_scale, epi, alpha_dev,
-                                       (unsigned int*)amax_out, e->zpage.p, st);
+    int rc = launch_gemm_f16x3_conv3x3(in_pairs, n, H, Wd, cin, sp->hi, cout, bias, res, ldr, C, ldc, sp->inv_scale, epi, alpha_dev,
+                                       (unsigned int*)amax_out, e->zpage.p, st, Cpairs, out_scale_dev);
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }

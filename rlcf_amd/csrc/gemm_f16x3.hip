@@ -40,6 +40,8 @@ struct GemmX3Args {
     // or 128 B of zeros (zpage) outside the image.  conv_C = 0: plain GEMM
     int conv_C, conv_H, conv_W;
     const _Float16* zpage;
+    const float* out_scale_dev;        // optional device scalar: the split output carries C * out_scale_dev[0] (a power of two chosen from
+                                       // an upper bound of |C| before the launch: the consumer undoes it through ITS alpha_dev)
 };
 // SINGLE (template flag of the kernels): plain f16 operands, ONE MFMA per product (RLCF_PREC_F16 — the arithmetic of the reference's
 // own fp16-autocast GPU path, tpt_cls_rl.py:52; NOT f32-grade).  A plain f16 row of K halves has exactly the memory layout of an
@@ -70,6 +72,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     if (g.bias) bv = *(const float4*)(g.bias + colc);
     const float al = x3_alpha(g);                          // (alpha_dev: the device-side undo of a data-dependent operand scale)
     const bool relu = g.epilogue == RLCF_EPI_RELU;         // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
+    const float os = (PAIR && g.out_scale_dev) ? g.out_scale_dev[0] : 1.0f;
     const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
     const int rbase = row0 + rsub;
     float4 rr[16];
@@ -103,7 +106,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
                 if constexpr (PAIR) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs = v[q] * os; hh[q] = (_Float16)vs; ll[q] = (_Float16)(vs - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + ocol) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + ocol) = ll;
                 }
@@ -119,7 +122,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
                 if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
                 if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = rr[it];
                 if constexpr (PAIR) {
-                    const float v[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    const float v[4] = {rr[it].x * os, rr[it].y * os, rr[it].z * os, rr[it].w * os};
                     h16x4 hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
@@ -137,8 +140,11 @@ __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
     if (g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
     const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
     // kinds 1 / 2 also carry the ResNet convolutions' epilogue: device-side alpha, ReLU after the identity add, max|C| for the next scale
-    if ((g.epilogue == RLCF_EPI_NONE || g.epilogue == RLCF_EPI_RELU) && f32o && !pair) return res ? 2 : 1;
-    if (g.amax_out || g.alpha_dev) return 0;
+    const bool lin = g.epilogue == RLCF_EPI_NONE || g.epilogue == RLCF_EPI_RELU;
+    if (lin && f32o && !pair) return res ? 2 : 1;
+    if (lin && !f32o && pair && !res) return 4;            // (in_proj -> Q / K / V pairs; ResNet conv1 / conv2 -> pairs of the next convolution)
+    if (lin && f32o && pair && res) return 5;              // ResNet conv3: block output as f32 (the next identity) AND as pairs (the next conv1)
+    if (g.amax_out || g.alpha_dev || g.out_scale_dev) return 0;
     if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
     if (g.epilogue == RLCF_EPI_NONE && !f32o && pair && !res) return 4;
     return 0;
@@ -148,6 +154,7 @@ __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
         if ((kind) == 1) x3_epilogue_slab<RLCF_EPI_NONE, false, true, false>(__VA_ARGS__);       /* in_proj (QKV), conv1 */      \
         else if ((kind) == 2) x3_epilogue_slab<RLCF_EPI_NONE, true, true, false>(__VA_ARGS__);   /* out_proj / c_proj + residual */ \
         else if ((kind) == 3) x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true>(__VA_ARGS__);   /* c_fc + QuickGELU -> pair */ \
+        else if ((kind) == 5) x3_epilogue_slab<RLCF_EPI_NONE, true, true, true>(__VA_ARGS__);    /* conv3 + identity -> f32 and pairs */ \
         else x3_epilogue_slab<RLCF_EPI_NONE, false, false, true>(__VA_ARGS__);                   /* in_proj -> Q / K / V pairs */    \
     }
 
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
         if (g.Chi) {
             h16x4 hh, ll;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)v[q]; ll[q] = (_Float16)(v[q] - (float)hh[q]); }
+            for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
             *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
             if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
         }
@@ -1165,7 +1172,7 @@ int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 2
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
-                      float* splitk_ws, size_t splitk_ws_bytes, int single) {
+                      float* splitk_ws, size_t splitk_ws_bytes, int single, const float* out_scale_dev) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && (Clo || single))));
     if (single) {       // plain f16 operands: a row of K halves == an interleaved pair row of K/2 logical columns (see GemmX3Args)
@@ -1176,7 +1183,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     g.Ahi = (const _Float16*)Ahi; g.Alo = (const _Float16*)Alo; g.lda = lda; g.Whi = (const _Float16*)Whi; g.Wlo = (const _Float16*)Wlo;
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
-    g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.c_il = c_il;
+    g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.c_il = c_il; g.out_scale_dev = out_scale_dev;
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     RLCF_ARG_CHECK((g.kstep == 64) == (Wlo == (const void*)((const _Float16*)Whi + 32)));   // both operands in the same layout
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
@@ -1295,15 +1302,16 @@ bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin) {
 }
 int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
                               const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
-                              unsigned int* amax_out, const void* zpage, hipStream_t st) {
+                              unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs, const float* out_scale_dev) {
     const int M = n * H * W, K = 9 * Cin;
-    RLCF_ARG_CHECK(act_pairs && Wpairs && C && zpage && gemm_f16x3_conv3x3_ok(M, Cout, Cin) && ldc % 4 == 0 && ldr % 4 == 0);
+    RLCF_ARG_CHECK(act_pairs && Wpairs && (C || Cpairs) && zpage && gemm_f16x3_conv3x3_ok(M, Cout, Cin) && ldc % 4 == 0 && ldr % 4 == 0);
     GemmX3Args g{};
     g.Ahi = (const _Float16*)act_pairs; g.Alo = g.Ahi + 32; g.lda = 2 * Cin;
     g.Whi = (const _Float16*)Wpairs; g.Wlo = g.Whi + 32; g.ldw = 2 * K;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = Cout; g.K = K; g.alpha = alpha;
     g.epilogue = epilogue; g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.kstep = 64;
     g.conv_C = Cin; g.conv_H = H; g.conv_W = W; g.zpage = (const _Float16*)zpage;
+    if (Cpairs) { RLCF_ARG_CHECK(Cout % 32 == 0); g.Chi = (_Float16*)Cpairs; g.Clo = g.Chi + 32; g.ldch = 2 * Cout; g.c_il = 1; g.out_scale_dev = out_scale_dev; }
     static int nofast = -1;
     if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }
     g.no_fast_epi = nofast;

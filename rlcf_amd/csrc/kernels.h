@@ -67,14 +67,16 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev = nullptr,
                       unsigned int* amax_out = nullptr, int c_il = 0, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
-                      int single = 0 /* plain f16 operands, one MFMA per product (RLCF_PREC_F16): see GemmX3Args */);
+                      int single = 0 /* plain f16 operands, one MFMA per product (RLCF_PREC_F16): see GemmX3Args */,
+                      const float* out_scale_dev = nullptr /* device scalar multiplied into the split output (GemmX3Args) */);
 #define X3_SPLITK_WS_BYTES ((size_t)4 * 128 * 128 * 128 * sizeof(float))   // 4 slices x (<= 128 tiles of 128x128): the largest split-K launch
 int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
 // implicit 3x3 convolution (stride 1, pad 1) on operand pairs of the NHWC activation; zpage: >= 1 KB of zeros (gemm_f16x3.hip)
 bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin);
 int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
                               const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
-                              unsigned int* amax_out, const void* zpage, hipStream_t st);
+                              unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs = nullptr,
+                              const float* out_scale_dev = nullptr);
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
 int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il = 0);
 int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il = 0);

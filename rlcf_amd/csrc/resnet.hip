@@ -169,6 +169,32 @@ static const float* raw_of(ClipModel& m, const std::string& k, size_t numel) {
     return it->second.as<float>();
 }
 
+// max_row sum_k |w[row, k]| -> out[0], max |b| -> out[1] (bit patterns of non-negative floats, atomicMax)
+__global__ __launch_bounds__(256) void conv_gain_kernel(const float* __restrict__ w, const float* __restrict__ b, int Kp, unsigned int* __restrict__ out) {
+    __shared__ float part[4];
+    const int row = blockIdx.x;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < Kp; i += 256) a += fabsf(w[(size_t)row * Kp + i]);
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out, __float_as_uint((part[0] + part[1]) + (part[2] + part[3])));
+        atomicMax(out + 1, __float_as_uint(fabsf(b[row])));
+    }
+}
+// s = 2^k with (gain max|in| + bmax + max|res|) s in [2^14, 2^15): |C| cannot exceed that bound, so the pairs the epilogue writes as
+// C s stay inside f16's range (max 65504) WITHOUT knowing max|C|, which only exists once the launch has finished.  The bound is
+// 10-30x above the real maximum for these layers: the pairs then sit around 2^10, where the split-f16 scheme wants them.
+__global__ void conv_bound_scale_kernel(const float* __restrict__ amax_in, const float* __restrict__ amax_res, float gain, float bmax,
+                                        float* __restrict__ out2) {
+    const float B = 1.02f * (gain * amax_in[0] + bmax + (amax_res ? amax_res[0] : 0.f));
+    int sh = 0;
+    if (B > 0.f && B < INFINITY) sh = 14 - (int)floorf(log2f(B));
+    sh = sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+    out2[0] = ldexpf(1.0f, sh);
+    out2[1] = ldexpf(1.0f, -sh);
+}
 static int fold(rlcf_engine* e, ClipModel& m, const std::string& conv, const std::string& bn, int cout, int cin, int k, ConvW& out,
                 hipStream_t st) {
     const int kk = k * k;
@@ -190,6 +216,16 @@ static int fold(rlcf_engine* e, ClipModel& m, const std::string& conv, const std
     conv_fold_kernel<<<dim3(cout), dim3(256), 0, st>>>(w, g, b, mu, var, wp, bp, cin, kk, out.Kp);
     RLCF_LAUNCH_CHECK();
     out.w = wp; out.b = bp;
+    {   // gain / bias bound of the folded convolution (host constants of the pair-emitting epilogues' scale choice)
+        TRY(e->dyn.ensure(3 * sizeof(float)));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->dyn.p, 0, 2 * sizeof(float), st));
+        conv_gain_kernel<<<dim3(cout), dim3(256), 0, st>>>(wp, bp, out.Kp, (unsigned int*)e->dyn.p);
+        RLCF_LAUNCH_CHECK();
+        float gb[2];
+        RLCF_HIP_CHECK(hipMemcpyAsync(gb, e->dyn.p, sizeof(gb), hipMemcpyDeviceToHost, st));
+        RLCF_HIP_CHECK(hipStreamSynchronize(st));
+        out.gain = gb[0]; out.bmax = gb[1];
+    }
     return engine_make_split(e, m, out.w, (size_t)cout * out.Kp, st);
 }
 
@@ -310,6 +346,38 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
                        cw.k == 1 ? in_amax : nullptr, out_amax);
 }
 
+// ---- pair-emitting form (inference tower, split-f16 mode): a convolution reads its input as operand pairs (written by the producing
+// GEMM's epilogue, or split here from f32) and can write its output as pairs for the next one, scaled by a power of two chosen from an
+// upper bound of |output| (conv_bound_scale_kernel): no stand-alone split pass, and no f32 copy of tensors only convolutions read.
+struct ConvIn { const float* f32 = nullptr; const float* amax = nullptr; const void* pairs = nullptr; const float* scale2 = nullptr; };
+struct ConvOut { float* f32 = nullptr; void* pairs = nullptr; float* scale2 = nullptr; float* amax = nullptr; };
+static bool conv_pairs_ok(rlcf_engine* e, const ConvW& cw, long M) {
+    if (!prec_x3(e) || prec_single(e) || M <= 512 || cw.cin % 32 || cw.cout % 32 || !engine_has_split(e, cw.w)) return false;
+    if ((size_t)M * cw.cin > e->a_split_elems) return false;
+    return cw.k == 1 || (cw.Kp == 9 * cw.cin && gemm_f16x3_conv3x3_ok((int)M, cw.cout, cw.cin));
+}
+// stride 1, NHWC; res / res_amax: identity branch and max|identity| (for the bound)
+static int conv_pairs(rlcf_engine* e, const ConvW& cw, ConvIn in, int n, int H, int W, const float* res, const float* res_amax, int epi,
+                      ConvOut out, hipStream_t st) {
+    const long M = (long)n * H * W;
+    if (!in.pairs) {
+        void* p = nullptr;
+        TRY(engine_split_operand(e, in.f32, M * cw.cin, in.amax, &p, &in.scale2, st));
+        in.pairs = p;
+    }
+    if (out.pairs) {
+        if (!in.amax) { rlcf_set_error("conv_pairs: the bound of a pair output needs max|input|"); return RLCF_ERR_STATE; }
+        conv_bound_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(in.amax, res_amax, cw.gain, cw.bmax, out.scale2);
+        RLCF_LAUNCH_CHECK();
+    }
+    if (out.amax) RLCF_HIP_CHECK(hipMemsetAsync(out.amax, 0, sizeof(float), st));       // (after the bound kernel read the old value)
+    if (cw.k == 1)
+        return engine_gemm_pairs(e, in.pairs, cw.cin, in.scale2 + 1, cw.w, cw.b, res, cw.cout, out.f32, cw.cout, out.pairs, out.scale2, (int)M,
+                                 cw.cout, epi, st, out.amax);
+    return engine_gemm_conv3x3(e, nullptr, in.scale2, cw.w, cw.b, res, cw.cout, out.f32, cw.cout, n, H, W, cw.cin, cw.cout, epi, st, out.amax,
+                               in.pairs, out.pairs, out.scale2);
+}
+
 static int avgpool2(const float* in, float* out, int n, int Ho, int Wo, int C, hipStream_t st) {
     const long total = (long)n * Ho * Wo * C;
     avgpool2_kernel<<<grid_for(total), dim3(256), 0, st>>>(in, out, total, C, Ho, Wo);
@@ -347,8 +415,36 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
         H /= 2;
         TRY(avgpool2(A, X, n, H, H, w, st));
         RLCF_HIP_CHECK(hipMemcpyAsync(amX, amA, sizeof(float), hipMemcpyDeviceToDevice, st));
+        static int no_fuse = -1;                                               // RLCF_RN_NOFUSE=1: every block on the f32-activation path (A/B)
+        if (no_fuse < 0) { const char* ev = getenv("RLCF_RN_NOFUSE"); no_fuse = ev ? atoi(ev) : 0; }
+        bool x_pairs = false;                                                  // Xp holds X as operand pairs (scale sX)
+        for (DevBuf& pb : e->rn_pairs) TRY(pb.ensure((size_t)chunk * r.act_per_img * 4));
+        TRY(e->rn_scale.ensure(8 * sizeof(float)));
+        void *Xp = e->rn_pairs[0].p, *Ap = e->rn_pairs[1].p, *Bp = e->rn_pairs[2].p;
+        float *sX = e->rn_scale.as<float>(), *sA = sX + 2, *sB = sX + 4;
         for (const BottleW& b : r.blocks) {                                    // Bottleneck.forward, model.py:42-55
             const int planes = b.c1.cout, Ho = H / b.stride;
+            const long Mi = (long)n * H * H;
+            if (!no_fuse && b.stride == 1 && conv_pairs_ok(e, b.c1, Mi) && conv_pairs_ok(e, b.c2, Mi) && conv_pairs_ok(e, b.c3, Mi) &&
+                (!b.has_down || conv_pairs_ok(e, b.down, Mi))) {
+                // conv1 -> pairs -> conv2 (implicit 3x3) -> pairs -> conv3 (+ identity, ReLU) -> X as f32 (the next identity) and as pairs
+                ConvIn in1;
+                if (x_pairs) { in1.pairs = Xp; in1.scale2 = sX; in1.amax = amX; } else { in1.f32 = X; in1.amax = amX; }
+                TRY(conv_pairs(e, b.c1, in1, n, H, H, nullptr, nullptr, RLCF_EPI_RELU, ConvOut{nullptr, Ap, sA, amA}, st));
+                if (!in1.pairs) { in1.f32 = X; }                                    // (conv_pairs split into the shared scratch: not reusable)
+                TRY(conv_pairs(e, b.c2, ConvIn{nullptr, amA, Ap, sA}, n, H, H, nullptr, nullptr, RLCF_EPI_RELU, ConvOut{nullptr, Bp, sB, amB}, st));
+                const float* idn = X;
+                const float* idn_amax = amX;
+                if (b.has_down) {
+                    TRY(conv_pairs(e, b.down, in1, n, H, H, nullptr, nullptr, RLCF_EPI_NONE, ConvOut{Dd, nullptr, nullptr, amD}, st));
+                    idn = Dd; idn_amax = amD;
+                }
+                // (the bound kernel inside reads max|identity| before amX is re-zeroed for the new X; X is updated in place)
+                TRY(conv_pairs(e, b.c3, ConvIn{nullptr, amB, Bp, sB}, n, H, H, idn, idn_amax, RLCF_EPI_RELU, ConvOut{X, Xp, sX, amX}, st));
+                x_pairs = true;
+                continue;
+            }
+            x_pairs = false;
             ZERO(amA);
             TRY(conv(e, b.c1, X, amX, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, amA, st));
             ZERO(amB);
