@@ -1024,6 +1024,27 @@ def test_bn_tuning_matches_reference_fixture(L, dev, name, prec):
     eng.close()
 
 
+def test_bn_tuning_with_resnet_reward_matches_oracle(L, dev):
+    """A ModifiedResNet student whose BatchNorms are tuned, scored by a ModifiedResNet REWARD model: the reward
+    model's inference pass runs between the student's train-form forward and its backward and shares the tower scratch with it (the
+    student's saved attention-pool tensors must survive it).  Against the oracle (pinned to the reference by the bn_* fixtures)."""
+    from rlcf_amd.engine import TTAConfig
+    N, n_cls = 8, 16
+    cfg = TTAConfig(selection_p=0.5, lr=1e-3, tta_steps=2)
+    eng, ssd, rsd, tokens, _ = make_engine(("tiny-rn", "tiny-rn"), N, n_cls, L.TEXT_SHARED, prec=2)
+    views = synth.make_views(1003, N, synth.GEOMETRIES["tiny-rn"].image_resolution)
+    ref = RR.tta_sample_ln(ssd, rsd, views, tokens, RR.TTAHyper(selection_p=0.5, tta_steps=2, sample_k=cfg.sample_k, lr=1e-3,
+                                                                 weight_decay=cfg.weight_decay))
+    o = eng.tta_sample_ln(views.to(dev), cfg)
+    assert o["selected_idx"].cpu().tolist() == ref["selected_idx"].tolist()
+    assert o["topk_idx"].cpu().reshape(-1).tolist() == ref["topk_idx"].reshape(-1).tolist()
+    gr, og = ref["ln_grad"], o["ln_grad"].cpu()
+    assert gr.norm() > 0 and (og - gr).norm() / gr.norm() < 2e-3
+    torch.testing.assert_close(o["final_logits"].cpu(), ref["final_logits"], atol=5e-3, rtol=0)
+    torch.testing.assert_close(eng.bn_stats().cpu(), ref["bn_stats_after"], atol=2e-4, rtol=2e-3)
+    eng.close()
+
+
 def test_bn_tuning_batch_and_refusals(L, dev):
     """rlcf_tta_batch_ln with a ResNet student runs the samples one by one (the batch statistics couple one sample's views);
     every-parameter tuning of a ResNet student is refused loudly."""
