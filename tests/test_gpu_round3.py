@@ -371,3 +371,24 @@ def test_backbone_tuning_bit_reproducible(L, dev, geo, n_cls):
         for k in ("ln_grad", "vis_grad", "vis_after", "final_logits"):
             assert torch.equal(o[k], full[0][k]), k
     eng.close()
+
+
+# ------------------------------------------------------------------------------ bench.py --config: the other single-GPU BASELINE configs
+@pytest.mark.parametrize("config,classes", [(0, 50), (2, 50), (4, 50)])
+def test_bench_config_switch_emits_the_contract_line(L, dev, config, classes):
+    """`bench.py --config N`: configs[0] (N = 8 views, selection_p 0.5), configs[2] (ViT-L/14 LayerNorm tuning through
+    rlcf_tta_batch_ln) and configs[4] (RN50x64 @448 student: the implicit 3x3 convolutions and the pair-to-pair hand-over of the ResNet
+    tower) emit the same JSON shape as the headline config: metric / value / roofline with a per-kernel table that names backward
+    kernels where the configuration has them."""
+    line = _run_json([sys.executable, "bench.py", "--config", str(config), "--steps", "2", "--warmup", "1", "--classes", str(classes),
+                      "--no-cpu-baseline", "--sustain-seconds", "0"])
+    assert line["metric"] and line["unit"] == "images/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["higher_is_better"] is True and line["config"]["classes"] == classes
+    arch = {0: "ViT-B/16 student", 2: "ViT-L/14 student", 4: "RN50x64 student"}[config]
+    assert arch in line["config"]["workload"] and line["config"]["views"] == {0: 8, 2: 64, 4: 32}[config]
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["achieved"] > 0
+    kinds = {r["kernel"] for r in roof["per_kernel_all_launches"]}
+    assert any("gemm" in k for k in kinds)
+    if config == 2:
+        assert any("attention backward" in k for k in kinds) and any("LayerNorm backward" in k for k in kinds)
