@@ -19,3 +19,10 @@ prof c1 45 "round 3 final build: rocprofv3 --kernel-trace --stats -- python benc
 prof c2 112 "round 3 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 2 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[2]: ViT-L/14 + ViT-L/14, LayerNorm tuning, N = 64, 16 images per pass; warm-up + timed + profiled passes)" --config 2 --no-cpu-baseline --sustain-seconds 0
 prof c4 97 "round 3 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 4 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[4]: RN50x64 @448 student + ViT-L/14 reward, N = 32, one image per pass; warm-up + timed + profiled images)" --config 4 --no-cpu-baseline --sustain-seconds 0
 ls -la $O | head -40
+# row a-R: RN50 student, BatchNorm tuning
+REWARD_ARCH=ViT-B/16 timeout 300 python tools/time_ln_path.py RN50 1000 1 1 > $O/bn_rn50.txt 2>&1
+REWARD_ARCH=ViT-B/16 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bn -- python tools/time_ln_path.py RN50 1000 1 1 > $O/prof_bn.log 2>&1
+db=$(find /tmp/prof_bn -name "*_results.db" | head -1)
+[ -n "$db" ] && python tools/prof_summary.py "$db" "row a-R, final build: RN50 student, BatchNorm tuning (rlcf_tta_sample_ln), N=64 views, C=1000, 1 step, ViT-B/16 reward; REWARD_ARCH=ViT-B/16 rocprofv3 --kernel-trace --stats -- python tools/time_ln_path.py RN50 1000 1 1 (6 test images incl. 2 warm-up)" 6 > $O/kernel_stats_bn.txt
+rm -rf /tmp/prof_bn $O/prof_bn.log
+tail -2 $O/bn_rn50.txt
