@@ -1,7 +1,7 @@
-"""Per-BatchNorm relative error of the gradient rlcf_tta_sample_ln returns for a ResNet student, against a bn_* reference fixture."""
+"""(diagnostic, run by hand: python tests/diag_bn_fixture.py [fixture]) Per-BatchNorm relative error of the gradient rlcf_tta_sample_ln returns for a ResNet student, against a bn_* reference fixture."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_parity import load_golden, _cfg_from_meta
 from oracle import rlcf_ref as RR
 from rlcf_amd import synth, _lib as L

@@ -1,4 +1,4 @@
-"""BatchNorm-tuning gradient of the HIP path vs the oracle (CPU) per layer, on ad-hoc ResNet geometries: bisects accuracy problems."""
+"""(diagnostic, run by hand: python tests/diag_bn_geometries.py tiny w64r64 ...) BatchNorm-tuning gradient of the HIP path vs the oracle (CPU) per layer, on ad-hoc ResNet geometries: bisects accuracy problems."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
