@@ -90,6 +90,15 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo,
                     int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream);
 
+/* 3x3 convolution, stride 1, padding 1, NHWC, as an IMPLICIT GEMM on the f16 matrix cores with split-f16 operands (no patch matrix: the
+ * 256x256 GEMM kernel's DMA reads every tap's K tile straight from the activation's operand pairs): the `conv2` of a Bottleneck
+ * (TPT/clip/model.py:20,44) with its BatchNorm folded, as the engine's ResNet towers run it.  x [n,H,W,Cin], w [Cout,3,3,Cin] ((ky,kx,c)
+ * order), bias [Cout] or NULL, residual [n,H,W,Cout] or NULL (added before the ReLU), epilogue RLCF_EPI_NONE | RLCF_EPI_RELU -> y
+ * [n,H,W,Cout].  Cin % 32 == 0, Cout % 4 == 0, ceil(n H W / 256) * ceil(Cout / 256) >= 192 (smaller grids: the engine keeps the
+ * patch-matrix form); operands should be O(1) (no pre-scale is applied here). */
+int rlcf_conv3x3_nhwc_f16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int n, int H, int W,
+                            int Cin, int Cout, int epilogue, rlcf_stream stream);
+
 /* Row LayerNorm, fp32, eps 1e-5, biased variance (TPT/clip/model.py:157-163). */
 int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        int rows, int width, rlcf_stream stream);

@@ -72,6 +72,26 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
     return launch_gemm_f16x3(Ahi, Alo, lda, Whi, Wlo, ldw, bias, residual, ldr, aux, ldaux, C, ldc, Chi, Clo, ldch, M, N, K, alpha,
                              epilogue, (hipStream_t)stream);
 }
+int rlcf_conv3x3_nhwc_f16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int n, int H, int W, int Cin,
+                            int Cout, int epilogue, rlcf_stream stream) {
+    RLCF_ARG_CHECK(x && w && y && n > 0 && H > 0 && W > 0 && (epilogue == RLCF_EPI_NONE || epilogue == RLCF_EPI_RELU));
+    const int M = n * H * W, K = 9 * Cin;
+    if (!gemm_f16x3_conv3x3_ok(M, Cout, Cin)) {
+        rlcf_set_error("rlcf_conv3x3_nhwc_f16x3: needs Cin %% 32 == 0, Cout %% 4 == 0 and >= 192 tiles of 256x256 (n*H*W = %d, Cout = %d)", M, Cout);
+        return RLCF_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ab = (size_t)M * Cin * 4, wb = (size_t)Cout * K * 4;            // operand pairs: 4 B per element
+    char* buf = nullptr;
+    RLCF_HIP_CHECK(hipMallocAsync((void**)&buf, ab + wb + 4096, st));
+    char *ap = buf, *wp = buf + ab, *zp = buf + ab + wb;
+    RLCF_HIP_CHECK(hipMemsetAsync(zp, 0, 4096, st));
+    int rc = launch_split_f16x2(x, ap, ap + 64, (int64_t)M * Cin, st, 1.0f, 1);
+    if (!rc) rc = launch_split_f16x2(w, wp, wp + 64, (int64_t)Cout * K, st, 1.0f, 1);
+    if (!rc) rc = launch_gemm_f16x3_conv3x3(ap, n, H, W, Cin, wp, Cout, bias, residual, Cout, y, Cout, 1.0f, epilogue, nullptr, nullptr, zp, st);
+    (void)hipFreeAsync(buf, st);
+    return rc;
+}
 int rlcf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int width, rlcf_stream stream) {
     RLCF_ARG_CHECK(x && gamma && beta && y);
     return launch_layernorm_fwd(x, gamma, beta, y, rows, width, (hipStream_t)stream);

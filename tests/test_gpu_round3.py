@@ -392,3 +392,27 @@ def test_bench_config_switch_emits_the_contract_line(L, dev, config, classes):
     assert any("gemm" in k for k in kinds)
     if config == 2:
         assert any("attention backward" in k for k in kinds) and any("LayerNorm backward" in k for k in kinds)
+
+
+# ------------------------------------------------------------------------------ implicit 3x3 convolution (op level)
+@pytest.mark.parametrize("n,H,W,Cin,Cout,epi,res", [(16, 56, 56, 64, 64, 3, False), (4, 28, 28, 32, 4096, 0, True), (40, 15, 15, 96, 1536, 3, True),
+                                                    (52, 10, 24, 128, 1024, 0, False)])
+def test_conv3x3_implicit_gemm_matches_conv2d(L, dev, n, H, W, Cin, Cout, epi, res):
+    """rlcf_conv3x3_nhwc_f16x3 (the 256x256 split-f16 GEMM gathering every tap's K tile from the activation's operand pairs, zero page
+    outside the image) against torch's conv2d in float64: square / odd / non-square maps, M tails, bias + identity + ReLU."""
+    x = synth.normal(3, "cv.x", (n, H, W, Cin)).to(dev)
+    w = (synth.normal(3, "cv.w", (Cout, 3, 3, Cin)) * (9 * Cin) ** -0.5).to(dev)
+    b = synth.normal(3, "cv.b", (Cout,), 0.1).to(dev)
+    r = synth.normal(3, "cv.r", (n, H, W, Cout)).to(dev) if res else None
+    y = torch.empty(n, H, W, Cout, device=dev)
+    L.check(L.lib().rlcf_conv3x3_nhwc_f16x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), n, H, W, Cin, Cout,
+                                            epi, torch.cuda.current_stream().cuda_stream))
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double()
+    if epi == 3:                              # RLCF_EPI_RELU
+        ref = ref.clamp_min(0)
+    torch.testing.assert_close(y.double(), ref, atol=2e-5, rtol=1e-5)
+    with pytest.raises(L.RlcfError):          # too few tiles for the 256x256 kernel: refused, not silently something else
+        L.check(L.lib().rlcf_conv3x3_nhwc_f16x3(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), 1, H, W, Cin, Cout, 0,
+                                                torch.cuda.current_stream().cuda_stream))
