@@ -40,6 +40,7 @@ struct GemmX3Args {
     // or 128 B of zeros (zpage) outside the image.  conv_C = 0: plain GEMM
     int conv_C, conv_H, conv_W;
     const _Float16* zpage;
+    int tile_group;                    // 256x256 interleaved kernel: M tiles per scheduling group (0 = 8)
     const float* out_scale_dev;        // optional device scalar: the split output carries C * out_scale_dev[0] (a power of two chosen from
                                        // an upper bound of |C| before the launch: the consumer undoes it through ITS alpha_dev)
 };
@@ -767,8 +768,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int per_group = 8 * tiles_n, grp = bid / per_group, first_m = grp * 8;
-    const int gsize = min(tiles_m - first_m, 8), in_g = bid - grp * per_group;
+    // M tiles per scheduling group: 8, or 4 when the problem is 3-4 tiles wide (K = 3072 x N = 768: +1.4 %, measured; 16 / 32: -1.5 / -8 %);
+    // RLCF_X3_GROUP pins it (measurements)
+    const int G = g.tile_group > 0 ? g.tile_group : (tiles_n <= 4 ? 4 : 8);
+    const int per_group = G * tiles_n, grp = bid / per_group, first_m = grp * G;
+    const int gsize = min(tiles_m - first_m, G), in_g = bid - grp * per_group;
     const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
@@ -1194,6 +1198,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     static int nofast = -1;
     if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }
     g.no_fast_epi = nofast;
+    static int tgroup = -1;
+    if (tgroup < 0) { const char* e = getenv("RLCF_X3_GROUP"); tgroup = e ? atoi(e) : 0; }
+    g.tile_group = tgroup;
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
     // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes
