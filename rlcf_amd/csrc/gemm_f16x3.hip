@@ -768,12 +768,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // M tiles per scheduling group: 8, or 4 when the problem is 3-4 tiles wide (K = 3072 x N = 768: +1.4 %, measured; 16 / 32: -1.5 / -8 %);
-    // RLCF_X3_GROUP pins it (measurements)
-    const int G = g.tile_group > 0 ? g.tile_group : (tiles_n <= 4 ? 4 : 8);
+    // M tiles per scheduling group: 8 (16 / 32: -1.5 / -8 %, measured); RLCF_X3_GROUP pins it (measurements)
+    const int G = g.tile_group > 0 ? g.tile_group % 100 : 8;
     const int per_group = G * tiles_n, grp = bid / per_group, first_m = grp * G;
     const int gsize = min(tiles_m - first_m, G), in_g = bid - grp * per_group;
-    const int m0 = (first_m + in_g % gsize) * V3_BM, n0 = (in_g / gsize) * V3_BN;
+    // order inside a group: M-fastest (neighbours share a W tile), or — problems 3-4 tiles wide, e.g. c_proj 768 x 3072 — N-fastest
+    // (neighbours share the A panel: 414 -> 421 TF; on the 9 / 12-tile-wide products it costs 1-2 %).  tile_group >= 100 forces it
+    const bool nfast = g.tile_group >= 100 || (g.tile_group == 0 && tiles_n <= 4);
+    const int m0 = (nfast ? first_m + in_g / tiles_n : first_m + in_g % gsize) * V3_BM;
+    const int n0 = (nfast ? in_g % tiles_n : in_g / gsize) * V3_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
 
