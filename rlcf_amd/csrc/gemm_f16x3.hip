@@ -769,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     // M tiles per scheduling group: 8 (16 / 32: -1.5 / -8 %, measured); RLCF_X3_GROUP pins it (measurements)
-    const int G = g.tile_group > 0 ? g.tile_group % 100 : 8;
+    const int G = g.tile_group % 100 > 0 ? g.tile_group % 100 : 8;
     const int per_group = G * tiles_n, grp = bid / per_group, first_m = grp * G;
     const int gsize = min(tiles_m - first_m, G), in_g = bid - grp * per_group;
     // order inside a group: M-fastest (neighbours share a W tile), or — problems 3-4 tiles wide, e.g. c_proj 768 x 3072 — N-fastest
