@@ -757,6 +757,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     amax_commit(g.amax_out, am);
 }
 
+// cache-policy bits of the operand DMA (one-off builds: -DV3_AUX_A=.. / -DV3_AUX_W=..; bit 0 sc0, bit 1 nt, bit 4 sc1)
+#ifndef V3_AUX_A
+#define V3_AUX_A 0
+#endif
+#ifndef V3_AUX_W
+#define V3_AUX_W 0
+#endif
 template <bool SINGLE, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
@@ -826,9 +833,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         if ((idx) < 4) {                                                                                                               \
             if constexpr (CONV) {                                                                                                      \
                 const _Float16* pa_ = ((vm[(idx) & 3] >> ctap_) & 1u) ? g.Ahi + (long)sa[(idx) & 3] + coff_ : zlane;                     \
-                __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);            \
-            } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);           \
-        } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, 0);              \
+                __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);            \
+            } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);           \
+        } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_W);              \
     }
 #undef V3_LDA
 #undef V3_LDB
