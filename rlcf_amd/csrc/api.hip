@@ -519,18 +519,18 @@ int rlcf_engine_get_bn_stats(rlcf_engine* e, float* out, int pristine, rlcf_stre
     return RLCF_OK;
 }
 int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && out && e->ln_count > 0);
+    RLCF_ARG_CHECK(e && out && rlcf_engine_ln_param_count(e) > 0);
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->ln_init.p : e->ln_params.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && in && e->ln_count > 0);
+    RLCF_ARG_CHECK(e && in && rlcf_engine_ln_param_count(e) > 0);
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && current && e->ln_count > 0 && momentum >= 0.0 && momentum <= 1.0);
+    RLCF_ARG_CHECK(e && current && rlcf_engine_ln_param_count(e) > 0 && momentum >= 0.0 && momentum <= 1.0);
     int rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
                                     update_w, apply, (hipStream_t)stream);
     if (rc != RLCF_OK) return rc;
@@ -540,7 +540,7 @@ int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double mom
     return RLCF_OK;
 }
 int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && e->ln_count > 0);
+    RLCF_ARG_CHECK(e && rlcf_engine_ln_param_count(e) > 0);
     hipStream_t st = (hipStream_t)stream;
     const size_t nb = (size_t)e->ln_count * sizeof(float);
     for (DevBuf* d : {&e->ln_params, &e->ln_init, &e->ln_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->ln_clip.p, nb, hipMemcpyDeviceToDevice, st));

@@ -1024,6 +1024,32 @@ def test_bn_tuning_matches_reference_fixture(L, dev, name, prec):
     eng.close()
 
 
+@pytest.mark.parametrize("prior", [-1, 0, 16])
+@pytest.mark.parametrize("prec", [0, 2])
+def test_encode_image_bn_matches_oracle(L, dev, prior, prec):
+    """rlcf_engine_encode_image_bn: the ResNet student's image features with its BatchNorms on batch statistics (train mode, or the prior
+    blend of `_modified_bn_forward`) and the LIVE tunable parameters, against the oracle's train-form encode (pinned to the reference by the
+    bn_* fixtures); the running statistics follow torch's momentum update in train mode and stay put under a prior."""
+    eng, ssd, rsd, tokens, _ = make_engine(("tiny-rn", "tiny-r"), 8, 16, L.TEXT_SHARED, prec=prec)
+    eng.set_bn_prior_strength(prior)
+    keys = RR.visual_bn_keys(ssd)
+    new = {k: ssd[k] * (1.0 + 0.05 * synth.normal(5, "bn." + k, tuple(ssd[k].shape))) + 0.02 for k in keys}      # perturbed gamma / beta
+    eng.set_ln_params(torch.cat([new[k].reshape(-1) for k in keys]))
+    views = synth.make_views(1001, 8, synth.GEOMETRIES["tiny-rn"].image_resolution)
+    mode = CR.BNMode("prior", prior / (prior + 1.0)) if prior >= 0 else CR.BNMode("train")
+    prev = CR.set_bn_mode(mode)
+    try:
+        sd = dict(ssd); sd.update(new)
+        ref = CR.l2_normalize(CR.encode_image(sd, views))
+    finally:
+        CR.set_bn_mode(prev)
+    got = eng.encode_image_bn(views.to(dev)).cpu()
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
+    st = [mode.stats.get(b, (ssd[b + ".running_mean"], ssd[b + ".running_var"])) for b in RR.visual_bn_stat_keys(ssd)]
+    torch.testing.assert_close(eng.bn_stats().cpu(), torch.cat([torch.cat([a.reshape(-1), b.reshape(-1)]) for a, b in st]), atol=1e-5, rtol=1e-4)
+    eng.close()
+
+
 def test_bn_tuning_with_resnet_reward_matches_oracle(L, dev):
     """A ModifiedResNet student whose BatchNorms are tuned, scored by a ModifiedResNet REWARD model: the reward
     model's inference pass runs between the student's train-form forward and its backward and shares the tower scratch with it (the
