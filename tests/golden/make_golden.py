@@ -587,6 +587,12 @@ def main():
             arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp)
             save("ln_tiny_momentum", arrays, dict(student="tiny", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
                                                    bank_seed=7, n_ctx=4, n_samples=3, **hp))
+        elif grp == "bnmom":
+            # ModifiedResNet student with momentum_update: the EMA runs over the whole visual state dict (BatchNorm weights / biases AND buffers)
+            hp = dict(BASE_HP, lr=1e-3, update_freq=2, update_w=0.5, momentum=0.9)
+            arrays = run_reference_ln_momentum(ref, "tiny-rn", "tiny-r", 8, 16, hp)
+            save("bn_tiny_momentum", arrays, dict(student="tiny-rn", reward="tiny-r", n_views=8, n_cls=16, student_seed=11, reward_seed=23,
+                                                   bank_seed=7, n_ctx=4, n_samples=3, prior_strength=-1, **hp))
         elif grp == "vismom":
             hp = dict(BASE_HP, lr=1e-4, update_freq=2, update_w=0.5, momentum=0.9)
             arrays = run_reference_ln_momentum(ref, "tiny", "tiny-r", 8, 16, hp, only_norm=False)

@@ -121,14 +121,14 @@ def _cls_tta_objects(dev, meta, only_norm):
     from rlcf_amd import clip_reward, clip_store, custom_clip, runtime
     runtime.reset_session()
     sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
-    clip_store.register_checkpoint("tiny", sg, synth.make_state_dict(sg, meta["student_seed"]))
+    clip_store.register_checkpoint(meta["student"], sg, synth.make_state_dict(sg, meta["student_seed"]))
     clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
     bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
     clip_store.set_tokenizer(bank.tokenize)
     args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000,
                                  min_entropy_reg=0, min_entropy_w=0.1, reward_arch="tiny-r", multiple_reward_models=0,
                                  sample_k=meta["sample_k"], reward_amplify=False, reward_process=True, process_batch=False)
-    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny", prompt_prefix="a_photo_of_a", only_visual=True,
+    model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch=meta["student"], prompt_prefix="a_photo_of_a", only_visual=True,
                                     only_norm=only_norm, momentum_update=True, update_freq=meta["update_freq"],
                                     update_w=meta["update_w"], momentum=meta["momentum"])
     reward_model = clip_reward.get_reward_model(dev, args)
@@ -137,7 +137,7 @@ def _cls_tta_objects(dev, meta, only_norm):
     return model, optimizer, copy.deepcopy(optimizer.state_dict()), reward_model, args, bank
 
 
-@pytest.mark.parametrize("fixture,only_norm", [("ln_tiny_momentum", True), ("vis_tiny_momentum", False)])
+@pytest.mark.parametrize("fixture,only_norm", [("ln_tiny_momentum", True), ("vis_tiny_momentum", False), ("bn_tiny_momentum", True)])
 def test_shipped_harness_applies_the_momentum_update(L, dev, fixture, only_norm):
     """rlcf_amd.tpt_cls_rl.test_time_adapt_eval with a CLIPCLS_TTA(momentum_update=True) model is TPT/tune_cls_rl.py:183-256: after every
     sample's clean-view inference it must call model.momentum_update_model() (:240).  Three consecutive samples THROUGH THE HARNESS:
@@ -177,7 +177,7 @@ def test_shipped_harness_applies_the_momentum_update(L, dev, fixture, only_norm)
         torch.testing.assert_close(_tensor_norms(ssd, keys, reset_state, ssd), g[f"vis_reset_delta_l2_{last}"], rtol=0.01, atol=1e-7)
         assert float(g[f"vis_reset_delta_l2_{last}"].sum()) > 0
     # next dataset: class bank swapped, visual state back to the checkpoint (after sample 0 the reference's reset state still IS the checkpoint)
-    model.reset_classnames_and_state(bank.classnames, "tiny")
+    model.reset_classnames_and_state(bank.classnames, meta["student"])
     eng = runtime.SESSION.engine()
     a, b = eng.ln_params(pristine=True), eng.ln_params(pristine=False)
     assert torch.equal(a, b) and torch.equal(model.ln.data, a)

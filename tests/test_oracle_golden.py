@@ -161,6 +161,35 @@ def test_ln_momentum_update_matches_reference():
     assert (g["ln_reset_1"] - g["ln_reset_0"]).abs().max() > 1e-5          # the reset state really moved
 
 
+def test_bn_momentum_update_matches_reference():
+    """The same three-sample momentum run with a ModifiedResNet student (CLIPCLS_TTA(arch = tiny-rn, only_norm=True, momentum_update=True)):
+    the EMA of the tuned BatchNorm weights / biases and the moving reset state against the reference's own run.  (The reference's EMA also
+    runs over the BatchNorm buffers; with the norm layers in train mode the running statistics never reach an output, so the restatement
+    carries the parameters only.)"""
+    g, meta = load("bn_tiny_momentum")
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    rsd = synth.make_state_dict(rg, meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    hp = R.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                    weight_decay=meta["weight_decay"])
+    clip = torch.cat([ssd[k].reshape(-1) for k in R.visual_bn_keys(ssd)])
+    mom, init, counter = clip.clone(), clip.clone(), 0
+    for i in range(meta["n_samples"]):
+        views = synth.make_views(1000 + i, meta["n_views"], sg.image_resolution)
+        o = R.tta_sample_ln(ssd, rsd, views, tokens, hp, ln_init=init, prior_strength=meta["prior_strength"])
+        d = (o["ln_after"] - g[f"ln_after_{i}"]).abs()
+        assert (d > 0.1 * meta["lr"]).float().mean() < 0.01
+        torch.testing.assert_close(o["final_logits"], g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        counter += 1
+        apply = counter >= meta["update_freq"]
+        mom, new_init = R.momentum_update(mom, g[f"ln_after_{i}"], clip, meta["momentum"], meta["update_w"], apply)
+        if apply:
+            counter, init = 0, new_init
+        torch.testing.assert_close(init, g[f"ln_reset_{i}"], atol=1e-7, rtol=1e-6)
+    assert (g["ln_reset_1"] - g["ln_reset_0"]).abs().max() > 1e-5
+
+
 def test_synth_is_deterministic():
     a = synth.normal(1, "x", (1000,))
     b = synth.normal(1, "x", (1000,))
