@@ -780,6 +780,7 @@ int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
     if (!m.finalized || !is_resnet(m.cfg)) { rlcf_set_error("BatchNorm tuning needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
     ResNetW& r = m.rn;
     if (r.bn_enabled) return RLCF_OK;
+    if (prec_single(e)) { rlcf_set_error("BatchNorm tuning runs in RLCF_PREC_F32 / RLCF_PREC_F16X3 (RLCF_PREC_F16 is the prompt path's performance mode)"); return RLCF_ERR_STATE; }
     m.derived.reserve(m.derived.size() + 8 * (r.blocks.size() * 4 + 3) + 16);
     const rlcf_clip_cfg& c = m.cfg;
     const int w = c.vision_width;

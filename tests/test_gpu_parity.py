@@ -1089,6 +1089,11 @@ def test_bn_tuning_batch_and_refusals(L, dev):
     with pytest.raises(L.RlcfError, match="VisionTransformer|BatchNorm"):
         eng.visual_layout()
     eng.close()
+    # the single-pass f16 performance mode has no tuning paths: refused, not run in reduced precision
+    e16, *_ = make_engine(("tiny-rn", "tiny-r"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16)
+    with pytest.raises(L.RlcfError, match="RLCF_PREC_F16"):
+        e16.tta_sample_ln(vs[0], cfg)
+    e16.close()
 
 
 @pytest.mark.parametrize("steps", [1, 3])
