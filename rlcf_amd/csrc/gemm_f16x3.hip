@@ -60,7 +60,9 @@ __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_
 // are parked and combined in registers (no store yet); then the 16 rows stream out back to back.  Each wave parks and re-reads only
 // its own LDS slice, so one barrier (the ring is no longer read) is all the synchronisation there is.
 // One call = the 64x64 slab of one wave: a0..a3 = accumulator tiles (i, j) = (0,0) (0,1) (1,0) (1,1); row0 / col0 = its origin.
-template <int EPI, bool RES, bool F32OUT, bool PAIR>
+// LEAN (the experimental 4-wave kernel, which has no register to spare): the forward towers' form only -- host alpha, no ReLU, no
+// max|C|, no output scale
+template <int EPI, bool RES, bool F32OUT, bool PAIR, bool LEAN = false>
 __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3,
                                                  float* park, int row0, int col0, int lane, float& am) {
     constexpr int ELD = 68;
@@ -71,9 +73,10 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     const int colc = colok ? col : 0;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) bv = *(const float4*)(g.bias + colc);
-    const float al = x3_alpha(g);                          // (alpha_dev: the device-side undo of a data-dependent operand scale)
-    const bool relu = g.epilogue == RLCF_EPI_RELU;         // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
-    const float os = (PAIR && g.out_scale_dev) ? g.out_scale_dev[0] : 1.0f;
+    const float al = LEAN ? g.alpha : x3_alpha(g);         // (alpha_dev: the device-side undo of a data-dependent operand scale)
+    const bool relu = !LEAN && g.epilogue == RLCF_EPI_RELU;     // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
+    const float os = (!LEAN && PAIR && g.out_scale_dev) ? g.out_scale_dev[0] : 1.0f;
+    const bool want_amax = !LEAN && g.amax_out != nullptr;
     const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
     const int rbase = row0 + rsub;
     float4 rr[16];
@@ -102,7 +105,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
             const int row = rbase + it * 4;
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (colok && row < g.M) {
-                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 if constexpr (PAIR) {
                     h16x4 hh, ll;
@@ -120,7 +123,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         for (int it = 0; it < 16; ++it) {
             const int row = rbase + it * 4;
             if (colok && row < g.M) {
-                if (g.amax_out) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
+                if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
                 if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = rr[it];
                 if constexpr (PAIR) {
                     const float v[4] = {rr[it].x * os, rr[it].y * os, rr[it].z * os, rr[it].w * os};
@@ -1171,12 +1174,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_f16x3_v4_kernel(GemmX3Args g) 
     float* parkf = (float*)smem + wave * (64 * 68);
     float am = 0.f;
     __syncthreads();
+    // (kinds 1-4 in their LEAN form: with the ResNet additions of the epilogue -- device alpha, ReLU, max|C|, output scale -- the 492
+    // registers no longer suffice and the accumulators spill; the launcher sends those products to the 8-wave kernel)
+#define V4_SLAB(...)                                                                                                     \
+    {                                                                                                                    \
+        if (ek == 1) x3_epilogue_slab<RLCF_EPI_NONE, false, true, false, true>(__VA_ARGS__);                             \
+        else if (ek == 2) x3_epilogue_slab<RLCF_EPI_NONE, true, true, false, true>(__VA_ARGS__);                         \
+        else if (ek == 3) x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true, true>(__VA_ARGS__);                   \
+        else x3_epilogue_slab<RLCF_EPI_NONE, false, false, true, true>(__VA_ARGS__);                                     \
+    }
 #pragma unroll
     for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
         for (int hc = 0; hc < 2; ++hc)
-            X3_EPILOGUE_SLAB(ek, g, acc[hr * 2][hc * 2], acc[hr * 2][hc * 2 + 1], acc[hr * 2 + 1][hc * 2], acc[hr * 2 + 1][hc * 2 + 1], parkf,
-                             m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane, am)
+            V4_SLAB(g, acc[hr * 2][hc * 2], acc[hr * 2][hc * 2 + 1], acc[hr * 2 + 1][hc * 2], acc[hr * 2 + 1][hc * 2 + 1], parkf,
+                    m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane, am)
     amax_commit(g.amax_out, am);
 }
 
