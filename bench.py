@@ -15,8 +15,10 @@ the max-over-ranks of the elapsed time use RCCL.  `--total-images T` switches fr
 Legs, in order (all on the launch stream of the engine = torch's current stream):
   1. warm-up (`--warmup` images, untimed) and the TIMED region: exactly `--steps` images, barrier + synchronize on
      both sides, max over ranks -> `value`, `ms_per_step`;
-  2. sustained leg (rank 0, N=1 runs): full passes repeated for >= `--sustain-seconds` with a HIP event pair per
-     pass -> mean / p50 / min / max ms per image (`sustained`);
+  2. sustained leg: full passes repeated for >= `--sustain-seconds` with a HIP event pair per pass -> mean / p50 / min / max ms
+     per image (`sustained`; N=1 runs).  Multi-rank runs: every rank first settles its GPU's clock with untimed passes
+     (`--settle-seconds`), the timed region reports each rank's own seconds and the slowest / fastest ratio, and the sustained leg
+     runs on EVERY rank concurrently (`distributed.sustained`: per-rank and aggregate images/s);
   3. roofline leg: ONE pass of exactly the pass size the timed region ran, with a HIP event pair round every GEMM and
      attention launch (rlcf_profile_*): dominant-kernel rate, per-shape table of the ViT-B/16 layer kernels (K4-K7);
   4. cpu_baseline: the oracle (CPU restatement of the reference graph) on BASELINE configs[0] — N=8 views,
@@ -178,6 +180,8 @@ def main():
     ap.add_argument("--total-images", type=int, default=0,
                     help="strong scaling: this many test images in total, split over the ranks (BASELINE configs[3]: 256); overrides --steps")
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained leg (0 = skip)")
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="multi-rank runs: untimed passes of the timed pass size for this long before the barrier (clock / power settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=300.0, help="seconds after which no further timed CPU sample is started")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary single-pass f16 measurement (RLCF_PREC_F16, not parity-grade)")
@@ -222,7 +226,7 @@ def main():
             ver = None
         dist_info = {"backend": a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else ""), "rccl_ranks": dist.get_world_size(),
                      "rccl_version": ".".join(str(v) for v in ver) if ver else None,
-                     "collectives": "barrier x2 + all_reduce(MAX) of the elapsed time; none on the data path"}
+                     "collectives": "barriers + all_reduce(MAX) of the elapsed time + all_gather of per-rank seconds; none on the data path"}
 
     geo = synth.GEOMETRIES[student_arch]
     n_ctx = 4
@@ -263,26 +267,76 @@ def main():
     if a.warmup:
         run_pass(wviews[: a.warmup])
     torch.cuda.synchronize()
+    settle = 0
+    if use_dist and a.settle_seconds > 0:
+        # multi-rank runs: the timed region is ONE short pass per rank, so every rank first brings its GPU to the clock / power state
+        # of the steady loop (untimed passes of the timed pass size) — otherwise the first N-GPU number measures clock ramp and
+        # launch skew, not the step
+        t_end = time.perf_counter() + a.settle_seconds
+        while time.perf_counter() < t_end:
+            run_pass(wviews[:pass_images])
+            torch.cuda.synchronize()
+            settle += 1
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     top5 = run_pass(views)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                    # this rank's own K steps (before it waits for the others)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cdev = dev if a.dist_backend == "nccl" else "cpu"
+    rank_seconds = [dt_own]
     if use_dist:
-        t = torch.tensor([dt], device=dev if a.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        own = torch.tensor([dt_own], device=cdev, dtype=torch.float64)
+        parts = [torch.empty_like(own) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, own)
+        rank_seconds = [float(x.item()) for x in parts]
     flops_exec = eng.last_flops()
     log(f"timed region: {total_steps} images in {dt:.3f} s")
     ms_per_step = dt / (total_steps / world) * 1e3       # per rank: every rank runs total/world images concurrently
 
+    dist_sustained = None
+    if use_dist and a.sustain_seconds > 0:
+        # ---- sustained leg of a multi-rank run: EVERY rank repeats full passes for >= sustain_seconds at the same time (barrier in
+        # front, none inside), one HIP event pair per pass; the per-rank rates are gathered (the aggregate is their sum: no rank waits
+        # for another on the data path)
+        pv = views[:pass_images]
+        dist.barrier()
+        evs, t_end = [], time.perf_counter() + a.sustain_seconds
+        while time.perf_counter() < t_end or len(evs) < 5:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run_pass(pv)
+            e1.record()
+            evs.append((e0, e1))
+            if len(evs) % 4 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        per_img = [e0.elapsed_time(e1) / pass_images for e0, e1 in evs]
+        mine = torch.tensor([statistics.fmean(per_img), float(len(per_img))], device=cdev, dtype=torch.float64)
+        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        ms = [float(x[0].item()) for x in parts]
+        dist_sustained = {"seconds_per_rank_at_least": a.sustain_seconds, "passes_per_rank": [int(x[1].item()) for x in parts],
+                          "images_per_pass": pass_images, "mean_ms_per_image_per_rank": ms,
+                          "images_per_s_per_rank": [1e3 / m for m in ms], "images_per_s_aggregate": sum(1e3 / m for m in ms),
+                          "slowest_over_fastest_rank": max(ms) / min(ms),
+                          "timer": "HIP events on each rank's launch stream, one pair per pass, all ranks running concurrently"}
     if rank == 0:
         lib = _lib.lib()
+        if dist_info:
+            dist_info["timed_region_seconds_per_rank"] = rank_seconds
+            dist_info["timed_region_slowest_over_fastest_rank"] = max(rank_seconds) / max(min(rank_seconds), 1e-12)
+            dist_info["settle_passes_before_timed_region"] = settle
+            if dist_sustained:
+                dist_info["sustained"] = dist_sustained
         peak = PEAK_TFLOPS["f32"] if a.precision == "f32" else PEAK_TFLOPS["f16"]
         passes = MFMA_PASSES[a.precision]
         tuned = "LayerNorm parameters of the image encoder" if mode_ln else "prompt"

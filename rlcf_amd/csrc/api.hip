@@ -69,8 +69,20 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                     int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {
     RLCF_ARG_CHECK(epilogue >= RLCF_EPI_NONE && epilogue <= RLCF_EPI_RELU && (epilogue != RLCF_EPI_QUICKGELU_BWD || aux));
-    return launch_gemm_f16x3(Ahi, Alo, lda, Whi, Wlo, ldw, bias, residual, ldr, aux, ldaux, C, ldc, Chi, Clo, ldch, M, N, K, alpha,
-                             epilogue, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // stateless call: the stream-K scratch of the 256x256 kernel (grids of >= 64 tiles that do not fill their last round) comes from
+    // the stream-ordered allocator; the engine path owns its own (engine.h: gemm_ws)
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    char* ws = nullptr;
+    unsigned epoch = 0;
+    static int sk_on = -1;                                   // (off by default: gemm_f16x3.hip says why)
+    if (sk_on < 0) { const char* ev = getenv("RLCF_X3_SK"); sk_on = ev ? atoi(ev) : 0; }
+    if (sk_on && tiles >= 64 && tiles % 256 != 0 && (const char*)Alo == (const char*)Ahi + 64) RLCF_HIP_CHECK(hipMallocAsync((void**)&ws, X3_WS_BYTES, st));
+    const int rc = launch_gemm_f16x3(Ahi, Alo, lda, Whi, Wlo, ldw, bias, residual, ldr, aux, ldaux, C, ldc, Chi, Clo, ldch, M, N, K, alpha,
+                                     epilogue, st, nullptr, nullptr, 0, (float*)ws,
+                                     ws ? X3_WS_BYTES : 0, 0, nullptr, ws ? &epoch : nullptr);
+    if (ws) (void)hipFreeAsync(ws, st);
+    return rc;
 }
 int rlcf_conv3x3_nhwc_f16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int n, int H, int W, int Cin,
                             int Cout, int epilogue, rlcf_stream stream) {
@@ -272,8 +284,8 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
          e->vit_cls_idx.ensure(cls_idx.size() * sizeof(int32_t)) == 0;
     if (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16) {
         e->a_split_elems = std::max((size_t)Tmax * Wmax * 4, (size_t)Pmax * Kpmax);
-        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_SPLITK_WS_BYTES) == 0 &&
-             e->gemm_ws2.ensure(X3_SPLITK_WS_BYTES) == 0;
+        ok = ok && e->a_hi.ensure(e->a_split_elems * 4) == 0 && e->gemm_ws.ensure(X3_WS_BYTES) == 0 &&
+             e->gemm_ws2.ensure(X3_WS_BYTES) == 0;
     }
     ok = ok && hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
@@ -285,42 +297,14 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     return e;
 }
 
-static void release_tower(Tower& t) {
-    t.x.release(); t.h.release(); t.qkv.release(); t.a.release(); t.f.release(); t.saved.release();
-    t.h2.release(); t.a2.release(); t.f2.release();
-}
-static void release_layout(TextLayout& L) {
-    L.seqs.release(); L.eot_rows.release(); L.ctx_row.release(); L.E.release(); L.class_start.release(); L.class_len.release();
-    L.class_eot_off.release(); L.ctx_rows_list.release(); L.row_token.release(); L.row_pos.release(); L.pk_seqs.release(); L.pk_rss.release();
-}
 void rlcf_engine_destroy(rlcf_engine* e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    for (auto& m : e->model) {
-        for (auto& kv : m.raw) kv.second.release();
-        for (auto& d : m.derived) d.release();
-    }
-    release_tower(e->vt); release_tower(e->tt); release_tower(e->st);
-    for (auto& L : e->lay) release_layout(L);
-    for (auto& L : e->qlay) release_layout(L);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    for (int m = 0; m < RLCF_MAX_REWARDS; ++m) { e->reward_cls[m].release(); e->rimg[m].release(); }
-    DevBuf* all[] = {&e->patches, &e->patch_out, &e->resized, &e->vit_seqs, &e->cls_rows, &e->cls_ln, &e->feat_raw, &e->eot_x, &e->eot_ln, &e->u,
-                     &e->inv_norm, &e->txt, &e->txt0, &e->ctx_init, &e->ctx, &e->adam_m, &e->adam_v, &e->ctx_grad, &e->sp_seqs,
-                     &e->sp_eot_rows, &e->sp_row_src, &e->sp_ctx_rows_list, &e->sp_dtxt, &e->sp_txt, &e->sp_inv_norm, &e->sp_eot_x,
-                     &e->sp_eot_ln, &e->sp_u, &e->sp_du, &e->sp_dxe, &e->dX, &e->dA, &e->dH, &e->dF, &e->dQKV, &e->img_feat,
-                     &e->sel_feat, &e->logits, &e->sel_logits, &e->entropy, &e->sel_idx, &e->views_sel, &e->topk_idx,
-                     &e->clip_score, &e->rewards, &e->loss, &e->dlogits, &e->dtxt_dense, &e->final_logits, &e->top5, &e->a_hi, &e->b_seqs_rep, &e->b_eot_rep, &e->b_ctx, &e->b_m, &e->b_v, &e->b_grad, &e->b_txt,
-                     &e->b_eot_x, &e->b_eot_ln, &e->b_u, &e->b_inv, &e->b_logits, &e->ln_params, &e->ln_init, &e->ln_grad, &e->ln_m, &e->ln_v,
-                     &e->vit_inv_norm, &e->cls_row_idx, &e->dfeat, &e->dcls, &e->txt0T, &e->ln_feat, &e->ln_clip, &e->ln_mom, &e->b_ln, &e->b_ln_m, &e->b_ln_v, &e->b_ln_grad};
-    for (DevBuf* d : all) d->release();
-    for (DevBuf& d : e->rn_buf) d.release();
-    for (DevBuf* d : {&e->rn_col, &e->rn_tok, &e->rn_q, &e->rn_kv, &e->rn_att, &e->rn_amax, &e->dyn, &e->bwd_amax, &e->vw, &e->vw_init, &e->vw_grad,
-                     &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom, &e->wg_yt, &e->wg_xt, &e->w_hi, &e->gemm_ws, &e->gemm_ws2, &e->a_hi2, &e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v, &e->tln, &e->tln_init,
-                     &e->tln_grad, &e->tln_m, &e->tln_v, &e->tw_clip, &e->tw_mom, &e->tln_clip, &e->tln_mom, &e->attn_pre_ws, &e->b_pk_rep, &e->b_rss_rep, &e->q_feat, &e->q_dfeat, &e->q_ls, &e->rl_stats, &e->step_skip, &e->vit_seqs_cls, &e->vit_cls_idx, &e->cls_a2, &e->cls_h2, &e->cls_f2}) d->release();
-    delete e;
+    for (hipEvent_t& ev : e->ev_part) if (ev) (void)hipEventDestroy(ev);
+    delete e;            // every DevBuf (towers, layouts, weights, scratch of every path) frees itself: ~DevBuf
 }
 
 int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const float* dev_ptr, int64_t numel) {
@@ -486,12 +470,40 @@ int rlcf_engine_momentum_update_visual(rlcf_engine* e, const float* current, dou
     }
     return RLCF_OK;
 }
+// Tunable norm-layer floats / BatchNorm statistics of a ModifiedResNet student, from the geometry alone (the layout engine_bn_enable
+// builds: stem bn1..3, then bn1..3 of every Bottleneck tuned; downsample.1 frozen but with statistics) — the getters have no side effects
+static void resnet_norm_counts(const rlcf_clip_cfg& c, int* tuned, int* stats) {
+    const int w = c.vision_width;
+    int p = 2 * (w / 2 + w / 2 + w), s = p, inpl = w;
+    for (int st = 0; st < 4; ++st) {
+        const int planes = w << st;
+        for (int b = 0; b < c.vision_stages[st]; ++b) {
+            p += 2 * 6 * planes; s += 2 * 6 * planes;
+            const int stride = (b == 0 && st > 0) ? 2 : 1;
+            if (stride > 1 || inpl != planes * 4) s += 2 * 4 * planes;        // model.py:30-36 (downsample)
+            inpl = planes * 4;
+        }
+    }
+    *tuned = p; *stats = s;
+}
 int rlcf_engine_ln_param_count(rlcf_engine* e) {
     if (!e) return 0;
-    // a ModifiedResNet student's norm layers are BatchNorms: their train-form state is built on first use
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (s.finalized && is_resnet(s.cfg) && !s.rn.bn_enabled && engine_bn_enable(e, nullptr) != RLCF_OK) return 0;
+    const ClipModel& s = e->model[RLCF_STUDENT];
+    if (s.finalized && is_resnet(s.cfg)) {
+        if (prec_single(e)) return 0;                  // BatchNorm tuning is refused in the single-pass f16 mode (engine_bn_enable says why)
+        int p = 0, st = 0;
+        resnet_norm_counts(s.cfg, &p, &st);
+        return p;
+    }
     return e->ln_count;
+}
+// the calls that READ or WRITE the tunable vector build a ResNet student's train form first, on the caller's stream, and hand its
+// error code (and text) back
+static int norm_ready(rlcf_engine* e, hipStream_t st) {
+    const ClipModel& s = e->model[RLCF_STUDENT];
+    if (s.finalized && is_resnet(s.cfg) && !s.rn.bn_enabled) return engine_bn_enable(e, st);
+    if (e->ln_count <= 0) { rlcf_set_error("the student has no tunable norm layers (not finalized?)"); return RLCF_ERR_STATE; }
+    return RLCF_OK;
 }
 int rlcf_engine_set_bn_prior_strength(rlcf_engine* e, int prior_strength) {
     RLCF_ARG_CHECK(e);
@@ -499,39 +511,47 @@ int rlcf_engine_set_bn_prior_strength(rlcf_engine* e, int prior_strength) {
     return RLCF_OK;
 }
 int rlcf_engine_encode_image_bn(rlcf_engine* e, const float* images, int n, float* out, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && images && out && n > 0);
+    RLCF_ARG_CHECK(e && images && out && n > 0 && n <= e->max_views);      // feat_raw / the GEMM scratch are sized for max_views
     ClipModel& s = e->model[RLCF_STUDENT];
     if (!s.finalized || !is_resnet(s.cfg)) { rlcf_set_error("rlcf_engine_encode_image_bn needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
     const int rc = engine_bn_enable(e, (hipStream_t)stream);
     return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, (hipStream_t)stream);
 }
 int rlcf_engine_bn_stats_count(rlcf_engine* e) {
-    if (!e || rlcf_engine_ln_param_count(e) <= 0) return 0;
-    ClipModel& s = e->model[RLCF_STUDENT];
-    return is_resnet(s.cfg) ? s.rn.n_stats : 0;
+    if (!e) return 0;
+    const ClipModel& s = e->model[RLCF_STUDENT];
+    if (!s.finalized || !is_resnet(s.cfg) || prec_single(e)) return 0;
+    int p = 0, st = 0;
+    resnet_norm_counts(s.cfg, &p, &st);
+    return st;
 }
 int rlcf_engine_get_bn_stats(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && out);
     const int n = rlcf_engine_bn_stats_count(e);
-    if (n <= 0) { rlcf_set_error("the student has no BatchNorm statistics (VisionTransformer, or not finalized)"); return RLCF_ERR_STATE; }
+    if (n <= 0) { rlcf_set_error("the student has no BatchNorm statistics (VisionTransformer, RLCF_PREC_F16, or not finalized)"); return RLCF_ERR_STATE; }
+    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->bn_stats_init.p : e->bn_stats.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && out && rlcf_engine_ln_param_count(e) > 0);
+    RLCF_ARG_CHECK(e && out);
+    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->ln_init.p : e->ln_params.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && in && rlcf_engine_ln_param_count(e) > 0);
+    RLCF_ARG_CHECK(e && in);
+    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return RLCF_OK;
 }
 int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && current && rlcf_engine_ln_param_count(e) > 0 && momentum >= 0.0 && momentum <= 1.0);
-    int rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
+    RLCF_ARG_CHECK(e && current && momentum >= 0.0 && momentum <= 1.0);
+    int rc = norm_ready(e, (hipStream_t)stream);
+    if (rc != RLCF_OK) return rc;
+    rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
                                     update_w, apply, (hipStream_t)stream);
     if (rc != RLCF_OK) return rc;
     if (apply)           // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy follows
@@ -540,8 +560,9 @@ int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double mom
     return RLCF_OK;
 }
 int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && rlcf_engine_ln_param_count(e) > 0);
+    RLCF_ARG_CHECK(e);
     hipStream_t st = (hipStream_t)stream;
+    { const int rc = norm_ready(e, st); if (rc != RLCF_OK) return rc; }
     const size_t nb = (size_t)e->ln_count * sizeof(float);
     for (DevBuf* d : {&e->ln_params, &e->ln_init, &e->ln_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->ln_clip.p, nb, hipMemcpyDeviceToDevice, st));
     if (e->vw_count) {

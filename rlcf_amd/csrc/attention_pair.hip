@@ -365,6 +365,7 @@ static int ap_launch(bool single, dim3 grid, hipStream_t st, const _Float16* qkv
         if (var & 1) AP_GO(true, 1, lds_single)
         AP_GO(true, 0, lds_single)
     }
+#ifdef RLCF_ATTN_ABLATION                                    // measurement builds only (make ABLATION=1): never in the shipped library
     if constexpr (NW == 8) {                                 // ablation / trace builds of the 8-wave launch (timing only: wrong numbers by design)
         if (var == 8) AP_GO(false, 8, lds_pair)
         if (var == 32) AP_GO(false, 32, lds_pair)
@@ -389,6 +390,9 @@ static int ap_launch(bool single, dim3 grid, hipStream_t st, const _Float16* qkv
             return RLCF_OK;
         }
     }
+#else
+    if (var & ~1) { rlcf_set_error("attention variant %d is an ablation build (make ABLATION=1); only 0 / 1 are shipped", var); return RLCF_ERR_ARG; }
+#endif
     if (var & 1) AP_GO(false, 1, lds_pair)
     AP_GO(false, 0, lds_pair)
 #undef AP_GO

@@ -28,6 +28,7 @@ int rlcf_func_lds(const void* fn, size_t bytes);
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));

@@ -7,9 +7,15 @@
 #include <vector>
 #include "kernels.h"
 
-struct DevBuf {
+struct DevBuf {                      // owning, move-only: an engine that is deleted gives back every buffer it ever grew
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+    ~DevBuf() { release(); }
     int ensure(size_t n);            // (re)allocate if smaller; contents undefined after growth
     void release();
     template <typename T> T* as() const { return (T*)p; }
@@ -179,6 +185,7 @@ struct rlcf_engine {
     // one-image calls: the reward models' tower pass of the selected views runs on a second stream next to the student's sparse text
     // forward (both leave most of the 256 CUs idle at one image's sizes); fork / join by events, its own split-K workspace
     DevBuf gemm_ws2;
+    unsigned ws_epoch[2] = {0, 0};   // stream-K launch counters of gemm_ws / gemm_ws2 (gemm_f16x3.hip: flags carry the launch's epoch)
     // ... its own copies of the image-tower scratch (engine_encode_image on the side stream: the reward models' pass of one part of a
     // sample batch runs beside the student tower of the next part, tta_batch_pipelined) ...
     // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode

@@ -55,6 +55,7 @@ static void prof_end(int slot, hipStream_t st, int kind = 0) {
 // part reaches 25.8 B/clk/CU, a 128-B one 45.5: profiles/r1_gemm_sq_counters.txt).  The lo part of a pair therefore starts 64 B after hi.
 static inline float* ws_ptr(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).as<float>(); }
 static inline size_t ws_bytes(rlcf_engine* e) { return (e->ws_sel ? e->gemm_ws2 : e->gemm_ws).bytes; }
+static inline unsigned* ws_epoch(rlcf_engine* e) { return &e->ws_epoch[e->ws_sel ? 1 : 0]; }
 // image-tower scratch / A-operand split buffer of the stream whose launches are being enqueued (see ws_sel)
 #define IMG_BUF(e, name) ((e)->ws_sel ? (e)->side_img.name : (e)->name)
 static inline void* a_ptr(rlcf_engine* e) { return e->ws_sel ? e->a_hi2.p : e->a_hi.p; }
@@ -100,7 +101,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
             int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
-                                       ws_ptr(e), ws_bytes(e));
+                                       ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -125,7 +126,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
-                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e));
+                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -141,7 +142,7 @@ int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* al
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(Apairs, lo_of(Apairs), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, Cpairs, Cpairs ? lo_of(Cpairs) : nullptr,
-                               2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), 0, out_scale_dev);
+                               2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), 0, out_scale_dev, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -197,7 +198,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
         if (!fw || K % 64) { rlcf_set_error("gemm_pre: weight has no plain f16 copy (K = %d)", K); return RLCF_ERR_STATE; }
         const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
         int rc = launch_gemm_f16x3(A2, lo_of(A2), lda, fw->hi, lo_of(fw->hi), K, bias, res, ldr, nullptr, 0, C, ldc, C2, nullptr, ldch, M, N, K,
-                                   fw->inv_scale, epi, st, nullptr, nullptr, 0, ws_ptr(e), ws_bytes(e), 1);
+                                   fw->inv_scale, epi, st, nullptr, nullptr, 0, ws_ptr(e), ws_bytes(e), 1, nullptr, ws_epoch(e));
         prof_end(slot, st, g_last_x3_variant);
         return rc;
     }
@@ -205,7 +206,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
-                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e));
+                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -248,13 +249,13 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     const float scale = std::ldexp(1.0f, sh);
     TRY(launch_split_f16x2(w, hi.p, lo, (int64_t)numel, st, scale, il));
     m.split_of[w] = ClipModel::SplitW{hi.p, lo, 1.0f / scale};
-    m.derived.push_back(hi);
+    m.derived.push_back(std::move(hi));
     if (prec_single(e) && numel % 64 == 0) {                 // plain f16 copy for the single-pass forward pipeline (same pre-scale)
         DevBuf f;
         TRY(f.ensure(numel * 2 + 64));
         TRY(launch_split_f16x2(w, f.p, nullptr, (int64_t)numel, st, scale, 0));
         m.f16_of[w] = ClipModel::SplitW{f.p, nullptr, 1.0f / scale};
-        m.derived.push_back(f);
+        m.derived.push_back(std::move(f));
     }
     return RLCF_OK;
 }
@@ -538,7 +539,7 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
         const int slot = prof_begin(st, 2.0 * N * K * Tp, N, K, Tp);
         rc = launch_gemm_f16x3(e->a_hi.p, lo_of(e->a_hi.p), 2 * Tp, e->w_hi.p, lo_of(e->w_hi.p), 2 * Tp, nullptr, nullptr, 0, nullptr, 0, dW, K,
                                nullptr, nullptr, 0, N, K, Tp, 1.f, RLCF_EPI_NONE, st, e->dyn.as<float>() + 2, nullptr, 0, ws_ptr(e),
-                               ws_bytes(e));
+                               ws_bytes(e), 0, nullptr, ws_epoch(e));
         prof_end(slot, st, g_last_x3_variant);
     } else {
         GemmArgs g{};
@@ -730,7 +731,11 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         float* park = nullptr;
         if (max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
             const size_t need = (size_t)n_seq * ((max_q_len + 31) / 32) * max_q_len * 2 * W * sizeof(float);
-            if (need <= ((size_t)16 << 30)) { TRY(e->attn_park.ensure(need)); park = e->attn_park.as<float>(); }
+            if (need <= ((size_t)16 << 30)) {
+                // no room for the parking space (another engine holds the memory): clear the error and meet by atomicAdd instead
+                if (e->attn_park.ensure(need) == RLCF_OK) park = e->attn_park.as<float>();
+                else (void)hipGetLastError();
+            }
         }
         if (!park) RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96 && prec_x3(e) && !bwd_f32) {

@@ -43,7 +43,16 @@ struct GemmX3Args {
     int tile_group;                    // 256x256 interleaved kernel: M tiles per scheduling group (0 = 8)
     const float* out_scale_dev;        // optional device scalar: the split output carries C * out_scale_dev[0] (a power of two chosen from
                                        // an upper bound of |C| before the launch: the consumer undoes it through ITS alpha_dev)
+    // stream-K tail of the 256x256 interleaved kernel (launch_gemm_f16x3): tiles [0, sk_first) of the linear order are whole-tile
+    // workgroups of the plain launch; the K steps of the remaining tiles are shared by the 2 * sk_blocks workgroups of the SK launch
+    int sk_first, sk_blocks;
+    unsigned sk_epoch;                 // value a "partial tile published" flag carries in THIS launch (flags are never reset)
+    unsigned* sk_flags;                // [X3_SK_MAX_BLOCKS] + [1] time-out marker
+    float* sk_ws;                      // [sk_blocks][256 x 256] raw partial accumulators, register layout
 };
+#define X3_SK_MAX_BLOCKS 1024
+#define X3_SK_FLAG_BYTES 8192                                   // flags + time-out word, at the end of the workspace
+#define X3_SK_SLAB_BYTES 262144
 // SINGLE (template flag of the kernels): plain f16 operands, ONE MFMA per product (RLCF_PREC_F16 — the arithmetic of the reference's
 // own fp16-autocast GPU path, tpt_cls_rl.py:52; NOT f32-grade).  A plain f16 row of K halves has exactly the memory layout of an
 // interleaved pair row of K/2 logical columns (every 128-B block = 32 "hi" + 32 "lo" halves), so the kernels run unchanged with
@@ -767,16 +776,74 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 #ifndef V3_AUX_W
 #define V3_AUX_W 0
 #endif
-template <bool SINGLE, bool CONV = false>
+// Stream-K tail (template flag SK; launch_gemm_f16x3).  With one 139-KB workgroup per CU a launch of T tiles costs ceil(T / 256) tile
+// rounds, however few tiles the last round holds (out_proj at 20 images per pass: 2955 tiles = 11.54 rounds -> 12; one image: 150
+// tiles on 256 CUs; the reward tower of a pass: 279 tiles).  The first sk_first = 256 * floor(T / 256) tiles stay whole-tile workgroups
+// (the plain instantiation, launched first); the K steps of the remaining R tiles are shared out evenly by a second launch:
+//   * the R tiles are cut into 8 chunks of whole tiles, chunk x served by the workgroups s with s % 8 == x (workgroups are dealt
+//     round-robin to the XCDs, so a chunk's workgroups share an L2 and no dependency crosses chunks);
+//   * inside a chunk the unit list (tile, k) is cut into q = sk_blocks / 8 contiguous ranges of <= nk units; a range touches at
+//     most two tiles and is worked on from its END: its FIRST piece is its part of the last tile it touches (workgroup s of the
+//     launch), its SECOND piece — if it straddles a tile boundary — the tail of the tile before (a workgroup of the second half of
+//     the grid, handed out shortest-first-piece first so that the two pieces of a range add up to the same time on whichever CU takes
+//     them: the CUs come free in the order of their first pieces);
+//   * the piece that ENDS a tile (k1 == nk) owns the tile: every other part of that tile is the first piece of a LOWER-numbered range
+//     of the chunk — a workgroup with a lower index (dispatched earlier, it never waits itself) — so the owner never waits for a
+//     workgroup that is not yet resident, and normally finds the parts already published;
+//   * a non-owner writes its raw accumulators to its slab with write-through (sc1) 16-byte stores in register layout (coalesced, no
+//     LDS pass), every wave drains vmcnt, one lane publishes the launch's epoch in the range's flag word (relaxed, agent scope); the
+//     owner polls that word relaxed, takes ONE agent-scope acquire, adds the slabs in increasing-k order with sc1 loads (fixed order:
+//     bit-reproducible) and runs the epilogue (cdna_hip_programming.md, Guideline 16 / R1).
+template <bool SINGLE, bool CONV = false, bool SK = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
     const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
+    int bid, k0 = 0, k1 = g.K / X3_BK;
+    int sk_chunk = 0, sk_idx = 0, sk_q = 1, sk_units = 1, sk_tile_c = 0;
+    if constexpr (!SK) {
+        const int nwg = gridDim.x;
+        bid = blockIdx.x;
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    } else {
+        const int nk_full = g.K / X3_BK;
+        int s_ = blockIdx.x;
+        const bool second = s_ >= g.sk_blocks;                         // the second piece of some range of this chunk
+        if (second) s_ -= g.sk_blocks;
+        const int R = tiles_m * tiles_n - g.sk_first;
+        sk_chunk = s_ & 7; sk_idx = s_ >> 3; sk_q = g.sk_blocks >> 3;
+        const int c0 = sk_chunk * R / 8, c1 = (sk_chunk + 1) * R / 8;       // (32-bit throughout: R < 256, <= 32 tiles x nk units per chunk)
+        sk_units = (c1 - c0) * nk_full;
+        if (sk_units <= 0) return;
+        if (second) {
+            // rank this chunk's two-piece ranges by (length of the first piece, index); this workgroup takes the one of rank sk_idx
+            int* pick = (int*)smem;
+            if (threadIdx.x == 0) *pick = -1;
+            __syncthreads();
+            if ((int)threadIdx.x < sk_q) {
+                auto key = [&](int i) -> int {
+                    const int a_ = i * sk_units / sk_q, b_ = (i + 1) * sk_units / sk_q;
+                    if (b_ <= a_ || a_ / nk_full == (b_ - 1) / nk_full) return 0x7fffffff;               // empty, or one piece only
+                    return (b_ - ((b_ - 1) / nk_full) * nk_full) * 64 + i;
+                };
+                const int mine = key(threadIdx.x);
+                int rank = 0;
+                for (int i = 0; i < sk_q; ++i) rank += key(i) < mine ? 1 : 0;
+                if (mine != 0x7fffffff && rank == sk_idx) *pick = threadIdx.x;
+            }
+            __syncthreads();
+            sk_idx = __builtin_amdgcn_readfirstlane(*pick);                // (wave-uniform: everything derived from it stays scalar)
+            __syncthreads();
+            if (sk_idx < 0) return;                                         // (fewer two-piece ranges than workgroups)
+        }
+        const int ua = sk_idx * sk_units / sk_q, ub = (sk_idx + 1) * sk_units / sk_q;
+        if (ub <= ua) return;                                               // (more workgroups than units in this chunk)
+        const int tb = (ub - 1) / nk_full, ta = ua / nk_full;
+        if (second && ta == tb) return;
+        if (!second) { sk_tile_c = tb; k0 = max(ua, tb * nk_full) - tb * nk_full; k1 = ub - tb * nk_full; }
+        else { sk_tile_c = ta; k0 = ua - ta * nk_full; k1 = nk_full; }
+        bid = g.sk_first + c0 + sk_tile_c;
     }
     // M tiles per scheduling group: 8 (16 / 32: -1.5 / -8 %, measured); RLCF_X3_GROUP pins it (measurements)
     const int G = g.tile_group % 100 > 0 ? g.tile_group % 100 : 8;
@@ -809,8 +876,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane, r = q >> 3, c = ((q & 7) ^ ((r >> 1) & 7)) * 8;
         const int row = min(m0 + r, g.M - 1);
-        sa[j] = (size_t)row * g.lda + c;
-        sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c;
+        sa[j] = (size_t)row * g.lda + c + (SK ? (size_t)k0 * g.kstep : (size_t)0);        // (stream-K pieces start at K step k0)
+        sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c + (SK ? (size_t)k0 * g.kstep : (size_t)0);
         if constexpr (CONV) {
             const int ox = row % g.conv_W, oy = (row / g.conv_W) % g.conv_H;
             unsigned m = 0;
@@ -858,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             BL[j] = *(const h16x8*)(sb + 32768 + boff + j * 4096 + cl_);                                                 \
         }                                                                                                                \
     }
-    const int nk = g.K / X3_BK;
+    const int nk = SK ? k1 - k0 : g.K / X3_BK;
     int ctap_ = 0;
     long coff_ = 0;
     if constexpr (CONV) coff_ = conv_off(0, ctap_);
@@ -935,6 +1002,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE }
+    }
+    if constexpr (SK) {
+        const int nk_full = g.K / X3_BK;
+        if (k1 < nk_full) {
+            // ---- a part that does not end its tile: publish the raw accumulators (register layout: 32 x 16 B per thread, coalesced)
+            const int gid = sk_chunk + 8 * sk_idx;                      // this range's slab / flag
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((char*)g.sk_ws + (size_t)gid * X3_SK_SLAB_BYTES, 0, X3_SK_SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const f32x16& a_ = acc[q >> 3][(q >> 2) & 1];
+                const f32x4 v_ = {a_[(q & 3) * 4], a_[(q & 3) * 4 + 1], a_[(q & 3) * 4 + 2], a_[(q & 3) * 4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v_), rs, (q * 512 + t) * 16, 0, 16 /* sc1: write-through */);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains its stores ...
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(g.sk_flags + gid, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
+            return;
+        }
+        // ---- the part that ends the tile: add the earlier parts (ranges first .. sk_idx - 1 of this chunk) in increasing-k order
+        const int first = ((sk_tile_c * nk_full + 1) * sk_q - 1) / sk_units;                      // range holding the tile's K step 0
+        for (int pi = first; pi < sk_idx; ++pi) {
+            const int gp = sk_chunk + 8 * pi;
+            if (t == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(g.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) { __hip_atomic_store(g.sk_flags + X3_SK_MAX_BLOCKS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((char*)g.sk_ws + (size_t)gp * X3_SK_SLAB_BYTES, 0, X3_SK_SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8) {
+                u32x4 v_[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v_[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q8 * 8 + u) * 512 + t) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q8 * 8 + u;
+                    const f32x4 f_ = __builtin_bit_cast(f32x4, v_[u]);
+                    f32x16& a_ = acc[q >> 3][(q >> 2) & 1];
+                    a_[(q & 3) * 4] += f_[0]; a_[(q & 3) * 4 + 1] += f_[1]; a_[(q & 3) * 4 + 2] += f_[2]; a_[(q & 3) * 4 + 3] += f_[3];
+                }
+            }
+        }
     }
     if (const int ek = x3_epilogue_kind(g)) {
         float* parkf = (float*)smem + wave * (64 * 68);
@@ -1198,8 +1311,13 @@ int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 2
 int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
-                      float* splitk_ws, size_t splitk_ws_bytes, int single, const float* out_scale_dev) {
+                      float* splitk_ws, size_t splitk_ws_bytes, int single, const float* out_scale_dev, unsigned* sk_epoch) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
+    // stream-K scratch (caller-owned, X3_WS_BYTES): slabs from the start of the workspace, flag words in its last X3_SK_FLAG_BYTES;
+    // *sk_epoch = the caller's launch counter for THIS workspace (0: flags not yet zeroed)
+    const bool sk_avail = sk_epoch && splitk_ws && splitk_ws_bytes >= (size_t)X3_SK_FLAG_BYTES + 8 * (size_t)X3_SK_SLAB_BYTES;
+    unsigned* sk_flags = sk_avail ? (unsigned*)((char*)splitk_ws + splitk_ws_bytes - X3_SK_FLAG_BYTES) : nullptr;
+    if (sk_avail) splitk_ws_bytes -= X3_SK_FLAG_BYTES;
     RLCF_ARG_CHECK(Ahi && Alo && Whi && Wlo && (C || (Chi && (Clo || single))));
     if (single) {       // plain f16 operands: a row of K halves == an interleaved pair row of K/2 logical columns (see GemmX3Args)
         RLCF_ARG_CHECK(K % 64 == 0 && Alo == (const void*)((const _Float16*)Ahi + 32) && Wlo == (const void*)((const _Float16*)Whi + 32));
@@ -1228,8 +1346,37 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes
     // ~0.575 of a 256x256 round (half the work at ~15 % lower efficiency).  Measured at M = 12608 (one test image): N = 768 runs
     // 61 us as one 59 %-full 256x256 round against 70 us as two 256x128 rounds; K = 3072: 188 against 233 us.
-    const double cost3 = (double)((blocks3 + 255) / 256), cost2 = 0.575 * (double)((blocks2 + 255) / 256);
-    const bool pick3 = blocks2 >= 256 && cost3 <= cost2;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    // Stream-K tail (see the kernel): the tiles of the last, partly filled round are shared out over the CUs by K steps.  Its cost in
+    // tile rounds = (K steps of the longest range + ~5 steps' worth of second launch and slab hand-over) / (nk + ~3 for a whole tile's
+    // epilogue).  MEASURED SLOWER THAN THE PLAIN LAUNCH on every shape tried (profiles/r4_gemm_tile_overhead.txt: one image's token
+    // matrix, 150 tiles on 256 CUs: 63.5 -> 100.5 us; out_proj at 20 images per pass, 11.54 rounds: 898 -> 943 us) — the partial tiles
+    // are 256 KB each, a round's worth of them is 30-64 MB written through to memory and read back, ~25 us of the chip's bandwidth
+    // against the ~35 us the balanced tail saves — so it is OFF by default; RLCF_X3_SK=1 switches it on (correct, bit-reproducible)
+    static int sk_mode = -1;
+    if (sk_mode < 0) { const char* e = getenv("RLCF_X3_SK"); sk_mode = e ? atoi(e) : 0; }
+    int sk_first = 0, sk_blocks = 0;
+    double cost3 = (double)((blocks3 + ncu - 1) / ncu);
+    {
+        const int nkt3 = K / X3_BK, R = blocks3 % ncu, min_steps = 6;
+        if (sk_mode && sk_avail && !single && g.kstep == 64 && v2_ok && ncu % 8 == 0 && ncu <= 256 && R > 0 && blocks3 >= 64 && nkt3 >= 2 * min_steps) {
+            int S = std::min(ncu, 8 * (int)((long)R * nkt3 / (8 * min_steps)));
+            S = std::min(S, (int)(std::min<size_t>(X3_SK_MAX_BLOCKS, splitk_ws_bytes / X3_SK_SLAB_BYTES) / 8 * 8));
+            if (S >= 8 * ((R + 7) / 8)) {                    // every range <= nk units: at most two tiles each
+                const int per = (((R + 7) / 8) * nkt3 + S / 8 - 1) / (S / 8);       // the longest range (the chunk with the most tiles)
+                const double tail = (per + 5.0) / (nkt3 + 3.0);
+                if (tail < 0.9) { sk_first = blocks3 - R; sk_blocks = S; cost3 = (double)(blocks3 / ncu) + tail; }
+            }
+        }
+    }
+    const double cost2 = 0.575 * (double)((blocks2 + ncu - 1) / ncu);
+    const bool pick3 = (blocks2 >= 256 || sk_blocks > 0) && cost3 <= cost2;
     // RLCF_X3_V4=1: the 4-wave form of the 256x256 tile where it applies (interleaved pairs, compile-time epilogues)
     static int v4 = -1;
     if (v4 < 0) { const char* e = getenv("RLCF_X3_V4"); v4 = e ? atoi(e) : 0; }
@@ -1256,6 +1403,15 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         if (g.kstep == 64 && single) {
             X3_LDS(gemm_nt_f16x3_v3i_kernel<true>, sh3);
             gemm_nt_f16x3_v3i_kernel<true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        } else if (g.kstep == 64 && sk_blocks > 0) {
+            if (*sk_epoch == 0) RLCF_HIP_CHECK(hipMemsetAsync(sk_flags, 0, X3_SK_FLAG_BYTES, st));      // first use of this workspace
+            if (++*sk_epoch == 0) { RLCF_HIP_CHECK(hipMemsetAsync(sk_flags, 0, X3_SK_FLAG_BYTES, st)); *sk_epoch = 1; }     // (wrapped)
+            g.sk_first = sk_first; g.sk_blocks = sk_blocks; g.sk_epoch = *sk_epoch; g.sk_flags = sk_flags; g.sk_ws = splitk_ws;
+            X3_LDS(gemm_nt_f16x3_v3i_kernel<false>, sh3);
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, true>), sh3);
+            // whole-tile workgroups for the full rounds, then the stream-K launch for the rest (first pieces, then second pieces)
+            if (sk_first > 0) gemm_nt_f16x3_v3i_kernel<false><<<dim3(sk_first), dim3(512), sh3, st>>>(g);
+            gemm_nt_f16x3_v3i_kernel<false, false, true><<<dim3(2 * sk_blocks), dim3(512), sh3, st>>>(g);
         } else if (g.kstep == 64) {
             X3_LDS(gemm_nt_f16x3_v3i_kernel<false>, sh3);
             gemm_nt_f16x3_v3i_kernel<false><<<dim3(blocks3), dim3(512), sh3, st>>>(g);

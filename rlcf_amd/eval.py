@@ -68,14 +68,25 @@ def run(args) -> dict:
     lo, hi = shard.shard_range(args.total_images, rank, world)
     targets = synthetic_targets(args.total_images, args.classes)
     top5 = torch.empty(hi - lo, 5, dtype=torch.int32, device=dev)
+    keep = min(max(args.keep_logits, 0), args.total_images)             # final logits of stream samples [0, keep): parity checks at size
+    if keep > shard.shard_range(args.total_images, 0, world)[1]:
+        raise ValueError("--keep-logits must fit in rank 0's shard")
+    kept = torch.empty(min(keep, hi - lo) if rank == 0 else 0, args.classes, device=dev)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for s in range(lo, hi, args.images_per_pass):                   # views are generated pass by pass: a shard need not fit in HBM
         e = min(s + args.images_per_pass, hi)
-        views = torch.stack([synth.make_views(shard.sample_seed(1000, i), args.views, geo.image_resolution, device=dev) for i in range(s, e)])
-        top5[s - lo: e - lo] = eng.tta_batch(views, cfg)
+        views = torch.stack([synth.make_views(shard.sample_seed(args.first_seed, i), args.views, geo.image_resolution, device=dev)
+                             for i in range(s, e)])
+        if s < kept.shape[0]:
+            t5, fl = eng.tta_batch(views, cfg, want_logits=True)
+            top5[s - lo: e - lo] = t5
+            n_k = min(e, kept.shape[0]) - s
+            kept[s: s + n_k] = fl[:n_k]
+        else:
+            top5[s - lo: e - lo] = eng.tta_batch(views, cfg)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pred = top5.long().cpu()
@@ -94,12 +105,18 @@ def run(args) -> dict:
         all_pred = torch.cat([p[: shard.shard_range(args.total_images, r, world)[1] - shard.shard_range(args.total_images, r, world)[0]]
                               for r, p in enumerate(parts)]).cpu()
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        per_rank = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)
+        rank_seconds = [float(x.item()) for x in per_rank]
+        dt = max(rank_seconds)
+    else:
+        rank_seconds = [dt]
     out = {"images": n, "acc1": round(acc1, 3), "acc5": round(acc5, 3), "n_gpus": world, "seconds": dt, "images_per_s": n / dt,
            "predictions_sha256": hashlib.sha256(all_pred.numpy().tobytes()).hexdigest(), "top5": all_pred.tolist(),
+           "rank_seconds": rank_seconds, "first_seed": args.first_seed,
+           "final_logits_first": kept.cpu().tolist() if kept.numel() else None,
            "distributed": ({"backend": args.dist_backend, "ranks": dist.get_world_size(),
-                            "collectives": "all_reduce(SUM) of 3 hit counters, all_gather of the top-5 block, all_reduce(MAX) of the time"}
+                            "collectives": "all_reduce(SUM) of 3 hit counters, all_gather of the top-5 block, all_gather of the shard time"}
                            if use_dist else None),
            "config": {"arch": args.arch, "reward_arch": args.reward_arch, "views": args.views, "classes": args.classes,
                       "tta_steps": args.tta_steps, "images_per_pass": args.images_per_pass, "precision": args.precision,
@@ -128,6 +145,8 @@ def main(argv=None):
     ap.add_argument("--images-per-pass", type=int, default=32)
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--first-seed", type=int, default=1000, help="view seed of stream sample 0 (sample i -> first_seed + i; SURVEY section 8d: 1000)")
+    ap.add_argument("--keep-logits", type=int, default=0, help="also report the final logits of stream samples [0, K) (must lie in rank 0's shard)")
     ap.add_argument("--out", default="", help="also write the JSON record to this file")
     a = ap.parse_args(argv)
     rec = run(a)

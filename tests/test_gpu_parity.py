@@ -448,7 +448,7 @@ def make_ensemble_engine(meta, mode, n_views=None, prec=0, device=None):
     from rlcf_amd import _lib
     from rlcf_amd.engine import Engine
     sg = synth.GEOMETRIES[meta["student"]]
-    ssd = synth.make_state_dict(sg, meta["student_seed"])
+    ssd = synth.make_state_dict(sg, meta["student_seed"], device=device) if device is not None else synth.make_state_dict(sg, meta["student_seed"])
     members = synth.reward_members(meta["reward"], meta["reward_seeds"], device=device)     # (full-size members: generated on the GPU)
     eng = Engine(sg, [g for g, _ in members], n_views or meta["n_views"], meta["n_cls"], prec)
     eng.load_state_dict(_lib.STUDENT, ssd)

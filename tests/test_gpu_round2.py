@@ -429,7 +429,7 @@ def test_retrieval_text_tuning_full_size_matches_oracle(L, dev):
     from rlcf_amd.engine import Engine, TTAConfig
     from oracle import retrieval_ref as QR, rlcf_ref as RR2
     sg = synth.GEOMETRIES["ViT-B/16"]
-    ssd, rsd = synth.make_state_dict(sg, 11), synth.make_state_dict(sg, 23)
+    ssd, rsd = ({k: v.cpu() for k, v in synth.make_state_dict(sg, sd_, device=dev).items()} for sd_ in (11, 23))     # (device generator: same bits, seconds)
     n, K, steps, lr = 5000, 12, 2, 1e-5
     gen = torch.Generator().manual_seed(5)
     sbank = torch.nn.functional.normalize(torch.randn(n, sg.embed_dim, generator=gen), dim=-1)
@@ -724,10 +724,11 @@ def test_ln_batch_matches_reference_at_full_size_l14_n64(L, dev):
     g, meta = load_golden("ln_l14_n64")
     sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
     eng = Engine(sg, rg, meta["n_views"] * 2, meta["n_cls"], L.PREC_F16X3)
-    eng.load_state_dict(L.STUDENT, synth.make_state_dict(sg, meta["student_seed"], device=dev))
+    ssd_d = synth.make_state_dict(sg, meta["student_seed"], device=dev)       # (generated on the device: bit-identical to the CPU generator,
+    eng.load_state_dict(L.STUDENT, ssd_d)                                      #  and a ViT-L/14 takes the CPU generator ~100 s)
     eng.load_state_dict(L.REWARD, synth.make_state_dict(rg, meta["reward_seed"], device=dev))
     eng.finalize()
-    ssd_tok = synth.make_state_dict(sg, meta["student_seed"])["token_embedding.weight"]
+    ssd_tok = ssd_d["token_embedding.weight"].cpu()
     tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
     ctx0 = ssd_tok[torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]))].clone()
     eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)

@@ -206,14 +206,14 @@ from oracle import clip_ref as CR
 g = synth.GEOMETRIES["ViT-B/16"]
 rewards = [g] * %(n_rewards)d
 eng = Engine(g, rewards if len(rewards) > 1 else g, 16, 24, _lib.PREC_F16X3)
-eng.load_state_dict(_lib.STUDENT, synth.make_state_dict(g, 11, device="cuda"))
+ssd_d = synth.make_state_dict(g, 11, device="cuda")
+eng.load_state_dict(_lib.STUDENT, ssd_d)
 for m in range(len(rewards)):
     eng.load_state_dict(_lib.REWARD + m, synth.make_state_dict(g, 23 + m, device="cuda"))
 eng.finalize()
 if len(rewards) > 1: eng.set_reward_mix([0.5, 0.2, 0.3][:len(rewards)])
 tokens = synth.make_token_bank(g, 24, seed=7, n_ctx=4)
-ssd = synth.make_state_dict(g, 11)
-ctx0 = CR.ctx_from_tokens(ssd, synth.ctx_token_ids_default(g, 4))
+ctx0 = CR.ctx_from_tokens({"token_embedding.weight": ssd_d["token_embedding.weight"].cpu()}, synth.ctx_token_ids_default(g, 4))
 eng.set_class_bank(tokens, 4, ctx0, %(text_mode)s)
 cfg = TTAConfig(selection_p=0.4, sample_k=3)          # 6 views x 3 classes: 18 prompts x 77 rows = 1386 > 512 in the dense layout
 outs = []
@@ -259,11 +259,12 @@ from oracle import clip_ref as CR
 g = synth.GEOMETRIES[%(geo)r]
 B, N, C = %(B)d, %(N)d, %(C)d
 eng = Engine(g, g, B * N, C, %(prec)s)
-eng.load_state_dict(_lib.STUDENT, synth.make_state_dict(g, 11, device="cuda"))
+ssd_d = synth.make_state_dict(g, 11, device="cuda")
+eng.load_state_dict(_lib.STUDENT, ssd_d)
 eng.load_state_dict(_lib.REWARD, synth.make_state_dict(g, 23, device="cuda"))
 eng.finalize()
 tokens = synth.make_token_bank(g, C, seed=7, n_ctx=4)
-ctx0 = CR.ctx_from_tokens(synth.make_state_dict(g, 11), synth.ctx_token_ids_default(g, 4))
+ctx0 = CR.ctx_from_tokens({"token_embedding.weight": ssd_d["token_embedding.weight"].cpu()}, synth.ctx_token_ids_default(g, 4))
 eng.set_class_bank(tokens, 4, ctx0, _lib.TEXT_SHARED)
 cfg = TTAConfig(selection_p=%(p)s, sample_k=3)
 outs = []
