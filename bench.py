@@ -138,6 +138,77 @@ def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
             "thread_sweep_seconds_at_64_classes": {str(k): round(v, 3) for k, v in sweep.items()}}
 
 
+def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, selection_p, lr, n_one=48, n_batched=96, ipp=32):
+    """The DROP-IN path: what a maintainer runs after INTEGRATION.md section A — the reference's harness loop
+    (TPT/tpt_cls_rl.py:219-279) through this package's mirror: rlcf_amd.tpt_cls_rl.test_time_adapt_eval, model / reward objects from
+    get_coop / get_reward_model, views from rlcf_amd.datautils.AugMixAugmenter (rlcf_make_views on the device from ONE decoded uint8
+    image, the reference's random crop boxes drawn on the host) — one image at a time as the reference feeds it, and with
+    `images_per_pass` test images per engine call.  Reported beside `value`; never the headline (the loader's host work is in it)."""
+    import copy
+    import types
+    from rlcf_amd import clip_reward, clip_store, custom_clip, datautils, runtime, tpt_cls_rl
+    runtime.reset_session()
+    sg, rg = synth.GEOMETRIES[student_arch], synth.GEOMETRIES[reward_arch]
+    clip_store.register_checkpoint(student_arch, sg, ssd)
+    clip_store.register_checkpoint(reward_arch + "#r", rg, rsd)
+    bank = clip_store.SyntheticBank(sg, n_cls, 4, 7)
+    clip_store.set_tokenizer(bank.tokenize)
+    args = types.SimpleNamespace(tta_steps=1, selection_p=selection_p, gpu=dev.index or 0, tpt=True, print_freq=10 ** 9, min_entropy_reg=0,
+                                 min_entropy_w=0.2, reward_arch=reward_arch + "#r", multiple_reward_models=0, weighted_scores=1, sample_k=3,
+                                 reward_amplify=False, reward_process=True, process_batch=False)
+    model = custom_clip.get_coop(student_arch, "I", dev, 4, "a_photo_of_a", classnames=bank.classnames)
+    for name, p_ in model.named_parameters():                   # tpt_cls_rl.py:103-105
+        if "prompt_learner" not in name:
+            p_.requires_grad_(False)
+    optimizer = torch.optim.AdamW(model.prompt_learner.parameters(), lr, weight_decay=5e-4)
+    optim_state = copy.deepcopy(optimizer.state_dict())
+    reward_model = clip_reward.get_reward_model(dev, args)
+    model.reset_classnames(bank.classnames, student_arch)
+    reward_model.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
+    aug = datautils.AugMixAugmenter(None, None, n_views=n_views - 1, augmix=False, resolution=sg.image_resolution, device=dev)
+    gen = torch.Generator().manual_seed(3)
+    photos = [torch.randint(0, 256, (375, 500, 3), dtype=torch.uint8, generator=gen) for _ in range(8)]      # decoded test images (ImageNet-sized)
+
+    class Loader:                                            # one (list of N views [1, 3, R, R], target) per test image, views made on the device
+        def __init__(self, n, staged=None):
+            self.n, self.staged = n, staged
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for i in range(self.n):
+                v = self.staged[i % len(self.staged)] if self.staged is not None else aug.views(photos[i % len(photos)])
+                yield [x.unsqueeze(0) for x in v.unbind(0)], torch.tensor([i % n_cls])
+
+    def run(n, images_per_pass, staged):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tpt_cls_rl.test_time_adapt_eval(Loader(n, staged), model, optimizer, optim_state, None, args, reward_model=reward_model,
+                                        images_per_pass=images_per_pass)
+        torch.cuda.synchronize()
+        return n / (time.perf_counter() - t0)
+
+    staged = [aug.views(ph) for ph in photos]
+    out = {"what": "rlcf_amd.tpt_cls_rl.test_time_adapt_eval (mirror of TPT/tpt_cls_rl.py:219-279) on a synthetic stream of 375x500 uint8 images; "
+                   "views by rlcf_amd.datautils.AugMixAugmenter -> rlcf_make_views (crop boxes drawn on ONE host thread: the reference "
+                   "spreads this over DataLoader workers); 'staged' rows re-use pre-made view tensors (the loop alone)",
+           "views": n_views, "classes": n_cls}
+    run(4, 1, staged)                                         # warm-up: engine build, class bank, workspaces
+    out["images_per_s_one_image_per_pass_staged_views"] = run(n_one, 1, staged)
+    out["images_per_s_one_image_per_pass_views_in_loop"] = run(n_one, 1, None)
+    run(ipp, ipp, staged)                                     # (batched workspaces)
+    out[f"images_per_s_{ipp}_images_per_pass_staged_views"] = run(n_batched, ipp, staged)
+    out[f"images_per_s_{ipp}_images_per_pass_views_in_loop"] = run(n_batched, ipp, None)
+    t0 = time.perf_counter()
+    for ph in photos:
+        aug.views(ph)
+    torch.cuda.synchronize()
+    out["view_generation_ms_per_image"] = (time.perf_counter() - t0) / len(photos) * 1e3
+    runtime.reset_session()
+    return out
+
+
 def profile_entries(lib):
     """per-launch records of the roofline leg: (kind, ms, flops, (d0, d1, d2))"""
     out = []
@@ -185,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=300.0, help="seconds after which no further timed CPU sample is started")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the secondary single-pass f16 measurement (RLCF_PREC_F16, not parity-grade)")
+    ap.add_argument("--no-harness-leg", action="store_true", help="skip the drop-in harness measurement (test_time_adapt_eval through the mirror)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch profiling leg (rocprofv3 runs: fewer launches in the trace)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
@@ -532,17 +604,22 @@ def main():
                 "attention_fwd_frac_of_f16_peak": (sum(e[2] for e in att_h) / max(sum(e[1] for e in att_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if att_h else None}
             eh.close()
             log("secondary f16 line done")
+        if world == 1 and a.config == 1 and is_default_wl and a.precision == "f16x3" and not a.no_harness_leg and not use_dist:
+            eng.close()                                      # (the mirror builds its own engine: free this one's workspace first)
+            eng = None
+            out["harness"] = harness_leg(dev, student_arch, a.reward_arch, ssd, rsd, a.classes, a.views, wl["selection_p"], wl["lr"])
+            log("harness leg done")
         if world == 1 and not a.no_cpu_baseline and not use_dist:
             # the reference's CPU path runs BASELINE configs[0] (ViT-B/16, N = 8): timed for configs 0 / 1; the ViT-L/14 and RN50x64
             # configurations would take minutes per image on the host and get the same oracle leg only when asked for with a budget
             if a.config in (0, 1):
                 out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in ssd.items()}, {k: v.cpu() for k, v in rsd.items()}, geo, a.classes,
                                                    budget_s=a.cpu_baseline_budget)
-            else:
-                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
-                                       "sample": "not timed for this configuration (the oracle's CPU leg is BASELINE configs[0]: run --config 0 or 1)"}
+            # (configs 2 / 4: no `cpu_baseline` key — the oracle's CPU leg is BASELINE configs[0]; a ViT-L/14 or RN50x64 sample takes the
+            # host minutes, and a null would read as a measurement)
         print(json.dumps(out))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
