@@ -318,6 +318,15 @@ int rlcf_engine_set_bn_prior_strength(rlcf_engine*, int prior_strength);
  * computes after tune_cls_rl.py:218's model.eval(), which leaves CLIPCLS_TTA's norm layers in train mode (custom_clip.py:487-497).
  * In train mode it updates the running statistics like any other pass. */
 int rlcf_engine_encode_image_bn(rlcf_engine*, const float* images, int n, float* out, rlcf_stream stream);
+/* The same with the BatchNorm form chosen by the caller — form < 0: the tuning form above; form = 0: EVAL form on the running statistics
+ * as the last tuning pass left them.  Version 7: every-parameter tuning of a ModifiedResNet student — CLIPCLS_TTA(only_norm=False) with
+ * `--arch RN50`, the parser defaults of TPT/tune_cls_rl.py (TPT/params.py:23,73; tune_cls_rl.py:67-71; custom_clip.py:477-479) — is
+ * served by rlcf_tta_sample_visual and the rlcf_engine_*visual* calls: the flat vector then holds, in named_parameters order, every
+ * visual tensor whose name does not contain 'bn' (convolution weights as stored [cout, cin, k, k], downsample.1.weight / .bias, the
+ * attention pool's positional_embedding, k / q / v / c projections); the 'bn' tensors stay in the norm-layer vector.  There
+ * CLIPCLS_TTA.train(mode) is plain nn.Module.train(mode) (custom_clip.py:487-497): the tuning passes run the BatchNorms in train mode,
+ * model(image) after model.eval() in eval form (form = 0). */
+int rlcf_engine_encode_image_bn_form(rlcf_engine*, const float* images, int n, int form, float* out, rlcf_stream stream);
 int rlcf_engine_bn_stats_count(rlcf_engine*);
 int rlcf_engine_get_bn_stats(rlcf_engine*, float* out, int pristine, rlcf_stream stream);
 /* copy the student's visual LayerNorm parameters out of / into the engine (layout above); `pristine` selects the

@@ -246,6 +246,24 @@ def visual_param_keys(sd):
     """CLIPCLS_TTA.parameters() with only_norm=False (custom_clip.py:477-479): every parameter of clip_model.visual, in
     named_parameters() order of VisionTransformer (model.py:206-221: direct parameters first, then conv1, ln_pre, the
     resblocks, ln_post)."""
+    if is_resnet_sd(sd):
+        # ModifiedResNet (model.py:94-154): stem conv / bn 1..3, per Bottleneck conv1 bn1 conv2 bn2 conv3 bn3 [downsample.0 downsample.1],
+        # then AttentionPool2d (model.py:58-66: positional_embedding, k_proj, q_proj, v_proj, c_proj)
+        keys = []
+        for i in (1, 2, 3):
+            keys += [f"visual.conv{i}.weight", f"visual.bn{i}.weight", f"visual.bn{i}.bias"]
+        for li in (1, 2, 3, 4):
+            nb = len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")})
+            for b in range(nb):
+                p = f"visual.layer{li}.{b}."
+                for i in (1, 2, 3):
+                    keys += [p + f"conv{i}.weight", p + f"bn{i}.weight", p + f"bn{i}.bias"]
+                if (p + "downsample.0.weight") in sd:
+                    keys += [p + "downsample.0.weight", p + "downsample.1.weight", p + "downsample.1.bias"]
+        keys.append("visual.attnpool.positional_embedding")
+        for nm in ("k_proj", "q_proj", "v_proj", "c_proj"):
+            keys += [f"visual.attnpool.{nm}.weight", f"visual.attnpool.{nm}.bias"]
+        return keys
     n = C.n_blocks(sd, "visual.transformer")
     keys = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight",
             "visual.ln_pre.weight", "visual.ln_pre.bias"]
@@ -272,14 +290,16 @@ def tta_sample_ln(student_sd, reward_sd, views: torch.Tensor, tokens: torch.Tens
     custom_clip.py:423-432; class text features are cached, :405-409) -> final clean-view inference.
     only_norm=False (the default of `--tune_norm`, params.py:73, what scripts/rlcf-tune.sh runs) tunes every visual parameter;
     `ln_grad` / `ln_after` / `ln_init` then hold all of them, concatenated in visual_param_keys order.
+    A ModifiedResNet student with only_norm=False (the parser defaults `--arch RN50 --tune_norm 0`): every convolution, BatchNorm
+    (downsample.1 included) and attention-pool tensor is tuned; CLIPCLS_TTA.train(mode) then is plain nn.Module.train(mode)
+    (custom_clip.py:487-497 touches the norm layers only under only_norm), so the tuning passes run the BatchNorms in train mode and the
+    final clean-view inference, after model.eval(), in EVAL mode on the running statistics those passes left behind.
     A ModifiedResNet student (only_norm): the tuned tensors are the BatchNorm weights / biases of visual_bn_keys; the tuning passes run
     the BatchNorm layers in train mode (prior_strength < 0, the parser default: batch statistics, running statistics updated in place
     and USED by the final clean-view inference) or through `_modified_bn_forward` (prior_strength >= 0, tune_cls_rl.py:35-44,73-76);
     `bn_stats_after` = the running statistics (mean | var per layer, visual_bn_stat_keys order) the final inference used."""
     out: Dict[str, torch.Tensor] = {}
     rn = is_resnet_sd(student_sd)
-    if rn and not only_norm:
-        raise NotImplementedError("ModifiedResNet student: only the norm-layer tuning (only_norm) is restated")
     if reward_cls is None:
         reward_cls = reward_class_features(reward_sd, tokens)
     with torch.no_grad():

@@ -119,6 +119,7 @@ SIGNATURES = {
     "rlcf_engine_set_bn_prior_strength": (I, [P, I]),
     "rlcf_engine_bn_stats_count": (I, [P]),
     "rlcf_engine_encode_image_bn": (I, [P, P, I, P, P]),
+    "rlcf_engine_encode_image_bn_form": (I, [P, P, I, I, P, P]),
     "rlcf_engine_get_bn_stats": (I, [P, P, I, P]),
     "rlcf_engine_get_ln_params": (I, [P, P, I, P]),
     "rlcf_engine_set_ln_params": (I, [P, P, P]),

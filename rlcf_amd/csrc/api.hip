@@ -32,7 +32,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 6; }   // 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 7; }   // 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -510,12 +510,15 @@ int rlcf_engine_set_bn_prior_strength(rlcf_engine* e, int prior_strength) {
     e->bn_prior_strength = prior_strength < 0 ? -1 : prior_strength;
     return RLCF_OK;
 }
-int rlcf_engine_encode_image_bn(rlcf_engine* e, const float* images, int n, float* out, rlcf_stream stream) {
-    RLCF_ARG_CHECK(e && images && out && n > 0 && n <= e->max_views);      // feat_raw / the GEMM scratch are sized for max_views
+int rlcf_engine_encode_image_bn_form(rlcf_engine* e, const float* images, int n, int form, float* out, rlcf_stream stream) {
+    RLCF_ARG_CHECK(e && images && out && n > 0 && n <= e->max_views && form <= 0);      // feat_raw / the GEMM scratch are sized for max_views
     ClipModel& s = e->model[RLCF_STUDENT];
     if (!s.finalized || !is_resnet(s.cfg)) { rlcf_set_error("rlcf_engine_encode_image_bn needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
     const int rc = engine_bn_enable(e, (hipStream_t)stream);
-    return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, (hipStream_t)stream);
+    return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, (hipStream_t)stream, form < 0 ? -1 : 0);
+}
+int rlcf_engine_encode_image_bn(rlcf_engine* e, const float* images, int n, float* out, rlcf_stream stream) {
+    return rlcf_engine_encode_image_bn_form(e, images, n, -1, out, stream);
 }
 int rlcf_engine_bn_stats_count(rlcf_engine* e) {
     if (!e) return 0;

@@ -71,7 +71,15 @@ struct BnUnit {
     int KpT = 0;
     int pofs = -1;                   // offset of (gamma | beta) in the tunable vector (e->ln_params); -1: frozen (downsample.1)
     int sofs = 0;                    // offset of (running_mean | running_var) in the statistics vector (e->bn_stats)
-    const float *gamma0 = nullptr, *beta0 = nullptr;     // checkpoint tensors (what a frozen unit reads)
+    const float *gamma0 = nullptr, *beta0 = nullptr;     // checkpoint tensors (what a frozen unit reads); every-parameter tuning: the live
+                                                         // downsample.1 weight / bias inside e->vw
+    // every-parameter tuning (engine_rn_visual_enable): the live convolution weight as stored ([cout, cin, k, k], inside e->vw; the
+    // GEMM-layout copies raw.w / wT and their split pairs are rebuilt from it after every optimizer step: rn_visual_refresh) and
+    // where the unit's gradients go in e->vw_grad; the input the last train-form forward fed it (weight gradient = dZ^T . patches)
+    const float* w_live = nullptr;
+    long vofs_w = -1, vofs_g = -1;                       // offsets of the weight / of downsample.1's (weight | bias) in the flat vector
+    float* wT_buf = nullptr;                             // (wT, writable)
+    const float* in_ptr = nullptr; int in_H = 0, in_W = 0, in_stride = 1; bool in_nchw = false;
 };
 struct ResNetW {                     // ModifiedResNet (TPT/clip/model.py:94-154), inference form
     bool present = false;
@@ -80,6 +88,12 @@ struct ResNetW {                     // ModifiedResNet (TPT/clip/model.py:94-154
     std::vector<BnUnit> units;
     std::vector<int> block_unit;     // index of a block's first unit
     const float *q_wT = nullptr, *kv_wT = nullptr, *c_wT = nullptr;      // transposes for the attention pool's backward
+    // every-parameter tuning of the student (CLIPCLS_TTA(only_norm=False) on a ModifiedResNet, the parser defaults of tune_cls_rl.py):
+    // offsets of the attention pool's tensors in the flat vector e->vw, in named_parameters order (positional_embedding, k_proj.weight,
+    // k_proj.bias, q_proj.weight, q_proj.bias, v_proj.weight, v_proj.bias, c_proj.weight, c_proj.bias); the live k|v concatenations
+    bool full_enabled = false;
+    long vofs_pool[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    float *kv_w_buf = nullptr, *kv_b_buf = nullptr, *q_wT_buf = nullptr, *kv_wT_buf = nullptr, *c_wT_buf = nullptr;
     int n_stats = 0;                 // floats of the statistics vector
     ConvW stem[3];
     std::vector<BottleW> blocks;
@@ -190,6 +204,7 @@ struct rlcf_engine {
     // sample batch runs beside the student tower of the next part, tta_batch_pipelined) ...
     // norm-layer tuning of a ModifiedResNet student: running statistics of every BatchNorm2d (reset per sample, updated by train-mode
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
+    DevBuf rn_wg_tmp;                // GEMM-layout weight gradient of one 3x3 convolution / the k|v projection (every-parameter tuning)
     DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
     DevBuf zpage;                    // 4 KB of zeros: what the implicit 3x3 convolution reads outside the image
     DevBuf parts_ws, attn_park;      // scratch of the bit-reproducible reductions: parameter-gradient partial sums; dK / dV per query block
@@ -198,6 +213,7 @@ struct rlcf_engine {
     std::vector<float*> bn_ms;       // per unit: (mean | rstd) used by the pass, inside bn_scratch
     int bn_saved_n = 0;
     float *bn_q = nullptr, *bn_kv = nullptr;     // attention pool: projected query [n, E] and keys|values [n*T, 2E] of the saved pass
+    float *bn_tok = nullptr, *bn_att = nullptr;  // ... its tokens [n*T, E] and attended output [n, E] (weight gradients of every-parameter tuning)
     struct ImgSide { DevBuf patch_out, patches, cls_rows, cls_ln, feat_raw, cls_a2, cls_h2, cls_f2, resized; Tower vt; } side_img;
     hipEvent_t ev_part[8] = {};      // "student tower of part k done" (created on first use)
     DevBuf a_hi2;                    // ... and its own A-operand split buffer: the main stream's text passes re-split into a_hi (M > 512:
@@ -242,9 +258,13 @@ int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* al
                       float* C, int ldc, void* Cpairs, const float* out_scale_dev, int M, int N, int epi, hipStream_t st, float* amax_out);
 int engine_split_operand(rlcf_engine* e, const float* in, int64_t n, const float* amax_in, void** pairs, const float** scale2, hipStream_t st);
 int engine_bn_enable(rlcf_engine* e, hipStream_t st);
-int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st);
-int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st);
-int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
+int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st, int mode_override = -1);
+int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st, float* vgrad = nullptr);
+int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full = false);
+int engine_rn_visual_enable(rlcf_engine* e, hipStream_t st);
+int rn_visual_refresh(rlcf_engine* e, hipStream_t st);
+// dW[N, K] = dY[T, N]^T X[T, K] (+ db[N] += column sums of dY) through the NT GEMM of the engine's precision (engine.hip)
+int engine_wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X, int ldx, int K, int T, float* dW, float* db, hipStream_t st);
 // engine.hip services used by resnet.hip
 int engine_gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldr, float* C,
                 int ldc, int M, int N, int K, int epi, hipStream_t st, const float* amax_in = nullptr, float* amax_out = nullptr);

@@ -452,7 +452,7 @@ int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
     if (e->vw_count) return RLCF_OK;
     ClipModel& m = e->model[RLCF_STUDENT];
     if (!m.finalized) { rlcf_set_error("student model not finalized"); return RLCF_ERR_STATE; }
-    if (is_resnet(m.cfg)) { rlcf_set_error("every-parameter image-encoder tuning needs a VisionTransformer student; a ModifiedResNet student tunes its BatchNorm weights / biases (rlcf_tta_sample_ln)"); return RLCF_ERR_STATE; }
+    if (is_resnet(m.cfg)) return engine_rn_visual_enable(e, st);          // (resnet.hip: convolutions, BatchNorms, attention pool)
     if (prec_single(e)) { rlcf_set_error("encoder tuning runs in RLCF_PREC_F32 / RLCF_PREC_F16X3 (RLCF_PREC_F16 is the prompt path's performance mode)"); return RLCF_ERR_STATE; }
     const rlcf_clip_cfg& c = m.cfg;
     const size_t Wv = c.vision_width, D = c.embed_dim, K = (size_t)3 * c.vision_patch_size * c.vision_patch_size, W2 = Wv * Wv;
@@ -518,7 +518,10 @@ static int refresh_derived(const std::vector<VwRefresh>& list, int Kp, hipStream
     }
     return RLCF_OK;
 }
-int engine_visual_refresh(rlcf_engine* e, hipStream_t st) { return refresh_derived(e->vw_refresh, e->model[RLCF_STUDENT].Kp, st); }
+int engine_visual_refresh(rlcf_engine* e, hipStream_t st) {
+    if (is_resnet(e->model[RLCF_STUDENT].cfg)) return rn_visual_refresh(e, st);
+    return refresh_derived(e->vw_refresh, e->model[RLCF_STUDENT].Kp, st);
+}
 
 // Linear weight gradient dW[N,K] = dY[T,N]^T X[T,K] (+ db[N] += column sums of dY): both operands are transposed to K-major
 // [*, Tp] (token dimension zero padded to the GEMM's K granule) and go through the NT GEMM of the engine's precision; in
@@ -531,7 +534,11 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
     TRY(launch_transpose_pad(X, ldx, xt, T, K, Tp, st));
     e->last_flops += 2.0 * N * K * T;
     int rc;
-    if (prec_x3(e) && N >= 256 && (size_t)N * Tp <= e->a_split_elems) {
+    // split-f16 kernels for wide outputs — and for ANY output when the token dimension is long (the convolutions of a ResNet student see
+    // n*H*W = 10^5..10^6 rows: there the split-f16 launcher cuts the K loop into slices, gemm_f16x3.hip; the f32 kernel would walk it in
+    // a handful of workgroups)
+    if (prec_x3(e) && (N >= 256 || Tp >= 8192) && K % 4 == 0) {
+        if ((size_t)N * Tp > e->a_split_elems) { TRY(e->a_hi.ensure((size_t)N * Tp * 4)); e->a_split_elems = (size_t)N * Tp; }
         TRY(e->w_hi.ensure((size_t)K * Tp * 4));
         TRY(e->dyn.ensure(3 * sizeof(float)));
         TRY(launch_split_f16x2_dyn(yt, e->a_hi.p, lo_of(e->a_hi.p), (int64_t)N * Tp, e->dyn.as<float>(), st, 1));
@@ -551,6 +558,11 @@ static int wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X
     TRY(rc);
     if (db) TRY(launch_colsum(dY, ldy, T, N, db, st, PARTS_WS(e)));
     return RLCF_OK;
+}
+
+int engine_wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X, int ldx, int K, int T, float* dW, float* db, hipStream_t st) {
+    if (db) TRY(e->parts_ws.ensure(RLCF_PARTS_WS_FLOATS * sizeof(float)));      // (bias column sums in a fixed order: bit-reproducible)
+    return wgrad(e, dY, ldy, N, X, ldx, K, T, dW, db, st);
 }
 
 // ------------------------------------------------------------------ transformer passes
@@ -1728,9 +1740,22 @@ int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, co
 // CLIPCLS_TTA.train() (custom_clip.py:487-497) puts the norm layers in train mode whatever `mode` is, so the final clean-view
 // inference ALSO normalises with batch statistics (of that one image): reproduced.  The running statistics the sample leaves behind
 // stay in e->bn_stats (rlcf_engine_get_bn_stats) until the next sample resets them.
-int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
+static int rn_visual_reset(rlcf_engine* e, hipStream_t st) {   // visual.load_state_dict(initial_state_dict) for the flat buffer of a ResNet student
+    if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    e->vw_dirty = false;
+    return rn_visual_refresh(e, st);
+}
+// full: every visual parameter is tuned (CLIPCLS_TTA(only_norm=False) on a ModifiedResNet — the parser defaults of tune_cls_rl.py,
+// TPT/params.py:23,73): convolution / downsample.1 / attention-pool gradients into e->vw_grad, a second AdamW launch, the derived
+// weight forms rebuilt after every step, and the final clean-view inference with the BatchNorms in EVAL form on the running statistics
+// the tuning passes left behind (model.eval() is plain nn.Module.eval() when only_norm is off, custom_clip.py:487-497)
+int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
     ClipModel& s = e->model[RLCF_STUDENT];
     TRY(engine_bn_enable(e, st));
+    if (full) TRY(engine_rn_visual_enable(e, st));
+    if (!full && s.rn.full_enabled && e->vw_dirty) TRY(rn_visual_reset(e, st));
+    const size_t vb = full ? e->vw_count * sizeof(float) : 0;
     const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
     const int n_sel = n_selected(a, N), n_e = n_sel * K;
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
@@ -1746,6 +1771,11 @@ int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_t
     RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats.p, e->bn_stats_init.p, (size_t)s.rn.n_stats * sizeof(float), hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
     RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
+    if (full) {
+        TRY(rn_visual_reset(e, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_m.p, 0, vb, st));
+        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_v.p, 0, vb, st));
+    }
     const float* cls_feat = e->txt0.as<float>();
     for (int j = 0; j < a->tta_steps; ++j) {
         const int n = j == 0 ? N : n_sel;
@@ -1773,8 +1803,10 @@ int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_t
         }
         // d feat = scale * dlogits @ class_features (custom_clip.py:429-430), then the tower's backward down to the stem's first BatchNorm
         TRY(launch_dimg(dlog, cls_feat, n, C, D, s.logit_scale_exp, e->dfeat.as<float>(), st));
-        TRY(rn_backward_bn(e, s, n, e->ln_feat.as<float>(), e->dfeat.as<float>(), e->ln_grad.as<float>(), st));
+        if (full) RLCF_HIP_CHECK(hipMemsetAsync(e->vw_grad.p, 0, vb, st));
+        TRY(rn_backward_bn(e, s, n, e->ln_feat.as<float>(), e->dfeat.as<float>(), e->ln_grad.as<float>(), st, full ? e->vw_grad.as<float>() : nullptr));
         if (j == 0) {
+            if (full) COPY_OUT(out->vis_grad, e->vw_grad.p, vb);
             COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
             COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
             COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
@@ -1783,19 +1815,29 @@ int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_t
             COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
         }
         TRY(launch_grad_nonfinite(e->ln_grad.as<float>(), e->ln_count, 1, e->step_skip.as<int32_t>(), st));
+        if (full) TRY(launch_grad_nonfinite(e->vw_grad.as<float>(), (int64_t)e->vw_count, 1, e->step_skip.as<int32_t>(), st, true));
         if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
         TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
                          a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->ln_count));
+        if (full) {
+            TRY(launch_adamw(e->vw.as<float>(), e->vw_grad.as<float>(), e->vw_m.as<float>(), e->vw_v.as<float>(), (int64_t)e->vw_count, j + 1,
+                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)e->vw_count));
+            e->vw_dirty = true;
+            TRY(rn_visual_refresh(e, st));
+        }
     }
     COPY_OUT(out->ln_after, e->ln_params.p, nb);
+    if (full) COPY_OUT(out->vis_after, e->vw.p, vb);
     if (!a->skip_final) {
-        TRY(rn_forward_train(e, s, views, 1, e->img_feat.as<float>(), st));          // (train-form: see the header comment)
+        // norm-layer tuning: the BatchNorms stay in train form (see the header comment); every-parameter tuning: eval form
+        TRY(rn_forward_train(e, s, views, 1, e->img_feat.as<float>(), st, full ? 0 : -1));
         TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
         TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
         COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
         COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
     }
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
+    if (full) TRY(rn_visual_reset(e, st));
     return RLCF_OK;
 }
 
@@ -1822,8 +1864,7 @@ static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const 
     const int n_sel = n_selected(a, N), n_e = n_sel * K;
     if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
     if (is_resnet(s.cfg)) {
-        if (full) { rlcf_set_error("a ModifiedResNet student tunes its BatchNorm weights / biases (--tune_norm 1); every-parameter tuning of it is not built"); return RLCF_ERR_STATE; }
-        return engine_tta_sample_bn(e, views, N, a, out, st);
+        return engine_tta_sample_bn(e, views, N, a, out, st, full);
     }
     RLCF_ARG_CHECK(s.tokens <= 320);
     const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;

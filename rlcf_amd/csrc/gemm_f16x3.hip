@@ -1451,6 +1451,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int nkt = K / X3_BK;
         int ksplit = 1;
         if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
+        // a very long K loop over a small output (the weight gradient of a convolution: K = n*H*W = 10^5..10^6 rows): as many slices as
+        // it takes to put ~384 workgroups on the chip, each at least 64 K tiles long, within the workspace
+        if (!nosplit && nkt >= 1024 && blocks2s < 384 && splitk_ws) {
+            const long by_ws = (long)(splitk_ws_bytes / ((size_t)M * N * sizeof(float)));
+            const long want = std::min<long>(std::min<long>((384 + blocks2s - 1) / blocks2s, nkt / 64), std::min<long>(by_ws, 64));      // (<= 64 slices of >= 64 K tiles: no slice is empty)
+            if (want > ksplit) ksplit = (int)want;
+        }
         if (ksplit > 1 && (!splitk_ws || (size_t)ksplit * M * N * sizeof(float) > splitk_ws_bytes)) ksplit = 1;
         g.ksplit = ksplit; g.ws = splitk_ws;
         if (single) gemm_nt_f16x3_v2_kernel<2, true><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);

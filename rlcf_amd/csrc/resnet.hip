@@ -799,6 +799,7 @@ int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
         conv_permute_kernel<<<dim3(cout), dim3(256), 0, st>>>(wr, wp, cin, kk, u.raw.Kp);
         RLCF_LAUNCH_CHECK();
         u.raw.w = wp; u.raw.b = nullptr;
+        u.w_live = wr;
         TRY(engine_make_split(e, m, u.raw.w, (size_t)cout * u.raw.Kp, st));
         if (need_dx) {
             if (k == 1) {
@@ -812,6 +813,7 @@ int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
                 RLCF_LAUNCH_CHECK();
                 u.wT = wt;
             }
+            u.wT_buf = (float*)u.wT;
             if (u.KpT % 32 == 0) TRY(engine_make_split(e, m, u.wT, (size_t)cin * u.KpT, st));
         }
         if (tuned) { u.pofs = pofs; pofs += 2 * cout; }
@@ -839,6 +841,7 @@ int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
     NEED(r.q_wT = transposed_of(m, r.q_w, E, E, st));
     NEED(r.kv_wT = transposed_of(m, r.kv_w, 2 * E, E, st));
     NEED(r.c_wT = transposed_of(m, r.c_w, D, E, st));
+    r.q_wT_buf = (float*)r.q_wT; r.kv_wT_buf = (float*)r.kv_wT; r.c_wT_buf = (float*)r.c_wT;
     TRY(engine_make_split(e, m, r.q_wT, (size_t)E * E, st));
     TRY(engine_make_split(e, m, r.kv_wT, (size_t)2 * E * E, st));
     TRY(engine_make_split(e, m, r.c_wT, (size_t)D * E, st));
@@ -888,6 +891,7 @@ int engine_bn_enable(rlcf_engine* e, hipStream_t st) {
 // ---- train-form pass -----------------------------------------------------------------------------------------------------------
 struct BnPass {
     rlcf_engine* e; ClipModel* m; hipStream_t st; int n; int mode; float prior; bool save;
+    float* vgrad = nullptr;          // every-parameter tuning: e->vw_grad (convolution / downsample.1 / attention-pool gradients)
 };
 static inline const float* bn_gamma(const rlcf_engine* e, const BnUnit& u) { return u.pofs >= 0 ? e->ln_params.as<float>() + u.pofs : u.gamma0; }
 static inline const float* bn_beta(const rlcf_engine* e, const BnUnit& u) { return u.pofs >= 0 ? e->ln_params.as<float>() + u.pofs + u.raw.cout : u.beta0; }
@@ -897,7 +901,8 @@ static inline const float* bn_beta(const rlcf_engine* e, const BnUnit& u) { retu
 static int bn_unit_fwd(const BnPass& P, int ui, const float* in, int in_unit, int H, int W, int stride, bool nchw, const float* idn, bool relu,
                        float* z, float* y) {
     rlcf_engine* e = P.e;
-    const BnUnit& u = P.m->rn.units[ui];
+    BnUnit& u = P.m->rn.units[ui];
+    u.in_ptr = in; u.in_H = H; u.in_W = W; u.in_stride = stride; u.in_nchw = nchw;       // (weight gradients of every-parameter tuning)
     const int Ho = H / stride, Wo = W / stride, C = u.raw.cout;
     const long M = (long)P.n * Ho * Wo;
     TRY(conv(e, u.raw, in, in_unit >= 0 ? e->bn_amax.as<float>() + in_unit : nullptr, P.n, H, W, stride, nchw, nullptr, RLCF_EPI_NONE, z, nullptr, P.st));
@@ -940,7 +945,7 @@ static void bn_plan(const ClipModel& m, std::vector<size_t>& out_elems, std::vec
 // ModifiedResNet.forward in train form over n images (ALL of them in one pass: the batch statistics couple them) + L2 normalisation.
 // z / y of every unit, the pooled intermediates and the attention pool's tensors are kept for rn_backward_bn (every unit writes its
 // own slots: no in-place reuse to reason about; RN50 at 64 views of 224^2: 5 GB, RN50x64 at 32 views of 448^2: ~55 GB of the 288).
-int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st) {
+int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st, int mode_override) {
     const bool save = true;
     const rlcf_clip_cfg& c = m.cfg;
     ResNetW& r = m.rn;
@@ -957,14 +962,16 @@ int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, f
     { float* p = e->bn_scratch.as<float>(); for (int i = 0; i < nu; ++i) { e->bn_ms[i] = p; p += 2 * (size_t)r.units[i].raw.cout; } }
     {
         // + pooled copies: stem pool, per strided block the pooled conv2 output and the pooled block input
-        size_t extra = (size_t)(R / 4) * (R / 4) * w + (size_t)T * 2 * E + E;        // (+ the attention pool's k|v and q)
+        size_t extra = (size_t)(R / 4) * (R / 4) * w + (size_t)T * 3 * E + 2 * E;    // (+ the attention pool's k|v, q, tokens and output)
         { int H = R / 4; for (const BottleW& b : r.blocks) { if (b.stride > 1) extra += (size_t)(H / 2) * (H / 2) * (b.c2.cout + b.down.cin); H /= b.stride; } }
         TRY(e->bn_saved.ensure(((size_t)n * (2 * act_total + extra)) * sizeof(float)));
         float* p = e->bn_saved.as<float>();
         for (int i = 0; i < nu; ++i) { e->bn_z[i] = p; p += (size_t)n * oe[i]; e->bn_y[i] = p; p += (size_t)n * oe[i]; }
         e->bn_saved_n = n;
     }
-    const int mode = e->bn_prior_strength >= 0 ? 2 : 1;
+    // mode_override 0: every BatchNorm in EVAL form on the running statistics (the final inference of every-parameter tuning: there
+    // CLIPCLS_TTA.train(mode) is plain nn.Module.train(mode), custom_clip.py:487-497, and the harness calls model.eval() first)
+    const int mode = mode_override >= 0 ? mode_override : (e->bn_prior_strength >= 0 ? 2 : 1);
     const float prior = e->bn_prior_strength >= 0 ? (float)e->bn_prior_strength / (float)(e->bn_prior_strength + 1) : 0.f;
     BnPass P{e, &m, st, n, mode, prior, save};
     float* pooled = e->bn_saved.as<float>() + (size_t)n * 2 * act_total;
@@ -1010,19 +1017,21 @@ int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, f
         H = Ho;
     }
     // attention pool (model.py:68-91), probabilities kept for the backward
-    attnpool_tokens_kernel<<<dim3((E + 255) / 256, n), dim3(256), 0, st>>>(x, r.pos, e->rn_tok.as<float>(), HW, E);
-    RLCF_LAUNCH_CHECK();
-    // q / k|v / probabilities stay with the saved pass (a ModifiedResNet reward model's encode, between this pass and its backward,
-    // reuses e->rn_q / e->rn_kv)
+    // tokens / q / k|v / probabilities / attended output stay with the saved pass (a ModifiedResNet reward model's encode, between this
+    // pass and its backward, reuses e->rn_tok / rn_q / rn_kv / rn_att)
     e->bn_kv = pooled; pooled += (size_t)n * T * 2 * E;
-    e->bn_q = pooled;
-    TRY(engine_gemm(e, e->rn_tok.as<float>(), T * E, r.q_w, E, r.q_b, nullptr, 0, e->bn_q, E, n, E, E, RLCF_EPI_NONE, st));
-    TRY(engine_gemm(e, e->rn_tok.as<float>(), E, r.kv_w, E, r.kv_b, nullptr, 0, e->bn_kv, 2 * E, n * T, 2 * E, E, RLCF_EPI_NONE, st));
+    e->bn_q = pooled; pooled += (size_t)n * E;
+    e->bn_tok = pooled; pooled += (size_t)n * T * E;
+    e->bn_att = pooled;
+    attnpool_tokens_kernel<<<dim3((E + 255) / 256, n), dim3(256), 0, st>>>(x, r.pos, e->bn_tok, HW, E);
+    RLCF_LAUNCH_CHECK();
+    TRY(engine_gemm(e, e->bn_tok, T * E, r.q_w, E, r.q_b, nullptr, 0, e->bn_q, E, n, E, E, RLCF_EPI_NONE, st));
+    TRY(engine_gemm(e, e->bn_tok, E, r.kv_w, E, r.kv_b, nullptr, 0, e->bn_kv, 2 * E, n * T, 2 * E, E, RLCF_EPI_NONE, st));
     TRY(e->bn_grad_b.ensure((size_t)n * r.heads * T * sizeof(float)));
-    attnpool_attend_save_kernel<<<dim3(r.heads, n), dim3(256), (T + 256) * sizeof(float), st>>>(e->bn_q, e->bn_kv, e->rn_att.as<float>(),
+    attnpool_attend_save_kernel<<<dim3(r.heads, n), dim3(256), (T + 256) * sizeof(float), st>>>(e->bn_q, e->bn_kv, e->bn_att,
                                                                                                 e->bn_grad_b.as<float>(), T, E);
     RLCF_LAUNCH_CHECK();
-    TRY(engine_gemm(e, e->rn_att.as<float>(), E, r.c_w, E, r.c_b, nullptr, 0, e->feat_raw.as<float>(), D, n, D, E, RLCF_EPI_NONE, st));
+    TRY(engine_gemm(e, e->bn_att, E, r.c_w, E, r.c_b, nullptr, 0, e->feat_raw.as<float>(), D, n, D, E, RLCF_EPI_NONE, st));
     TRY(e->vit_inv_norm.ensure((size_t)std::max(n, e->max_views) * sizeof(float)));
     TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));
     return RLCF_OK;
@@ -1041,6 +1050,7 @@ static int bn_unit_bwd(const BnPass& P, int ui, const float* dy, long M, bool re
     bn_bwd_partial_kernel<<<dim3((C + 63) / 64, chunks), dim3(256), 0, P.st>>>(dy, y, z, ms, e->bn_grad_c.as<float>(), M, C, relu ? 1 : 0);
     RLCF_LAUNCH_CHECK();
     float* dg = (bn_grad && u.pofs >= 0) ? bn_grad + u.pofs : nullptr;
+    if (u.pofs < 0 && P.vgrad && u.vofs_g >= 0) dg = P.vgrad + u.vofs_g;        // downsample.1 (every-parameter tuning): weight | bias in e->vw_grad
     bn_bwd_final_kernel<<<dim3((C + 63) / 64), dim3(1024), 0, P.st>>>(e->bn_grad_c.as<float>(), chunks, C, e->bn_grad_a.as<float>(), dg, dg ? dg + C : nullptr);
     RLCF_LAUNCH_CHECK();
     if (dz) {
@@ -1074,29 +1084,84 @@ static int avgpool2_bwd(const float* dout, float* din, int n, int Ho, int Wo, in
     return RLCF_OK;
 }
 
+// ---- every-parameter tuning of a ModifiedResNet student: weight gradients ------------------------------------------------------------
+// GEMM-layout gradient [cout, Kp] ((ky, kx, ci) order) -> the state-dict layout [cout, cin, k, k]
+__global__ void conv_unpermute_kernel(const float* __restrict__ g, float* __restrict__ out, int Cin, int kk, int Kp) {
+    const int co = blockIdx.x;
+    for (int i = threadIdx.x; i < kk * Cin; i += blockDim.x) {
+        const int tap = i / Cin, ci = i - tap * Cin;
+        out[((size_t)co * Cin + ci) * kk + tap] = g[(size_t)co * Kp + i];
+    }
+}
+// d positional_embedding[t, c] = sum over the images of dtok[img, t, c] (fixed order)
+__global__ void attnpool_dpos_kernel(const float* __restrict__ dtok, float* __restrict__ dpos, int n, long TE) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < TE; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < n; ++b) s += dtok[(size_t)b * TE + i];
+        dpos[i] = s;
+    }
+}
+// d conv.weight of unit ui = dZ^T . patches(input the forward fed it): dz [M, cout] at the unit's OUTPUT resolution
+static int rn_conv_wgrad(const BnPass& P, int ui, const float* dz, long M) {
+    rlcf_engine* e = P.e;
+    const BnUnit& u = P.m->rn.units[ui];
+    if (!P.vgrad || u.vofs_w < 0) return RLCF_OK;
+    const int cout = u.raw.cout, cin = u.raw.cin, Kp = u.raw.Kp;
+    float* dst = P.vgrad + u.vofs_w;
+    if (u.raw.k == 1) return engine_wgrad(e, dz, cout, cout, u.in_ptr, cin, cin, (int)M, dst, nullptr, P.st);     // [cout, cin] as stored
+    const int H = u.in_H, W = u.in_W, Ho = H / u.in_stride, Wo = W / u.in_stride;
+    const long total = M * Kp;
+    TRY(e->rn_col.ensure((size_t)total * sizeof(float)));
+    const long sN = (long)cin * H * W, sC = u.in_nchw ? (long)H * W : 1, sH = u.in_nchw ? W : (long)W * cin, sW = u.in_nchw ? 1 : cin;
+    im2col3x3_kernel<<<grid_for(total), dim3(256), 0, P.st>>>(u.in_ptr, e->rn_col.as<float>(), total, cin, H, W, Ho, Wo, u.in_stride, Kp, sN, sC, sH, sW);
+    RLCF_LAUNCH_CHECK();
+    TRY(e->rn_wg_tmp.ensure((size_t)cout * Kp * sizeof(float)));
+    float* tmp = e->rn_wg_tmp.as<float>();
+    TRY(engine_wgrad(e, dz, cout, cout, e->rn_col.as<float>(), Kp, Kp, (int)M, tmp, nullptr, P.st));
+    conv_unpermute_kernel<<<dim3(cout), dim3(256), 0, P.st>>>(tmp, dst, cin, 9, Kp);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
 // d loss / d (BatchNorm weights, biases) of the pass rn_forward_train just ran over n images, from dfeat [n, D] = d loss / d (the
 // L2-normalised features).  bn_grad: [e->ln_count] in the tunable vector's layout.
-int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st) {
+int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st, float* vgrad) {
     const rlcf_clip_cfg& c = m.cfg;
     ResNetW& r = m.rn;
     const int R = c.image_resolution, E = r.E, D = c.embed_dim, HW = r.out_hw * r.out_hw, T = HW + 1;
     if (e->bn_saved_n != n) { rlcf_set_error("rn_backward_bn: the saved pass holds %d images, not %d", e->bn_saved_n, n); return RLCF_ERR_STATE; }
     const int mode = e->bn_prior_strength >= 0 ? 2 : 1;
     BnPass P{e, &m, st, n, mode, 0.f, true};
+    P.vgrad = vgrad;
     RLCF_HIP_CHECK(hipMemsetAsync(e->bn_amax.as<float>() + r.units.size(), 0, r.units.size() * sizeof(float), st));
     float *G0 = e->rn_buf[0].as<float>(), *G1 = e->rn_buf[1].as<float>(), *G2 = e->rn_buf[2].as<float>(), *G3 = e->rn_buf[3].as<float>(),
           *G4 = e->rn_buf[4].as<float>();
     // features -> attention pool
     TRY(launch_l2norm_bwd(feats, dfeat, e->vit_inv_norm.as<float>(), dfeat, n, D, st));
+    if (vgrad) TRY(engine_wgrad(e, dfeat, D, D, e->bn_att, E, E, n, vgrad + r.vofs_pool[7], vgrad + r.vofs_pool[8], st));      // c_proj.weight / .bias
     TRY(engine_gemm(e, dfeat, D, r.c_wT, D, nullptr, nullptr, 0, G0, E, n, E, D, RLCF_EPI_NONE, st));                 // d att [n, E]
     float *dq = G1, *dkv = G2;
     attnpool_attend_bwd_kernel<<<dim3(r.heads, n), dim3(256), (T + 256) * sizeof(float), st>>>(e->bn_q, e->bn_kv, e->bn_grad_b.as<float>(), G0, dq,
                                                                                                dkv, T, E);
     RLCF_LAUNCH_CHECK();
     float* dtok = G3;
+    if (vgrad) {
+        // q_proj (its input: token 0 of every image, row stride T*E); k_proj | v_proj as ONE product on the concatenated gradient, then
+        // the halves go to their own slots
+        TRY(engine_wgrad(e, dq, E, E, e->bn_tok, T * E, E, n, vgrad + r.vofs_pool[3], vgrad + r.vofs_pool[4], st));
+        TRY(e->rn_wg_tmp.ensure(((size_t)2 * E * E + 2 * E) * sizeof(float)));
+        float *dwkv = e->rn_wg_tmp.as<float>(), *dbkv = dwkv + (size_t)2 * E * E;
+        RLCF_HIP_CHECK(hipMemsetAsync(dbkv, 0, 2 * E * sizeof(float), st));
+        TRY(engine_wgrad(e, dkv, 2 * E, 2 * E, e->bn_tok, E, E, n * T, dwkv, dbkv, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(vgrad + r.vofs_pool[1], dwkv, (size_t)E * E * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(vgrad + r.vofs_pool[5], dwkv + (size_t)E * E, (size_t)E * E * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(vgrad + r.vofs_pool[2], dbkv, E * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RLCF_HIP_CHECK(hipMemcpyAsync(vgrad + r.vofs_pool[6], dbkv + E, E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     TRY(engine_gemm(e, dkv, 2 * E, r.kv_wT, 2 * E, nullptr, nullptr, 0, dtok, E, n * T, E, 2 * E, RLCF_EPI_NONE, st));
     TRY(engine_gemm(e, dq, E, r.q_wT, E, nullptr, nullptr, 0, G0, E, n, E, E, RLCF_EPI_NONE, st));                    // d tok0 through q_proj
     { const long tot = (long)n * E; attnpool_add_row0_kernel<<<grid_for(tot), dim3(256), 0, st>>>(dtok, G0, T, E, tot); RLCF_LAUNCH_CHECK(); }
+    if (vgrad) { const long TE = (long)T * E; attnpool_dpos_kernel<<<grid_for(TE), dim3(256), 0, st>>>(dtok, vgrad + r.vofs_pool[0], n, TE); RLCF_LAUNCH_CHECK(); }
     float* dOut = G4;                                                  // gradient at the last block's output [n*HW, E]
     { const long tot = (long)n * HW * E; attnpool_tokens_bwd_kernel<<<grid_for(tot), dim3(256), 0, st>>>(dtok, dOut, HW, E, tot); RLCF_LAUNCH_CHECK(); }
     // spatial size of every block's input
@@ -1109,22 +1174,26 @@ int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, floa
         const long Mo = (long)n * Ho * Ho, Mi = (long)n * H * H;
         // conv3 + bn3 (+ identity) + ReLU: dz3 -> G0, masked gradient g -> G1 (identity branch)
         TRY(bn_unit_bwd(P, u0 + 2, dOut, Mo, true, G0, G1, bn_grad));
+        TRY(rn_conv_wgrad(P, u0 + 2, G0, Mo));
         TRY(bn_conv_dx(P, u0 + 2, G0, Ho, Ho, nullptr, G2));                                   // d t2 [Mo, planes]
         const float* dB = G2;
         if (b.stride > 1) { TRY(avgpool2_bwd(G2, G0, n, Ho, Ho, planes, st)); dB = G0; }       // -> [Mi, planes]
         // conv2 + bn2 + ReLU
         float* dz2 = dB == G0 ? G2 : G0;
         TRY(bn_unit_bwd(P, u0 + 1, dB, Mi, true, dz2, nullptr, bn_grad));
+        TRY(rn_conv_wgrad(P, u0 + 1, dz2, Mi));
         float* dA = dz2 == G0 ? G2 : G0;
         TRY(bn_conv_dx(P, u0 + 1, dz2, H, H, nullptr, dA));                                   // [Mi, planes]
         // conv1 + bn1 + ReLU
         float* dz1 = dA == G0 ? G2 : G0;
         TRY(bn_unit_bwd(P, u0, dA, Mi, true, dz1, nullptr, bn_grad));
+        TRY(rn_conv_wgrad(P, u0, dz1, Mi));
         // identity branch into G3 [Mi, inpl], then the main branch adds onto it (GEMM residual) -> new dOut in G4
         const float* idg = G1;                                      // g [Mo, 4 planes]
         if (b.has_down) {
             float* dzd = dz1 == G0 ? G2 : G0;                       // (the buffer dz1 does not use)
             TRY(bn_unit_bwd(P, u0 + 3, G1, Mo, false, dzd, nullptr, nullptr));
+            TRY(rn_conv_wgrad(P, u0 + 3, dzd, Mo));
             if (b.stride > 1) {
                 TRY(bn_conv_dx(P, u0 + 3, dzd, Ho, Ho, nullptr, G1));                         // [Mo, inpl] (G1's g is consumed)
                 TRY(avgpool2_bwd(G1, G3, n, Ho, Ho, inpl, st));                               // [Mi, inpl]
@@ -1139,9 +1208,123 @@ int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, floa
     const long Ms = (long)n * Hs * Hs;
     TRY(avgpool2_bwd(dOut, G0, n, R / 4, R / 4, w, st));
     TRY(bn_unit_bwd(P, 2, G0, Ms, true, G1, nullptr, bn_grad));
+    TRY(rn_conv_wgrad(P, 2, G1, Ms));
     TRY(bn_conv_dx(P, 2, G1, Hs, Hs, nullptr, G2));
     TRY(bn_unit_bwd(P, 1, G2, Ms, true, G0, nullptr, bn_grad));
+    TRY(rn_conv_wgrad(P, 1, G0, Ms));
     TRY(bn_conv_dx(P, 1, G0, Hs, Hs, nullptr, G1));
-    TRY(bn_unit_bwd(P, 0, G1, Ms, true, nullptr, nullptr, bn_grad));
+    // the stem's first convolution: only its BatchNorm gradient is needed for norm-layer tuning; its weight gradient needs dz as well
+    TRY(bn_unit_bwd(P, 0, G1, Ms, true, vgrad ? G2 : nullptr, nullptr, bn_grad));
+    if (vgrad) TRY(rn_conv_wgrad(P, 0, G2, Ms));
+    return RLCF_OK;
+}
+
+
+// ---- every-parameter tuning of a ModifiedResNet student -------------------------------------------------------------------------------
+// CLIPCLS_TTA(only_norm=False) with `--arch RN50` — the PARSER DEFAULTS of tune_cls_rl.py (TPT/params.py:23,73; tune_cls_rl.py:67-71;
+// parameters() = clip_model.visual.parameters(), custom_clip.py:477-479).  The BatchNorm tensors whose name contains 'bn' stay in
+// e->ln_params (the norm-layer path's vector); every other visual tensor — the convolution weights as stored [cout, cin, k, k],
+// downsample.1's weight / bias, the attention pool — moves into the flat buffer e->vw in named_parameters order, so AdamW is two
+// launches and reset() two copies, as for a VisionTransformer student (engine_visual_enable).  After every optimizer step / reset the
+// derived forms the passes read (GEMM-layout weights, flipped / transposed dX operands, k|v concatenations, split-f16 pairs) are
+// rebuilt from the live tensors: rn_visual_refresh.
+static int resplit(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
+    auto it = m.split_of.find(w);
+    if (it == m.split_of.end()) return RLCF_OK;
+    const ClipModel::SplitW& sp = it->second;
+    return launch_split_f16x2(w, sp.hi, sp.lo, (int64_t)numel, st, 1.0f / sp.inv_scale, sp.lo == (void*)((char*)sp.hi + 64) ? 1 : 0);
+}
+int rn_visual_refresh(rlcf_engine* e, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    ResNetW& r = m.rn;
+    if (!r.full_enabled) return RLCF_OK;
+    for (BnUnit& u : r.units) {
+        const int cout = u.raw.cout, cin = u.raw.cin, kk = u.raw.k * u.raw.k;
+        conv_permute_kernel<<<dim3(cout), dim3(256), 0, st>>>(u.w_live, (float*)u.raw.w, cin, kk, u.raw.Kp);
+        RLCF_LAUNCH_CHECK();
+        TRY(resplit(e, m, u.raw.w, (size_t)cout * u.raw.Kp, st));
+        if (u.wT_buf) {
+            if (u.raw.k == 1) TRY(launch_transpose(u.w_live, u.wT_buf, cout, cin, st));
+            else { conv_flip_kernel<<<dim3(cin), dim3(256), 0, st>>>(u.w_live, u.wT_buf, cin, cout, u.KpT); RLCF_LAUNCH_CHECK(); }
+            TRY(resplit(e, m, u.wT, (size_t)cin * u.KpT, st));
+        }
+    }
+    const size_t E = r.E, D = m.cfg.embed_dim;
+    const float* vw = e->vw.as<float>();
+    RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_w_buf, vw + r.vofs_pool[1], E * E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_w_buf + E * E, vw + r.vofs_pool[5], E * E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_b_buf, vw + r.vofs_pool[2], E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_b_buf + E, vw + r.vofs_pool[6], E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    TRY(resplit(e, m, r.kv_w, 2 * E * E, st));
+    TRY(resplit(e, m, r.q_w, E * E, st));
+    TRY(resplit(e, m, r.c_w, D * E, st));
+    TRY(launch_transpose(r.q_w, r.q_wT_buf, (int)E, (int)E, st));
+    TRY(launch_transpose(r.kv_w, r.kv_wT_buf, (int)(2 * E), (int)E, st));
+    TRY(launch_transpose(r.c_w, r.c_wT_buf, (int)D, (int)E, st));
+    TRY(resplit(e, m, r.q_wT, E * E, st));
+    TRY(resplit(e, m, r.kv_wT, 2 * E * E, st));
+    TRY(resplit(e, m, r.c_wT, D * E, st));
+    return RLCF_OK;
+}
+
+int engine_rn_visual_enable(rlcf_engine* e, hipStream_t st) {
+    ClipModel& m = e->model[RLCF_STUDENT];
+    if (!m.finalized || !is_resnet(m.cfg)) { rlcf_set_error("every-parameter tuning: the student is not a finalized ModifiedResNet"); return RLCF_ERR_STATE; }
+    ResNetW& r = m.rn;
+    if (r.full_enabled) return RLCF_OK;
+    TRY(engine_bn_enable(e, st));
+    const size_t E = r.E, D = m.cfg.embed_dim, T = (size_t)r.out_hw * r.out_hw + 1;
+    // slots in named_parameters order of clip_model.visual, the 'bn' tensors (e->ln_params) left out
+    size_t total = 0;
+    e->vw_slots.clear();
+    auto slot = [&](size_t numel) -> long { const size_t off = total; e->vw_slots.push_back(VwSlot{off, numel}); total += (numel + 63) / 64 * 64; return (long)off; };
+    // (downsample.1's weight | bias: the BatchNorm backward writes d gamma at vofs_g and d beta right behind it, at vofs_g + cout, so
+    // the two slots are adjacent WITHOUT padding between them)
+    total = 0; e->vw_slots.clear();
+    for (BnUnit& u : r.units) {
+        u.vofs_w = slot((size_t)u.raw.cout * u.raw.cin * u.raw.k * u.raw.k);
+        if (u.pofs < 0) {
+            const size_t off = total;
+            e->vw_slots.push_back(VwSlot{off, (size_t)u.raw.cout});
+            e->vw_slots.push_back(VwSlot{off + u.raw.cout, (size_t)u.raw.cout});
+            total += ((size_t)2 * u.raw.cout + 63) / 64 * 64;
+            u.vofs_g = (long)off;
+        }
+    }
+    const size_t pool_numel[9] = {T * E, E * E, E, E * E, E, E * E, E, D * E, D};
+    for (int i = 0; i < 9; ++i) r.vofs_pool[i] = slot(pool_numel[i]);
+    const size_t nb = total * sizeof(float);
+    for (DevBuf* d : {&e->vw, &e->vw_init, &e->vw_grad, &e->vw_m, &e->vw_v, &e->vw_clip, &e->vw_mom}) TRY(d->ensure(nb));
+    RLCF_HIP_CHECK(hipMemsetAsync(e->vw.p, 0, nb, st));
+    float* vw = e->vw.as<float>();
+    auto take = [&](const float* src, long off, size_t numel) -> const float* {
+        (void)hipMemcpyAsync(vw + off, src, numel * sizeof(float), hipMemcpyDeviceToDevice, st);
+        return vw + off;
+    };
+    for (BnUnit& u : r.units) {
+        u.w_live = take(u.w_live, u.vofs_w, (size_t)u.raw.cout * u.raw.cin * u.raw.k * u.raw.k);
+        if (u.pofs < 0) { u.gamma0 = take(u.gamma0, u.vofs_g, u.raw.cout); u.beta0 = take(u.beta0, u.vofs_g + u.raw.cout, u.raw.cout); }
+    }
+    // attention pool: positional embedding, q / c projections are read where they live; k | v keep their concatenated copies
+    const float *kw = raw_of(m, "visual.attnpool.k_proj.weight", E * E), *kb = raw_of(m, "visual.attnpool.k_proj.bias", E);
+    const float *vwt = raw_of(m, "visual.attnpool.v_proj.weight", E * E), *vb = raw_of(m, "visual.attnpool.v_proj.bias", E);
+    NEED(kw); NEED(kb); NEED(vwt); NEED(vb);
+    auto move_split = [&](const float* old, const float* now) {        // the split copy follows the tensor to its new address
+        auto sp = m.split_of.find(old);
+        if (sp != m.split_of.end()) { const ClipModel::SplitW s_ = sp->second; m.split_of.erase(sp); m.split_of[now] = s_; }
+    };
+    { const float* n_ = take(r.pos, r.vofs_pool[0], T * E); r.pos = n_; }
+    take(kw, r.vofs_pool[1], E * E); take(kb, r.vofs_pool[2], E);
+    { const float* n_ = take(r.q_w, r.vofs_pool[3], E * E); move_split(r.q_w, n_); r.q_w = n_; }
+    { const float* n_ = take(r.q_b, r.vofs_pool[4], E); r.q_b = n_; }
+    take(vwt, r.vofs_pool[5], E * E); take(vb, r.vofs_pool[6], E);
+    { const float* n_ = take(r.c_w, r.vofs_pool[7], D * E); move_split(r.c_w, n_); r.c_w = n_; }
+    { const float* n_ = take(r.c_b, r.vofs_pool[8], D); r.c_b = n_; }
+    r.kv_w_buf = (float*)r.kv_w; r.kv_b_buf = (float*)r.kv_b;
+    for (DevBuf* d : {&e->vw_init, &e->vw_clip, &e->vw_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->vw.p, nb, hipMemcpyDeviceToDevice, st));
+    e->vw_count = total;
+    e->vw_dirty = false;
+    r.full_enabled = true;
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));
     return RLCF_OK;
 }

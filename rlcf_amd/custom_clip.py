@@ -217,9 +217,6 @@ class CLIPCLS_TTA(nn.Module):
         # a ModifiedResNet student (RN50 .. RN50x64): the norm layers are BatchNorms; `ln` then holds their weights / biases and the
         # forward runs them on batch statistics, as the reference's does even after model.eval() (custom_clip.py:481-497)
         self.resnet = "visual.layer1.0.conv1.weight" in self.clip_model.state_dict
-        if self.resnet and not only_norm:
-            raise NotImplementedError("a ModifiedResNet student tunes its BatchNorm weights / biases (--tune_norm 1): every-parameter "
-                                      "tuning of it is not built")
         runtime.SESSION.set_student(self.clip_model)
         self.device, self.prompt_prefix = device, prompt_prefix
         self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
@@ -313,9 +310,17 @@ class CLIPCLS_TTA(nn.Module):
         eng = runtime.SESSION.engine(image.shape[0])
         eng.set_ln_params(self.ln.data)
         if self.resnet:
-            img = eng.encode_image_bn(image)
+            # norm-layer tuning: CLIPCLS_TTA.train(mode) keeps the BatchNorms in train mode whatever `mode` is; every-parameter tuning:
+            # train(mode) is plain nn.Module.train(mode) (custom_clip.py:487-497), so after model.eval() they run in eval form on the
+            # running statistics the tuning passes left behind
+            adapted = not self.only_norm and not torch.equal(self.vis.data, self._vis_init)
+            if adapted:
+                eng.set_visual_params(self.vis.data)
+            img = eng.encode_image_bn(image, eval_form=(not self.only_norm) and not self.training)
             out = eng.logits(img, eng.text_features(runtime.SESSION.ctx_init.to(img.device)))
             eng.set_ln_params(self._ln_init)
+            if adapted:
+                eng.set_visual_params(self._vis_init)
             return out
         adapted = not self.only_norm and not torch.equal(self.vis.data, self._vis_init)
         if adapted:

@@ -249,11 +249,14 @@ class Engine:
         """`--prior_strength` (TPT/params.py:91): < 0 = nn.BatchNorm2d train mode, >= 0 = `_modified_bn_forward` (tune_cls_rl.py:35-44)."""
         L.check(self.lib.rlcf_engine_set_bn_prior_strength(self.h, int(prior_strength)), "set_bn_prior_strength")
 
-    def encode_image_bn(self, images: torch.Tensor) -> torch.Tensor:
-        """ResNet student, BatchNorms on batch statistics, live tunable parameters (what CLIPCLS_TTA's forward computes: include/rlcf_hip.h)."""
+    def encode_image_bn(self, images: torch.Tensor, eval_form: bool = False) -> torch.Tensor:
+        """ResNet student, live tunable parameters; BatchNorms on batch statistics (what CLIPCLS_TTA's forward computes under norm-layer
+        tuning) or, eval_form, on the running statistics as the last tuning pass left them (every-parameter tuning after model.eval():
+        include/rlcf_hip.h)."""
         images = images.to(self.device, torch.float32).contiguous()
         out = torch.empty(images.shape[0], self.student.embed_dim, device=self.device)
-        L.check(self.lib.rlcf_engine_encode_image_bn(self.h, _ptr(images), images.shape[0], _ptr(out), _stream()), "encode_image_bn")
+        L.check(self.lib.rlcf_engine_encode_image_bn_form(self.h, _ptr(images), images.shape[0], 0 if eval_form else -1, _ptr(out), _stream()),
+                "encode_image_bn")
         return out
 
     def bn_stats(self, pristine: bool = False) -> torch.Tensor:
@@ -264,28 +267,73 @@ class Engine:
         return out
 
     # ---- full image-encoder tuning (CLIPCLS_TTA only_norm=False, TPT/clip/custom_clip.py:477-479)
+    def _resnet_visual_names(self):
+        """names of the flat vector's tensors for a ModifiedResNet student: clip_model.visual.named_parameters() order without the
+        tensors whose name contains 'bn' (those live in the norm-layer vector)"""
+        names = ["visual.conv1.weight", "visual.conv2.weight", "visual.conv3.weight"]
+        w = self.student.vision_width
+        inpl = w
+        for li, nb in enumerate(self.student.vision_layers):
+            planes = w << li
+            for b in range(nb):
+                p = f"visual.layer{li + 1}.{b}."
+                names += [p + "conv1.weight", p + "conv2.weight", p + "conv3.weight"]
+                if (b == 0 and li > 0) or inpl != planes * 4:
+                    names += [p + "downsample.0.weight", p + "downsample.1.weight", p + "downsample.1.bias"]
+                inpl = planes * 4
+        names.append("visual.attnpool.positional_embedding")
+        for nm in ("k_proj", "q_proj", "v_proj", "c_proj"):
+            names += [f"visual.attnpool.{nm}.weight", f"visual.attnpool.{nm}.bias"]
+        return names
+
     def visual_layout(self):
-        """[(state-dict key, offset, numel)] of the flat non-LayerNorm visual parameter vector (include/rlcf_hip.h)."""
-        layers = self.student.vision_layers if isinstance(self.student.vision_layers, int) else 0     # (ModifiedResNet: the call refuses)
-        n = 4 + 8 * layers
+        """[(state-dict key, offset, numel)] of the flat non-norm visual parameter vector (include/rlcf_hip.h)."""
+        if not isinstance(self.student.vision_layers, int):          # ModifiedResNet student
+            names = self._resnet_visual_names()
+        else:
+            layers = self.student.vision_layers
+            names = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight"]
+            for i in range(layers):
+                b = f"visual.transformer.resblocks.{i}."
+                names += [b + "attn.in_proj_weight", b + "attn.in_proj_bias", b + "attn.out_proj.weight", b + "attn.out_proj.bias",
+                          b + "mlp.c_fc.weight", b + "mlp.c_fc.bias", b + "mlp.c_proj.weight", b + "mlp.c_proj.bias"]
+        n = len(names)
         off, num = (C.c_int64 * n)(), (C.c_int64 * n)()
         got = self.lib.rlcf_engine_visual_param_layout(self.h, off, num, n, _stream())
         if got < 0:
             L.check(got, "visual_param_layout")
-        names = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight"]
-        for i in range(layers):
-            b = f"visual.transformer.resblocks.{i}."
-            names += [b + "attn.in_proj_weight", b + "attn.in_proj_bias", b + "attn.out_proj.weight", b + "attn.out_proj.bias",
-                      b + "mlp.c_fc.weight", b + "mlp.c_fc.bias", b + "mlp.c_proj.weight", b + "mlp.c_proj.bias"]
         assert got == len(names)
         return [(k, int(off[i]), int(num[i])) for i, k in enumerate(names)]
 
     def merge_visual(self, ln_vec: torch.Tensor, vis_vec: torch.Tensor) -> torch.Tensor:
-        """LayerNorm vector + flat vector -> one vector in clip_model.visual.named_parameters() order (what the reference's
+        """norm-layer vector + flat vector -> one vector in clip_model.visual.named_parameters() order (what the reference's
         optimizer sees with only_norm=False; oracle.rlcf_ref.visual_param_keys)."""
+        t = {k: vis_vec[o: o + n] for k, o, n in self.visual_layout()}
+        if not isinstance(self.student.vision_layers, int):
+            # ModifiedResNet: the norm vector holds (weight | bias) per tuned BatchNorm in named order: stem bn1..3, then bn1..3 per block
+            out, pos = [], 0
+
+            def bn(c):
+                nonlocal pos
+                v = [ln_vec[pos: pos + c], ln_vec[pos + c: pos + 2 * c]]
+                pos += 2 * c
+                return v
+            for i in (1, 2, 3):
+                wt = t[f"visual.conv{i}.weight"]
+                out += [wt] + bn(self._rn_cout(f"visual.conv{i}.weight"))
+            for k, _, _ in self.visual_layout():
+                if ".layer" not in k:
+                    continue
+                out.append(t[k])
+                if k.endswith(("conv1.weight", "conv2.weight", "conv3.weight")):
+                    out += bn(self._rn_cout(k))
+            out.append(t["visual.attnpool.positional_embedding"])
+            for nm in ("k_proj", "q_proj", "v_proj", "c_proj"):
+                out += [t[f"visual.attnpool.{nm}.weight"], t[f"visual.attnpool.{nm}.bias"]]
+            assert pos == ln_vec.numel()
+            return torch.cat([x.reshape(-1) for x in out])
         Wv, Lv = self.student.vision_width, self.student.vision_layers
         ln = ln_vec.view(-1, Wv)                                   # rows: ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x L, ln_post.w/.b
-        t = {k: vis_vec[o: o + n] for k, o, n in self.visual_layout()}
         out = [t["visual.class_embedding"], t["visual.positional_embedding"], t["visual.proj"], t["visual.conv1.weight"], ln[0], ln[1]]
         for i in range(Lv):
             b = f"visual.transformer.resblocks.{i}."
@@ -294,6 +342,15 @@ class Engine:
                     t[b + "mlp.c_proj.bias"], ln[4 + 4 * i], ln[5 + 4 * i]]
         out += [ln[2 + 4 * Lv], ln[3 + 4 * Lv]]
         return torch.cat([x.reshape(-1) for x in out])
+
+    def _rn_cout(self, key: str) -> int:
+        """output channels of a ModifiedResNet convolution, from the geometry (model.py:10-55,94-127)"""
+        w = self.student.vision_width
+        if ".layer" not in key:
+            return {"visual.conv1.weight": w // 2, "visual.conv2.weight": w // 2, "visual.conv3.weight": w}[key]
+        li = int(key.split(".layer")[1][0]) - 1
+        planes = w << li
+        return planes * 4 if key.endswith(("conv3.weight", "downsample.0.weight")) else planes
 
     def visual_params(self, which: int = 0) -> torch.Tensor:
         """flat vector: 0 live, 1 reset state, 2 checkpoint, 3 momentum state"""

@@ -304,7 +304,8 @@ def run_reference_ln(ref, student, reward, n_views, n_cls, hp, view_seed=1000, n
         vsd = model.clip_model.visual.state_dict()
         bns = RR.visual_bn_stat_keys({"visual." + k: v for k, v in vsd.items()})
         bn_stats = torch.cat([torch.cat([vsd[b[len("visual."):] + ".running_mean"].reshape(-1), vsd[b[len("visual."):] + ".running_var"].reshape(-1)]) for b in bns])
-        assert ["visual." + n for n in names] == RR.visual_bn_keys(s_sd), "oracle key order != named_parameters order"
+        if only_norm:
+            assert ["visual." + n for n in names] == RR.visual_bn_keys(s_sd), "oracle key order != named_parameters order"
     out = dict(logits=taps["logits"], selected_idx=taps["selected_idx"], topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]),
                clip_score=taps["clip_score"], rewards=taps["rewards"],
                final_logits=final, top5=torch.topk(final, min(5, n_cls), dim=-1).indices[0])
@@ -396,6 +397,11 @@ VIS_CASES = {      # CLIPCLS_TTA(only_norm=False): name -> (student, reward, vie
     "vis_tinyp6_s3": ("tiny-p6", "tiny-r", 8, 16, dict(lr=1e-4, tta_steps=3), False),        # padded conv1 columns (as ViT-L/14)
     "vis_small_s1": ("small", "small", 16, 40, dict(lr=1e-4, selection_p=0.25), False),
     "vis_b16_s3": ("ViT-B/16", "ViT-B/16", 8, 1000, dict(lr=1e-5, tta_steps=3, selection_p=0.25), False),   # rlcf-tune.sh: lr 1e-5, 3 steps
+}
+RNVIS_CASES = {    # ModifiedResNet student, CLIPCLS_TTA(only_norm=False) — the parser defaults of tune_cls_rl.py (`--arch RN50 --tune_norm 0`)
+    "rnvis_tiny_s1": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-4), True),
+    "rnvis_tiny_s3": ("tiny-rn", "tiny-r", 8, 16, dict(lr=1e-4, tta_steps=3), False),
+    "rnvis_rn50": ("RN50", "ViT-B/16", 16, 40, dict(lr=1e-5, selection_p=0.5, sample_k=6), False),
 }
 LN_CASES = {
     "ln_tiny_s1": ("tiny", "tiny-r", 8, 16, dict(lr=1e-3)),
@@ -606,6 +612,17 @@ def main():
                 arrays = run_reference_ln(ref, student, reward, n, c, hp, only_norm=False, full_vectors=full)
                 meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23, view_seed=1000,
                             bank_seed=7, n_ctx=4, only_norm=0, **hp)
+                save(name, arrays, meta)
+                print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
+                      f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")
+        elif grp in ("rnvis", "rnvisrn50"):
+            for name in [k for k in RNVIS_CASES if ("rn50" in k) == (grp == "rnvisrn50")]:
+                student, reward, n, c, over, full = RNVIS_CASES[name]
+                hp = dict(BASE_HP, **over)
+                t0 = time.time()
+                arrays = run_reference_ln(ref, student, reward, n, c, hp, only_norm=False, full_vectors=full)
+                meta = dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23, view_seed=1000,
+                            bank_seed=7, n_ctx=4, only_norm=0, prior_strength=-1, **hp)
                 save(name, arrays, meta)
                 print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
                       f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")

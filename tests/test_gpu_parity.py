@@ -1073,7 +1073,7 @@ def test_bn_tuning_with_resnet_reward_matches_oracle(L, dev):
 
 def test_bn_tuning_batch_and_refusals(L, dev):
     """rlcf_tta_batch_ln with a ResNet student runs the samples one by one (the batch statistics couple one sample's views);
-    every-parameter tuning of a ResNet student is refused loudly."""
+    every-parameter tuning of a ResNet student is built since round 4 (tests/test_gpu_round4.py) — its layout call answers."""
     from rlcf_amd.engine import TTAConfig
     N, n_cls = 8, 16
     cfg = TTAConfig(selection_p=0.5, lr=1e-3, tta_steps=1)
@@ -1086,8 +1086,8 @@ def test_bn_tuning_batch_and_refusals(L, dev):
         torch.testing.assert_close(fl[i], ref[i]["final_logits"][0], atol=1e-5, rtol=0)
     g, meta = load_golden("bn_tiny_train")
     torch.testing.assert_close(fl[0].cpu(), g["final_logits"][0], atol=5e-3, rtol=0)
-    with pytest.raises(L.RlcfError, match="VisionTransformer|BatchNorm"):
-        eng.visual_layout()
+    lay = eng.visual_layout()                      # (round 4: the flat vector of a ModifiedResNet student — convolutions, downsample.1, attention pool)
+    assert lay[0][0] == "visual.conv1.weight" and lay[-1][0] == "visual.attnpool.c_proj.bias"
     eng.close()
     # the single-pass f16 performance mode has no tuning paths: refused, not run in reduced precision
     e16, *_ = make_engine(("tiny-rn", "tiny-r"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16)
@@ -1198,8 +1198,7 @@ def test_cls_tta_harness_resnet_student(L, dev, name):
         out = model(views[:1])
         torch.testing.assert_close(out.cpu(), g["final_logits"], atol=2e-3, rtol=0)
         assert out.topk(5).indices[0].tolist() == g["top5"].tolist()
-    with pytest.raises(NotImplementedError, match="BatchNorm"):
-        custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch="tiny-rn", prompt_prefix="a_photo_of_a", only_visual=True, only_norm=False)
+    # (only_norm=False on a ModifiedResNet — the parser defaults — is built since round 4: tests/test_gpu_round4.py)
     runtime.reset_session()
 
 
