@@ -28,6 +28,9 @@ for prec in (0, 2):
     print(f"prec {prec}: vs f64: HIP {((og.double() - g64).norm() / g64.norm()).item():.3e}  reference {float(z64['ref_err']):.3e}   "
           f"final logits vs f64: HIP {(o['final_logits'].cpu().double() - torch.from_numpy(z64['final_logits'])).abs().max().item():.2e} "
           f"reference {(g['final_logits'].double() - torch.from_numpy(z64['final_logits'])).abs().max().item():.2e}")
+    if "logits" in z64.files:
+        l64 = torch.from_numpy(z64["logits"])
+        print(f"prec {prec}: FIRST-PASS logits vs f64: HIP {(o['logits'].cpu().double() - l64).abs().max().item():.2e}  reference {float(z64['ref_logit_err']):.2e}")
     print(f"prec {prec}: total rel {((og - gr).norm() / gr.norm()).item():.3e}  logits {(o['logits'].cpu() - g['logits']).abs().max().item():.2e} "
           f"final {(o['final_logits'].cpu() - g['final_logits']).abs().max().item():.2e} "
           f"stats {(eng.bn_stats().cpu() - g['bn_stats_after']).abs().max().item():.2e}")

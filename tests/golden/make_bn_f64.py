@@ -39,10 +39,14 @@ def main(names):
         assert o["selected_idx"].tolist() == z["selected_idx"].tolist() and o["topk_idx"].reshape(-1).tolist() == z["topk_idx"].reshape(-1).tolist()
         g64, g32 = o["ln_grad"].numpy(), z["ln_grad"].astype(np.float64)
         ref_err = float(np.linalg.norm(g32 - g64) / np.linalg.norm(g64))
+        # (round 4: + the FIRST-PASS logits of all views — forward only, no gradient involved — and the reference's own distance from them)
+        l64 = o["logits"].numpy()
+        ref_logit_err = float(np.abs(z["logits"].astype(np.float64) - l64).max())
         np.savez_compressed(os.path.join(HERE, name + "_f64.npz"), ln_grad=g64, final_logits=o["final_logits"].numpy(),
-                            bn_stats_after=o["bn_stats_after"].numpy(), ref_err=np.float64(ref_err))
-        print(f"{name}: |reference f32 - f64| / |f64| = {ref_err:.3e}   final logits {np.abs(z['final_logits'] - o['final_logits'].numpy()).max():.2e}",
-              flush=True)
+                            bn_stats_after=o["bn_stats_after"].numpy(), ref_err=np.float64(ref_err), logits=l64,
+                            ref_logit_err=np.float64(ref_logit_err))
+        print(f"{name}: |reference f32 - f64| / |f64| = {ref_err:.3e}   first-pass logits {ref_logit_err:.2e}   "
+              f"final logits {np.abs(z['final_logits'] - o['final_logits'].numpy()).max():.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -997,12 +997,16 @@ def test_bn_tuning_matches_reference_fixture(L, dev, name, prec):
     assert c("selected_idx").tolist() == g["selected_idx"].tolist()
     assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
     assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
-    torch.testing.assert_close(c("logits"), g["logits"], atol=2e-3, rtol=0)
+    # first-pass logits: forward only.  Round 4 tightened this from 2e-3 to 3e-4 against the fixture and pinned it to the float64 value:
+    # measured |HIP - f64| 4.7e-5 (train mode) / 1.6e-5 (prior 16) at RN50 in split-f16 mode, the reference's own float32 run 2.7e-5 /
+    # 1.3e-5 (tests/golden/make_bn_f64.py; the old bar was simply loose, no reduction of the train-form BatchNorm costs 1e-3)
+    torch.testing.assert_close(c("logits"), g["logits"], atol=3e-4, rtol=0)
     torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
     # The float32 gradient of the REFERENCE is itself only good to `ref_err` of its norm here (2e-6 on the tiny towers, 1e-4 .. 7e-3 at
     # RN50: tests/golden/make_bn_f64.py has the why), so the HIP gradient is judged against the float64 value of the (reference-pinned)
     # oracle -- no further from it than twice the reference is -- and against the float32 fixture at the width of that noise band.
     z64 = np.load(os.path.join(GOLDEN, name + "_f64.npz"))
+    assert (c("logits").double() - torch.from_numpy(z64["logits"])).abs().max() < max(2e-4, 4 * float(z64["ref_logit_err"]))
     g64, ref_err = torch.from_numpy(z64["ln_grad"]), float(z64["ref_err"])
     gr, og = g["ln_grad"], c("ln_grad")
     assert gr.norm() > 0
@@ -1016,7 +1020,11 @@ def test_bn_tuning_matches_reference_fixture(L, dev, name, prec):
     torch.testing.assert_close(st, gs, atol=2e-4, rtol=2e-3)
     if meta["prior_strength"] >= 0:                       # `_modified_bn_forward` never writes the running statistics
         torch.testing.assert_close(st, eng.bn_stats(pristine=True).cpu(), atol=0, rtol=0)
-    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3, rtol=0)
+    # final logits depend on the gradient (one AdamW step of -lr sign(g) per element): against the float32 fixture at the width of its own
+    # noise band, and against the float64 value no further than 1e-3 / twice the reference's distance (5.4e-4 at RN50 in train mode)
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if ref_err > 1e-3 else 1e-3, rtol=0)
+    f64 = torch.from_numpy(z64["final_logits"])
+    assert (c("final_logits").double() - f64).abs().max() < max(1e-3, 2 * (g["final_logits"].double() - f64).abs().max().item())
     # every sample starts from the checkpoint's parameters AND running statistics; the frozen-student prompt path is untouched
     o2 = eng.tta_sample_ln(views, _cfg_from_meta(meta))
     torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
