@@ -493,12 +493,12 @@ def main():
             # HBM/fabric bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters perturb timing
             # and cannot be read in-process); they are quoted only from a committed profile of this exact pass size
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r2_gemm_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r4_gemm_hbm_traffic.json")
             if a.precision == "f16x3" and os.path.exists(tpath) and a.config == 1 and is_default_wl:
                 rec = json.load(open(tpath)).get("bytes_per_launch_by_images_per_pass", {}).get(str(pass_images))
                 if rec:
-                    traffic, tsrc = rec, (f"profiles/r2_gemm_hbm_traffic.json (rocprofv3 --pmc pass of this GEMM at {pass_images} images per pass; the kernel's "
-                                          "main loop is unchanged since; Infinity-Cache hits are inside the counter: profiles/r3_gemm_experiments.txt)")
+                    traffic, tsrc = rec, (f"profiles/r4_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this GEMM at {pass_images} images per "
+                                          "pass on the round-4 build, tools/pmc_gemm_traffic.sh; Infinity-Cache hits are inside the counter)")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_source": tsrc, "mfma_passes": passes,

@@ -195,7 +195,9 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
     RLCF_ARG_CHECK(g.lda % 4 == 0 && g.ldw % 4 == 0);
     RLCF_ARG_CHECK(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.W & 15) == 0);
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (g.M <= 512 && g.K % 64 == 0) {
+    static int small_mode = -1;              // RLCF_F32_SMALL=1: small-M products on the LDS-tiled 64x64 kernel (A/B measurements)
+    if (small_mode < 0) { const char* e = getenv("RLCF_F32_SMALL"); small_mode = e ? atoi(e) : 0; }
+    if (g.M <= 512 && g.K % 64 == 0 && !(small_mode == 1 && g.M > 64)) {
         const long nb = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
         if (g.K >= 512) gemm_nt_f32_splitk_kernel<8><<<dim3((unsigned)nb), dim3(512), 0, st>>>(g);
         else gemm_nt_f32_splitk_kernel<4><<<dim3((unsigned)nb), dim3(256), 0, st>>>(g);
