@@ -1305,6 +1305,126 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_f16x3_v4_kernel(GemmX3Args g) 
     amax_commit(g.amax_out, am);
 }
 
+extern int g_last_x3_variant;
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Skinny split-f16 GEMM: M <= 256 rows of an f32 activation against a pre-split weight (the one-image path: the sparse text forward /
+// backward works on ~239 rows, 96 such products per test image; they ran on the f32-MFMA split-K kernel at 12-23 TF).
+//   * A stays f32 in memory and is split into (hi, lo) IN the kernel, by the wave that owns the rows — no stand-alone split launch,
+//     no f16 copy of A; its power-of-two scale is 1 (forward activations) or comes from a device scalar max|A| the producing kernel
+//     left behind (amax_in: the scale 2^(9 - floor(log2 max)) is formed here, its inverse folded into alpha);
+//   * W = the interleaved pair rows the big kernels read ([N, 2K] halves, 32 hi | 32 lo per K block);
+//   * grid (N / 32, 2 [, K slices]): a workgroup = 4 waves x one 32x32 output tile each (rows [128 y + 32 w, +32), columns
+//     [32 x, +32)), K walked in steps of 16, three MFMAs per step; fragments go global -> registers (A rows are L2-resident, a W
+//     fragment is 2 x 16 B per lane);
+//   * K slices (K >= 1024): raw partial tiles to ws[slice][M][N], gemm_x3_splitk_reduce_kernel applies alpha / bias / epilogue /
+//     residual in a fixed order; otherwise the epilogue runs here.
+struct SkinnyArgs {
+    const float* A; int lda;
+    const float* amax_in;              // optional: device max|A| -> power-of-two operand scale
+    float* inv_scale_out;              // where 1 / scale goes when K slices hand the epilogue to the reduce kernel (alpha_dev of it)
+    GemmX3Args g;                      // W pairs (Whi, ldw), bias, residual, aux, C, M, N, K, alpha, epilogue, amax_out, ksplit, ws
+};
+__global__ __launch_bounds__(256) void gemm_skinny_x3_kernel(SkinnyArgs s) {
+    const GemmX3Args& g = s.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 128 + wave * 32;
+    if (m0 >= g.M) return;
+    float scale = 1.f, inv = 1.f;
+    if (s.amax_in) {
+        const float mx = s.amax_in[0];
+        int sh = 0;
+        if (mx > 0.f && mx < INFINITY) sh = 9 - (int)floorf(log2f(mx));
+        sh = sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+        scale = ldexpf(1.0f, sh); inv = ldexpf(1.0f, -sh);
+        if (s.inv_scale_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) s.inv_scale_out[0] = inv;
+    }
+    const int nk = g.K / 16;
+    int k_lo = 0, k_hi = nk;
+    if (g.ksplit > 1) { const int per = (nk + g.ksplit - 1) / g.ksplit; k_lo = blockIdx.z * per; k_hi = min(nk, k_lo + per); }
+    const int row = m0 + l32;
+    const bool rok = row < g.M;
+    const float* ap = s.A + (size_t)(rok ? row : g.M - 1) * s.lda + h * 8;
+    const int ncol = min(n0 + l32, g.N - 1);
+    const _Float16* wp = g.Whi + (size_t)ncol * g.ldw + h * 8;           // K block b = 64 halves: [32 hi | 32 lo]; step t covers k = 16 t .. 16 t + 15
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = k_lo; t < k_hi; ++t) {
+        const float4 a0 = *(const float4*)(ap + t * 16), a1 = *(const float4*)(ap + t * 16 + 4);
+        const _Float16* wq = wp + (t >> 1) * 64 + (t & 1) * 16;
+        const h16x8 wh = *(const h16x8*)wq, wl = *(const h16x8*)(wq + 32);
+        const float v[8] = {a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale, a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale};
+        h16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 hh = (_Float16)(rok ? v[e] : 0.f);
+            ah[e] = hh;
+            al[e] = (_Float16)((rok ? v[e] : 0.f) - (float)hh);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+    }
+    const int col = n0 + l32;
+    if (col >= g.N) return;
+    if (g.ksplit > 1) {                                  // raw partial tile; alpha / bias / epilogue in the reduce pass
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = m0 + mfma32_row(r, h);
+            if (rr < g.M) g.ws[((size_t)blockIdx.z * g.M + rr) * g.N + col] = acc[r];
+        }
+        return;
+    }
+    const float al_ = g.alpha * inv;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    float am = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = m0 + mfma32_row(r, h);
+        if (rr >= g.M) continue;
+        float v = al_ * acc[r] + bv;
+        if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
+        else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad_fast(g.aux[(size_t)rr * g.ldaux + col]);
+        if (g.residual) v += g.residual[(size_t)rr * g.ldr + col];
+        if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
+        am = fmaxf(am, fabsf(v));
+        g.C[(size_t)rr * g.ldc + col] = v;
+    }
+    amax_commit(g.amax_out, am);
+}
+// A [M, K] f32 (lda), W pairs [N, 2K] interleaved; C f32 [M, N].  ws / ws_bytes: split-K scratch (K >= 1024); inv_scale_scratch: one
+// device float (needed with amax_in AND K slices).  Returns RLCF_ERR_ARG for shapes it does not serve (the caller falls back).
+bool gemm_skinny_x3_ok(int M, int N, int K, int lda, int ldc) { return M > 0 && M <= 256 && N % 4 == 0 && K % 32 == 0 && lda % 4 == 0 && ldc % 4 == 0; }
+int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const float* bias, const float* residual, int ldr, const float* aux,
+                          int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in,
+                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st) {
+    RLCF_ARG_CHECK(A && Wpairs && C && gemm_skinny_x3_ok(M, N, K, lda, ldc) && ((uintptr_t)A & 15) == 0);
+    RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
+    SkinnyArgs s{};
+    s.A = A; s.lda = lda; s.amax_in = amax_in;
+    GemmX3Args& g = s.g;
+    g.Whi = (const _Float16*)Wpairs; g.Wlo = g.Whi + 32; g.ldw = 2 * K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.amax_out = amax_out; g.kstep = 64;
+    const int tiles = ((N + 31) / 32) * ((M + 127) / 128);
+    int ksplit = 1;
+    if (K >= 1024 && tiles < 192 && ws && N % 4 == 0) {
+        ksplit = std::min(K / 256, std::max(1, 256 / tiles));
+        while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > ws_bytes) --ksplit;
+        if (amax_in && !inv_scale_scratch) ksplit = 1;
+    }
+    g.ksplit = ksplit; g.ws = ws;
+    if (ksplit > 1 && amax_in) { s.inv_scale_out = inv_scale_scratch; g.alpha_dev = inv_scale_scratch; }
+    gemm_skinny_x3_kernel<<<dim3((N + 31) / 32, (M + 127) / 128, ksplit), dim3(256), 0, st>>>(s);
+    RLCF_LAUNCH_CHECK();
+    if (ksplit > 1) {
+        const long groups = (long)M * (N / 4);
+        gemm_x3_splitk_reduce_kernel<<<dim3((unsigned)std::min<long>((groups + 255) / 256, 2048)), dim3(256), 0, st>>>(g);
+        RLCF_LAUNCH_CHECK();
+    }
+    g_last_x3_variant = 4;
+    return RLCF_OK;
+}
+
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 // splitk_ws / splitk_ws_bytes: caller-owned scratch for the split-K form of the small-grid kernel (the engine sizes it once at
 // create); without it those shapes run unsplit.  Nothing is allocated here.

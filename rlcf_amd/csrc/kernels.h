@@ -70,9 +70,15 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       int single = 0 /* plain f16 operands, one MFMA per product (RLCF_PREC_F16): see GemmX3Args */,
                       const float* out_scale_dev = nullptr /* device scalar multiplied into the split output (GemmX3Args) */,
                       unsigned* sk_epoch = nullptr /* host launch counter of this workspace: enables the stream-K tail of the 256x256 kernel */);
+// M <= 256 rows of an f32 activation against a pre-split (interleaved-pair) weight, A split in the kernel (gemm_f16x3.hip)
+bool gemm_skinny_x3_ok(int M, int N, int K, int lda, int ldc);
+int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const float* bias, const float* residual, int ldr, const float* aux,
+                          int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in,
+                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st);
 #define X3_SPLITK_WS_BYTES ((size_t)4 * 128 * 128 * 128 * sizeof(float))   // 4 slices x (<= 128 tiles of 128x128): the largest split-K launch
 // engine GEMM scratch: split-K partial tiles (above) or the stream-K slabs (256 workgroups x 256 KB), + 8 KB of stream-K flag words at its end
 #define X3_WS_BYTES ((size_t)256 * 262144 + 8192)
+#define X3_SK_FLAG_BYTES_RESERVED 8192      // (the flag words at the end of the workspace: never handed out as split-K space)
 int launch_dyn_scale(const float* x, int64_t n, float* scratch3, hipStream_t st);     // scratch3 = {max|x|, s, 1/s}, s = 2^k
 // implicit 3x3 convolution (stride 1, pad 1) on operand pairs of the NHWC activation; zpage: >= 1 KB of zeros (gemm_f16x3.hip)
 bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin);

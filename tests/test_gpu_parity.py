@@ -639,7 +639,7 @@ def test_errors_are_loud(L, dev):
     o = four.tta_sample(views, TTAConfig(selection_p=0.5))
     assert len(o["reward_image_features"]) == 4 and torch.isfinite(o["final_logits"]).all()
     four.close()
-    # a ModifiedResNet student: the norm-layer path tunes its BatchNorms (row a-R); every-parameter tuning of it is refused
+    # a ModifiedResNet student: the norm-layer path tunes its BatchNorms (row a-R); every-parameter tuning of it runs too (round 4)
     rn = synth.GEOMETRIES["tiny-rn32"]
     e2 = Engine(rn, tr, 8, 16)
     e2.load_state_dict(L.STUDENT, synth.make_state_dict(rn, 11)); e2.load_state_dict(L.REWARD, synth.make_state_dict(tr, 23))
@@ -648,8 +648,8 @@ def test_errors_are_loud(L, dev):
     e2.set_class_bank(tok2, 4, CR.ctx_from_tokens(synth.make_state_dict(rn, 11), synth.ctx_token_ids_default(rn, 4)), L.TEXT_SHARED)
     o = e2.tta_sample_ln(views, TTAConfig(selection_p=0.5))
     assert torch.isfinite(o["final_logits"]).all() and torch.isfinite(o["ln_grad"]).all() and o["ln_grad"].abs().max() > 0
-    with pytest.raises(L.RlcfError, match="BatchNorm"):
-        e2.tta_sample_visual(views, TTAConfig(selection_p=0.5))
+    ov = e2.tta_sample_visual(views, TTAConfig(selection_p=0.5, lr=1e-4))
+    assert torch.isfinite(ov["final_logits"]).all() and torch.isfinite(ov["vis_grad"]).all() and ov["vis_grad"].abs().max() > 0
     e2.close()
 
 
