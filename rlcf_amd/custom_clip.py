@@ -211,7 +211,7 @@ def get_coop(clip_arch, test_set, device, n_ctx, ctx_init, learned_cls=False, cl
 
 class CLIPCLS_TTA(nn.Module):
     """TPT/clip/custom_clip.py:364-497 — CLIP classification with test-time adaptation of the image encoder.
-    `only_visual=True` only.  only_norm=True (BASELINE configs[2], the `--tune_norm 1` setting): the tunable set is every
+    only_norm=True (BASELINE configs[2], the `--tune_norm 1` setting): the tunable set is every
     visual LayerNorm weight/bias and `parameters()` returns ONE flat tensor holding them in named_parameters order
     ([ln_pre.w, ln_pre.b, (ln_1.w, ln_1.b, ln_2.w, ln_2.b) x layers, ln_post.w, ln_post.b]) instead of 4L+4 tensors.
     only_norm=False (the reference default, what scripts/rlcf-tune.sh runs): every visual parameter is tuned; `parameters()`
@@ -220,8 +220,11 @@ class CLIPCLS_TTA(nn.Module):
     def __init__(self, device, classnames, arch="ViT-L/14", prompt_prefix=None, only_visual=True, momentum_update=False,
                  update_freq=256, update_w=1.0, momentum=0.9999, only_norm=False):
         super().__init__()
-        if not only_visual:
-            raise NotImplementedError("text-encoder tuning is not built: only_visual=True only (SURVEY.md §8 a14)")
+        # only_visual=False changes NOTHING the reference computes: parameters() returns clip_model.visual's tensors whatever only_visual is
+        # (custom_clip.py:477-485), forward() reads the class features cached under no_grad (:405-409, :423-432), freeze_parameters only
+        # skips a requires_grad_(False) on tensors no optimizer ever sees (:411-421), and reset_classnames_and_state re-reads the SAME
+        # checkpoint for the class features (:442-447).  Verified against the reference itself: its runs with only_visual=False are
+        # bit-identical to the committed only_visual=True fixtures (tests/golden/make_golden.py --only onlyvisual).  Accepted, same path.
         self.clip_model, _, _ = clip_store.load(arch, device=device)
         # a ModifiedResNet student (RN50 .. RN50x64): the norm layers are BatchNorms; `ln` then holds their weights / biases and the
         # forward runs them on batch statistics, as the reference's does even after model.eval() (custom_clip.py:481-497)

@@ -615,6 +615,29 @@ def main():
                 save(name, arrays, meta)
                 print(f"  {name}: {time.time() - t0:.1f}s idx={arrays['selected_idx']} top5={arrays['top5']} "
                       f"|g|={np.linalg.norm(arrays['vis_grad_l2']):.3e} |d|={np.linalg.norm(arrays['vis_delta_l2']):.3e}")
+        elif grp == "onlyvisual":
+            # CHECK, no fixture: CLIPCLS_TTA(only_visual=False) is computationally the only_visual=True model (parameters() ignores the flag,
+            # custom_clip.py:477-485; class features are cached under no_grad) — the reference's own runs must reproduce the committed
+            # fixtures bit for bit.  rlcf_amd.custom_clip.CLIPCLS_TTA therefore serves only_visual=False on the same path.
+            orig_cls = ref.custom.CLIPCLS_TTA
+
+            class _TextToo(orig_cls):
+                def __init__(self, *a, **k):
+                    k["only_visual"] = False
+                    super().__init__(*a, **k)
+            ref.custom.CLIPCLS_TTA = _TextToo
+            try:
+                for name, kw, keys in (("ln_tiny_s1", dict(), ("logits", "ln_grad", "ln_after", "final_logits")),
+                                       ("vis_tiny_s1", dict(only_norm=False), ("logits", "vis_grad_l2", "vis_delta_l2", "final_logits"))):
+                    z = np.load(os.path.join(HERE, name + ".npz"))
+                    meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+                    hp = dict(BASE_HP, lr=meta["lr"], tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], sample_k=meta["sample_k"])
+                    arrays = run_reference_ln(ref, meta["student"], meta["reward"], meta["n_views"], meta["n_cls"], hp, **kw)
+                    for k in keys:
+                        assert np.array_equal(arrays[k], z[k]), (name, k)
+                    print(f"  only_visual=False == {name} (bit-identical: {', '.join(keys)})")
+            finally:
+                ref.custom.CLIPCLS_TTA = orig_cls
         elif grp in ("rnvis", "rnvisrn50"):
             for name in [k for k in RNVIS_CASES if ("rn50" in k) == (grp == "rnvisrn50")]:
                 student, reward, n, c, over, full = RNVIS_CASES[name]

@@ -195,3 +195,41 @@ def test_resnet_every_parameter_tuning_through_the_mirror(L, dev):
             out = model(views[:1])
         torch.testing.assert_close(out.cpu(), g["final_logits"], atol=1e-3, rtol=0)
     runtime.reset_session()
+
+
+# ------------------------------------------------------------------------------ BASELINE configs[4] at the class count bench.py runs
+def test_config4_full_geometry_1000_classes_properties(L, dev):
+    """BASELINE configs[4] exactly as `bench.py --config 4` runs it — RN50x64 student @448^2, ViT-L/14 reward behind the bicubic resample,
+    N = 32 views, 1000 classes (the reference-generated fixture of this geometry stops at 200 classes: the reference's autograd tape over
+    1000 does not fit the build container) — through size-independent properties:
+    (1) a permutation of views 1..31 permutes the selection and leaves the adapted prompt, the final logits and the top-5 unchanged;
+    (2) the K rewards of every selected view sum to zero and so does the loss gradient of its logits;
+    (3) lr = 0 is plain inference: final logits = the first-pass logits of view 0.
+    (The 200-class reference fixture itself: tests/test_gpu_round2.py::test_config5_full_geometry_matches_reference_fixture.)"""
+    from rlcf_amd.engine import Engine, TTAConfig
+    sg, rg = synth.GEOMETRIES["RN50x64"], synth.GEOMETRIES["ViT-L/14"]
+    ssd, rsd = synth.make_state_dict(sg, 11, device=dev), synth.make_state_dict(rg, 23, device=dev)
+    N, C = 32, 1000
+    tokens = synth.make_token_bank(sg, C, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, 4), device=dev)].clone()
+    eng = Engine(sg, rg, N, C, L.PREC_F16X3)
+    eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
+    eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+    cfg = TTAConfig(selection_p=0.1, sample_k=3, lr=7e-3, weight_decay=5e-4)
+    views = synth.make_views(1000, N, 448, device=dev)
+    o = eng.tta_sample(views, cfg)
+    gperm = torch.Generator().manual_seed(5)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(N - 1, generator=gperm)]).to(dev)
+    o2 = eng.tta_sample(views[perm], cfg)
+    sel, sel2 = o["selected_idx"].long(), o2["selected_idx"].long()
+    assert perm[sel2].tolist() == sel.tolist()                                                            # (1)
+    torch.testing.assert_close(o2["ctx_after"], o["ctx_after"], atol=1e-6, rtol=0)
+    torch.testing.assert_close(o2["final_logits"], o["final_logits"], atol=2e-4, rtol=0)
+    assert o2["top5"].tolist() == o["top5"].tolist()
+    n_sel = sel.numel()
+    assert n_sel == 3
+    torch.testing.assert_close(o["rewards"].view(n_sel, 3).sum(1), torch.zeros(n_sel, device=dev), atol=2e-5, rtol=0)      # (2)
+    torch.testing.assert_close(o["dlogits"].sum(1), torch.zeros(n_sel, device=dev), atol=1e-6, rtol=0)
+    o0 = eng.tta_sample(views, TTAConfig(selection_p=0.1, sample_k=3, lr=0.0, weight_decay=0.0), want_intermediates=True)  # (3)
+    torch.testing.assert_close(o0["final_logits"][0], o0["logits"][0], atol=2e-4, rtol=0)
+    eng.close()
