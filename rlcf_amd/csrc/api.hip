@@ -3,6 +3,7 @@
 #include "engine.h"
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 static thread_local char g_err[1024] = "";
@@ -156,11 +157,15 @@ int rlcf_attention_bwd_flash_prec(const float* qkv, const float* out, const floa
     std::vector<rlcf_seq> hs(n_seq);
     RLCF_HIP_CHECK(hipMemcpyAsync(hs.data(), seqs, (size_t)n_seq * sizeof(rlcf_seq), hipMemcpyDeviceToHost, st));
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
-    for (const rlcf_seq& q : hs) rows = std::max(rows, q.q_start + q.q_len);
+    bool plain = !causal;                       // no shared prefix anywhere, no mask: the two-kernel form (attention_bwd_x3b.hip), as the engine picks it
+    for (const rlcf_seq& q : hs) { rows = std::max(rows, q.q_start + q.q_len); plain = plain && q.pre_len == 0 && q.q_len <= max_q_len; }
+    static int bwd_old = -1;
+    if (bwd_old < 0) { const char* ev = getenv("RLCF_ATTN_BWD_OLD"); bwd_old = ev ? atoi(ev) : 0; }
     float* amax = nullptr;
     RLCF_HIP_CHECK(hipMallocAsync((void**)&amax, sizeof(float), st));
     int rc = launch_absmax(dout, (int64_t)rows * width, amax, st);
-    if (rc == RLCF_OK) rc = launch_attention_bwd_x3(qkv, out, lse, dout, amax, seqs, n_seq, max_q_len, width, causal, dqkv, st);
+    if (rc == RLCF_OK && plain && !bwd_old) rc = launch_attention_bwd_x3_split(qkv, out, lse, dout, amax, seqs, n_seq, max_q_len, width, dqkv, st);
+    else if (rc == RLCF_OK) rc = launch_attention_bwd_x3(qkv, out, lse, dout, amax, seqs, n_seq, max_q_len, width, causal, dqkv, st);
     (void)hipFreeAsync(amax, st);
     return rc;
 }

@@ -760,7 +760,9 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         static int bwd_atomic = -1;
         if (bwd_atomic < 0) { const char* ev = getenv("RLCF_ATTN_BWD_ATOMIC"); bwd_atomic = ev ? atoi(ev) : 0; }
         float* park = nullptr;
-        if (max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
+        static int bwd_old0 = -1;
+        if (bwd_old0 < 0) { const char* ev = getenv("RLCF_ATTN_BWD_OLD"); bwd_old0 = ev ? atoi(ev) : 0; }
+        if (bwd_old0 && max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
             const size_t need = (size_t)n_seq * ((max_q_len + 31) / 32) * max_q_len * 2 * W * sizeof(float);
             if (need <= ((size_t)16 << 30)) {
                 // no room for the parking space (another engine holds the memory): clear the error and meet by atomicAdd instead
@@ -768,6 +770,15 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
                 else (void)hipGetLastError();
             }
         }
+        // ... and since round 4 the two-kernel form (attention_bwd_x3b.hip): dQ per 64 queries, dK / dV per 64 keys with the accumulators
+        // kept in registers across all query blocks — single writers, nothing parked.  RLCF_ATTN_BWD_OLD=1 switches back (A/B)
+        static int bwd_old = -1;
+        if (bwd_old < 0) { const char* ev = getenv("RLCF_ATTN_BWD_OLD"); bwd_old = ev ? atoi(ev) : 0; }
+        const bool split_form = max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic && !bwd_old;
+        if (split_form) {
+            TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));
+            TRY(launch_attention_bwd_x3_split(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len, W, dQKV, st));
+        } else {
         if (!park) RLCF_HIP_CHECK(hipMemsetAsync(dQKV, 0, (size_t)T * 3 * W * sizeof(float), st));
         if (max_keys > 96 && prec_x3(e) && !bwd_f32) {
             TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));       // range of dO for the f16 pairs
@@ -781,6 +792,7 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
             float* pws = nullptr;
             if (need * sizeof(float) <= ((size_t)512 << 20)) { TRY(e->attn_pre_ws.ensure(need * sizeof(float))); pws = e->attn_pre_ws.as<float>(); }
             TRY(launch_attention_bwd(s.qkv, dA, seqs, n_seq, max_keys, W, causal, dQKV, st, pws, pws ? need : 0, max_keys));
+        }
         }
         prof_end(pslot, st, 12);
         e->last_flops += 10.0 * attn_pairs * W;

@@ -133,6 +133,9 @@ void attention_pair_debug(int oneshot, int var);      // measurement switches of
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                               int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
 // split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)
+// two-kernel form for sequences without a shared prefix / causal mask (attention_bwd_x3b.hip): dqkv written completely, single writers
+int launch_attention_bwd_x3_split(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,
+                                  int n_seq, int max_q_len, int width, float* dqkv, hipStream_t st);
 int launch_attention_bwd_x3(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,
                             int n_seq, int max_q_len, int width, int causal, float* dqkv, hipStream_t st, float* park = nullptr);
 int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_seq* seqs, int n_seq, int max_q_len, int max_keys,

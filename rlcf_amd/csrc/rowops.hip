@@ -321,6 +321,86 @@ __global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* _
         if (c < width) { part[((size_t)w * 2) * width + c] = ag[j]; part[((size_t)w * 2 + 1) * width + c] = ab[j]; }
     }
 }
+// The same for widths that are multiples of 256 (every CLIP tower: 512 / 768 / 1024 / 1280): 16-byte accesses (lane l owns columns
+// 256 g + 4 l .. + 3 of group g) and the next row's x / dy fetched while this row's four wave reductions run — the scalar-access form
+// above streams at 1.7 TB/s (r3_config2_kernel_stats.txt), bound by the dependent reduction chain of one row at a time.
+template <int NG>
+__global__ __launch_bounds__(256) void layernorm_bwd_parts4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ dy, const float* __restrict__ dres,
+                                                                   float* __restrict__ dx, float* __restrict__ part, int rows, int group_rows,
+                                                                   int gamma_stride, int rpw, int wpg, int n_groups) {
+    constexpr int width = NG * 256;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int g = w / wpg, k = w - g * wpg;
+    if (g >= n_groups) return;
+    const int gend = min(rows, (g + 1) * group_rows), row0 = g * group_rows + k * rpw, row1 = min(gend, row0 + rpw);
+    float4 gm[NG], ag[NG], ab[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        gm[j] = *(const float4*)(gamma + (size_t)g * gamma_stride + j * 256 + lane * 4);
+        ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
+    }
+    float4 v[NG], d[NG], vn[NG], dn[NG];
+    if (row0 < row1) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            vn[j] = *(const float4*)(x + (size_t)row0 * width + j * 256 + lane * 4);
+            dn[j] = *(const float4*)(dy + (size_t)row0 * width + j * 256 + lane * 4);
+        }
+    }
+    for (int row = row0; row < row1; ++row) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { v[j] = vn[j]; d[j] = dn[j]; }
+        if (row + 1 < row1) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                vn[j] = *(const float4*)(x + (size_t)(row + 1) * width + j * 256 + lane * 4);
+                dn[j] = *(const float4*)(dy + (size_t)(row + 1) * width + j * 256 + lane * 4);
+            }
+        }
+        float4 rz[NG];
+        if (dres) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) rz[j] = *(const float4*)(dres + (size_t)row * width + j * 256 + lane * 4);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        const float mu = wave_sum(s) / width;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        const float rstd = rsqrtf(wave_sum(q) / width + LN_EPS);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            v[j].x *= rstd; v[j].y *= rstd; v[j].z *= rstd; v[j].w *= rstd;                 // x hat
+            ag[j].x += d[j].x * v[j].x; ag[j].y += d[j].y * v[j].y; ag[j].z += d[j].z * v[j].z; ag[j].w += d[j].w * v[j].w;
+            ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+            d[j].x *= gm[j].x; d[j].y *= gm[j].y; d[j].z *= gm[j].z; d[j].w *= gm[j].w;     // dy gamma
+            s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
+            s2 += (d[j].x * v[j].x + d[j].y * v[j].y) + (d[j].z * v[j].z + d[j].w * v[j].w);
+        }
+        s1 = wave_sum(s1) / width;
+        s2 = wave_sum(s2) / width;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            float4 o = make_float4(rstd * (d[j].x - s1 - v[j].x * s2), rstd * (d[j].y - s1 - v[j].y * s2), rstd * (d[j].z - s1 - v[j].z * s2),
+                                   rstd * (d[j].w - s1 - v[j].w * s2));
+            if (dres) { o.x += rz[j].x; o.y += rz[j].y; o.z += rz[j].z; o.w += rz[j].w; }
+            *(float4*)(dx + (size_t)row * width + j * 256 + lane * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        *(float4*)(part + ((size_t)w * 2) * width + j * 256 + lane * 4) = ag[j];
+        *(float4*)(part + ((size_t)w * 2 + 1) * width + j * 256 + lane * 4) = ab[j];
+    }
+}
 // out_a[g * stride + c] += sum_k part[g * wpg + k][0][c], out_b likewise from [1]: block = 64 columns x 16 sub-sums (k = q, q + 16, ...)
 __global__ __launch_bounds__(1024) void colparts_reduce_kernel(const float* __restrict__ part, int wpg, int width, float* __restrict__ out_a,
                                                               float* __restrict__ out_b, int stride) {
@@ -358,8 +438,16 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
         parts_plan(rows, group_rows > 0 ? group_rows : rows, rpw, wpg, ng);
         const size_t waves = (size_t)wpg * ng;
         if (waves * 2 * width <= part_ws_floats) {
-            layernorm_bwd_parts_kernel<<<dim3((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, st>>>(
-                x, gamma, dy, dres, dx, part_ws, rows, width, group_rows > 0 ? group_rows : rows, gamma_stride, rpw, wpg, ng);
+            const dim3 grid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+            const int gr = group_rows > 0 ? group_rows : rows;
+            const bool al16 = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)(dres ? dres : x)) & 15) == 0 && gamma_stride % 4 == 0;
+#define LNB4(NG_) layernorm_bwd_parts4_kernel<NG_><<<grid, dim3(256), 0, st>>>(x, gamma, dy, dres, dx, part_ws, rows, gr, gamma_stride, rpw, wpg, ng)
+            if (al16 && width == 512) LNB4(2);
+            else if (al16 && width == 768) LNB4(3);
+            else if (al16 && width == 1024) LNB4(4);
+            else if (al16 && width == 1280) LNB4(5);
+            else layernorm_bwd_parts_kernel<<<grid, dim3(256), 0, st>>>(x, gamma, dy, dres, dx, part_ws, rows, width, gr, gamma_stride, rpw, wpg, ng);
+#undef LNB4
             RLCF_LAUNCH_CHECK();
             colparts_reduce_kernel<<<dim3((width + 63) / 64, ng), dim3(1024), 0, st>>>(part_ws, wpg, width, dgamma, dbeta, group_stride);
             RLCF_LAUNCH_CHECK();

@@ -233,3 +233,34 @@ def test_config4_full_geometry_1000_classes_properties(L, dev):
     o0 = eng.tta_sample(views, TTAConfig(selection_p=0.1, sample_k=3, lr=0.0, weight_decay=0.0), want_intermediates=True)  # (3)
     torch.testing.assert_close(o0["final_logits"][0], o0["logits"][0], atol=2e-4, rtol=0)
     eng.close()
+
+
+# ------------------------------------------------------------------------------ attention backward, two-kernel form (attention_bwd_x3b.hip)
+@pytest.mark.parametrize("tokens,n_seq,W", [(257, 3, 128), (197, 2, 192), (50, 4, 64), (65, 2, 64), (577, 1, 64)])
+def test_attention_backward_two_kernel_form(L, dev, tokens, n_seq, W):
+    """dQ per 64 queries, dK / dV per 64 keys with the accumulators kept in registers over all query blocks (no parking, no atomics): the
+    plain (no prefix, no mask) sequences of the image towers.  Against the float64 gradient, bit-reproducible run to run, and equal to
+    the one-kernel form (RLCF_ATTN_BWD_OLD) within rounding — incl. ragged tails (257 = 4 x 64 + 1, 65, 577 tokens)."""
+    from test_gpu_parity import _attn_ref
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    T = tokens * n_seq
+    seqs = [(i * tokens, tokens, 0, 0) for i in range(n_seq)]
+    qkv = synth.normal(5, f"attb.{tokens}.{W}", (T, 3 * W), 1.5)
+    do = synth.normal(5, f"attb.do.{tokens}.{W}", (T, W)) * 1e-4            # the magnitude the tuning paths see
+    sq = (L.Seq * len(seqs))(*[L.Seq(*s) for s in seqs])
+    sbuf = torch.frombuffer(bytearray(bytes(sq)), dtype=torch.int32).to(dev)
+    qd, dod = qkv.to(dev), do.to(dev)
+    out, lse = torch.zeros(T, W, device=dev), torch.zeros(T, W // 64, device=dev)
+    L.check(L.lib().rlcf_attention_fwd(qd.data_ptr(), sbuf.data_ptr(), n_seq, tokens, W, 0, out.data_ptr(), lse.data_ptr(), L.PREC_F32, st()))
+    q64 = qkv.double().requires_grad_(True)
+    (_attn_ref(q64, seqs, W, 0) * do.double()).sum().backward()
+    runs = []
+    for _ in range(2):
+        dq = torch.full((T, 3 * W), float("nan"), device=dev)             # (every element must be WRITTEN: there is no zero fill any more)
+        L.check(L.lib().rlcf_attention_bwd_flash_prec(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), dod.data_ptr(), sbuf.data_ptr(), n_seq,
+                                                      tokens, W, 0, dq.data_ptr(), L.PREC_F16X3, st()))
+        runs.append(dq.cpu())
+    assert torch.isfinite(runs[0]).all() and torch.equal(runs[0], runs[1])
+    err, gref = (runs[0].double() - q64.grad).abs(), q64.grad.abs()
+    assert float((err > 3e-9 + 2e-4 * gref).double().mean()) < 1e-3
+    assert float(err.max()) <= 2e-4 * float(gref.max())
