@@ -220,7 +220,7 @@ def profile_entries(lib):
 
 
 KIND_NAMES = {0: "gemm_nt_f32 (f32 MFMA)", 1: "gemm_nt_f16x3 128x128 (DMA ring / split-K / register-staged)", 2: "gemm_nt_f16x3_v2 256x128",
-              3: "gemm_nt_f16x3_v3i 256x256", 4: "gemm_skinny_x3 (M <= 256: A split in the kernel)", 10: "attention forward (QK^T, softmax, PV)", 11: "LayerNorm forward -> operand pairs (HBM-bound)",
+              3: "gemm_nt_f16x3_v3i 256x256", 4: "gemm_skinny_x3 (M <= 256: A split in the kernel)", 5: "gemm_nt_f16x3_v3i 192x256", 10: "attention forward (QK^T, softmax, PV)", 11: "LayerNorm forward -> operand pairs (HBM-bound)",
               12: "attention backward (dQ, dK, dV)", 13: "LayerNorm backward (HBM-bound)"}
 HBM_KINDS = (11, 13)
 CONFIGS = {

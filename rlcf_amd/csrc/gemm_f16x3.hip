@@ -71,7 +71,7 @@ __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_
 // One call = the 64x64 slab of one wave: a0..a3 = accumulator tiles (i, j) = (0,0) (0,1) (1,0) (1,1); row0 / col0 = its origin.
 // LEAN (the experimental 4-wave kernel, which has no register to spare): the forward towers' form only -- host alpha, no ReLU, no
 // max|C|, no output scale
-template <int EPI, bool RES, bool F32OUT, bool PAIR, bool LEAN = false>
+template <int EPI, bool RES, bool F32OUT, bool PAIR, bool LEAN = false, int NIT = 16>
 __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3,
                                                  float* park, int row0, int col0, int lane, float& am) {
     constexpr int ELD = 68;
@@ -91,15 +91,16 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     float4 rr[16];
     if constexpr (RES) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) rr[it] = *(const float4*)(g.residual + (size_t)min(rbase + it * 4, g.M - 1) * g.ldr + colc);
+        for (int it = 0; it < NIT; ++it) rr[it] = *(const float4*)(g.residual + (size_t)min(rbase + it * 4, g.M - 1) * g.ldr + colc);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int pr = mfma32_row(r, h) * ELD + l32;
-        park[pr] = a0[r]; park[pr + 32] = a1[r]; park[pr + 32 * ELD] = a2[r]; park[pr + 32 * ELD + 32] = a3[r];
+        park[pr] = a0[r]; park[pr + 32] = a1[r];
+        if constexpr (NIT == 16) { park[pr + 32 * ELD] = a2[r]; park[pr + 32 * ELD + 32] = a3[r]; }        // (NIT = 8: a 32-row half slab, a0 / a1 only)
     }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const float4 a4 = *(const float4*)(park + (it * 4 + rsub) * ELD + c4);
         float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
         if constexpr (EPI == RLCF_EPI_QUICKGELU) {
@@ -129,7 +130,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     if constexpr (RES) {
         asm volatile("" ::: "memory");                     // no store moves above this point, no load below it
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int row = rbase + it * 4;
             if (colok && row < g.M) {
                 if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
@@ -169,6 +170,15 @@ __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
         else if ((kind) == 3) x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true>(__VA_ARGS__);   /* c_fc + QuickGELU -> pair */ \
         else if ((kind) == 5) x3_epilogue_slab<RLCF_EPI_NONE, true, true, true>(__VA_ARGS__);    /* conv3 + identity -> f32 and pairs */ \
         else x3_epilogue_slab<RLCF_EPI_NONE, false, false, true>(__VA_ARGS__);                   /* in_proj -> Q / K / V pairs */    \
+    }
+
+#define X3_EPILOGUE_HALFSLAB(kind, ...)                                                                                  \
+    {                                                                                                                    \
+        if ((kind) == 1) x3_epilogue_slab<RLCF_EPI_NONE, false, true, false, false, 8>(__VA_ARGS__);                     \
+        else if ((kind) == 2) x3_epilogue_slab<RLCF_EPI_NONE, true, true, false, false, 8>(__VA_ARGS__);                 \
+        else if ((kind) == 3) x3_epilogue_slab<RLCF_EPI_QUICKGELU, false, false, true, false, 8>(__VA_ARGS__);           \
+        else if ((kind) == 5) x3_epilogue_slab<RLCF_EPI_NONE, true, true, true, false, 8>(__VA_ARGS__);                  \
+        else x3_epilogue_slab<RLCF_EPI_NONE, false, false, true, false, 8>(__VA_ARGS__);                                 \
     }
 
 #define X3_BM 128
@@ -794,11 +804,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 //     LDS pass), every wave drains vmcnt, one lane publishes the launch's epoch in the range's flag word (relaxed, agent scope); the
 //     owner polls that word relaxed, takes ONE agent-scope acquire, adds the slabs in increasing-k order with sc1 loads (fixed order:
 //     bit-reproducible) and runs the epilogue (cdna_hip_programming.md, Guideline 16 / R1).
-template <bool SINGLE, bool CONV = false, bool SK = false>
+// MT = 32-row accumulator tiles per wave group: 4 = the 256-row tile; 3 = a 192-row tile for launches whose 256-row tiles fill
+// little more than half of one round of workgroups (one image's token matrix against a W x W / W x 4W weight: 150 tiles on 256 CUs
+// -> 198 tiles of 3/4 the work each)
+template <bool SINGLE, bool CONV = false, bool SK = false, int MT = 4>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
+    static_assert(MT == 4 || (MT == 3 && !SK && !CONV), "192-row tiles: plain products only");
+    constexpr int BM = MT * 64;
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
-    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
+    const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + BM - 1) / BM;
     int bid, k0 = 0, k1 = g.K / X3_BK;
     int sk_chunk = 0, sk_idx = 0, sk_q = 1, sk_units = 1, sk_tile_c = 0;
     if constexpr (!SK) {
@@ -852,14 +867,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     // order inside a group: M-fastest (neighbours share a W tile), or — problems 3-4 tiles wide, e.g. c_proj 768 x 3072 — N-fastest
     // (neighbours share the A panel: 414 -> 421 TF; on the 9 / 12-tile-wide products it costs 1-2 %).  tile_group >= 100 forces it
     const bool nfast = g.tile_group >= 100 || (g.tile_group == 0 && tiles_n <= 4);
-    const int m0 = (nfast ? first_m + in_g / tiles_n : first_m + in_g % gsize) * V3_BM;
+    const int m0 = (nfast ? first_m + in_g / tiles_n : first_m + in_g % gsize) * BM;
     const int n0 = (nfast ? in_g % tiles_n : in_g / gsize) * V3_BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
 
-    f32x16 acc[4][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -875,8 +890,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane, r = q >> 3, c = ((q & 7) ^ ((r >> 1) & 7)) * 8;
-        const int row = min(m0 + r, g.M - 1);
-        sa[j] = (size_t)row * g.lda + c + (SK ? (size_t)k0 * g.kstep : (size_t)0);        // (stream-K pieces start at K step k0)
+        // (MT = 3: the A tile is 192 rows = 3 pieces per wave, piece j of wave w = rows 8 (3 w + j) ..)
+        const int qa = (wave * MT + j) * 64 + lane, ra = MT == 4 ? r : qa >> 3, ca = MT == 4 ? c : ((qa & 7) ^ ((ra >> 1) & 7)) * 8;
+        const int row = min(m0 + ra, g.M - 1);
+        sa[j] = (size_t)row * g.lda + ca + (SK ? (size_t)k0 * g.kstep : (size_t)0);        // (stream-K pieces start at K step k0)
         sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c + (SK ? (size_t)k0 * g.kstep : (size_t)0);
         if constexpr (CONV) {
             const int ox = row % g.conv_W, oy = (row / g.conv_W) % g.conv_H;
@@ -901,10 +918,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #define V3_PIECE(idx, kk, sb_)                                                                                                         \
     {                                                                                                                                  \
         if ((idx) < 4) {                                                                                                               \
-            if constexpr (CONV) {                                                                                                      \
+            if (MT < 4 && ((idx) & 3) >= MT) { /* a 192-row A tile has 3 pieces per wave */ }                                        \
+            else if constexpr (CONV) {                                                                                                      \
                 const _Float16* pa_ = ((vm[(idx) & 3] >> ctap_) & 1u) ? g.Ahi + (long)sa[(idx) & 3] + coff_ : zlane;                     \
-                __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);            \
-            } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);           \
+                __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * MT + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);            \
+            } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * MT + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);           \
         } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_W);              \
     }
 #undef V3_LDA
@@ -912,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #define V3_LDA(ks, AH, AL)                                                                                               \
     {                                                                                                                    \
         const int ch_ = (((ks) * 2 + h) ^ swz) * 16, cl_ = ((4 + (ks) * 2 + h) ^ swz) * 16;                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                 \
             AH[i] = *(const h16x8*)(sb + aoff + i * 4096 + ch_);                                                         \
             AL[i] = *(const h16x8*)(sb + aoff + i * 4096 + cl_);                                                         \
         }                                                                                                                \
@@ -935,12 +953,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, 0, s0)
     }
     const int swz = (l32 >> 1) & 7;
-    const int aoff = (wm * 128 + l32) * 128, boff = (wn * 64 + l32) * 128;
+    const int aoff = (wm * (MT * 32) + l32) * 128, boff = (wn * 64 + l32) * 128;
     // Ping-pong: the two waves of a SIMD belong to the row groups wm = 0 / 1, which run the same K loop half an iteration apart.
     // Two barriers per K tile (g = 2kt: tile kt has landed; g = 2kt+1); in every interval one group is in its pure-MFMA half
     // (second k-substep, fragments already in registers) while the other waits for its first fragments, so the matrix pipe always
     // has work.  Both groups issue their DMA pieces of tile kt+1 in the interval [2kt, 2kt+1].
-    h16x8 ah0[4], al0[4], bh0[2], bl0[2], ah1[4], al1[4], bh1[2], bl1[2];
+    h16x8 ah0[MT], al0[MT], bh0[2], bl0[2], ah1[MT], al1[MT], bh1[2], bl1[2];
     if (wm == 0) {
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -954,16 +972,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
             V2_FENCE
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 V2_MMA3_PAIR(i, ah0, al0, bh0, bl0) V2_FENCE
                 if (pf) { V3_PIECE(i * 2, kn, sn) V3_PIECE(i * 2 + 1, kn, sn) }
+                if (MT == 3 && i == 2 && pf) { V3_PIECE(6, kn, sn) V3_PIECE(7, kn, sn) }
                 if (i == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
                 V2_FENCE
             }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE }
+            for (int i = 0; i < MT; ++i) { V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE }
         }
         __builtin_amdgcn_s_barrier();                              // pairs with the other group's last half step
     } else {
@@ -978,9 +997,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             const char* sb = smem + (kt & 1) * V3_STAGE;
             if (kt > 0) {                                          // second k-substep of tile kt-1 + the DMA of tile kt+1
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MT; ++i) {
                     V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE
                     if (pf) { V3_PIECE(i * 2, kn, sn) V3_PIECE(i * 2 + 1, kn, sn) }
+                    if (MT == 3 && i == 2 && pf) { V3_PIECE(6, kn, sn) V3_PIECE(7, kn, sn) }
                     V2_FENCE
                 }
             } else if (pf) {
@@ -992,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             V3_LDA(0, ah0, al0) V3_LDB(0, bh0, bl0)
             V2_FENCE
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 V2_MMA3_PAIR(i, ah0, al0, bh0, bl0) V2_FENCE
                 if (i == 0) { V3_LDA(1, ah1, al1) V3_LDB(1, bh1, bl1) }
                 V2_FENCE
@@ -1001,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE }
+        for (int i = 0; i < MT; ++i) { V2_MMA3_PAIR(i, ah1, al1, bh1, bl1) V2_FENCE }
     }
     if constexpr (SK) {
         const int nk_full = g.K / X3_BK;
@@ -1053,9 +1073,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         float* parkf = (float*)smem + wave * (64 * 68);
         __syncthreads();
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < MT / 2; ++half)
             X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
-                             m0 + wm * 128 + half * 64, n0 + wn * 64, lane, am)
+                             m0 + wm * (MT * 32) + half * 64, n0 + wn * 64, lane, am)
+        if constexpr (MT == 3)           // the third 32-row tile: half a slab
+            X3_EPILOGUE_HALFSLAB(ek, g, acc[2][0], acc[2][1], acc[2][0], acc[2][1], parkf, m0 + wm * 96 + 64, n0 + wn * 64, lane, am)
         amax_commit(g.amax_out, am);
         return;
     }
@@ -1074,13 +1096,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    if (half * 2 + i < MT) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i < MT ? half * 2 + i : 0][j][r];
         __syncthreads();
         if (col < g.N) {
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int rl = it * 4 + rsub, row = m0 + wm * 128 + half * 64 + rl;
-                if (row >= g.M) continue;
+                const int rl = it * 4 + rsub, row = m0 + wm * (MT * 32) + half * 64 + rl;
+                if (row >= g.M || half * 64 + rl >= MT * 32) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
                 float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
@@ -1496,6 +1519,24 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         }
     }
     const double cost2 = 0.575 * (double)((blocks2 + ncu - 1) / ncu);
+    // 192 x 256 tiles (MT = 3): a round costs ~0.78 of a 256 x 256 round (3/4 of the products and of the epilogue, the same W tile
+    // traffic); taken where the rounds it saves outweigh that — one image's token matrix against a W x W / W x 4W weight: 150 tiles =
+    // one 59 %-full round -> 198 tiles = one 77 %-full round of 3/4 the length.  RLCF_X3_MT3=0 switches it off, =2 forces it
+    static int mt3 = -1;
+    if (mt3 < 0) { const char* e = getenv("RLCF_X3_MT3"); mt3 = e ? atoi(e) : 1; }
+    const int blocks3h = ((M + 191) / 192) * ((N + V3_BN - 1) / V3_BN);
+    const double cost3h = 0.78 * (double)((blocks3h + ncu - 1) / ncu);
+    const bool pick3h = v2_ok && !single && g.kstep == 64 && sk_blocks == 0 && force == 0 && blocks3h >= 128 && !(C && Chi && residual) &&      // (conv3's f32 + pairs + identity epilogue: slower there)
+                       
+                        (mt3 == 2 || (mt3 == 1 && cost3h < 0.97 * std::min(cost3, blocks2 >= 256 ? cost2 : cost3)));
+    if (pick3h) {
+        const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
+        X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3>), sh3);
+        gemm_nt_f16x3_v3i_kernel<false, false, false, 3><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
+        g_last_x3_variant = 5;
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
+    }
     const bool pick3 = (blocks2 >= 256 || sk_blocks > 0) && cost3 <= cost2;
     // RLCF_X3_V4=1: the 4-wave form of the 256x256 tile where it applies (interleaved pairs, compile-time epilogues)
     static int v4 = -1;

@@ -264,3 +264,51 @@ def test_attention_backward_two_kernel_form(L, dev, tokens, n_seq, W):
     err, gref = (runs[0].double() - q64.grad).abs(), q64.grad.abs()
     assert float((err > 3e-9 + 2e-4 * gref).double().mean()) < 1e-3
     assert float(err.max()) <= 2e-4 * float(gref.max())
+
+
+# ------------------------------------------------------------------------------ 192 x 256 tile form of the split-f16 GEMM (gemm_f16x3.hip, MT = 3)
+@pytest.mark.parametrize("N,K,epi,res,pair", [(768, 768, 0, True, False), (768, 3072, 0, True, False), (768, 768, 1, False, True), (768, 768, 0, False, False)])
+def test_gemm_192_row_tiles_bit_identical_to_the_other_tile_shapes(L, dev, N, K, epi, res, pair):
+    """One image's token matrix (M = 12608 = 64 views x 197 tokens) against a W x W / W x 4W weight: 150 tiles of 256 x 256 fill 59 %
+    of one round of workgroups, so the launcher takes 192 x 256 tiles there.  Every output element is the same sum of the same
+    products in the same K order with the same epilogue arithmetic whatever the tile shape: the product computed in ONE call
+    (192-row tiles) must be BIT-IDENTICAL to the same product computed as two calls of 6304 rows (too few tiles for that form: they
+    run on the 256 x 128 / 128 x 128 kernels), and within 3e-4 of the float64 product."""
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    lib = L.lib()
+    M = 12608
+    a = synth.normal(9, f"mt3.a.{K}", (M, K)).to(dev)
+    w = (synth.normal(9, f"mt3.w.{N}.{K}", (N, K)) * K ** -0.5).to(dev)
+    b = (synth.normal(9, f"mt3.b.{N}", (N,)) * 0.1).to(dev)
+    x = synth.normal(9, f"mt3.x.{N}", (M, N)).to(dev) if res else None
+
+    def pairs(t):
+        R, Kk = t.shape
+        h, l = torch.empty(R, Kk, dtype=torch.float16, device=dev), torch.empty(R, Kk, dtype=torch.float16, device=dev)
+        L.check(lib.rlcf_split_f16x2(t.data_ptr(), h.data_ptr(), l.data_ptr(), R * Kk, st()))
+        return torch.stack([h.view(R, Kk // 32, 32), l.view(R, Kk // 32, 32)], dim=2).reshape(R, 2 * Kk).contiguous()
+    a2, w2 = pairs(a), pairs(w)
+
+    def run(r0, r1):
+        rows = r1 - r0
+        c = None if pair else torch.empty(rows, N, device=dev)
+        ch = torch.empty(rows, N, dtype=torch.float16, device=dev) if pair else None
+        cl = torch.empty_like(ch) if pair else None
+        ap = a2.data_ptr() + r0 * 2 * K * 2
+        L.check(lib.rlcf_gemm_f16x3(ap, ap + 64, 2 * K, w2.data_ptr(), w2.data_ptr() + 64, 2 * K, b.data_ptr(),
+                                    x[r0:r1].data_ptr() if res else None, N, None, 0, c.data_ptr() if c is not None else None, N,
+                                    ch.data_ptr() if pair else None, cl.data_ptr() if pair else None, N, rows, N, K, 1.0, epi, st()))
+        torch.cuda.synchronize()
+        return (ch, cl) if pair else (c,)
+    whole = run(0, M)
+    parts = [run(0, M // 2), run(M // 2, M)]
+    for i, t in enumerate(whole):
+        assert torch.equal(t, torch.cat([parts[0][i], parts[1][i]]))
+    got = (whole[0].float() + whole[1].float()) if pair else whole[0]
+    rows = torch.arange(0, M, 53, device=dev)
+    ref = a[rows].double() @ w.double().t() + b.double()
+    if epi == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if res:
+        ref = ref + x[rows].double()
+    assert float((got[rows].double() - ref).abs().max()) < 3e-4
