@@ -205,6 +205,21 @@ int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* 
                            const float* std3, const rlcf_augmix_op* ops, const float* w, const float* m, float* views, void* scratch,
                            size_t scratch_bytes, rlcf_stream stream);
 
+/* The `hard_aug` pre-augmentation (get_preaugment(hard_aug=True), TPT/data/datautils.py:77-87; --hard_aug 1 of TPT/tune_cls_tpt.py:115 /
+ * tune_cls_kd.py:122): between the resized crop (RandomResizedCrop(224, scale=(0.2, 1))) and the flip, view 1+v goes through
+ * RandomApply([ColorJitter(0.4, 0.4, 0.2, 0.1)], 0.5), RandomGrayscale(0.2) and RandomApply([GaussianBlur(3, (0.1, 2))], 0.1).
+ * hard[v] carries the draws of view 1+v: order = ColorJitter.get_params' randperm(4) (0 brightness, 1 contrast, 2 saturation, 3 hue;
+ * order[0] = -1: ColorJitter skipped), b / c / s = the three factors, hue = uint8(hue_factor * 255) (0..255, added to H modulo 256),
+ * gray = RandomGrayscale's coin, blur / k = GaussianBlur applied / its float32 3x3 kernel, row-major (torchvision
+ * _get_gaussian_kernel2d).  Bit-exact with Pillow's ImageEnhance / HSV / L conversions; the blur is nine float32 fused multiply-adds
+ * in row-major order, rounded half to even (what torch's CPU conv2d computes).  ops / w / m: the AugMix plan as in
+ * rlcf_make_views_augmix, or all NULL (no AugMix).  hard, ops, w, m are HOST arrays. */
+typedef struct { int order[4]; float b, c, s; int hue; int gray; int blur; float k[9]; } rlcf_hard_aug;
+size_t rlcf_make_views_hard_scratch_bytes(int H, int n_crops, int res);
+int rlcf_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
+                         const float* std3, const rlcf_hard_aug* hard, const rlcf_augmix_op* ops, const float* w, const float* m,
+                         float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream);
+
 /* ------------------------------------------------------------------ engine ------
  * Owns device copies of the weights (plus derived layouts) and all workspace. */
 rlcf_engine* rlcf_engine_create(const rlcf_clip_cfg* student, const rlcf_clip_cfg* reward /*NULL: none*/,

@@ -327,3 +327,165 @@ def augmix_view(x_orig_u8: np.ndarray, plan) -> np.ndarray:
             x = apply_augmix_op(x, op, ip, coeffs)
         mix = mix + w[i] * to_tensor_normalize(x)
     return m * xp + (np.float32(1) - m) * mix
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# hard_aug: the BYOL-style pre-augmentation (TPT/data/datautils.py:77-87, get_preaugment(hard_aug=True), reached through
+# --hard_aug 1 of tune_cls_tpt.py / tune_cls_kd.py): RandomResizedCrop(224, scale=(0.2, 1)) -> RandomApply([ColorJitter(0.4, 0.4,
+# 0.2, 0.1)], p=0.5) -> RandomGrayscale(p=0.2) -> RandomApply([GaussianBlur(3, sigma=(0.1, 2))], p=0.1) -> RandomHorizontalFlip.
+# On PIL images torchvision 0.14.1 (absent from /root/reference; restated from its published source) maps these to Pillow:
+#   adjust_brightness / contrast / saturation = ImageEnhance.Brightness / Contrast / Color = Image.blend(degenerate, image, factor)
+#     (libImaging/Blend.c: float arithmetic, truncation, clipping only when the factor leaves [0, 1]); degenerate = black / the solid
+#     grey int(mean(L) + 0.5) / the image's own L; L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16 (libImaging/Convert.c rgb2l);
+#   adjust_hue = convert("HSV"), h += uint8(hue_factor * 255) (wraps), convert back (Convert.c rgb2hsv_row / hsv2rgb);
+#   rgb_to_grayscale(3 channels) = L stacked three times;
+#   gaussian_blur = torchvision's TENSOR kernel on pil_to_tensor(img): float32 3x3 kernel (outer product of the normalised 1-d
+#     pdf), reflect padding, conv2d, torch.round (half to even) back to uint8.
+# Pinned by tests/golden/hardaug_*.npz (generated with Pillow + torch, tests/golden/make_views_golden.py) and, for the colour
+# conversions, exhaustively against the installed Pillow (tests/test_views.py).  Blur: nine fused multiply-adds in row-major tap order
+# (= torch's CPU conv2d here); another summation order can move a value that lies within ~1e-5 of x.5 by one level (~3 pixels per
+# million), which is what a reference run on another conv2d backend would also see.
+def rgb_to_l(u8: np.ndarray) -> np.ndarray:
+    x = u8.astype(np.int64)
+    return ((x[..., 0] * 19595 + x[..., 1] * 38470 + x[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def blend_u8(in1: np.ndarray, in2: np.ndarray, alpha: float) -> np.ndarray:
+    """Image.blend(im1, im2, alpha) (libImaging/Blend.c): out = (UINT8)(in1 + alpha * (in2 - in1)) in C float arithmetic."""
+    a = np.float32(alpha)
+    if a == 0.0:
+        return in1.copy()
+    if a == 1.0:
+        return in2.copy()
+    i1, i2 = in1.astype(np.int32), in2.astype(np.int32)
+    t = i1.astype(np.float32) + a * (i2 - i1).astype(np.float32)              # float32 product, float32 sum (no contraction)
+    if 0.0 <= a <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)                             # (truncation; the value lies in [0, 255])
+    return np.where(t <= 0.0, 0, np.where(t >= 255.0, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def adjust_brightness_u8(u8: np.ndarray, factor: float) -> np.ndarray:
+    return blend_u8(np.zeros_like(u8), u8, factor)
+
+
+def adjust_contrast_u8(u8: np.ndarray, factor: float) -> np.ndarray:
+    lum = rgb_to_l(u8)
+    mean = int(float(lum.astype(np.int64).sum()) / lum.size + 0.5)            # int(ImageStat.Stat(L).mean[0] + 0.5)
+    return blend_u8(np.full_like(u8, mean), u8, factor)
+
+
+def adjust_saturation_u8(u8: np.ndarray, factor: float) -> np.ndarray:
+    return blend_u8(np.repeat(rgb_to_l(u8)[..., None], 3, axis=-1), u8, factor)
+
+
+def rgb_to_hsv_u8(u8: np.ndarray) -> np.ndarray:
+    """Convert.c rgb2hsv_row: float (C float) intermediates, h through double (fmod(h / 6.0 + 1.0, 1.0)), truncation to 8 bits."""
+    r, g, b = (u8[..., i].astype(np.int32) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    safe = np.where(cr == 0, np.float32(1), cr)
+    s = cr / np.where(maxc == 0, 1, maxc).astype(np.float32)
+    rc, gc, bc = ((maxc - c).astype(np.float32) / safe for c in (r, g, b))
+    rd, gd, bd = rc.astype(np.float64), gc.astype(np.float64), bc.astype(np.float64)       # (`2.0 + rc - bc`: the literal makes it double)
+    h = np.where(r == maxc, (bc - gc).astype(np.float64), np.where(g == maxc, 2.0 + rd - bd, 4.0 + gd - rd)).astype(np.float32)
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    grey = minc == maxc
+    return np.stack([np.where(grey, 0, uh), np.where(grey, 0, us), maxc], axis=-1).astype(np.uint8)
+
+
+def hsv_to_rgb_u8(hsv: np.ndarray) -> np.ndarray:
+    """Convert.c hsv2rgb: i = floor(h * 6 / 255), f = the remainder (C float), p / q / t = round(v * (1 - ...)) (half away from zero)."""
+    h, s, v = (hsv[..., i].astype(np.float32) for i in range(3))
+    h6 = h.astype(np.float64) * 6.0 / 255.0
+    i = np.floor(h6).astype(np.int32)
+    f = (h6 - i).astype(np.float32)
+    fs = (s.astype(np.float64) / 255.0).astype(np.float32)
+    vd = v.astype(np.float64)
+
+    def rnd(x):                                                                # C round(): half away from zero (x >= 0 here)
+        return np.clip(np.floor(x + 0.5).astype(np.int32), 0, 255)
+    p = rnd(vd * (1.0 - fs.astype(np.float64)))
+    q = rnd(vd * (1.0 - (fs * f).astype(np.float64)))
+    t = rnd(vd * (1.0 - (fs * (np.float32(1.0) - f)).astype(np.float64)))
+    vi = hsv[..., 2].astype(np.int32)
+    k = i % 6
+    r = np.choose(k, [vi, q, p, p, t, vi])
+    g = np.choose(k, [t, vi, vi, q, p, p])
+    b = np.choose(k, [p, p, t, vi, vi, q])
+    grey = hsv[..., 1] == 0
+    return np.stack([np.where(grey, vi, r), np.where(grey, vi, g), np.where(grey, vi, b)], axis=-1).astype(np.uint8)
+
+
+def hue_shift_u8(hue_factor: float) -> int:
+    """np.uint8(hue_factor * 255) of torchvision's F_pil.adjust_hue: truncation toward zero, then modulo 256."""
+    return int(hue_factor * 255) % 256
+
+
+def adjust_hue_u8(u8: np.ndarray, hue_factor: float) -> np.ndarray:
+    hsv = rgb_to_hsv_u8(u8)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int32) + hue_shift_u8(hue_factor)).astype(np.uint8)
+    return hsv_to_rgb_u8(hsv)
+
+
+def to_grayscale3_u8(u8: np.ndarray) -> np.ndarray:
+    return np.repeat(rgb_to_l(u8)[..., None], 3, axis=-1)
+
+
+def gaussian_kernel3(sigma: float) -> np.ndarray:
+    """torchvision _get_gaussian_kernel2d for kernel_size 3: float32 [3, 3], with torch's own float32 ops (numpy's exp differs from
+    torch's in the last bit for some sigma)."""
+    import torch
+    x = torch.linspace(-1.0, 1.0, steps=3)
+    pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+    k1 = pdf / pdf.sum()
+    return torch.mm(k1[:, None], k1[None, :]).numpy()
+
+
+def gaussian_blur3_u8(u8: np.ndarray, kernel: np.ndarray) -> np.ndarray:
+    """reflect padding; acc = fma(k[i][j], x, acc) over the nine taps in row-major order (what torch's CPU conv2d computes, bit for
+    bit, in this image's build: checked on the float outputs); round half to even, back to uint8.  The fused multiply-add is
+    emulated in float64: the product of two float32 values is exact there, and so is its sum with acc whenever they overlap."""
+    x = np.pad(u8.astype(np.float32), ((1, 1), (1, 1), (0, 0)), mode="reflect").astype(np.float64)
+    H, W = u8.shape[:2]
+    acc = np.zeros(u8.shape, np.float32)
+    for i in range(3):
+        for j in range(3):
+            acc = (acc.astype(np.float64) + np.float64(kernel[i, j]) * x[i: i + H, j: j + W]).astype(np.float32)
+    return np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+
+
+JITTER_FNS = ("brightness", "contrast", "saturation", "hue")
+
+
+def hard_aug_u8(u8: np.ndarray, plan) -> np.ndarray:
+    """The colour / blur part of the hard recipe on the 8-bit resized crop.  plan = (order, b, c, s, h, gray, kernel): order = the
+    randperm(4) of ColorJitter.get_params or None (RandomApply skipped it), gray = RandomGrayscale's coin, kernel = the float32
+    [3, 3] blur kernel or None.  The flip that follows commutes with all of it."""
+    order, b, c, s, h, gray, kernel = plan
+    x = u8
+    if order is not None:
+        for fn in order:
+            x = (adjust_brightness_u8(x, b) if fn == 0 else adjust_contrast_u8(x, c) if fn == 1 else
+                 adjust_saturation_u8(x, s) if fn == 2 else adjust_hue_u8(x, h))
+    if gray:
+        x = to_grayscale3_u8(x)
+    if kernel is not None:
+        x = gaussian_blur3_u8(x, kernel)
+    return x
+
+
+def draw_hard_plan(rng):
+    """The draws between the crop box and the flip coin (torchvision 0.14.1 transforms.py: RandomApply.forward, ColorJitter.get_params,
+    RandomGrayscale.forward, GaussianBlur.get_params), `rng` standing in for torch's global generator: rng.rand() -> float in [0, 1),
+    rng.randperm(n) -> list, rng.uniform(a, b) -> float."""
+    order = b = c = s = h = None
+    if not (0.5 < rng.rand()):
+        order = list(rng.randperm(4))
+        b, c, s, h = rng.uniform(0.6, 1.4), rng.uniform(0.6, 1.4), rng.uniform(0.8, 1.2), rng.uniform(-0.1, 0.1)
+    gray = rng.rand() < 0.2
+    kernel = None
+    if not (0.1 < rng.rand()):
+        kernel = gaussian_kernel3(rng.uniform(0.1, 2.0))
+    return order, b, c, s, h, gray, kernel

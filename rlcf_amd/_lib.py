@@ -31,6 +31,11 @@ class AugmixOp(C.Structure):
     _fields_ = [("op", C.c_int), ("ip", C.c_int), ("c", C.c_double * 6)]
 
 
+class HardAug(C.Structure):    # rlcf_hard_aug: the draws of the hard_aug recipe for one view (include/rlcf_hip.h)
+    _fields_ = [("order", C.c_int * 4), ("b", C.c_float), ("c", C.c_float), ("s", C.c_float), ("hue", C.c_int), ("gray", C.c_int),
+                ("blur", C.c_int), ("k", C.c_float * 9)]
+
+
 class Crop(C.Structure):       # rlcf_crop: RandomResizedCrop box + RandomHorizontalFlip
     _fields_ = [(n, C.c_int) for n in ("top", "left", "h", "w", "flip")]
 
@@ -91,6 +96,8 @@ SIGNATURES = {
     "rlcf_make_views": (I, [P, I, I, P, I, I, P, P, P, P, C.c_size_t, P]),
     "rlcf_make_views_augmix_scratch_bytes": (C.c_size_t, [I, I, I]),
     "rlcf_make_views_augmix": (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, C.c_size_t, P]),
+    "rlcf_make_views_hard_scratch_bytes": (C.c_size_t, [I, I, I]),
+    "rlcf_make_views_hard": (I, [P, I, I, P, I, I, P, P, P, P, P, P, P, P, C.c_size_t, P]),
     "rlcf_tta_batch_ln": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, P]),
     "rlcf_engine_momentum_update": (I, [P, P, D, D, I, P]),
     "rlcf_engine_reset_visual_state": (I, [P, P]),

@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 7; }   // 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 8; }   // 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -219,6 +219,12 @@ int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* 
                            const float* std3, const rlcf_augmix_op* ops, const float* w, const float* m, float* views, void* scratch,
                            size_t scratch_bytes, rlcf_stream stream) {
     return launch_make_views_augmix(image, H, W, crops, n_crops, res, mean3, std3, ops, w, m, views, scratch, scratch_bytes, (hipStream_t)stream);
+}
+size_t rlcf_make_views_hard_scratch_bytes(int H, int n_crops, int res) { return views_hard_scratch_bytes(H, 1 + n_crops, res); }
+int rlcf_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
+                         const float* std3, const rlcf_hard_aug* hard, const rlcf_augmix_op* ops, const float* w, const float* m,
+                         float* views, void* scratch, size_t scratch_bytes, rlcf_stream stream) {
+    return launch_make_views_hard(image, H, W, crops, n_crops, res, mean3, std3, hard, ops, w, m, views, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ engine

@@ -154,5 +154,9 @@ size_t views_augmix_scratch_bytes(int H, int n_views, int res);
 int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
                              const float* std3, const rlcf_augmix_op* ops_host, const float* w_host, const float* m_host, float* views,
                              void* scratch, size_t scratch_bytes, hipStream_t st);
+size_t views_hard_scratch_bytes(int H, int n_views, int res);
+int launch_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
+                           const float* std3, const rlcf_hard_aug* hard_host, const rlcf_augmix_op* ops_host, const float* w_host,
+                           const float* m_host, float* views, void* scratch, size_t scratch_bytes, hipStream_t st);
 int launch_momentum_update(float* mom, const float* cur, const float* clip, float* init, int64_t n, double momentum, double update_w, int apply,
                            hipStream_t st);

@@ -314,12 +314,10 @@ size_t views_augmix_scratch_bytes(int H, int n_views, int res) {
     return n;
 }
 
-int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
-                             const float* std3, const rlcf_augmix_op* ops_host, const float* w_host, const float* m_host, float* views,
-                             void* scratch, size_t scratch_bytes, hipStream_t st) {
-    RLCF_ARG_CHECK(n_crops > 0 && ops_host && w_host && m_host && scratch && res > 0);
-    const int n_views = 1 + n_crops, chains = n_crops * 3;
-    RLCF_ARG_CHECK(scratch_bytes >= views_augmix_scratch_bytes(H, n_views, res));
+// the AugMix rounds + the mix on 8-bit views already in `xo` ([n_views] images, view 0 unused); p = scratch after the views
+static int augmix_stage(const uint8_t* xo, int n_crops, int res, const float* mean3, const float* std3, const rlcf_augmix_op* ops_host,
+                        const float* w_host, const float* m_host, float* views, char* p, hipStream_t st) {
+    const int chains = n_crops * 3;
     for (int i = 0; i < chains * 3; ++i) {
         const rlcf_augmix_op& o = ops_host[i];
         if (o.op < AUG_NONE || o.op > AUG_TRANSLATE_Y || (o.op == AUG_POSTERIZE && (o.ip < 0 || o.ip > 8))) {
@@ -328,15 +326,11 @@ int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop
         }
     }
     const size_t img = (size_t)res * res * 3;
-    char* p = (char*)scratch + ((views_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255);
-    uint8_t* xo = (uint8_t*)p; p += ((size_t)n_views * img + 255) & ~(size_t)255;
     uint8_t* b0 = (uint8_t*)p; p += ((size_t)chains * img + 255) & ~(size_t)255;
     uint8_t* b1 = (uint8_t*)p; p += ((size_t)chains * img + 255) & ~(size_t)255;
     uint8_t* luts = (uint8_t*)p; p += ((size_t)chains * 768 + 255) & ~(size_t)255;
     rlcf_augmix_op* ops = (rlcf_augmix_op*)p; p += ((size_t)chains * 3 * sizeof(rlcf_augmix_op) + 255) & ~(size_t)255;
     float* wm = (float*)p;
-    int rc = launch_make_views(image, H, W, crops_host, n_crops, res, mean3, std3, views, scratch, views_scratch_bytes(H, n_views, res), st, xo);
-    if (rc != RLCF_OK) return rc;
     RLCF_HIP_CHECK(hipMemcpyAsync(ops, ops_host, (size_t)chains * 3 * sizeof(rlcf_augmix_op), hipMemcpyHostToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(wm, w_host, (size_t)n_crops * 3 * sizeof(float), hipMemcpyHostToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(wm + n_crops * 3, m_host, (size_t)n_crops * sizeof(float), hipMemcpyHostToDevice, st));
@@ -350,6 +344,202 @@ int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop
     augmix_mix_kernel<<<dim3((res * res + 255) / 256, n_crops), dim3(256), 0, st>>>(xo, b0, wm, wm + n_crops * 3, res, mean3[0], mean3[1], mean3[2],
                                                                                    std3[0], std3[1], std3[2], views);
     RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
+                             const float* std3, const rlcf_augmix_op* ops_host, const float* w_host, const float* m_host, float* views,
+                             void* scratch, size_t scratch_bytes, hipStream_t st) {
+    RLCF_ARG_CHECK(n_crops > 0 && ops_host && w_host && m_host && scratch && res > 0);
+    const int n_views = 1 + n_crops;
+    RLCF_ARG_CHECK(scratch_bytes >= views_augmix_scratch_bytes(H, n_views, res));
+    const size_t img = (size_t)res * res * 3;
+    char* p = (char*)scratch + ((views_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255);
+    uint8_t* xo = (uint8_t*)p; p += ((size_t)n_views * img + 255) & ~(size_t)255;
+    int rc = launch_make_views(image, H, W, crops_host, n_crops, res, mean3, std3, views, scratch, views_scratch_bytes(H, n_views, res), st, xo);
+    if (rc != RLCF_OK) return rc;
+    rc = augmix_stage(xo, n_crops, res, mean3, std3, ops_host, w_host, m_host, views, p, st);
+    if (rc != RLCF_OK) return rc;
     RLCF_HIP_CHECK(hipStreamSynchronize(st));                       // the plan was read from caller-owned host memory
+    return RLCF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// hard_aug (TPT/data/datautils.py:77-87 get_preaugment(hard_aug=True); --hard_aug 1 of tune_cls_tpt.py:115 / tune_cls_kd.py:122): between
+// the resized crop and the flip the recipe applies, each with its own coin, ColorJitter(0.4, 0.4, 0.2, 0.1), RandomGrayscale and
+// GaussianBlur(3).  On PIL images torchvision routes the first two to Pillow and the blur to its tensor kernel; reproduced here on the
+// 8-bit views bit for bit (the flip, already applied by the resampling kernel, commutes with all of it):
+//   brightness / contrast / saturation = Image.blend(degenerate, image, factor), libImaging/Blend.c: (UINT8)(in1 + alpha * (in2 - in1))
+//     in C float arithmetic, clipped when alpha leaves [0, 1]; degenerate = black / the solid grey int(mean(L) + 0.5) / the pixel's L,
+//     L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16;
+//   hue = RGB -> HSV (Convert.c rgb2hsv_row) -> h += shift (mod 256) -> RGB (hsv2rgb), float / double mix as in the C source;
+//   grayscale = L in all three bands;  blur = nine fused multiply-adds of the float32 3x3 kernel in row-major order over the
+//     reflect-padded view, round half to even (torchvision F_t.gaussian_blur on the uint8 tensor).
+// One workgroup per view: the contrast step needs the mean luminance of the WHOLE view as it is when ColorJitter reaches that step,
+// so the workgroup first sums L over the view with the preceding steps applied, then rewrites the view in place.
+__device__ __forceinline__ int hard_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__device__ __forceinline__ int hard_blend(int in1, int in2, float alpha) {
+#pragma clang fp contract(off)
+    const float t = (float)in1 + alpha * (float)(in2 - in1);
+    if (alpha >= 0.f && alpha <= 1.0f) return (int)t;
+    return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+}
+__device__ void hard_hue(int& r, int& g, int& b, int shift) {
+#pragma clang fp contract(off)
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    int uh = 0, us = 0;
+    const int uv = maxc;
+    if (minc != maxc) {
+        const float cr = (float)(maxc - minc);
+        const float s = cr / (float)maxc;
+        const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+        float h;
+        if (r == maxc) h = bc - gc;
+        else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+        else h = (float)(4.0 + (double)gc - (double)rc);
+        h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+        uh = min(max((int)((double)h * 255.0), 0), 255);
+        us = min(max((int)((double)s * 255.0), 0), 255);
+    }
+    uh = (uh + shift) & 255;
+    if (us == 0) { r = g = b = uv; return; }
+    const double h6 = (double)(float)uh * 6.0 / 255.0;
+    const int i = (int)floor(h6);
+    const float f = (float)(h6 - (double)i);
+    const float fs = (float)((double)(float)us / 255.0);
+    const double vd = (double)uv;
+    const int p = min(max((int)floor(vd * (1.0 - (double)fs) + 0.5), 0), 255);
+    const int q = min(max((int)floor(vd * (1.0 - (double)(fs * f)) + 0.5), 0), 255);
+    const int t = min(max((int)floor(vd * (1.0 - (double)(fs * (1.0f - f))) + 0.5), 0), 255);
+    switch (i % 6) {
+        case 0: r = uv; g = t; b = p; break;
+        case 1: r = q; g = uv; b = p; break;
+        case 2: r = p; g = uv; b = t; break;
+        case 3: r = p; g = q; b = uv; break;
+        case 4: r = t; g = p; b = uv; break;
+        default: r = uv; g = p; b = q; break;
+    }
+}
+__device__ __forceinline__ void hard_step(int fn, const rlcf_hard_aug& pl, int mean, int& r, int& g, int& b) {
+    if (fn == 0) { r = hard_blend(0, r, pl.b); g = hard_blend(0, g, pl.b); b = hard_blend(0, b, pl.b); }
+    else if (fn == 1) { r = hard_blend(mean, r, pl.c); g = hard_blend(mean, g, pl.c); b = hard_blend(mean, b, pl.c); }
+    else if (fn == 2) { const int l = hard_l(r, g, b); r = hard_blend(l, r, pl.s); g = hard_blend(l, g, pl.s); b = hard_blend(l, b, pl.s); }
+    else hard_hue(r, g, b, pl.hue);
+}
+__global__ __launch_bounds__(1024) void hard_pixel_kernel(uint8_t* __restrict__ xo, const rlcf_hard_aug* __restrict__ plans, int res) {
+    const int v = blockIdx.x, npix = res * res;
+    const rlcf_hard_aug pl = plans[v];
+    uint8_t* x = xo + (size_t)(1 + v) * npix * 3;
+    const bool jitter = pl.order[0] >= 0;
+    if (!jitter && !pl.gray) return;
+    __shared__ unsigned long long part[16];
+    __shared__ int mean_s;
+    int mean = 0;
+    if (jitter) {
+        int pc = 0;
+        while (pc < 4 && pl.order[pc] != 1) ++pc;                         // the steps before the contrast step
+        unsigned long long sum = 0;
+        for (int p = threadIdx.x; p < npix; p += 1024) {
+            int r = x[p * 3], g = x[p * 3 + 1], b = x[p * 3 + 2];
+            for (int k = 0; k < pc; ++k) hard_step(pl.order[k], pl, 0, r, g, b);
+            sum += (unsigned)hard_l(r, g, b);
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 16; ++i) tot += part[i];
+            mean_s = (int)((double)tot / (double)npix + 0.5);             // int(ImageStat.Stat(L).mean[0] + 0.5)
+        }
+        __syncthreads();
+        mean = mean_s;
+    }
+    for (int p = threadIdx.x; p < npix; p += 1024) {
+        int r = x[p * 3], g = x[p * 3 + 1], b = x[p * 3 + 2];
+        if (jitter)
+            for (int k = 0; k < 4; ++k) hard_step(pl.order[k], pl, mean, r, g, b);
+        if (pl.gray) { const int l = hard_l(r, g, b); r = g = b = l; }
+        x[p * 3] = (uint8_t)r; x[p * 3 + 1] = (uint8_t)g; x[p * 3 + 2] = (uint8_t)b;
+    }
+}
+// xh[1 + v] = blur(xo[1 + v]) (or a copy); with `views`: also the normalised float view (no AugMix stage follows)
+__global__ __launch_bounds__(256) void hard_blur_kernel(const uint8_t* __restrict__ xo, const rlcf_hard_aug* __restrict__ plans, int res,
+                                                        uint8_t* __restrict__ xh, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                        float* __restrict__ views) {
+    const int v = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= res * res) return;
+    const size_t plane = (size_t)res * res;
+    const uint8_t* x = xo + (size_t)(1 + v) * plane * 3;
+    int out[3];
+    if (plans[v].blur) {
+        const int y = p / res, xx = p - y * res;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int yy = y + i - 1;
+            yy = yy < 0 ? -yy : (yy >= res ? 2 * res - 2 - yy : yy);     // reflect (no edge repeat)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int xj = xx + j - 1;
+                xj = xj < 0 ? -xj : (xj >= res ? 2 * res - 2 - xj : xj);
+                const float k = plans[v].k[i * 3 + j];
+                const uint8_t* s = x + ((size_t)yy * res + xj) * 3;
+                acc[0] = __fmaf_rn(k, (float)s[0], acc[0]); acc[1] = __fmaf_rn(k, (float)s[1], acc[1]); acc[2] = __fmaf_rn(k, (float)s[2], acc[2]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = min(max((int)rintf(acc[c]), 0), 255);
+    } else { out[0] = x[(size_t)p * 3]; out[1] = x[(size_t)p * 3 + 1]; out[2] = x[(size_t)p * 3 + 2]; }
+    uint8_t* o = xh + ((size_t)(1 + v) * plane + p) * 3;
+    o[0] = (uint8_t)out[0]; o[1] = (uint8_t)out[1]; o[2] = (uint8_t)out[2];
+    if (views) {
+        float* f = views + (size_t)(1 + v) * 3 * plane + p;
+        f[0] = ((float)out[0] / 255.0f - m0) / d0; f[plane] = ((float)out[1] / 255.0f - m1) / d1; f[2 * plane] = ((float)out[2] / 255.0f - m2) / d2;
+    }
+}
+
+size_t views_hard_scratch_bytes(int H, int n_views, int res) {
+    const size_t img = (size_t)res * res * 3;
+    return ((views_augmix_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255) + (((size_t)n_views * img + 255) & ~(size_t)255) +
+           (((size_t)(n_views - 1) * sizeof(rlcf_hard_aug) + 255) & ~(size_t)255);
+}
+
+int launch_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* crops_host, int n_crops, int res, const float* mean3,
+                           const float* std3, const rlcf_hard_aug* hard_host, const rlcf_augmix_op* ops_host, const float* w_host,
+                           const float* m_host, float* views, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    RLCF_ARG_CHECK(n_crops > 0 && hard_host && scratch && res > 1 && (!ops_host || (w_host && m_host)));
+    const int n_views = 1 + n_crops;
+    RLCF_ARG_CHECK(scratch_bytes >= views_hard_scratch_bytes(H, n_views, res));
+    for (int i = 0; i < n_crops; ++i) {
+        const rlcf_hard_aug& h = hard_host[i];
+        bool ok = h.hue >= 0 && h.hue <= 255;
+        if (h.order[0] >= 0) {
+            int seen = 0;
+            for (int k = 0; k < 4; ++k) if (h.order[k] >= 0 && h.order[k] < 4) seen |= 1 << h.order[k];
+            ok = ok && seen == 15;
+        }
+        if (!ok) { rlcf_set_error("make_views_hard: plan %d is not a ColorJitter draw (order must be a permutation of 0..3 or start with -1; hue shift 0..255)", i); return RLCF_ERR_ARG; }
+    }
+    const size_t img = (size_t)res * res * 3;
+    char* p = (char*)scratch + ((views_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255);
+    uint8_t* xo = (uint8_t*)p; p += ((size_t)n_views * img + 255) & ~(size_t)255;
+    char* aug = p;
+    p = (char*)scratch + ((views_augmix_scratch_bytes(H, n_views, res) + 255) & ~(size_t)255);
+    uint8_t* xh = (uint8_t*)p; p += ((size_t)n_views * img + 255) & ~(size_t)255;
+    rlcf_hard_aug* plans = (rlcf_hard_aug*)p;
+    int rc = launch_make_views(image, H, W, crops_host, n_crops, res, mean3, std3, views, scratch, views_scratch_bytes(H, n_views, res), st, xo);
+    if (rc != RLCF_OK) return rc;
+    RLCF_HIP_CHECK(hipMemcpyAsync(plans, hard_host, (size_t)n_crops * sizeof(rlcf_hard_aug), hipMemcpyHostToDevice, st));
+    hard_pixel_kernel<<<dim3(n_crops), dim3(1024), 0, st>>>(xo, plans, res);
+    RLCF_LAUNCH_CHECK();
+    hard_blur_kernel<<<dim3((res * res + 255) / 256, n_crops), dim3(256), 0, st>>>(xo, plans, res, xh, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
+                                                                                  std3[2], ops_host ? nullptr : views);
+    RLCF_LAUNCH_CHECK();
+    if (ops_host) {
+        rc = augmix_stage(xh, n_crops, res, mean3, std3, ops_host, w_host, m_host, views, aug, st);
+        if (rc != RLCF_OK) return rc;
+    }
+    RLCF_HIP_CHECK(hipStreamSynchronize(st));                       // the plans were read from caller-owned host memory
     return RLCF_OK;
 }

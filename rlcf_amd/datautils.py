@@ -10,7 +10,10 @@ datautils.py:94-110 / augmix_ops.py: the ops, levels, signs and the Dirichlet / 
 calls the reference makes (same order, numpy's global legacy stream, so `np.random.seed` reproduces the reference's chains) and
 `rlcf_make_views_augmix` applies them on the device, bit-exact with Pillow.
 
-Not built: the BYOL-style `hard_aug` recipe — it raises.
+`hard_aug=True` (get_preaugment(hard_aug=True), datautils.py:77-87; --hard_aug 1 of tune_cls_tpt.py / tune_cls_kd.py) is the BYOL-style
+recipe: RandomResizedCrop(scale=(0.2, 1)), then ColorJitter (p 0.5), RandomGrayscale (p 0.2), GaussianBlur (p 0.1), then the flip.
+`HardAugParams` makes torchvision's generator calls in torchvision's order; `rlcf_make_views_hard` applies the draws on the device,
+bit-exact with Pillow's ImageEnhance / HSV / L arithmetic (the blur: torchvision's float32 tensor kernel).
 """
 from __future__ import annotations
 
@@ -35,6 +38,11 @@ class RandomResizedCropParams:
         self.scale, self.ratio, self.flip_p = scale, ratio, flip_p
 
     def __call__(self, height: int, width: int) -> Tuple[int, int, int, int, bool]:
+        box = self.draw_box(height, width)
+        flip = bool(torch.rand(1) < self.flip_p)
+        return (*box, flip)
+
+    def draw_box(self, height: int, width: int) -> Tuple[int, int, int, int]:
         area = height * width
         log_ratio = torch.log(torch.tensor(self.ratio))
         box = None
@@ -59,14 +67,49 @@ class RandomResizedCropParams:
             else:
                 w, h = width, height
             box = ((height - h) // 2, (width - w) // 2, h, w)
-        flip = bool(torch.rand(1) < self.flip_p)
-        return (*box, flip)
+        return box
+
+
+class HardAugParams:
+    """The draws of get_preaugment(hard_aug=True) (datautils.py:77-87) for one view, from torch's global generator in the order
+    torchvision 0.14.1 makes them: RandomResizedCrop.get_params (scale (crop_min, 1)); RandomApply.forward's `p < torch.rand(1)` and,
+    if ColorJitter runs, ColorJitter.get_params (randperm(4), then brightness / contrast / saturation / hue uniforms);
+    RandomGrayscale's `torch.rand(1) < p`; RandomApply's coin and GaussianBlur.get_params (sigma uniform); RandomHorizontalFlip's
+    coin.  -> ((top, left, h, w, flip), plan) with plan = (order | None, b, c, s, hue_factor, gray, float32 [3, 3] kernel | None)."""
+
+    def __init__(self, crop_min=0.2):
+        self.box = RandomResizedCropParams(scale=(crop_min, 1.0), flip_p=0.0)
+
+    @staticmethod
+    def gaussian_kernel3(sigma: float) -> torch.Tensor:
+        """torchvision _get_gaussian_kernel2d(kernel_size=3, sigma): float32 [3, 3]"""
+        x = torch.linspace(-1.0, 1.0, steps=3)
+        pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+        k1 = pdf / pdf.sum()
+        return torch.mm(k1[:, None], k1[None, :])
+
+    def __call__(self, height: int, width: int):
+        box = self.box.draw_box(height, width)
+        order = b = c = s = h = None
+        if not (0.5 < torch.rand(1)):                                  # RandomApply([ColorJitter(0.4, 0.4, 0.2, 0.1)], p=0.5)
+            order = torch.randperm(4).tolist()
+            b = float(torch.empty(1).uniform_(0.6, 1.4))
+            c = float(torch.empty(1).uniform_(0.6, 1.4))
+            s = float(torch.empty(1).uniform_(0.8, 1.2))
+            h = float(torch.empty(1).uniform_(-0.1, 0.1))
+        gray = bool(torch.rand(1) < 0.2)                               # RandomGrayscale(p=0.2)
+        kernel = None
+        if not (0.1 < torch.rand(1)):                                  # RandomApply([GaussianBlur(3, sigma=(0.1, 2.0))], p=0.1)
+            kernel = self.gaussian_kernel3(torch.empty(1).uniform_(0.1, 2.0).item())
+        flip = bool(torch.rand(1) < 0.5)                               # RandomHorizontalFlip()
+        return (*box, flip), (order, b, c, s, h, gray, kernel)
 
 
 def get_preaugment(hard_aug=False, resolution=224, crop_min=0.2):
-    """datautils.py:76-91: the parameter sampler of RandomResizedCrop(resolution) + RandomHorizontalFlip()."""
+    """datautils.py:76-91: the parameter sampler of the pre-augmentation — RandomResizedCrop(resolution) + RandomHorizontalFlip(), or
+    the hard_aug recipe (HardAugParams)."""
     if hard_aug:
-        raise NotImplementedError("hard_aug (ColorJitter / Grayscale / GaussianBlur recipe, datautils.py:77-87) is not built")
+        return HardAugParams(crop_min=crop_min)
     return RandomResizedCropParams()
 
 
@@ -137,8 +180,33 @@ def _as_u8_hwc(x) -> torch.Tensor:
     return t.contiguous()
 
 
+def hue_shift_u8(hue_factor: float) -> int:
+    """np.uint8(hue_factor * 255) of torchvision's F_pil.adjust_hue under the numpy 1.x the reference pins: truncation toward zero,
+    then modulo 256"""
+    return int(hue_factor * 255) % 256
+
+
+def _hard_structs(hard_plans):
+    arr = (L.HardAug * len(hard_plans))()
+    for v, (order, b, c, s, h, gray, kernel) in enumerate(hard_plans):
+        o = arr[v]
+        if order is None:
+            o.order[0] = -1
+        else:
+            for q in range(4):
+                o.order[q] = int(order[q])
+            o.b, o.c, o.s, o.hue = float(b), float(c), float(s), hue_shift_u8(h)
+        o.gray = int(bool(gray))
+        o.blur = int(kernel is not None)
+        if kernel is not None:
+            k = torch.as_tensor(kernel, dtype=torch.float32).reshape(9).tolist()
+            for q in range(9):
+                o.k[q] = k[q]
+    return arr
+
+
 def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resolution: int = 224, mean=CLIP_MEAN, std=CLIP_STD,
-               device=None, augmix_plans=None) -> torch.Tensor:
+               device=None, augmix_plans=None, hard_plans=None) -> torch.Tensor:
     """[1 + len(crops), 3, R, R] float32 on the GPU: view 0 = Resize(R, bicubic) + CenterCrop(R) of the image, the others its
     resized crops (bilinear) with optional flip; ToTensor + Normalize.  augmix_plans: one draw_augmix_plan() result per crop — the
     crop views then go through the AugMix loop.  No CPU fallback."""
@@ -154,6 +222,8 @@ def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resoluti
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     out = torch.empty(1 + n, 3, resolution, resolution, device=dev)
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    if hard_plans is not None and (len(hard_plans) != n or n == 0):
+        raise ValueError("hard_plans: one plan per crop")
     if augmix_plans is not None:
         if len(augmix_plans) != n or n == 0:
             raise ValueError("augmix_plans: one plan per crop")
@@ -174,10 +244,24 @@ def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resoluti
                                 o.c[q] = float(chains[i][j][2][q])
                     else:
                         o.op = -1
+        if hard_plans is not None:
+            nbytes = int(lib.rlcf_make_views_hard_scratch_bytes(H, n, resolution))
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            L.check(lib.rlcf_make_views_hard(img.data_ptr(), H, W, arr, n, resolution, m3, s3, _hard_structs(hard_plans), ops, wv, mv,
+                                             out.data_ptr(), scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                    "make_views_hard")
+            return out
         nbytes = int(lib.rlcf_make_views_augmix_scratch_bytes(H, n, resolution))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         L.check(lib.rlcf_make_views_augmix(img.data_ptr(), H, W, arr, n, resolution, m3, s3, ops, wv, mv, out.data_ptr(),
                                            scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "make_views_augmix")
+        return out
+    if hard_plans is not None:
+        nbytes = int(lib.rlcf_make_views_hard_scratch_bytes(H, n, resolution))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.rlcf_make_views_hard(img.data_ptr(), H, W, arr, n, resolution, m3, s3, _hard_structs(hard_plans), None, None, None,
+                                         out.data_ptr(), scratch.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                "make_views_hard")
         return out
     L.check(lib.rlcf_make_views(img.data_ptr(), H, W, arr, n, resolution, m3, s3, out.data_ptr(), scratch.data_ptr(), nbytes,
                                 torch.cuda.current_stream().cuda_stream), "make_views")
@@ -195,17 +279,23 @@ class AugMixAugmenter:
         self.n_views, self.resolution, self.device = n_views, resolution, device
         self.aug_list: List = list(AUG_OPS) if augmix else []          # (names: the ops themselves run on the device)
         self.severity = severity
+        self.hard_aug = bool(hard_aug)
         self.preaugment = get_preaugment(hard_aug=hard_aug, resolution=resolution, crop_min=0.2)
 
     def views(self, x) -> torch.Tensor:
         img = _as_u8_hwc(x)
         H, W = int(img.shape[0]), int(img.shape[1])
-        crops, plans = [], [] if self.aug_list else None
-        for _ in range(self.n_views):                                  # per view: crop box + flip (torch), then the AugMix draws (numpy)
-            crops.append(self.preaugment(H, W))
+        crops, plans, hard = [], [] if self.aug_list else None, [] if self.hard_aug else None
+        for _ in range(self.n_views):                                  # per view: the pre-augmentation draws (torch), then the AugMix draws (numpy)
+            if self.hard_aug:
+                box, hp = self.preaugment(H, W)
+                crops.append(box)
+                hard.append(hp)
+            else:
+                crops.append(self.preaugment(H, W))
             if self.aug_list:
                 plans.append(draw_augmix_plan(self.severity))
-        return make_views(img, crops, self.resolution, device=self.device, augmix_plans=plans)
+        return make_views(img, crops, self.resolution, device=self.device, augmix_plans=plans, hard_plans=hard)
 
     def __call__(self, x):
         return list(self.views(x).unbind(0))

@@ -1,6 +1,6 @@
 """Flags of the RLCF classification entry points: same names, types and defaults as the reference (TPT/params.py:13-98), so the command
 lines of TPT/scripts/*.sh parse identically.  Flags the HIP path has no use for (--workers, --dataset_mode, --cocoop, --corruption,
---level, --kd_loss, --confidence_gap*) are accepted and ignored; --hard_aug 1 reaches the view pipeline, which refuses it."""
+--level, --kd_loss, --confidence_gap*) are accepted and ignored; --hard_aug 1 selects the BYOL-style recipe of the view pipeline (datautils.HardAugParams)."""
 import argparse
 
 
@@ -31,7 +31,7 @@ def get_args(argv=None):
     p.add_argument("--output", type=str, default="exp_01")
     p.add_argument("--dataset_mode", type=str, default="test", help="accepted (the HIP path ships a synthetic stream only)")
     p.add_argument("--workers", default=8, type=int, help="accepted (views are generated on the device: no loader workers)")
-    p.add_argument("--hard_aug", type=int, default=0, help="BYOL-style recipe of the view pipeline (datautils.py:77-87): not built, 1 raises there")
+    p.add_argument("--hard_aug", type=int, default=0, help="BYOL-style recipe of the view pipeline (datautils.py:77-87)")
     p.add_argument("--confidence_gap", type=int, default=0, help="experimental in the reference, never read by its loop: accepted, ignored")
     p.add_argument("--confidence_gap_w", type=float, default=0.5)
     p.add_argument("--corruption", type=str, default="defocus_blur")

@@ -41,7 +41,88 @@ def resized_output_size(h, w, size):
     return (new_long, new_short) if w <= h else (new_short, new_long)
 
 
+# hard_aug recipe (datautils.py:77-87): name -> (H, W, res, [(top, left, h, w, flip, order | None, b, c, s, h, gray, sigma | None)])
+HARD_CASES = {
+    "hardaug_small": (48, 64, 32, [
+        (0, 0, 48, 64, False, (0, 1, 2, 3), 1.3, 0.7, 1.1, 0.05, False, None),
+        (5, 7, 20, 31, True, (3, 2, 1, 0), 0.65, 1.39, 0.81, -0.1, False, 1.0),
+        (10, 3, 9, 12, False, None, None, None, None, None, True, None),
+        (0, 30, 48, 17, True, None, None, None, None, None, False, 0.1),
+        (40, 60, 8, 4, False, (1, 3, 0, 2), 1.0, 1.0, 1.0, 0.0, True, 2.0),
+        (2, 2, 40, 50, False, (2, 0, 3, 1), 1.4, 0.6, 1.2, -0.02, False, 0.55)]),
+    "hardaug_imagenet": (375, 500, 224, [
+        (37, 101, 240, 313, True, (1, 0, 3, 2), 0.8241, 1.2203, 0.9417, 0.0831, False, None),
+        (300, 10, 60, 45, False, (3, 1, 2, 0), 1.3711, 0.6102, 1.1903, -0.0612, True, 1.7312),
+        (1, 2, 373, 300, True, None, None, None, None, None, False, 0.3149),
+        (0, 0, 375, 500, False, (0, 2, 1, 3), 0.6, 1.4, 0.8, 0.1, False, 0.9)]),
+}
+
+
+def hard_plan_for_oracle(entry):
+    """(order, b, c, s, h, gray, kernel) of oracle.views_ref.hard_aug_u8 from a HARD_CASES entry (factors as float32 values: the
+    factors torchvision draws are float32 uniforms)."""
+    from oracle import views_ref as V
+    order, b, c, s, h, gray, sigma = entry[5:]
+    f32 = lambda v: None if v is None else float(np.float32(v))
+    return (order, f32(b), f32(c), f32(s), f32(h), gray, None if sigma is None else V.gaussian_kernel3(f32(sigma)))
+
+
+def pil_hard_view(img, entry, res):
+    """The reference's pipeline on a PIL image, written with Pillow + torch as torchvision 0.14.1 does (F_pil.adjust_* =
+    ImageEnhance / HSV round trip; rgb_to_grayscale; F_t.gaussian_blur on the uint8 tensor), flip LAST as in the recipe."""
+    import torch
+    import torch.nn.functional as F
+    from PIL import ImageEnhance
+    t, l, ch, cw, flip, order, b, c, s, h, gray, sigma = entry
+    f32 = lambda v: float(np.float32(v))
+    v = img.crop((l, t, l + cw, t + ch)).resize((res, res), Image.BILINEAR)
+    if order is not None:
+        for fn in order:
+            if fn == 0:
+                v = ImageEnhance.Brightness(v).enhance(f32(b))
+            elif fn == 1:
+                v = ImageEnhance.Contrast(v).enhance(f32(c))
+            elif fn == 2:
+                v = ImageEnhance.Color(v).enhance(f32(s))
+            else:
+                hh, ss, vv = v.convert("HSV").split()
+                np_h = np.array(hh, dtype=np.uint8)
+                np_h += np.uint8(int(f32(h) * 255) % 256)          # numpy 1.x: np.uint8(negative float) wraps
+                v = Image.merge("HSV", (Image.fromarray(np_h, "L"), ss, vv)).convert("RGB")
+    if gray:
+        g = np.array(v.convert("L"), dtype=np.uint8)
+        v = Image.fromarray(np.dstack([g, g, g]), "RGB")
+    if sigma is not None:
+        x = torch.linspace(-1.0, 1.0, steps=3)
+        pdf = torch.exp(-0.5 * (x / f32(sigma)).pow(2))
+        k1 = pdf / pdf.sum()
+        k = torch.mm(k1[:, None], k1[None, :]).expand(3, 1, 3, 3)
+        timg = torch.from_numpy(np.asarray(v).copy()).permute(2, 0, 1).unsqueeze(0).to(torch.float32)
+        timg = F.conv2d(F.pad(timg, [1, 1, 1, 1], mode="reflect"), k, groups=3)
+        v = Image.fromarray(torch.round(timg).squeeze(0).to(torch.uint8).permute(1, 2, 0).numpy(), "RGB")
+    if flip:
+        v = v.transpose(Image.FLIP_LEFT_RIGHT)
+    return np.asarray(v)
+
+
+def main_hard():
+    for name, (h, w, res, entries) in HARD_CASES.items():
+        arr = synth_image(name, h, w)
+        img = Image.fromarray(arr, "RGB")
+        outs = [pil_hard_view(img, e, res) for e in entries]
+        out = {"hw_res": np.asarray([h, w, res], np.int32), "n": np.asarray(len(entries), np.int32)}
+        if res <= 32:
+            out["views_u8"] = np.stack(outs)
+        else:
+            out["sha1"] = np.asarray([hashlib.sha1(np.ascontiguousarray(o).tobytes()).hexdigest() for o in outs])
+            out["corner_u8"] = np.stack([o[:16, :16] for o in outs])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    main_hard()
     for name, (h, w, res, crops) in CASES.items():
         arr = synth_image(name, h, w)
         img = Image.fromarray(arr, "RGB")

@@ -113,8 +113,8 @@ def test_augmenter_surface_and_errors():
         D.make_views(img, [(0, 0, 376, 10, False)])
     with pytest.raises(_lib.RlcfError):                     # 40x downscale needs more taps than the kernel carries
         D.make_views(torch.zeros(9000, 300, 3, dtype=torch.uint8), [(0, 0, 9000, 300, False)])
-    with pytest.raises(NotImplementedError):
-        D.AugMixAugmenter(None, None, n_views=3, hard_aug=True)
+    with pytest.raises(_lib.RlcfError):                     # a ColorJitter order that is not a permutation
+        D.make_views(img, [(0, 0, 100, 100, False)], hard_plans=[([0, 0, 1, 2], 1.0, 1.0, 1.0, 0.0, False, None)])
 
 
 # ------------------------------------------------------------------------------ AugMix op chains (fine-grained sets)
@@ -228,3 +228,132 @@ def test_hip_augmix_every_op_and_augmenter():
     bad = [(np.float32([1, 0, 0]), np.float32(0.5), [[(11, 0, None)], [(0, 0, None)], [(0, 0, None)]])]
     with pytest.raises(_lib.RlcfError, match="AugMix"):
         D.make_views(torch.from_numpy(arr), [(0, 0, 224, 224, False)], 224, augmix_plans=bad)
+
+
+# ------------------------------------------------------------------------------ hard_aug recipe (datautils.py:77-87)
+HARD_NAMES = sorted(G.HARD_CASES)
+
+
+def _oracle_hard_u8(name):
+    h, w, res, entries = G.HARD_CASES[name]
+    img = G.synth_image(name, h, w)
+    outs = []
+    for e in entries:
+        t, l, ch, cw, flip = e[:5]
+        x = V.hard_aug_u8(V.crop_view_u8(img, t, l, ch, cw, False, res), G.hard_plan_for_oracle(e))
+        outs.append(x[:, ::-1] if flip else x)             # the recipe flips LAST
+    return img, outs
+
+
+@pytest.mark.parametrize("name", HARD_NAMES)
+def test_oracle_hard_aug_matches_pillow_golden(name):
+    """fixtures: the recipe run on PIL images with Pillow's ImageEnhance / HSV / L conversions and torch's conv2d, as torchvision 0.14.1
+    does (tests/golden/make_views_golden.py:pil_hard_view)"""
+    _, outs = _oracle_hard_u8(name)
+    _check_u8(outs, np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def test_oracle_colour_arithmetic_exhaustive_against_pillow():
+    """Every RGB colour through convert('L') and convert('HSV'), every HSV triple through convert('RGB'), and Image.blend on all
+    65536 (in1, in2) byte pairs for factors inside and outside [0, 1]: the restatement equals the installed Pillow everywhere."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    g, b = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    for r in range(256):
+        rgb = np.stack([np.full_like(g, r), g, b], -1).astype(np.uint8)
+        im = Image.fromarray(rgb, "RGB")
+        assert np.array_equal(V.rgb_to_l(rgb), np.asarray(im.convert("L")))
+        assert np.array_equal(V.rgb_to_hsv_u8(rgb), np.asarray(im.convert("HSV")))
+        assert np.array_equal(V.hsv_to_rgb_u8(rgb), np.asarray(Image.fromarray(rgb, "HSV").convert("RGB")))
+    a = np.repeat(g[..., None], 3, axis=-1).astype(np.uint8)
+    c = np.repeat(b[..., None], 3, axis=-1).astype(np.uint8)
+    ia, ic = Image.fromarray(a, "RGB"), Image.fromarray(c, "RGB")
+    for f in (0.0, 1.0, 0.6, 0.8, 0.7531, 0.999999, 1.000001, 1.2, 1.4, 1.39999, 0.5, 1.0 / 3.0):
+        assert np.array_equal(V.blend_u8(a, c, f), np.asarray(Image.blend(ia, ic, f))), f
+
+
+def test_hard_aug_draw_order_host_mirror():
+    """rlcf_amd.datautils.HardAugParams makes torch's generator calls; oracle.views_ref.draw_hard_plan restates the order over an
+    abstract rng: replaying the same generator through both gives the same boxes, jitter orders, factors, coins and kernels."""
+    from rlcf_amd import datautils as D
+
+    class Replay:
+        def uniform(self, a, b):
+            return torch.empty(1).uniform_(a, b).item()
+
+        def randint(self, n):
+            return torch.randint(0, n, size=(1,)).item()
+
+        def rand(self):
+            return float(torch.rand(1))
+
+        def randperm(self, n):
+            return torch.randperm(n).tolist()
+
+    lr = torch.log(torch.tensor((3.0 / 4.0, 4.0 / 3.0)))
+    ratio = (float(torch.exp(lr[0])), float(torch.exp(lr[1])))
+    torch.manual_seed(77)
+    mine = [D.HardAugParams()(375, 500) for _ in range(200)]
+    torch.manual_seed(77)
+    seen = {"jitter": 0, "gray": 0, "blur": 0}
+    for (box, plan) in mine:
+        rb = V.random_resized_crop_params(375, 500, Replay(), scale=(0.2, 1.0), ratio=ratio)
+        rp = V.draw_hard_plan(Replay())
+        flip = float(torch.rand(1)) < 0.5
+        assert tuple(box[:4]) == tuple(rb) and box[4] == flip
+        assert plan[0] == rp[0] and plan[5] == rp[5] and (plan[6] is None) == (rp[6] is None)
+        if plan[0] is not None:
+            assert [float(np.float32(v)) for v in plan[1:5]] == [float(np.float32(v)) for v in rp[1:5]]
+            assert 0.6 <= plan[1] <= 1.4 and 0.6 <= plan[2] <= 1.4 and 0.8 <= plan[3] <= 1.2 and -0.1 <= plan[4] <= 0.1
+        if plan[6] is not None:
+            assert np.array_equal(plan[6].numpy(), rp[6])
+        seen["jitter"] += plan[0] is not None; seen["gray"] += bool(plan[5]); seen["blur"] += plan[6] is not None
+    assert 70 <= seen["jitter"] <= 130 and 20 <= seen["gray"] <= 65 and 5 <= seen["blur"] <= 40          # p = 0.5 / 0.2 / 0.1 of 200
+    assert D.hue_shift_u8(-12.7 / 255) == 244 and D.hue_shift_u8(0.1) == 25 and V.hue_shift_u8(-0.05) == D.hue_shift_u8(-0.05)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HARD_NAMES)
+def test_hip_hard_aug_views_bit_exact(name):
+    from rlcf_amd import datautils as D
+    h, w, res, entries = G.HARD_CASES[name]
+    img, outs = _oracle_hard_u8(name)
+    plans = [G.hard_plan_for_oracle(e) for e in entries]
+    views = D.make_views(torch.from_numpy(img), [e[:5] for e in entries], res, hard_plans=plans).cpu().numpy()
+    ref = np.stack([V.to_tensor_normalize(V.center_view_u8(img, res))] + [V.to_tensor_normalize(o) for o in outs])
+    assert views.shape == ref.shape
+    for v in range(ref.shape[0]):
+        assert np.array_equal(views[v], ref[v]), v
+    mean = np.asarray(V.CLIP_MEAN, np.float32)[:, None, None]
+    std = np.asarray(V.CLIP_STD, np.float32)[:, None, None]
+    u8 = np.rint((views[1:] * std + mean) * 255.0).astype(np.uint8).transpose(0, 2, 3, 1)
+    _check_u8(list(u8), np.load(os.path.join(GOLDEN, name + ".npz")))          # and the Pillow + torch fixture itself
+
+
+@pytest.mark.gpu
+def test_hip_hard_aug_with_augmix_and_augmenter_surface():
+    """hard_aug feeds the AugMix chains (x_orig = preaugment(image), datautils.py:96): device views == oracle on the same plans; the
+    augmenter with hard_aug=True is reproducible under a seed and equals the oracle replay of its own draws."""
+    from rlcf_amd import datautils as D
+    name = "hardaug_imagenet"
+    h, w, res, entries = G.HARD_CASES[name]
+    img, outs = _oracle_hard_u8(name)
+    hplans = [G.hard_plan_for_oracle(e) for e in entries]
+    np.random.seed(11)
+    aplans = [D.draw_augmix_plan(3) for _ in entries]
+    views = D.make_views(torch.from_numpy(img), [e[:5] for e in entries], res, hard_plans=hplans, augmix_plans=aplans).cpu().numpy()
+    for v, o in enumerate(outs):
+        assert np.array_equal(views[1 + v], V.augmix_view(o, _to_oracle_plan(aplans[v]))), v
+    torch.manual_seed(5)
+    aug = D.AugMixAugmenter(None, None, n_views=15, hard_aug=True)
+    a = aug.views(torch.from_numpy(img))
+    torch.manual_seed(5)
+    drawn = [D.HardAugParams()(h, w) for _ in range(15)]
+    torch.manual_seed(5)
+    b = aug.views(torch.from_numpy(img))
+    assert a.shape == (16, 3, 224, 224) and torch.equal(a, b)
+    for v, (box, plan) in enumerate(drawn):
+        t, l, ch, cw, flip = box
+        kern = None if plan[6] is None else plan[6].numpy()
+        x = V.hard_aug_u8(V.crop_view_u8(img, t, l, ch, cw, False, 224), (plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], kern))
+        assert np.array_equal(a[1 + v].cpu().numpy(), V.to_tensor_normalize(x[:, ::-1] if flip else x)), v
