@@ -1521,12 +1521,14 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const double cost2 = 0.575 * (double)((blocks2 + ncu - 1) / ncu);
     // 192 x 256 tiles (MT = 3): a round costs ~0.78 of a 256 x 256 round (3/4 of the products and of the epilogue, the same W tile
     // traffic); taken where the rounds it saves outweigh that — one image's token matrix against a W x W / W x 4W weight: 150 tiles =
-    // one 59 %-full round -> 198 tiles = one 77 %-full round of 3/4 the length.  RLCF_X3_MT3=0 switches it off, =2 forces it
+    // one 59 %-full round -> 198 tiles = one 77 %-full round of 3/4 the length.  Only in the big-tile regime (>= 256 tiles of 256 x 128):
+    // below it the 128 x 128 split-K kernel is the alternative and measures the same or better (M = 6272 convolutions of RN50x64's layer4).
+    // RLCF_X3_MT3=0 switches it off, =2 forces it
     static int mt3 = -1;
     if (mt3 < 0) { const char* e = getenv("RLCF_X3_MT3"); mt3 = e ? atoi(e) : 1; }
     const int blocks3h = ((M + 191) / 192) * ((N + V3_BN - 1) / V3_BN);
     const double cost3h = 0.78 * (double)((blocks3h + ncu - 1) / ncu);
-    const bool pick3h = v2_ok && !single && g.kstep == 64 && sk_blocks == 0 && force == 0 && blocks3h >= 128 && !(C && Chi && residual) &&      // (conv3's f32 + pairs + identity epilogue: slower there)
+    const bool pick3h = v2_ok && !single && g.kstep == 64 && sk_blocks == 0 && force == 0 && blocks3h >= 128 && blocks2 >= 256 && !(C && Chi && residual) &&      // (conv3's f32 + pairs + identity epilogue: slower there)
                        
                         (mt3 == 2 || (mt3 == 1 && cost3h < 0.97 * std::min(cost3, blocks2 >= 256 ? cost2 : cost3)));
     if (pick3h) {
