@@ -123,6 +123,14 @@ int rlcf_attention_fwd_pairs(const void* qkv_pairs, const rlcf_seq* seqs, int n_
  * 0 = eager softmax rescale; 8 / 32 / 40 / 64 = ablation builds of the 8-wave launch that give WRONG numbers by design; 16 = s_memtime
  * trace).  The first argument is reserved (0). */
 int rlcf_attention_debug(int reserved, int variant);
+/* Few-row products of the one-image path (M <= 256: the sparse text forward / backward over the ~239 rows of the sampled classes,
+ * TPT/clip/custom_clip.py:53-73 under TPT/tpt_cls_rl.py:60-75): C[M,N] = epi(alpha A W^T + bias) (+ residual) with A f32 [M,K]
+ * (split into f16 pairs inside the kernel) and W as interleaved operand pairs [N,2K] (rlcf_split_pairs); K % 32 == 0, N % 4 == 0.
+ * amax_in: device max|A| (the power-of-two operand scale is derived from it) or NULL; local_amax != 0 with amax_in == NULL: every
+ * workgroup scales its rows by their own max, found in the kernel (gradients nobody measured); both 0 / NULL: scale 1. */
+int rlcf_gemm_skinny(const float* A, int lda, const void* W_pairs, const float* bias, const float* residual, int ldr, const float* aux,
+                     int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in, int local_amax,
+                     rlcf_stream stream);
 /* x[n] f32 -> the operand layout above: interleaved (hi | lo) pairs per 32-element block (RLCF_PREC_F16X3, 4n bytes) or plain f16
  * (RLCF_PREC_F16, 2n bytes); n % 32 == 0 and rows that are multiples of 32 columns keep their row structure. */
 int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rlcf_attention_fwd": (I, [P, P, I, I, I, I, P, P, I, P]),
     "rlcf_attention_fwd_pairs": (I, [P, P, I, I, I, P, P, P, I, P]),
     "rlcf_split_pairs": (I, [P, P, C.c_int64, I, P]),
+    "rlcf_gemm_skinny": (I, [P, I, P, P, P, I, P, I, P, I, I, I, I, F, I, P, I, P]),
     "rlcf_attention_debug": (I, [I, I]),
     "rlcf_attention_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "rlcf_entropy_select": (I, [P, I, I, I, P, P, P]),

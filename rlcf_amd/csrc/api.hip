@@ -131,6 +131,16 @@ int rlcf_attention_fwd_pairs(const void* qkv_pairs, const rlcf_seq* seqs, int n_
                                      precision == RLCF_PREC_F16);
 }
 int rlcf_attention_debug(int oneshot, int variant) { attention_pair_debug(oneshot, variant); return RLCF_OK; }
+int rlcf_gemm_skinny(const float* A, int lda, const void* W_pairs, const float* bias, const float* residual, int ldr, const float* aux,
+                     int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in, int local_amax,
+                     rlcf_stream stream) {
+    RLCF_ARG_CHECK(A && W_pairs && C && gemm_skinny_x3_ok(M, N, K, lda, ldc) && ldr % 4 == 0 && ldaux % 4 == 0);
+    static float* ws = nullptr;                            // K-slice scratch of the op-level call (the engine passes its own)
+    const size_t ws_bytes = (size_t)64 << 20;
+    if (!ws) RLCF_HIP_CHECK(hipMalloc((void**)&ws, ws_bytes + 256));
+    return launch_gemm_skinny_x3(A, lda, W_pairs, bias, residual, ldr, aux, ldaux, C, ldc, M, N, K, alpha, epilogue, amax_in, nullptr, ws,
+                                 ws_bytes, (float*)((char*)ws + ws_bytes), (hipStream_t)stream, local_amax);
+}
 int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream) {
     RLCF_ARG_CHECK(x && pairs && n > 0 && n % 32 == 0 && (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16));
     if (precision == RLCF_PREC_F16) return launch_split_f16x2(x, pairs, nullptr, n, (hipStream_t)stream, 1.0f, 0);

@@ -106,12 +106,12 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             return rc;
         }
     }
-    // small M (the one-image path's sparse text passes, ~239 rows): the skinny split-f16 kernel splits A itself; operands with a known
-    // range (forward activations) or a max|A| left behind by the producer qualify — the others stay on the f32-MFMA kernel, which needs
-    // no scale.  RLCF_SKINNY=0 switches it off (A/B measurements)
+    // small M (the one-image path's sparse text passes, ~239 rows): the skinny split-f16 kernel splits A itself, scaled by 1 (forward
+    // activations: known range), by the max|A| the producer left behind, or — gradients nobody measured — per wave by the max of its
+    // own 32 rows, found in the kernel.  RLCF_SKINNY=0 switches it off (A/B measurements)
     static int skinny = -1;
     if (skinny < 0) { const char* ev = getenv("RLCF_SKINNY"); skinny = ev ? atoi(ev) : 1; }
-    if (skinny && prec_x3(e) && !prec_single(e) && M > 32 && (!dyn_scale || amax_in) && a_scale == 1.0f && lda % 4 == 0 && ldw == K && C &&
+    if (skinny && prec_x3(e) && !prec_single(e) && M > 32 && a_scale == 1.0f && lda % 4 == 0 && ldw == K && C &&
         gemm_skinny_x3_ok(M, N, K, lda, ldc) && ldr % 4 == 0 && ldaux % 4 == 0) {
         const ClipModel::SplitW* sp = nullptr;
         for (auto& m : e->model) { auto it = m.split_of.find(W); if (it != m.split_of.end()) { sp = &it->second; break; } }
@@ -120,7 +120,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
             int rc = launch_gemm_skinny_x3(A, lda, sp->hi, bias, res, ldr, aux, ldaux, C, ldc, M, N, K, alpha * sp->inv_scale, epi,
                                            dyn_scale ? amax_in : nullptr, amax_out, ws_ptr(e), ws_bytes(e) - X3_SK_FLAG_BYTES_RESERVED,
-                                           e->dyn.as<float>() + 2, st);
+                                           e->dyn.as<float>() + 2, st, dyn_scale && !amax_in);
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }

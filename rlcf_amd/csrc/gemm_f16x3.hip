@@ -1344,14 +1344,21 @@ extern int g_last_x3_variant;
 struct SkinnyArgs {
     const float* A; int lda;
     const float* amax_in;              // optional: device max|A| -> power-of-two operand scale
+    int local_amax;                    // no max|A| known: every workgroup scales its 128 rows by their own max (found in the kernel)
     float* inv_scale_out;              // where 1 / scale goes when K slices hand the epilogue to the reduce kernel (alpha_dev of it)
     GemmX3Args g;                      // W pairs (Whi, ldw), bias, residual, aux, C, M, N, K, alpha, epilogue, amax_out, ksplit, ws
 };
 __global__ __launch_bounds__(256) void gemm_skinny_x3_kernel(SkinnyArgs s) {
     const GemmX3Args& g = s.g;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 128 + wave * 32;
-    if (m0 >= g.M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, mb = blockIdx.y * 128, m0 = mb + wave * 32;
+    // LDS: one K chunk (64 columns) of the workgroup's 128 A rows as f16 hi | lo (row = 128 B hi + 128 B lo, + 16 B: a 16-lane ds_read_b128
+    // group of consecutive rows covers all 64 banks) and of its 32 W rows as they lie in memory (2 blocks of [32 hi | 32 lo])
+    constexpr int RS = 272;
+    __shared__ __attribute__((aligned(16))) char lds[(128 + 32) * RS];
+    __shared__ float red[4];
+    char* la = lds;
+    char* lw = lds + 128 * RS;
     float scale = 1.f, inv = 1.f;
     if (s.amax_in) {
         const float mx = s.amax_in[0];
@@ -1361,57 +1368,149 @@ __global__ __launch_bounds__(256) void gemm_skinny_x3_kernel(SkinnyArgs s) {
         scale = ldexpf(1.0f, sh); inv = ldexpf(1.0f, -sh);
         if (s.inv_scale_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) s.inv_scale_out[0] = inv;
     }
-    const int nk = g.K / 16;
-    int k_lo = 0, k_hi = nk;
-    if (g.ksplit > 1) { const int per = (nk + g.ksplit - 1) / g.ksplit; k_lo = blockIdx.z * per; k_hi = min(nk, k_lo + per); }
-    const int row = m0 + l32;
-    const bool rok = row < g.M;
-    const float* ap = s.A + (size_t)(rok ? row : g.M - 1) * s.lda + h * 8;
-    const int ncol = min(n0 + l32, g.N - 1);
-    const _Float16* wp = g.Whi + (size_t)ncol * g.ldw + h * 8;           // K block b = 64 halves: [32 hi | 32 lo]; step t covers k = 16 t .. 16 t + 15
+    // cooperative, coalesced loads: thread (r16 = tid >> 4, p = tid & 15) takes 16 bytes p of the 256-byte K chunk of rows r16 + 16 j
+    const int r16 = tid >> 4, p16 = tid & 15;
+    const int nc = (g.K + 63) / 64;                       // K chunks of 64 columns (K % 32 == 0: the last one may be half)
+    int c_lo = 0, c_hi = nc;
+    if (g.ksplit > 1) { const int per = (nc + g.ksplit - 1) / g.ksplit; c_lo = blockIdx.z * per; c_hi = min(nc, c_lo + per); }
+    const float* arow[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) arow[j] = s.A + (size_t)min(mb + r16 + 16 * j, g.M - 1) * s.lda;
+    const _Float16* wrow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wrow[q] = g.Whi + (size_t)min(n0 + r16 + 16 * q, g.N - 1) * g.ldw;
+    // every load is UNCONDITIONAL on a clamped address and masked afterwards: a conditional load compiles to a branch followed by
+    // s_waitcnt vmcnt(0) — one exposed round trip per load, which is what the first forms of this kernel spent their 20-30 us on
+    if (s.local_amax) {
+        // operand range unknown and no producer left a max|A| behind (the gradients entering the sparse text backward): the workgroup
+        // scales its 128 rows by their own max over the WHOLE K range (every K slice of these rows finds the same scale)
+        float mx = 0.f;
+        for (int c = 0; c < nc; c += 4) {                   // 32 independent loads in flight per thread (A is L2-resident: ~1 us per group)
+            float4 v[4][8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int ko = min(min(c + d, nc - 1) * 64 + p16 * 4, g.K - 4);       // (a repeated piece does not change the max)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[d][j] = *(const float4*)(arow[j] + ko);
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[d][j].x), fabsf(v[d][j].y)), fmaxf(fabsf(v[d][j].z), fabsf(v[d][j].w))));
+        }
+        mx = wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int sh = 0;
+        if (mx > 0.f && mx < INFINITY) sh = 9 - (int)floorf(log2f(mx));
+        sh = sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+        scale = ldexpf(1.0f, sh); inv = ldexpf(1.0f, -sh);
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int t = k_lo; t < k_hi; ++t) {
-        const float4 a0 = *(const float4*)(ap + t * 16), a1 = *(const float4*)(ap + t * 16 + 4);
-        const _Float16* wq = wp + (t >> 1) * 64 + (t & 1) * 16;
-        const h16x8 wh = *(const h16x8*)wq, wl = *(const h16x8*)(wq + 32);
-        const float v[8] = {a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale, a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale};
-        h16x8 ah, al;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const _Float16 hh = (_Float16)(rok ? v[e] : 0.f);
-            ah[e] = hh;
-            al[e] = (_Float16)((rok ? v[e] : 0.f) - (float)hh);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+    // The direct form of this kernel (every lane fetching its own row's 16 bytes per K step) ran 25-30 us per launch whatever the
+    // batching of its loads: 32 cache lines per load instruction, four instructions per K step and wave — the texture addresser, not
+    // latency, was the limit.  Here a chunk costs 320 line requests per workgroup instead of 2048.
+    // ... and the loop is a chain of memory latencies (a few dozen workgroups in the whole launch, W straight from HBM): chunks are
+    // fetched SK_D ahead into registers, so K = 512 exposes two round trips instead of eight
+    constexpr int SK_D = 4;
+    float4 ar[SK_D][8];
+    h16x8 wr[SK_D][2];
+#define SK_LOAD(c_, d_)                                                                                                  \
+    {                                                                                                                    \
+        const int ka_ = min((c_) * 64 + p16 * 4, g.K - 4), kw_ = min((c_) * 128 + p16 * 8, 2 * g.K - 8);                 \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) ar[d_][j] = *(const float4*)(arow[j] + ka_);                      \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) wr[d_][q] = *(const h16x8*)(wrow[q] + kw_);                       \
     }
+#pragma unroll
+    for (int d = 0; d < SK_D; ++d)
+        SK_LOAD(min(c_lo + d, nc - 1), d)
+    const char* fa = la + (wave * 32 + l32) * RS + h * 16;
+    const char* fw = lw + l32 * RS + h * 16;
+    for (int c0 = c_lo; c0 < c_hi; c0 += SK_D) {
+#pragma unroll
+        for (int d = 0; d < SK_D; ++d) {
+            const int c = c0 + d;
+            if (c >= c_hi) break;
+            __syncthreads();                                // the previous chunk's fragments have been read
+            const bool kok = c * 64 + p16 * 4 < g.K;        // (K % 64 == 32: the upper half of the last chunk is zero)
+            const bool wok = c * 64 + (p16 >> 3) * 32 < g.K;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool rok = kok && mb + r16 + 16 * j < g.M;
+                const float v[4] = {ar[d][j].x * scale, ar[d][j].y * scale, ar[d][j].z * scale, ar[d][j].w * scale};
+                h16x4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = rok ? v[e] : 0.f;
+                    hh[e] = (_Float16)x;
+                    ll[e] = (_Float16)(x - (float)hh[e]);
+                }
+                char* dst = la + (r16 + 16 * j) * RS + p16 * 8;
+                *(h16x4*)dst = hh;
+                *(h16x4*)(dst + 128) = ll;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 w_ = __builtin_bit_cast(u32x4, wr[d][q]);
+                const unsigned m_ = wok ? 0xffffffffu : 0u;
+                w_[0] &= m_; w_[1] &= m_; w_[2] &= m_; w_[3] &= m_;
+                *(u32x4*)(lw + (r16 + 16 * q) * RS + p16 * 16) = w_;
+            }
+            __syncthreads();
+            SK_LOAD(min(c + SK_D, nc - 1), d)                // refill this slot (clamped: a spare load at the end): in flight for the next SK_D - 1 chunks
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const h16x8 ah = *(const h16x8*)(fa + u * 32), al = *(const h16x8*)(fa + 128 + u * 32);
+                const h16x8 wh = *(const h16x8*)(fw + (u >> 1) * 128 + (u & 1) * 32), wl = *(const h16x8*)(fw + (u >> 1) * 128 + 64 + (u & 1) * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+            }
+        }
+    }
+#undef SK_LOAD
+    if (m0 >= g.M) return;
     const int col = n0 + l32;
     if (col >= g.N) return;
     if (g.ksplit > 1) {                                  // raw partial tile; alpha / bias / epilogue in the reduce pass
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = m0 + mfma32_row(r, h);
-            if (rr < g.M) g.ws[((size_t)blockIdx.z * g.M + rr) * g.N + col] = acc[r];
+            if (rr < g.M) g.ws[((size_t)blockIdx.z * g.M + rr) * g.N + col] = s.local_amax ? acc[r] * inv : acc[r];     // (a power of two: exact)
         }
         return;
     }
     const float al_ = g.alpha * inv;
     const float bv = g.bias ? g.bias[col] : 0.f;
     float am = 0.f;
+    // aux / residual of all 16 rows are fetched first, unconditionally (rows clamped): a load inside the row loop's `if` would be one
+    // exposed round trip per row
+    float auxv[16], resv[16];
+    const bool has_aux = g.epilogue == RLCF_EPI_QUICKGELU_BWD, has_res = g.residual != nullptr;
+    if (has_aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) auxv[r] = g.aux[(size_t)min(m0 + mfma32_row(r, h), g.M - 1) * g.ldaux + col];
+    }
+    if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) resv[r] = g.residual[(size_t)min(m0 + mfma32_row(r, h), g.M - 1) * g.ldr + col];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = m0 + mfma32_row(r, h);
-        if (rr >= g.M) continue;
         float v = al_ * acc[r] + bv;
         if (g.epilogue == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
-        else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) v *= quick_gelu_grad_fast(g.aux[(size_t)rr * g.ldaux + col]);
-        if (g.residual) v += g.residual[(size_t)rr * g.ldr + col];
+        else if (has_aux) v *= quick_gelu_grad_fast(auxv[r]);
+        if (has_res) v += resv[r];
         if (g.epilogue == RLCF_EPI_RELU) v = fmaxf(v, 0.f);
-        am = fmaxf(am, fabsf(v));
-        g.C[(size_t)rr * g.ldc + col] = v;
+        if (rr < g.M) {
+            am = fmaxf(am, fabsf(v));
+            g.C[(size_t)rr * g.ldc + col] = v;
+        }
     }
     amax_commit(g.amax_out, am);
 }
@@ -1420,18 +1519,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_x3_kernel(SkinnyArgs s) {
 bool gemm_skinny_x3_ok(int M, int N, int K, int lda, int ldc) { return M > 0 && M <= 256 && N % 4 == 0 && K % 32 == 0 && lda % 4 == 0 && ldc % 4 == 0; }
 int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const float* bias, const float* residual, int ldr, const float* aux,
                           int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in,
-                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st) {
+                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st, int local_amax) {
     RLCF_ARG_CHECK(A && Wpairs && C && gemm_skinny_x3_ok(M, N, K, lda, ldc) && ((uintptr_t)A & 15) == 0);
     RLCF_ARG_CHECK(epilogue != RLCF_EPI_QUICKGELU_BWD || aux);
     SkinnyArgs s{};
-    s.A = A; s.lda = lda; s.amax_in = amax_in;
+    s.A = A; s.lda = lda; s.amax_in = amax_in; s.local_amax = (local_amax && !amax_in) ? 1 : 0;
     GemmX3Args& g = s.g;
     g.Whi = (const _Float16*)Wpairs; g.Wlo = g.Whi + 32; g.ldw = 2 * K; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.amax_out = amax_out; g.kstep = 64;
     const int tiles = ((N + 31) / 32) * ((M + 127) / 128);
     int ksplit = 1;
-    if (K >= 1024 && tiles < 192 && ws && N % 4 == 0) {
-        ksplit = std::min(K / 256, std::max(1, 256 / tiles));
+    static int sk_kmin = -1, sk_per = -1;
+    if (sk_kmin < 0) { const char* e = getenv("RLCF_SKINNY_KMIN"); sk_kmin = e ? atoi(e) : 1024; }
+    if (sk_per < 0) { const char* e = getenv("RLCF_SKINNY_KPER"); sk_per = e ? atoi(e) : 256; }
+    if (K >= sk_kmin && tiles < 192 && ws && N % 4 == 0) {
+        ksplit = std::min(K / sk_per, std::max(1, 256 / tiles));
         while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > ws_bytes) --ksplit;
         if (amax_in && !inv_scale_scratch) ksplit = 1;
     }

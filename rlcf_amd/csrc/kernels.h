@@ -74,7 +74,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
 bool gemm_skinny_x3_ok(int M, int N, int K, int lda, int ldc);
 int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const float* bias, const float* residual, int ldr, const float* aux,
                           int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in,
-                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st);
+                          unsigned int* amax_out, float* ws, size_t ws_bytes, float* inv_scale_scratch, hipStream_t st, int local_amax = 0);
 #define X3_SPLITK_WS_BYTES ((size_t)4 * 128 * 128 * 128 * sizeof(float))   // 4 slices x (<= 128 tiles of 128x128): the largest split-K launch
 // engine GEMM scratch: split-K partial tiles (above) or the stream-K slabs (256 workgroups x 256 KB), + 8 KB of stream-K flag words at its end
 #define X3_WS_BYTES ((size_t)256 * 262144 + 8192)
