@@ -1145,26 +1145,29 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
     const long total = (long)g.M * n4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = (int)(i / n4), col = (int)(i % n4) * 4;
-        float4 a4 = *(const float4*)(g.ws + (size_t)row * g.N + col);
-        for (int z = 1; z < g.ksplit; ++z) {
-            const float4 t = *(const float4*)(g.ws + ((size_t)z * g.M + row) * g.N + col);
-            a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
-        }
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        // bias / aux / residual first, then the slices four at a time (independent loads in flight together; the adds stay in slice order)
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), x4 = bv, r4 = bv;
         if (g.bias) bv = *(const float4*)(g.bias + col);
+        if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
+        if (g.residual) r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
+        float4 a4 = *(const float4*)(g.ws + (size_t)row * g.N + col);
+        for (int z = 1; z < g.ksplit; z += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const float4*)(g.ws + ((size_t)min(z + u, g.ksplit - 1) * g.M + row) * g.N + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (z + u < g.ksplit) { a4.x += t[u].x; a4.y += t[u].y; a4.z += t[u].z; a4.w += t[u].w; }
+        }
         const float al = x3_alpha(g);
         float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
         if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
         } else if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) {
-            const float4 x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
             v[0] *= quick_gelu_grad_fast(x4.x); v[1] *= quick_gelu_grad_fast(x4.y); v[2] *= quick_gelu_grad_fast(x4.z); v[3] *= quick_gelu_grad_fast(x4.w);
         }
-        if (g.residual) {
-            const float4 r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
+        if (g.residual) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
         if (g.epilogue == RLCF_EPI_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
