@@ -36,6 +36,8 @@ class RandomResizedCropParams:
 
     def __init__(self, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), flip_p: float = 0.5):
         self.scale, self.ratio, self.flip_p = scale, ratio, flip_p
+        lr = torch.log(torch.tensor(self.ratio))           # float32, as torchvision computes it; the bounds reach uniform_ as Python floats
+        self._log_ratio = (lr[0].item(), lr[1].item())
 
     def __call__(self, height: int, width: int) -> Tuple[int, int, int, int, bool]:
         box = self.draw_box(height, width)
@@ -44,7 +46,7 @@ class RandomResizedCropParams:
 
     def draw_box(self, height: int, width: int) -> Tuple[int, int, int, int]:
         area = height * width
-        log_ratio = torch.log(torch.tensor(self.ratio))
+        log_ratio = self._log_ratio
         box = None
         for _ in range(10):
             target_area = area * torch.empty(1).uniform_(self.scale[0], self.scale[1]).item()
