@@ -1645,6 +1645,10 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         return RLCF_OK;
     }
     const bool pick3 = (blocks2 >= 256 || sk_blocks > 0) && cost3 <= cost2;
+    // smallest grid of 256x128 tiles that takes the 8-wave kernel: 160 (two waves per SIMD on 160+ CUs beat one wave per SIMD on twice as
+    // many 128x128 workgroups: [4095, 1536, 512] 30.8 -> 27.3 us; below ~100 tiles the small tile wins).  RLCF_X3_V2MIN=256: the old rule
+    static int v2min = -1;
+    if (v2min < 0) { const char* e = getenv("RLCF_X3_V2MIN"); v2min = e ? atoi(e) : 160; }
     // RLCF_X3_V4=1: the 4-wave form of the 256x256 tile where it applies (interleaved pairs, compile-time epilogues)
     static int v4 = -1;
     if (v4 < 0) { const char* e = getenv("RLCF_X3_V4"); v4 = e ? atoi(e) : 0; }
@@ -1691,7 +1695,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
     }
-    if (v2_ok && (force == 2 || (force == 0 && blocks2 >= 256))) {
+    if (v2_ok && (force == 2 || (force == 0 && blocks2 >= v2min))) {
         const size_t sh2 = (size_t)3 * V2_STAGE;
         if (single) {
             X3_LDS((gemm_nt_f16x3_v2_kernel<4, true>), sh2);
@@ -1719,6 +1723,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int nkt = K / X3_BK;
         int ksplit = 1;
         if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
+        // ... and the 24-tile K loops of grids below a quarter of the chip (one image's reward tower: [1182, 768, 768] = 60 workgroups)
+        // in three slices (bench.py --batch 1, with the 256x128 threshold below: 75.2-75.7 -> 76.6 images/s).  RLCF_X3_SPLIT24=0: off
+        static int split24 = -1;
+        if (split24 < 0) { const char* e = getenv("RLCF_X3_SPLIT24"); split24 = e ? atoi(e) : 2; }
+        if (split24 && !nosplit && ksplit == 1 && blocks2s <= 64 && nkt >= 24) ksplit = split24 + 1;
         // a very long K loop over a small output (the weight gradient of a convolution: K = n*H*W = 10^5..10^6 rows): as many slices as
         // it takes to put ~384 workgroups on the chip, each at least 64 K tiles long, within the workspace
         if (!nosplit && nkt >= 1024 && blocks2s < 384 && splitk_ws) {
