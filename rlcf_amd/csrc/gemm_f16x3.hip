@@ -1592,7 +1592,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
     // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes
-    // ~0.575 of a 256x256 round (half the work at ~15 % lower efficiency).  Measured at M = 12608 (one test image): N = 768 runs
+    // ~0.62 of a 256x256 round (half the work at ~20 % lower efficiency).  Measured at M = 12608 (one test image): N = 768 runs
     // 61 us as one 59 %-full 256x256 round against 70 us as two 256x128 rounds; K = 3072: 188 against 233 us.
     static int ncu = 0;
     if (!ncu) {
@@ -1623,7 +1623,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             }
         }
     }
-    const double cost2 = 0.575 * (double)((blocks2 + ncu - 1) / ncu);
+    // (0.62 since round 4, re-measured with W from HBM: [12608, 3072, 768] 5 rounds of 256x128 = 181.6 us against 3 rounds of 256x256 =
+    // 175.0 us; [81900, 512, 512] 151.2 against 138.3 us; [81900, 512, 2048] 482 against 452 us — tools/gemm_mid_bench.py)
+    const double cost2 = 0.62 * (double)((blocks2 + ncu - 1) / ncu);
     // 192 x 256 tiles (MT = 3): a round costs ~0.78 of a 256 x 256 round (3/4 of the products and of the epilogue, the same W tile
     // traffic); taken where the rounds it saves outweigh that — one image's token matrix against a W x W / W x 4W weight: 150 tiles =
     // one 59 %-full round -> 198 tiles = one 77 %-full round of 3/4 the length.  Only in the big-tile regime (>= 256 tiles of 256 x 128):
