@@ -537,7 +537,7 @@ def test_tta_batch_and_reset(L, dev):
 
 @pytest.mark.parametrize("steps", [1, 3])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("geo,reward,n_cls,p", [("tiny", "tiny-r", 16, 0.5), ("small", "small", 40, 0.25)])
+@pytest.mark.parametrize("geo,reward,n_cls,p", [("tiny", "tiny-r", 16, 0.5), ("small", "small", 40, 0.25), ("tiny-rn", "tiny-r", 16, 0.5)])
 def test_fused_sample_batch_equals_per_sample(L, dev, geo, reward, n_cls, p, mode, steps):
     """rlcf_tta_batch runs B samples per tower pass when the engine has room for B*N views; every sample must come
     out as if it had been processed alone (independent units) — also with several tuning steps

@@ -312,3 +312,32 @@ def test_gemm_192_row_tiles_bit_identical_to_the_other_tile_shapes(L, dev, N, K,
     if res:
         ref = ref + x[rows].double()
     assert float((got[rows].double() - ref).abs().max()) < 3e-4
+
+
+def test_config4_images_per_pass_equals_one_at_a_time(L, dev):
+    """`bench.py --config 4` runs EIGHT test images per tower pass (the convolutions' GEMMs then see 256 views): at the full geometry —
+    RN50x64 student @448^2, ViT-L/14 reward, N = 32 — every image of a fused pass must come out as if it had been processed alone
+    (independent units): same top-5, final logits within 2e-4.  Three images (one pass of 3) against three
+    single-image calls; 200 classes."""
+    from rlcf_amd.engine import Engine, TTAConfig
+    sg, rg = synth.GEOMETRIES["RN50x64"], synth.GEOMETRIES["ViT-L/14"]
+    ssd, rsd = synth.make_state_dict(sg, 11, device=dev), synth.make_state_dict(rg, 23, device=dev)
+    N, C, B = 32, 200, 3
+    tokens = synth.make_token_bank(sg, C, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, 4), device=dev)].clone()
+    cfg = TTAConfig(selection_p=0.1, sample_k=3, lr=7e-3, weight_decay=5e-4)
+    vs = torch.stack([synth.make_views(3000 + i, N, 448, device=dev) for i in range(B)])
+    outs = []
+    for n_img in (1, B):
+        eng = Engine(sg, rg, N * n_img, C, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
+        eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+        if n_img == 1:
+            ref = [eng.tta_sample(vs[i], cfg, want_intermediates=False) for i in range(B)]
+            outs.append(([r["top5"].tolist() for r in ref], torch.stack([r["final_logits"][0] for r in ref])))
+        else:
+            top5, fl = eng.tta_batch(vs, cfg, want_logits=True)
+            outs.append(([t.tolist() for t in top5], fl))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    torch.testing.assert_close(outs[1][1], outs[0][1], atol=2e-4, rtol=0)

@@ -16,8 +16,8 @@ prof() { name=$1; nimg=$2; title=$3; shift 3; timeout 900 rocprofv3 --kernel-tra
          if [ -n "$db" ]; then python tools/prof_summary.py "$db" "$title" $nimg > $O/kernel_stats_$name.txt; else echo "prof $name: no database"; fi
          tail -c 1500 $O/prof_$name.log > $O/prof_$name.tail; rm -f $O/prof_$name.log; rm -rf /tmp/prof_$name; }
 prof c1 65 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line --no-harness-leg (BASELINE configs[1]; set-up pass of 20 + 5 warm-up + 20 timed + 20 profiled images = 65)" --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line --no-harness-leg
-prof c2 112 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 2 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[2]: ViT-L/14 + ViT-L/14, LayerNorm tuning, N = 64, 16 images per pass; warm-up + timed + profiled passes)" --config 2 --no-cpu-baseline --sustain-seconds 0
-prof c4 97 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 4 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[4]: RN50x64 @448 student + ViT-L/14 reward, N = 32, one image per pass; warm-up + timed + profiled images)" --config 4 --no-cpu-baseline --sustain-seconds 0
+prof c2 120 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 2 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[2]: ViT-L/14 + ViT-L/14, LayerNorm tuning, N = 64, 20 images per pass; set-up + warm-up + timed + profiled passes)" --config 2 --no-cpu-baseline --sustain-seconds 0
+prof c4 56 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --config 4 --no-cpu-baseline --sustain-seconds 0 (BASELINE configs[4]: RN50x64 @448 student + ViT-L/14 reward, N = 32, 8 images per pass; set-up + warm-up + timed + profiled passes)" --config 4 --no-cpu-baseline --sustain-seconds 0
 prof b1 26 "round 4 final build: rocprofv3 --kernel-trace --stats -- python bench.py --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line --no-harness-leg --no-roofline (one image per pass: set-up + 5 warm-up + 20 timed images)" --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line --no-harness-leg --no-roofline
 ls -la $O | head -40
 # row a-R: RN50 student, BatchNorm tuning
