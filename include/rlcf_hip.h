@@ -206,7 +206,7 @@ int rlcf_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops, 
  * threshold), 5 shear_x, 6 shear_y, 7 translate_x, 8 translate_y; ops 3 and 5-8 carry the six coefficients Image.transform(AFFINE)
  * receives in c (for rotate: the matrix Image.rotate builds).  Bit-exact with Pillow (look-up tables; bilinear affine resampling
  * in double precision, truncated).  ops, w [n_crops,3], m [n_crops] are HOST arrays drawn by the caller with the reference's
- * numpy calls (the call returns after the stream has consumed them). */
+ * numpy calls; they are copied (through pinned staging) before the call returns, which does not wait for the device. */
 typedef struct { int op; int ip; double c[6]; } rlcf_augmix_op;
 size_t rlcf_make_views_augmix_scratch_bytes(int H, int n_crops, int res);
 int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,
@@ -221,7 +221,7 @@ int rlcf_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop* 
  * gray = RandomGrayscale's coin, blur / k = GaussianBlur applied / its float32 3x3 kernel, row-major (torchvision
  * _get_gaussian_kernel2d).  Bit-exact with Pillow's ImageEnhance / HSV / L conversions; the blur is nine float32 fused multiply-adds
  * in row-major order, rounded half to even (what torch's CPU conv2d computes).  ops / w / m: the AugMix plan as in
- * rlcf_make_views_augmix, or all NULL (no AugMix).  hard, ops, w, m are HOST arrays. */
+ * rlcf_make_views_augmix, or all NULL (no AugMix).  hard, ops, w, m are HOST arrays, copied before the call returns. */
 typedef struct { int order[4]; float b, c, s; int hue; int gray; int blur; float k[9]; } rlcf_hard_aug;
 size_t rlcf_make_views_hard_scratch_bytes(int H, int n_crops, int res);
 int rlcf_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* crops, int n_crops, int res, const float* mean3,

@@ -11,6 +11,41 @@
 #include "kernels.h"
 #include <cmath>
 
+#include <cstring>
+#include <mutex>
+
+// Host -> device hand-over of the small parameter arrays (crop boxes, AugMix / hard_aug plans): a copy from PAGEABLE host memory is
+// stream-ordered but blocks the calling thread until every earlier launch of that stream has finished — one full device drain per test
+// image in a loop that makes its views on the fly.  The arrays go through a ring of pinned slots instead (host memcpy, then a truly
+// asynchronous copy; an event per slot guards its reuse), so the call returns at once and the caller's arrays are free again.
+#define VW_SLOTS 32
+#define VW_SLOT_BYTES (128 * 1024)
+static int views_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+    static std::mutex mu;
+    static char* ring = nullptr;
+    static hipEvent_t ev[VW_SLOTS];
+    static int next = 0;
+    if (bytes == 0) return RLCF_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring && bytes <= VW_SLOT_BYTES) {
+        if (hipHostMalloc((void**)&ring, (size_t)VW_SLOTS * VW_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { ring = nullptr; (void)hipGetLastError(); }
+        else for (int i = 0; i < VW_SLOTS; ++i) RLCF_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    if (!ring || bytes > VW_SLOT_BYTES) {                 // (too large, or no pinned memory: the blocking form)
+        RLCF_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        RLCF_HIP_CHECK(hipStreamSynchronize(st));
+        return RLCF_OK;
+    }
+    const int slot = next;
+    next = (next + 1) % VW_SLOTS;
+    RLCF_HIP_CHECK(hipEventSynchronize(ev[slot]));        // (its previous copy has been consumed; a fresh event is complete)
+    char* p = ring + (size_t)slot * VW_SLOT_BYTES;
+    memcpy(p, src_host, bytes);
+    RLCF_HIP_CHECK(hipMemcpyAsync(dst_dev, p, bytes, hipMemcpyHostToDevice, st));
+    RLCF_HIP_CHECK(hipEventRecord(ev[slot], st));
+    return RLCF_OK;
+}
+
 #define VW_KMAX 64                 // taps per output sample: ceil(support)*2+1 <= 64  (bilinear: downscale <= 31x, bicubic <= 15.5x)
 #define VW_PREC 22
 
@@ -153,7 +188,7 @@ int launch_make_views(const uint8_t* image, int H, int W, const rlcf_crop* crops
     int32_t* tab = (int32_t*)scratch;
     uint8_t* tmp = (uint8_t*)scratch + (size_t)n_views * 2 * res * (VW_KMAX + 2) * sizeof(int32_t);
     rlcf_crop* crops = (rlcf_crop*)(tmp + (((size_t)n_views * H * res * 3 + 15) & ~(size_t)15));
-    if (n_crops) RLCF_HIP_CHECK(hipMemcpyAsync(crops, crops_host, (size_t)n_crops * sizeof(rlcf_crop), hipMemcpyHostToDevice, st));
+    if (n_crops) { int rcu = views_upload(crops, crops_host, (size_t)n_crops * sizeof(rlcf_crop), st); if (rcu != RLCF_OK) return rcu; }
     const int nt = n_views * 2 * res;
     views_coeffs_kernel<<<dim3((nt + 127) / 128), dim3(128), 0, st>>>(crops, n_views, H, W, res, nw, nh, off_x, off_y, tab);
     RLCF_LAUNCH_CHECK();
@@ -331,9 +366,9 @@ static int augmix_stage(const uint8_t* xo, int n_crops, int res, const float* me
     uint8_t* luts = (uint8_t*)p; p += ((size_t)chains * 768 + 255) & ~(size_t)255;
     rlcf_augmix_op* ops = (rlcf_augmix_op*)p; p += ((size_t)chains * 3 * sizeof(rlcf_augmix_op) + 255) & ~(size_t)255;
     float* wm = (float*)p;
-    RLCF_HIP_CHECK(hipMemcpyAsync(ops, ops_host, (size_t)chains * 3 * sizeof(rlcf_augmix_op), hipMemcpyHostToDevice, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(wm, w_host, (size_t)n_crops * 3 * sizeof(float), hipMemcpyHostToDevice, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(wm + n_crops * 3, m_host, (size_t)n_crops * sizeof(float), hipMemcpyHostToDevice, st));
+    { int rcu = views_upload(ops, ops_host, (size_t)chains * 3 * sizeof(rlcf_augmix_op), st); if (rcu != RLCF_OK) return rcu; }
+    { int rcu = views_upload(wm, w_host, (size_t)n_crops * 3 * sizeof(float), st); if (rcu != RLCF_OK) return rcu; }
+    { int rcu = views_upload(wm + n_crops * 3, m_host, (size_t)n_crops * sizeof(float), st); if (rcu != RLCF_OK) return rcu; }
     const dim3 grid((res * res + 255) / 256, chains);
     for (int round = 0; round < 3; ++round) {                      // round r applies op r of every chain: b0 <- x, b1 <- b0, b0 <- b1
         augmix_lut_kernel<<<dim3(chains), dim3(256), 0, st>>>(xo, b0, b1, ops, round, res, luts);
@@ -360,7 +395,6 @@ int launch_make_views_augmix(const uint8_t* image, int H, int W, const rlcf_crop
     if (rc != RLCF_OK) return rc;
     rc = augmix_stage(xo, n_crops, res, mean3, std3, ops_host, w_host, m_host, views, p, st);
     if (rc != RLCF_OK) return rc;
-    RLCF_HIP_CHECK(hipStreamSynchronize(st));                       // the plan was read from caller-owned host memory
     return RLCF_OK;
 }
 
@@ -530,7 +564,7 @@ int launch_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* 
     rlcf_hard_aug* plans = (rlcf_hard_aug*)p;
     int rc = launch_make_views(image, H, W, crops_host, n_crops, res, mean3, std3, views, scratch, views_scratch_bytes(H, n_views, res), st, xo);
     if (rc != RLCF_OK) return rc;
-    RLCF_HIP_CHECK(hipMemcpyAsync(plans, hard_host, (size_t)n_crops * sizeof(rlcf_hard_aug), hipMemcpyHostToDevice, st));
+    { int rcu = views_upload(plans, hard_host, (size_t)n_crops * sizeof(rlcf_hard_aug), st); if (rcu != RLCF_OK) return rcu; }
     hard_pixel_kernel<<<dim3(n_crops), dim3(1024), 0, st>>>(xo, plans, res);
     RLCF_LAUNCH_CHECK();
     hard_blur_kernel<<<dim3((res * res + 255) / 256, n_crops), dim3(256), 0, st>>>(xo, plans, res, xh, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
@@ -540,6 +574,5 @@ int launch_make_views_hard(const uint8_t* image, int H, int W, const rlcf_crop* 
         rc = augmix_stage(xh, n_crops, res, mean3, std3, ops_host, w_host, m_host, views, aug, st);
         if (rc != RLCF_OK) return rc;
     }
-    RLCF_HIP_CHECK(hipStreamSynchronize(st));                       // the plans were read from caller-owned host memory
     return RLCF_OK;
 }

@@ -63,6 +63,7 @@ class PromptLearner(nn.Module):
         """The harness assigns a pre-trained (CoOp) prompt here (`--load`, tpt_cls_rl.py:95-101): the engine's reset state and
         its cached step-0 text features follow."""
         self._ctx_init_state = value.detach().to(self.device, torch.float32).clone()
+        self._at_reset = False
         if self.tokenized_prompts is not None:
             self._publish_bank()
 
@@ -107,6 +108,10 @@ class PromptLearner(nn.Module):
 
     def reset(self):                                   # custom_clip.py:161-167
         self.ctx.data.copy_(self.ctx_init_state)
+        # (host-side note that ctx IS the reset state now — rlcf_amd.tpt_cls_rl.test_time_tuning then need not compare the two tensors,
+        # which would make the host wait for the device once per test image; an in-place edit of the Parameter bumps its version)
+        self._reset_stamp = self.ctx._version
+        self._at_reset = True
 
     def reset_classnames(self, classnames, arch):      # custom_clip.py:169-196 (without re-loading CLIP from disk)
         self._set_classnames(classnames)
@@ -187,11 +192,14 @@ class ClipTestTimeTuning(nn.Module):
     def inference(self, image):
         cache = getattr(self, "_tuned_view_cache", None)
         if cache is not None and not torch.is_grad_enabled():
-            view0, version, logits = cache
+            view0, version, logits, hint, hint_version = cache
             # the clean view rlcf_amd.tpt_cls_rl.test_time_tuning just tuned on, with the prompt it left behind: the fused step already
-            # computed these logits (same arithmetic: frozen image tower, text tower of the adapted prompt)
-            if self.prompt_learner.ctx._version == version and image.shape == view0.shape and image.device == view0.device and torch.equal(image, view0):
-                return logits.clone()
+            # computed these logits (same arithmetic: frozen image tower, text tower of the adapted prompt).  The mirror's own loop names
+            # the tensor it will ask about (same object, unmodified: no device round trip); any other caller is answered after comparing
+            # the contents (torch.equal: the host waits for the device once)
+            if self.prompt_learner.ctx._version == version and image.shape == view0.shape and image.device == view0.device:
+                if (hint is not None and image is hint and image._version == hint_version) or torch.equal(image, view0):
+                    return logits.clone()
         return _LogitsFn.apply(self.prompt_learner.ctx, image, self)
 
     def forward(self, input):

@@ -182,6 +182,26 @@ def _as_u8_hwc(x) -> torch.Tensor:
     return t.contiguous()
 
 
+_COPY_STREAMS = {}
+
+
+def _upload(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    """Host -> device copy of the decoded image on a side stream: a copy issued on the compute stream would make the host wait for
+    every launch already queued there (the previous test image's whole step) before it could draw the next image's views."""
+    if t.is_cuda:
+        return t.to(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    cs = _COPY_STREAMS.get(key)
+    if cs is None:
+        cs = _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(cs):
+        d = t.to(dev)                                      # (blocks the host only until THIS copy is done: the side stream is idle)
+    cur.wait_stream(cs)
+    d.record_stream(cur)
+    return d
+
+
 def hue_shift_u8(hue_factor: float) -> int:
     """np.uint8(hue_factor * 255) of torchvision's F_pil.adjust_hue under the numpy 1.x the reference pins: truncation toward zero,
     then modulo 256"""
@@ -215,7 +235,7 @@ def make_views(image, crops: Sequence[Tuple[int, int, int, int, bool]], resoluti
     if not torch.cuda.is_available():
         raise L.RlcfError("rlcf_amd.datautils.make_views needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device(device or "cuda")
-    img = _as_u8_hwc(image).to(dev)
+    img = _upload(_as_u8_hwc(image), dev)
     H, W = int(img.shape[0]), int(img.shape[1])
     n = len(crops)
     arr = (L.Crop * max(n, 1))(*[L.Crop(int(t), int(l), int(h), int(w), int(bool(f))) for t, l, h, w, f in crops])

@@ -10,6 +10,7 @@ import torch
 
 from . import _lib as L
 from . import runtime
+from .datautils import _upload
 from .engine import TTAConfig
 
 
@@ -69,7 +70,8 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
         model.ln.grad = None
         return
     pl = model.prompt_learner
-    ctx_in = None if torch.equal(pl.ctx.data, pl.ctx_init_state) else pl.ctx.data
+    at_reset = getattr(pl, "_at_reset", False) and pl.ctx._version == getattr(pl, "_reset_stamp", -1)      # reset() just ran (no device round trip)
+    ctx_in = None if at_reset or torch.equal(pl.ctx.data, pl.ctx_init_state) else pl.ctx.data
     # The harness asks for model(image) on the clean view right after this call (tpt_cls_rl.py:260-262).  The image tower is frozen, so
     # the engine already holds that view's features (row 0 of the N-view pass): the fused call finishes the sample — text features of
     # the adapted prompt, logits — and the result is kept for ClipTestTimeTuning.inference, which returns it when it is asked for
@@ -78,7 +80,10 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
     with torch.no_grad():
         pl.ctx.data.copy_(out["ctx_after"])
     pl.ctx.grad = None
-    model._tuned_view_cache = (inputs[:1], pl.ctx._version, out["final_logits"])
+    pl._at_reset = False
+    hint = getattr(model, "_clean_view_hint", None)            # set by test_time_adapt_eval: the tensor it will pass to model(image) next
+    model._clean_view_hint = None
+    model._tuned_view_cache = (inputs[:1], pl.ctx._version, out["final_logits"], hint, hint._version if hint is not None else None)
     return
 
 
@@ -98,18 +103,22 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
     `images_per_pass` of them share every tower pass inside the engine (rlcf_tta_batch / rlcf_tta_batch_ln); same predictions."""
     cfg = _config(args, optimizer, reward_model)
     prompt = hasattr(model, "prompt_learner")
-    n, s1, s5, buf, tgt = 0, 0.0, 0.0, [], []
+    n, s1_t, s5_t, buf, tgt = 0, None, None, [], []
 
     def flush():
-        nonlocal n, s1, s5, buf, tgt
+        # (hit counts stay on the device until the end: reading them per pass would stop the host from preparing the next pass's views
+        # while this one runs; labels go up on a side stream for the same reason)
+        nonlocal n, s1_t, s5_t, buf, tgt
         if not buf:
             return
         views = torch.stack(buf)
         eng = runtime.SESSION.engine(views.shape[0] * views.shape[1])
         top5 = (eng.tta_batch if prompt else eng.tta_batch_ln)(views, cfg).long()
-        t = torch.stack(tgt).view(-1, 1).to(top5.device)
-        s1 += float((top5[:, :1] == t).any(1).float().sum()) * 100.0
-        s5 += float((top5 == t).any(1).float().sum()) * 100.0
+        t = torch.stack(tgt).view(-1, 1)
+        t = _upload(t, top5.device) if not t.is_cuda else t.to(top5.device)
+        h1, h5 = (top5[:, :1] == t).any(1).float().sum(), (top5 == t).any(1).float().sum()
+        s1_t = h1 if s1_t is None else s1_t + h1
+        s5_t = h5 if s5_t is None else s5_t + h5
         n += len(buf)
         buf, tgt = [], []
 
@@ -123,6 +132,7 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
         if len(buf) == images_per_pass:
             flush()
     flush()
+    s1, s5 = (float(s1_t) * 100.0, float(s5_t) * 100.0) if n else (0.0, 0.0)
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
 
 
@@ -138,7 +148,10 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
         with torch.no_grad():
             model.reset()
         return _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass)
-    n, s1, s5 = 0, 0.0, 0.0
+    # The hit counts accumulate ON THE DEVICE (exact: sums of 0 / 100 in float32) and are read at print_freq and at the end: the
+    # reference reads them after every image (float(acc1[0])), which makes the host wait for the GPU before it may draw the next
+    # image's views — the one place where following the loop line by line would leave the GPU idle.  Same numbers.
+    n, s1_t, s5_t = 0, None, None
     model.eval()
     with torch.no_grad():
         model.reset()
@@ -154,7 +167,8 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
                 images = images.squeeze(0)
             images = images.cuda(args.gpu, non_blocking=True)
             image = images
-        target = target.cuda(args.gpu, non_blocking=True)
+        # (the label goes up on a side stream: a host-memory copy issued on the compute stream makes the host wait for everything queued there)
+        target = _upload(target, torch.device("cuda", args.gpu)) if not target.is_cuda and not target.is_pinned() else target.cuda(args.gpu, non_blocking=True)
         if args.tpt and isinstance(images, list):
             images = torch.cat(images, dim=0)
         if args.tta_steps > 0:
@@ -163,6 +177,8 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
         optimizer.load_state_dict(optim_state)
         if backbone:
             model.train()                                           # tune_cls_rl.py:216
+        elif args.tpt and image is not images and image.dim() == 4 and image.size(0) == 1:
+            model._clean_view_hint = image                          # images = cat([image, views...]): row 0 of the step's input IS this tensor
         test_time_tuning(model, images, optimizer, scaler, args, reward_model=reward_model)
         if backbone:
             model.eval()                                            # tune_cls_rl.py:218
@@ -171,8 +187,14 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
         if backbone:
             model.momentum_update_model()                           # tune_cls_rl.py:240 (no-op unless momentum_update)
         acc1, acc5 = accuracy(output, target, topk=(1, 5))
-        n += image.size(0); s1 += float(acc1[0]) * image.size(0); s5 += float(acc5[0]) * image.size(0)
+        bs = image.size(0)
+        n += bs
+        s1_t = acc1[0] * bs if s1_t is None else s1_t + acc1[0] * bs
+        s5_t = acc5[0] * bs if s5_t is None else s5_t + acc5[0] * bs
         if (i + 1) % getattr(args, "print_freq", 500) == 0:
-            print(f"Test: [{i + 1}/{len(val_loader)}] Time {time.time() - end:6.3f} Acc@1 {s1 / n:6.2f} Acc@5 {s5 / n:6.2f}")
+            print(f"Test: [{i + 1}/{len(val_loader)}] Time {time.time() - end:6.3f} Acc@1 {float(s1_t) / n:6.2f} Acc@5 {float(s5_t) / n:6.2f}")
+        elif (i + 1) % 32 == 0:
+            torch.cuda.current_stream().synchronize()                # (bounds how far the host runs ahead of the device)
         end = time.time()
+    s1, s5 = (float(s1_t), float(s5_t)) if n else (0.0, 0.0)
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
