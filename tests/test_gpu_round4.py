@@ -341,3 +341,56 @@ def test_config4_images_per_pass_equals_one_at_a_time(L, dev):
         eng.close()
     assert outs[0][0] == outs[1][0]
     torch.testing.assert_close(outs[1][1], outs[0][1], atol=2e-4, rtol=0)
+
+
+def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
+    """rlcf_amd.tpt_cls_rl.test_time_tuning starts from the cached reset state without comparing tensors when PromptLearner.reset() just
+    ran (no host-device round trip per test image).  It must NOT take that shortcut after the prompt was edited: (1) reset -> tune gives
+    the reference fixture's result; (2) reset -> an in-place edit of the Parameter (what an optimizer step is) -> tune gives the oracle's
+    result FROM THE EDITED PROMPT; (3) a new ctx_init_state -> reset -> tune starts from the new state.  And model(image) on the clean
+    view returns the fused step's logits for the very tensor the loop named, and recomputes for any other tensor."""
+    from test_gpu_parity import _harness_objects
+    from rlcf_amd import runtime, tpt_cls_rl
+    g, meta = load_golden("tta_tiny_s1")
+    model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+    pl = model.prompt_learner
+    views = synth.make_views(meta["view_seed"], meta["n_views"], 32).to(dev)
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    ssd, rsd = synth.make_state_dict(sg, meta["student_seed"]), synth.make_state_dict(rg, meta["reward_seed"])
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    hyper = RR.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                        weight_decay=meta["weight_decay"])
+
+    def tune():
+        optimizer.load_state_dict(optim_state)
+        tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+        with torch.no_grad():
+            return model(views[:1]).cpu()
+    with torch.no_grad():
+        model.reset()
+    assert pl._at_reset
+    out1 = tune()
+    assert not pl._at_reset
+    torch.testing.assert_close(out1, g["final_logits"], atol=1e-3, rtol=0)                                   # (1)
+    with torch.no_grad():
+        model.reset()
+        pl.ctx.add_(synth.normal(41, "edit.ctx", tuple(pl.ctx.shape), 0.05).to(dev))       # (2) in-place edit after reset() (not a uniform shift: LayerNorm removes those)
+    edited = pl.ctx.detach().cpu().clone()
+    out2 = tune()
+    ref2 = RR.tta_sample(ssd, rsd, views.cpu(), tokens, edited, hyper)
+    torch.testing.assert_close(out2, ref2["final_logits"], atol=1e-3, rtol=0)
+    assert (out2 - out1).abs().max() > 1e-3
+    pre = synth.normal(31, "coop.ctx", tuple(pl.ctx.shape), 0.02).to(dev)                                  # (3)
+    pl.ctx_init_state = pre
+    assert not pl._at_reset
+    with torch.no_grad():
+        model.reset()
+    out3 = tune()
+    ref3 = RR.tta_sample(ssd, rsd, views.cpu(), tokens, pre.cpu(), hyper)
+    torch.testing.assert_close(out3, ref3["final_logits"], atol=1e-3, rtol=0)
+    # the clean-view cache: the loop's own tensor is answered from the fused step, another tensor with other contents is computed afresh
+    other = synth.make_views(meta["view_seed"] + 1, 1, 32).to(dev)
+    with torch.no_grad():
+        o_other = model(other).cpu()
+    assert (o_other - out3).abs().max() > 1e-3
+    runtime.reset_session()
