@@ -29,3 +29,22 @@ t1 = time.perf_counter()
 for _ in range(50): [D.draw_augmix_plan(1) for _ in crops]
 dq = (time.perf_counter() - t1) / 50
 print(f"make_views + AugMix chains (63 views x 3 chains x <=3 ops): {da*1e6:.0f} us per image; plan sampling on host {dq*1e6:.0f} us")
+# the hard_aug recipe (rlcf_make_views_hard): ColorJitter / RandomGrayscale / GaussianBlur between the resized crop and the flip
+torch.manual_seed(0)
+hp = D.HardAugParams()
+drawn = [hp(375, 500) for _ in range(63)]
+hcrops, hplans = [d[0] for d in drawn], [d[1] for d in drawn]
+for _ in range(3): D.make_views(img, hcrops, hard_plans=hplans)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): D.make_views(img, hcrops, hard_plans=hplans)
+torch.cuda.synchronize(); dh = (time.perf_counter() - t0) / 50
+t1 = time.perf_counter()
+for _ in range(50): [hp(375, 500) for _ in range(63)]
+dhq = (time.perf_counter() - t1) / 50
+nj, ng, nb = sum(p[0] is not None for p in hplans), sum(bool(p[5]) for p in hplans), sum(p[6] is not None for p in hplans)
+print(f"make_views + hard_aug (63 views: {nj} colour-jittered, {ng} grayscale, {nb} blurred): {dh*1e6:.0f} us per image; parameter sampling on host {dhq*1e6:.0f} us")
+for _ in range(3): D.make_views(img, hcrops, hard_plans=hplans, augmix_plans=plans)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): D.make_views(img, hcrops, hard_plans=hplans, augmix_plans=plans)
+torch.cuda.synchronize(); dha = (time.perf_counter() - t0) / 50
+print(f"make_views + hard_aug + AugMix chains: {dha*1e6:.0f} us per image")
