@@ -288,6 +288,10 @@ class CLIPCLS_TTA(nn.Module):
         self.ln.data.copy_(self._ln_init)
         if not self.only_norm:
             self.vis.data.copy_(self._vis_init)
+        # (host-side note that the tunable tensors ARE the reset state: rlcf_amd.tpt_cls_rl.test_time_tuning then skips its tensor
+        # comparisons — one host-device round trip per test image; in-place edits of the Parameters bump the stamped versions)
+        self._reset_stamp = (self.ln._version, None if self.only_norm else self.vis._version)
+        self._at_reset = True
 
     @torch.no_grad()
     def reset_classnames_and_state(self, classnames, arch):   # custom_clip.py:434-454
@@ -322,6 +326,7 @@ class CLIPCLS_TTA(nn.Module):
             self._ln_init = eng.ln_params(pristine=True)
             if not self.only_norm:
                 self._vis_init = eng.visual_params(1)
+            self._at_reset = False                           # (the reset state itself moved: reset() establishes it again)
 
     @torch.no_grad()
     def forward(self, image):

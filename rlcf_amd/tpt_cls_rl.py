@@ -59,8 +59,10 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
     eng = runtime.SESSION.engine(inputs.shape[0])
     if not hasattr(model, "prompt_learner"):               # CLIPCLS_TTA: image-encoder tuning (TPT/tune_cls_rl.py:31,217)
         full = not model.only_norm
-        if not torch.equal(model.ln.data, model._ln_init) or (full and not torch.equal(model.vis.data, model._vis_init)):
+        at_reset = getattr(model, "_at_reset", False) and getattr(model, "_reset_stamp", None) == (model.ln._version, model.vis._version if full else None)
+        if not at_reset and (not torch.equal(model.ln.data, model._ln_init) or (full and not torch.equal(model.vis.data, model._vis_init))):
             raise NotImplementedError("image-encoder tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
+        model._at_reset = False
         out = (eng.tta_sample_visual if full else eng.tta_sample_ln)(inputs, cfg, skip_final=True)
         with torch.no_grad():
             model.ln.data.copy_(out["ln_after"])
