@@ -679,6 +679,32 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         if (cls_out && cls_idx) TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
         return RLCF_OK;
     }
+    static int save_pairs = -1;                               // RLCF_SAVE_NOPAIRS=1: the saved forward back on f32 hand-overs (A/B)
+    if (save_pairs < 0) { const char* ev = getenv("RLCF_SAVE_NOPAIRS"); save_pairs = ev && atoi(ev) ? 0 : 1; }
+    if (save_pairs && save && prec_x3(e) && !prec_single(e) && T > 512 && W % 32 == 0) {
+        // the saved forward of the tuning paths with the no-grad pipeline's hand-overs: LayerNorm and the attention kernel write the
+        // next GEMM's operand pairs themselves (the attention output also as f32: the backward reads it), and c_proj's operand comes
+        // from ONE pass over the saved pre-activation (QuickGELU + split) — the same values as the f32 hand-overs, four stand-alone
+        // passes per layer fewer (configs[2]: 0.47 ms/image)
+        TRY(x3_ensure(ws, T, W));
+        for (int l = 0; l < L; ++l) {
+            const BlockW& b = w.blk[l];
+            float* xin = ws.sv[l].x;
+            float* x1 = ws.sv[l].x1;
+            float* xout = l + 1 < L ? ws.sv[l + 1].x : ws.x.as<float>();
+            LN_FWD_SPLIT(xin, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.sv[l].qkv, 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            TRY(launch_attention_fwd_x3(ws.sv[l].qkv, seqs, n_seq, max_q_len, W, causal, ws.sv[l].a, ws.a2.p, lo_of(ws.a2.p), st, 1, ws.sv[l].lse));
+            e->last_flops += 4.0 * attn_pairs * W;
+            TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, xin, W, x1, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
+            LN_FWD_SPLIT(x1, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            TRY(gemm_pre(e, ws.h2.p, W, b.fc_w, b.fc_b, nullptr, 0, ws.sv[l].f, 4 * W, nullptr, 0, T, 4 * W, W, RLCF_EPI_NONE, st));
+            TRY(launch_split_f16x2(ws.sv[l].f, ws.f2.p, lo_of(ws.f2.p), (int64_t)T * 4 * W, st, 1.0f, 1, 1));
+            TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x1, W, xout, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
+        }
+        if (cls_out && cls_idx) TRY(launch_gather_rows(ws.x.as<float>(), W, cls_idx, cls_out, W, n_seq, W, st));
+        return RLCF_OK;
+    }
     for (int l = 0; l < L; ++l) {
         const BlockW& b = w.blk[l];
         float* xin = save ? ws.sv[l].x : ws.x.as<float>();

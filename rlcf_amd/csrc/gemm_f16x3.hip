@@ -1798,9 +1798,16 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
 // x -> (hi, lo): hi = f16(x), lo = f16((x - hi) * 2^11).  8 elements per thread.
 // il: interleaved output — 8-element group i (32-element block i/4, position i%4) lands at 8*((i/4)*8 + i%4) (hi) and 32 halves later (lo)
 __device__ __forceinline__ int64_t split_dst(int64_t i, int il) { return il ? ((i >> 2) << 3) + (i & 3) : i; }
+// GELU: the operand is QuickGELU(x) (model.py:166-168, the exact form of quickgelu_kernel): the saved-forward pass of the tuning paths
+// keeps the pre-activation for the backward and feeds c_proj from this one pass instead of a QuickGELU pass plus a split pass
+template <bool GELU>
 __global__ void split_f16x2_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n8, float scale, int il) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+        float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+        if constexpr (GELU) {
+            a.x = quick_gelu(a.x); a.y = quick_gelu(a.y); a.z = quick_gelu(a.z); a.w = quick_gelu(a.w);
+            b.x = quick_gelu(b.x); b.y = quick_gelu(b.y); b.z = quick_gelu(b.z); b.w = quick_gelu(b.w);
+        }
         const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
         h16x8 vh, vl;
 #pragma unroll
@@ -1872,11 +1879,12 @@ int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float*
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
-int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale, int il) {
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale, int il, int gelu) {
     RLCF_ARG_CHECK(n > 0 && n % 8 == 0);
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    split_f16x2_kernel<<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale, il);
+    if (gelu) split_f16x2_kernel<true><<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale, il);
+    else split_f16x2_kernel<false><<<dim3(blocks), dim3(256), 0, st>>>(x, (_Float16*)hi, (_Float16*)lo, n / 8, scale, il);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

@@ -89,7 +89,7 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
 int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il = 0);
 int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il = 0);
-int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f, int il = 0);
+int launch_split_f16x2(const float* x, void* hi, void* lo, int64_t n, hipStream_t st, float scale = 1.0f, int il = 0, int gelu = 0 /* operand = QuickGELU(x) */);
 int launch_absmax(const float* x, int64_t n, float* out_dev, hipStream_t st);
 // the same by scanning: dctx[b, j] = sum of dX rows r of group b whose source row (row_src[r], or r itself) carries learnable vector j
 int launch_ctx_grad_scan(const float* dX, const int32_t* row_src, const int32_t* ctx_row, int groups, int group_rows, int n_ctx, int width,
