@@ -370,9 +370,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NWM, bool SINGLE>         // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
+// RT = 32-row accumulator tiles per wave: 2 (64 x 64 per wave) or 1 — <4, ., 1> is the 128x128 tile on EIGHT waves of 32 x 64: the grids
+// the 128x128 tile serves put one workgroup on a CU, and with four waves that is one wave per SIMD, whose LDS reads and barriers nothing
+// hides (~1.0 us per K tile against 0.67 us per 128x128-equivalent on the 8-wave 256x128 kernel, measured on [4095, 1536, 512])
+template <int NWM, bool SINGLE, int RT = 2>         // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
-    constexpr int BM = 64 * NWM, A_BYTES = BM * 64, W_BYTES = V2_BN * 64;
+    constexpr int BM = 32 * RT * NWM, A_BYTES = BM * 64, W_BYTES = V2_BN * 64;
+    constexpr int NP = 2 * RT + 2 * (4 / NWM);             // DMA pieces per wave and stage
     constexpr int STAGE = 2 * A_BYTES + 2 * W_BYTES, ALO = A_BYTES, WHI = 2 * A_BYTES, WLO = WHI + W_BYTES;
     constexpr int WPW = 4 / NWM;            // W-tile DMA instructions per wave and array (512 chunks over 2*NWM waves)
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
@@ -393,30 +397,30 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // DMA sources: A tile = 1024 chunks (2 wave-instructions per wave per array), W tile = 512 (1 each)
-    const int qa0 = (wave * 2) * 64 + lane, qa1 = qa0 + 64, qw = (wave * WPW) * 64 + lane, qw1 = qw + 64;
+    // DMA sources: A tile = BM x 4 chunks (RT wave-instructions per wave per array), W tile = 512 (WPW each)
+    const int qa0 = (wave * RT) * 64 + lane, qa1 = qa0 + 64, qw = (wave * WPW) * 64 + lane, qw1 = qw + 64;
     const int ra0 = qa0 >> 2, ra1 = qa1 >> 2, rw = qw >> 2, rw1 = qw1 >> 2;
     const size_t sa0 = (size_t)min(m0 + ra0, g.M - 1) * g.lda + (((qa0 & 3) ^ ((ra0 >> 2) & 3)) * 8);
     const size_t sa1 = (size_t)min(m0 + ra1, g.M - 1) * g.lda + (((qa1 & 3) ^ ((ra1 >> 2) & 3)) * 8);
     const size_t sw = (size_t)min(n0 + rw, g.N - 1) * g.ldw + (((qw & 3) ^ ((rw >> 2) & 3)) * 8);
     const size_t sw1 = (size_t)min(n0 + rw1, g.N - 1) * g.ldw + (((qw1 & 3) ^ ((rw1 >> 2) & 3)) * 8);       // (WPW == 2 only)
-    const int da0 = (wave * 2) * 1024, da1 = da0 + 1024, dw = (wave * WPW) * 1024, dw1 = dw + 1024;     // wave-uniform LDS byte offsets
+    const int da0 = (wave * RT) * 1024, da1 = da0 + 1024, dw = (wave * WPW) * 1024, dw1 = dw + 1024;     // wave-uniform LDS byte offsets
     // one DMA piece (1 KiB per wave-instruction); the six pieces of a stage are issued BETWEEN the MFMA groups of the
     // current tile so that their ~100-cycle issue cost hides under matrix work instead of delaying it
 #define V2_PIECE(idx, kk, sb_)                                                                                           \
     {                                                                                                                    \
         if ((idx) == 0) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa0 + (kk)), (lptr_t)((sb_) + da0), 16, 0, 0);            \
-        if ((idx) == 1) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa1 + (kk)), (lptr_t)((sb_) + da1), 16, 0, 0);            \
+        if ((idx) == 1 && RT == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa1 + (kk)), (lptr_t)((sb_) + da1), 16, 0, 0); \
         if ((idx) == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa0 + (kk)), (lptr_t)((sb_) + ALO + da0), 16, 0, 0);      \
-        if ((idx) == 3) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa1 + (kk)), (lptr_t)((sb_) + ALO + da1), 16, 0, 0);      \
+        if ((idx) == 3 && RT == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Alo + sa1 + (kk)), (lptr_t)((sb_) + ALO + da1), 16, 0, 0); \
         if ((idx) == 4) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw + (kk)), (lptr_t)((sb_) + WHI + dw), 16, 0, 0);        \
         if ((idx) == 5) __builtin_amdgcn_global_load_lds((gptr_t)(g.Wlo + sw + (kk)), (lptr_t)((sb_) + WLO + dw), 16, 0, 0);        \
         if ((idx) == 6 && WPW == 2) __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw1 + (kk)), (lptr_t)((sb_) + WHI + dw1), 16, 0, 0); \
@@ -431,9 +435,11 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
 #define V2_LDFRAG(ks, AH, AL, BH, BL)                                                                                    \
     {                                                                                                                    \
         const int co_ = (((ks) * 2 + h) ^ swz) * 16;                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+        _Pragma("unroll") for (int i = 0; i < RT; ++i) {                                                                 \
             AH[i] = *(const h16x8*)(sb + aoff + i * 2048 + co_);                                                         \
             AL[i] = *(const h16x8*)(sb + ALO + aoff + i * 2048 + co_);                                                   \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
             BH[i] = *(const h16x8*)(sb + WHI + boff + i * 2048 + co_);                                                   \
             BL[i] = *(const h16x8*)(sb + WLO + boff + i * 2048 + co_);                                                   \
         }                                                                                                                \
@@ -473,20 +479,18 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     V2_ISSUE(kb, 0)
     if (nk > 1) V2_ISSUE(kb + g.kstep, 1)
     const int swz = (l32 >> 2) & 3;
-    const int aoff = (wm * 64 + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
+    const int aoff = (wm * (32 * RT) + l32) * 64, boff = (wn * 64 + l32) * 64;      // row byte offsets
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {                 // the pieces of the newest stage (6, or 8 with two W instructions per wave) may stay in flight
-            if constexpr (WPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");      // the NP pieces of the newest stage may stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const bool pf = kt + 2 < nk;
         const int kn = kb + (kt + 2) * g.kstep;
         char* sn = smem + (cur >= 1 ? cur - 1 : 2) * STAGE;                // stage (cur + 2) % 3
         const char* sb = smem + cur * STAGE;
-        h16x8 ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
+        h16x8 ah0[RT], al0[RT], bh0[2], bl0[2], ah1[RT], al1[RT], bh1[2], bl1[2];
         V2_LDFRAG(0, ah0, al0, bh0, bl0)
         V2_FENCE
         V2_MMA3(0, 0, ah0, al0, bh0, bl0) V2_FENCE
@@ -494,22 +498,32 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         V2_LDFRAG(1, ah1, al1, bh1, bl1)
         V2_FENCE
         V2_MMA3(0, 1, ah0, al0, bh0, bl0) V2_FENCE
-        if (pf) V2_PIECE(1, kn, sn)
-        V2_FENCE
-        V2_MMA3(1, 0, ah0, al0, bh0, bl0) V2_FENCE
-        if (pf) V2_PIECE(2, kn, sn)
-        V2_FENCE
-        V2_MMA3(1, 1, ah0, al0, bh0, bl0) V2_FENCE
-        if (pf) V2_PIECE(3, kn, sn)
-        V2_FENCE
-        V2_MMA3(0, 0, ah1, al1, bh1, bl1) V2_FENCE
-        if (pf) { V2_PIECE(4, kn, sn) V2_PIECE(6, kn, sn) }
-        V2_FENCE
-        V2_MMA3(0, 1, ah1, al1, bh1, bl1) V2_FENCE
-        if (pf) { V2_PIECE(5, kn, sn) V2_PIECE(7, kn, sn) }
-        V2_FENCE
-        V2_MMA3(1, 0, ah1, al1, bh1, bl1)
-        V2_MMA3(1, 1, ah1, al1, bh1, bl1)
+        if constexpr (RT == 2) {
+            if (pf) V2_PIECE(1, kn, sn)
+            V2_FENCE
+            V2_MMA3(1, 0, ah0, al0, bh0, bl0) V2_FENCE
+            if (pf) V2_PIECE(2, kn, sn)
+            V2_FENCE
+            V2_MMA3(1, 1, ah0, al0, bh0, bl0) V2_FENCE
+            if (pf) V2_PIECE(3, kn, sn)
+            V2_FENCE
+            V2_MMA3(0, 0, ah1, al1, bh1, bl1) V2_FENCE
+            if (pf) { V2_PIECE(4, kn, sn) V2_PIECE(6, kn, sn) }
+            V2_FENCE
+            V2_MMA3(0, 1, ah1, al1, bh1, bl1) V2_FENCE
+            if (pf) { V2_PIECE(5, kn, sn) V2_PIECE(7, kn, sn) }
+            V2_FENCE
+            V2_MMA3(1, 0, ah1, al1, bh1, bl1)
+            V2_MMA3(1, 1, ah1, al1, bh1, bl1)
+        } else {                            // one row tile per wave: four MFMA groups, the four pieces (A hi, A lo, W hi, W lo) between them
+            if (pf) V2_PIECE(2, kn, sn)
+            V2_FENCE
+            V2_MMA3(0, 0, ah1, al1, bh1, bl1) V2_FENCE
+            if (pf) { V2_PIECE(4, kn, sn) V2_PIECE(6, kn, sn) }
+            V2_FENCE
+            V2_MMA3(0, 1, ah1, al1, bh1, bl1)
+            if (pf) { V2_PIECE(5, kn, sn) V2_PIECE(7, kn, sn) }
+        }
         cur = cur == 2 ? 0 : cur + 1;
     }
 
@@ -517,15 +531,19 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
     // re-reads it row-wise, so bias / residual / stores are 16-byte accesses covering whole 256-B row segments
     __syncthreads();
     if (const int ek = x3_epilogue_kind(g)) {
-        X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (float*)smem + wave * (64 * 68), m0 + wm * 64, n0 + wn * 64, lane, am)
+        if constexpr (RT == 2) {
+            X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (float*)smem + wave * (64 * 68), m0 + wm * 64, n0 + wn * 64, lane, am)
+        } else {
+            X3_EPILOGUE_HALFSLAB(ek, g, acc[0][0], acc[0][1], acc[0][0], acc[0][1], (float*)smem + wave * (32 * 68), m0 + wm * 32, n0 + wn * 64, lane, am)
+        }
         amax_commit(g.amax_out, am);
         return;
     }
     {
         constexpr int ELD = 68;                                            // floats per parked row (64 + 4 pad)
-        float* park = (float*)smem + wave * (64 * ELD);
+        float* park = (float*)smem + wave * (32 * RT * ELD);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -538,8 +556,8 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
             float* wsz = g.ws + (size_t)blockIdx.y * g.M * g.N;
             if (col < g.N)
 #pragma unroll 4
-                for (int it = 0; it < 16; ++it) {
-                    const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
+                for (int it = 0; it < 8 * RT; ++it) {
+                    const int rl = it * 4 + rsub, row = m0 + wm * (32 * RT) + rl;
                     if (row < g.M) *(float4*)(wsz + (size_t)row * g.N + col) = *(const float4*)(park + rl * ELD + c4);
                 }
             return;
@@ -548,8 +566,8 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
+            for (int it = 0; it < 8 * RT; ++it) {
+                const int rl = it * 4 + rsub, row = m0 + wm * (32 * RT) + rl;
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
@@ -1716,7 +1734,21 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int blocks2s = ((M + 127) / 128) * ((N + V2_BN - 1) / V2_BN);
         const size_t sh2s = (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) > (size_t)4 * 64 * 68 * sizeof(float)
                                 ? (size_t)3 * (2 * 128 * 64 + 2 * V2_BN * 64) : (size_t)4 * 64 * 68 * sizeof(float);
+        // Grids of 65-128 tiles of 128x128 leave half of the chip idle, and a workgroup's K tile is bound by its own MFMA issue (~0.55 us,
+        // whatever the ring depth or the wave count): they run on 64x128 tiles (<2, ., 1>: four waves of 32 x 64, twice the workgroups —
+        // [1182, 768, 768] 20.0 -> 14.2 us, [4095, 512, 2048] 46.1 -> 35.0, [771, 1024, 4096] 84 -> 62); larger grids on the eight-wave
+        // form of the 128x128 tile (<4, ., 1>: +2-3 %).  Same products in the same order: bit-identical (tools/gemm_mid_bench.py prints a
+        // checksum).  RLCF_V2S8=0: the four-wave 128x128 kernel everywhere (measurements)
+        static int v2s8 = -1;
+        if (v2s8 < 0) { const char* e = getenv("RLCF_V2S8"); v2s8 = e ? atoi(e) : 1; }
+        // (grids of <= 64 tiles keep the 128x128 tile with K slices: [1182, 768, 3072] 27 us so against 37 us on sliced half tiles)
+        const bool half_m = v2s8 && !single && blocks2s > 64 && blocks2s <= 128;
+        const bool eight = v2s8 && !single && !half_m;
+        const int blocks_h = ((M + 63) / 64) * ((N + V2_BN - 1) / V2_BN);
+        const int nblk = half_m ? blocks_h : blocks2s;           // workgroups per K slice
         if (single) X3_LDS((gemm_nt_f16x3_v2_kernel<2, true>), sh2s);
+        else if (eight) X3_LDS((gemm_nt_f16x3_v2_kernel<4, false, 1>), sh2s);
+        else if (half_m) X3_LDS((gemm_nt_f16x3_v2_kernel<2, false, 1>), sh2s);
         else X3_LDS((gemm_nt_f16x3_v2_kernel<2, false>), sh2s);
         // few tiles and a long K loop (one image's token matrix against a W x 4W / W x 3W weight): split the K loop over blockIdx.y
         // and finish in a reduce + epilogue pass (RLCF_X3_NOSPLITK=1 switches it off)
@@ -1724,22 +1756,24 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         if (nosplit < 0) { const char* e = getenv("RLCF_X3_NOSPLITK"); nosplit = e ? atoi(e) : 0; }
         const int nkt = K / X3_BK;
         int ksplit = 1;
-        if (!nosplit && blocks2s <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
+        if (!nosplit && nblk <= 128 && nkt >= 48) ksplit = nkt >= 96 ? 4 : 3;
         // ... and the 24-tile K loops of grids below a quarter of the chip (one image's reward tower: [1182, 768, 768] = 60 workgroups)
         // in three slices (bench.py --batch 1, with the 256x128 threshold below: 75.2-75.7 -> 76.6 images/s).  RLCF_X3_SPLIT24=0: off
         static int split24 = -1;
         if (split24 < 0) { const char* e = getenv("RLCF_X3_SPLIT24"); split24 = e ? atoi(e) : 2; }
-        if (split24 && !nosplit && ksplit == 1 && blocks2s <= 64 && nkt >= 24) ksplit = split24 + 1;
+        if (split24 && !nosplit && ksplit == 1 && nblk <= 64 && nkt >= 24) ksplit = split24 + 1;
         // a very long K loop over a small output (the weight gradient of a convolution: K = n*H*W = 10^5..10^6 rows): as many slices as
         // it takes to put ~384 workgroups on the chip, each at least 64 K tiles long, within the workspace
-        if (!nosplit && nkt >= 1024 && blocks2s < 384 && splitk_ws) {
+        if (!nosplit && nkt >= 1024 && nblk < 384 && splitk_ws) {
             const long by_ws = (long)(splitk_ws_bytes / ((size_t)M * N * sizeof(float)));
-            const long want = std::min<long>(std::min<long>((384 + blocks2s - 1) / blocks2s, nkt / 64), std::min<long>(by_ws, 64));      // (<= 64 slices of >= 64 K tiles: no slice is empty)
+            const long want = std::min<long>(std::min<long>((384 + nblk - 1) / nblk, nkt / 64), std::min<long>(by_ws, 64));      // (<= 64 slices of >= 64 K tiles: no slice is empty)
             if (want > ksplit) ksplit = (int)want;
         }
         if (ksplit > 1 && (!splitk_ws || (size_t)ksplit * M * N * sizeof(float) > splitk_ws_bytes)) ksplit = 1;
         g.ksplit = ksplit; g.ws = splitk_ws;
         if (single) gemm_nt_f16x3_v2_kernel<2, true><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
+        else if (eight) gemm_nt_f16x3_v2_kernel<4, false, 1><<<dim3(blocks2s, ksplit), dim3(512), sh2s, st>>>(g);
+        else if (half_m) gemm_nt_f16x3_v2_kernel<2, false, 1><<<dim3(blocks_h, ksplit), dim3(256), sh2s, st>>>(g);
         else gemm_nt_f16x3_v2_kernel<2, false><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
