@@ -394,3 +394,42 @@ def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
         o_other = model(other).cpu()
     assert (o_other - out3).abs().max() > 1e-3
     runtime.reset_session()
+
+
+@pytest.mark.parametrize("M,N,K", [(239, 512, 512), (200, 100, 96), (33, 36, 32), (256, 2048, 1536), (129, 64, 2080)])
+@pytest.mark.parametrize("mode", ["scale1", "amax_in", "local"])
+def test_gemm_skinny_matches_f64(L, dev, M, N, K, mode):
+    """rlcf_gemm_skinny (the few-row split-f16 product of the one-image path: A split in the kernel, coalesced loads staged through LDS,
+    K chunks of 64 with a half-empty last chunk when K % 64 == 32, K slices + ordered reduce from K = 1024): against the float64
+    product for the three operand scales — 1, from a producer's max|A|, per workgroup found in the kernel — on gradients-sized data
+    (1e-5) for the scaled modes; with bias, residual, the QuickGELU epilogue and its backward form; ragged M, N not a multiple of 32."""
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    lib = L.lib()
+    scale = 1.0 if mode == "scale1" else 1e-5
+    a = (synth.normal(13, f"sk.a.{M}.{K}", (M, K)) * scale).to(dev)
+    w = (synth.normal(13, f"sk.w.{N}.{K}", (N, K)) * K ** -0.5).to(dev)
+    b = (synth.normal(13, f"sk.b.{N}", (N,)) * 0.1 * scale).to(dev)
+    res = (synth.normal(13, f"sk.r.{M}.{N}", (M, N)) * scale).to(dev)
+    aux = synth.normal(13, f"sk.x.{M}.{N}", (M, N)).to(dev)
+    wp = torch.empty(N, K, device=dev)
+    L.check(lib.rlcf_split_pairs(w.data_ptr(), wp.data_ptr(), N * K, L.PREC_F16X3, st()))
+    amax = a.abs().max().reshape(1).contiguous()
+    ref0 = a.double() @ w.double().t() + b.double()
+    for epi, use_res in ((0, False), (0, True), (1, False), (2, True)):
+        if epi == 1 and mode != "scale1":
+            continue                                           # (QuickGELU of 1e-5-sized values is linear: nothing to see)
+        c = torch.full((M, N), float("nan"), device=dev)
+        L.check(lib.rlcf_gemm_skinny(a.data_ptr(), K, wp.data_ptr(), b.data_ptr(), res.data_ptr() if use_res else None, N,
+                                     aux.data_ptr() if epi == 2 else None, N if epi == 2 else 0, c.data_ptr(), N, M, N, K, 1.0, epi,
+                                     amax.data_ptr() if mode == "amax_in" else None, 1 if mode == "local" else 0, st()))
+        ref = ref0.clone()
+        if epi == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        if epi == 2:
+            x = aux.double(); sg = torch.sigmoid(1.702 * x)
+            ref = ref * (sg * (1 + 1.702 * x * (1 - sg)))
+        if use_res:
+            ref = ref + res.double()
+        assert torch.isfinite(c).all()
+        err = float((c.double() - ref).abs().max() / ref.abs().max())
+        assert err < (3e-6 if epi != 2 else 2e-5), (epi, use_res, err)
