@@ -433,3 +433,48 @@ def test_gemm_skinny_matches_f64(L, dev, M, N, K, mode):
         assert torch.isfinite(c).all()
         err = float((c.double() - ref).abs().max() / ref.abs().max())
         assert err < (3e-6 if epi != 2 else 2e-5), (epi, use_res, err)
+
+
+@pytest.mark.parametrize("M,N,K,epi,res,pair", [(1536, 1024, 512, 0, True, False), (1500, 1000, 768, 0, False, False), (1400, 1024, 512, 1, False, True),
+                                                (1536, 1024, 2048, 0, True, False)])
+def test_gemm_half_tile_and_eight_wave_forms_bit_identical(L, dev, M, N, K, epi, res, pair):
+    """The 128x128 split-f16 kernel's two new forms (gemm_f16x3.hip, RT = 1): grids of 65-128 tiles run on 64x128 tiles, the others on eight
+    waves.  One call over M rows (96 / 94 / 88 tiles: the half-tile form) against two calls over its halves (<= 64 tiles each: the
+    eight-wave form): every element is the same sum of the same products in the same order, so the outputs must be bit-identical — ragged
+    last row tile, N not a multiple of 128, residual, QuickGELU -> operand pairs, and a K loop long enough for K slices in the engine —
+    and within 3e-4 of the float64 product."""
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    lib = L.lib()
+    a = synth.normal(17, f"h.a.{M}.{K}", (M, K)).to(dev)
+    w = (synth.normal(17, f"h.w.{N}.{K}", (N, K)) * K ** -0.5).to(dev)
+    b = (synth.normal(17, f"h.b.{N}", (N,)) * 0.1).to(dev)
+    x = synth.normal(17, f"h.x.{M}.{N}", (M, N)).to(dev) if res else None
+
+    def pairs(t):
+        p = torch.empty(t.shape[0], t.shape[1], device=dev)
+        L.check(lib.rlcf_split_pairs(t.contiguous().data_ptr(), p.data_ptr(), t.numel(), L.PREC_F16X3, st()))
+        return p
+    a2, w2 = pairs(a), pairs(w)
+
+    def run(r0, r1):
+        rows = r1 - r0
+        c = None if pair else torch.empty(rows, N, device=dev)
+        ch = torch.empty(rows, N, dtype=torch.float16, device=dev) if pair else None
+        cl = torch.empty_like(ch) if pair else None
+        ap = a2.data_ptr() + r0 * K * 4
+        L.check(lib.rlcf_gemm_f16x3(ap, ap + 64, 2 * K, w2.data_ptr(), w2.data_ptr() + 64, 2 * K, b.data_ptr(), x[r0:r1].data_ptr() if res else None, N,
+                                    None, 0, c.data_ptr() if c is not None else None, N, ch.data_ptr() if pair else None,
+                                    cl.data_ptr() if pair else None, N, rows, N, K, 1.0, epi, st()))
+        torch.cuda.synchronize()
+        return torch.cat([ch, cl], dim=1).view(torch.int16) if pair else c.view(torch.int32)
+    whole = run(0, M)
+    h = (M // 2 + 63) // 64 * 64
+    parts = torch.cat([run(0, h), run(h, M)])
+    assert torch.equal(whole, parts)
+    whole = whole.view(torch.float32) if not pair else whole
+    if not pair:
+        rows = torch.arange(0, M, 37, device=dev)
+        ref = a[rows].double() @ w.double().t() + b.double()
+        if res:
+            ref = ref + x[rows].double()
+        assert float((whole[rows].double() - ref).abs().max()) < 3e-4
