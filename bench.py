@@ -265,6 +265,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo lets two ranks share one GPU in a smoke test")
     a = ap.parse_args()
+    # `python bench.py --gpus N` typed without a launcher: become N ranks under torch.distributed.run (rlcf_amd/shard.py)
+    rc = shard.self_launch(a.gpus, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     wl = CONFIGS[a.config]
     if a.steps is None: a.steps = wl.get("steps", 64)
     if a.warmup is None: a.warmup = wl.get("warmup", 32)

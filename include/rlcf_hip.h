@@ -90,6 +90,15 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo,
                     int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream);
 
+/* Single-pass f16 GEMM (RLCF_PREC_F16, the labelled performance mode — NOT parity-grade): the arithmetic of the reference's own GPU runs,
+ * every nn.Linear of TPT/clip/model.py:171-192 under torch.cuda.amp.autocast() (TPT/tpt_cls_rl.py:52,182,261): f16 operands, one f16 MFMA
+ * per product, f32 accumulate.  A [M,K] f16 (lda halves), W [N,K] f16 (ldw halves), bias f32 [N] or NULL; outputs: C f32 [M,N] (+ residual
+ * f32 [M,N], may alias C) and / or C16 f16 [M,N] (epilogue RLCF_EPI_NONE | RLCF_EPI_QUICKGELU applied before the f16 rounding).
+ * K % 64 == 0, N % 4 == 0, lda / ldw % 8 == 0.  Grids of >= 256 tiles of 256x128 run the dedicated 256x256 eight-phase kernel
+ * (rlcf_amd/csrc/gemm_f16.hip), smaller ones the 128x128 / 256x128 kernels. */
+int rlcf_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                  void* C16, int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream);
+
 /* 3x3 convolution, stride 1, padding 1, NHWC, as an IMPLICIT GEMM on the f16 matrix cores with split-f16 operands (no patch matrix: the
  * 256x256 GEMM kernel's DMA reads every tap's K tile straight from the activation's operand pairs): the `conv2` of a Bottleneck
  * (TPT/clip/model.py:20,44) with its BatchNorm folded, as the engine's ResNet towers run it.  x [n,H,W,Cin], w [Cout,3,3,Cin] ((ky,kx,c)

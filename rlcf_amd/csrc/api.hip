@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 8; }   // 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 9; }   // 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -66,6 +66,15 @@ int rlcf_split_f16x2(const float* x, void* hi, void* lo, int64_t n, rlcf_stream 
     RLCF_ARG_CHECK(x && hi && lo);
     return launch_split_f16x2(x, hi, lo, n, (hipStream_t)stream);
 }
+int rlcf_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                  void* C16, int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {
+    RLCF_ARG_CHECK(A && W && (C || C16) && M > 0 && N > 0 && K > 0 && K % 64 == 0);
+    RLCF_ARG_CHECK(epilogue == RLCF_EPI_NONE || epilogue == RLCF_EPI_QUICKGELU);
+    // (plain f16 rows: the "lo" pointers of the pair interface are the second 32 halves of every 64-half block)
+    return launch_gemm_f16x3(A, (const _Float16*)A + 32, lda, W, (const _Float16*)W + 32, ldw, bias, residual, ldr, nullptr, 0, C, ldc, C16, nullptr,
+                             ldch, M, N, K, alpha, epilogue, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, 0, 1);
+}
+
 int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                     int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {

@@ -1,0 +1,430 @@
+// Single-pass f16 GEMM for the performance mode (RLCF_PREC_F16): plain f16 operands, ONE v_mfma_f32_32x32x16_f16 per product, f32
+// accumulate — the arithmetic of the reference's own fp16-autocast GPU path (TPT/tpt_cls_rl.py:52; every nn.Linear of
+// TPT/clip/model.py:171-192 under torch.cuda.amp.autocast).  Not parity-grade; the split-f16 kernels of gemm_f16x3.hip are.
+//
+// C[M,N] = epi(alpha * A.W^T + bias) (+ residual);  A [M,K] f16 row-major (lda halves), W [N,K] f16 row-major (ldw halves), K % 64 == 0.
+//
+// Structure (its own kernel, not the K/2 alias of the pair kernels): 256x256 block tile, BK = 64, eight waves as 2 (M) x 4 (N), each
+// wave a contiguous 128x64 output block = 4x2 accumulator tiles of 32x32 (128 accumulator registers).  A K tile is FOUR half tiles of
+// 128 rows x 128 B (16 KB): A_lo / A_hi = the first / second 64 rows of every wave's 128, B_lo / B_hi = the first / second 32 columns
+// of every wave's 64 (the DMA's per-lane source address makes any row set free).  A K tile is worked through in four PHASES, one
+// accumulator quadrant (64 rows x 32 columns x K = 64: 8 MFMAs) each:
+//      P1 (A_lo, B_lo)   P2 (A_lo, B_hi)   P3 (A_hi, B_hi)   P4 (A_hi, B_lo)
+// so that each phase reads ONE new operand part from LDS (P1: both) and each half-tile buffer is free again right after the phase that
+// reads it last: A_lo after P1, B_hi after P2 (P3 re-uses P2's B_hi fragments from registers), A_hi after P3,
+// B_lo after P4.  Every phase therefore re-fills the buffer the previous phase freed with a half tile of K tile t+2 (P1: B_lo of t+1)
+// — 2 DMA instructions (global_load_lds_dwordx4, 1 KB each) per wave and phase, 1.75 K tiles of prefetch distance in TWO K tiles of
+// LDS (128 KB), one counted s_waitcnt vmcnt(6) per K tile (never 0 inside the loop).
+// A phase = [LDS reads of its operand part + its 2 DMA issues | s_barrier | 8 MFMAs | s_barrier]; the two wave groups (waves 0-3 /
+// 4-7 = the two waves of every SIMD) run ONE barrier apart, so one wave of each SIMD is always in its pure-MFMA section while the
+// other issues its reads and DMA (cdna_hip_programming.md, "256^2 8-phase template").
+// Ordering rules kept (same source): a buffer is read one phase after the vmcnt that retires it (each wave waits BEFORE its barrier,
+// the readers are past a later barrier); a buffer is re-staged one phase after its last read and every wave retires its reads
+// (lgkmcnt(0)) BEFORE the barrier that ends its read section, so the other group's reads are complete too.
+#include "gemm_x3.h"
+#include <cstdlib>
+#include <algorithm>
+
+#define P8_HALF 16384                   // bytes of a half tile: 128 rows x 128 B
+#define P8_PAR 65536                    // bytes of a K tile: A_lo | A_hi | B_lo | B_hi
+#define P8_B0 32768
+
+template <bool PRIO>
+__global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
+    float am = 0.f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR] (+ epilogue parking: 8 x 64 x 68 floats)
+    const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + 255) / 256;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // every XCD takes a contiguous range of tiles, walked in groups of G tile rows: M-fastest (neighbours share a W tile), N-fastest for
+    // problems 3-4 tiles wide (neighbours share the A panel) — the order of gemm_nt_f16x3_v3i_kernel
+    const int G = g.tile_group % 100 > 0 ? g.tile_group % 100 : 8;
+    const int per_group = G * tiles_n, grp = bid / per_group, first_m = grp * G;
+    const int gsize = min(tiles_m - first_m, G), in_g = bid - grp * per_group;
+    const bool nfast = g.tile_group >= 100 || (g.tile_group == 0 && tiles_n <= 4);
+    const int m0 = (nfast ? first_m + in_g / tiles_n : first_m + in_g % gsize) * 256;
+    const int n0 = (nfast ? in_g % tiles_n : in_g / gsize) * 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA: a half tile = 16 pieces of 8 rows x 128 B; wave w moves pieces 2w, 2w+1 = local rows 16w .. 16w+15.  LDS rows are 128 B; the
+    // 16-B chunk c of local row r sits in slot c ^ ((r >> 1) & 7) (applied to the SOURCE address: the DMA writes lane-linearly), so the
+    // 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) cover all 64 banks.
+    // source = scalar base of the tile's first row (+ the K tile) + a 32-bit per-lane byte offset inside the tile's rows
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const char* abase = (const char*)(g.Ahi + (size_t)m0 * g.lda);
+    const char* wbase = (const char*)(g.Whi + (size_t)n0 * g.ldw);
+    unsigned sa[2][2], sw[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr = wave * 16 + j * 8 + (lane >> 3), c = ((lane & 7) ^ ((lr >> 1) & 7)) * 16;
+            sa[hf][j] = (unsigned)(min((lr >> 6) * 128 + hf * 64 + (lr & 63), g.M - 1 - m0) * g.lda) * 2u + c;
+            sw[hf][j] = (unsigned)(min((lr >> 5) * 64 + hf * 32 + (lr & 31), g.N - 1 - n0) * g.ldw) * 2u + c;
+        }
+#define P8_STAGE_A(hf, kt)                                                                                                          \
+    {                                                                                                                               \
+        char* d_ = smem + ((kt) & 1) * P8_PAR + (hf) * P8_HALF + wave_s * 2048;                                                      \
+        const char* s_ = abase + (size_t)(kt) * 128;                                                                                \
+        __builtin_amdgcn_global_load_lds((gptr_t)(s_ + sa[hf][0]), (lptr_t)d_, 16, 0, 0);                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(s_ + sa[hf][1]), (lptr_t)(d_ + 1024), 16, 0, 0);                                   \
+    }
+#define P8_STAGE_B(hf, kt)                                                                                                          \
+    {                                                                                                                               \
+        char* d_ = smem + ((kt) & 1) * P8_PAR + P8_B0 + (hf) * P8_HALF + wave_s * 2048;                                              \
+        const char* s_ = wbase + (size_t)(kt) * 128;                                                                                \
+        __builtin_amdgcn_global_load_lds((gptr_t)(s_ + sw[hf][0]), (lptr_t)d_, 16, 0, 0);                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(s_ + sw[hf][1]), (lptr_t)(d_ + 1024), 16, 0, 0);                                   \
+    }
+    const int nk = g.K / 64;
+    // prologue: K tile 0 complete, then the three half tiles of K tile 1 the loop does not stage itself (B_lo of t+1 is staged by P1 of t)
+    P8_STAGE_A(0, 0) P8_STAGE_B(0, 0) P8_STAGE_B(1, 0) P8_STAGE_A(1, 0)
+    if (nk > 1) {
+        P8_STAGE_A(0, 1) P8_STAGE_B(1, 1) P8_STAGE_A(1, 1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int swz = (l32 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + h) ^ swz) * 16;
+    const int aoff = (wm * 64 + l32) * 128, boff = P8_B0 + (wn * 32 + l32) * 128;
+    h16x8 a[2][4], b[4];
+#define P8_LDA(hf, par)                                                                                                             \
+    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                            \
+            a[i2][ks] = *(const h16x8*)(smem + (par) * P8_PAR + (hf) * P8_HALF + aoff + i2 * 4096 + coff[ks]);
+#define P8_LDB(hf, par)                                                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b[ks] = *(const h16x8*)(smem + (par) * P8_PAR + (hf) * P8_HALF + boff + coff[ks]);
+#define P8_MMA(ib, j)                                                                                                               \
+    {                                                                                                                               \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                            \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                        \
+                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                                    \
+    }
+// end of a phase's read section: this wave's LDS reads are complete BEFORE it arrives (the buffer may be re-staged by the other group
+// right after this barrier)
+#define P8_MID                                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define P8_END                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define P8_KTILE(kt, par)                                                                                                           \
+    {                                                                                                                               \
+        P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
+        if ((kt) + 1 < nk) P8_STAGE_B(0, (kt) + 1)                                                                                  \
+        P8_MID P8_MMA(0, 0) P8_END                                                                                                  \
+        P8_LDB(1, par)                                                                                                              \
+        if ((kt) + 2 < nk) P8_STAGE_A(0, (kt) + 2)                                                                                  \
+        P8_MID P8_MMA(0, 1) P8_END                                                                                                  \
+        P8_LDA(1, par)                                                                                                              \
+        if ((kt) + 2 < nk) P8_STAGE_B(1, (kt) + 2)                                                                                  \
+        P8_MID P8_MMA(1, 1) P8_END                                                                                                  \
+        P8_LDB(0, par)                                                                                                              \
+        if ((kt) + 2 < nk) {                                                                                                        \
+            P8_STAGE_A(1, (kt) + 2)                                                                                                 \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                        \
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                     \
+        P8_MID P8_MMA(1, 0) P8_END                                                                                                  \
+    }
+    if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the second group runs one barrier behind
+    for (int kt = 0; kt < nk; kt += 2) {
+        P8_KTILE(kt, 0)
+        if (kt + 1 < nk) P8_KTILE(kt + 1, 1)
+    }
+    if (wm == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+    // epilogue: the compile-time forms of the forward towers (gemm_x3.h), each wave through its own 17-KB LDS slice
+    const int ek = x3_epilogue_kind(g);
+    float* parkf = (float*)smem + wave * (64 * 68);
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+        X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
+                         m0 + wm * 128 + half * 64, n0 + wn * 64, lane, am)
+    amax_commit(g.amax_out, am);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The PERSISTENT form for f16 outputs (in_proj -> Q/K/V, c_fc + QuickGELU, and — since round 5 — out_proj / c_proj, whose residual add
+// moved into the LayerNorm kernel that follows them: rowops.hip, layernorm_add_fwd).  With K = 768 a 256x256 tile is only 12 K tiles
+// long: launched one workgroup per tile, a third of every tile's time went to the first loads (nothing to compute on), the LDS-parked
+// epilogue and the write burst at the end of every tile round (SQ_VALU_MFMA_BUSY 0.44 of the active cycles against 0.67 at K = 8192:
+// profiles/r5_gemm_f16_counters.txt).  Here one workgroup per CU walks its XCD's tile range and
+//   * the DMA ring never drains: the last two K tiles of a tile stage the first 1.75 K tiles of the NEXT tile (buffer_load ... lds
+//     through a per-tile buffer descriptor: scalar base / soffset, one constant 32-bit lane offset per piece, rows beyond M / N read as
+//     zeros by the descriptor's range check — no clamps, no per-piece address arithmetic),
+//   * the epilogue uses no LDS and no barrier: alpha / bias / QuickGELU on the accumulators (bias is a per-lane constant in the 32x32
+//     accumulator layout), a 4x4 lane <-> register transpose inside every quad (two DPP quad_perm exchanges) that leaves each lane 4
+//     consecutive columns of one row, f16 rounding, 8-byte stores (8 lanes = 64 B of a row); the stores drain while the next tile's K
+//     loop runs,
+//   * the two wave groups line up for the epilogue (one extra barrier each per tile) so that both run it at the same time.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR]
+    const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + 255) / 256, ntiles = tiles_m * tiles_n;
+    // XCD x owns a contiguous range of the tile order; its G/8 workgroups walk it G/8 tiles at a time
+    const int wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+    const int tq = ntiles / 8, tr = ntiles % 8;
+    const int xstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, xend = xstart + tq + (xcd < tr ? 1 : 0);
+    int lin = xstart + widx;
+    if (lin >= xend) return;
+    const int G = g.tile_group % 100 > 0 ? g.tile_group % 100 : 8;
+    const bool nfast = g.tile_group >= 100 || (g.tile_group == 0 && tiles_n <= 4);
+    auto tile_origin = [&](int bid, int& m0_, int& n0_) {
+        const int per_group = G * tiles_n, grp = bid / per_group, first_m = grp * G;
+        const int gsize = min(tiles_m - first_m, G), in_g = bid - grp * per_group;
+        m0_ = (nfast ? first_m + in_g / tiles_n : first_m + in_g % gsize) * 256;
+        n0_ = (nfast ? in_g % tiles_n : in_g / gsize) * 256;
+    };
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+
+    // DMA lane offsets (bytes from the tile's first row; the same for every tile and K tile)
+    unsigned va[2][2], vw[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr = wave * 16 + j * 8 + (lane >> 3), c = ((lane & 7) ^ ((lr >> 1) & 7)) * 16;
+            va[hf][j] = (unsigned)(((lr >> 6) * 128 + hf * 64 + (lr & 63)) * g.lda) * 2u + c;
+            vw[hf][j] = (unsigned)(((lr >> 5) * 64 + hf * 32 + (lr & 31)) * g.ldw) * 2u + c;
+        }
+    auto rsrc_a = [&](int m0_) {
+        const size_t bytes = (size_t)(g.M - m0_) * g.lda * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(g.Ahi + (size_t)m0_ * g.lda), 0, (int)(unsigned)(bytes > 0xfffff000u ? 0xfffff000u : bytes), 0x00020000);
+    };
+    auto rsrc_w = [&](int n0_) {
+        const size_t bytes = (size_t)(g.N - n0_) * g.ldw * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(g.Whi + (size_t)n0_ * g.ldw), 0, (int)(unsigned)(bytes > 0xfffff000u ? 0xfffff000u : bytes), 0x00020000);
+    };
+#define PP_STAGE_A(hf, par, rs, kt)                                                                                                 \
+    {                                                                                                                               \
+        char* d_ = smem + (par) * P8_PAR + (hf) * P8_HALF + wave_s * 2048;                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)d_, 16, va[hf][0], (kt) * 128, 0, 0);                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(d_ + 1024), 16, va[hf][1], (kt) * 128, 0, 0);                           \
+    }
+#define PP_STAGE_B(hf, par, rs, kt)                                                                                                 \
+    {                                                                                                                               \
+        char* d_ = smem + (par) * P8_PAR + P8_B0 + (hf) * P8_HALF + wave_s * 2048;                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)d_, 16, vw[hf][0], (kt) * 128, 0, 0);                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(d_ + 1024), 16, vw[hf][1], (kt) * 128, 0, 0);                           \
+    }
+    const int nk = g.K / 64;                     // even (launcher)
+    int m0, n0;
+    tile_origin(lin, m0, n0);
+    auto ra = rsrc_a(m0), rw = rsrc_w(n0);
+    PP_STAGE_A(0, 0, ra, 0) PP_STAGE_B(0, 0, rw, 0) PP_STAGE_B(1, 0, rw, 0) PP_STAGE_A(1, 0, ra, 0)
+    PP_STAGE_A(0, 1, ra, 1) PP_STAGE_B(1, 1, rw, 1) PP_STAGE_A(1, 1, ra, 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int swz = (l32 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + h) ^ swz) * 16;
+    const int aoff = (wm * 64 + l32) * 128, boff = P8_B0 + (wn * 32 + l32) * 128;
+    h16x8 a[2][4], b[4];
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define PP_MMA(ib, j)                                                                                                               \
+    {                                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                            \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                        \
+                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+    }
+// one K tile of the steady state: stages B_lo of K tile kt+1 and the other three half tiles of kt+2, all of THIS tile
+#define PP_KTILE(kt, par)                                                                                                           \
+    {                                                                                                                               \
+        P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
+        PP_STAGE_B(0, (par) ^ 1, rw, (kt) + 1)                                                                                      \
+        P8_MID PP_MMA(0, 0) P8_END                                                                                                  \
+        P8_LDB(1, par)                                                                                                              \
+        PP_STAGE_A(0, par, ra, (kt) + 2)                                                                                            \
+        P8_MID PP_MMA(0, 1) P8_END                                                                                                  \
+        P8_LDA(1, par)                                                                                                              \
+        PP_STAGE_B(1, par, rw, (kt) + 2)                                                                                            \
+        P8_MID PP_MMA(1, 1) P8_END                                                                                                  \
+        P8_LDB(0, par)                                                                                                              \
+        PP_STAGE_A(1, par, ra, (kt) + 2)                                                                                            \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                            \
+        P8_MID PP_MMA(1, 0) P8_END                                                                                                  \
+    }
+// the last two K tiles of a tile: K tile nk-2 stages B_lo of nk-1 (this tile) and A_lo / B_hi / A_hi of the NEXT tile's K tile 0;
+// K tile nk-1 stages the next tile's B_lo of K tile 0 and A_lo / B_hi / A_hi of its K tile 1 (nothing when this is the last tile)
+#define PP_KTILE_TAIL(par, first)                                                                                                   \
+    {                                                                                                                               \
+        P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
+        if (first) PP_STAGE_B(0, (par) ^ 1, rw, nk - 1)                                                                             \
+        else if (have_next) PP_STAGE_B(0, (par) ^ 1, rwn, 0)                                                                        \
+        P8_MID PP_MMA(0, 0) P8_END                                                                                                  \
+        P8_LDB(1, par)                                                                                                              \
+        if (have_next) PP_STAGE_A(0, par, ran, (first) ? 0 : 1)                                                                     \
+        P8_MID PP_MMA(0, 1) P8_END                                                                                                  \
+        P8_LDA(1, par)                                                                                                              \
+        if (have_next) PP_STAGE_B(1, par, rwn, (first) ? 0 : 1)                                                                     \
+        P8_MID PP_MMA(1, 1) P8_END                                                                                                  \
+        P8_LDB(0, par)                                                                                                              \
+        if (have_next) {                                                                                                            \
+            PP_STAGE_A(1, par, ran, (first) ? 0 : 1)                                                                                \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                        \
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                     \
+        P8_MID PP_MMA(1, 0) P8_END                                                                                                  \
+    }
+    const float al = g.alpha;
+    const int i0 = lane & 1, i1 = (lane >> 1) & 1;
+    if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the second group runs one barrier behind
+    for (;;) {
+        const int nlin = lin + wpx;
+        const bool have_next = nlin < xend;
+        int m0n = 0, n0n = 0;
+        if (have_next) tile_origin(nlin, m0n, n0n);
+        auto ran = rsrc_a(m0n), rwn = rsrc_w(n0n);
+        for (int kt = 0; kt + 2 < nk; kt += 2) {
+            PP_KTILE(kt, 0)
+            PP_KTILE(kt + 1, 1)
+        }
+        PP_KTILE_TAIL(0, true)
+        PP_KTILE_TAIL(1, false)
+        // ---- epilogue of this tile, both groups at the same time
+        if (wm == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        {
+            const int colb = n0 + wn * 64 + l32;                           // bias: a per-lane constant in the accumulator layout
+            float bj[2] = {0.f, 0.f};
+            if (g.bias) { bj[0] = colb < g.N ? g.bias[colb] : 0.f; bj[1] = colb + 32 < g.N ? g.bias[colb + 32] : 0.f; }
+            const int ocol = n0 + wn * 64 + (l32 >> 2) * 4;                // after the transpose: 4 columns from here, row (lane & 3) of a 4-row group
+            const int orow = m0 + wm * 128 + 4 * h + (lane & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16& c = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = al * c[r] + bj[j];
+                        if constexpr (EPI == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
+                        c[r] = v;
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float r0 = c[gq * 4], r1 = c[gq * 4 + 1], r2 = c[gq * 4 + 2], r3 = c[gq * 4 + 3];
+                        // lane bit 0 <-> register bit 0, then lane bit 1 <-> register bit 1 (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
+#define PP_DPP(x, ctl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctl, 0xf, 0xf, true))
+                        const float p0 = PP_DPP(r0, 0xB1), p1 = PP_DPP(r1, 0xB1), p2 = PP_DPP(r2, 0xB1), p3 = PP_DPP(r3, 0xB1);
+                        const float s0 = i0 ? p1 : r0, s1 = i0 ? r1 : p0, s2 = i0 ? p3 : r2, s3 = i0 ? r3 : p2;
+                        const float q0 = PP_DPP(s0, 0x4E), q1 = PP_DPP(s1, 0x4E), q2 = PP_DPP(s2, 0x4E), q3 = PP_DPP(s3, 0x4E);
+                        const float t0 = i1 ? q2 : s0, t2 = i1 ? s2 : q0, t1 = i1 ? q3 : s1, t3 = i1 ? s3 : q1;
+                        const int row = orow + i * 32 + gq * 8, col = ocol + j * 32;
+                        if (row < g.M && col < g.N) {
+                            h16x4 o = {(_Float16)t0, (_Float16)t1, (_Float16)t2, (_Float16)t3};
+                            *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = o;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                }
+        }
+        if (!have_next) break;
+        if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // back to one barrier behind
+        lin = nlin; m0 = m0n; n0 = n0n; ra = ran; rw = rwn;
+    }
+#endif
+}
+
+// which launches take this kernel: the compile-time epilogues (f32 out; f32 out + residual; QuickGELU -> f16; f16 only) — the four
+// products of a ViT layer in the single-pass forward pipeline.  RLCF_F16_P8=0 switches it off (the K/2 alias kernels: A/B measurements)
+bool gemm_f16_p8_ok(const void* C, const void* Chi, const float* residual, const float* aux, int epilogue, const float* alpha_dev,
+                    unsigned int* amax_out, const float* out_scale_dev, int N, int K, int lda, int ldw, int ldc, int ldr, int ldch) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("RLCF_F16_P8"); on = e ? atoi(e) : 1; }
+    if (!on || aux || alpha_dev || amax_out || out_scale_dev) return false;
+    if (K % 64 || N % 4 || lda % 8 || ldw % 8 || ldc % 4 || ldr % 4 || ldch % 4) return false;
+    const bool f32o = C != nullptr, f16o = Chi != nullptr, res = residual != nullptr;
+    if (epilogue == RLCF_EPI_NONE && f32o && !f16o) return true;                 // kinds 1 / 2
+    if (epilogue == RLCF_EPI_NONE && !f32o && f16o && !res) return true;         // kind 4
+    if (epilogue == RLCF_EPI_QUICKGELU && !f32o && f16o && !res) return true;    // kind 3
+    return false;
+}
+
+// RLCF_F16_PP=0: the one-workgroup-per-tile kernel for f16 outputs too (A/B measurements)
+static int f16_pp_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("RLCF_F16_PP"); on = e ? atoi(e) : 1; }
+    return on;
+}
+
+int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                       void* Cf16, int ldch, int M, int N, int K, float alpha, int epilogue, int tile_group, hipStream_t st) {
+    RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0 && A && W && (C || Cf16));
+    GemmX3Args g{};
+    g.Ahi = (const _Float16*)A; g.Alo = nullptr; g.lda = lda; g.Whi = (const _Float16*)W; g.Wlo = nullptr; g.ldw = ldw;
+    g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Chi = (_Float16*)Cf16; g.Clo = nullptr; g.ldch = ldch;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.kstep = 64; g.ksplit = 1; g.tile_group = tile_group;
+    const int blocks = ((M + 255) / 256) * ((N + 255) / 256);
+    if (f16_pp_enabled() && !C && !residual && Cf16 && K % 128 == 0 && ldch % 4 == 0 && (size_t)256 * lda * 2 < 0x7fffffffu && (size_t)256 * ldw * 2 < 0x7fffffffu) {
+        // persistent form: one workgroup per CU (a multiple of 8: the XCDs take equal shares of the workgroups)
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
+        const size_t shp = (size_t)2 * P8_PAR;
+        if (epilogue == RLCF_EPI_QUICKGELU) {
+            int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<RLCF_EPI_QUICKGELU>, shp);
+            if (rc != RLCF_OK) return rc;
+            gemm_nt_f16_pp_kernel<RLCF_EPI_QUICKGELU><<<dim3(grid), dim3(512), shp, st>>>(g);
+        } else {
+            int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<RLCF_EPI_NONE>, shp);
+            if (rc != RLCF_OK) return rc;
+            gemm_nt_f16_pp_kernel<RLCF_EPI_NONE><<<dim3(grid), dim3(512), shp, st>>>(g);
+        }
+        RLCF_LAUNCH_CHECK();
+        return RLCF_OK;
+    }
+    const size_t sh = (size_t)8 * 64 * 68 * sizeof(float);               // 139 264 B: the parking space of the epilogue > 2 K tiles (131 072 B)
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("RLCF_F16_P8_PRIO"); prio = e ? atoi(e) : 1; }
+    if (prio) {
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_p8_kernel<true>, sh);
+        if (rc != RLCF_OK) return rc;
+        gemm_nt_f16_p8_kernel<true><<<dim3(blocks), dim3(512), sh, st>>>(g);
+    } else {
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_p8_kernel<false>, sh);
+        if (rc != RLCF_OK) return rc;
+        gemm_nt_f16_p8_kernel<false><<<dim3(blocks), dim3(512), sh, st>>>(g);
+    }
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

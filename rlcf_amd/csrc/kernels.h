@@ -70,6 +70,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       int single = 0 /* plain f16 operands, one MFMA per product (RLCF_PREC_F16): see GemmX3Args */,
                       const float* out_scale_dev = nullptr /* device scalar multiplied into the split output (GemmX3Args) */,
                       unsigned* sk_epoch = nullptr /* host launch counter of this workspace: enables the stream-K tail of the 256x256 kernel */);
+// gemm_f16.hip: the dedicated single-pass f16 kernel (256x256 tile, eight phases per two K tiles) and its applicability test
+bool gemm_f16_p8_ok(const void* C, const void* Chi, const float* residual, const float* aux, int epilogue, const float* alpha_dev,
+                    unsigned int* amax_out, const float* out_scale_dev, int N, int K, int lda, int ldw, int ldc, int ldr, int ldch);
+int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                       void* Cf16, int ldch, int M, int N, int K, float alpha, int epilogue, int tile_group, hipStream_t st);
 // M <= 256 rows of an f32 activation against a pre-split (interleaved-pair) weight, A split in the kernel (gemm_f16x3.hip)
 bool gemm_skinny_x3_ok(int M, int N, int K, int lda, int ldc);
 int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const float* bias, const float* residual, int ldr, const float* aux,

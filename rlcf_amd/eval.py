@@ -20,6 +20,7 @@ import argparse
 import hashlib
 import json
 import os
+import sys
 import time
 
 import torch
@@ -149,6 +150,9 @@ def main(argv=None):
     ap.add_argument("--keep-logits", type=int, default=0, help="also report the final logits of stream samples [0, K) (must lie in rank 0's shard)")
     ap.add_argument("--out", default="", help="also write the JSON record to this file")
     a = ap.parse_args(argv)
+    rc = shard.self_launch(a.gpus, list(argv) if argv is not None else sys.argv[1:], module="rlcf_amd.eval")      # --gpus N without a launcher
+    if rc is not None:
+        sys.exit(rc)
     rec = run(a)
     if rec:
         line = json.dumps(rec)

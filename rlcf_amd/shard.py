@@ -3,7 +3,11 @@ reference TPT/tpt_cls_rl.py:251-255), so the data path needs no collective: rank
 The only communication is the end-of-dataset reduction of the hit counters (RCCL all_reduce on GPUs, gloo in tests)."""
 from __future__ import annotations
 
-from typing import Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -30,3 +34,23 @@ def reduce_hits(top1_hits: int, top5_hits: int, n: int, device="cpu") -> Tuple[f
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     a, b, c = (int(x) for x in t.tolist())
     return 100.0 * a / max(c, 1), 100.0 * b / max(c, 1), c
+
+
+def self_launch(n_gpus: int, script_argv: List[str], module: Optional[str] = None) -> Optional[int]:
+    """`python bench.py --gpus N` / `python -m rlcf_amd.eval --gpus N` typed WITHOUT a launcher: when N > 1 and no rank environment is
+    present (WORLD_SIZE unset), start the same command line as N ranks — one process per GPU — under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the launch the driver itself uses) and return its exit code; return None
+    when this process already IS a rank (or N == 1) and should simply run.  The port is a free one of the loopback interface, so two
+    such commands can run side by side.  The ranks' stdout / stderr are inherited: rank 0's JSON line is this command's JSON line."""
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)]
+    cmd += (["-m", module] if module else [os.path.abspath(sys.argv[0])]) + list(script_argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    return subprocess.call(cmd, env=env)

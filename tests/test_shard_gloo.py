@@ -46,3 +46,35 @@ def test_two_ranks_gloo():
     assert seeds == [1000 + i for i in range(11)]                     # every sample exactly once, placement-independent seeds
     for _, _, a1, a5, n in res:                                       # both ranks hold the same reduced result
         assert n == 11 and abs(a1 - 100.0 * 4 / 11) < 1e-9 and abs(a5 - 100.0 * 6 / 11) < 1e-9
+
+
+def test_self_launch_becomes_n_ranks(tmp_path):
+    """`python <script> --gpus 2` typed without a launcher (no WORLD_SIZE): shard.self_launch starts the same command line as two ranks
+    under torch.distributed.run on 127.0.0.1 (what bench.py / rlcf_amd.eval do first thing); inside a rank it is a no-op."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "probe.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from rlcf_amd import shard\n"
+        "rc = shard.self_launch(2, sys.argv[1:])\n"
+        "if rc is not None:\n"
+        "    print('parent rc', rc); sys.exit(rc)\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "print('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'], 'args', sys.argv[1:], 'master', os.environ['MASTER_ADDR'], flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert "rank 0 of 2 args ['--gpus', '2', '--steps', '3'] master 127.0.0.1" in out and "rank 1 of 2" in out and "parent rc 0" in out
+    # a process that already is a rank (or N == 1) just runs
+    assert shard.self_launch(1, []) is None
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        assert shard.self_launch(2, []) is None
+    finally:
+        del os.environ["WORLD_SIZE"]
