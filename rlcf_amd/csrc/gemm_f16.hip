@@ -209,7 +209,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         for (int j = 0; j < 2; ++j) {
             const int lr = wave * 16 + j * 8 + (lane >> 3), c = ((lane & 7) ^ ((lr >> 1) & 7)) * 16;
             va[hf][j] = (unsigned)(((lr >> 6) * 128 + hf * 64 + (lr & 63)) * g.lda) * 2u + c;
-            vw[hf][j] = (unsigned)(((lr >> 5) * 64 + hf * 32 + (lr & 31)) * g.ldw) * 2u + c;
+            // B half tiles: the two 32-column accumulator tiles of a wave interleave at 4-column granularity (tile j holds columns 8 q + 4 j
+            // + {0..3} of the wave's 64), so that after the epilogue's 4x4 transpose a lane owns 8 CONSECUTIVE columns of a row: 16-byte stores
+            vw[hf][j] = (unsigned)(((lr >> 5) * 64 + ((lr & 31) >> 2) * 8 + hf * 4 + (lr & 3)) * g.ldw) * 2u + c;
         }
     auto rsrc_a = [&](int m0_) {
         const size_t bytes = (size_t)(g.M - m0_) * g.lda * 2;
@@ -232,6 +234,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(d_ + 1024), 16, vw[hf][1], (kt) * 128, 0, 0);                           \
     }
     const int nk = g.K / 64;                     // even (launcher)
+    // De-synchronised cohorts: all workgroups start together and every tile takes the same time, so the epilogues of all 256 CUs — 32 MB
+    // of stores — would hit the fabric in the same ~4 us of every tile round, and the next tile's first loads queue behind them (s_memtime
+    // trace: the K loop after a store burst runs 20 % slower per K tile than in the middle of a long tile).  Cohort c of P (by the
+    // workgroup's index inside its XCD) therefore starts c / P of a tile late: the bursts of the cohorts interleave with the others' K loops.
+    if (g.sk_blocks > 1 || g.sk_blocks < -1) {
+        const int P = g.sk_blocks > 0 ? g.sk_blocks : -g.sk_blocks;
+        const int c = g.sk_blocks > 0 ? widx % P : xcd % P;                 // (negative: whole XCDs as cohorts — their workgroups stay in step)
+        const int cyc = c * (nk * 2800 + 6000) / P;              // ~ cycles per tile: 8 intervals of ~350 per K tile + epilogue
+        for (int q = cyc >> 10; q > 0; --q) __builtin_amdgcn_s_sleep(16);            // (s_sleep counts 64-cycle units)
+    }
     int m0, n0;
     tile_origin(lin, m0, n0);
     auto ra = rsrc_a(m0), rw = rsrc_w(n0);
@@ -248,12 +260,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     const int aoff = (wm * 64 + l32) * 128, boff = P8_B0 + (wn * 32 + l32) * 128;
     h16x8 a[2][4], b[4];
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// first K tile of a tile: the first product of every accumulator takes C = 0 (no zero fill, and the accumulators are not live across the
+// tile boundary: the epilogue's outputs and the deferred stores use their registers)
+#define PP_MMA0(ib, j)                                                                                                              \
+    {                                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                            \
+            acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][0], b[0], zero16, 0, 0, 0);                         \
+        _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                                            \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                        \
+                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+    }
 #define PP_MMA(ib, j)                                                                                                               \
     {                                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                              \
@@ -262,23 +281,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                 acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
         __builtin_amdgcn_s_setprio(0);                                                                                              \
     }
-// one K tile of the steady state: stages B_lo of K tile kt+1 and the other three half tiles of kt+2, all of THIS tile
-#define PP_KTILE(kt, par)                                                                                                           \
+// one K tile of the steady state: stages B_lo of K tile kt+1 and the other three half tiles of kt+2, all of THIS tile.  MMA_ = PP_MMA, or
+// PP_MMA0 for K tile 0; H_(n) = a hook in the read section of phase n (unused: deferring the epilogue's stores into the next tile's K tile
+// 0 needs 64 more registers than hipcc finds without spilling — measured, profiles/KERNEL_NOTES.md)
+#define PP_KTILE_X(kt, par, MMA_, H_)                                                                                               \
     {                                                                                                                               \
         P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
         PP_STAGE_B(0, (par) ^ 1, rw, (kt) + 1)                                                                                      \
-        P8_MID PP_MMA(0, 0) P8_END                                                                                                  \
+        H_(0)                                                                                                                       \
+        P8_MID MMA_(0, 0) P8_END                                                                                                    \
         P8_LDB(1, par)                                                                                                              \
         PP_STAGE_A(0, par, ra, (kt) + 2)                                                                                            \
-        P8_MID PP_MMA(0, 1) P8_END                                                                                                  \
+        H_(1)                                                                                                                       \
+        P8_MID MMA_(0, 1) P8_END                                                                                                    \
         P8_LDA(1, par)                                                                                                              \
         PP_STAGE_B(1, par, rw, (kt) + 2)                                                                                            \
-        P8_MID PP_MMA(1, 1) P8_END                                                                                                  \
+        H_(2)                                                                                                                       \
+        P8_MID MMA_(1, 1) P8_END                                                                                                    \
         P8_LDB(0, par)                                                                                                              \
         PP_STAGE_A(1, par, ra, (kt) + 2)                                                                                            \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                            \
-        P8_MID PP_MMA(1, 0) P8_END                                                                                                  \
+        H_(3)                                                                                                                       \
+        P8_MID MMA_(1, 0) P8_END                                                                                                    \
     }
+#define PP_NOHOOK(n)
+#define PP_KTILE(kt, par) PP_KTILE_X(kt, par, PP_MMA, PP_NOHOOK)
 // the last two K tiles of a tile: K tile nk-2 stages B_lo of nk-1 (this tile) and A_lo / B_hi / A_hi of the NEXT tile's K tile 0;
 // K tile nk-1 stages the next tile's B_lo of K tile 0 and A_lo / B_hi / A_hi of its K tile 1 (nothing when this is the last tile)
 #define PP_KTILE_TAIL(par, first)                                                                                                   \
@@ -303,56 +330,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     const float al = g.alpha;
     const int i0 = lane & 1, i1 = (lane >> 1) & 1;
     if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the second group runs one barrier behind
+    // (measurement: g.ws != null -> s_memtime stamps of waves 0 / 4 for the first 64 tiles of every workgroup: K loop start, K loop end,
+    //  groups lined up, epilogue issued)
+    unsigned long long* trace = (unsigned long long*)g.ws;
+    int tile_it = 0;
+#define PP_STAMP(k) if (trace && (wave & 3) == 0 && lane == 0 && tile_it < 64) trace[(((size_t)blockIdx.x * 64 + tile_it) * 2 + wm) * 16 + (k)] = __builtin_amdgcn_s_memtime();
     for (;;) {
         const int nlin = lin + wpx;
         const bool have_next = nlin < xend;
+        PP_STAMP(0)
         int m0n = 0, n0n = 0;
         if (have_next) tile_origin(nlin, m0n, n0n);
         auto ran = rsrc_a(m0n), rwn = rsrc_w(n0n);
-        for (int kt = 0; kt + 2 < nk; kt += 2) {
+        PP_KTILE_X(0, 0, PP_MMA0, PP_NOHOOK)
+        PP_KTILE(1, 1)
+        if (trace) { PP_STAMP(4) }
+        for (int kt = 2; kt + 2 < nk; kt += 2) {
             PP_KTILE(kt, 0)
             PP_KTILE(kt + 1, 1)
+            if (trace && kt < 20) { PP_STAMP(4 + (kt >> 1)) }
         }
         PP_KTILE_TAIL(0, true)
         PP_KTILE_TAIL(1, false)
         // ---- epilogue of this tile, both groups at the same time
+        PP_STAMP(1)
         if (wm == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-        {
-            const int colb = n0 + wn * 64 + l32;                           // bias: a per-lane constant in the accumulator layout
+        PP_STAMP(2)
+        if (g.ksplit != 2) {                                                // (ksplit 2: measurement without any epilogue)
+            // accumulator tile j, lane l32 = column 8 (l32 >> 2) + 4 j + (l32 & 3) of the wave's 64: bias is a per-lane constant
+            const int colb = n0 + wn * 64 + (l32 >> 2) * 8 + (l32 & 3);
             float bj[2] = {0.f, 0.f};
-            if (g.bias) { bj[0] = colb < g.N ? g.bias[colb] : 0.f; bj[1] = colb + 32 < g.N ? g.bias[colb + 32] : 0.f; }
-            const int ocol = n0 + wn * 64 + (l32 >> 2) * 4;                // after the transpose: 4 columns from here, row (lane & 3) of a 4-row group
+            if (g.bias) { bj[0] = colb < g.N ? g.bias[colb] : 0.f; bj[1] = colb + 4 < g.N ? g.bias[colb + 4] : 0.f; }
+            // after the transposes: lane = row (lane & 3) of a 4-row group, columns 8 (l32 >> 2) .. + 7 (tile 0's four, then tile 1's four)
+            const int ocol = n0 + wn * 64 + (l32 >> 2) * 8;
             const int orow = m0 + wm * 128 + 4 * h + (lane & 3);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16& c = acc[i][j];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = al * c[r] + bj[j];
-                        if constexpr (EPI == RLCF_EPI_QUICKGELU) v = quick_gelu_fast(v);
-                        c[r] = v;
-                    }
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float r0 = c[gq * 4], r1 = c[gq * 4 + 1], r2 = c[gq * 4 + 2], r3 = c[gq * 4 + 3];
-                        // lane bit 0 <-> register bit 0, then lane bit 1 <-> register bit 1 (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
+            const bool inside = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;       // (whole tile, 16-byte aligned rows: no masks)
+            _Float16* obase = g.Chi + (size_t)orow * g.ldch + ocol;
 #define PP_DPP(x, ctl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctl, 0xf, 0xf, true))
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    h16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x16& c = acc[i][j];
+                        float r0 = al * c[gq * 4] + bj[j], r1 = al * c[gq * 4 + 1] + bj[j], r2 = al * c[gq * 4 + 2] + bj[j], r3 = al * c[gq * 4 + 3] + bj[j];
+                        if constexpr (EPI == RLCF_EPI_QUICKGELU) { r0 = quick_gelu_fast(r0); r1 = quick_gelu_fast(r1); r2 = quick_gelu_fast(r2); r3 = quick_gelu_fast(r3); }
+                        // lane bit 0 <-> register bit 0, then lane bit 1 <-> register bit 1 (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
                         const float p0 = PP_DPP(r0, 0xB1), p1 = PP_DPP(r1, 0xB1), p2 = PP_DPP(r2, 0xB1), p3 = PP_DPP(r3, 0xB1);
                         const float s0 = i0 ? p1 : r0, s1 = i0 ? r1 : p0, s2 = i0 ? p3 : r2, s3 = i0 ? r3 : p2;
                         const float q0 = PP_DPP(s0, 0x4E), q1 = PP_DPP(s1, 0x4E), q2 = PP_DPP(s2, 0x4E), q3 = PP_DPP(s3, 0x4E);
                         const float t0 = i1 ? q2 : s0, t2 = i1 ? s2 : q0, t1 = i1 ? q3 : s1, t3 = i1 ? s3 : q1;
-                        const int row = orow + i * 32 + gq * 8, col = ocol + j * 32;
-                        if (row < g.M && col < g.N) {
-                            h16x4 o = {(_Float16)t0, (_Float16)t1, (_Float16)t2, (_Float16)t3};
-                            *(h16x4*)(g.Chi + (size_t)row * g.ldch + col) = o;
+                        o[j * 4] = (_Float16)t0; o[j * 4 + 1] = (_Float16)t1; o[j * 4 + 2] = (_Float16)t2; o[j * 4 + 3] = (_Float16)t3;
+                    }
+                    _Float16* op = obase + (size_t)(i * 32 + gq * 8) * g.ldch;
+                    if (g.ksplit == 1 && o[0] != (_Float16)123.0f) continue;            // (measurement: no stores)
+                    if (inside) *(h16x8*)op = o;
+                    else {
+                        const int row = orow + i * 32 + gq * 8;
+                        if (row < g.M) {
+                            if (ocol + 8 <= g.N && (g.ldch & 7) == 0) *(h16x8*)op = o;
+                            else {
+                                if (ocol + 4 <= g.N) *(h16x4*)op = h16x4{o[0], o[1], o[2], o[3]};
+                                if (ocol + 8 <= g.N) *(h16x4*)(op + 4) = h16x4{o[4], o[5], o[6], o[7]};
+                            }
                         }
                     }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
                 }
+            }
         }
+        PP_STAMP(3)
+        ++tile_it;
         if (!have_next) break;
         if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // back to one barrier behind
         lin = nlin; m0 = m0n; n0 = n0n; ra = ran; rw = rwn;
@@ -389,8 +438,10 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
     g.Ahi = (const _Float16*)A; g.Alo = nullptr; g.lda = lda; g.Whi = (const _Float16*)W; g.Wlo = nullptr; g.ldw = ldw;
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Chi = (_Float16*)Cf16; g.Clo = nullptr; g.ldch = ldch;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.kstep = 64; g.ksplit = 1; g.tile_group = tile_group;
+    static int abl = -1;                                     // RLCF_F16_PP_ABL: measurement ablations of the persistent kernel (wrong results)
+    if (abl < 0) { const char* e = getenv("RLCF_F16_PP_ABL"); abl = e ? atoi(e) : 0; }
     const int blocks = ((M + 255) / 256) * ((N + 255) / 256);
-    if (f16_pp_enabled() && !C && !residual && Cf16 && K % 128 == 0 && ldch % 4 == 0 && (size_t)256 * lda * 2 < 0x7fffffffu && (size_t)256 * ldw * 2 < 0x7fffffffu) {
+    if (f16_pp_enabled() && !C && !residual && Cf16 && K % 128 == 0 && K >= 256 && ldch % 4 == 0 && (size_t)256 * lda * 2 < 0x7fffffffu && (size_t)256 * ldw * 2 < 0x7fffffffu) {
         // persistent form: one workgroup per CU (a multiple of 8: the XCDs take equal shares of the workgroups)
         static int ncu = 0;
         if (!ncu) {
@@ -401,6 +452,20 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
         }
         const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
         const size_t shp = (size_t)2 * P8_PAR;
+        g.ksplit = abl;
+        static int desync = -1;                              // RLCF_F16_PP_DESYNC=P: start-time cohorts (1 = all together)
+        if (desync < 0) { const char* e = getenv("RLCF_F16_PP_DESYNC"); desync = e ? atoi(e) : 1; }
+        g.sk_blocks = blocks > grid ? desync : 1;            // (one tile per workgroup: nothing to interleave)
+        // RLCF_F16_PP_TRACE=1 (measurement): stamp buffer, dumped after every launch (synchronises: not for timing runs)
+        static int trace_on = -1;
+        static unsigned long long* trace_buf = nullptr;
+        if (trace_on < 0) { const char* e = getenv("RLCF_F16_PP_TRACE"); trace_on = e ? atoi(e) : 0; }
+        const size_t trace_n = (size_t)256 * 64 * 2 * 16;
+        if (trace_on) {
+            if (!trace_buf) RLCF_HIP_CHECK(hipMalloc((void**)&trace_buf, trace_n * 8));
+            RLCF_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
+            g.ws = (float*)trace_buf;
+        }
         if (epilogue == RLCF_EPI_QUICKGELU) {
             int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<RLCF_EPI_QUICKGELU>, shp);
             if (rc != RLCF_OK) return rc;
@@ -411,6 +476,34 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
             gemm_nt_f16_pp_kernel<RLCF_EPI_NONE><<<dim3(grid), dim3(512), shp, st>>>(g);
         }
         RLCF_LAUNCH_CHECK();
+        if (trace_on) {
+            static unsigned long long* host = nullptr;
+            if (!host) host = (unsigned long long*)malloc(trace_n * 8);
+            RLCF_HIP_CHECK(hipStreamSynchronize(st));
+            RLCF_HIP_CHECK(hipMemcpy(host, trace_buf, trace_n * 8, hipMemcpyDeviceToHost));
+            // per group: mean cycles of K loop / line-up wait / epilogue / tile-to-tile, over the tiles 1.. of a few workgroups
+            for (int wgi : {0, 1, 8, 100, 255}) {
+                if (wgi >= grid) continue;
+                for (int grp = 0; grp < 2; ++grp) {
+                    double kl = 0, lu = 0, ep = 0, tt = 0, pairs[10] = {0}; int n = 0;
+                    for (int ti = 1; ti < 64; ++ti) {
+                        const unsigned long long* r = host + (((size_t)wgi * 64 + ti) * 2 + grp) * 16;
+                        const unsigned long long* pr = r - 32;
+                        if (!r[3] || !pr[0]) break;
+                        kl += (double)(r[1] - r[0]); lu += (double)(r[2] - r[1]); ep += (double)(r[3] - r[2]); tt += (double)(r[0] - pr[0]); ++n;
+                        unsigned long long prev = r[0];
+                        for (int q = 0; q < 10 && 2 * q + 2 < K / 64; ++q) { pairs[q] += (double)(r[4 + q] - prev); prev = r[4 + q]; }
+                    }
+                    if (n) {
+                        fprintf(stderr, "[pp trace]   K-tile pairs:");
+                        for (int q = 0; q < 10 && 2 * q + 2 < K / 64; ++q) fprintf(stderr, " %.0f", pairs[q] / n);
+                        fprintf(stderr, "\n");
+                    }
+                    if (n) fprintf(stderr, "[pp trace] M=%d N=%d K=%d wg %3d group %d: tiles %2d  K loop %.0f  line-up %.0f  epilogue %.0f  tile-to-tile %.0f (s_memtime ticks)\n",
+                                   M, N, K, wgi, grp, n, kl / n, lu / n, ep / n, tt / n);
+                }
+            }
+        }
         return RLCF_OK;
     }
     const size_t sh = (size_t)8 * 64 * 68 * sizeof(float);               // 139 264 B: the parking space of the epilogue > 2 K tiles (131 072 B)

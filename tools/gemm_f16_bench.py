@@ -10,11 +10,13 @@ W = 768
 rows_n = 64
 tag = "alias" if os.environ.get("RLCF_F16_P8") == "0" else ("p8" if os.environ.get("RLCF_F16_PP") == "0" else "pp")
 tot_ms, tot_fl = 0.0, 0.0
+only = os.environ.get('BENCH_ONLY', '')          # substring of the shape names to run (PMC passes: one shape per pass)
 for name, M, N, K, epi, res, f16o in [("in_proj->f16", M0, 3 * W, W, 0, False, True), ("out_proj->f16", M0, W, W, 0, False, True),
                                       ("c_fc+gelu->f16", M0, 4 * W, W, 1, False, True), ("c_proj->f16", M0, W, 4 * W, 0, False, True),
                                       ("out_proj+res f32", M0, W, W, 0, True, False), ("c_proj+res f32", M0, W, 4 * W, 0, True, False),
                                       ("square8k f16out", 8192, 8192, 8192, 0, False, True), ("square8k f32out", 8192, 8192, 8192, 0, False, False),
                                       ("M=65536 N=4096 K=4096 f16", 65536, 4096, 4096, 0, False, True)]:
+    if only and only not in name: continue
     a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * K ** -0.5).half(); b = torch.randn(N, device=dev) * 0.1
     x = torch.randn(M, N, device=dev) if res else None
     c = x.clone() if res else (None if f16o else torch.empty(M, N, device=dev))
@@ -39,4 +41,4 @@ for name, M, N, K, epi, res, f16o in [("in_proj->f16", M0, 3 * W, W, 0, False, T
     tf = 2 * M * N * K / ms / 1e9
     if M == M0 and f16o: tot_ms += ms; tot_fl += 2.0 * M * N * K
     print(f"[{tag}] {name:28s} M={M:6d} N={N:5d} K={K:5d}: {ms*1e3:8.1f} us {tf:7.1f} TF  frac {tf/2500:.3f}  relerr={err:.2e}", flush=True)
-print(f"[{tag}] layer GEMMs total {tot_ms:.3f} ms = {tot_fl/tot_ms/1e9:.1f} TF  frac {tot_fl/tot_ms/1e9/2500:.3f}")
+if tot_ms > 0: print(f"[{tag}] layer GEMMs total {tot_ms:.3f} ms = {tot_fl/tot_ms/1e9:.1f} TF  frac {tot_fl/tot_ms/1e9/2500:.3f}")

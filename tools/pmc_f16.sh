@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the single-pass f16 GEMM kernel (tools/gemm_f16_bench.py): run on the GPU box from the repo root.
 # usage: tools/pmc_f16.sh <out tag> [kernel substring]
-TAG=${1:-r5}; SUB=${2:-gemm_nt_f16_p8}
+TAG=${1:-r5}; SUB=${2:-gemm_nt_f16_p8}      # BENCH_ONLY=<shape name substring> restricts the bench to one shape
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
