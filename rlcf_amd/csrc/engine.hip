@@ -608,6 +608,14 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
          prof_end(ps_, st, 11);                                                                                                \
          TRY(rc_ln_); } while (0)
 
+// RLCF_PREC_F16: x += d (the f16 output of the preceding out_proj / c_proj product, in dh), then LayerNorm(x) -> plain f16 into dh itself
+#define LN_ADD_FWD(xp, wp, bp, dh, rows, W)                                                                                 \
+    do { const LnRef gw_ = ln_ref(e, (wp), ln_view_rows), gb_ = ln_ref(e, (bp), ln_view_rows);                              \
+         const int ps_ = prof_begin(st, (double)(rows) * (W) * 12.0, (rows), (W), 0);       /* kind 11: f32 row in + out, f16 row in + out */ \
+         int rc_ln_ = launch_layernorm_add_fwd((xp), (dh), gw_.p, gb_.p, (dh), (rows), (W), st, gw_.group_rows, gw_.group_stride);          \
+         prof_end(ps_, st, 11);                                                                                                \
+         TRY(rc_ln_); } while (0)
+
 // cls_seqs / cls_idx / cls_out (image towers, split-f16 pipeline): only row `cls_idx[s]` of every sequence is consumed after the
 // last block (ln_post(x[:, 0]) @ proj, model.py:235-238), and out_proj, the MLP and the residual adds act row by row — so the LAST
 // block runs its attention for that one query per sequence (keys: the whole sequence; cls_seqs = {q_start = cls row, q_len = 1,
@@ -622,9 +630,19 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         // split-f16 pipeline: LN, attention and the QuickGELU epilogue emit (hi, lo) f16 pairs for the next GEMM
         TRY(x3_ensure(ws, T, W));
         float* x = ws.x.as<float>();
+        // RLCF_PREC_F16: out_proj / c_proj write their product d as f16 (into the LayerNorm buffer, dead by then) and the residual add rides
+        // in the LayerNorm kernel that follows (x += d; h = LN(x), in place over d) — the linear output rounded to f16 before the add is
+        // the reference's own autocast arithmetic (TPT/clip/model.py:187-192 under tpt_cls_rl.py:52); the GEMM's epilogue then moves 128 KB
+        // per 256x256 tile instead of 512 KB and all four products of a block run on the persistent f16 kernel (gemm_f16.hip).
+        // RLCF_F16_RESADD=0: the f32 residual epilogues (A/B measurements)
+        static int f16res_env = -1;
+        if (f16res_env < 0) { const char* ev = getenv("RLCF_F16_RESADD"); f16res_env = ev ? atoi(ev) : 1; }
+        const bool f16res = prec_single(e) && f16res_env && W % 4 == 0;
+        bool have_d = false;                                  // ws.h2 holds a product still to be added to x
         for (int l = 0; l < L; ++l) {
             const BlockW& b = w.blk[l];
-            LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            if (have_d) { LN_ADD_FWD(x, b.ln1_w, b.ln1_b, ws.h2.p, T, W); have_d = false; }
+            else LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
             // image towers (non-causal): in_proj writes Q / K / V as the f16 operand pairs the attention kernel DMAs into LDS
             // (attention_pair.hip; a pair row is as long as an f32 row, so the same buffer serves); RLCF_ATTN_OLD=1 keeps the f32 hand-over
             static int attn_old = -1;
@@ -671,11 +689,20 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                 TRY(arc);
             }
             e->last_flops += 4.0 * attn_pairs * W;
-            TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
-            LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            if (f16res) {
+                TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, nullptr, 0, nullptr, 0, ws.h2.p, W, T, W, W, RLCF_EPI_NONE, st));
+                LN_ADD_FWD(x, b.ln2_w, b.ln2_b, ws.h2.p, T, W);
+            } else {
+                TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
+                LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            }
             TRY(gemm_pre(e, ws.h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.f2.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
-            TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
+            if (f16res) {
+                TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, nullptr, 0, nullptr, 0, ws.h2.p, W, T, W, 4 * W, RLCF_EPI_NONE, st));
+                have_d = true;
+            } else TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
         }
+        if (have_d) TRY(launch_add_f16(x, ws.h2.p, (int64_t)T * W, st));            // (no class-token shortcut: every row's last product)
         if (cls_out && cls_idx) TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
         return RLCF_OK;
     }

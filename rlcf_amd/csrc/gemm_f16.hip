@@ -386,8 +386,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                     }
                     _Float16* op = obase + (size_t)(i * 32 + gq * 8) * g.ldch;
                     if (g.ksplit == 1 && o[0] != (_Float16)123.0f) continue;            // (measurement: no stores)
-                    if (inside) *(h16x8*)op = o;
-                    else {
+                    if (inside) {
+                        if (g.ksplit == 3) *(h16x8*)op = o;
+                        else if (g.ksplit == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(op), "v"(o) : "memory");
+                        else if (g.ksplit == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(op), "v"(o) : "memory");
+                        else if (g.ksplit == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(op), "v"(o) : "memory");
+                        else __builtin_nontemporal_store(o, (h16x8*)op);          // (streaming output: ~2 % over the default policy on the layer's four products)
+                    } else {
                         const int row = orow + i * 32 + gq * 8;
                         if (row < g.M) {
                             if (ocol + 8 <= g.N && (g.ldch & 7) == 0) *(h16x8*)op = o;

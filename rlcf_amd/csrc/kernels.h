@@ -15,6 +15,9 @@ int launch_layernorm_bwd(const float* x, const float* gamma, const float* dy, co
 int launch_im2col(const float* images, float* out, void* out_hi, void* out_lo, int n, int R, int ps, int Kp, hipStream_t st, int il = 0);
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st, int group_rows = 0, int group_stride = 0, int il = 0);
+int launch_layernorm_add_fwd(float* x, const void* d16, const float* gamma, const float* beta, void* yh, int rows, int width, hipStream_t st,
+                             int group_rows = 0, int group_stride = 0);            // x += d16; yh = LayerNorm(x) as plain f16 (RLCF_PREC_F16)
+int launch_add_f16(float* x, const void* d16, int64_t n, hipStream_t st);         // x += d16
 // x[n,1+G*G,W] = ln_pre([cls | patch_out] + pos)
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                         const float* beta, float* x, int n, int tokens, int width, hipStream_t st, int group_imgs = 0, int group_stride = 0);

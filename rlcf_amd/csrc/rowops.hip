@@ -14,11 +14,15 @@ __device__ __forceinline__ size_t pair_off(int row, int c, int width, int il) {
 
 // ---------------------------------------------------------------- LayerNorm fwd
 // TPT/clip/model.py:157-163 (fp32, eps 1e-5, biased variance about the mean)
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// ADD (RLCF_PREC_F16 pipeline): the residual add of the block rides here — x <- x + d, d = the f16 output of the preceding out_proj / c_proj
+// product (TPT/clip/model.py:187-192: x = x + attention(ln_1(x)); x = x + mlp(ln_2(x))), read as f16, added in f32, x written back; the
+// normalised row may overwrite d in place (yh == add16: a row is read completely before any of it is written)
+template <bool ADD>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                            _Float16* __restrict__ yh,
+                                                            _Float16* yh,
                                                             _Float16* __restrict__ yl, int rows, int width, int group_rows, int group_stride,
-                                                            int il) {
+                                                            int il, const _Float16* add16 = nullptr, float* xout = nullptr) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -36,6 +40,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         for (int j = 0; j < MAX_PER_LANE / 4; ++j)
             if (j < n4) {
                 float4 t = *(const float4*)(xr + j * 256 + lane * 4);
+                if constexpr (ADD) {
+                    const h16x4 d4 = *(const h16x4*)(add16 + (size_t)row * width + j * 256 + lane * 4);
+                    t.x += (float)d4[0]; t.y += (float)d4[1]; t.z += (float)d4[2]; t.w += (float)d4[3];
+                    *(float4*)(xout + (size_t)row * width + j * 256 + lane * 4) = t;
+                }
                 v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
                 s += t.x + t.y + t.z + t.w;
             }
@@ -44,6 +53,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         for (int j = 0; j < MAX_PER_LANE; ++j) {
             int c = j * 64 + lane;
             v[j] = c < width ? xr[c] : 0.f;
+            if constexpr (ADD) {
+                if (c < width) { v[j] += (float)add16[(size_t)row * width + c]; xout[(size_t)row * width + c] = v[j]; }
+            }
             s += v[j];
         }
     }
@@ -105,9 +117,33 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st, int group_rows, int group_stride, int il) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
-    layernorm_fwd_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
-                                                                                                   (_Float16*)yl, rows, width, group_rows,
-                                                                                                   group_rows > 0 ? group_stride : 0, il);
+    layernorm_fwd_kernel<false><<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
+                                                                                                          (_Float16*)yl, rows, width, group_rows,
+                                                                                                          group_rows > 0 ? group_stride : 0, il);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// x <- x + d16 (f32), yh <- LayerNorm(x) as plain f16 (may be d16 itself): the residual add of the single-pass f16 pipeline
+int launch_layernorm_add_fwd(float* x, const void* d16, const float* gamma, const float* beta, void* yh, int rows, int width, hipStream_t st,
+                             int group_rows, int group_stride) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0 && x && d16 && yh && width % 4 == 0);
+    layernorm_fwd_kernel<true><<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(
+        x, gamma, beta, nullptr, (_Float16*)yh, nullptr, rows, width, group_rows, group_rows > 0 ? group_stride : 0, 0, (const _Float16*)d16, x);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// x <- x + d16 alone (after the last block of a tower whose every row is consumed)
+__global__ __launch_bounds__(256) void add_f16_kernel(float* __restrict__ x, const _Float16* __restrict__ d, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 t = *(const float4*)(x + i * 4);
+        const h16x4 d4 = *(const h16x4*)(d + i * 4);
+        t.x += (float)d4[0]; t.y += (float)d4[1]; t.z += (float)d4[2]; t.w += (float)d4[3];
+        *(float4*)(x + i * 4) = t;
+    }
+}
+int launch_add_f16(float* x, const void* d16, int64_t n, hipStream_t st) {
+    RLCF_ARG_CHECK(n > 0 && n % 4 == 0);
+    add_f16_kernel<<<dim3((unsigned)std::min<int64_t>((n / 4 + 255) / 256, 8192)), dim3(256), 0, st>>>(x, (const _Float16*)d16, n / 4);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
