@@ -623,13 +623,21 @@ static inline LnRef ln_ref(const rlcf_engine* e, const float* p, int view_rows) 
 // (ws.x then holds the input of the last block).  Exact: no other row of the last block's output is ever read.
 static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const rlcf_seq* seqs, int n_seq, int max_q_len,
                                long attn_pairs, int causal, int T, bool save, hipStream_t st, const rlcf_seq* cls_seqs = nullptr,
-                               const int32_t* cls_idx = nullptr, float* cls_out = nullptr) {
+                               const int32_t* cls_idx = nullptr, float* cls_out = nullptr, int row0 = 0 /* first row of this call in the tower buffers (chunked image passes) */) {
     const int W = w.width, L = w.layers;
     const int ln_view_rows = max_q_len;          // (per-view LayerNorm sets only exist for the image tower: one sequence per view)
     if (prec_x3(e) && !save && T > 512 && W % 32 == 0 && (!prec_single(e) || W % 64 == 0)) {
         // split-f16 pipeline: LN, attention and the QuickGELU epilogue emit (hi, lo) f16 pairs for the next GEMM
-        TRY(x3_ensure(ws, T, W));
-        float* x = ws.x.as<float>();
+        TRY(x3_ensure(ws, row0 + T, W));
+        // this call works on rows [row0, row0 + T) of the tower buffers (row0 != 0: a chunk of views of a larger pass); sequence descriptors
+        // and class-token indices hold ABSOLUTE rows, so the attention kernel and the row gathers take the base pointers
+        const size_t es = prec_single(e) ? 2 : 4;                           // bytes per element of an operand matrix (plain f16 / hi|lo pair)
+        float* const xb = ws.x.as<float>();
+        float* x = xb + (size_t)row0 * W;
+        void* const h2 = (char*)ws.h2.p + (size_t)row0 * W * es;
+        void* const a2 = (char*)ws.a2.p + (size_t)row0 * W * es;
+        void* const qkv = (char*)ws.qkv.p + (size_t)row0 * 3 * W * es;
+        void* const f2 = (char*)ws.f2.p + (size_t)row0 * 4 * W * es;
         // RLCF_PREC_F16: out_proj / c_proj write their product d as f16 (into the LayerNorm buffer, dead by then) and the residual add rides
         // in the LayerNorm kernel that follows (x += d; h = LN(x), in place over d) — the linear output rounded to f16 before the add is
         // the reference's own autocast arithmetic (TPT/clip/model.py:187-192 under tpt_cls_rl.py:52); the GEMM's epilogue then moves 128 KB
@@ -641,15 +649,15 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         bool have_d = false;                                  // ws.h2 holds a product still to be added to x
         for (int l = 0; l < L; ++l) {
             const BlockW& b = w.blk[l];
-            if (have_d) { LN_ADD_FWD(x, b.ln1_w, b.ln1_b, ws.h2.p, T, W); have_d = false; }
-            else LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+            if (have_d) { LN_ADD_FWD(x, b.ln1_w, b.ln1_b, h2, T, W); have_d = false; }
+            else LN_FWD_SPLIT(x, b.ln1_w, b.ln1_b, h2, lo_of(h2), T, W);
             // image towers (non-causal): in_proj writes Q / K / V as the f16 operand pairs the attention kernel DMAs into LDS
             // (attention_pair.hip; a pair row is as long as an f32 row, so the same buffer serves); RLCF_ATTN_OLD=1 keeps the f32 hand-over
             static int attn_old = -1;
             if (attn_old < 0) { const char* ev = getenv("RLCF_ATTN_OLD"); attn_old = ev ? atoi(ev) : 0; }
             const bool pair_attn = !causal && !attn_old;
-            if (pair_attn) TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, nullptr, 0, ws.qkv.p, 3 * W, T, 3 * W, W, RLCF_EPI_NONE, st));
-            else TRY(gemm_pre(e, ws.h2.p, W, b.in_w, b.in_b, nullptr, 0, ws.qkv.as<float>(), 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
+            if (pair_attn) TRY(gemm_pre(e, h2, W, b.in_w, b.in_b, nullptr, 0, nullptr, 0, qkv, 3 * W, T, 3 * W, W, RLCF_EPI_NONE, st));
+            else TRY(gemm_pre(e, h2, W, b.in_w, b.in_b, nullptr, 0, (float*)qkv, 3 * W, nullptr, 0, T, 3 * W, W, RLCF_EPI_NONE, st));
             if (l == L - 1 && cls_out && cls_seqs && cls_idx && !causal) {
                 // last block, class-token rows only (see above).  Pair rows are W * 4 bytes like f32 rows: gather_rows moves both.
                 const size_t nw = (size_t)n_seq * W * sizeof(float);
@@ -665,7 +673,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
                     const int rw = prec_single(e) ? W / 2 : W;           // row length of the operand matrix in floats (plain f16: W halves)
                     TRY(launch_gather_rows((const float*)ws.a2.p, rw, cls_idx, IMG_BUF(e, cls_a2).as<float>(), rw, n_seq, rw, st));
                 }
-                TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
+                TRY(launch_gather_rows(xb, W, cls_idx, cls_out, W, n_seq, W, st));
                 TRY(gemm_pre(e, IMG_BUF(e, cls_a2).p, W, b.out_w, b.out_b, cls_out, W, cls_out, W, nullptr, 0, n_seq, W, W, RLCF_EPI_NONE, st));
                 {   // LayerNorm sets per view (batched LN-tuning inference): one row per view here
                     const int ln_view_rows = 1;
@@ -690,20 +698,20 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
             }
             e->last_flops += 4.0 * attn_pairs * W;
             if (f16res) {
-                TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, nullptr, 0, nullptr, 0, ws.h2.p, W, T, W, W, RLCF_EPI_NONE, st));
-                LN_ADD_FWD(x, b.ln2_w, b.ln2_b, ws.h2.p, T, W);
+                TRY(gemm_pre(e, a2, W, b.out_w, b.out_b, nullptr, 0, nullptr, 0, h2, W, T, W, W, RLCF_EPI_NONE, st));
+                LN_ADD_FWD(x, b.ln2_w, b.ln2_b, h2, T, W);
             } else {
-                TRY(gemm_pre(e, ws.a2.p, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
-                LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, ws.h2.p, lo_of(ws.h2.p), T, W);
+                TRY(gemm_pre(e, a2, W, b.out_w, b.out_b, x, W, x, W, nullptr, 0, T, W, W, RLCF_EPI_NONE, st));
+                LN_FWD_SPLIT(x, b.ln2_w, b.ln2_b, h2, lo_of(h2), T, W);
             }
-            TRY(gemm_pre(e, ws.h2.p, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, ws.f2.p, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
+            TRY(gemm_pre(e, h2, W, b.fc_w, b.fc_b, nullptr, 0, nullptr, 0, f2, 4 * W, T, 4 * W, W, RLCF_EPI_QUICKGELU, st));
             if (f16res) {
-                TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, nullptr, 0, nullptr, 0, ws.h2.p, W, T, W, 4 * W, RLCF_EPI_NONE, st));
+                TRY(gemm_pre(e, f2, 4 * W, b.proj_w, b.proj_b, nullptr, 0, nullptr, 0, h2, W, T, W, 4 * W, RLCF_EPI_NONE, st));
                 have_d = true;
-            } else TRY(gemm_pre(e, ws.f2.p, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
+            } else TRY(gemm_pre(e, f2, 4 * W, b.proj_w, b.proj_b, x, W, x, W, nullptr, 0, T, W, 4 * W, RLCF_EPI_NONE, st));
         }
-        if (have_d) TRY(launch_add_f16(x, ws.h2.p, (int64_t)T * W, st));            // (no class-token shortcut: every row's last product)
-        if (cls_out && cls_idx) TRY(launch_gather_rows(x, W, cls_idx, cls_out, W, n_seq, W, st));
+        if (have_d) TRY(launch_add_f16(x, h2, (int64_t)T * W, st));                 // (no class-token shortcut: every row's last product)
+        if (cls_out && cls_idx) TRY(launch_gather_rows(xb, W, cls_idx, cls_out, W, n_seq, W, st));
         return RLCF_OK;
     }
     static int save_pairs = -1;                               // RLCF_SAVE_NOPAIRS=1: the saved forward back on f32 hand-overs (A/B)
@@ -903,9 +911,21 @@ int engine_encode_image(rlcf_engine* e, int which, const float* images, int n, f
         TRY(launch_vit_assemble(IMG_BUF(e, patch_out).as<float>(), m.cls, m.vpos, gw.p, gb.p, IMG_BUF(e, vt).x.as<float>(), n, tok, Wv, st, gw.group_rows, gw.group_stride));
     }
     // class-token rows come out compact: the last block is evaluated for them only (transformer_forward)
-    TRY(transformer_forward(e, m.vis, IMG_BUF(e, vt), e->vit_seqs.as<rlcf_seq>() + (size_t)which * e->max_views, n, tok, (long)n * tok * tok, 0, T,
-                            false, st, e->vit_seqs_cls.as<rlcf_seq>() + (size_t)which * e->max_views,
-                            e->vit_cls_idx.as<int32_t>() + (size_t)which * e->max_views, IMG_BUF(e, cls_rows).as<float>()));
+    // RLCF_PREC_F16, large passes: the blocks run over CHUNKS of views (all 12 blocks on one chunk, then the next): a view's rows never
+    // meet another view's, and a chunk's hand-over tensors (Q/K/V, the MLP's hidden rows: 58 + 77 MB per ViT-B/16 test image in f16) are
+    // then still in the 256-MB Infinity Cache when the next kernel reads them instead of coming back from HBM.  RLCF_F16_CHUNK_VIEWS=n
+    // sets the chunk (0 = one chunk)
+    static int chunk_views = -1;
+    if (chunk_views < 0) { const char* ev = getenv("RLCF_F16_CHUNK_VIEWS"); chunk_views = ev ? atoi(ev) : 0; }
+    const int cv = (prec_single(e) && prec_x3(e) && chunk_views > 0 && T > 512) ? chunk_views : n;
+    if (cv < n) TRY(x3_ensure(IMG_BUF(e, vt), T, Wv));                    // (the buffers must not move between chunks)
+    for (int s0 = 0; s0 < n; s0 += cv) {
+        const int ns = std::min(cv, n - s0);
+        const size_t so = (size_t)which * e->max_views + s0;
+        TRY(transformer_forward(e, m.vis, IMG_BUF(e, vt), e->vit_seqs.as<rlcf_seq>() + so, ns, tok, (long)ns * tok * tok, 0, ns * tok,
+                                false, st, e->vit_seqs_cls.as<rlcf_seq>() + so, e->vit_cls_idx.as<int32_t>() + so,
+                                IMG_BUF(e, cls_rows).as<float>() + (size_t)s0 * Wv, s0 * tok));
+    }
     {
         const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);      // one class-token row per view
         TRY(launch_layernorm_fwd(IMG_BUF(e, cls_rows).as<float>(), gw.p, gb.p, IMG_BUF(e, cls_ln).as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
