@@ -234,6 +234,9 @@ CONFIGS = {
     2: dict(student="ViT-L/14", reward="ViT-L/14", views=64, selection_p=0.1, mode="ln", lr=1e-5, batch=20, steps=60, warmup=20,
             what="BASELINE configs[2]: ViT-L/14 student + ViT-L/14 reward, N=64, LayerNorm tuning of the image encoder"),
     # (8 images per tower pass: the convolutions' GEMMs see 256 views — 72.6 ms/image one at a time, 69.9 at 4, 66.0 at 8, 65.9 at 16)
+    # the setting the paper ships (TPT/scripts/rlcf-prompt.sh:13-41): ViT-B/16 student, ViT-L/14 reward model, 3 AdamW steps per test image
+    5: dict(student="ViT-B/16", reward="ViT-L/14", views=64, selection_p=0.1, mode="prompt", lr=7e-3, batch=20, steps=40, warmup=20, tta_steps=3,
+            what="rlcf-prompt.sh (TPT/scripts/rlcf-prompt.sh:13-41): ViT-B/16 student + ViT-L/14 reward, N=64, 3 prompt-tuning steps per image"),
     4: dict(student="RN50x64", reward="ViT-L/14", views=32, selection_p=0.1, mode="prompt", lr=7e-3, batch=8, steps=32, warmup=8,
             what="BASELINE configs[4]: RN50x64 image encoder student @448 + ViT-L/14 reward, N=32, prompt tuning"),
 }
@@ -244,13 +247,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed test images (default: 64; configs 2 / 4: a multiple of their images per pass)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up images (default: 32; configs 2 / 4: one pass)")
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i] (3 = config 1 with --gpus 8 --total-images 256)")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i] (3 = config 1 with --gpus 8 --total-images 256); 5 = the shipped script rlcf-prompt.sh")
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--text-mode", default="shared", choices=["dense", "packed", "shared"])
     ap.add_argument("--precision", default="f16x3", choices=sorted(PRECISIONS))
     ap.add_argument("--reward-arch", default=None, help="reward CLIP (BASELINE configs[1]: ViT-B/16; rlcf-prompt.sh: ViT-L/14)")
-    ap.add_argument("--tta-steps", type=int, default=1, help="AdamW steps per test image (BASELINE metric: 1; rlcf-prompt.sh runs 3)")
+    ap.add_argument("--tta-steps", type=int, default=None, help="AdamW steps per test image (BASELINE metric: 1; rlcf-prompt.sh = --config 5 runs 3)")
     ap.add_argument("--batch", type=int, default=None, help="independent test images per tower pass (engine-internal batching)")
     ap.add_argument("--total-images", type=int, default=0,
                     help="strong scaling: this many test images in total, split over the ranks (BASELINE configs[3]: 256); overrides --steps")
@@ -273,9 +276,10 @@ def main():
     if a.steps is None: a.steps = wl.get("steps", 64)
     if a.warmup is None: a.warmup = wl.get("warmup", 32)
     a.views = a.views if a.views is not None else wl["views"]
+    if a.tta_steps is None: a.tta_steps = wl.get("tta_steps", 1)
     a.reward_arch = a.reward_arch or wl["reward"]
     student_arch, mode_ln = wl["student"], wl["mode"] == "ln"
-    is_default_wl = (a.views, a.reward_arch, a.classes, a.tta_steps) == (wl["views"], wl["reward"], 1000, 1)
+    is_default_wl = (a.views, a.reward_arch, a.classes, a.tta_steps) == (wl["views"], wl["reward"], 1000, wl.get("tta_steps", 1))
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -509,9 +513,18 @@ def main():
                 if rec:
                     traffic, tsrc = rec, (f"profiles/r4_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this GEMM at {pass_images} images per "
                                           "pass on the round-4 build, tools/pmc_gemm_traffic.sh; Infinity-Cache hits are inside the counter)")
+            # MFMA-pipe utilisation by COUNTER (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)) of the dominant kernel on this round's build:
+            # like `traffic`, read from the committed rocprofv3 --pmc profile of the same GEMM shapes (counters cannot be read in-process)
+            busy, bsrc = None, None
+            cpath = os.path.join(ROOT, "profiles", "r5_sq_counters.json")
+            if a.precision == "f16x3" and os.path.exists(cpath) and a.config == 1 and is_default_wl:
+                busy = json.load(open(cpath)).get("summary", {}).get("dominant_gemm_parity_mode_mfma_busy")
+                bsrc = ("profiles/r5_sq_counters.txt: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA over the four layer products "
+                        "at 20 images per pass (tools/r5_sq_counters.sh), cycles summed over the launches; at the clock the part sustains under the counters")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_source": tsrc, "mfma_passes": passes,
+                "mfma_busy_counter": busy, "mfma_busy_counter_source": bsrc,
                 "frac_of_mfma_pipe": passes * achieved / peak,     # issued MFMA flops / peak (computed: passes x achieved, not a counter)
                 "kernel": KIND_NAMES.get(dom_kind, str(dom_kind)) + (" (3x v_mfma_f32_32x32x16_f16 per f32-grade product)" if a.precision == "f16x3" else ""),
                 "profiled_images_per_pass": pass_images, "launches": len(dom), "avg_launch_ms": d_ms / max(len(dom), 1),
@@ -611,7 +624,13 @@ def main():
                 "top1_agreement_vs_split_f16": float((top5x[:, 0] == top5h[:, 0]).float().mean().item()),
                 "dominant_gemm_tflops": ach_h, "dominant_gemm_frac_of_f16_peak": ach_h / PEAK_TFLOPS["f16"],
                 "in_proj_qkv_gemm_frac_of_f16_peak": (sum(e[2] for e in qkv_h) / max(sum(e[1] for e in qkv_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if qkv_h else None,
-                "attention_fwd_frac_of_f16_peak": (sum(e[2] for e in att_h) / max(sum(e[1] for e in att_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if att_h else None}
+                "attention_fwd_frac_of_f16_peak": (sum(e[2] for e in att_h) / max(sum(e[1] for e in att_h), 1e-9) / 1e9 / PEAK_TFLOPS["f16"]) if att_h else None,
+                # the attention forward's own bound in this mode is HBM, not the matrix pipe: Q, K, V rows in + O rows out as plain f16
+                "attention_fwd_hbm_roofline_ms": (pass_images * a.views * tok * Wv * 8.0 / (HBM_PEAK_GBS * 1e6)),
+                "attention_fwd_avg_ms": (sum(e[1] for e in att_h) / len(att_h)) if att_h else None,
+                "kernels": "gemm_nt_f16_pp_kernel (persistent 256x256 eight-phase kernel, gemm_f16.hip) for the four block products; residual add in layernorm_add_fwd",
+                "mfma_busy_counter": (json.load(open(os.path.join(ROOT, "profiles", "r5_sq_counters.json"))).get("summary", {})
+                                      if os.path.exists(os.path.join(ROOT, "profiles", "r5_sq_counters.json")) else None)}
             eh.close()
             log("secondary f16 line done")
         if world == 1 and a.config == 1 and is_default_wl and a.precision == "f16x3" and not a.no_harness_leg and not use_dist:

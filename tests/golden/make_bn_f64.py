@@ -21,6 +21,10 @@ from oracle import rlcf_ref as R          # noqa: E402
 from rlcf_amd import synth               # noqa: E402
 
 CASES = ["bn_tiny_train", "bn_tiny_train_s3", "bn_tiny_prior0", "bn_tiny_prior16_s3", "bn_rn50_train", "bn_rn50_prior16"]
+# every-parameter tuning of a ModifiedResNet student (CLIPCLS_TTA(only_norm=False), tests/golden/make_golden.py --only rnvis,rnvisrn50): the same
+# float64 re-run of the oracle; what is kept is what the float32 fixtures keep — per-tensor gradient norms, every 7th gradient element
+# where the fixture has them, the first-pass and the final logits — plus the reference's own distance from each (round 5)
+VIS_CASES = ["rnvis_tiny_s1", "rnvis_rn50"]
 
 
 def main(names):
@@ -49,5 +53,44 @@ def main(names):
               f"final logits {np.abs(z['final_logits'] - o['final_logits'].numpy()).max():.2e}", flush=True)
 
 
+def main_vis(names):
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    for name in names:
+        z = np.load(os.path.join(HERE, name + ".npz"))
+        meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta_")}
+        sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+        ssd, rsd = synth.make_state_dict(sg, meta["student_seed"]), synth.make_state_dict(rg, meta["reward_seed"])
+        tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+        views = synth.make_views(meta["view_seed"], meta["n_views"], sg.image_resolution)
+        hp = R.TTAHyper(selection_p=meta["selection_p"], tta_steps=meta["tta_steps"], sample_k=meta["sample_k"], lr=meta["lr"],
+                        weight_decay=meta["weight_decay"])
+        o = R.tta_sample_ln(dbl(ssd), dbl(rsd), views.double(), tokens, hp, only_norm=False)
+        assert o["selected_idx"].tolist() == z["selected_idx"].tolist() and o["topk_idx"].reshape(-1).tolist() == z["topk_idx"].reshape(-1).tolist()
+        keys = R.visual_param_keys(ssd)
+        g64 = o["ln_grad"]
+        norms, off = [], 0
+        for k in keys:
+            n = ssd[k].numel()
+            norms.append(float(g64[off:off + n].norm())); off += n
+        norms = np.array(norms)
+        ref_norm_err = np.abs(z["vis_grad_l2"].astype(np.float64) - norms) / np.maximum(norms, 1e-300)
+        l64, f64 = o["logits"].numpy(), o["final_logits"].numpy()
+        out = dict(vis_grad_l2=norms, ref_grad_l2_relerr=ref_norm_err, logits=l64, final_logits=f64,
+                   ref_logit_err=np.float64(np.abs(z["logits"].astype(np.float64) - l64).max()),
+                   ref_final_err=np.float64(np.abs(z["final_logits"].astype(np.float64) - f64).max()), bn_stats_after=o["bn_stats_after"].numpy())
+        if "vis_grad_sample" in z.files:
+            gs = g64[::7].numpy()
+            out["vis_grad_sample"] = gs
+            out["ref_sample_err"] = np.float64(np.linalg.norm(z["vis_grad_sample"].astype(np.float64) - gs) / np.linalg.norm(gs))
+        np.savez_compressed(os.path.join(HERE, name + "_f64.npz"), **out)
+        print(f"{name}: reference f32 vs f64 — per-tensor gradient norms worst {ref_norm_err.max():.3e} (median {np.median(ref_norm_err):.3e}), "
+              f"first-pass logits {out['ref_logit_err']:.2e}, final logits {out['ref_final_err']:.2e}", flush=True)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:] or CASES)
+    args = sys.argv[1:]
+    vis = [a for a in args if a.startswith("rnvis")]
+    bn = [a for a in args if not a.startswith("rnvis")]
+    if vis: main_vis(vis)
+    if bn or not args: main(bn or CASES)

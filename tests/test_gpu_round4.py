@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -15,6 +16,7 @@ from test_gpu_parity import _cfg_from_meta, _tensor_norms, load_golden
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 ENV = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
@@ -124,9 +126,18 @@ def test_resnet_every_parameter_tuning_matches_reference_fixture(L, dev, name, p
     assert c("selected_idx").tolist() == g["selected_idx"].tolist()
     assert c("topk_idx").reshape(-1).tolist() == g["topk_idx"].reshape(-1).tolist()
     assert c("top5").tolist()[: g["top5"].numel()] == g["top5"].tolist()
-    torch.testing.assert_close(c("logits"), g["logits"], atol=2e-3 if big else 1e-3, rtol=0)
+    # first-pass logits are forward only: the bar of the BatchNorm-tuning test (test_gpu_parity.py: 3e-4 against the float32 fixture, and
+    # pinned to the float64 value of the reference-pinned oracle, tests/golden/make_bn_f64.py rnvis_*) — the forward is the same kernels
+    torch.testing.assert_close(c("logits"), g["logits"], atol=3e-4, rtol=0)
     torch.testing.assert_close(c("rewards"), g["rewards"].reshape(-1), atol=5e-5, rtol=1e-3)
-    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=5e-3 if big else 1e-3, rtol=0)
+    z64 = np.load(os.path.join(GOLDEN, name + "_f64.npz")) if os.path.exists(os.path.join(GOLDEN, name + "_f64.npz")) else None
+    if z64 is not None:
+        e_l = (c("logits").double() - torch.from_numpy(z64["logits"])).abs().max().item()
+        assert e_l < max(2e-4, 4 * float(z64["ref_logit_err"])), f"first-pass logits vs f64: {e_l:.2e} (reference: {float(z64['ref_logit_err']):.2e})"
+        # final logits ride on one AdamW step of ~lr sign(g) per element: against float64 no further than 1e-3 / three times the reference
+        e_f = (c("final_logits").double() - torch.from_numpy(z64["final_logits"])).abs().max().item()
+        assert e_f < max(1e-3, 3 * float(z64["ref_final_err"])), f"final logits vs f64: {e_f:.2e} (reference: {float(z64['ref_final_err']):.2e})"
+    torch.testing.assert_close(c("final_logits"), g["final_logits"], atol=2e-3 if big else 1e-3, rtol=0)
     torch.testing.assert_close(eng.bn_stats().cpu(), g["bn_stats_after"], atol=1e-4, rtol=1e-3)
     keys = RR.visual_param_keys(ssd)
     grad, after = eng.merge_visual(o["ln_grad"], o["vis_grad"]), eng.merge_visual(o["ln_after"], o["vis_after"])
@@ -137,8 +148,18 @@ def test_resnet_every_parameter_tuning_matches_reference_fixture(L, dev, name, p
     if meta["tta_steps"] == 1:
         # train-mode BatchNorm amplifies rounding noise through the backward (BatchNorm tuning: at RN50 size the
         # reference's own f32 gradient is up to 7e-3 from the f64 value): tensors are compared at that width at full size
-        torch.testing.assert_close(gn[keep], rn_[keep], rtol=2e-2 if big else 3e-3, atol=1e-8)
+        torch.testing.assert_close(gn[keep], rn_[keep], rtol=1e-2 if big else 3e-3, atol=1e-8)
         assert gn[kb] < 1e-6 * rn_.max()
+        if z64 is not None:
+            # ... and every tensor's gradient norm against the float64 value, next to the reference's own float32 distance from it: the TYPICAL
+            # tensor no further than twice the reference's median (measured at RN50: 1.09e-4 f32 mode / 1.52e-4 split-f16 against 1.05e-4 —
+            # the same noise band), the WORST tensor within four times the reference's worst (5.3e-3 / 3.4e-3 against 1.6e-3: which tensor
+            # draws the tail of the train-form BatchNorm noise differs between two float32 summation orders)
+            n64, r64 = torch.from_numpy(z64["vis_grad_l2"])[keep], torch.from_numpy(z64["ref_grad_l2_relerr"])[keep]
+            err = ((gn[keep].double() - n64).abs() / n64)
+            print(f"[{name} prec {prec}] per-tensor |g| vs f64: worst {err.max():.2e} (reference {r64.max():.2e}), median {err.median():.2e} "
+                  f"(reference {r64.median():.2e}); first-pass logits {e_l:.2e}, final logits {e_f:.2e}")
+            assert err.max() < max(1e-3, 4 * r64.max().item()) and err.median() < max(3e-4, 2 * r64.median().item())
     torch.testing.assert_close(_tensor_norms(ssd, keys, after, ssd)[keep], g["vis_delta_l2"][keep], rtol=0.05 if big else 0.01, atol=1e-7)
     if "vis_grad_sample" in g:
         gr, og = g["vis_grad_sample"], grad[::7].cpu()
