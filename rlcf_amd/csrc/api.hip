@@ -144,11 +144,16 @@ int rlcf_gemm_skinny(const float* A, int lda, const void* W_pairs, const float* 
                      int ldaux, float* C, int ldc, int M, int N, int K, float alpha, int epilogue, const float* amax_in, int local_amax,
                      rlcf_stream stream) {
     RLCF_ARG_CHECK(A && W_pairs && C && gemm_skinny_x3_ok(M, N, K, lda, ldc) && ldr % 4 == 0 && ldaux % 4 == 0);
-    static float* ws = nullptr;                            // K-slice scratch of the op-level call (the engine passes its own)
-    const size_t ws_bytes = (size_t)64 << 20;
-    if (!ws) RLCF_HIP_CHECK(hipMalloc((void**)&ws, ws_bytes + 256));
-    return launch_gemm_skinny_x3(A, lda, W_pairs, bias, residual, ldr, aux, ldaux, C, ldc, M, N, K, alpha, epilogue, amax_in, nullptr, ws,
-                                 ws_bytes, (float*)((char*)ws + ws_bytes), (hipStream_t)stream, local_amax);
+    // stateless call: the K-slice scratch (and the inverse-scale word behind it) comes from the stream-ordered allocator of the CURRENT
+    // device, per call — two callers on different streams / threads / GPUs never share it (the engine passes its own workspace)
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ws_bytes = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)8 * M * N * sizeof(float), 4096));     // <= 8 K slices of [M, N]
+    float* ws = nullptr;
+    RLCF_HIP_CHECK(hipMallocAsync((void**)&ws, ws_bytes + 256, st));
+    const int rc = launch_gemm_skinny_x3(A, lda, W_pairs, bias, residual, ldr, aux, ldaux, C, ldc, M, N, K, alpha, epilogue, amax_in, nullptr, ws,
+                                         ws_bytes, (float*)((char*)ws + ws_bytes), st, local_amax);
+    (void)hipFreeAsync(ws, st);
+    return rc;
 }
 int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream) {
     RLCF_ARG_CHECK(x && pairs && n > 0 && n % 32 == 0 && (precision == RLCF_PREC_F16X3 || precision == RLCF_PREC_F16));

@@ -20,29 +20,41 @@
 // asynchronous copy; an event per slot guards its reuse), so the call returns at once and the caller's arrays are free again.
 #define VW_SLOTS 32
 #define VW_SLOT_BYTES (128 * 1024)
+#define VW_MAX_DEVICES 16
 static int views_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+    // one ring (pinned slots + their events) PER DEVICE: an event belongs to the device it was created on, and recording it on a stream of
+    // another GPU fails.  A ring whose set-up failed half way is torn down and that device keeps the blocking form.
+    struct Ring { char* mem = nullptr; hipEvent_t ev[VW_SLOTS]; int next = 0; bool failed = false; };
     static std::mutex mu;
-    static char* ring = nullptr;
-    static hipEvent_t ev[VW_SLOTS];
-    static int next = 0;
+    static Ring rings[VW_MAX_DEVICES];
     if (bytes == 0) return RLCF_OK;
+    int dev = 0;
+    RLCF_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    if (!ring && bytes <= VW_SLOT_BYTES) {
-        if (hipHostMalloc((void**)&ring, (size_t)VW_SLOTS * VW_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { ring = nullptr; (void)hipGetLastError(); }
-        else for (int i = 0; i < VW_SLOTS; ++i) RLCF_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    Ring* r = (dev >= 0 && dev < VW_MAX_DEVICES) ? &rings[dev] : nullptr;
+    if (r && !r->mem && !r->failed && bytes <= VW_SLOT_BYTES) {
+        int made = 0;
+        if (hipHostMalloc((void**)&r->mem, (size_t)VW_SLOTS * VW_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) r->mem = nullptr;
+        else for (; made < VW_SLOTS; ++made) if (hipEventCreateWithFlags(&r->ev[made], hipEventDisableTiming) != hipSuccess) break;
+        if (!r->mem || made < VW_SLOTS) {
+            for (int i = 0; i < made; ++i) (void)hipEventDestroy(r->ev[i]);
+            if (r->mem) (void)hipHostFree(r->mem);
+            r->mem = nullptr; r->failed = true;
+            (void)hipGetLastError();
+        }
     }
-    if (!ring || bytes > VW_SLOT_BYTES) {                 // (too large, or no pinned memory: the blocking form)
+    if (!r || !r->mem || bytes > VW_SLOT_BYTES) {         // (too large, or no pinned ring on this device: the blocking form)
         RLCF_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
         RLCF_HIP_CHECK(hipStreamSynchronize(st));
         return RLCF_OK;
     }
-    const int slot = next;
-    next = (next + 1) % VW_SLOTS;
-    RLCF_HIP_CHECK(hipEventSynchronize(ev[slot]));        // (its previous copy has been consumed; a fresh event is complete)
-    char* p = ring + (size_t)slot * VW_SLOT_BYTES;
+    const int slot = r->next;
+    r->next = (r->next + 1) % VW_SLOTS;
+    RLCF_HIP_CHECK(hipEventSynchronize(r->ev[slot]));     // (its previous copy has been consumed; a fresh event is complete)
+    char* p = r->mem + (size_t)slot * VW_SLOT_BYTES;
     memcpy(p, src_host, bytes);
     RLCF_HIP_CHECK(hipMemcpyAsync(dst_dev, p, bytes, hipMemcpyHostToDevice, st));
-    RLCF_HIP_CHECK(hipEventRecord(ev[slot], st));
+    RLCF_HIP_CHECK(hipEventRecord(r->ev[slot], st));
     return RLCF_OK;
 }
 

@@ -13,6 +13,48 @@ from . import clip_store, runtime
 from . import _lib as L
 
 
+class _ResetTracker:
+    """Host-side knowledge "these tunable tensors ARE the reset state right now" without a device round trip per test image.
+
+    `Parameter._version` does not see edits made through `.data` (the idiom this mirror itself — and the reference — use), so the
+    knowledge is kept explicitly: every mirror-side write goes through `wrote()` (a generation counter), `mark_reset()` records the
+    generation and the versions at which the tensors were set to the reset state, and `at_reset()` holds only while neither moved.
+    An edit that bypasses both (a foreign `p.data.copy_(...)` between reset() and test_time_tuning) cannot be seen from the host; it is
+    caught on the DEVICE instead: whoever takes the fast path calls `guard(tensor, expected)`, an asynchronous comparison whose
+    one-byte result is read at the NEXT entry point (long finished by then: no wait) and raises — a silent wrong result becomes a
+    loud error one sample later."""
+
+    def __init__(self):
+        self.gen = 0
+        self._reset_gen = -1
+        self._reset_versions = None
+        self._guards = []
+
+    def wrote(self):
+        self.gen += 1
+
+    def mark_reset(self, *tensors):
+        self.gen += 1
+        self._reset_gen = self.gen
+        self._reset_versions = tuple(None if t is None else t._version for t in tensors)
+
+    def at_reset(self, *tensors) -> bool:
+        return self._reset_gen == self.gen and self._reset_versions == tuple(None if t is None else t._version for t in tensors)
+
+    def guard(self, tensor: torch.Tensor, expected: torch.Tensor, what: str):
+        """queue `tensor == expected` on the device (no synchronisation); checked by check()"""
+        self._guards.append(((tensor.detach() != expected.detach()).any(), what))
+
+    def check(self):
+        """called at every entry point: the comparisons queued by EARLIER calls have finished long ago"""
+        pending, self._guards = self._guards, []
+        for flag, what in pending:
+            if bool(flag):
+                raise RuntimeError(f"rlcf_amd mirror: {what} — the tensor was edited behind the mirror's back (through `.data` or a raw "
+                                   "pointer) after the state the previous call assumed; the previous result was computed from the "
+                                   "unedited state.  Edit through the mirror (reset(), ctx_init_state = ..., in-place ops on the Parameter).")
+
+
 class PromptLearner(nn.Module):
     """TPT/clip/custom_clip.py:76-289.  Holds the learnable context `ctx` [n_ctx, W], its pristine copy
     `ctx_init_state`, and `tokenized_prompts` int64 [C, 77] of "<prefix> <class>."."""
@@ -50,6 +92,7 @@ class PromptLearner(nn.Module):
         self.prompt_prefix, self.n_ctx, self.ctx_init = prompt_prefix, n_ctx, ctx_init
         ctx_vectors = ctx_vectors.detach().to(self.device).clone()
         self.tokenized_prompts = None
+        self._track = _ResetTracker()
         self._ctx_init_state = ctx_vectors.detach().clone()
         self.ctx = nn.Parameter(ctx_vectors)
         self._set_classnames(classnames)
@@ -63,7 +106,7 @@ class PromptLearner(nn.Module):
         """The harness assigns a pre-trained (CoOp) prompt here (`--load`, tpt_cls_rl.py:95-101): the engine's reset state and
         its cached step-0 text features follow."""
         self._ctx_init_state = value.detach().to(self.device, torch.float32).clone()
-        self._at_reset = False
+        self._track.wrote()                               # (the reset state itself moved: reset() establishes it again)
         if self.tokenized_prompts is not None:
             self._publish_bank()
 
@@ -110,10 +153,10 @@ class PromptLearner(nn.Module):
         self.ctx.data.copy_(self.ctx_init_state)
         # (host-side note that ctx IS the reset state now — rlcf_amd.tpt_cls_rl.test_time_tuning then need not compare the two tensors,
         # which would make the host wait for the device once per test image; an in-place edit of the Parameter bumps its version)
-        self._reset_stamp = self.ctx._version
-        self._at_reset = True
+        self._track.mark_reset(self.ctx)
 
     def reset_classnames(self, classnames, arch):      # custom_clip.py:169-196 (without re-loading CLIP from disk)
+        self._track.wrote()
         self._set_classnames(classnames)
 
     def forward(self, init=None):
@@ -190,17 +233,23 @@ class ClipTestTimeTuning(nn.Module):
         return runtime.SESSION.engine().text_features(self.prompt_learner.ctx)
 
     def inference(self, image):
+        pl = self.prompt_learner
+        pl._track.check()
         cache = getattr(self, "_tuned_view_cache", None)
         if cache is not None and not torch.is_grad_enabled():
-            view0, version, logits, hint, hint_version = cache
+            view0, gen, version, ctx_after, logits, hint_key = cache
             # the clean view rlcf_amd.tpt_cls_rl.test_time_tuning just tuned on, with the prompt it left behind: the fused step already
-            # computed these logits (same arithmetic: frozen image tower, text tower of the adapted prompt).  The mirror's own loop names
-            # the tensor it will ask about (same object, unmodified: no device round trip); any other caller is answered after comparing
-            # the contents (torch.equal: the host waits for the device once)
-            if self.prompt_learner.ctx._version == version and image.shape == view0.shape and image.device == view0.device:
-                if (hint is not None and image is hint and image._version == hint_version) or torch.equal(image, view0):
+            # computed these logits (same arithmetic: frozen image tower, text tower of the adapted prompt).  Valid only while the prompt is
+            # the one that call wrote: every mirror-side write bumps the tracker's generation, in-place edits of the Parameter bump its
+            # version, and an edit through `.data` is caught by the device-side guard below (loudly, at the next entry point).  The mirror's
+            # own loop names the tensor it will ask about (same storage, shape, version: no device round trip); any other caller is
+            # answered after comparing the contents (torch.equal: the host waits for the device once)
+            if pl._track.gen == gen and pl.ctx._version == version and image.shape == view0.shape and image.device == view0.device:
+                same = hint_key is not None and hint_key == (image.data_ptr(), tuple(image.shape), image._version)
+                if same or torch.equal(image, view0):
+                    pl._track.guard(pl.ctx.data, ctx_after, "the prompt changed between test_time_tuning and model(image)")
                     return logits.clone()
-        return _LogitsFn.apply(self.prompt_learner.ctx, image, self)
+        return _LogitsFn.apply(pl.ctx, image, self)
 
     def forward(self, input):
         if isinstance(input, tuple) or input.dim() == 2:
@@ -242,6 +291,7 @@ class CLIPCLS_TTA(nn.Module):
         self.only_visual, self.only_norm, self.momentum_update = only_visual, only_norm, momentum_update
         self.update_freq, self.update_w, self.momentum, self.update_counter = update_freq, update_w, momentum, 0
         self._ln = self._vis = None
+        self._track = _ResetTracker()
         self._set_classnames(classnames)
 
     def _set_classnames(self, classnames):
@@ -290,8 +340,7 @@ class CLIPCLS_TTA(nn.Module):
             self.vis.data.copy_(self._vis_init)
         # (host-side note that the tunable tensors ARE the reset state: rlcf_amd.tpt_cls_rl.test_time_tuning then skips its tensor
         # comparisons — one host-device round trip per test image; in-place edits of the Parameters bump the stamped versions)
-        self._reset_stamp = (self.ln._version, None if self.only_norm else self.vis._version)
-        self._at_reset = True
+        self._track.mark_reset(self.ln, None if self.only_norm else self.vis)
 
     @torch.no_grad()
     def reset_classnames_and_state(self, classnames, arch):   # custom_clip.py:434-454
@@ -314,6 +363,12 @@ class CLIPCLS_TTA(nn.Module):
         Samples become order-dependent: run on one replica."""
         if not self.momentum_update:
             return
+        if self.resnet and not self.only_norm:
+            # the reference EMAs the WHOLE visual state dict — BatchNorm running_mean / running_var included (custom_clip.py:460-475) — and
+            # in this mode the clean-view inference runs the BatchNorms in eval form on those statistics: the engine's EMA covers the
+            # parameters only, so the combination is refused rather than left to drift from the reference after update_freq samples
+            raise NotImplementedError("momentum_update with only_norm=False on a ModifiedResNet student: the EMA of the BatchNorm running "
+                                      "statistics is not built (use only_norm=True, or momentum_update=False)")
         self.update_counter += 1
         apply = self.update_counter >= self.update_freq
         if apply:
@@ -326,7 +381,7 @@ class CLIPCLS_TTA(nn.Module):
             self._ln_init = eng.ln_params(pristine=True)
             if not self.only_norm:
                 self._vis_init = eng.visual_params(1)
-            self._at_reset = False                           # (the reset state itself moved: reset() establishes it again)
+            self._track.wrote()                              # (the reset state itself moved: reset() establishes it again)
 
     @torch.no_grad()
     def forward(self, image):

@@ -51,6 +51,10 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
     """TPT/tpt_cls_rl.py:47-79.  `optimizer` supplies the AdamW hyper-parameters (its state is reset per
     sample by the harness, :255, so the fused step starts from step 1); `scaler` is accepted and unused:
     the HIP path computes in f32-grade precision, there is no loss scaling to apply."""
+    # the tensor test_time_adapt_eval will pass to model(image) next (row 0 of `inputs`): consumed HERE, whatever happens below — an early
+    # return or an exception must not leave it behind for an unrelated later call
+    hint = getattr(model, "_clean_view_hint", None)
+    model._clean_view_hint = None
     if reward_model is None:
         raise ValueError("RLCF needs a reward model (get_reward_model)")
     if args.tta_steps <= 0:
@@ -59,21 +63,33 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
     eng = runtime.SESSION.engine(inputs.shape[0])
     if not hasattr(model, "prompt_learner"):               # CLIPCLS_TTA: image-encoder tuning (TPT/tune_cls_rl.py:31,217)
         full = not model.only_norm
-        at_reset = getattr(model, "_at_reset", False) and getattr(model, "_reset_stamp", None) == (model.ln._version, model.vis._version if full else None)
+        trk = model._track
+        trk.check()
+        # reset() just ran and nothing the mirror can see has touched the tensors since (no device round trip); an edit through `.data`
+        # in between is invisible from the host: the device-side guard queued below reports it at the next entry point
+        at_reset = trk.at_reset(model.ln, model.vis if full else None)
         if not at_reset and (not torch.equal(model.ln.data, model._ln_init) or (full and not torch.equal(model.vis.data, model._vis_init))):
             raise NotImplementedError("image-encoder tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
-        model._at_reset = False
+        if at_reset:
+            trk.guard(model.ln.data, model._ln_init, "CLIPCLS_TTA: the norm-layer parameters were not the reset state when test_time_tuning ran")
+            if full:
+                trk.guard(model.vis.data, model._vis_init, "CLIPCLS_TTA: the visual parameters were not the reset state when test_time_tuning ran")
         out = (eng.tta_sample_visual if full else eng.tta_sample_ln)(inputs, cfg, skip_final=True)
         with torch.no_grad():
             model.ln.data.copy_(out["ln_after"])
             if full:
                 model.vis.data.copy_(out["vis_after"])
                 model.vis.grad = None
+        trk.wrote()
         model.ln.grad = None
         return
     pl = model.prompt_learner
-    at_reset = getattr(pl, "_at_reset", False) and pl.ctx._version == getattr(pl, "_reset_stamp", -1)      # reset() just ran (no device round trip)
+    trk = pl._track
+    trk.check()
+    at_reset = trk.at_reset(pl.ctx)                          # reset() just ran (no device round trip)
     ctx_in = None if at_reset or torch.equal(pl.ctx.data, pl.ctx_init_state) else pl.ctx.data
+    if at_reset:
+        trk.guard(pl.ctx.data, pl.ctx_init_state, "the prompt was not its reset state when test_time_tuning ran (a `.data` edit after reset())")
     # The harness asks for model(image) on the clean view right after this call (tpt_cls_rl.py:260-262).  The image tower is frozen, so
     # the engine already holds that view's features (row 0 of the N-view pass): the fused call finishes the sample — text features of
     # the adapted prompt, logits — and the result is kept for ClipTestTimeTuning.inference, which returns it when it is asked for
@@ -82,10 +98,13 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
     with torch.no_grad():
         pl.ctx.data.copy_(out["ctx_after"])
     pl.ctx.grad = None
-    pl._at_reset = False
-    hint = getattr(model, "_clean_view_hint", None)            # set by test_time_adapt_eval: the tensor it will pass to model(image) next
-    model._clean_view_hint = None
-    model._tuned_view_cache = (inputs[:1], pl.ctx._version, out["final_logits"], hint, hint._version if hint is not None else None)
+    trk.wrote()
+    # the hint is honoured only if it IS row 0 of this call's input (same storage start, one image of the same shape) — and the cache keeps
+    # a COPY of that row (600 KB), not a view that would pin the whole N-view tensor until the next reset
+    hint_key = None
+    if hint is not None and hint.dim() == inputs.dim() and hint.shape[0] == 1 and hint.shape[1:] == inputs.shape[1:] and hint.device == inputs.device:
+        hint_key = (hint.data_ptr(), tuple(hint.shape), hint._version)
+    model._tuned_view_cache = (inputs[:1].clone(), trk.gen, pl.ctx._version, out["ctx_after"], out["final_logits"], hint_key)
     return
 
 

@@ -389,9 +389,9 @@ def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
             return model(views[:1]).cpu()
     with torch.no_grad():
         model.reset()
-    assert pl._at_reset
+    assert pl._track.at_reset(pl.ctx)
     out1 = tune()
-    assert not pl._at_reset
+    assert not pl._track.at_reset(pl.ctx)
     torch.testing.assert_close(out1, g["final_logits"], atol=1e-3, rtol=0)                                   # (1)
     with torch.no_grad():
         model.reset()
@@ -403,7 +403,7 @@ def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
     assert (out2 - out1).abs().max() > 1e-3
     pre = synth.normal(31, "coop.ctx", tuple(pl.ctx.shape), 0.02).to(dev)                                  # (3)
     pl.ctx_init_state = pre
-    assert not pl._at_reset
+    assert not pl._track.at_reset(pl.ctx)
     with torch.no_grad():
         model.reset()
     out3 = tune()
@@ -414,6 +414,33 @@ def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
     with torch.no_grad():
         o_other = model(other).cpu()
     assert (o_other - out3).abs().max() > 1e-3
+    # (round 5) writes that do NOT bump Parameter._version — the `.data` idiom of the reference and of this mirror:
+    # (4) PromptLearner.reset() called DIRECTLY after a tuning call: model(image) on the clean view is the reset prompt's answer, not the
+    #     cached logits of the tuned prompt
+    with torch.no_grad():
+        model.reset()
+    out4 = tune()
+    with torch.no_grad():
+        pl.reset()                                            # (not ClipTestTimeTuning.reset: the cache is invalidated by the generation)
+        o_reset = model(views[:1]).cpu()
+    zero_shot = RR.tta_sample(ssd, rsd, views.cpu(), tokens, pl.ctx_init_state.cpu(), hyper)["logits"][:1]
+    torch.testing.assert_close(o_reset, zero_shot, atol=1e-3, rtol=0)
+    assert (o_reset - out4).abs().max() > 1e-4
+    # (5) a `.data` edit between reset() and test_time_tuning is invisible from the host: the call runs from the reset state, and the
+    #     device-side guard makes the NEXT entry point raise instead of leaving a silently wrong result behind
+    with torch.no_grad():
+        model.reset()
+        pl.ctx.data.copy_(edited.to(dev))
+    optimizer.load_state_dict(optim_state)
+    tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+    with pytest.raises(RuntimeError, match="behind the mirror's back"):
+        with torch.no_grad():
+            model(views[:1])
+    # (6) the hint of the harness loop is consumed by the call it was set for, also when that call returns early
+    model._clean_view_hint = views[:1]
+    args0 = type(args)(**{**vars(args), "tta_steps": 0}) if hasattr(args, "__dict__") else args
+    tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args0, reward_model=reward_model)
+    assert getattr(model, "_clean_view_hint", None) is None
     runtime.reset_session()
 
 
