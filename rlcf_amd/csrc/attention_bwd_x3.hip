@@ -349,9 +349,11 @@ int launch_attention_bwd_x3(const float* qkv, const float* out, const float* lse
     attention_bwd_x3_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, (const unsigned int*)amax_dout, seqs, width, causal, dqkv, park,
                                                             max_q_len);
     RLCF_LAUNCH_CHECK();
-    if (park) {
-        attention_bwd_park_reduce_kernel<<<dim3(max_q_len, n_seq), dim3(256), 0, st>>>(park, seqs, max_q_len, (int)grid.x, width, dqkv);
-        RLCF_LAUNCH_CHECK();
-    }
+    if (park) return launch_attention_bwd_park_reduce(park, seqs, n_seq, max_q_len, (int)grid.x, width, dqkv, st);
+    return RLCF_OK;
+}
+int launch_attention_bwd_park_reduce(const float* park, const rlcf_seq* seqs, int n_seq, int park_rows, int n_qb, int width, float* dqkv, hipStream_t st) {
+    attention_bwd_park_reduce_kernel<<<dim3(park_rows, n_seq), dim3(256), 0, st>>>(park, seqs, park_rows, n_qb, width, dqkv);
+    RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

@@ -440,7 +440,7 @@ int launch_attention_bwd_long(const float* qkv, const float* dout, const rlcf_se
 __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
                                                                  const rlcf_seq* __restrict__ seqs, int width, int causal,
-                                                                 float* __restrict__ dqkv) {
+                                                                 float* __restrict__ dqkv, float* __restrict__ park, int park_rows) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const rlcf_seq sq = seqs[blockIdx.y];
     const int head = blockIdx.z, q0 = blockIdx.x * 32;
@@ -543,10 +543,17 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const float* __
             for (int r = 0; r < 16; ++r) {
                 const int kap = kt + mfma32_row(r, h);
                 if (kap < nk) {
-                    const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
-                    float* base = dqkv + (size_t)row * ld + head * HEAD_DIM + l32;
-                    atomicAdd(base + 2 * width, dv0[r]); atomicAdd(base + 2 * width + 32, dv1[r]);
-                    atomicAdd(base + width, dk0[r]);     atomicAdd(base + width + 32, dk1[r]);
+                    if (park) {        // (no shared prefix) this query block's contribution to key kap, parked [seq][q block][key][K | V] and added
+                                       // in block order by attention_bwd_park_reduce_kernel: bit-reproducible, no zero fill of the K / V parts
+                        float* base = park + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * park_rows + kap) * (2 * width) + head * HEAD_DIM + l32;
+                        base[width] = dv0[r]; base[width + 32] = dv1[r];
+                        base[0] = dk0[r];     base[32] = dk1[r];
+                    } else {
+                        const int row = kap < sq.pre_len ? sq.pre_start + kap : sq.q_start + kap - sq.pre_len;
+                        float* base = dqkv + (size_t)row * ld + head * HEAD_DIM + l32;
+                        atomicAdd(base + 2 * width, dv0[r]); atomicAdd(base + 2 * width + 32, dv1[r]);
+                        atomicAdd(base + width, dk0[r]);     atomicAdd(base + width + 32, dk1[r]);
+                    }
                 }
             }
         }
@@ -569,14 +576,17 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const float* __
     }
 }
 
+// park (optional; sequences WITHOUT a shared prefix and without a causal mask only — the image towers): n_seq * ceil(max_q_len / 32) * max_q_len
+// * 2 * width floats; with it dK / dV are bit-reproducible run to run (as launch_attention_bwd_x3) and dqkv needs no zero fill
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
-                              int max_q_len, int width, int causal, float* dqkv, hipStream_t st) {
+                              int max_q_len, int width, int causal, float* dqkv, hipStream_t st, float* park) {
     RLCF_ARG_CHECK(n_seq > 0 && width % HEAD_DIM == 0 && max_q_len > 0 && qkv && out && lse && dout && dqkv);
     const size_t bytes = (size_t)(2 * 32 * ABM_LD + 2 * 128 * ABM_LD + 2 * 32 * ABM_PLD + 64) * sizeof(float);
     { int rc_ = rlcf_func_lds((const void*)attention_bwd_mfma_kernel, bytes); if (rc_ != RLCF_OK) return rc_; }
     dim3 grid((max_q_len + 31) / 32, n_seq, width / HEAD_DIM);
     RLCF_ARG_CHECK(grid.y <= 65535);
-    attention_bwd_mfma_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, seqs, width, causal, dqkv);
+    attention_bwd_mfma_kernel<<<grid, dim3(256), bytes, st>>>(qkv, out, lse, dout, seqs, width, causal, dqkv, park, max_q_len);
     RLCF_LAUNCH_CHECK();
+    if (park) return launch_attention_bwd_park_reduce(park, seqs, n_seq, max_q_len, (int)grid.x, width, dqkv, st);
     return RLCF_OK;
 }

@@ -823,7 +823,10 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
         float* park = nullptr;
         static int bwd_old0 = -1;
         if (bwd_old0 < 0) { const char* ev = getenv("RLCF_ATTN_BWD_OLD"); bwd_old0 = ev ? atoi(ev) : 0; }
-        if (bwd_old0 && max_keys > 96 && prec_x3(e) && !bwd_f32 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
+        // (the f32-MFMA backward — RLCF_PREC_F32, or RLCF_ATTN_BWD_F32=1 — parks too since round 5: its float atomics were the last source
+        // of run-to-run differences in that mode)
+        const bool f32_form = max_keys > 96 && (!prec_x3(e) || bwd_f32);
+        if (((bwd_old0 && prec_x3(e) && !bwd_f32) || f32_form) && max_keys > 96 && !causal && max_q_len > 0 && max_q_len == max_keys && !bwd_atomic) {
             const size_t need = (size_t)n_seq * ((max_q_len + 31) / 32) * max_q_len * 2 * W * sizeof(float);
             if (need <= ((size_t)16 << 30)) {
                 // no room for the parking space (another engine holds the memory): clear the error and meet by atomicAdd instead
@@ -845,7 +848,7 @@ static int transformer_backward(rlcf_engine* e, const TowerW& w, Tower& ws, cons
             TRY(launch_absmax(dA, (int64_t)T * W, e->bwd_amax.as<float>(), st));       // range of dO for the f16 pairs
             TRY(launch_attention_bwd_x3(s.qkv, s.a, s.lse, dA, e->bwd_amax.as<float>(), seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal,
                                         dQKV, st, park));
-        } else if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st));
+        } else if (max_keys > 96) TRY(launch_attention_bwd_mfma(s.qkv, s.a, s.lse, dA, seqs, n_seq, max_q_len > 0 ? max_q_len : max_keys, W, causal, dQKV, st, park));
         else {
             // shared-prefix layouts: the prefix rows' dK / dV are summed in sequence order through a per-sequence workspace (reproducible
             // bit for bit); sized on first use like the other lazily grown scratch, atomics beyond 512 MB (dense backward of a huge bank)

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         const bool have_next = nlin < xend;
         PP_STAMP(0)
         int m0n = 0, n0n = 0;
-        if (have_next) tile_origin(nlin, m0n, n0n);
+        if (have_next) tile_origin(g.ksplit == 8 ? lin : nlin, m0n, n0n);          // (ksplit 8: measurement — every tile of a workgroup is its first)
         auto ran = rsrc_a(m0n), rwn = rsrc_w(n0n);
         PP_KTILE_X(0, 0, PP_MMA0, PP_NOHOOK)
         PP_KTILE(1, 1)

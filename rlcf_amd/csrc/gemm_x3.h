@@ -74,6 +74,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     const bool relu = !LEAN && g.epilogue == RLCF_EPI_RELU;     // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
     const float os = (!LEAN && PAIR && g.out_scale_dev) ? g.out_scale_dev[0] : 1.0f;
     const bool want_amax = !LEAN && g.amax_out != nullptr;
+    const bool nt = !LEAN && (g.no_fast_epi & 2);             // non-temporal output stores (RLCF_X3_NT=0: default cache policy, A/B)
     const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
     const int rbase = row0 + rsub;
     float4 rr[16];
@@ -104,13 +105,16 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (colok && row < g.M) {
                 if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (F32OUT) { const f32x4 o4_ = {v[0], v[1], v[2], v[3]}; if (nt) __builtin_nontemporal_store(o4_, (f32x4*)(g.C + (size_t)row * g.ldc + col)); else *(f32x4*)(g.C + (size_t)row * g.ldc + col) = o4_; }
                 if constexpr (PAIR) {
                     h16x4 hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const float vs = v[q] * os; hh[q] = (_Float16)vs; ll[q] = (_Float16)(vs - (float)hh[q]); }
+                    if (nt) { __builtin_nontemporal_store(hh, (h16x4*)(g.Chi + (size_t)row * g.ldch + ocol)); if (g.Clo) __builtin_nontemporal_store(ll, (h16x4*)(g.Clo + (size_t)row * g.ldch + ocol)); }
+                    else {
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + ocol) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + ocol) = ll;
+                    }
                 }
             }
         }
@@ -122,7 +126,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
             const int row = rbase + it * 4;
             if (colok && row < g.M) {
                 if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(rr[it].x), fabsf(rr[it].y)), fmaxf(fabsf(rr[it].z), fabsf(rr[it].w))));
-                if constexpr (F32OUT) *(float4*)(g.C + (size_t)row * g.ldc + col) = rr[it];
+                if constexpr (F32OUT) { const f32x4 o4_ = {rr[it].x, rr[it].y, rr[it].z, rr[it].w}; if (nt) __builtin_nontemporal_store(o4_, (f32x4*)(g.C + (size_t)row * g.ldc + col)); else *(f32x4*)(g.C + (size_t)row * g.ldc + col) = o4_; }
                 if constexpr (PAIR) {
                     const float v[4] = {rr[it].x * os, rr[it].y * os, rr[it].z * os, rr[it].w * os};
                     h16x4 hh, ll;
@@ -139,7 +143,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
 // which specialisation (wave-uniform): 0 = none (generic epilogue), 1 = f32 out, 2 = f32 out + residual, 3 = QuickGELU -> operand pair,
 // 4 = operand pair only (in_proj of the image towers: Q / K / V go to the attention kernel as f16 pairs, attention_pair.hip)
 __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
-    if (g.aux || g.no_fast_epi || g.ksplit > 1) return 0;
+    if (g.aux || (g.no_fast_epi & 1) || g.ksplit > 1) return 0;
     const bool f32o = g.C != nullptr, pair = g.Chi != nullptr, res = g.residual != nullptr;
     // kinds 1 / 2 also carry the ResNet convolutions' epilogue: device-side alpha, ReLU after the identity add, max|C| for the next scale
     const bool lin = g.epilogue == RLCF_EPI_NONE || g.epilogue == RLCF_EPI_RELU;

@@ -139,7 +139,9 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
                               hipStream_t st, float* lse = nullptr, int single = 0);
 void attention_pair_debug(int oneshot, int var);      // measurement switches of attention_pair.hip
 int launch_attention_bwd_mfma(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
-                              int max_q_len, int width, int causal, float* dqkv, hipStream_t st);
+                              int max_q_len, int width, int causal, float* dqkv, hipStream_t st, float* park = nullptr);
+// adds the parked per-query-block contributions to dK / dV in block order (attention_bwd_x3.hip; also behind the f32-MFMA backward)
+int launch_attention_bwd_park_reduce(const float* park, const rlcf_seq* seqs, int n_seq, int park_rows, int n_qb, int width, float* dqkv, hipStream_t st);
 // split-f16 form of launch_attention_bwd_mfma (attention_bwd_x3.hip); amax_dout: device scalar, max |dout| (launch_absmax)
 // two-kernel form for sequences without a shared prefix / causal mask (attention_bwd_x3b.hip): dqkv written completely, single writers
 int launch_attention_bwd_x3_split(const float* qkv, const float* out, const float* lse, const float* dout, const float* amax_dout, const rlcf_seq* seqs,

@@ -669,6 +669,25 @@ def main():
                             bank_seed=7, n_ctx=4, **hp)
                 save(name, arrays, meta)
                 print(f"  {name}: idx={arrays['selected_idx']} top5={arrays['top5']} |g|={np.linalg.norm(arrays['ln_grad']):.3e}")
+        elif grp == "lnl14stream":
+            # BASELINE configs[2] at full size as a short STREAM: four consecutive test images (view seeds 1000..1003) through the harness
+            # body of TPT/tune_cls_rl.py:206-227, one at a time (sample 0 is the ln_l14_n64 fixture itself); pins rlcf_tta_batch_ln on more
+            # than one full-size sample.  ~15 min of CPU per sample here.
+            hp = dict(BASE_HP, **LN_CASES["ln_l14_n64"][4])
+            student, reward, n, c, _ = LN_CASES["ln_l14_n64"]
+            arrays, n_s = {}, int(os.environ.get("STREAM_N", "4"))
+            z0 = np.load(os.path.join(HERE, "ln_l14_n64.npz"))
+            for i in range(n_s):
+                t0 = time.time()
+                if i == 0:
+                    a_i = {k: z0[k] for k in z0.files if not k.startswith("meta_")}
+                else:
+                    a_i = run_reference_ln(ref, student, reward, n, c, dict(hp), view_seed=1000 + i)
+                for k in ("selected_idx", "topk_idx", "clip_score", "rewards", "final_logits", "top5", "ln_grad"):
+                    arrays[f"{k}_{i}"] = np.asarray(a_i[k])
+                print(f"  ln stream sample {i}: {time.time() - t0:.1f}s idx={arrays[f'selected_idx_{i}']} top5={arrays[f'top5_{i}']}", flush=True)
+            save("ln_l14_n64_stream", arrays, dict(student=student, reward=reward, n_views=n, n_cls=c, student_seed=11, reward_seed=23,
+                                                   view_seed0=1000, n_samples=n_s, bank_seed=7, n_ctx=4, **hp))
         elif grp == "b16stream":
             # BASELINE configs[1] as a STREAM: eight consecutive test images (view seeds 1113..1120) through the harness body
             # TPT/tpt_cls_rl.py:251-262 one at a time (reset -> test_time_tuning -> clean-view logits); pins rlcf_tta_batch at the
