@@ -64,7 +64,8 @@ def test_self_launch_becomes_n_ranks(tmp_path):
         "    print('parent rc', rc); sys.exit(rc)\n"
         "import torch.distributed as dist\n"
         "dist.init_process_group('gloo')\n"
-        "print('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'], 'args', sys.argv[1:], 'master', os.environ['MASTER_ADDR'], flush=True)\n"
+        # one write() per rank: the ranks share the launcher's pipe and print()'s per-argument writes interleave
+        "sys.stdout.write('rank %s of %s args %s master %s\\n' % (os.environ['RANK'], os.environ['WORLD_SIZE'], sys.argv[1:], os.environ['MASTER_ADDR'])); sys.stdout.flush()\n"
         "dist.barrier(); dist.destroy_process_group()\n")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, str(script), "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
