@@ -99,6 +99,20 @@ int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, 
 int rlcf_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
                   void* C16, int ldch, int M, int N, int K, float alpha, int epilogue, rlcf_stream stream);
 
+/* The same product with the preceding LayerNorm FOLDED in (RLCF_PREC_F16 image towers; rlcf_amd/csrc/gemm_f16.hip, MODE 1 / 2).  Under
+ * autocast the reference's residual stream is an fp16 tensor — its LayerNorm computes in fp32 and casts back to the input type, and
+ * x = x + attention(ln_1(x)) adds fp16 tensors (TPT/clip/model.py:157-163,187-192 under TPT/tpt_cls_rl.py:52) — so
+ *   mode 1 (ln_1 -> in_proj, ln_2 -> c_fc):  out16[M,N] = epi(rstd_r (alpha x16.Wg^T - mu_r s) + bias),  x16 = the f16 residual rows, Wg = the
+ *          f16 copy of W diag(gamma), s [N] = its row sums (times alpha), bias = W beta + b, ln_mr [M][2] = (mean, rstd) of x16's rows;
+ *   mode 2 (out_proj, c_proj + residual add): out16[M,N] (the residual stream, IN PLACE) = f16(out16 + alpha A.W^T + bias), and the partial
+ *          (sum, sum of squares) of every updated row over each 64-column slice goes to ln_part [(N/64)][M][2];
+ * rlcf_ln_stats_final adds the N/64 partials of a row in order -> ln_mr (eps 1e-5, biased variance: nn.LayerNorm);  rlcf_resid16_init
+ * rounds an f32 stream to f16 rows and leaves their (mean, rstd).  N % 256 == 0, K % 128 == 0, K >= 256. */
+int rlcf_gemm_f16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
+                     int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, rlcf_stream stream);
+int rlcf_ln_stats_final(const float* ln_part, int parts, int rows, int width, float* ln_mr, rlcf_stream stream);
+int rlcf_resid16_init(const float* x, void* x16, float* ln_mr, int rows, int width, rlcf_stream stream);
+
 /* 3x3 convolution, stride 1, padding 1, NHWC, as an IMPLICIT GEMM on the f16 matrix cores with split-f16 operands (no patch matrix: the
  * 256x256 GEMM kernel's DMA reads every tap's K tile straight from the activation's operand pairs): the `conv2` of a Bottleneck
  * (TPT/clip/model.py:20,44) with its BatchNorm folded, as the engine's ResNet towers run it.  x [n,H,W,Cin], w [Cout,3,3,Cin] ((ky,kx,c)

@@ -70,6 +70,9 @@ SIGNATURES = {
     "rlcf_split_f16x2": (I, [P, P, P, I64, P]),
     "rlcf_conv3x3_nhwc_f16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "rlcf_gemm_f16": (I, [P, I, P, I, P, P, I, P, I, P, I, I, I, I, F, I, P]),
+    "rlcf_gemm_f16_ln": (I, [P, I, P, I, P, P, I, I, I, I, F, I, I, P, P, P, P]),
+    "rlcf_ln_stats_final": (I, [P, I, I, I, P, P]),
+    "rlcf_resid16_init": (I, [P, P, P, I, I, P]),
     "rlcf_gemm_f16x3": (I, [P, P, I, P, P, I, P, P, I, P, I, P, I, P, P, I, I, I, I, F, I, P]),
     "rlcf_layernorm_fwd": (I, [P, P, P, P, I, I, P]),
     "rlcf_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),

@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 9; }   // 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 10; }   // 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -75,6 +75,16 @@ int rlcf_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* b
                              ldch, M, N, K, alpha, epilogue, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, 0, 1);
 }
 
+int rlcf_gemm_f16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
+                     int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, rlcf_stream stream) {
+    return launch_gemm_f16_pp_ln(A, lda, W, ldw, bias, out16, ldo, M, N, K, alpha, epilogue, mode, ln_mr, ln_s, ln_part, (hipStream_t)stream);
+}
+int rlcf_ln_stats_final(const float* ln_part, int parts, int rows, int width, float* ln_mr, rlcf_stream stream) {
+    return launch_ln_stats_final(ln_part, parts, rows, width, ln_mr, (hipStream_t)stream);
+}
+int rlcf_resid16_init(const float* x, void* x16, float* ln_mr, int rows, int width, rlcf_stream stream) {
+    return launch_resid16_init(x, x16, ln_mr, rows, width, (hipStream_t)stream);
+}
 int rlcf_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi, const void* Wlo, int ldw, const float* bias,
                     const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                     int M, int N, int K, float alpha, int epilogue, rlcf_stream stream) {

@@ -52,6 +52,7 @@ struct Tower {                       // workspace of one transformer pass over T
     int T = 0, width = 0;
     DevBuf x, h, qkv, a, f;          // f32 activations
     DevBuf h2, a2, f2;               // interleaved split-f16 operand pairs written by the producers (F16X3 mode): LN out, attention out, fc out
+    DevBuf x16, lnmr, lnpart;        // RLCF_PREC_F16 image towers with folded LayerNorms: f16 residual stream, (mean, rstd) per row, partial row statistics
     int x3_T = 0, x3_W = 0;
     DevBuf saved;                    // per-layer saved activations for backward
     std::vector<SavedLayer> sv;
@@ -122,6 +123,10 @@ struct ClipModel {
     struct SplitW { void *hi, *lo; float inv_scale; };                    // W * 2^s = hi + lo; inv_scale = 2^-s
     std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 / F16 modes)
     std::unordered_map<const float*, SplitW> f16_of;                      // f32 weight -> plain f16 copy (.hi; RLCF_PREC_F16 mode only)
+    // RLCF_PREC_F16 image towers: in_proj / c_fc weight with the preceding LayerNorm folded in (engine.hip make_lnfold): w16 = f16 copy of
+    // W diag(gamma) 2^s, inv_scale = 2^-s, s = row sums of that copy times 2^-s, bprime = W beta + b
+    struct LnFold { void* w16; float inv_scale; const float* s; const float* bprime; };
+    std::unordered_map<const float*, LnFold> lnfold_of;
 };
 
 // full image-encoder tuning (CLIPCLS_TTA only_norm=False): one entry per non-LayerNorm visual tensor of the flat buffer, and the

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
     for (int half = 0; half < 2; ++half)
         X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
                          m0 + wm * 128 + half * 64, n0 + wn * 64, lane, am)
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
 //     consecutive columns of one row, f16 rounding, 8-byte stores (8 lanes = 64 B of a row); the stores drain while the next tile's K
 //     loop runs,
 //   * the two wave groups line up for the epilogue (one extra barrier each per tile) so that both run it at the same time.
-template <int EPI>
+template <int EPI, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR]
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     tile_origin(lin, m0, n0);
     auto ra = rsrc_a(m0), rw = rsrc_w(n0);
     PP_STAGE_A(0, 0, ra, 0) PP_STAGE_B(0, 0, rw, 0) PP_STAGE_B(1, 0, rw, 0) PP_STAGE_A(1, 0, ra, 0)
-    PP_STAGE_A(0, 1, ra, 1) PP_STAGE_B(1, 1, rw, 1) PP_STAGE_A(1, 1, ra, 1)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    PP_STAGE_A(0, 1, ra, 1) PP_STAGE_B(1, 1, rw, 1) PP_STAGE_A(1, 1, ra, 1) PP_STAGE_B(0, 1, rw, 1)      // (B_lo of K tile 1 last: see PP_KTILE_FIRST)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -267,10 +267,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     {                                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                              \
         _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                            \
-            acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][0], b[0], zero16, 0, 0, 0);                         \
+            acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0], a[i2][0], zero16, 0, 0, 0);                         \
         _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                                            \
             _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                        \
-                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
+                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks], a[i2][ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
         __builtin_amdgcn_s_setprio(0);                                                                                              \
     }
 #define PP_MMA(ib, j)                                                                                                               \
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         __builtin_amdgcn_s_setprio(1);                                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                            \
             _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                                        \
-                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i2][ks], b[ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
+                acc[(ib) * 2 + i2][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks], a[i2][ks], acc[(ib) * 2 + i2][j], 0, 0, 0);    \
         __builtin_amdgcn_s_setprio(0);                                                                                              \
     }
 // one K tile of the steady state: stages B_lo of K tile kt+1 and the other three half tiles of kt+2, all of THIS tile.  MMA_ = PP_MMA, or
@@ -300,11 +300,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         P8_MID MMA_(1, 1) P8_END                                                                                                    \
         P8_LDB(0, par)                                                                                                              \
         PP_STAGE_A(1, par, ra, (kt) + 2)                                                                                            \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                            \
+        PP_WAIT_##H_                                                                                                                \
         H_(3)                                                                                                                       \
         P8_MID MMA_(1, 0) P8_END                                                                                                    \
     }
 #define PP_NOHOOK(n)
+#define PP_WAIT_PP_NOHOOK asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#define PP_ST(v, p) { if (g.sk_epoch) __builtin_nontemporal_store(v, (h16x8*)(p)); else *(h16x8*)(p) = v; }      // (g.sk_epoch: RLCF_F16_PP_NT)
+// K tile 0 of a tile (round 5).  Stores count in vmcnt like loads and retire in order, and the epilogue's 16 stores per wave take
+// ~6 us to retire when every CU of the chip bursts its 128-KB tile at the same moment (without stores in_proj runs 818 instead of
+// 1031 us, c_fc 1023 instead of 1363: profiles/r5_notes.md) — whatever load the NEXT wait covers that was issued AFTER them waits for
+// them.  The first form staged B_lo of K tile 1 in phase 1 of K tile 0, i.e. behind the stores, and needed it one K tile later.  Now B_lo
+// of K tile 1 is staged at the START of the epilogue (its buffer — parity 1 — was last read in phase 4 of the tile's last K tile, and both
+// wave groups have lined up behind that phase), so the loads K tile 1 needs are all OLDER than the stores: K tile 0 stages only its
+// three half tiles of K tile 2 and its wait leaves them AND the stores outstanding (vmcnt(6 + stores)); the stores have until the end
+// of K tile 1, two K tiles instead of three quarters of one, to retire.  (Measured and dropped on the way: keeping half of a tile's
+// output in registers and storing it one instruction per phase under K tiles 0 and 1 — slower, 1051 -> 1078 us on in_proj: every one
+// of those K tiles' waits then sits behind a store.)
+// nst (wave-uniform): 0 = no store of this wave may be outstanding (first tile of the workgroup; a tile at the matrix edge, whose
+// epilogue drains), 1 = the 16 stores of a whole tile, 2 = the 20 of a MODE 2 tile (+ 4 partial-statistics stores)
+#define PP_KTILE_FIRST(MMA_)                                                                                                        \
+    {                                                                                                                               \
+        P8_LDB(0, 0) P8_LDA(0, 0)                                                                                                   \
+        P8_MID MMA_(0, 0) P8_END                                                                                                    \
+        P8_LDB(1, 0)                                                                                                                \
+        PP_STAGE_A(0, 0, ra, 2)                                                                                                     \
+        P8_MID MMA_(0, 1) P8_END                                                                                                    \
+        P8_LDA(1, 0)                                                                                                                \
+        PP_STAGE_B(1, 0, rw, 2)                                                                                                     \
+        P8_MID MMA_(1, 1) P8_END                                                                                                    \
+        P8_LDB(0, 0)                                                                                                                \
+        PP_STAGE_A(1, 0, ra, 2)                                                                                                     \
+        if (nst == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                              \
+        else if (nst == 1) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                                                        \
+        else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                                                                      \
+        P8_MID MMA_(1, 0) P8_END                                                                                                    \
+    }
 #define PP_KTILE(kt, par) PP_KTILE_X(kt, par, PP_MMA, PP_NOHOOK)
 // the last two K tiles of a tile: K tile nk-2 stages B_lo of nk-1 (this tile) and A_lo / B_hi / A_hi of the NEXT tile's K tile 0;
 // K tile nk-1 stages the next tile's B_lo of K tile 0 and A_lo / B_hi / A_hi of its K tile 1 (nothing when this is the last tile)
@@ -328,12 +359,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         P8_MID PP_MMA(1, 0) P8_END                                                                                                  \
     }
     const float al = g.alpha;
-    const int i0 = lane & 1, i1 = (lane >> 1) & 1;
     if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the second group runs one barrier behind
     // (measurement: g.ws != null -> s_memtime stamps of waves 0 / 4 for the first 64 tiles of every workgroup: K loop start, K loop end,
     //  groups lined up, epilogue issued)
     unsigned long long* trace = (unsigned long long*)g.ws;
     int tile_it = 0;
+    int nst = 0;                                 // what the previous epilogue of this wave left outstanding (see PP_KTILE_FIRST)
+    static_assert(MODE == 0 || MODE == 1 || MODE == 2, "epilogue mode");
 #define PP_STAMP(k) if (trace && (wave & 3) == 0 && lane == 0 && tile_it < 64) trace[(((size_t)blockIdx.x * 64 + tile_it) * 2 + wm) * 16 + (k)] = __builtin_amdgcn_s_memtime();
     for (;;) {
         const int nlin = lin + wpx;
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         int m0n = 0, n0n = 0;
         if (have_next) tile_origin(g.ksplit == 8 ? lin : nlin, m0n, n0n);          // (ksplit 8: measurement — every tile of a workgroup is its first)
         auto ran = rsrc_a(m0n), rwn = rsrc_w(n0n);
-        PP_KTILE_X(0, 0, PP_MMA0, PP_NOHOOK)
+        PP_KTILE_FIRST(PP_MMA0)
         PP_KTILE(1, 1)
         if (trace) { PP_STAMP(4) }
         for (int kt = 2; kt + 2 < nk; kt += 2) {
@@ -356,58 +388,122 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         PP_STAMP(1)
         if (wm == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
         PP_STAMP(2)
+        // B_lo of the next tile's K tile 1, BEFORE this tile's stores (see PP_KTILE_FIRST)
+        if (have_next) PP_STAGE_B(0, 1, rwn, 1)
         if (g.ksplit != 2) {                                                // (ksplit 2: measurement without any epilogue)
-            // accumulator tile j, lane l32 = column 8 (l32 >> 2) + 4 j + (l32 & 3) of the wave's 64: bias is a per-lane constant
-            const int colb = n0 + wn * 64 + (l32 >> 2) * 8 + (l32 & 3);
-            float bj[2] = {0.f, 0.f};
-            if (g.bias) { bj[0] = colb < g.N ? g.bias[colb] : 0.f; bj[1] = colb + 4 < g.N ? g.bias[colb + 4] : 0.f; }
-            // after the transposes: lane = row (lane & 3) of a 4-row group, columns 8 (l32 >> 2) .. + 7 (tile 0's four, then tile 1's four)
-            const int ocol = n0 + wn * 64 + (l32 >> 2) * 8;
-            const int orow = m0 + wm * 128 + 4 * h + (lane & 3);
+            // The MFMAs ran with the operands swapped (W fragment first): an accumulator tile is C^T, so lane l32 owns ROW l32 of the 32-row
+            // tile i and register r the tile column c = 8 (r >> 2) + 4 h + (r & 3), i.e. (B half tiles interleaved at 4-column granularity,
+            // see vw) column 16 (r >> 2) + 8 h + 4 j + (r & 3) of the wave's 64: the two tiles j give a lane 8 CONSECUTIVE columns per register
+            // quad -> one 16-byte store, with no transpose at all (the round-5 first form moved every value through two DPP exchanges and
+            // two selects to get there: 6.5 VALU operations per output value with the matrix pipe idle, now 2.5).  A store instruction
+            // writes 32 rows x 32 B; the four register quads of a row follow each other and complete its 128-byte line in the L2.
+            const int ocol = n0 + wn * 64 + 8 * h;
+            const int orow = m0 + wm * 128 + l32;
             const bool inside = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;       // (whole tile, 16-byte aligned rows: no masks)
             _Float16* obase = g.Chi + (size_t)orow * g.ldch + ocol;
-#define PP_DPP(x, ctl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctl, 0xf, 0xf, true))
+            float bj[4][8];
+            if (g.bias && n0 + 256 <= g.N && (((uintptr_t)g.bias) & 15) == 0) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 b0 = *(const float4*)(g.bias + ocol + gq * 16), b1 = *(const float4*)(g.bias + ocol + gq * 16 + 4);
+                    bj[gq][0] = b0.x; bj[gq][1] = b0.y; bj[gq][2] = b0.z; bj[gq][3] = b0.w;
+                    bj[gq][4] = b1.x; bj[gq][5] = b1.y; bj[gq][6] = b1.z; bj[gq][7] = b1.w;
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bj[gq][e] = (g.bias && ocol + gq * 16 + e < g.N) ? g.bias[ocol + gq * 16 + e] : 0.f;
+            }
+            if constexpr (MODE == 2) {
+                // residual rows: every load is issued before the first store (stores count in vmcnt: a load behind one would wait for it)
+                h16x8 xr[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const _Float16* rp = g.Chi + (size_t)min(orow + i * 32, g.M - 1) * g.ldch + ocol;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) xr[i][gq] = *(const h16x8*)(rp + gq * 16);
+                }
+                const int part = (n0 >> 8) * 4 + wn;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = orow + i * 32;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        h16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const _Float16 v = (_Float16)((float)xr[i][gq][j * 4 + q] + (al * acc[i][j][gq * 4 + q] + bj[gq][j * 4 + q]));
+                                const float vf = (float)v;             // the statistics describe the STORED row (what the next product reads)
+                                s1 += vf; s2 += vf * vf;
+                                o[j * 4 + q] = v;
+                            }
+                        if (row < g.M) *(h16x8*)(g.Chi + (size_t)row * g.ldch + ocol + gq * 16) = o;
+                    }
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);        // the other half-wave holds the row's other 32 columns
+                    if (h == 0 && row < g.M) *(float2*)(g.ln_part + ((size_t)part * g.M + row) * 2) = make_float2(s1, s2);
+                }
+            } else {
+            // RLCF_F16_PP_DEFER=0 (g.sk_first): every store at once (A/B measurements)
+            float sj[4][8];
+            float rA[4], rB[4];
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 s0 = *(const float4*)(g.ln_s + ocol + gq * 16), s1 = *(const float4*)(g.ln_s + ocol + gq * 16 + 4);
+                    sj[gq][0] = s0.x; sj[gq][1] = s0.y; sj[gq][2] = s0.z; sj[gq][3] = s0.w;
+                    sj[gq][4] = s1.x; sj[gq][5] = s1.y; sj[gq][6] = s1.z; sj[gq][7] = s1.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 mr = *(const float2*)(g.ln_mr + (size_t)min(orow + i * 32, g.M - 1) * 2);
+                    rA[i] = al * mr.y; rB[i] = -mr.y * mr.x;          // rstd (alpha acc - mu s) + b' = (alpha rstd) acc + ((-rstd mu) s + b')
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     h16x8 o;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const f32x16& c = acc[i][j];
-                        float r0 = al * c[gq * 4] + bj[j], r1 = al * c[gq * 4 + 1] + bj[j], r2 = al * c[gq * 4 + 2] + bj[j], r3 = al * c[gq * 4 + 3] + bj[j];
-                        if constexpr (EPI == RLCF_EPI_QUICKGELU) { r0 = quick_gelu_fast(r0); r1 = quick_gelu_fast(r1); r2 = quick_gelu_fast(r2); r3 = quick_gelu_fast(r3); }
-                        // lane bit 0 <-> register bit 0, then lane bit 1 <-> register bit 1 (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E)
-                        const float p0 = PP_DPP(r0, 0xB1), p1 = PP_DPP(r1, 0xB1), p2 = PP_DPP(r2, 0xB1), p3 = PP_DPP(r3, 0xB1);
-                        const float s0 = i0 ? p1 : r0, s1 = i0 ? r1 : p0, s2 = i0 ? p3 : r2, s3 = i0 ? r3 : p2;
-                        const float q0 = PP_DPP(s0, 0x4E), q1 = PP_DPP(s1, 0x4E), q2 = PP_DPP(s2, 0x4E), q3 = PP_DPP(s3, 0x4E);
-                        const float t0 = i1 ? q2 : s0, t2 = i1 ? s2 : q0, t1 = i1 ? q3 : s1, t3 = i1 ? s3 : q1;
-                        o[j * 4] = (_Float16)t0; o[j * 4 + 1] = (_Float16)t1; o[j * 4 + 2] = (_Float16)t2; o[j * 4 + 3] = (_Float16)t3;
-                    }
-                    _Float16* op = obase + (size_t)(i * 32 + gq * 8) * g.ldch;
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float r;
+                            if constexpr (MODE == 1) r = rA[i] * acc[i][j][gq * 4 + q] + (rB[i] * sj[gq][j * 4 + q] + bj[gq][j * 4 + q]);
+                            else r = al * acc[i][j][gq * 4 + q] + bj[gq][j * 4 + q];
+                            if constexpr (EPI == RLCF_EPI_QUICKGELU) r = quick_gelu_fast(r);
+                            o[j * 4 + q] = (_Float16)r;
+                        }
+                    _Float16* op = obase + (size_t)(i * 32) * g.ldch + gq * 16;
                     if (g.ksplit == 1 && o[0] != (_Float16)123.0f) continue;            // (measurement: no stores)
                     if (inside) {
-                        if (g.ksplit == 3) *(h16x8*)op = o;
-                        else if (g.ksplit == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(op), "v"(o) : "memory");
-                        else if (g.ksplit == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(op), "v"(o) : "memory");
-                        else if (g.ksplit == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(op), "v"(o) : "memory");
-                        else __builtin_nontemporal_store(o, (h16x8*)op);          // (streaming output: ~2 % over the default policy on the layer's four products)
-                    } else {
-                        const int row = orow + i * 32 + gq * 8;
-                        if (row < g.M) {
-                            if (ocol + 8 <= g.N && (g.ldch & 7) == 0) *(h16x8*)op = o;
-                            else {
-                                if (ocol + 4 <= g.N) *(h16x4*)op = h16x4{o[0], o[1], o[2], o[3]};
-                                if (ocol + 8 <= g.N) *(h16x4*)(op + 4) = h16x4{o[4], o[5], o[6], o[7]};
-                            }
+                        PP_ST(o, op)
+                    } else if (orow + i * 32 < g.M) {
+                        const int c0 = ocol + gq * 16;
+                        if (c0 + 8 <= g.N && (g.ldch & 7) == 0) *(h16x8*)op = o;
+                        else {
+                            if (c0 + 4 <= g.N) *(h16x4*)op = h16x4{o[0], o[1], o[2], o[3]};
+                            if (c0 + 8 <= g.N) *(h16x4*)(op + 4) = h16x4{o[4], o[5], o[6], o[7]};
                         }
                     }
                 }
+            }
             }
         }
         PP_STAMP(3)
         ++tile_it;
         if (!have_next) break;
+        {
+            // what this wave's epilogue left in flight behind the early B_lo: the 16 (MODE 2: 20) stores of a whole tile, or nothing —
+            // a tile at the matrix edge issues a data-dependent number of masked stores, so it drains instead
+            const bool whole = g.ksplit == 0 && m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;
+            if (g.ksplit == 0 && !whole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            nst = whole ? (MODE == 2 ? 2 : 1) : 0;
+        }
         if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // back to one barrier behind
         lin = nlin; m0 = m0n; n0 = n0n; ra = ran; rw = rwn;
     }
@@ -436,6 +532,51 @@ static int f16_pp_enabled() {
     return on;
 }
 
+// RLCF_F16_PP_NT=1: non-temporal output stores.  The first (transposing) epilogue wrote whole 128-byte lines per instruction and gained ~2 %
+// from them; the transpose-free epilogue writes 32 rows x 32 B per instruction, and a non-temporal store of a PART of a line is a partial
+// write at the memory (tools/probes/store_rate.hip: 32x32-B pieces, 256 CUs: 5.6 TB/s with the default policy, 0.97 TB/s non-temporal)
+static int pp_nt_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("RLCF_F16_PP_NT"); on = e ? atoi(e) : 0; }
+    return on;
+}
+// LayerNorm-folded products of the single-pass f16 image towers (GemmX3Args::ln_*): always the persistent kernel.
+//   mode 1: out[M, N] (f16) = epi(rstd_r (alpha A.W'^T - mu_r s) + bias'),  A = the f16 residual stream, ln_mr [M][2], ln_s [N]
+//   mode 2: x[M, N] (f16, in place) += alpha A.W^T + bias;  ln_part [(N / 256) * 4][M][2] receives the partial row statistics
+int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
+                          int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, hipStream_t st) {
+    RLCF_ARG_CHECK(M > 0 && A && W && out16 && (mode == 1 || mode == 2) && K % 128 == 0 && K >= 256 && N % 256 == 0 && ldo % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0);
+    RLCF_ARG_CHECK(mode == 1 ? (ln_mr && ln_s && (epilogue == RLCF_EPI_NONE || epilogue == RLCF_EPI_QUICKGELU)) : (ln_part && epilogue == RLCF_EPI_NONE));
+    RLCF_ARG_CHECK((size_t)256 * lda * 2 < 0x7fffffffu && (size_t)256 * ldw * 2 < 0x7fffffffu && (((uintptr_t)ln_s) & 15) == 0 && (((uintptr_t)bias) & 15) == 0);
+    GemmX3Args g{};
+    g.Ahi = (const _Float16*)A; g.lda = lda; g.Whi = (const _Float16*)W; g.ldw = ldw; g.bias = bias; g.Chi = (_Float16*)out16; g.ldch = ldo;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.kstep = 64; g.ksplit = 0; g.tile_group = 0; g.sk_blocks = 1;
+    g.ln_mr = ln_mr; g.ln_s = ln_s; g.ln_part = ln_part;
+    g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int blocks = ((M + 255) / 256) * (N / 256);
+    const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
+    const size_t shp = (size_t)2 * P8_PAR;
+#define PP_LN_GO(E, MD)                                                                                                             \
+    {                                                                                                                               \
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD>, shp);                                                      \
+        if (rc != RLCF_OK) return rc;                                                                                               \
+        gemm_nt_f16_pp_kernel<E, MD><<<dim3(grid), dim3(512), shp, st>>>(g);                                                         \
+    }
+    if (mode == 2) PP_LN_GO(RLCF_EPI_NONE, 2)
+    else if (epilogue == RLCF_EPI_QUICKGELU) PP_LN_GO(RLCF_EPI_QUICKGELU, 1)
+    else PP_LN_GO(RLCF_EPI_NONE, 1)
+#undef PP_LN_GO
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
 int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
                        void* Cf16, int ldch, int M, int N, int K, float alpha, int epilogue, int tile_group, hipStream_t st) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0 && A && W && (C || Cf16));
@@ -458,6 +599,7 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
         const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
         const size_t shp = (size_t)2 * P8_PAR;
         g.ksplit = abl;
+        g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
         static int desync = -1;                              // RLCF_F16_PP_DESYNC=P: start-time cohorts (1 = all together)
         if (desync < 0) { const char* e = getenv("RLCF_F16_PP_DESYNC"); desync = e ? atoi(e) : 1; }
         g.sk_blocks = blocks > grid ? desync : 1;            // (one tile per workgroup: nothing to interleave)

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
         if (col < g.N) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
+            const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int rl = it * 4 + rsub, row = m0 + wm * 64 + rl;
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = v[q] * osd_; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
-        amax_commit(g.amax_out, am);
+        amax_commit(g.amax_out, am); x3_publish_scale(g);
         return;
     }
 #pragma unroll
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 }
             }
         }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         } else {
             X3_EPILOGUE_HALFSLAB(ek, g, acc[0][0], acc[0][1], acc[0][0], acc[0][1], (float*)smem + wave * (32 * 68), m0 + wm * 32, n0 + wn * 64, lane, am)
         }
-        amax_commit(g.amax_out, am);
+        amax_commit(g.amax_out, am); x3_publish_scale(g);
         return;
     }
     {
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         if (col < g.N) {                                                    // N % 4 == 0 is checked by the launcher
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
+            const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 8 * RT; ++it) {
                 const int rl = it * 4 + rsub, row = m0 + wm * (32 * RT) + rl;
@@ -428,14 +430,14 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = v[q] * osd_; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
     }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 for (int r = 0; r < 16; ++r) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i][j][r];
         __syncthreads();
         if (col < g.N) {
+            const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int rl = it * 4 + rsub, row = m0 + wm * 128 + half * 64 + rl;
@@ -623,14 +626,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = v[q] * osd_; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
     }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // cache-policy bits of the operand DMA (one-off builds: -DV3_AUX_A=.. / -DV3_AUX_W=..; bit 0 sc0, bit 1 nt, bit 4 sc1)
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                              m0 + wm * (MT * 32) + half * 64, n0 + wn * 64, lane, am)
         if constexpr (MT == 3)           // the third 32-row tile: half a slab
             X3_EPILOGUE_HALFSLAB(ek, g, acc[2][0], acc[2][1], acc[2][0], acc[2][1], parkf, m0 + wm * 96 + 64, n0 + wn * 64, lane, am)
-        amax_commit(g.amax_out, am);
+        amax_commit(g.amax_out, am); x3_publish_scale(g);
         return;
     }
     // epilogue through LDS, two passes of 64 rows per wave (8 waves x 64 x 68 floats = 139 KB)
@@ -954,6 +957,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                     if (half * 2 + i < MT) park[(i * 32 + mfma32_row(r, h)) * ELD + j * 32 + l32] = acc[half * 2 + i < MT ? half * 2 + i : 0][j][r];
         __syncthreads();
         if (col < g.N) {
+            const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int rl = it * 4 + rsub, row = m0 + wm * (MT * 32) + half * 64 + rl;
@@ -981,14 +985,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                 if (g.Chi) {
                     h16x4 hh, ll;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = v[q] * osd_; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
                     if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
                 }
             }
         }
     }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // second pass of the split-K form: C = epi(alpha * sum_z ws[z] + bias) (+ residual), the epilogue of the kernels above, one thread
@@ -997,6 +1001,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
     float am = 0.f;
     const int n4 = g.N >> 2;
     const long total = (long)g.M * n4;
+    const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int row = (int)(i / n4), col = (int)(i % n4) * 4;
         // bias / aux / residual first, then the slices four at a time (independent loads in flight together; the adds stay in slice order)
@@ -1031,12 +1036,12 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
         if (g.Chi) {
             h16x4 hh, ll;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const float vs_ = g.out_scale_dev ? v[q] * g.out_scale_dev[0] : v[q]; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
+                    for (int q = 0; q < 4; ++q) { const float vs_ = v[q] * osd_; hh[q] = (_Float16)vs_; ll[q] = (_Float16)(vs_ - (float)hh[q]); }
             *(h16x4*)(g.Chi + (size_t)row * g.ldch + x3_ocol(g, col)) = hh;
             if (g.Clo) *(h16x4*)(g.Clo + (size_t)row * g.ldch + x3_ocol(g, col)) = ll;
         }
     }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -1182,7 +1187,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_f16x3_v4_kernel(GemmX3Args g) 
         for (int hc = 0; hc < 2; ++hc)
             V4_SLAB(g, acc[hr * 2][hc * 2], acc[hr * 2][hc * 2 + 1], acc[hr * 2 + 1][hc * 2], acc[hr * 2 + 1][hc * 2 + 1], parkf,
                     m0 + wm * 128 + hr * 64, n0 + wn * 128 + hc * 64, lane, am)
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 
 extern int g_last_x3_variant;
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_x3_kernel(SkinnyArgs s) {
             g.C[(size_t)rr * g.ldc + col] = v;
         }
     }
-    amax_commit(g.amax_out, am);
+    amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 // A [M, K] f32 (lda), W pairs [N, 2K] interleaved; C f32 [M, N].  ws / ws_bytes: split-K scratch (K >= 1024); inv_scale_scratch: one
 // device float (needed with amax_in AND K slices).  Returns RLCF_ERR_ARG for shapes it does not serve (the caller falls back).
@@ -1407,6 +1412,18 @@ int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const flo
     return RLCF_OK;
 }
 
+// bound-derived output scale of the NEXT pair-emitting launch of this thread (GemmX3Args::bnd_*; resnet.hip's conv_pairs): consumed by
+// launch_gemm_f16x3 / launch_gemm_f16x3_conv3x3
+struct X3Bound { const float* in; const float* res; float gain, bmax; float* out2; };
+static thread_local X3Bound g_next_bound = {nullptr, nullptr, 0.f, 0.f, nullptr};
+void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float gain, float bmax, float* out2) {
+    g_next_bound = X3Bound{amax_in, amax_res, gain, bmax, out2};
+}
+static inline void x3_take_bound(GemmX3Args& g) {
+    g.bnd_in = g_next_bound.in; g.bnd_res = g_next_bound.res; g.bnd_gain = g_next_bound.gain; g.bnd_bmax = g_next_bound.bmax;
+    g.bnd_out2 = g_next_bound.out2;
+    g_next_bound = X3Bound{nullptr, nullptr, 0.f, 0.f, nullptr};
+}
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 // splitk_ws / splitk_ws_bytes: caller-owned scratch for the split-K form of the small-grid kernel (the engine sizes it once at
 // create); without it those shapes run unsplit.  Nothing is allocated here.
@@ -1430,6 +1447,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
     g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.c_il = c_il; g.out_scale_dev = out_scale_dev;
+    x3_take_bound(g);
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     RLCF_ARG_CHECK((g.kstep == 64) == (Wlo == (const void*)((const _Float16*)Whi + 32)));   // both operands in the same layout
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
@@ -1661,6 +1679,7 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = Cout; g.K = K; g.alpha = alpha;
     g.epilogue = epilogue; g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.kstep = 64;
     g.conv_C = Cin; g.conv_H = H; g.conv_W = W; g.zpage = (const _Float16*)zpage;
+    x3_take_bound(g);
     if (Cpairs) { RLCF_ARG_CHECK(Cout % 32 == 0); g.Chi = (_Float16*)Cpairs; g.Clo = g.Chi + 32; g.ldch = 2 * Cout; g.c_il = 1; g.out_scale_dev = out_scale_dev; }
     static int nofast = -1;
     if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }

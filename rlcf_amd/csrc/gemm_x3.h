@@ -37,6 +37,19 @@ struct GemmX3Args {
     unsigned sk_epoch;                 // value a "partial tile published" flag carries in THIS launch (flags are never reset)
     unsigned* sk_flags;                // [X3_SK_MAX_BLOCKS] + [1] time-out marker
     float* sk_ws;                      // [sk_blocks][256 x 256] raw partial accumulators, register layout
+    // Output scale of a pair-emitting convolution chosen INSIDE the launch (round 5; before: conv_bound_scale_kernel, a one-thread launch
+    // in front of every such GEMM — 136 launches per test image at RN50x64): bnd_in / bnd_res = device scalars max|input| and
+    // max|identity| (complete before this launch), bnd_gain / bnd_bmax = host constants of the folded convolution; every thread derives
+    // the same power of two s with (gain max|in| + bmax + max|res|) s in [2^14, 2^15) and thread 0 of workgroup 0 publishes (s, 1 / s) in
+    // bnd_out2 for the CONSUMER of the pairs (its alpha_dev).  bnd_in == nullptr: out_scale_dev as before.
+    const float *bnd_in, *bnd_res; float bnd_gain, bnd_bmax; float* bnd_out2;
+    // LayerNorm folded into the single-pass f16 products of an image tower (gemm_f16.hip, gemm_nt_f16_pp_kernel<EPI, MODE>):
+    //   MODE 1 (in_proj, c_fc): A is the f16 RESIDUAL STREAM itself and W carries the LayerNorm's gamma; the epilogue finishes the
+    //          normalisation per row: rstd_r (alpha acc - mu_r s_c) + b'_c with ln_mr = [M][2] (mu, rstd), ln_s = [N] row sums of the folded
+    //          f16 weight (what the MFMAs summed for a row of ones), bias = W beta + b
+    //   MODE 2 (out_proj, c_proj): Chi IS the residual stream: x[r, c] = f16(x[r, c] + alpha acc + b_c) in place, and the row's
+    //          (sum, sum of squares) over this wave's 64 columns goes to ln_part[(n0 / 256) * 4 + wn][r] for the next LayerNorm's statistics
+    const float* ln_mr; const float* ln_s; float* ln_part;
 };
 #define X3_SK_MAX_BLOCKS 1024
 #define X3_SK_FLAG_BYTES 8192                                   // flags + time-out word, at the end of the workspace
@@ -49,7 +62,26 @@ struct GemmX3Args {
 
 __device__ __forceinline__ int x3_ocol(const GemmX3Args& g, int col) { return g.c_il ? (((col >> 5) << 6) | (col & 31)) : col; }
 __device__ __forceinline__ float x3_alpha(const GemmX3Args& g) { return g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha; }
-
+// the scale the split output carries (1 when none): a device scalar chosen before the launch, or the bound-derived power of two (see bnd_in).
+// Evaluated where the epilogue uses it (NOT at kernel entry: a value live across the K loop costs the 256-register kernels a spill).
+__device__ __forceinline__ int x3_bound_shift(const GemmX3Args& g) {
+    const float B = 1.02f * (g.bnd_gain * g.bnd_in[0] + g.bnd_bmax + (g.bnd_res ? g.bnd_res[0] : 0.f));
+    int sh = 0;
+    if (B > 0.f && B < INFINITY) sh = 14 - (int)floorf(log2f(B));
+    return sh < -40 ? -40 : (sh > 40 ? 40 : sh);
+}
+__device__ __forceinline__ float x3_out_scale(const GemmX3Args& g) {
+    if (!g.bnd_in) return g.out_scale_dev ? g.out_scale_dev[0] : 1.0f;
+    return ldexpf(1.0f, x3_bound_shift(g));
+}
+// end of a kernel: thread 0 of workgroup 0 publishes (s, 1 / s) for the consumer of the pairs
+__device__ __forceinline__ void x3_publish_scale(const GemmX3Args& g) {
+    if (g.bnd_in && g.bnd_out2 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        const int sh = x3_bound_shift(g);
+        g.bnd_out2[0] = ldexpf(1.0f, sh);
+        g.bnd_out2[1] = ldexpf(1.0f, -sh);
+    }
+}
 // Epilogue of the DMA-ring kernels for the shapes of the forward towers, specialised at compile time (no per-row branches on the
 // epilogue kind) and written so that NOTHING waits inside the row loop: on gfx9 stores count in vmcnt like loads, so a residual load
 // issued after a store cannot be awaited without draining that store — the generic loops (load, wait, store, per row) pay one
@@ -72,7 +104,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     if (g.bias) bv = *(const float4*)(g.bias + colc);
     const float al = LEAN ? g.alpha : x3_alpha(g);         // (alpha_dev: the device-side undo of a data-dependent operand scale)
     const bool relu = !LEAN && g.epilogue == RLCF_EPI_RELU;     // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
-    const float os = (!LEAN && PAIR && g.out_scale_dev) ? g.out_scale_dev[0] : 1.0f;
+    const float os = (!LEAN && PAIR) ? x3_out_scale(g) : 1.0f;
     const bool want_amax = !LEAN && g.amax_out != nullptr;
     const bool nt = !LEAN && (g.no_fast_epi & 2);             // non-temporal output stores (RLCF_X3_NT=0: default cache policy, A/B)
     const int ocol = g.c_il ? (((colc >> 5) << 6) | (colc & 31)) : colc;
@@ -150,7 +182,7 @@ __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
     if (lin && f32o && !pair) return res ? 2 : 1;
     if (lin && !f32o && pair && !res) return 4;            // (in_proj -> Q / K / V pairs; ResNet conv1 / conv2 -> pairs of the next convolution)
     if (lin && f32o && pair && res) return 5;              // ResNet conv3: block output as f32 (the next identity) AND as pairs (the next conv1)
-    if (g.amax_out || g.alpha_dev || g.out_scale_dev) return 0;
+    if (g.amax_out || g.alpha_dev || g.out_scale_dev || g.bnd_in) return 0;
     if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
     if (g.epilogue == RLCF_EPI_NONE && !f32o && pair && !res) return 4;
     return 0;

@@ -25,6 +25,12 @@ int launch_vit_assemble(const float* patch_out, const float* cls, const float* p
 int launch_text_assemble(const float* E, const int32_t* row_src, const int32_t* ctx_row, const float* ctx, float* X, int rows,
                          int width, int rep_rows, int ctx_stride, hipStream_t st);
 // out[i] = in[idx[i]] rows (idx device, may be null = identity)
+// LayerNorm folded into the single-pass f16 products (rowops.hip, end of file)
+int launch_resid16_init(const float* x, void* x16, float* mr, int rows, int width, hipStream_t st);
+int launch_ln_stats_final(const float* part, int P, int rows, int width, float* mr, hipStream_t st);
+int launch_rows_h2f(const void* in16, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st);
+int launch_ln_fold_w(const float* W, const float* gamma, const float* beta, const float* b, float* Wg, float* bprime, int N, int K, hipStream_t st);
+int launch_rowsum_f16(const void* Wf16, float inv_scale, float* s, int N, int K, hipStream_t st);
 int launch_gather_rows(const float* in, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st);
 int launch_l2norm_rows(const float* in, float* out, float* inv_norm, int rows, int width, hipStream_t st);
 // backward of t = u/|u|: du = (dt - t <t,dt>) * inv_norm
@@ -76,6 +82,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
 // gemm_f16.hip: the dedicated single-pass f16 kernel (256x256 tile, eight phases per two K tiles) and its applicability test
 bool gemm_f16_p8_ok(const void* C, const void* Chi, const float* residual, const float* aux, int epilogue, const float* alpha_dev,
                     unsigned int* amax_out, const float* out_scale_dev, int N, int K, int lda, int ldw, int ldc, int ldr, int ldch);
+int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
+                          int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, hipStream_t st);
+// the output scale of the NEXT pair-emitting launch_gemm_f16x3 / _conv3x3 call of this thread is derived inside that launch from an upper
+// bound of |C| (device scalars max|input| / max|identity|, host constants gain / bmax) and published in out2 = (s, 1 / s): gemm_x3.h
+void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float gain, float bmax, float* out2);
 int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr, float* C, int ldc,
                        void* Cf16, int ldch, int M, int N, int K, float alpha, int epilogue, int tile_group, hipStream_t st);
 // M <= 256 rows of an f32 activation against a pre-split (interleaved-pair) weight, A split in the kernel (gemm_f16x3.hip)

@@ -367,10 +367,17 @@ static int conv_pairs(rlcf_engine* e, const ConvW& cw, ConvIn in, int n, int H, 
     }
     if (out.pairs) {
         if (!in.amax) { rlcf_set_error("conv_pairs: the bound of a pair output needs max|input|"); return RLCF_ERR_STATE; }
-        conv_bound_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(in.amax, res_amax, cw.gain, cw.bmax, out.scale2);
-        RLCF_LAUNCH_CHECK();
+        // RLCF_CONV_BOUND_KERNEL=0: derive the scale INSIDE the GEMM launch instead of this one-thread launch (GemmX3Args::bnd_*; same values,
+        // 136 launches per test image fewer at RN50x64) — built in round 5 and measured SLOWER, twice, A/B/A/B on one box: configs[4]
+        // 64.4 -> 69.2 ms/image (profiles/r5_notes.md); the stand-alone launch stays the default
+        static int bound_kernel = -1;
+        if (bound_kernel < 0) { const char* ev = getenv("RLCF_CONV_BOUND_KERNEL"); bound_kernel = ev ? atoi(ev) : 1; }
+        if (bound_kernel) {
+            conv_bound_scale_kernel<<<dim3(1), dim3(1), 0, st>>>(in.amax, res_amax, cw.gain, cw.bmax, out.scale2);
+            RLCF_LAUNCH_CHECK();
+        } else gemm_f16x3_next_bound(in.amax, res_amax, cw.gain, cw.bmax, out.scale2);     // (derived inside the GEMM launch below)
     }
-    if (out.amax) RLCF_HIP_CHECK(hipMemsetAsync(out.amax, 0, sizeof(float), st));       // (after the bound kernel read the old value)
+    // out.amax is a fresh slot of the chunk's zeroed max|.| arena (resnet_encode): nothing to clear here
     if (cw.k == 1)
         return engine_gemm_pairs(e, in.pairs, cw.cin, in.scale2 + 1, cw.w, cw.b, res, cw.cout, out.f32, cw.cout, out.pairs, out.scale2, (int)M,
                                  cw.cout, epi, st, out.amax);
@@ -399,12 +406,17 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
         const int n = std::min(chunk, n_total - i0);
         const float* img = images + (size_t)i0 * 3 * R * R;
         int H = R / 2;
-        // max|.| of the five activation buffers (X, A, B, Cb, Dd), refreshed by whichever GEMM writes the buffer; an
-        // average-pooled copy inherits the scalar of its source (a valid, slightly conservative bound)
-        TRY(e->rn_amax.ensure(8 * sizeof(float)));
+        // max|.| of the activation buffers (X, A, B, Dd), written (atomicMax) by whichever GEMM writes the buffer; an average-pooled copy
+        // inherits the scalar of its source (a valid, slightly conservative bound).  Every write of a buffer gets a FRESH scalar of an arena
+        // that is cleared ONCE per chunk (round 4 cleared one scalar per convolution: 195 four-byte fills per test image at RN50x64,
+        // 0.96 ms of the 65 ms step — profiles/r4_config5_kernel_stats.txt)
+        const int am_slots = 8 + 6 * (int)r.blocks.size();
+        TRY(e->rn_amax.ensure((size_t)am_slots * sizeof(float)));
         float* am = e->rn_amax.as<float>();
-        float *amX = am, *amA = am + 1, *amB = am + 2, *amD = am + 4;
-#define ZERO(p) RLCF_HIP_CHECK(hipMemsetAsync((p), 0, sizeof(float), st))
+        RLCF_HIP_CHECK(hipMemsetAsync(am, 0, (size_t)am_slots * sizeof(float), st));
+        int am_next = 0;
+        float *amX = nullptr, *amA = nullptr, *amB = nullptr, *amD = nullptr;
+#define ZERO(p) do { if (am_next >= am_slots) { rlcf_set_error("resnet_encode: max|.| arena exhausted"); return RLCF_ERR_STATE; } (p) = am + am_next++; } while (0)
         // stem (model.py:139-145): conv 3x3 s2 -> conv 3x3 -> conv 3x3 -> avgpool 2
         ZERO(amA);
         TRY(conv(e, r.stem[0], img, nullptr, n, R, R, 2, true, nullptr, RLCF_EPI_RELU, A, amA, st));
@@ -414,7 +426,7 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
         TRY(conv(e, r.stem[2], B, amB, n, H, H, 1, false, nullptr, RLCF_EPI_RELU, A, amA, st));
         H /= 2;
         TRY(avgpool2(A, X, n, H, H, w, st));
-        RLCF_HIP_CHECK(hipMemcpyAsync(amX, amA, sizeof(float), hipMemcpyDeviceToDevice, st));
+        amX = amA;                                                             // (the pooled copy's bound is its source's)
         static int no_fuse = -1;                                               // RLCF_RN_NOFUSE=1: every block on the f32-activation path (A/B)
         if (no_fuse < 0) { const char* ev = getenv("RLCF_RN_NOFUSE"); no_fuse = ev ? atoi(ev) : 0; }
         bool x_pairs = false;                                                  // Xp holds X as operand pairs (scale sX)
@@ -430,17 +442,23 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
                 // conv1 -> pairs -> conv2 (implicit 3x3) -> pairs -> conv3 (+ identity, ReLU) -> X as f32 (the next identity) and as pairs
                 ConvIn in1;
                 if (x_pairs) { in1.pairs = Xp; in1.scale2 = sX; in1.amax = amX; } else { in1.f32 = X; in1.amax = amX; }
+                ZERO(amA);
                 TRY(conv_pairs(e, b.c1, in1, n, H, H, nullptr, nullptr, RLCF_EPI_RELU, ConvOut{nullptr, Ap, sA, amA}, st));
                 if (!in1.pairs) { in1.f32 = X; }                                    // (conv_pairs split into the shared scratch: not reusable)
+                ZERO(amB);
                 TRY(conv_pairs(e, b.c2, ConvIn{nullptr, amA, Ap, sA}, n, H, H, nullptr, nullptr, RLCF_EPI_RELU, ConvOut{nullptr, Bp, sB, amB}, st));
                 const float* idn = X;
                 const float* idn_amax = amX;
                 if (b.has_down) {
+                    ZERO(amD);
                     TRY(conv_pairs(e, b.down, in1, n, H, H, nullptr, nullptr, RLCF_EPI_NONE, ConvOut{Dd, nullptr, nullptr, amD}, st));
                     idn = Dd; idn_amax = amD;
                 }
-                // (the bound kernel inside reads max|identity| before amX is re-zeroed for the new X; X is updated in place)
-                TRY(conv_pairs(e, b.c3, ConvIn{nullptr, amB, Bp, sB}, n, H, H, idn, idn_amax, RLCF_EPI_RELU, ConvOut{X, Xp, sX, amX}, st));
+                // (the bound kernel inside reads max|identity| of the OLD X; the new X — updated in place — gets its own scalar)
+                float* amXn = nullptr;
+                ZERO(amXn);
+                TRY(conv_pairs(e, b.c3, ConvIn{nullptr, amB, Bp, sB}, n, H, H, idn, idn_amax, RLCF_EPI_RELU, ConvOut{X, Xp, sX, amXn}, st));
+                amX = amXn;
                 x_pairs = true;
                 continue;
             }
@@ -459,7 +477,7 @@ int resnet_encode(rlcf_engine* e, ClipModel& m, const float* images, int n_total
                 TRY(conv(e, b.down, xp, amX, n, Ho, Ho, 1, false, nullptr, RLCF_EPI_NONE, Dd, amD, st));
                 idn = Dd;
             }
-            // in place when idn == X (elementwise); amX is re-zeroed first: the GEMM reads X only as the residual operand
+            // in place when idn == X (elementwise): the GEMM reads X only as the residual operand; the new X gets its own scalar
             ZERO(amX);
             TRY(conv(e, b.c3, t2, amB, n, Ho, Ho, 1, false, idn, RLCF_EPI_RELU, X, amX, st));
             H = Ho;

@@ -1166,3 +1166,106 @@ int launch_bicubic(const float* in, float* out, int planes, int Ri, int Ro, hipS
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+// ====================================================================================================================================
+// LayerNorm folded into the single-pass f16 products of an image tower (RLCF_PREC_F16; gemm_f16.hip MODE 1 / 2, engine.hip).
+// Under torch.cuda.amp.autocast the reference's residual stream is an fp16 tensor (TPT/clip/model.py:157-163: LayerNorm computes in
+// fp32 and casts back to the input's type; :187-192: x = x + attention(ln_1(x)) adds two fp16 tensors), so the stream is kept as f16
+// rows x16 here; LN(x16) W^T + b = rstd (x16 (W gamma)^T - mu rowsum(W gamma)) + (W beta + b): the consumer product reads x16 itself
+// against the gamma-folded weight, the producer product (out_proj / c_proj) adds into x16 and leaves the row statistics behind.
+// ====================================================================================================================================
+// x (f32, the tower input after ln_pre) -> x16, and (mean, rstd) of the STORED f16 rows; one wave per row
+__global__ __launch_bounds__(256) void resid16_init_kernel(const float* __restrict__ x, _Float16* __restrict__ x16, float* __restrict__ mr,
+                                                           int rows, int width) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 4; c < width; c += 256) {
+        const float4 t = *(const float4*)(x + (size_t)row * width + c);
+        const h16x4 o = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+        *(h16x4*)(x16 + (size_t)row * width + c) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float v = (float)o[e]; s += v; q += v * v; }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (lane == 0) {
+        const float mu = s / width, var = fmaxf(q / width - mu * mu, 0.f);
+        *(float2*)(mr + (size_t)row * 2) = make_float2(mu, rsqrtf(var + LN_EPS));
+    }
+}
+int launch_resid16_init(const float* x, void* x16, float* mr, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width % 4 == 0 && x && x16 && mr);
+    resid16_init_kernel<<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, (_Float16*)x16, mr, rows, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// the P partial (sum, sum of squares) of every row (written by the MODE 2 epilogues, part-major) -> (mean, rstd); added in part order
+__global__ __launch_bounds__(256) void ln_stats_final_kernel(const float* __restrict__ part, int P, int rows, int width, float* __restrict__ mr) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < P; ++p) { const float2 t = *(const float2*)(part + ((size_t)p * rows + row) * 2); s += t.x; q += t.y; }
+    const float mu = s / width, var = fmaxf(q / width - mu * mu, 0.f);
+    *(float2*)(mr + (size_t)row * 2) = make_float2(mu, rsqrtf(var + LN_EPS));
+}
+int launch_ln_stats_final(const float* part, int P, int rows, int width, float* mr, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && P > 0 && part && mr);
+    ln_stats_final_kernel<<<dim3((rows + 255) / 256), dim3(256), 0, st>>>(part, P, rows, width, mr);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// rows idx[r] of an f16 matrix -> f32 rows (idx == nullptr: every row in order)
+__global__ __launch_bounds__(256) void rows_h2f_kernel(const _Float16* __restrict__ in, int ld_in, const int32_t* __restrict__ idx,
+                                                       float* __restrict__ out, int ld_out, int width) {
+    const int r = blockIdx.x;
+    const size_t src = idx ? (size_t)idx[r] : (size_t)r;
+    for (int c = threadIdx.x * 4; c < width; c += 1024) {
+        const h16x4 t = *(const h16x4*)(in + src * ld_in + c);
+        *(float4*)(out + (size_t)r * ld_out + c) = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    }
+}
+int launch_rows_h2f(const void* in16, int ld_in, const int32_t* idx, float* out, int ld_out, int rows, int width, hipStream_t st) {
+    RLCF_ARG_CHECK(rows > 0 && width > 0 && width % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && in16 && out);
+    rows_h2f_kernel<<<dim3(rows), dim3(256), 0, st>>>((const _Float16*)in16, ld_in, idx, out, ld_out, width);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// finalize-time preparation of a folded product: Wg[c, k] = W[c, k] gamma[k];  bprime[c] = b[c] + sum_k W[c, k] beta[k];
+// s[c] = inv_scale * sum_k Wf16[c, k] over the ROUNDED f16 copy (what the MFMAs add up for a row of ones).  One workgroup per output row.
+__global__ __launch_bounds__(256) void ln_fold_w_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ b, float* __restrict__ Wg, float* __restrict__ bprime, int K) {
+    const int c = blockIdx.x;
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[(size_t)c * K + k];
+        Wg[(size_t)c * K + k] = w * gamma[k];
+        acc += (double)w * (double)beta[k];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) bprime[c] = (float)((double)(b ? b[c] : 0.f) + red[0]);
+}
+__global__ __launch_bounds__(256) void rowsum_f16_kernel(const _Float16* __restrict__ Wf, float inv_scale, float* __restrict__ s, int K) {
+    const int c = blockIdx.x;
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) acc += (double)(float)Wf[(size_t)c * K + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) s[c] = (float)(red[0] * (double)inv_scale);
+}
+int launch_ln_fold_w(const float* W, const float* gamma, const float* beta, const float* b, float* Wg, float* bprime, int N, int K, hipStream_t st) {
+    RLCF_ARG_CHECK(N > 0 && K > 0 && W && gamma && beta && Wg && bprime);
+    ln_fold_w_kernel<<<dim3(N), dim3(256), 0, st>>>(W, gamma, beta, b, Wg, bprime, K);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+int launch_rowsum_f16(const void* Wf16, float inv_scale, float* s, int N, int K, hipStream_t st) {
+    RLCF_ARG_CHECK(N > 0 && K > 0 && Wf16 && s);
+    rowsum_f16_kernel<<<dim3(N), dim3(256), 0, st>>>((const _Float16*)Wf16, inv_scale, s, K);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -80,3 +80,91 @@ def test_gemm_f16_eight_phase_kernel_is_bit_reproducible():
         c, _ = _gemm_f16(a, w, None, None, L.EPI_NONE, True, False)
         digests.append(hashlib.sha256(c.cpu().numpy().tobytes()).hexdigest())
     assert digests[0] == digests[1] == digests[2]
+
+
+# ------------------------------------------------------------------ LayerNorm folded into the single-pass f16 products (MODE 1 / 2)
+def _ln_fold_operands(W, gamma, beta, b):
+    """What engine.hip's make_lnfold prepares: the f16 copy of W diag(gamma) 2^s, alpha = 2^-s, the row sums of that copy times alpha,
+    and W beta + b."""
+    wg = W * gamma[None, :]
+    sh = 9 - int(torch.floor(torch.log2(wg.abs().max())).item())
+    scale = 2.0 ** max(-8, min(12, sh))
+    w16 = (wg * scale).half()
+    s = (w16.double().sum(1) / scale).float()
+    bprime = (b.double() + W.double() @ beta.double()).float()
+    return w16, 1.0 / scale, s, bprime
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(12608 * 2, 2304, 768, "none"), (12608 * 2 + 77, 3072, 768, "gelu"), (256 * 9 + 5, 1024, 1024, "none"),
+                                       (100, 256, 256, "gelu")])
+def test_gemm_f16_layernorm_folded_consumer_matches_f64(M, N, K, epi):
+    """MODE 1: LN(x16) W^T + b computed as rstd (x16 (W gamma)^T - mu s) + (W beta + b) on the f16 residual rows themselves, against the
+    float64 LayerNorm of the SAME f16 rows followed by the float64 product (nn.LayerNorm: biased variance, eps 1e-5; TPT/clip/model.py:157-163).
+    The statistics come from rlcf_resid16_init (a residual stream with a large common offset and outlier channels, as CLIP's is)."""
+    torch.manual_seed(5)
+    x = torch.randn(M, K, device=DEV) * 1.5 + 0.7
+    x[:, 7] += 40.0
+    x[:, 300 % K] -= 25.0
+    W = torch.randn(N, K, device=DEV) * K ** -0.5
+    gamma, beta, b = 1.0 + 0.3 * torch.randn(K, device=DEV), 0.2 * torch.randn(K, device=DEV), 0.1 * torch.randn(N, device=DEV)
+    w16, alpha, s, bprime = _ln_fold_operands(W, gamma, beta, b)
+    x16 = torch.empty(M, K, dtype=torch.float16, device=DEV)
+    mr = torch.empty(M, 2, device=DEV)
+    lib = L.lib()
+    L.check(lib.rlcf_resid16_init(x.data_ptr(), x16.data_ptr(), mr.data_ptr(), M, K, _st()))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    e = L.EPI_QUICKGELU if epi == "gelu" else L.EPI_NONE
+    L.check(lib.rlcf_gemm_f16_ln(x16.data_ptr(), K, w16.data_ptr(), K, bprime.data_ptr(), out.data_ptr(), N, M, N, K, alpha, e, 1, mr.data_ptr(),
+                                 s.data_ptr(), None, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(x16, x.half())
+    xd = x16.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    torch.testing.assert_close(mr[:, 0].double(), mu[:, 0], atol=1e-5, rtol=1e-6)
+    torch.testing.assert_close(mr[:, 1].double(), (var[:, 0] + 1e-5).rsqrt(), atol=0, rtol=2e-5)
+    rows = torch.randint(0, M, (256,), device=DEV)
+    ln = (xd[rows] - mu[rows]) / (var[rows] + 1e-5).sqrt() * gamma.double() + beta.double()
+    ref = ln @ W.double().t() + b.double()
+    if epi == "gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    got = out[rows].double()
+    # f16 weight rounding (2^-11 relative per element, ~K^0.5 terms) + the f16 rounding of the output: the plain kernel's bar
+    err = ((got - ref).abs() / (ref.abs() + 1.0)).max().item()
+    assert err < 4e-3, err
+
+
+@pytest.mark.parametrize("M,N,K", [(12608 * 2, 768, 768), (12608 * 2 + 77, 768, 3072), (256 * 9 + 5, 1024, 1024), (100, 256, 256)])
+def test_gemm_f16_residual_in_place_with_row_statistics(M, N, K):
+    """MODE 2: x16 <- f16(x16 + A W^T + b) in place, and the (mean, rstd) of the STORED rows via the partial sums + rlcf_ln_stats_final.  The
+    update is exact up to the one f16 rounding (float64 product of the same f16 operands); the statistics must describe the stored row."""
+    torch.manual_seed(6)
+    a16 = torch.randn(M, K, device=DEV).half()
+    w16 = (torch.randn(N, K, device=DEV) * K ** -0.5).half()
+    b = 0.1 * torch.randn(N, device=DEV)
+    x16 = (torch.randn(M, N, device=DEV) * 2 + 0.5).half()
+    x16[:, 11] += 30.0
+    x0 = x16.clone()
+    P = N // 64
+    part = torch.full((P, M, 2), float("nan"), device=DEV)
+    mr = torch.empty(M, 2, device=DEV)
+    lib = L.lib()
+    L.check(lib.rlcf_gemm_f16_ln(a16.data_ptr(), K, w16.data_ptr(), K, b.data_ptr(), x16.data_ptr(), N, M, N, K, 1.0, L.EPI_NONE, 2, None, None,
+                                 part.data_ptr(), _st()))
+    L.check(lib.rlcf_ln_stats_final(part.data_ptr(), P, M, N, mr.data_ptr(), _st()))
+    torch.cuda.synchronize()
+    rows = torch.randint(0, M, (256,), device=DEV)
+    ref = x0[rows].double() + a16[rows].double() @ w16.double().t() + b.double()
+    err = (x16[rows].double() - ref).abs() / (ref.abs() + 1.0)
+    assert err.max().item() < 1.5e-3, err.max().item()          # one f16 rounding of the sum (2^-11) + f32 accumulation
+    xd = x16.double()
+    mu, var = xd.mean(1), xd.var(1, unbiased=False)
+    assert torch.isfinite(part).all()
+    torch.testing.assert_close(mr[:, 0].double(), mu, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(mr[:, 1].double(), (var + 1e-5).rsqrt(), atol=0, rtol=1e-4)
+    # bit-reproducible: same launch again from the same state
+    x16b = x0.clone()
+    part2 = torch.empty_like(part)
+    L.check(lib.rlcf_gemm_f16_ln(a16.data_ptr(), K, w16.data_ptr(), K, b.data_ptr(), x16b.data_ptr(), N, M, N, K, 1.0, L.EPI_NONE, 2, None, None,
+                                 part2.data_ptr(), _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(x16b, x16) and torch.equal(part2, part)

@@ -1,6 +1,7 @@
 // Per-CU global store throughput on gfx950 for the epilogue patterns of the persistent f16 GEMM (tools/probes, measurement only).
 // 256 workgroups x 512 threads; every wave issues `per_wave` 16-byte-per-lane stores per "tile", `reps` tiles; patterns:
-//   0: 8 rows x 128 B per instruction, row stride ld (the GEMM's f16 output tile)      1: 1 KB contiguous per instruction
+//   0: 8 rows x 128 B per instruction, row stride ld (the GEMM's f16 output tile, first form)      1: 1 KB contiguous per instruction
+//   2: 32 rows x 32 B per instruction (the transpose-free epilogue: lane = row; four instructions complete a row's 128-B line)
 // policy: 0 default, 1 nontemporal, 2 sc1 (write-through), 3 sc0 sc1
 // build: hipcc --offload-arch=gfx950 -O3 -o store_rate store_rate.hip ; run: ./store_rate
 #include <hip/hip_runtime.h>
@@ -17,6 +18,7 @@ __global__ __launch_bounds__(512) void k(char* out, size_t ld, int reps, size_t 
         for (int s = 0; s < 16; ++s) {
             char* p;
             if (PAT == 0) p = base + (size_t)(wm * 128 + s * 8 + (lane >> 3)) * ld + wn * 128 + (lane & 7) * 16;
+            else if (PAT == 2) p = base + (size_t)(wm * 128 + (s >> 2) * 32 + (lane & 31)) * ld + wn * 128 + (s & 3) * 32 + (lane >> 5) * 16;
             else p = base + (size_t)(wave * 16 + s) * 1024 + lane * 16;
             if (POL == 0) *(u32x4*)p = v;
             else if (POL == 1) __builtin_nontemporal_store(v, (u32x4*)p);
@@ -49,6 +51,10 @@ int main() {
     run("rows 8x128B, default", k<0, 0>, tile_stride);
     run("rows 8x128B, nontemporal", k<0, 1>, tile_stride);
     run("rows 8x128B, sc1", k<0, 2>, tile_stride);
+    run("rows 32x32B, default", k<2, 0>, tile_stride);
+    run("rows 32x32B, nontemporal", k<2, 1>, tile_stride);
+    for (int gsz : {8, 64}) { grid = gsz; printf("grid %d: ", gsz); run("rows 32x32B, nontemporal", k<2, 1>, tile_stride); }
+    grid = 256;
     run("contiguous 1KB, default", k<1, 0>, 131072);
     run("contiguous 1KB, nontemporal", k<1, 1>, 131072);
     run("contiguous 1KB, sc1", k<1, 2>, 131072);

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r5/exp4; mkdir -p $O
+hipcc --offload-arch=gfx950 -O3 -o /tmp/store_rate tools/probes/store_rate.hip && /tmp/store_rate | tee $O/store_rate.txt
+timeout 900 python -m pytest tests/test_gpu_round5.py -x -q 2>&1 | tail -15
+for f in 1 0; do RLCF_F16_LNFOLD=$f timeout 600 python bench.py --precision f16 --steps 20 --warmup 5 --no-cpu-baseline --no-f16-line --no-harness-leg > $O/bench_f16_fold$f.json 2>$O/bench_f16_fold$f.err; python -c "
+import json; d=json.loads(open('$O/bench_f16_fold$f.json').read().strip().splitlines()[-1]); print('f16 LNFOLD=$f images/s', d['value'], d['sustained']['images_per_s_mean']); r=d['roofline']; print([(e['kernel'][:12],round(e.get('tflops',0)), round(e.get('avg_ms',0),3)) for e in r['per_kernel']])" || tail -5 $O/bench_f16_fold$f.err; done
+timeout 900 python -m pytest tests/test_gpu_round2.py -x -q -k "f16" 2>&1 | tail -15
+timeout 900 python -m pytest tests -m gpu -x -q -k "f16 or F16 or single" 2>&1 | tail -5
