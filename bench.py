@@ -507,12 +507,12 @@ def main():
             # HBM/fabric bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters perturb timing
             # and cannot be read in-process); they are quoted only from a committed profile of this exact pass size
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r4_gemm_hbm_traffic.json")
-            if a.precision == "f16x3" and os.path.exists(tpath) and a.config == 1 and is_default_wl:
-                rec = json.load(open(tpath)).get("bytes_per_launch_by_images_per_pass", {}).get(str(pass_images))
+            tname = next((n for n in ("r5_gemm_hbm_traffic.json", "r4_gemm_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+            if a.precision == "f16x3" and tname and a.config == 1 and is_default_wl:
+                rec = json.load(open(os.path.join(ROOT, "profiles", tname))).get("bytes_per_launch_by_images_per_pass", {}).get(str(pass_images))
                 if rec:
-                    traffic, tsrc = rec, (f"profiles/r4_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this GEMM at {pass_images} images per "
-                                          "pass on the round-4 build, tools/pmc_gemm_traffic.sh; Infinity-Cache hits are inside the counter)")
+                    traffic, tsrc = rec, (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this GEMM at {pass_images} images per "
+                                          f"pass on the round-{tname[1]} build; Infinity-Cache hits are inside the counter)")
             # MFMA-pipe utilisation by COUNTER (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)) of the dominant kernel on this round's build:
             # like `traffic`, read from the committed rocprofv3 --pmc profile of the same GEMM shapes (counters cannot be read in-process)
             busy, bsrc = None, None
@@ -628,7 +628,9 @@ def main():
                 # the attention forward's own bound in this mode is HBM, not the matrix pipe: Q, K, V rows in + O rows out as plain f16
                 "attention_fwd_hbm_roofline_ms": (pass_images * a.views * tok * Wv * 8.0 / (HBM_PEAK_GBS * 1e6)),
                 "attention_fwd_avg_ms": (sum(e[1] for e in att_h) / len(att_h)) if att_h else None,
-                "kernels": "gemm_nt_f16_pp_kernel (persistent 256x256 eight-phase kernel, gemm_f16.hip) for the four block products; residual add in layernorm_add_fwd",
+                "kernels": ("gemm_nt_f16_pp_kernel (persistent 256x256 eight-phase kernel, gemm_f16.hip) for the four block products; image towers: f16 residual "
+                            "stream with the LayerNorms folded into the products (MODE 1 / 2; RLCF_F16_LNFOLD=0: layernorm_add_fwd pipeline)"),
+                "notes": "profiles/r5_notes.md: store bursts = 21-25 % of a K = 768 product; attention forward is HBM-bound (0.25 of the MFMA peak needs 6.35 TB/s)",
                 "mfma_busy_counter": (json.load(open(os.path.join(ROOT, "profiles", "r5_sq_counters.json"))).get("summary", {})
                                       if os.path.exists(os.path.join(ROOT, "profiles", "r5_sq_counters.json")) else None)}
             eh.close()
