@@ -336,13 +336,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                                                                      \
         P8_MID MMA_(1, 0) P8_END                                                                                                    \
     }
-// (MODE 2) line (wave * 2 + j) * 64 + lane of the 256 x 512-byte residual tile: row = line >> 2, 128-byte piece = line & 3
-#define PP_TOUCH(j)                                                                                                                 \
-    {                                                                                                                               \
-        const int ln_ = (wave_s * 2 + (j)) * 64 + lane;                                                                             \
-        const _Float16* tp_ = g.Chi + (size_t)min(m0 + (ln_ >> 2), g.M - 1) * g.ldch + n0 + (ln_ & 3) * 64;                          \
-        __builtin_amdgcn_global_load_lds((gptr_t)tp_, (lptr_t)(smem + 2 * P8_PAR + wave_s * 256), 4, 0, 0);                          \
-    }
 #define PP_KTILE(kt, par) PP_KTILE_X(kt, par, PP_MMA, PP_NOHOOK)
 // the last two K tiles of a tile: K tile nk-2 stages B_lo of nk-1 (this tile) and A_lo / B_hi / A_hi of the NEXT tile's K tile 0;
 // K tile nk-1 stages the next tile's B_lo of K tile 0 and A_lo / B_hi / A_hi of its K tile 1 (nothing when this is the last tile)
@@ -385,22 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         PP_KTILE(1, 1)
         if (trace) { PP_STAMP(4) }
         for (int kt = 2; kt + 2 < nk; kt += 2) {
-            // MODE 2: the residual rows this tile's epilogue will read are touched (one dword per 128-byte line, by LDS-DMA into a dummy
-            // slot: no destination register) four to one K tiles ahead, a quarter of the tile's 1024 lines per K tile, so that the read
-            // burst of all CUs' residual tiles (32 MB chip-wide) streams in under the K loop instead of in front of the epilogue
-            if constexpr (MODE == 2) {
-                if (g.sk_first == 0 && (kt + 6 == nk || kt + 4 == nk)) {
-                    const int j = kt + 4 == nk ? 1 : 0;
-                    if ((wave_s & 1) == 0) PP_TOUCH(j)
-                }
-            }
             PP_KTILE(kt, 0)
-            if constexpr (MODE == 2) {
-                if (g.sk_first == 0 && (kt + 6 == nk || kt + 4 == nk)) {
-                    const int j = kt + 4 == nk ? 1 : 0;
-                    if ((wave_s & 1) == 1) PP_TOUCH(j)
-                }
-            }
             PP_KTILE(kt + 1, 1)
             if (trace && kt < 20) { PP_STAMP(4 + (kt >> 1)) }
         }
@@ -469,7 +447,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                     if (h == 0 && row < g.M) *(float2*)(g.ln_part + ((size_t)part * g.M + row) * 2) = make_float2(s1, s2);
                 }
             } else {
-            // RLCF_F16_PP_DEFER=0 (g.sk_first): every store at once (A/B measurements)
             float sj[4][8];
             float rA[4], rB[4];
             if constexpr (MODE == 1) {
@@ -574,9 +551,6 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     g.Ahi = (const _Float16*)A; g.lda = lda; g.Whi = (const _Float16*)W; g.ldw = ldw; g.bias = bias; g.Chi = (_Float16*)out16; g.ldch = ldo;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.kstep = 64; g.ksplit = 0; g.tile_group = 0; g.sk_blocks = 1;
     g.ln_mr = ln_mr; g.ln_s = ln_s; g.ln_part = ln_part;
-    static int touch = -1;                                   // RLCF_F16_PP_TOUCH=0: no early touch of the residual tile (A/B measurements)
-    if (touch < 0) { const char* e = getenv("RLCF_F16_PP_TOUCH"); touch = e ? atoi(e) : 1; }
-    g.sk_first = touch ? 0 : 1;
     g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
     static int ncu = 0;
     if (!ncu) {
@@ -587,7 +561,7 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     }
     const int blocks = ((M + 255) / 256) * (N / 256);
     const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
-    const size_t shp = (size_t)2 * P8_PAR + 8 * 256;         // + the dummy slots of PP_TOUCH
+    const size_t shp = (size_t)2 * P8_PAR;
 #define PP_LN_GO(E, MD)                                                                                                             \
     {                                                                                                                               \
         int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD>, shp);                                                      \

@@ -676,6 +676,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     if constexpr (!SK) {
         const int nwg = gridDim.x;
         bid = blockIdx.x;
+        if (g.stagger > 1 && blockIdx.x < 256) {                        // (see GemmX3Args::stagger)
+            const int c = (blockIdx.x >> 3) % g.stagger;
+            const int cyc = c * (k1 * 5200 + 12000) / g.stagger;        // ~ cycles per tile: ~5 200 per K tile of 32 + epilogue
+            for (int q2 = cyc >> 13; q2 > 0; --q2) __builtin_amdgcn_s_sleep(127);       // (127 x 64 cycles ~ 2^13)
+        }
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     } else {
@@ -1463,6 +1468,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     static int tgroup = -1;
     if (tgroup < 0) { const char* e = getenv("RLCF_X3_GROUP"); tgroup = e ? atoi(e) : 0; }
     g.tile_group = tgroup;
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("RLCF_X3_STAGGER"); stagger = e ? atoi(e) : 0; }
+    g.stagger = stagger;
     const bool v2_ok = N % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldaux % 4 == 0 && ldch % 4 == 0;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
     // tile choice: both big kernels run one block per CU, so a launch costs ceil(tiles/256) block rounds; a 256x128 round takes

@@ -50,6 +50,9 @@ struct GemmX3Args {
     //   MODE 2 (out_proj, c_proj): Chi IS the residual stream: x[r, c] = f16(x[r, c] + alpha acc + b_c) in place, and the row's
     //          (sum, sum of squares) over this wave's 64 columns goes to ln_part[(n0 / 256) * 4 + wn][r] for the next LayerNorm's statistics
     const float* ln_mr; const float* ln_s; float* ln_part;
+    // 256x256 split-f16 kernel, measurement (RLCF_X3_STAGGER=P): the workgroups of the FIRST tile round start c/P of a tile late (c = index
+    // inside the XCD mod P), so that the CUs are out of step for the whole launch and their store bursts do not meet (profiles/r5_notes.md)
+    int stagger;
 };
 #define X3_SK_MAX_BLOCKS 1024
 #define X3_SK_FLAG_BYTES 8192                                   // flags + time-out word, at the end of the workspace
