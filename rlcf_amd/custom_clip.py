@@ -42,16 +42,33 @@ class _ResetTracker:
         return self._reset_gen == self.gen and self._reset_versions == tuple(None if t is None else t._version for t in tensors)
 
     def guard(self, tensor: torch.Tensor, expected: torch.Tensor, what: str):
-        """queue `tensor == expected` on the device (no synchronisation); checked by check()"""
-        self._guards.append(((tensor.detach() != expected.detach()).any(), what))
+        """queue `tensor == expected` on the device (no synchronisation); checked by check().  The one-byte result travels to a pinned
+        host byte by an asynchronous copy with an event behind it, so that reading it later never makes the host wait for the device."""
+        flag = (tensor.detach() != expected.detach()).any()
+        if flag.is_cuda:
+            host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+            host.copy_(flag.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._guards.append((host, what, ev))
+        else:
+            self._guards.append((flag.reshape(1), what, None))
 
-    def check(self):
-        """called at every entry point: the comparisons queued by EARLIER calls have finished long ago"""
+    def check(self, wait: bool = False):
+        """called at every entry point: reads the comparisons queued by EARLIER calls that have FINISHED (event query, no wait — round 5: a
+        blocking read here made the host wait for the previous image's step at every image and cost the harness loop its host / device
+        overlap: 76 -> 68 images/s with the views made in the loop); an unfinished one stays queued for the next entry point.  wait=True
+        (end of an evaluation loop) drains the queue."""
         pending, self._guards = self._guards, []
-        for flag, what in pending:
-            if bool(flag):
+        for host, what, ev in pending:
+            if ev is not None and not wait and not ev.query():
+                self._guards.append((host, what, ev))
+                continue
+            if ev is not None and wait:
+                ev.synchronize()
+            if bool(host[0]):
                 raise RuntimeError(f"rlcf_amd mirror: {what} — the tensor was edited behind the mirror's back (through `.data` or a raw "
-                                   "pointer) after the state the previous call assumed; the previous result was computed from the "
+                                   "pointer) after the state an earlier call assumed; that call's result was computed from the "
                                    "unedited state.  Edit through the mirror (reset(), ctx_init_state = ..., in-place ops on the Parameter).")
 
 

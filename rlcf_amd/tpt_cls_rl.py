@@ -218,4 +218,7 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
             torch.cuda.current_stream().synchronize()                # (bounds how far the host runs ahead of the device)
         end = time.time()
     s1, s5 = (float(s1_t), float(s5_t)) if n else (0.0, 0.0)
+    for trk in (getattr(model, "_track", None), getattr(getattr(model, "prompt_learner", None), "_track", None)):
+        if trk is not None:
+            trk.check(wait=True)                                     # (the guards of the last samples: the loop is over, waiting costs nothing)
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]

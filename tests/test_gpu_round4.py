@@ -433,6 +433,7 @@ def test_mirror_reset_state_fast_path_still_sees_edits(L, dev):
         pl.ctx.data.copy_(edited.to(dev))
     optimizer.load_state_dict(optim_state)
     tpt_cls_rl.test_time_tuning(model, views, optimizer, None, args, reward_model=reward_model)
+    torch.cuda.synchronize()              # (the guard is read without waiting: an entry point reports it once its comparison has finished)
     with pytest.raises(RuntimeError, match="behind the mirror's back"):
         with torch.no_grad():
             model(views[:1])
