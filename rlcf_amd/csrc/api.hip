@@ -593,6 +593,7 @@ int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream strea
     RLCF_ARG_CHECK(e && in);
     { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    e->lnfold_stale = true;          // (RLCF_PREC_F16: weights with the finalize-time gamma / beta folded in are no longer valid)
     return RLCF_OK;
 }
 int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
@@ -602,9 +603,11 @@ int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double mom
     rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
                                     update_w, apply, (hipStream_t)stream);
     if (rc != RLCF_OK) return rc;
-    if (apply)           // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy follows
+    if (apply) {         // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy follows
         RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
                                       (hipStream_t)stream));
+        e->lnfold_stale = true;
+    }
     return RLCF_OK;
 }
 int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {

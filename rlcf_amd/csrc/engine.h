@@ -211,6 +211,8 @@ struct rlcf_engine {
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
     DevBuf rn_wg_tmp;                // GEMM-layout weight gradient of one 3x3 convolution / the k|v projection (every-parameter tuning)
     DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
+    bool lnfold_stale = false;       // the student's LayerNorm parameters were written after finalize (rlcf_engine_set_ln_params, an applied EMA): the
+                                     // gamma / beta folded into the RLCF_PREC_F16 image-tower weights no longer match them -> the unfolded pipeline runs
     DevBuf zpage;                    // 4 KB of zeros: what the implicit 3x3 convolution reads outside the image
     DevBuf parts_ws, attn_park;      // scratch of the bit-reproducible reductions: parameter-gradient partial sums; dK / dV per query block
     int bn_prior_strength = -1;

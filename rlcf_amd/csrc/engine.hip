@@ -357,6 +357,7 @@ int engine_finalize(rlcf_engine* e, int which, hipStream_t st) {
     m.split_of.clear();
     m.f16_of.clear();
     m.lnfold_of.clear();
+    if (which == RLCF_STUDENT) e->lnfold_stale = false;
     const int Wt = c.text_width, D = c.embed_dim;
     const bool rn = is_resnet(c);
     if (which == RLCF_STUDENT) {          // the flat tunable buffer pointed into the previous weights
@@ -688,7 +689,7 @@ static int transformer_forward(rlcf_engine* e, const TowerW& w, Tower& ws, const
         static int lnfold_env = -1;
         if (lnfold_env < 0) { const char* ev = getenv("RLCF_F16_LNFOLD"); lnfold_env = ev ? atoi(ev) : 1; }
         const ClipModel::LnFold* fold_in0 = nullptr;
-        if (f16res && lnfold_env && !causal && !e->lng_base && W % 256 == 0 && cls_out && cls_seqs && cls_idx)
+        if (f16res && lnfold_env && !causal && !e->lng_base && W % 256 == 0 && cls_out && cls_seqs && cls_idx && !(e->lnfold_stale && &w == &e->model[RLCF_STUDENT].vis))
             for (auto& mm : e->model) { auto it = mm.lnfold_of.find(w.blk[0].in_w); if (it != mm.lnfold_of.end()) fold_in0 = &it->second; }
         if (fold_in0) {
             auto fold_of = [&](const float* Wp) -> const ClipModel::LnFold* {

@@ -435,12 +435,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const _Float16 v = (_Float16)((float)xr[i][gq][j * 4 + q] + (al * acc[i][j][gq * 4 + q] + bj[gq][j * 4 + q]));
-                                const float vf = (float)v;             // the statistics describe the STORED row (what the next product reads)
-                                s1 += vf; s2 += vf * vf;
-                                o[j * 4 + q] = v;
-                            }
+                            for (int q = 0; q < 4; ++q)
+                                o[j * 4 + q] = (_Float16)((float)xr[i][gq][j * 4 + q] + (al * acc[i][j][gq * 4 + q] + bj[gq][j * 4 + q]));
+                        // the statistics describe the STORED f16 row (what the next product reads): v_dot2_f32_f16 adds two products of f16
+                        // values (exact in f32) per instruction — sum of squares with the pair itself, sum with (1, 1)
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            const h16x2 v2 = {o[2 * e2], o[2 * e2 + 1]};
+                            const h16x2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+                            s1 = __builtin_amdgcn_fdot2(v2, one2, s1, false);
+                            s2 = __builtin_amdgcn_fdot2(v2, v2, s2, false);
+                        }
                         if (row < g.M) *(h16x8*)(g.Chi + (size_t)row * g.ldch + ocol + gq * 16) = o;
                     }
                     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);        // the other half-wave holds the row's other 32 columns

@@ -334,6 +334,25 @@ def test_f16_single_pass_mode_small(L, dev):
     ex.close(); eh.close()
 
 
+def test_f16_folded_layernorms_follow_later_writes_of_the_parameters(L, dev):
+    """The f16 mode folds the image tower's LayerNorm gamma / beta into its in_proj / c_fc weights at finalize.  Parameters written AFTER
+    that (rlcf_engine_set_ln_params: a loaded CLIPCLS_TTA state, an applied EMA) must still be honoured: the engine falls back to the
+    unfolded pipeline, which reads the live parameters."""
+    N, n_cls = 64, 40
+    ex, *_ = make_engine(("small", "small"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16X3)
+    eh, *_ = make_engine(("small", "small"), N, n_cls, L.TEXT_SHARED, prec=L.PREC_F16)
+    views = synth.make_views(2001, N, 64).to(dev)
+    f0 = eh.encode_image(L.STUDENT, views).clone()
+    p = ex.ln_params()
+    p2 = p * (1.0 + 0.2 * torch.sin(torch.arange(p.numel(), device=dev, dtype=torch.float32))) + 0.05
+    ex.set_ln_params(p2); eh.set_ln_params(p2)
+    fx, fh = ex.encode_image(L.STUDENT, views), eh.encode_image(L.STUDENT, views)
+    assert (fh - f0).abs().max().item() > 1e-2                      # the new parameters matter ...
+    d = (fx - fh).abs().max().item()
+    assert d < 5e-3, d                                              # ... and the f16 engine used them
+    ex.close(); eh.close()
+
+
 def test_f16_single_pass_mode_b16_stream(L, dev):
     """The same on BASELINE configs[1] against the REFERENCE stream (32 samples): max |dlogit| reported (SURVEY section 0 fact 9 measured
     0.0185 for fp16 autocast on the reference ViT-B/16; the bound asserted here is 0.1), and every sample that leaves that bound is
