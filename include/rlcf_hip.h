@@ -348,6 +348,11 @@ int rlcf_tta_sample(rlcf_engine*, const float* views, int N, const rlcf_tta_args
 int rlcf_tta_sample_ln(rlcf_engine*, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out,
                        rlcf_stream stream);
 int rlcf_engine_ln_param_count(rlcf_engine*);
+/* (ABI version 11) How many GEMM weights of model `which` sit on the fp16 grid — their split-f16 lo halves are identically zero, as for every
+ * Conv / Linear / MultiheadAttention / projection weight of a released CLIP checkpoint (the archives store them as fp16; TPT/clip/model.py:375-436
+ * copies them into float32 parameters) — and how many do not (*others, may be NULL).  For such a weight the a_hi . w_lo MFMA pass of the 256x256
+ * split-f16 kernel adds exact zeros and is dropped at launch: the same bits in two passes instead of three (RLCF_X3_WLO0=0 at finalize: off). */
+int rlcf_engine_f16_grid_weights(rlcf_engine*, int which, int* others);
 /* A ModifiedResNet student (arch RN50 .. RN50x64) has BatchNorms where the ViT has LayerNorms: CLIPCLS_TTA(only_norm=True) tunes the
  * weight / bias of every BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485; downsample.1 stays frozen) and
  * rlcf_tta_sample_ln / rlcf_tta_batch_ln / rlcf_engine_{ln_param_count,get_ln_params,set_ln_params,momentum_update} serve them

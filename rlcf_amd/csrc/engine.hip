@@ -101,7 +101,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
             int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
-                                       ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
+                                       ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
             prof_end(slot, st, g_last_x3_variant);
             return rc;
         }
@@ -145,7 +145,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
-                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
+                               sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -161,7 +161,7 @@ int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* al
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(Apairs, lo_of(Apairs), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, Cpairs, Cpairs ? lo_of(Cpairs) : nullptr,
-                               2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), 0, out_scale_dev, ws_epoch(e));
+                               2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, out_scale_dev, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -225,7 +225,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
-                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e), 0, nullptr, ws_epoch(e));
+                               2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
     return rc;
 }
@@ -267,7 +267,27 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     if (mx > 0.f && std::isfinite(mx)) sh = std::max(-8, std::min(12, 9 - (int)std::floor(std::log2(mx))));
     const float scale = std::ldexp(1.0f, sh);
     TRY(launch_split_f16x2(w, hi.p, lo, (int64_t)numel, st, scale, il));
-    m.split_of[w] = ClipModel::SplitW{hi.p, lo, 1.0f / scale};
+    // Is the lo half identically zero?  It is for every GEMM weight of a released CLIP checkpoint (stored as fp16 in the archives the
+    // reference loads, TPT/clip/clip.py:120-141 / model.py:399-436), and then the a_hi . w_lo pass of every product with this weight adds
+    // exact zeros: the 256x256 kernel drops it (gemm_f16x3.hip, WLO0).  RLCF_X3_WLO0=0 keeps three passes (A/B; read at finalize).
+    bool lo_zero = false;
+    {
+        const char* ev = getenv("RLCF_X3_WLO0");
+        if (il && !(ev && atoi(ev) == 0)) {
+            DevBuf flag;
+            TRY(flag.ensure(sizeof(int)));
+            RLCF_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+            TRY(launch_f16_grid_check(w, (int64_t)numel, scale, (int*)flag.p, st));
+            int bad = 1;
+            RLCF_HIP_CHECK(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            RLCF_HIP_CHECK(hipStreamSynchronize(st));
+            flag.release();
+            lo_zero = bad == 0;
+        }
+    }
+    ClipModel::SplitW sw{hi.p, lo, 1.0f / scale};
+    sw.lo_zero = lo_zero;
+    m.split_of[w] = sw;
     m.derived.push_back(std::move(hi));
     if (prec_single(e) && numel % 64 == 0) {                 // plain f16 copy for the single-pass forward pipeline (same pre-scale)
         DevBuf f;
@@ -536,6 +556,7 @@ int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
     e->vw_refresh.clear();
     auto add_split = [&](const float* w, size_t numel) {
         auto it = m.split_of.find(w);
+        if (it != m.split_of.end()) it->second.lo_zero = false;          // (a TUNED weight leaves the fp16 grid at its first step: three passes)
         if (it != m.split_of.end())
             e->vw_refresh.push_back(VwRefresh{VW_SPLIT, w, nullptr, numel, 0, it->second.hi, it->second.lo, 1.0f / it->second.inv_scale,
                                               it->second.lo == lo_of(it->second.hi)});
@@ -2224,6 +2245,7 @@ int engine_text_enable(rlcf_engine* e, hipStream_t st) {
     e->tw_refresh.clear();
     auto add_split = [&](const float* w, size_t numel) {
         auto it = m.split_of.find(w);
+        if (it != m.split_of.end()) it->second.lo_zero = false;          // (a TUNED weight leaves the fp16 grid at its first step: three passes)
         if (it != m.split_of.end())
             e->tw_refresh.push_back(VwRefresh{VW_SPLIT, w, nullptr, numel, 0, it->second.hi, it->second.lo, 1.0f / it->second.inv_scale,
                                               it->second.lo == lo_of(it->second.hi)});

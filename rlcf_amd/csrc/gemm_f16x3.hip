@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
 // RT = 32-row accumulator tiles per wave: 2 (64 x 64 per wave) or 1 — <4, ., 1> is the 128x128 tile on EIGHT waves of 32 x 64: the grids
 // the 128x128 tile serves put one workgroup on a CU, and with four waves that is one wave per SIMD, whose LDS reads and barriers nothing
 // hides (~1.0 us per K tile against 0.67 us per 128x128-equivalent on the 8-wave 256x128 kernel, measured on [4095, 1536, 512])
-template <int NWM, bool SINGLE, int RT = 2>         // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
+template <int NWM, bool SINGLE, int RT = 2, bool WLO0 = false>         // wave rows: 4 -> 256x128 tile, 8 waves; 2 -> 128x128 tile, 4 waves
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_kernel(GemmX3Args g) {
     constexpr int BM = 32 * RT * NWM, A_BYTES = BM * 64, W_BYTES = V2_BN * 64;
     constexpr int NP = 2 * RT + 2 * (4 / NWM);             // DMA pieces per wave and stage
@@ -281,12 +281,16 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
             BL[i] = *(const h16x8*)(sb + WLO + boff + i * 2048 + co_);                                                   \
         }                                                                                                                \
     }
+// WLO0 (constexpr in scope; round 5): the weight's lo halves are all ZERO — the weight sits on the f16 grid, as every Linear / conv / projection
+// weight of a released CLIP checkpoint does (the archives store them as fp16; TPT/clip/model.py:399-436 copies them into float32
+// parameters) — so the product a_hi . w_lo adds exact zeros and its MFMA is dropped: two passes instead of three, the same bits
+// (up to the sign of an exact zero).  The engine finds out per weight at finalize (engine.hip make_split).
 #define V2_MMA3(i, j, AH, AL, BH, BL)                                                                                    \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);                                \
     if constexpr (SINGLE) {                                                                                              \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BL[j], acc[i][j], 0, 0, 0);                            \
     } else {                                                                                                             \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);                            \
+        if constexpr (!WLO0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);       \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);                            \
     }
 // the same for the tile pair (i, 0), (i, 1), pass by pass: no MFMA directly follows its predecessor on the same accumulator (each
@@ -298,8 +302,10 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BL[0], acc[i][0], 0, 0, 0);                            \
         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BL[1], acc[i][1], 0, 0, 0);                            \
     } else {                                                                                                             \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[0], acc[i][0], 0, 0, 0);                            \
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[1], acc[i][1], 0, 0, 0);                            \
+        if constexpr (!WLO0) {                                                                                           \
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[0], acc[i][0], 0, 0, 0);                        \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[1], acc[i][1], 0, 0, 0);                        \
+        }                                                                                                                \
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[0], acc[i][0], 0, 0, 0);                            \
         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[1], acc[i][1], 0, 0, 0);                            \
     }
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
 #define V3_WLO 49152
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) {
     constexpr bool SINGLE = false;      // (separate hi / lo arrays: the plain C-ABI call, split-f16 only)
+    constexpr bool WLO0 = false;
     float am = 0.f;                 // max|C| of this thread's outputs (amax_out)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][V3_STAGE] (+ epilogue parking)
     const int tiles_n = (g.N + V3_BN - 1) / V3_BN, tiles_m = (g.M + V3_BM - 1) / V3_BM;
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 // MT = 32-row accumulator tiles per wave group: 4 = the 256-row tile; 3 = a 192-row tile for launches whose 256-row tiles fill
 // little more than half of one round of workgroups (one image's token matrix against a W x W / W x 4W weight: 150 tiles on 256 CUs
 // -> 198 tiles of 3/4 the work each)
-template <bool SINGLE, bool CONV = false, bool SK = false, int MT = 4>
+template <bool SINGLE, bool CONV = false, bool SK = false, int MT = 4, bool WLO0 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     static_assert(MT == 4 || (MT == 3 && !SK && !CONV), "192-row tiles: plain products only");
     constexpr int BM = MT * 64;
@@ -1437,6 +1444,8 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
                       float* splitk_ws, size_t splitk_ws_bytes, int single, const float* out_scale_dev, unsigned* sk_epoch) {
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
+    const bool wlo0 = single == 2;           // single: 0 = split-f16 (three passes), 1 = plain f16 operands (RLCF_PREC_F16), 2 = split-f16 with an all-zero W lo part (two passes)
+    if (wlo0) single = 0;
     // stream-K scratch (caller-owned, X3_WS_BYTES): slabs from the start of the workspace, flag words in its last X3_SK_FLAG_BYTES;
     // *sk_epoch = the caller's launch counter for THIS workspace (0: flags not yet zeroed)
     const bool sk_avail = sk_epoch && splitk_ws && splitk_ws_bytes >= (size_t)X3_SK_FLAG_BYTES + 8 * (size_t)X3_SK_SLAB_BYTES;
@@ -1522,8 +1531,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                         (mt3 == 2 || (mt3 == 1 && cost3h < 0.97 * std::min(cost3, blocks2 >= 256 ? cost2 : cost3)));
     if (pick3h) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
+        if (wlo0) {
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3, true>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 3, true><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
+        } else {
         X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3>), sh3);
         gemm_nt_f16x3_v3i_kernel<false, false, false, 3><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
+        }
         g_last_x3_variant = 5;
         RLCF_LAUNCH_CHECK();
         return RLCF_OK;
@@ -1575,6 +1589,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             // whole-tile workgroups for the full rounds, then the stream-K launch for the rest (first pieces, then second pieces)
             if (sk_first > 0) gemm_nt_f16x3_v3i_kernel<false><<<dim3(sk_first), dim3(512), sh3, st>>>(g);
             gemm_nt_f16x3_v3i_kernel<false, false, true><<<dim3(2 * sk_blocks), dim3(512), sh3, st>>>(g);
+        } else if (g.kstep == 64 && wlo0) {
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 4, true>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 4, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
         } else if (g.kstep == 64) {
             X3_LDS(gemm_nt_f16x3_v3i_kernel<false>, sh3);
             gemm_nt_f16x3_v3i_kernel<false><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
@@ -1592,8 +1609,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             X3_LDS((gemm_nt_f16x3_v2_kernel<4, true>), sh2);
             gemm_nt_f16x3_v2_kernel<4, true><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
         } else {
+            if (wlo0) {
+                X3_LDS((gemm_nt_f16x3_v2_kernel<4, false, 2, true>), sh2);
+                gemm_nt_f16x3_v2_kernel<4, false, 2, true><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+            } else {
             X3_LDS((gemm_nt_f16x3_v2_kernel<4, false>), sh2);
             gemm_nt_f16x3_v2_kernel<4, false><<<dim3(blocks2), dim3(512), sh2, st>>>(g);
+            }
         }
         g_last_x3_variant = 2;
         RLCF_LAUNCH_CHECK();
@@ -1618,8 +1640,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         const int blocks_h = ((M + 63) / 64) * ((N + V2_BN - 1) / V2_BN);
         const int nblk = half_m ? blocks_h : blocks2s;           // workgroups per K slice
         if (single) X3_LDS((gemm_nt_f16x3_v2_kernel<2, true>), sh2s);
+        else if (eight && wlo0) X3_LDS((gemm_nt_f16x3_v2_kernel<4, false, 1, true>), sh2s);
         else if (eight) X3_LDS((gemm_nt_f16x3_v2_kernel<4, false, 1>), sh2s);
+        else if (half_m && wlo0) X3_LDS((gemm_nt_f16x3_v2_kernel<2, false, 1, true>), sh2s);
         else if (half_m) X3_LDS((gemm_nt_f16x3_v2_kernel<2, false, 1>), sh2s);
+        else if (wlo0) X3_LDS((gemm_nt_f16x3_v2_kernel<2, false, 2, true>), sh2s);
         else X3_LDS((gemm_nt_f16x3_v2_kernel<2, false>), sh2s);
         // few tiles and a long K loop (one image's token matrix against a W x 4W / W x 3W weight): split the K loop over blockIdx.y
         // and finish in a reduce + epilogue pass (RLCF_X3_NOSPLITK=1 switches it off)
@@ -1643,8 +1668,11 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
         if (ksplit > 1 && (!splitk_ws || (size_t)ksplit * M * N * sizeof(float) > splitk_ws_bytes)) ksplit = 1;
         g.ksplit = ksplit; g.ws = splitk_ws;
         if (single) gemm_nt_f16x3_v2_kernel<2, true><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
+        else if (eight && wlo0) gemm_nt_f16x3_v2_kernel<4, false, 1, true><<<dim3(blocks2s, ksplit), dim3(512), sh2s, st>>>(g);
         else if (eight) gemm_nt_f16x3_v2_kernel<4, false, 1><<<dim3(blocks2s, ksplit), dim3(512), sh2s, st>>>(g);
+        else if (half_m && wlo0) gemm_nt_f16x3_v2_kernel<2, false, 1, true><<<dim3(blocks_h, ksplit), dim3(256), sh2s, st>>>(g);
         else if (half_m) gemm_nt_f16x3_v2_kernel<2, false, 1><<<dim3(blocks_h, ksplit), dim3(256), sh2s, st>>>(g);
+        else if (wlo0) gemm_nt_f16x3_v2_kernel<2, false, 2, true><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         else gemm_nt_f16x3_v2_kernel<2, false><<<dim3(blocks2s, ksplit), dim3(256), sh2s, st>>>(g);
         g_last_x3_variant = 1;
         RLCF_LAUNCH_CHECK();
@@ -1701,6 +1729,21 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     return RLCF_OK;
 }
 
+// does every element of w * scale sit on the f16 grid (its lo half is zero)?  flag[0] |= 1 otherwise
+__global__ void f16_grid_check_kernel(const float* __restrict__ w, int64_t n, float scale, int* __restrict__ flag) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = w[i] * scale;
+        if ((float)(_Float16)v != v) bad = 1;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+int launch_f16_grid_check(const float* w, int64_t n, float scale, int* flag, hipStream_t st) {
+    RLCF_ARG_CHECK(w && flag && n > 0);
+    f16_grid_check_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st>>>(w, n, scale, flag);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
 // x -> (hi, lo): hi = f16(x), lo = f16((x - hi) * 2^11).  8 elements per thread.
 // il: interleaved output — 8-element group i (32-element block i/4, position i%4) lands at 8*((i/4)*8 + i%4) (hi) and 32 halves later (lo)
 __device__ __forceinline__ int64_t split_dst(int64_t i, int il) { return il ? ((i >> 2) << 3) + (i & 3) : i; }

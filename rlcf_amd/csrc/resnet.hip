@@ -1249,6 +1249,7 @@ int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, floa
 static int resplit(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
     auto it = m.split_of.find(w);
     if (it == m.split_of.end()) return RLCF_OK;
+    it->second.lo_zero = false;            // (a weight that is re-split is a TUNED weight: off the fp16 grid after its first step)
     const ClipModel::SplitW& sp = it->second;
     return launch_split_f16x2(w, sp.hi, sp.lo, (int64_t)numel, st, 1.0f / sp.inv_scale, sp.lo == (void*)((char*)sp.hi + 64) ? 1 : 0);
 }

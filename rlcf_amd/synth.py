@@ -179,6 +179,24 @@ def make_state_dict(geo: ClipGeometry, seed: int, device="cpu",
     return sd
 
 
+def to_fp16_grid(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The state dict with the tensors a RELEASED CLIP checkpoint stores as fp16 rounded to fp16 values (still float32 tensors): what
+    the reference actually holds after `clip.load` — the archives carry the weights of every Conv / Linear / MultiheadAttention and the
+    two projections as fp16 (convert_weights, TPT/clip/model.py:375-396, applied before they were saved), and build_model copies them
+    into float32 parameters (model.py:399-436, the re-conversion at :435 commented out).  LayerNorm parameters, embeddings and
+    logit_scale stay as they are.  The engine recognises such weights at finalize (their split-f16 lo halves are zero) and drops the
+    a_hi . w_lo pass of their products — bit for bit the same results in two MFMA passes instead of three."""
+    out = {}
+    for k, v in sd.items():
+        grid = v.is_floating_point() and (
+            k.endswith(("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight", "c_fc.bias", "c_proj.weight",
+                        "c_proj.bias", "conv1.weight", "conv2.weight", "conv3.weight", "q_proj.weight", "k_proj.weight", "v_proj.weight",
+                        "q_proj.bias", "k_proj.bias", "v_proj.bias", "downsample.0.weight"))
+            or k in ("visual.proj", "text_projection") or (k.startswith("visual.attnpool.") and k.endswith((".weight", ".bias")) and "positional" not in k))
+        out[k] = v.half().float() if grid else v
+    return out
+
+
 def _bn(sd, seed, key, ch, device, gain=1.0):
     """BatchNorm2d buffers and affine in eval form: non-trivial running statistics so that the folding is exercised."""
     sd[key + ".weight"] = normal(seed, key + ".w", (ch,), 0.1, gain, device=device)

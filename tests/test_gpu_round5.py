@@ -168,3 +168,75 @@ def test_gemm_f16_residual_in_place_with_row_statistics(M, N, K):
                                  part2.data_ptr(), _st()))
     torch.cuda.synchronize()
     assert torch.equal(x16b, x16) and torch.equal(part2, part)
+
+
+# ------------------------------------------------------------------ two-pass products for weights on the fp16 grid (parity mode)
+def test_weights_on_the_fp16_grid_run_two_exact_passes(monkeypatch):
+    """Every Conv / Linear / attention / projection weight of a released CLIP checkpoint is an fp16 number (the archives store them as
+    fp16; TPT/clip/model.py:375-436 copies them into float32 parameters), so its split-f16 lo half is identically zero and the
+    a_hi . w_lo MFMA pass of a product with it adds exact zeros.  The engine recognises such weights at finalize and the 256x256
+    split-f16 kernel drops that pass.  Checked at ViT-B/16 size (64 views x 197 tokens: the 256x256 / 192x256 kernels run): with the
+    three-pass form forced (RLCF_X3_WLO0=0 at finalize) the image features and the whole prompt-tuning step give the SAME numbers
+    (torch.equal: an exact zero can only differ in sign); weights off the grid are not mistaken for grid weights."""
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine, TTAConfig
+    g = synth.GEOMETRIES["ViT-B/16"]
+    sd32 = synth.make_state_dict(g, 11, device=DEV)
+    sd16 = synth.to_fp16_grid(sd32)
+    tokens = synth.make_token_bank(g, 16, seed=7, n_ctx=4)
+    ctx0 = sd32["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(g, 4), device=DEV)].clone()
+    views = synth.make_views(1113, 64, g.image_resolution, device=DEV)
+    outs = []
+    for env, sd in (("0", sd16), (None, sd16), (None, sd32)):
+        if env is None:
+            monkeypatch.delenv("RLCF_X3_WLO0", raising=False)
+        else:
+            monkeypatch.setenv("RLCF_X3_WLO0", env)
+        eng = Engine(g, g, 64, 16, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, sd)
+        eng.load_state_dict(L.REWARD, sd)
+        eng.finalize()
+        import ctypes
+        others = ctypes.c_int(0)
+        on = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+        eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+        f = eng.encode_image(L.STUDENT, views).clone()
+        o = eng.tta_sample(views, TTAConfig(selection_p=0.1))
+        outs.append((on, others.value, f, o["final_logits"].clone(), o["ctx_after"].clone()))
+        eng.close()
+    (on0, off0, f0, l0, c0), (on1, off1, f1, l1, c1), (on2, off2, f2, l2, c2) = outs
+    assert on0 == 0 and on1 > 90 and on2 == 0, (on0, on1, on2)        # 12 + 12 blocks x 4 (x 2 with the transposed copies of the text tower) + projections
+    assert off1 == 0 or off1 < on1
+    assert torch.equal(f0, f1) and torch.equal(l0, l1) and torch.equal(c0, c1)
+    assert not torch.equal(f1, f2)                                    # (other weights: other numbers)
+
+
+@pytest.mark.parametrize("path", ["ln", "visual"])
+def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
+    """The same exactness through the image-encoder tuning paths at small geometry (the 128x128 kernels): LayerNorm tuning keeps every GEMM
+    weight frozen (two passes throughout); every-parameter tuning moves the weights off the grid at its first step, so a tuned weight's
+    products must run three passes from the moment the path is enabled — both must give the numbers of the forced three-pass build."""
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine, TTAConfig
+    sg, rg = synth.GEOMETRIES["small"], synth.GEOMETRIES["small"]
+    ssd, rsd = synth.to_fp16_grid(synth.make_state_dict(sg, 11, device=DEV)), synth.to_fp16_grid(synth.make_state_dict(rg, 23, device=DEV))
+    tokens = synth.make_token_bank(sg, 40, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, 4), device=DEV)].clone()
+    views = synth.make_views(2002, 64, sg.image_resolution, device=DEV)
+    outs = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RLCF_X3_WLO0", raising=False)
+        else:
+            monkeypatch.setenv("RLCF_X3_WLO0", env)
+        eng = Engine(sg, rg, 64, 40, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, ssd)
+        eng.load_state_dict(L.REWARD, rsd)
+        eng.finalize()
+        eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+        cfg = TTAConfig(selection_p=0.25, tta_steps=2, lr=1e-4)
+        o = eng.tta_sample_ln(views, cfg) if path == "ln" else eng.tta_sample_visual(views, cfg)
+        outs.append({k: o[k].clone() for k in ("final_logits", "ln_grad", "ln_after")})
+        eng.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
