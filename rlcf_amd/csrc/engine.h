@@ -61,6 +61,10 @@ struct Tower {                       // workspace of one transformer pass over T
 
 struct ConvW {                       // conv with folded BatchNorm
     const float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1, Kp = 0;
+    // the same convolution with the BatchNorm scale kept OUT of the weight: wg = W permuted / padded like w but unscaled, cs[co] = gamma /
+    // sqrt(var + eps) applied per output column in the GEMM epilogue (GemmX3Args::col_scale).  Set only when wg sits on the fp16 grid (a
+    // released checkpoint's convolution weights do): its products then run two MFMA passes; used by the pair-emitting path
+    const float* wg = nullptr; const float* cs = nullptr;
     float gain = 0.f, bmax = 0.f;    // max_row sum_k |w[row, k]| and max |b|: |conv(x)| <= gain max|x| + bmax, the bound the scale of a
 };                                   // pair-emitting epilogue is chosen from BEFORE the launch (resnet.hip)
 struct BottleW { ConvW c1, c2, c3, down; bool has_down = false; int stride = 1; };                          // model.py:10-55

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
         if (col < g.N) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
+            const float4 cs4 = g.col_scale ? *(const float4*)(g.col_scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);      // (exactly 1 when none)
             const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f16x3_kernel(GemmX3Args g) {
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
-                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+                float v[4] = {al * cs4.x * a4.x + bv.x, al * cs4.y * a4.y + bv.y, al * cs4.z * a4.z + bv.z, al * cs4.w * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
         if (col < g.N) {                                                    // N % 4 == 0 is checked by the launcher
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g.bias) bv = *(const float4*)(g.bias + col);
+            const float4 cs4 = g.col_scale ? *(const float4*)(g.col_scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);      // (exactly 1 when none)
             const float osd_ = g.Chi ? x3_out_scale(g) : 1.0f;   // scale of the split output, read BEFORE the first store of the loop (exactly 1 when none: v * 1 == v)
 #pragma unroll 4
             for (int it = 0; it < 8 * RT; ++it) {
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 2 : 1) void gemm_nt_f16x3_v2_
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
-                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+                float v[4] = {al * cs4.x * a4.x + bv.x, al * cs4.y * a4.y + bv.y, al * cs4.z * a4.z + bv.z, al * cs4.w * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
     const int col = n0 + wn * 64 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && col < g.N) bv = *(const float4*)(g.bias + col);
+    const float4 cs4 = (g.col_scale && col < g.N) ? *(const float4*)(g.col_scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);      // (exactly 1 when none)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
                 if (row >= g.M) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
-                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+                float v[4] = {al * cs4.x * a4.x + bv.x, al * cs4.y * a4.y + bv.y, al * cs4.z * a4.z + bv.z, al * cs4.w * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -957,6 +960,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     const int col = n0 + wn * 64 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && col < g.N) bv = *(const float4*)(g.bias + col);
+    const float4 cs4 = (g.col_scale && col < g.N) ? *(const float4*)(g.col_scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);      // (exactly 1 when none)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                 if (row >= g.M || half * 64 + rl >= MT * 32) continue;
                 const float4 a4 = *(const float4*)(park + rl * ELD + c4);
                 const float al = x3_alpha(g);
-                float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+                float v[4] = {al * cs4.x * a4.x + bv.x, al * cs4.y * a4.y + bv.y, al * cs4.z * a4.z + bv.z, al * cs4.w * a4.w + bv.w};
                 if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
         // bias / aux / residual first, then the slices four at a time (independent loads in flight together; the adds stay in slice order)
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), x4 = bv, r4 = bv;
         if (g.bias) bv = *(const float4*)(g.bias + col);
+        const float4 cs4 = g.col_scale ? *(const float4*)(g.col_scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
         if (g.epilogue == RLCF_EPI_QUICKGELU_BWD) x4 = *(const float4*)(g.aux + (size_t)row * g.ldaux + col);
         if (g.residual) r4 = *(const float4*)(g.residual + (size_t)row * g.ldr + col);
         float4 a4 = *(const float4*)(g.ws + (size_t)row * g.N + col);
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(256) void gemm_x3_splitk_reduce_kernel(GemmX3Args g
                 if (z + u < g.ksplit) { a4.x += t[u].x; a4.y += t[u].y; a4.z += t[u].z; a4.w += t[u].w; }
         }
         const float al = x3_alpha(g);
-        float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+        float v[4] = {al * cs4.x * a4.x + bv.x, al * cs4.y * a4.y + bv.y, al * cs4.z * a4.z + bv.z, al * cs4.w * a4.w + bv.w};
         if (g.epilogue == RLCF_EPI_QUICKGELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -1427,6 +1432,8 @@ int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const flo
 // bound-derived output scale of the NEXT pair-emitting launch of this thread (GemmX3Args::bnd_*; resnet.hip's conv_pairs): consumed by
 // launch_gemm_f16x3 / launch_gemm_f16x3_conv3x3
 struct X3Bound { const float* in; const float* res; float gain, bmax; float* out2; };
+static thread_local const float* g_next_col_scale = nullptr;      // per-output-column factor of the NEXT launch (GemmX3Args::col_scale)
+void gemm_f16x3_next_col_scale(const float* cs) { g_next_col_scale = cs; }
 static thread_local X3Bound g_next_bound = {nullptr, nullptr, 0.f, 0.f, nullptr};
 void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float gain, float bmax, float* out2) {
     g_next_bound = X3Bound{amax_in, amax_res, gain, bmax, out2};
@@ -1434,6 +1441,7 @@ void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float ga
 static inline void x3_take_bound(GemmX3Args& g) {
     g.bnd_in = g_next_bound.in; g.bnd_res = g_next_bound.res; g.bnd_gain = g_next_bound.gain; g.bnd_bmax = g_next_bound.bmax;
     g.bnd_out2 = g_next_bound.out2;
+    g.col_scale = g_next_col_scale; g_next_col_scale = nullptr;
     g_next_bound = X3Bound{nullptr, nullptr, 0.f, 0.f, nullptr};
 }
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
@@ -1706,7 +1714,7 @@ bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin) {
 }
 int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
                               const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
-                              unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs, const float* out_scale_dev) {
+                              unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs, const float* out_scale_dev, int wlo0) {
     const int M = n * H * W, K = 9 * Cin;
     RLCF_ARG_CHECK(act_pairs && Wpairs && (C || Cpairs) && zpage && gemm_f16x3_conv3x3_ok(M, Cout, Cin) && ldc % 4 == 0 && ldr % 4 == 0);
     GemmX3Args g{};
@@ -1722,8 +1730,13 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     g.no_fast_epi = nofast;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((Cout + V3_BN - 1) / V3_BN);
     const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
+    if (wlo0) {
+        { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true, false, 4, true>), sh3); if (rc_ != RLCF_OK) return rc_; }
+        gemm_nt_f16x3_v3i_kernel<false, true, false, 4, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+    } else {
     { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true>), sh3); if (rc_ != RLCF_OK) return rc_; }
     gemm_nt_f16x3_v3i_kernel<false, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+    }
     g_last_x3_variant = 3;
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;

@@ -53,6 +53,9 @@ struct GemmX3Args {
     // 256x256 split-f16 kernel, measurement (RLCF_X3_STAGGER=P): the workgroups of the FIRST tile round start c/P of a tile late (c = index
     // inside the XCD mod P), so that the CUs are out of step for the whole launch and their store bursts do not meet (profiles/r5_notes.md)
     int stagger;
+    // optional per-output-column factor applied to alpha * acc before the bias (generic epilogues only): the BatchNorm scale of a ResNet
+    // convolution whose weight is kept UNFOLDED on the fp16 grid so that its products run two MFMA passes (resnet.hip)
+    const float* col_scale;
 };
 #define X3_SK_MAX_BLOCKS 1024
 #define X3_SK_FLAG_BYTES 8192                                   // flags + time-out word, at the end of the workspace
@@ -106,6 +109,9 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) bv = *(const float4*)(g.bias + colc);
     const float al = LEAN ? g.alpha : x3_alpha(g);         // (alpha_dev: the device-side undo of a data-dependent operand scale)
+    // alpha times the optional per-column factor (GemmX3Args::col_scale: the BatchNorm scale of an unfolded ResNet convolution; exactly alpha when none)
+    float4 alc = make_float4(al, al, al, al);
+    if (!LEAN && g.col_scale) { const float4 cs4 = *(const float4*)(g.col_scale + colc); alc = make_float4(al * cs4.x, al * cs4.y, al * cs4.z, al * cs4.w); }
     const bool relu = !LEAN && g.epilogue == RLCF_EPI_RELU;     // ResNet convolutions: ReLU after the identity add (wave-uniform, one select per value)
     const float os = (!LEAN && PAIR) ? x3_out_scale(g) : 1.0f;
     const bool want_amax = !LEAN && g.amax_out != nullptr;
@@ -126,7 +132,7 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const float4 a4 = *(const float4*)(park + (it * 4 + rsub) * ELD + c4);
-        float v[4] = {al * a4.x + bv.x, al * a4.y + bv.y, al * a4.z + bv.z, al * a4.w + bv.w};
+        float v[4] = {alc.x * a4.x + bv.x, alc.y * a4.y + bv.y, alc.z * a4.z + bv.z, alc.w * a4.w + bv.w};
         if constexpr (EPI == RLCF_EPI_QUICKGELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = quick_gelu_fast(v[q]);
@@ -185,7 +191,7 @@ __device__ __forceinline__ int x3_epilogue_kind(const GemmX3Args& g) {
     if (lin && f32o && !pair) return res ? 2 : 1;
     if (lin && !f32o && pair && !res) return 4;            // (in_proj -> Q / K / V pairs; ResNet conv1 / conv2 -> pairs of the next convolution)
     if (lin && f32o && pair && res) return 5;              // ResNet conv3: block output as f32 (the next identity) AND as pairs (the next conv1)
-    if (g.amax_out || g.alpha_dev || g.out_scale_dev || g.bnd_in) return 0;
+    if (g.amax_out || g.alpha_dev || g.out_scale_dev || g.bnd_in || g.col_scale) return 0;
     if (g.epilogue == RLCF_EPI_QUICKGELU && !f32o && pair && !res) return 3;
     if (g.epilogue == RLCF_EPI_NONE && !f32o && pair && !res) return 4;
     return 0;

@@ -84,6 +84,7 @@ bool gemm_f16_p8_ok(const void* C, const void* Chi, const float* residual, const
                     unsigned int* amax_out, const float* out_scale_dev, int N, int K, int lda, int ldw, int ldc, int ldr, int ldch);
 int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
                           int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, hipStream_t st);
+void gemm_f16x3_next_col_scale(const float* cs);          // per-output-column factor of the next launch_gemm_f16x3 / _conv3x3 call of this thread (GemmX3Args::col_scale)
 int launch_f16_grid_check(const float* w, int64_t n, float scale, int* flag, hipStream_t st);       // flag[0] |= 1 unless every w * scale is an f16 number
 // the output scale of the NEXT pair-emitting launch_gemm_f16x3 / _conv3x3 call of this thread is derived inside that launch from an upper
 // bound of |C| (device scalars max|input| / max|identity|, host constants gain / bmax) and published in out2 = (s, 1 / s): gemm_x3.h
@@ -105,7 +106,7 @@ bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin);
 int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
                               const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
                               unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs = nullptr,
-                              const float* out_scale_dev = nullptr);
+                              const float* out_scale_dev = nullptr, int wlo0 = 0 /* the weight's lo halves are zero: two MFMA passes */);
 int launch_dyn_scale_from(const float* amax_dev, float* scale2, hipStream_t st);            // scale2 = {s, 1/s} from a known max|x|
 int launch_split_f16x2_dev(const float* x, void* hi, void* lo, int64_t n, const float* scale_dev, hipStream_t st, int il = 0);
 int launch_split_f16x2_dyn(const float* x, void* hi, void* lo, int64_t n, float* scratch3, hipStream_t st, int il = 0);

@@ -195,6 +195,12 @@ __global__ void conv_bound_scale_kernel(const float* __restrict__ amax_in, const
     out2[0] = ldexpf(1.0f, sh);
     out2[1] = ldexpf(1.0f, -sh);
 }
+__global__ void conv_permute_kernel(const float* __restrict__ w, float* __restrict__ wout, int Cin, int kk, int Kp);        // (below)
+// s[co] = gamma / sqrt(var + 1e-5): the factor conv_fold_kernel multiplies into the weight, kept apart (ConvW::cs)
+__global__ void conv_bn_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ var, float* __restrict__ cs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cs[i] = gamma[i] / sqrtf(var[i] + 1e-5f);
+}
 static int fold(rlcf_engine* e, ClipModel& m, const std::string& conv, const std::string& bn, int cout, int cin, int k, ConvW& out,
                 hipStream_t st) {
     const int kk = k * k;
@@ -226,7 +232,33 @@ static int fold(rlcf_engine* e, ClipModel& m, const std::string& conv, const std
         RLCF_HIP_CHECK(hipStreamSynchronize(st));
         out.gain = gb[0]; out.bmax = gb[1];
     }
-    return engine_make_split(e, m, out.w, (size_t)cout * out.Kp, st);
+    TRY(engine_make_split(e, m, out.w, (size_t)cout * out.Kp, st));
+    // The unfolded form, kept only if the raw weight sits on the fp16 grid (then its products need two MFMA passes, and
+    // folding the BatchNorm scale into it would take it off the grid).  RLCF_X3_WLO0=0 (read by engine_make_split) and RLCF_CONV_GRID=0: off
+    out.wg = nullptr; out.cs = nullptr;
+    const char* ev = getenv("RLCF_CONV_GRID");
+    if (!(ev && atoi(ev) == 0) && out.Kp % 32 == 0) {
+        DevBuf wgb, csb;
+        TRY(wgb.ensure((size_t)cout * out.Kp * sizeof(float)));
+        conv_permute_kernel<<<dim3(cout), dim3(256), 0, st>>>(w, wgb.as<float>(), cin, kk, out.Kp);
+        RLCF_LAUNCH_CHECK();
+        TRY(engine_make_split(e, m, wgb.as<float>(), (size_t)cout * out.Kp, st));
+        auto it = m.split_of.find(wgb.as<float>());
+        if (it != m.split_of.end() && it->second.lo_zero) {
+            TRY(csb.ensure((size_t)cout * sizeof(float)));
+            conv_bn_scale_kernel<<<dim3((cout + 255) / 256), dim3(256), 0, st>>>(g, var, csb.as<float>(), cout);
+            RLCF_LAUNCH_CHECK();
+            out.wg = wgb.as<float>(); out.cs = csb.as<float>();
+            m.derived.push_back(std::move(wgb));
+            m.derived.push_back(std::move(csb));
+        } else {
+            // (not on the grid: drop the copy again — its split pair stays in m.derived until the next finalize, unused)
+            if (it != m.split_of.end()) m.split_of.erase(it);
+            RLCF_HIP_CHECK(hipStreamSynchronize(st));
+            wgb.release();
+        }
+    }
+    return RLCF_OK;
 }
 
 // build_model's ResNet branch (model.py:408-412) fixed the geometry; here: fold, permute and (F16X3) split every weight
@@ -378,10 +410,13 @@ static int conv_pairs(rlcf_engine* e, const ConvW& cw, ConvIn in, int n, int H, 
         } else gemm_f16x3_next_bound(in.amax, res_amax, cw.gain, cw.bmax, out.scale2);     // (derived inside the GEMM launch below)
     }
     // out.amax is a fresh slot of the chunk's zeroed max|.| arena (resnet_encode): nothing to clear here
+    // weight on the fp16 grid: the unfolded copy (two MFMA passes) with the BatchNorm scale as the epilogue's column factor
+    const float* Wuse = cw.wg ? cw.wg : cw.w;
+    if (cw.wg) gemm_f16x3_next_col_scale(cw.cs);
     if (cw.k == 1)
-        return engine_gemm_pairs(e, in.pairs, cw.cin, in.scale2 + 1, cw.w, cw.b, res, cw.cout, out.f32, cw.cout, out.pairs, out.scale2, (int)M,
+        return engine_gemm_pairs(e, in.pairs, cw.cin, in.scale2 + 1, Wuse, cw.b, res, cw.cout, out.f32, cw.cout, out.pairs, out.scale2, (int)M,
                                  cw.cout, epi, st, out.amax);
-    return engine_gemm_conv3x3(e, nullptr, in.scale2, cw.w, cw.b, res, cw.cout, out.f32, cw.cout, n, H, W, cw.cin, cw.cout, epi, st, out.amax,
+    return engine_gemm_conv3x3(e, nullptr, in.scale2, Wuse, cw.b, res, cw.cout, out.f32, cw.cout, n, H, W, cw.cin, cw.cout, epi, st, out.amax,
                                in.pairs, out.pairs, out.scale2);
 }
 

@@ -240,3 +240,33 @@ def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
         eng.close()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_resnet_convolutions_on_the_fp16_grid_keep_the_batchnorm_scale_in_the_epilogue(monkeypatch):
+    """A ModifiedResNet tower folds its BatchNorms into the convolutions (model.py:18-31 in eval mode), which takes the weights off the fp16
+    grid.  For checkpoint weights the engine keeps an UNFOLDED copy (two MFMA passes) and applies gamma / sqrt(var + eps) per output column
+    in the GEMM epilogue instead (ConvW::wg / cs, GemmX3Args::col_scale; the fused pair-emitting blocks).  Same function, another rounding
+    order: the features must agree with the folded form (RLCF_CONV_GRID=0) to float32 accuracy, and with float32 random weights nothing
+    changes at all."""
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine
+    g, rg = synth.GEOMETRIES["RN50"], synth.GEOMETRIES["tiny-r"]
+    sd32 = synth.make_state_dict(g, 11, device=DEV)
+    sd16 = synth.to_fp16_grid(sd32)
+    rsd = synth.make_state_dict(rg, 23, device=DEV)
+    views = synth.make_views(3000, 32, g.image_resolution, device=DEV)       # (32 views: the fused pair-emitting blocks are taken)
+    feats = {}
+    for name, env, sd in (("grid", None, sd16), ("folded", "0", sd16), ("f32", None, sd32), ("f32_folded", "0", sd32)):
+        if env is None:
+            monkeypatch.delenv("RLCF_CONV_GRID", raising=False)
+        else:
+            monkeypatch.setenv("RLCF_CONV_GRID", env)
+        eng = Engine(g, rg, 32, 16, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, sd)
+        eng.load_state_dict(L.REWARD, rsd)
+        eng.finalize()
+        feats[name] = eng.encode_image(L.STUDENT, views).clone()
+        eng.close()
+    assert torch.equal(feats["f32"], feats["f32_folded"])              # weights off the grid: the folded form, bit for bit
+    d = (feats["grid"] - feats["folded"]).abs().max().item()
+    assert 0 < d < 2e-5, d                                             # (unit-norm features; the two forms round differently)
