@@ -1438,11 +1438,18 @@ static thread_local X3Bound g_next_bound = {nullptr, nullptr, 0.f, 0.f, nullptr}
 void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float gain, float bmax, float* out2) {
     g_next_bound = X3Bound{amax_in, amax_res, gain, bmax, out2};
 }
-static inline void x3_take_bound(GemmX3Args& g) {
-    g.bnd_in = g_next_bound.in; g.bnd_res = g_next_bound.res; g.bnd_gain = g_next_bound.gain; g.bnd_bmax = g_next_bound.bmax;
-    g.bnd_out2 = g_next_bound.out2;
-    g.col_scale = g_next_col_scale; g_next_col_scale = nullptr;
+// what the caller announced for THIS launch: taken (and cleared) on entry of the launcher, before any argument check can return, so that an
+// announcement can never outlive the call it was made for
+struct X3Next { X3Bound b; const float* col_scale; };
+static inline X3Next x3_take_next() {
+    const X3Next n{g_next_bound, g_next_col_scale};
     g_next_bound = X3Bound{nullptr, nullptr, 0.f, 0.f, nullptr};
+    g_next_col_scale = nullptr;
+    return n;
+}
+static inline void x3_apply_next(GemmX3Args& g, const X3Next& n) {
+    g.bnd_in = n.b.in; g.bnd_res = n.b.res; g.bnd_gain = n.b.gain; g.bnd_bmax = n.b.bmax; g.bnd_out2 = n.b.out2;
+    g.col_scale = n.col_scale;
 }
 int g_last_x3_variant = 0;          // 1 = 128x128 register-staged kernel, 2 = 256x128 DMA-ring kernel (profiling tag)
 // splitk_ws / splitk_ws_bytes: caller-owned scratch for the split-K form of the small-grid kernel (the engine sizes it once at
@@ -1451,6 +1458,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                       const float* residual, int ldr, const float* aux, int ldaux, float* C, int ldc, void* Chi, void* Clo, int ldch,
                       int M, int N, int K, float alpha, int epilogue, hipStream_t st, const float* alpha_dev, unsigned int* amax_out, int c_il,
                       float* splitk_ws, size_t splitk_ws_bytes, int single, const float* out_scale_dev, unsigned* sk_epoch) {
+    const X3Next next = x3_take_next();
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     const bool wlo0 = single == 2;           // single: 0 = split-f16 (three passes), 1 = plain f16 operands (RLCF_PREC_F16), 2 = split-f16 with an all-zero W lo part (two passes)
     if (wlo0) single = 0;
@@ -1469,7 +1477,7 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.aux = aux; g.ldaux = ldaux; g.C = C; g.ldc = ldc;
     g.Chi = (_Float16*)Chi; g.Clo = (_Float16*)Clo; g.ldch = ldch; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue;
     g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.c_il = c_il; g.out_scale_dev = out_scale_dev;
-    x3_take_bound(g);
+    x3_apply_next(g, next);
     g.kstep = (Alo == (const void*)((const _Float16*)Ahi + 32)) ? 64 : X3_BK;     // interleaved [hi32|lo32] blocks
     RLCF_ARG_CHECK((g.kstep == 64) == (Wlo == (const void*)((const _Float16*)Whi + 32)));   // both operands in the same layout
     const size_t sh = (size_t)2 * 4 * X3_TILE * sizeof(_Float16);
@@ -1715,6 +1723,7 @@ bool gemm_f16x3_conv3x3_ok(int M, int N, int Cin) {
 int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Cin, const void* Wpairs, int Cout, const float* bias,
                               const float* residual, int ldr, float* C, int ldc, float alpha, int epilogue, const float* alpha_dev,
                               unsigned int* amax_out, const void* zpage, hipStream_t st, void* Cpairs, const float* out_scale_dev, int wlo0) {
+    const X3Next next = x3_take_next();
     const int M = n * H * W, K = 9 * Cin;
     RLCF_ARG_CHECK(act_pairs && Wpairs && (C || Cpairs) && zpage && gemm_f16x3_conv3x3_ok(M, Cout, Cin) && ldc % 4 == 0 && ldr % 4 == 0);
     GemmX3Args g{};
@@ -1723,7 +1732,7 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = Cout; g.K = K; g.alpha = alpha;
     g.epilogue = epilogue; g.alpha_dev = alpha_dev; g.amax_out = amax_out; g.kstep = 64;
     g.conv_C = Cin; g.conv_H = H; g.conv_W = W; g.zpage = (const _Float16*)zpage;
-    x3_take_bound(g);
+    x3_apply_next(g, next);
     if (Cpairs) { RLCF_ARG_CHECK(Cout % 32 == 0); g.Chi = (_Float16*)Cpairs; g.Clo = g.Chi + 32; g.ldch = 2 * Cout; g.c_il = 1; g.out_scale_dev = out_scale_dev; }
     static int nofast = -1;
     if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }

@@ -351,7 +351,10 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
         TRY(e->dyn.ensure(3 * sizeof(float)));
         if (in_amax) TRY(launch_dyn_scale_from(in_amax, e->dyn.as<float>() + 1, st));
         else TRY(launch_dyn_scale(in, (int64_t)M * cw.cin, e->dyn.as<float>(), st));
-        return engine_gemm_conv3x3(e, in, e->dyn.as<float>() + 1, cw.w, cw.b, res, cw.cout, out, cw.cout, n, H, W, cw.cin, cw.cout, epi, st, out_amax);
+        // (weight on the fp16 grid: the unfolded copy — two MFMA passes — with the BatchNorm scale as the epilogue's column factor)
+        if (cw.wg && engine_has_split(e, cw.wg)) gemm_f16x3_next_col_scale(cw.cs);
+        return engine_gemm_conv3x3(e, in, e->dyn.as<float>() + 1, cw.wg && engine_has_split(e, cw.wg) ? cw.wg : cw.w, cw.b, res, cw.cout, out, cw.cout, n, H, W,
+                                   cw.cin, cw.cout, epi, st, out_amax);
     }
     if (cw.k == 3 && !nchw && prec_x3(e) && cw.cin % 8 == 0 && M > 512 && (size_t)M * cw.Kp <= e->a_split_elems &&
         engine_has_split(e, cw.w)) {
@@ -364,7 +367,9 @@ static int conv(rlcf_engine* e, const ConvW& cw, const float* in, const float* i
         im2col3x3_split_kernel<<<grid_for(total8), dim3(256), 0, st>>>(in, (_Float16*)e->a_hi.p, (_Float16*)e->a_hi.p + 32, total8, cw.cin, H, W,
                                                                       Ho, Wo, stride, cw.Kp, e->dyn.as<float>() + 1);
         RLCF_LAUNCH_CHECK();
-        return engine_gemm_presplit(e, cw.w, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi, e->dyn.as<float>() + 2, st, out_amax);
+        if (cw.wg && engine_has_split(e, cw.wg)) gemm_f16x3_next_col_scale(cw.cs);
+        return engine_gemm_presplit(e, cw.wg && engine_has_split(e, cw.wg) ? cw.wg : cw.w, cw.b, res, cw.cout, out, cw.cout, (int)M, cw.cout, cw.Kp, epi,
+                                    e->dyn.as<float>() + 2, st, out_amax);
     }
     if (cw.k == 3) {
         const long total = M * cw.Kp;
