@@ -124,7 +124,7 @@ struct ClipModel {
     const float* vproj = nullptr;          // [Wv, D] as stored (backward operand)
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
-    struct SplitW { void *hi, *lo; float inv_scale; bool lo_zero = false; };   // W * 2^s = hi + lo; inv_scale = 2^-s; lo_zero: W 2^s sits on the f16 grid (two MFMA passes suffice)
+    struct SplitW { void *hi, *lo; float inv_scale; bool lo_zero = false; void* hi_only = nullptr; /* lo_zero: the hi halves alone as a plain f16 matrix */ };   // W * 2^s = hi + lo; inv_scale = 2^-s; lo_zero: W 2^s sits on the f16 grid (two MFMA passes suffice)
     std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 / F16 modes)
     std::unordered_map<const float*, SplitW> f16_of;                      // f32 weight -> plain f16 copy (.hi; RLCF_PREC_F16 mode only)
     // RLCF_PREC_F16 image towers: in_proj / c_fc weight with the preceding LayerNorm folded in (engine.hip make_lnfold): w16 = f16 copy of

@@ -99,6 +99,7 @@ static int gemm(rlcf_engine* e, const float* A, int lda, const float* W, int ldw
                 TRY(launch_split_f16x2(A, a_ptr(e), lo_of(a_ptr(e)), (int64_t)M * K, st, a_scale, 1));
             }
             const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+            if (sp->lo_zero && sp->hi_only) gemm_f16x3_next_packed_w(sp->hi_only);
             int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, aux, ldaux, C, ldc, nullptr,
                                        nullptr, 0, M, N, K, alpha * sp->inv_scale / a_scale, epi, st, alpha_dev, amax_out, 0,
                                        ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
@@ -144,6 +145,7 @@ int engine_gemm_presplit(rlcf_engine* e, const float* W, const float* bias, cons
     if (!sp) { rlcf_set_error("engine_gemm_presplit: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+    if (sp->lo_zero && sp->hi_only) gemm_f16x3_next_packed_w(sp->hi_only);
     int rc = launch_gemm_f16x3(a_ptr(e), lo_of(a_ptr(e)), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, nullptr, nullptr, 0, M, N, K,
                                sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 0, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
@@ -160,6 +162,7 @@ int engine_gemm_pairs(rlcf_engine* e, const void* Apairs, int K, const float* al
     if (!sp) { rlcf_set_error("engine_gemm_pairs: weight has no split copy"); return RLCF_ERR_STATE; }
     e->last_flops += 2.0 * M * N * K;
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+    if (sp->lo_zero && sp->hi_only) gemm_f16x3_next_packed_w(sp->hi_only);
     int rc = launch_gemm_f16x3(Apairs, lo_of(Apairs), 2 * K, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, Cpairs, Cpairs ? lo_of(Cpairs) : nullptr,
                                2 * N, M, N, K, sp->inv_scale, epi, st, alpha_dev, (unsigned int*)amax_out, 1, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, out_scale_dev, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
@@ -224,6 +227,7 @@ static int gemm_pre(rlcf_engine* e, const void* A2, int lda, const float* W, con
     const ClipModel::SplitW* sp = split_of(e, W);
     if (!sp) { rlcf_set_error("gemm_pre: weight has no split copy"); return RLCF_ERR_STATE; }
     const int slot = prof_begin(st, 2.0 * M * N * K, M, N, K);
+    if (sp->lo_zero && sp->hi_only) gemm_f16x3_next_packed_w(sp->hi_only);
     int rc = launch_gemm_f16x3(A2, lo_of(A2), 2 * lda, sp->hi, sp->lo, 2 * K, bias, res, ldr, nullptr, 0, C, ldc, C2, C2 ? lo_of(C2) : nullptr,
                                2 * ldch, M, N, K, sp->inv_scale, epi, st, nullptr, nullptr, 1, ws_ptr(e), ws_bytes(e), sp->lo_zero ? 2 : 0, nullptr, ws_epoch(e));
     prof_end(slot, st, g_last_x3_variant);
@@ -287,6 +291,13 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
     }
     ClipModel::SplitW sw{hi.p, lo, 1.0f / scale};
     sw.lo_zero = lo_zero;
+    if (lo_zero) {                                         // the hi halves alone, row-major: what the packed-W form of the 256x256 kernel stages
+        DevBuf ho;
+        TRY(ho.ensure(numel * 2 + 256));
+        TRY(launch_split_f16x2(w, ho.p, nullptr, (int64_t)numel, st, scale, 0));
+        sw.hi_only = ho.p;
+        m.derived.push_back(std::move(ho));
+    }
     m.split_of[w] = sw;
     m.derived.push_back(std::move(hi));
     if (prec_single(e) && numel % 64 == 0) {                 // plain f16 copy for the single-pass forward pipeline (same pre-scale)

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3_kernel(GemmX3Args g) 
 // MT = 32-row accumulator tiles per wave group: 4 = the 256-row tile; 3 = a 192-row tile for launches whose 256-row tiles fill
 // little more than half of one round of workgroups (one image's token matrix against a W x W / W x 4W weight: 150 tiles on 256 CUs
 // -> 198 tiles of 3/4 the work each)
-template <bool SINGLE, bool CONV = false, bool SK = false, int MT = 4, bool WLO0 = false>
+template <bool SINGLE, bool CONV = false, bool SK = false, int MT = 4, int WLO0 = 0>       // WLO0: 0 three passes, 1 two passes (w_lo == 0), 2 two passes + packed hi-only W
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g) {
     static_assert(MT == 4 || (MT == 3 && !SK && !CONV), "192-row tiles: plain products only");
     constexpr int BM = MT * 64;
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     // byte: 25.8 against 45.5 B/clk/CU in the delivery micro-benchmark).  LDS row = 128 B; 16-B chunk c (0-3 hi, 4-7 lo) of row r sits
     // in slot c ^ ((r>>1)&7), so a 16-lane ds_read_b128 group (16 consecutive rows, one chunk) covers all 64 banks.
     size_t sa[4], sw[4];
+    size_t swp[4] = {0, 0, 0, 0};                               // (WLO0 == 2) the same rows of the packed hi-only copy
     unsigned vm[4] = {0x1ffu, 0x1ffu, 0x1ffu, 0x1ffu};      // CONV: bit t = tap t of this lane's row lies inside the image
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
         const int row = min(m0 + ra, g.M - 1);
         sa[j] = (size_t)row * g.lda + ca + (SK ? (size_t)k0 * g.kstep : (size_t)0);        // (stream-K pieces start at K step k0)
         sw[j] = (size_t)min(n0 + r, g.N - 1) * g.ldw + c + (SK ? (size_t)k0 * g.kstep : (size_t)0);
+        if constexpr (WLO0 == 2) swp[j] = (size_t)min(n0 + r, g.N - 1) * g.ldwpk + c;
         if constexpr (CONV) {
             const int ox = row % g.conv_W, oy = (row / g.conv_W) % g.conv_H;
             unsigned m = 0;
@@ -795,6 +797,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
                 const _Float16* pa_ = ((vm[(idx) & 3] >> ctap_) & 1u) ? g.Ahi + (long)sa[(idx) & 3] + coff_ : zlane;                     \
                 __builtin_amdgcn_global_load_lds((gptr_t)pa_, (lptr_t)((sb_) + (wave * MT + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);            \
             } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Ahi + sa[(idx) & 3] + (kk)), (lptr_t)((sb_) + (wave * MT + ((idx) & 3)) * 1024), 16, 0, V3_AUX_A);           \
+        } else if constexpr (WLO0 == 2) {                                                                                                \
+            /* packed W: the pair of K tiles (kt+1, kt+2) when kt+1 is even, into the W buffer of that pair's parity */                     \
+            if (wnext_) __builtin_amdgcn_global_load_lds((gptr_t)(g.Wpk + swp[(idx) & 3] + kkw_), (lptr_t)(smem + wb_ * V3_STAGE + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_W); \
         } else __builtin_amdgcn_global_load_lds((gptr_t)(g.Whi + sw[(idx) & 3] + (kk)), (lptr_t)((sb_) + 32768 + (wave * 4 + ((idx) & 3)) * 1024), 16, 0, V3_AUX_W);              \
     }
 #undef V3_LDA
@@ -809,10 +814,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     }
 #define V3_LDB(ks, BH, BL)                                                                                               \
     {                                                                                                                    \
+        if constexpr (WLO0 == 2) {                                                                                       \
+            /* K tile kt = half (kt & 1) of its pair's 128-byte rows (chunks 0-3 / 4-7), in the W buffer of the pair's parity */ \
+            const int ch_ = ((((kt) & 1) * 4 + (ks) * 2 + h) ^ swz) * 16;                                                  \
+            const char* sw_ = smem + (((kt) >> 1) & 1) * V3_STAGE + 32768 + boff;                                          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) { BH[j] = *(const h16x8*)(sw_ + j * 4096 + ch_); BL[j] = BH[j]; }  \
+        } else {                                                                                                         \
         const int ch_ = (((ks) * 2 + h) ^ swz) * 16, cl_ = ((4 + (ks) * 2 + h) ^ swz) * 16;                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
             BH[j] = *(const h16x8*)(sb + 32768 + boff + j * 4096 + ch_);                                                 \
             BL[j] = *(const h16x8*)(sb + 32768 + boff + j * 4096 + cl_);                                                 \
+        }                                                                                                                \
         }                                                                                                                \
     }
     const int nk = SK ? k1 - k0 : g.K / X3_BK;
@@ -821,6 +833,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     if constexpr (CONV) coff_ = conv_off(0, ctap_);
     {
         char* s0 = smem;
+        const bool wnext_ = true; const int kkw_ = 0, wb_ = 0;      // (WLO0 == 2: the first pair of K tiles)
+        (void)wnext_; (void)kkw_; (void)wb_;
 #pragma unroll
         for (int pi = 0; pi < 8; ++pi) V3_PIECE(pi, 0, s0)
     }
@@ -838,6 +852,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = kt + 1 < nk;
             const int kn = (kt + 1) * g.kstep;
+            const bool wnext_ = ((kt + 1) & 1) == 0; const int kkw_ = ((kt + 1) >> 1) * 64, wb_ = ((kt + 1) >> 1) & 1;      // (WLO0 == 2)
+            (void)wnext_; (void)kkw_; (void)wb_;
             if constexpr (CONV) { if (pf) coff_ = conv_off(kt + 1, ctap_); }
             char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
             const char* sb = smem + (kt & 1) * V3_STAGE;
@@ -864,6 +880,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
             __builtin_amdgcn_sched_barrier(0);
             const bool pf = kt + 1 < nk;
             const int kn = (kt + 1) * g.kstep;
+            const bool wnext_ = ((kt + 1) & 1) == 0; const int kkw_ = ((kt + 1) >> 1) * 64, wb_ = ((kt + 1) >> 1) & 1;      // (WLO0 == 2)
+            (void)wnext_; (void)kkw_; (void)wb_;
             if constexpr (CONV) { if (pf) coff_ = conv_off(kt + 1, ctap_); }
             char* sn = smem + ((kt + 1) & 1) * V3_STAGE;
             const char* sb = smem + (kt & 1) * V3_STAGE;
@@ -1432,6 +1450,8 @@ int launch_gemm_skinny_x3(const float* A, int lda, const void* Wpairs, const flo
 // bound-derived output scale of the NEXT pair-emitting launch of this thread (GemmX3Args::bnd_*; resnet.hip's conv_pairs): consumed by
 // launch_gemm_f16x3 / launch_gemm_f16x3_conv3x3
 struct X3Bound { const float* in; const float* res; float gain, bmax; float* out2; };
+static thread_local const _Float16* g_next_wpk = nullptr;      // packed hi-only copy of the NEXT launch's weight (GemmX3Args::Wpk), row length K halves
+void gemm_f16x3_next_packed_w(const void* wpk) { g_next_wpk = (const _Float16*)wpk; }
 static thread_local const float* g_next_col_scale = nullptr;      // per-output-column factor of the NEXT launch (GemmX3Args::col_scale)
 void gemm_f16x3_next_col_scale(const float* cs) { g_next_col_scale = cs; }
 static thread_local X3Bound g_next_bound = {nullptr, nullptr, 0.f, 0.f, nullptr};
@@ -1440,11 +1460,12 @@ void gemm_f16x3_next_bound(const float* amax_in, const float* amax_res, float ga
 }
 // what the caller announced for THIS launch: taken (and cleared) on entry of the launcher, before any argument check can return, so that an
 // announcement can never outlive the call it was made for
-struct X3Next { X3Bound b; const float* col_scale; };
+struct X3Next { X3Bound b; const float* col_scale; const _Float16* wpk; };
 static inline X3Next x3_take_next() {
-    const X3Next n{g_next_bound, g_next_col_scale};
+    const X3Next n{g_next_bound, g_next_col_scale, g_next_wpk};
     g_next_bound = X3Bound{nullptr, nullptr, 0.f, 0.f, nullptr};
     g_next_col_scale = nullptr;
+    g_next_wpk = nullptr;
     return n;
 }
 static inline void x3_apply_next(GemmX3Args& g, const X3Next& n) {
@@ -1462,6 +1483,10 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     RLCF_ARG_CHECK(M > 0 && N > 0 && K > 0 && K % X3_BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
     const bool wlo0 = single == 2;           // single: 0 = split-f16 (three passes), 1 = plain f16 operands (RLCF_PREC_F16), 2 = split-f16 with an all-zero W lo part (two passes)
     if (wlo0) single = 0;
+    // packed hi-only W (announced by the caller, plain f16 [N, K]): K tiles come in pairs.  RLCF_X3_WPK=0: interleaved W rows (A/B measurements)
+    static int wpk_on = -1;
+    if (wpk_on < 0) { const char* e = getenv("RLCF_X3_WPK"); wpk_on = e ? atoi(e) : 1; }
+    const bool wpk_ok = wlo0 && next.wpk && wpk_on && K % 64 == 0 && (size_t)N * K < ((size_t)1 << 31);
     // stream-K scratch (caller-owned, X3_WS_BYTES): slabs from the start of the workspace, flag words in its last X3_SK_FLAG_BYTES;
     // *sk_epoch = the caller's launch counter for THIS workspace (0: flags not yet zeroed)
     const bool sk_avail = sk_epoch && splitk_ws && splitk_ws_bytes >= (size_t)X3_SK_FLAG_BYTES + 8 * (size_t)X3_SK_SLAB_BYTES;
@@ -1547,9 +1572,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
                         (mt3 == 2 || (mt3 == 1 && cost3h < 0.97 * std::min(cost3, blocks2 >= 256 ? cost2 : cost3)));
     if (pick3h) {
         const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
-        if (wlo0) {
-            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3, true>), sh3);
-            gemm_nt_f16x3_v3i_kernel<false, false, false, 3, true><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
+        if (wlo0 && wpk_ok) {
+            g.Wpk = next.wpk; g.ldwpk = K;
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3, 2>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 3, 2><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
+        } else if (wlo0) {
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3, 1>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 3, 1><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
         } else {
         X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 3>), sh3);
         gemm_nt_f16x3_v3i_kernel<false, false, false, 3><<<dim3(blocks3h), dim3(512), sh3, st>>>(g);
@@ -1605,9 +1634,13 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
             // whole-tile workgroups for the full rounds, then the stream-K launch for the rest (first pieces, then second pieces)
             if (sk_first > 0) gemm_nt_f16x3_v3i_kernel<false><<<dim3(sk_first), dim3(512), sh3, st>>>(g);
             gemm_nt_f16x3_v3i_kernel<false, false, true><<<dim3(2 * sk_blocks), dim3(512), sh3, st>>>(g);
+        } else if (g.kstep == 64 && wlo0 && wpk_ok) {
+            g.Wpk = next.wpk; g.ldwpk = K;
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 4, 2>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 4, 2><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
         } else if (g.kstep == 64 && wlo0) {
-            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 4, true>), sh3);
-            gemm_nt_f16x3_v3i_kernel<false, false, false, 4, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+            X3_LDS((gemm_nt_f16x3_v3i_kernel<false, false, false, 4, 1>), sh3);
+            gemm_nt_f16x3_v3i_kernel<false, false, false, 4, 1><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
         } else if (g.kstep == 64) {
             X3_LDS(gemm_nt_f16x3_v3i_kernel<false>, sh3);
             gemm_nt_f16x3_v3i_kernel<false><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
@@ -1740,8 +1773,8 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((Cout + V3_BN - 1) / V3_BN);
     const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
     if (wlo0) {
-        { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true, false, 4, true>), sh3); if (rc_ != RLCF_OK) return rc_; }
-        gemm_nt_f16x3_v3i_kernel<false, true, false, 4, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+        { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 1>), sh3); if (rc_ != RLCF_OK) return rc_; }
+        gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 1><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
     } else {
     { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true>), sh3); if (rc_ != RLCF_OK) return rc_; }
     gemm_nt_f16x3_v3i_kernel<false, true><<<dim3(blocks3), dim3(512), sh3, st>>>(g);

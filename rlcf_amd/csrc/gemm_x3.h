@@ -56,6 +56,10 @@ struct GemmX3Args {
     // optional per-output-column factor applied to alpha * acc before the bias (generic epilogues only): the BatchNorm scale of a ResNet
     // convolution whose weight is kept UNFOLDED on the fp16 grid so that its products run two MFMA passes (resnet.hip)
     const float* col_scale;
+    // 256x256 split-f16 kernel, WLO0 == 2: the weight's hi halves alone as a plain f16 matrix [N, K] (ldwpk halves per row).  One 128-byte
+    // row block then holds the hi halves of TWO K tiles, so W pieces are staged every other K tile only (6 instead of 8 LDS-DMA
+    // instructions per wave and K tile) and no zero lo half travels
+    const _Float16* Wpk; int ldwpk;
 };
 #define X3_SK_MAX_BLOCKS 1024
 #define X3_SK_FLAG_BYTES 8192                                   // flags + time-out word, at the end of the workspace

@@ -84,6 +84,7 @@ bool gemm_f16_p8_ok(const void* C, const void* Chi, const float* residual, const
                     unsigned int* amax_out, const float* out_scale_dev, int N, int K, int lda, int ldw, int ldc, int ldr, int ldch);
 int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const float* bias, void* out16, int ldo, int M, int N, int K, float alpha,
                           int epilogue, int mode, const float* ln_mr, const float* ln_s, float* ln_part, hipStream_t st);
+void gemm_f16x3_next_packed_w(const void* wpk);          // plain f16 [N, K] copy of the next launch's weight hi halves (GemmX3Args::Wpk)
 void gemm_f16x3_next_col_scale(const float* cs);          // per-output-column factor of the next launch_gemm_f16x3 / _conv3x3 call of this thread (GemmX3Args::col_scale)
 int launch_f16_grid_check(const float* w, int64_t n, float scale, int* flag, hipStream_t st);       // flag[0] |= 1 unless every w * scale is an f16 number
 // the output scale of the NEXT pair-emitting launch_gemm_f16x3 / _conv3x3 call of this thread is derived inside that launch from an upper
