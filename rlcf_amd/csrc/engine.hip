@@ -194,6 +194,7 @@ int engine_gemm_conv3x3(rlcf_engine* e, const float* in, const float* scale2_dev
     const float* alpha_dev = scale2_dev + 1;
     e->last_flops += 2.0 * M * cout * 9.0 * cin;
     const int slot = prof_begin(st, 2.0 * M * cout * 9.0 * cin, M, cout, 9 * cin);
+    if (sp->lo_zero && sp->hi_only) gemm_f16x3_next_packed_w(sp->hi_only);
     int rc = launch_gemm_f16x3_conv3x3(in_pairs, n, H, Wd, cin, sp->hi, cout, bias, res, ldr, C, ldc, sp->inv_scale, epi, alpha_dev,
                                        (unsigned int*)amax_out, e->zpage.p, st, Cpairs, out_scale_dev, sp->lo_zero ? 1 : 0);
     prof_end(slot, st, g_last_x3_variant);

@@ -1772,7 +1772,13 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
     g.no_fast_epi = nofast;
     const int blocks3 = ((M + V3_BM - 1) / V3_BM) * ((Cout + V3_BN - 1) / V3_BN);
     const size_t sh3 = (size_t)8 * 64 * 68 * sizeof(float) > (size_t)2 * V3_STAGE ? (size_t)8 * 64 * 68 * sizeof(float) : (size_t)2 * V3_STAGE;
-    if (wlo0) {
+    static int wpk_on = -1;
+    if (wpk_on < 0) { const char* e = getenv("RLCF_X3_WPK"); wpk_on = e ? atoi(e) : 1; }
+    if (wlo0 && next.wpk && wpk_on && K % 64 == 0 && (size_t)Cout * K < ((size_t)1 << 31)) {       // hi-only W rows, two K tiles per row block
+        g.Wpk = next.wpk; g.ldwpk = K;
+        { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 2>), sh3); if (rc_ != RLCF_OK) return rc_; }
+        gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 2><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
+    } else if (wlo0) {
         { int rc_ = rlcf_func_lds((const void*)(gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 1>), sh3); if (rc_ != RLCF_OK) return rc_; }
         gemm_nt_f16x3_v3i_kernel<false, true, false, 4, 1><<<dim3(blocks3), dim3(512), sh3, st>>>(g);
     } else {
