@@ -165,19 +165,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The PERSISTENT form for f16 outputs (in_proj -> Q/K/V, c_fc + QuickGELU, and — since round 5 — out_proj / c_proj, whose residual add
-// moved into the LayerNorm kernel that follows them: rowops.hip, layernorm_add_fwd).  With K = 768 a 256x256 tile is only 12 K tiles
+// The PERSISTENT form for f16 outputs: the four products of a block in RLCF_PREC_F16.  With K = 768 a 256x256 tile is only 12 K tiles
 // long: launched one workgroup per tile, a third of every tile's time went to the first loads (nothing to compute on), the LDS-parked
-// epilogue and the write burst at the end of every tile round (SQ_VALU_MFMA_BUSY 0.44 of the active cycles against 0.67 at K = 8192:
-// profiles/r5_gemm_f16_counters.txt).  Here one workgroup per CU walks its XCD's tile range and
+// epilogue and the write burst at the end of every tile round (one workgroup per tile, gemm_nt_f16_p8_kernel above: 4.21 ms for the
+// layer's four products against 3.82 here, profiles/r5_notes.md section 1).  Here one workgroup per CU walks its XCD's tile range and
 //   * the DMA ring never drains: the last two K tiles of a tile stage the first 1.75 K tiles of the NEXT tile (buffer_load ... lds
 //     through a per-tile buffer descriptor: scalar base / soffset, one constant 32-bit lane offset per piece, rows beyond M / N read as
-//     zeros by the descriptor's range check — no clamps, no per-piece address arithmetic),
-//   * the epilogue uses no LDS and no barrier: alpha / bias / QuickGELU on the accumulators (bias is a per-lane constant in the 32x32
-//     accumulator layout), a 4x4 lane <-> register transpose inside every quad (two DPP quad_perm exchanges) that leaves each lane 4
-//     consecutive columns of one row, f16 rounding, 8-byte stores (8 lanes = 64 B of a row); the stores drain while the next tile's K
-//     loop runs,
+//     zeros by the descriptor's range check — no clamps, no per-piece address arithmetic), and B_lo of its K tile 1 goes out at the
+//     START of the epilogue, ahead of the stores (PP_KTILE_FIRST);
+//   * the epilogue uses no LDS and no barrier, and no transpose either: the MFMAs run with the operands SWAPPED (W fragment first), so an
+//     accumulator tile is C^T — a lane owns a ROW, and with the two tiles of a wave interleaved at 4-column granularity a register quad
+//     pair is 8 consecutive columns: alpha / bias / QuickGELU, f16 rounding, one 16-byte store;
+//   * MODE 1 / 2 fold the LayerNorms of an image tower into the products (GemmX3Args::ln_*; engine.hip, transformer_forward):
+//     MODE 1 normalises per row in the epilogue (A = the f16 residual stream itself, W carries gamma), MODE 2 adds into the residual
+//     stream in place and leaves per-row partial (sum, sum of squares) for the next LayerNorm's statistics;
 //   * the two wave groups line up for the epilogue (one extra barrier each per tile) so that both run it at the same time.
+// What was measured and dropped on the way (start-time cohorts, deferred stores, an early touch of the residual tile): r5_notes.md.
 template <int EPI, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
             const int lr = wave * 16 + j * 8 + (lane >> 3), c = ((lane & 7) ^ ((lr >> 1) & 7)) * 16;
             va[hf][j] = (unsigned)(((lr >> 6) * 128 + hf * 64 + (lr & 63)) * g.lda) * 2u + c;
             // B half tiles: the two 32-column accumulator tiles of a wave interleave at 4-column granularity (tile j holds columns 8 q + 4 j
-            // + {0..3} of the wave's 64), so that after the epilogue's 4x4 transpose a lane owns 8 CONSECUTIVE columns of a row: 16-byte stores
+            // + {0..3} of the wave's 64), so that in the transposed accumulator (operands swapped) a lane owns 8 CONSECUTIVE columns of a row: 16-byte stores
             vw[hf][j] = (unsigned)(((lr >> 5) * 64 + ((lr & 31) >> 2) * 8 + hf * 4 + (lr & 3)) * g.ldw) * 2u + c;
         }
     auto rsrc_a = [&](int m0_) {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     f32x16 acc[4][2];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 // first K tile of a tile: the first product of every accumulator takes C = 0 (no zero fill, and the accumulators are not live across the
-// tile boundary: the epilogue's outputs and the deferred stores use their registers)
+// tile boundary: the epilogue's outputs use their registers)
 #define PP_MMA0(ib, j)                                                                                                              \
     {                                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                              \
@@ -282,8 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         __builtin_amdgcn_s_setprio(0);                                                                                              \
     }
 // one K tile of the steady state: stages B_lo of K tile kt+1 and the other three half tiles of kt+2, all of THIS tile.  MMA_ = PP_MMA, or
-// PP_MMA0 for K tile 0; H_(n) = a hook in the read section of phase n (unused: deferring the epilogue's stores into the next tile's K tile
-// 0 needs 64 more registers than hipcc finds without spilling — measured, profiles/KERNEL_NOTES.md)
+// PP_MMA0 for K tile 0; H_(n) = a hook in the read section of phase n (unused since the deferred-store experiment: r5_notes.md section 1)
 #define PP_KTILE_X(kt, par, MMA_, H_)                                                                                               \
     {                                                                                                                               \
         P8_LDB(0, par) P8_LDA(0, par)                                                                                               \

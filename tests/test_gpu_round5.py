@@ -270,3 +270,27 @@ def test_resnet_convolutions_on_the_fp16_grid_keep_the_batchnorm_scale_in_the_ep
     assert torch.equal(feats["f32"], feats["f32_folded"])              # weights off the grid: the folded form, bit for bit
     d = (feats["grid"] - feats["folded"]).abs().max().item()
     assert 0 < d < 2e-5, d                                             # (unit-norm features; the two forms round differently)
+
+
+def test_two_pass_packed_weight_rows_at_vit_l14_shapes(monkeypatch):
+    """The same bit-equality at the other tower geometry the BASELINE configs use (ViT-L/14: K = 1024 / 4096, N = 3072 / 1024 / 4096, 257
+    tokens per view — ragged row tiles), image features of 48 views: forced three passes against two passes on packed hi-only W rows."""
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine
+    g, rg = synth.GEOMETRIES["ViT-L/14"], synth.GEOMETRIES["tiny-r"]
+    sd = synth.to_fp16_grid(synth.make_state_dict(g, 11, device=DEV))
+    rsd = synth.make_state_dict(rg, 23, device=DEV)
+    views = synth.make_views(4000, 48, g.image_resolution, device=DEV)
+    feats = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RLCF_X3_WLO0", raising=False)
+        else:
+            monkeypatch.setenv("RLCF_X3_WLO0", env)
+        eng = Engine(g, rg, 48, 16, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, sd)
+        eng.load_state_dict(L.REWARD, rsd)
+        eng.finalize()
+        feats.append(eng.encode_image(L.STUDENT, views).clone())
+        eng.close()
+    assert torch.equal(feats[0], feats[1])
