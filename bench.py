@@ -138,7 +138,7 @@ def cpu_baseline(ssd, rsd, geo, n_cls, n_ctx=4, timed=3, budget_s=300.0):
             "thread_sweep_seconds_at_64_classes": {str(k): round(v, 3) for k, v in sweep.items()}}
 
 
-def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, selection_p, lr, n_one=48, n_batched=96, ipp=32):
+def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, selection_p, lr, n_one=48, n_batched=96, ipp=32, one_only=False):
     """The DROP-IN path: what a maintainer runs after INTEGRATION.md section A — the reference's harness loop
     (TPT/tpt_cls_rl.py:219-279) through this package's mirror: rlcf_amd.tpt_cls_rl.test_time_adapt_eval, model / reward objects from
     get_coop / get_reward_model, views from rlcf_amd.datautils.AugMixAugmenter (rlcf_make_views on the device from ONE decoded uint8
@@ -197,9 +197,10 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     run(4, 1, staged)                                         # warm-up: engine build, class bank, workspaces
     out["images_per_s_one_image_per_pass_staged_views"] = run(n_one, 1, staged)
     out["images_per_s_one_image_per_pass_views_in_loop"] = run(n_one, 1, None)
-    run(ipp, ipp, staged)                                     # (batched workspaces)
-    out[f"images_per_s_{ipp}_images_per_pass_staged_views"] = run(n_batched, ipp, staged)
-    out[f"images_per_s_{ipp}_images_per_pass_views_in_loop"] = run(n_batched, ipp, None)
+    if not one_only:
+        run(ipp, ipp, staged)                                     # (batched workspaces)
+        out[f"images_per_s_{ipp}_images_per_pass_staged_views"] = run(n_batched, ipp, staged)
+        out[f"images_per_s_{ipp}_images_per_pass_views_in_loop"] = run(n_batched, ipp, None)
     t0 = time.perf_counter()
     for ph in photos:
         aug.views(ph)
@@ -685,6 +686,12 @@ def main():
             eng.close()                                      # (the mirror builds its own engine: free this one's workspace first)
             eng = None
             out["harness"] = harness_leg(dev, student_arch, a.reward_arch, ssd, rsd, a.classes, a.views, wl["selection_p"], wl["lr"])
+            if a.weights == "fp32":
+                # the same loop on checkpoint-grid weights (see secondary_checkpoint_grid_weights): one image per pass only
+                hg = harness_leg(dev, student_arch, a.reward_arch, synth.to_fp16_grid(ssd), synth.to_fp16_grid(rsd), a.classes, a.views,
+                                 wl["selection_p"], wl["lr"], one_only=True)
+                hg["what"] = "the harness leg above with the GEMM weights on the fp16 grid (as a released checkpoint holds them): one image per pass"
+                out["harness_checkpoint_grid_weights"] = hg
             log("harness leg done")
         if world == 1 and not a.no_cpu_baseline and not use_dist:
             # the reference's CPU path runs BASELINE configs[0] (ViT-B/16, N = 8): timed for configs 0 / 1; the ViT-L/14 and RN50x64
