@@ -173,6 +173,11 @@ int rlcf_attention_bwd_flash(const float* qkv, const float* out, const float* ls
  * device).  The op-level call reads the sequence descriptors back once to find the extent of dout (engine calls do not). */
 int rlcf_attention_bwd_flash_prec(const float* qkv, const float* out, const float* lse, const float* dout, const rlcf_seq* seqs, int n_seq,
                                   int max_q_len, int width, int causal, float* dqkv, int precision, rlcf_stream stream);
+/* (ABI version 12) Stand-alone conveniences of the harness: avg_entropy (TPT/tpt_cls_rl.py:38-44: entropy of the views' mean softmax; inside a
+ * tuning step the regulariser and its gradient come from rlcf_reward_loss) and accuracy for topk = (1, 5) (TPT/utils/tools.py:84-98):
+ * out[0] / out[1] = percentage of rows whose target is in the top 1 / top 5; target int64 [B]; top5_scratch int32 [B, 5]. */
+int rlcf_avg_entropy(const float* logits, int n, int C, float* out, rlcf_stream stream);
+int rlcf_accuracy(const float* logits, const int64_t* target, int B, int C, int32_t* top5_scratch, float* out, rlcf_stream stream);
 int rlcf_entropy_select(const float* logits, int n, int C, int n_sel, float* entropy,
                         int32_t* idx, rlcf_stream stream);
 

@@ -129,6 +129,8 @@ SIGNATURES = {
     "rlcf_engine_momentum_update_visual": (I, [P, P, D, D, I, P]),
     "rlcf_engine_ln_param_count": (I, [P]),
     "rlcf_engine_f16_grid_weights": (I, [P, I, P]),
+    "rlcf_avg_entropy": (I, [P, I, I, P, P]),
+    "rlcf_accuracy": (I, [P, P, I, I, P, P, P]),
     "rlcf_engine_set_bn_prior_strength": (I, [P, I]),
     "rlcf_engine_bn_stats_count": (I, [P]),
     "rlcf_engine_encode_image_bn": (I, [P, P, I, P, P]),

@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 11; }   // 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 12; }   // 12: rlcf_avg_entropy, rlcf_accuracy (the harness mirror's conveniences as kernels); 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -530,6 +530,10 @@ static void resnet_norm_counts(const rlcf_clip_cfg& c, int* tuned, int* stats) {
         }
     }
     *tuned = p; *stats = s;
+}
+int rlcf_avg_entropy(const float* logits, int n, int C, float* out, rlcf_stream stream) { return launch_avg_entropy(logits, n, C, out, (hipStream_t)stream); }
+int rlcf_accuracy(const float* logits, const int64_t* target, int B, int C, int32_t* top5_scratch, float* out, rlcf_stream stream) {
+    return launch_accuracy(logits, target, B, C, top5_scratch, out, (hipStream_t)stream);
 }
 int rlcf_engine_f16_grid_weights(rlcf_engine* e, int which, int* others) {
     RLCF_ARG_CHECK(e && (which == RLCF_STUDENT || which == RLCF_REWARD || (which >= 0 && which < (int)(sizeof(e->model) / sizeof(e->model[0])))));

@@ -65,6 +65,8 @@ int launch_reward_loss(const float* logits, int ld_logits, const int32_t* sel, i
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
                  float b2, float eps, float wd, hipStream_t st, const int32_t* skip = nullptr, int64_t per_group = 0);
 int launch_grad_nonfinite(const float* g, int64_t per_group, int groups, int32_t* flag, hipStream_t st, bool accumulate = false);   // accumulate: OR into flags already set (a second gradient buffer of the same optimizer)
+int launch_avg_entropy(const float* logits, int n, int C, float* out, hipStream_t st);
+int launch_accuracy(const float* logits, const int64_t* target, int B, int C, int32_t* top5_scratch, float* out, hipStream_t st);
 int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st);
 int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st);
 int launch_build_sparse_layout(const int32_t* cls, int groups, int n_e, const int32_t* class_start, const int32_t* class_len,

@@ -456,3 +456,68 @@ int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st) {
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
+
+
+// ---- stand-alone conveniences of the harness mirror (round 5: they were torch expressions) ----------------------------------------
+// avg_entropy (TPT/tpt_cls_rl.py:38-44): H of the mean over the n views of softmax(logits): logp = x - lse(x) per row,
+// avg_c = lse_n(logp[n, c]) - log n (clamped at the smallest float, as torch.clamp(min = finfo.min)), out = -sum_c avg_c exp(avg_c).
+// One workgroup; row log-sum-exps first (LDS, n <= 4096), then the classes.
+__global__ __launch_bounds__(TTA_THREADS) void avg_entropy_kernel(const float* __restrict__ x, int n, int C, float* __restrict__ out) {
+    extern __shared__ float lse[];                    // [n]
+    __shared__ float red[TTA_THREADS / 64];
+    for (int r = 0; r < n; ++r) {
+        const float* row = x + (size_t)r * C;
+        float m = -INFINITY;
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) m = fmaxf(m, row[c]);
+        m = block_max(m, red);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) sum += expf(row[c] - m);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) lse[r] = m + logf(sum);
+        __syncthreads();
+    }
+    float acc = 0.f;
+    const float logn = logf((float)n);
+    for (int c = threadIdx.x; c < C; c += TTA_THREADS) {
+        float m = -INFINITY;
+        for (int r = 0; r < n; ++r) m = fmaxf(m, x[(size_t)r * C + c] - lse[r]);
+        float sum = 0.f;
+        for (int r = 0; r < n; ++r) sum += expf(x[(size_t)r * C + c] - lse[r] - m);
+        float a = m + logf(sum) - logn;
+        a = fmaxf(a, -3.402823466e+38f);          // (torch.clamp(min = finfo(float32).min))
+        acc -= a * expf(a);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = acc;
+}
+int launch_avg_entropy(const float* logits, int n, int C, float* out, hipStream_t st) {
+    RLCF_ARG_CHECK(logits && out && n > 0 && n <= 4096 && C > 0);
+    avg_entropy_kernel<<<dim3(1), dim3(TTA_THREADS), (size_t)n * sizeof(float), st>>>(logits, n, C, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+// accuracy (TPT/utils/tools.py:84-98) for topk = (1, 5): out[0] / out[1] = 100 / B * #(target in the top 1 / top 5 of its row), from the
+// rows' top-5 indices (top5_kernel: ties go to the lower index)
+__global__ void accuracy_kernel(const int32_t* __restrict__ top5, const int64_t* __restrict__ target, int B, int C, float* __restrict__ out) {
+    __shared__ int h1, h5;
+    if (threadIdx.x == 0) { h1 = 0; h5 = 0; }
+    __syncthreads();
+    const int nk = C < 5 ? C : 5;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int t = (int)target[b];
+        int a1 = top5[b * 5] == t, a5 = 0;
+        for (int k = 0; k < nk; ++k) a5 |= (top5[b * 5 + k] == t);
+        if (a1) atomicAdd(&h1, 1);
+        if (a5) atomicAdd(&h5, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = 100.0f * h1 / B; out[1] = 100.0f * h5 / B; }
+}
+int launch_accuracy(const float* logits, const int64_t* target, int B, int C, int32_t* top5_scratch, float* out, hipStream_t st) {
+    RLCF_ARG_CHECK(logits && target && top5_scratch && out && B > 0 && C > 0);
+    top5_kernel<<<dim3(B), dim3(TTA_THREADS), 0, st>>>(logits, C, top5_scratch);
+    RLCF_LAUNCH_CHECK();
+    accuracy_kernel<<<dim3(1), dim3(256), 0, st>>>(top5_scratch, target, B, C, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}

@@ -28,8 +28,14 @@ def select_confident_samples(logits, top):
 
 
 def avg_entropy(outputs):
-    """TPT/tpt_cls_rl.py:38-44 (stand-alone convenience on device tensors; inside the tuning step the
-    regulariser and its gradient come from the fused rlcf_reward_loss kernel)."""
+    """TPT/tpt_cls_rl.py:38-44 (stand-alone convenience on device tensors; inside the tuning step the regulariser and its gradient
+    come from the fused rlcf_reward_loss kernel).  One launch of avg_entropy_kernel (rlcf_avg_entropy); tensors with autograd history
+    or off the GPU take the reference's torch expression."""
+    if outputs.is_cuda and not outputs.requires_grad and outputs.dim() == 2 and outputs.shape[0] <= 4096:
+        x = outputs.detach().float().contiguous()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        L.check(L.lib().rlcf_avg_entropy(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), torch.cuda.current_stream().cuda_stream), "avg_entropy")
+        return out
     logits = outputs - outputs.logsumexp(dim=-1, keepdim=True)
     avg_logits = logits.logsumexp(dim=0) - math.log(logits.shape[0])
     avg_logits = torch.clamp(avg_logits, min=torch.finfo(avg_logits.dtype).min)
@@ -109,7 +115,17 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
 
 
 def accuracy(output, target, topk=(1,)):
-    """TPT/utils/tools.py:84-98."""
+    """TPT/utils/tools.py:84-98.  topk drawn from {1, 5} on device tensors: top5_kernel + accuracy_kernel (rlcf_accuracy; ties go to the
+    lower class index); anything else takes the reference's torch expression."""
+    if output.is_cuda and output.dim() == 2 and target.is_cuda and set(topk) <= {1, 5} and not output.requires_grad:
+        x = output.detach().float().contiguous()
+        t = target.detach().to(torch.int64).contiguous()
+        B, C = x.shape
+        scratch = torch.empty(B, 5, dtype=torch.int32, device=x.device)
+        res = torch.empty(2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().rlcf_accuracy(x.data_ptr(), t.data_ptr(), B, C, scratch.data_ptr(), res.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                "accuracy")
+        return [res[0:1] if k == 1 else res[1:2] for k in topk]
     with torch.no_grad():
         maxk = max(topk)
         batch_size = target.size(0)

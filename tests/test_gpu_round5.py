@@ -294,3 +294,31 @@ def test_two_pass_packed_weight_rows_at_vit_l14_shapes(monkeypatch):
         feats.append(eng.encode_image(L.STUDENT, views).clone())
         eng.close()
     assert torch.equal(feats[0], feats[1])
+
+
+def test_harness_conveniences_run_as_kernels_and_match_the_reference_expressions():
+    """rlcf_amd.tpt_cls_rl.avg_entropy / accuracy on device tensors are single launches (rlcf_avg_entropy, rlcf_accuracy) since round 5:
+    against the reference's torch expressions (TPT/tpt_cls_rl.py:38-44, TPT/utils/tools.py:84-98), on logits at CLIP's scale."""
+    import math
+    from rlcf_amd import tpt_cls_rl
+    torch.manual_seed(3)
+    x = (torch.randn(64, 1000, device=DEV) * 3.0 + torch.randn(1, 1000, device=DEV) * 5.0)
+    logp = x.double() - x.double().logsumexp(-1, keepdim=True)
+    avg = logp.logsumexp(0) - math.log(64)
+    ref = -(avg * avg.exp()).sum()
+    got = tpt_cls_rl.avg_entropy(x)
+    assert got.shape == () and abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    one = tpt_cls_rl.avg_entropy(x[:1])                                   # one view: the row's own entropy
+    p1 = logp[:1].exp()
+    assert abs(one.item() - float(-(p1 * logp[:1]).sum())) < 1e-5
+    # accuracy: batch of rows, topk (1, 5), (1,), (5,)
+    tgt = torch.randint(0, 1000, (64,), device=DEV)
+    tgt[:10] = x[:10].argmax(-1)                                          # some top-1 hits
+    tgt[10:20] = x[10:20].topk(5, -1).indices[:, 3]                       # some top-5-only hits
+    _, pred = x.topk(5, 1, True, True)
+    corr = pred.t().eq(tgt.view(1, -1).expand(5, -1))
+    ref1, ref5 = corr[:1].float().sum() * (100.0 / 64), corr[:5].float().sum() * (100.0 / 64)
+    a1, a5 = tpt_cls_rl.accuracy(x, tgt, topk=(1, 5))
+    assert a1.shape == (1,) and abs(a1.item() - ref1.item()) < 1e-4 and abs(a5.item() - ref5.item()) < 1e-4
+    assert abs(tpt_cls_rl.accuracy(x, tgt, topk=(5,))[0].item() - ref5.item()) < 1e-4
+    assert abs(tpt_cls_rl.accuracy(x[:1], tgt[:1])[0].item() - 100.0) < 1e-4
