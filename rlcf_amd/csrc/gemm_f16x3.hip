@@ -1792,16 +1792,17 @@ int launch_gemm_f16x3_conv3x3(const void* act_pairs, int n, int H, int W, int Ci
 
 // does every element of w * scale sit on the f16 grid (its lo half is zero)?  flag[0] |= 1 otherwise
 __global__ void f16_grid_check_kernel(const float* __restrict__ w, int64_t n, float scale, int* __restrict__ flag) {
+    if (*(volatile int*)flag) return;                      // (another workgroup has found an off-grid element already)
     int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n && !bad; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = w[i] * scale;
         if ((float)(_Float16)v != v) bad = 1;
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0 && *(volatile int*)flag == 0) atomicOr(flag, 1);
 }
 int launch_f16_grid_check(const float* w, int64_t n, float scale, int* flag, hipStream_t st) {
     RLCF_ARG_CHECK(w && flag && n > 0);
-    f16_grid_check_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st>>>(w, n, scale, flag);
+    f16_grid_check_kernel<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st>>>(w, n, scale, flag);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
