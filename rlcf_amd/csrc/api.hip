@@ -511,6 +511,7 @@ int rlcf_engine_momentum_update_visual(rlcf_engine* e, const float* current, dou
     if (apply) {         // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy and its derived forms follow
         RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         e->vw_dirty = false;
+        e->vw_init_is_ckpt = false;      // (an averaged reset state is off the fp16 grid: three MFMA passes from here on)
         return engine_visual_refresh(e, (hipStream_t)stream);
     }
     return RLCF_OK;
@@ -631,7 +632,8 @@ int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
         const size_t vb = e->vw_count * sizeof(float);
         for (DevBuf* d : {&e->vw, &e->vw_init, &e->vw_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->vw_clip.p, vb, hipMemcpyDeviceToDevice, st));
         e->vw_dirty = false;
-        return engine_visual_refresh(e, st);
+        e->vw_init_is_ckpt = true;
+        return engine_visual_refresh(e, st, true);
     }
     return RLCF_OK;
 }

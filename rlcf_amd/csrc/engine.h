@@ -124,7 +124,7 @@ struct ClipModel {
     const float* vproj = nullptr;          // [Wv, D] as stored (backward operand)
     float logit_scale_exp = 1.f;
     int Kp = 0, tokens = 0;
-    struct SplitW { void *hi, *lo; float inv_scale; bool lo_zero = false; void* hi_only = nullptr; /* lo_zero: the hi halves alone as a plain f16 matrix */ };   // W * 2^s = hi + lo; inv_scale = 2^-s; lo_zero: W 2^s sits on the f16 grid (two MFMA passes suffice)
+    struct SplitW { void *hi, *lo; float inv_scale; bool lo_zero = false; void* hi_only = nullptr; bool lo_zero_ckpt = false; /* lo_zero of the checkpoint's values (hi_only is their copy) */ /* lo_zero: the hi halves alone as a plain f16 matrix */ };   // W * 2^s = hi + lo; inv_scale = 2^-s; lo_zero: W 2^s sits on the f16 grid (two MFMA passes suffice)
     std::unordered_map<const float*, SplitW> split_of;                    // f32 weight -> split-f16 copy (F16X3 / F16 modes)
     std::unordered_map<const float*, SplitW> f16_of;                      // f32 weight -> plain f16 copy (.hi; RLCF_PREC_F16 mode only)
     // RLCF_PREC_F16 image towers: in_proj / c_fc weight with the preceding LayerNorm folded in (engine.hip make_lnfold): w16 = f16 copy of
@@ -136,7 +136,7 @@ struct ClipModel {
 // full image-encoder tuning (CLIPCLS_TTA only_norm=False): one entry per non-LayerNorm visual tensor of the flat buffer, and the
 // derived copies (padded / transposed / split-f16) that have to follow the live weights after an optimizer step or a reset
 struct VwSlot { size_t off, numel; };
-struct VwRefresh { int kind; const float* src; float* dst; size_t rows, cols; void *hi, *lo; float scale; int il; };
+struct VwRefresh { int kind; const float* src; float* dst; size_t rows, cols; void *hi, *lo; float scale; int il; ClipModel::SplitW* sw = nullptr; };
 enum { VW_PAD = 0, VW_TRANSPOSE = 1, VW_SPLIT = 2 };
 
 struct rlcf_engine {
@@ -183,6 +183,7 @@ struct rlcf_engine {
     DevBuf vw, vw_init, vw_grad, vw_m, vw_v, vw_clip, vw_mom;
     size_t vw_count = 0;
     bool vw_dirty = false;           // live weights differ from the reset state
+    bool vw_init_is_ckpt = true;     // the reset state (vw_init) still holds the checkpoint's values (no EMA has been applied to it)
     std::vector<VwSlot> vw_slots;
     std::vector<VwRefresh> vw_refresh;
     // text-encoder tuning (retrieval text -> image, CLIPRet_TTA only_visual=False: every non-visual parameter, custom_models.py:139-147):
@@ -300,7 +301,7 @@ int engine_text_enable(rlcf_engine* e, hipStream_t st);
 int engine_text_reset(rlcf_engine* e, hipStream_t st, bool force);
 int engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, hipStream_t st);
 int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st);
-int engine_visual_refresh(rlcf_engine* e, hipStream_t st);
+int engine_visual_refresh(rlcf_engine* e, hipStream_t st, bool at_checkpoint = false);   // at_checkpoint: the live weights ARE the checkpoint's (reset of a pristine initial state)
 int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
                         hipStream_t st);
 int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,

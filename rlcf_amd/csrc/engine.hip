@@ -291,7 +291,7 @@ static int make_split(rlcf_engine* e, ClipModel& m, const float* w, size_t numel
         }
     }
     ClipModel::SplitW sw{hi.p, lo, 1.0f / scale};
-    sw.lo_zero = lo_zero;
+    sw.lo_zero = lo_zero; sw.lo_zero_ckpt = lo_zero;
     if (lo_zero) {                                         // the hi halves alone, row-major: what the packed-W form of the 256x256 kernel stages
         DevBuf ho;
         TRY(ho.ensure(numel * 2 + 256));
@@ -568,10 +568,11 @@ int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
     e->vw_refresh.clear();
     auto add_split = [&](const float* w, size_t numel) {
         auto it = m.split_of.find(w);
-        if (it != m.split_of.end()) it->second.lo_zero = false;          // (a TUNED weight leaves the fp16 grid at its first step: three passes)
+        // a TUNED weight leaves the fp16 grid at its first optimizer step (three passes from then on) and is back on it after every reset
+        // to the checkpoint's values (refresh_derived: lo_zero follows; hi_only stays the checkpoint's copy)
         if (it != m.split_of.end())
             e->vw_refresh.push_back(VwRefresh{VW_SPLIT, w, nullptr, numel, 0, it->second.hi, it->second.lo, 1.0f / it->second.inv_scale,
-                                              it->second.lo == lo_of(it->second.hi)});
+                                              it->second.lo == lo_of(it->second.hi), &it->second});
     };
     auto add_T = [&](const float* w, const float* wT, size_t rows, size_t cols) {
         if (!wT) return;
@@ -587,11 +588,12 @@ int engine_visual_enable(rlcf_engine* e, hipStream_t st) {
     }
     e->vw_count = total;
     e->vw_dirty = false;
+    e->vw_init_is_ckpt = true;
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     return RLCF_OK;
 }
 
-static int refresh_derived(const std::vector<VwRefresh>& list, int Kp, hipStream_t st) {
+static int refresh_derived(const std::vector<VwRefresh>& list, int Kp, hipStream_t st, bool at_checkpoint = false) {
     for (const VwRefresh& r : list) {
         if (r.kind == VW_PAD) {
             pad_rows_kernel<<<dim3(1024), dim3(256), 0, st>>>(r.src, r.dst, (int)r.rows, (int)r.cols, Kp);
@@ -600,13 +602,14 @@ static int refresh_derived(const std::vector<VwRefresh>& list, int Kp, hipStream
             TRY(launch_transpose(r.src, r.dst, (int)r.rows, (int)r.cols, st));
         } else {
             TRY(launch_split_f16x2(r.src, r.hi, r.lo, (int64_t)r.rows, st, r.scale, r.il));
+            if (r.sw) r.sw->lo_zero = at_checkpoint && r.sw->lo_zero_ckpt;      // (host-side launch choice: in stream order with the split above)
         }
     }
     return RLCF_OK;
 }
-int engine_visual_refresh(rlcf_engine* e, hipStream_t st) {
+int engine_visual_refresh(rlcf_engine* e, hipStream_t st, bool at_checkpoint) {
     if (is_resnet(e->model[RLCF_STUDENT].cfg)) return rn_visual_refresh(e, st);
-    return refresh_derived(e->vw_refresh, e->model[RLCF_STUDENT].Kp, st);
+    return refresh_derived(e->vw_refresh, e->model[RLCF_STUDENT].Kp, st, at_checkpoint);
 }
 
 // Linear weight gradient dW[N,K] = dY[T,N]^T X[T,K] (+ db[N] += column sums of dY): both operands are transposed to K-major
@@ -2108,7 +2111,7 @@ static int visual_reset(rlcf_engine* e, hipStream_t st) {      // visual.load_st
     if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
     RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
     e->vw_dirty = false;
-    return engine_visual_refresh(e, st);
+    return engine_visual_refresh(e, st, e->vw_init_is_ckpt);
 }
 static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
     ClipModel& s = e->model[RLCF_STUDENT];

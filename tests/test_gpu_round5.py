@@ -2,6 +2,7 @@
 rlcf_amd/csrc/gemm_f16.hip) against float64 products of the SAME f16 operands — what is checked is the kernel (tiling, DMA ring
 ordering, phase schedule, epilogues), not the f16 rounding of the inputs, which is the mode's labelled arithmetic
 (TPT/tpt_cls_rl.py:52: torch.cuda.amp.autocast)."""
+import ctypes
 import os
 
 import pytest
@@ -214,8 +215,9 @@ def test_weights_on_the_fp16_grid_run_two_exact_passes(monkeypatch):
 @pytest.mark.parametrize("path", ["ln", "visual"])
 def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
     """The same exactness through the image-encoder tuning paths at small geometry (the 128x128 kernels): LayerNorm tuning keeps every GEMM
-    weight frozen (two passes throughout); every-parameter tuning moves the weights off the grid at its first step, so a tuned weight's
-    products must run three passes from the moment the path is enabled — both must give the numbers of the forced three-pass build."""
+    weight frozen (two passes throughout); every-parameter tuning moves the weights off the grid at its first optimizer step (three passes
+    for the second step and the final inference) and every sample's reset puts the checkpoint's values back (two passes for the 64-view
+    forward, the selected views' forward and the backward's transposed products) — both must give the numbers of the forced three-pass build."""
     from rlcf_amd import synth
     from rlcf_amd.engine import Engine, TTAConfig
     sg, rg = synth.GEOMETRIES["small"], synth.GEOMETRIES["small"]
@@ -236,10 +238,31 @@ def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
         eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
         cfg = TTAConfig(selection_p=0.25, tta_steps=2, lr=1e-4)
         o = eng.tta_sample_ln(views, cfg) if path == "ln" else eng.tta_sample_visual(views, cfg)
-        outs.append({k: o[k].clone() for k in ("final_logits", "ln_grad", "ln_after")})
+        keys = ("final_logits", "ln_grad", "ln_after") + (("vis_grad", "vis_after") if path == "visual" else ())
+        rec = {k: o[k].clone() for k in keys}
+        if path == "visual":
+            # a second sample starts from the reset: same numbers again, and the weights are back on the grid afterwards
+            o2 = eng.tta_sample_visual(views, cfg)
+            for k in keys:
+                assert torch.equal(o2[k], rec[k]), k
+            others = ctypes.c_int(0)
+            rec["on_grid_after_reset"] = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+            # an averaged reset state (custom_clip.py:460-475) is off the grid: its products run three passes from then on
+            eng.momentum_update_visual(o["vis_after"], 0.5, 1.0, True)
+            on_ema = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+            o3 = eng.tta_sample_visual(views, cfg)
+            on_ema2 = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+            rec["ema_final_logits"], rec["ema_vis_grad"] = o3["final_logits"].clone(), o3["vis_grad"].clone()
+            assert on_ema == on_ema2 and on_ema < max(rec["on_grid_after_reset"], 1) or env == "0", (on_ema, on_ema2, rec["on_grid_after_reset"])
+            eng.reset_visual_state()
+            assert int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others))) == rec["on_grid_after_reset"]
+        outs.append(rec)
         eng.close()
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
+        if k == "on_grid_after_reset":
+            assert outs[0][k] == 0 and outs[1][k] > 20, (outs[0][k], outs[1][k])      # 2 blocks x 4 weights + their transposes + text tower
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]), k
 
 
 def test_resnet_convolutions_on_the_fp16_grid_keep_the_batchnorm_scale_in_the_epilogue(monkeypatch):

@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 geo = synth.GEOMETRIES[arch]
 rgeo = synth.GEOMETRIES[os.environ.get("REWARD_ARCH", arch)]             # (a ResNet ARCH: BatchNorm tuning, row a-R)
 ssd, rsd = synth.make_state_dict(geo, 11, device=dev), synth.make_state_dict(rgeo, 23, device=dev)
+if os.environ.get("GRID") == "1":                                          # GEMM weights on the fp16 grid, as a released checkpoint holds them
+    ssd, rsd = synth.to_fp16_grid(ssd), synth.to_fp16_grid(rsd)
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # test images per tower pass (rlcf_tta_batch_ln)
 eng = Engine(geo, rgeo, 64 * B, n_cls, L.PREC_F16X3)
 eng.load_state_dict(L.STUDENT, ssd); eng.load_state_dict(L.REWARD, rsd); eng.finalize()
