@@ -274,7 +274,7 @@ int rn_forward_train(rlcf_engine* e, ClipModel& m, const float* images, int n, f
 int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, float* dfeat, float* bn_grad, hipStream_t st, float* vgrad = nullptr);
 int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full = false);
 int engine_rn_visual_enable(rlcf_engine* e, hipStream_t st);
-int rn_visual_refresh(rlcf_engine* e, hipStream_t st);
+int rn_visual_refresh(rlcf_engine* e, hipStream_t st, bool at_checkpoint = false);
 // dW[N, K] = dY[T, N]^T X[T, K] (+ db[N] += column sums of dY) through the NT GEMM of the engine's precision (engine.hip)
 int engine_wgrad(rlcf_engine* e, const float* dY, int ldy, int N, const float* X, int ldx, int K, int T, float* dW, float* db, hipStream_t st);
 // engine.hip services used by resnet.hip

@@ -608,7 +608,7 @@ static int refresh_derived(const std::vector<VwRefresh>& list, int Kp, hipStream
     return RLCF_OK;
 }
 int engine_visual_refresh(rlcf_engine* e, hipStream_t st, bool at_checkpoint) {
-    if (is_resnet(e->model[RLCF_STUDENT].cfg)) return rn_visual_refresh(e, st);
+    if (is_resnet(e->model[RLCF_STUDENT].cfg)) return rn_visual_refresh(e, st, at_checkpoint);
     return refresh_derived(e->vw_refresh, e->model[RLCF_STUDENT].Kp, st, at_checkpoint);
 }
 
@@ -2001,7 +2001,7 @@ static int rn_visual_reset(rlcf_engine* e, hipStream_t st) {   // visual.load_st
     if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
     RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
     e->vw_dirty = false;
-    return rn_visual_refresh(e, st);
+    return rn_visual_refresh(e, st, e->vw_init_is_ckpt);
 }
 // full: every visual parameter is tuned (CLIPCLS_TTA(only_norm=False) on a ModifiedResNet — the parser defaults of tune_cls_rl.py,
 // TPT/params.py:23,73): convolution / downsample.1 / attention-pool gradients into e->vw_grad, a second AdamW launch, the derived

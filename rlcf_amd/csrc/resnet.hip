@@ -1286,14 +1286,16 @@ int rn_backward_bn(rlcf_engine* e, ClipModel& m, int n, const float* feats, floa
 // launches and reset() two copies, as for a VisionTransformer student (engine_visual_enable).  After every optimizer step / reset the
 // derived forms the passes read (GEMM-layout weights, flipped / transposed dX operands, k|v concatenations, split-f16 pairs) are
 // rebuilt from the live tensors: rn_visual_refresh.
-static int resplit(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st) {
+static int resplit(rlcf_engine* e, ClipModel& m, const float* w, size_t numel, hipStream_t st, bool at_checkpoint) {
     auto it = m.split_of.find(w);
     if (it == m.split_of.end()) return RLCF_OK;
-    it->second.lo_zero = false;            // (a weight that is re-split is a TUNED weight: off the fp16 grid after its first step)
+    // a weight that is re-split is a TUNED weight: off the fp16 grid after its first step, back on it when a reset has put the checkpoint's
+    // values back (hi_only is still their copy)
+    it->second.lo_zero = at_checkpoint && it->second.lo_zero_ckpt;
     const ClipModel::SplitW& sp = it->second;
     return launch_split_f16x2(w, sp.hi, sp.lo, (int64_t)numel, st, 1.0f / sp.inv_scale, sp.lo == (void*)((char*)sp.hi + 64) ? 1 : 0);
 }
-int rn_visual_refresh(rlcf_engine* e, hipStream_t st) {
+int rn_visual_refresh(rlcf_engine* e, hipStream_t st, bool at_checkpoint) {
     ClipModel& m = e->model[RLCF_STUDENT];
     ResNetW& r = m.rn;
     if (!r.full_enabled) return RLCF_OK;
@@ -1301,11 +1303,11 @@ int rn_visual_refresh(rlcf_engine* e, hipStream_t st) {
         const int cout = u.raw.cout, cin = u.raw.cin, kk = u.raw.k * u.raw.k;
         conv_permute_kernel<<<dim3(cout), dim3(256), 0, st>>>(u.w_live, (float*)u.raw.w, cin, kk, u.raw.Kp);
         RLCF_LAUNCH_CHECK();
-        TRY(resplit(e, m, u.raw.w, (size_t)cout * u.raw.Kp, st));
+        TRY(resplit(e, m, u.raw.w, (size_t)cout * u.raw.Kp, st, at_checkpoint));
         if (u.wT_buf) {
             if (u.raw.k == 1) TRY(launch_transpose(u.w_live, u.wT_buf, cout, cin, st));
             else { conv_flip_kernel<<<dim3(cin), dim3(256), 0, st>>>(u.w_live, u.wT_buf, cin, cout, u.KpT); RLCF_LAUNCH_CHECK(); }
-            TRY(resplit(e, m, u.wT, (size_t)cin * u.KpT, st));
+            TRY(resplit(e, m, u.wT, (size_t)cin * u.KpT, st, at_checkpoint));
         }
     }
     const size_t E = r.E, D = m.cfg.embed_dim;
@@ -1314,15 +1316,15 @@ int rn_visual_refresh(rlcf_engine* e, hipStream_t st) {
     RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_w_buf + E * E, vw + r.vofs_pool[5], E * E * sizeof(float), hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_b_buf, vw + r.vofs_pool[2], E * sizeof(float), hipMemcpyDeviceToDevice, st));
     RLCF_HIP_CHECK(hipMemcpyAsync(r.kv_b_buf + E, vw + r.vofs_pool[6], E * sizeof(float), hipMemcpyDeviceToDevice, st));
-    TRY(resplit(e, m, r.kv_w, 2 * E * E, st));
-    TRY(resplit(e, m, r.q_w, E * E, st));
-    TRY(resplit(e, m, r.c_w, D * E, st));
+    TRY(resplit(e, m, r.kv_w, 2 * E * E, st, at_checkpoint));
+    TRY(resplit(e, m, r.q_w, E * E, st, at_checkpoint));
+    TRY(resplit(e, m, r.c_w, D * E, st, at_checkpoint));
     TRY(launch_transpose(r.q_w, r.q_wT_buf, (int)E, (int)E, st));
     TRY(launch_transpose(r.kv_w, r.kv_wT_buf, (int)(2 * E), (int)E, st));
     TRY(launch_transpose(r.c_w, r.c_wT_buf, (int)D, (int)E, st));
-    TRY(resplit(e, m, r.q_wT, E * E, st));
-    TRY(resplit(e, m, r.kv_wT, 2 * E * E, st));
-    TRY(resplit(e, m, r.c_wT, D * E, st));
+    TRY(resplit(e, m, r.q_wT, E * E, st, at_checkpoint));
+    TRY(resplit(e, m, r.kv_wT, 2 * E * E, st, at_checkpoint));
+    TRY(resplit(e, m, r.c_wT, D * E, st, at_checkpoint));
     return RLCF_OK;
 }
 
@@ -1384,6 +1386,7 @@ int engine_rn_visual_enable(rlcf_engine* e, hipStream_t st) {
     e->vw_count = total;
     e->vw_dirty = false;
     r.full_enabled = true;
+    e->vw_init_is_ckpt = true;
     RLCF_HIP_CHECK(hipStreamSynchronize(st));
     return RLCF_OK;
 }

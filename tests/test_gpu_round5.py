@@ -265,6 +265,54 @@ def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
             assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("student,reward,n_views,n_cls", [("tiny-rn", "tiny-r64", 32, 40), ("RN50", "ViT-B/32", 16, 64)])
+def test_fp16_grid_weights_through_resnet_every_parameter_tuning(monkeypatch, student, reward, n_views, n_cls):
+    """Every-parameter tuning of a ModifiedResNet student (the parser defaults of TPT/tune_cls_rl.py) on checkpoint-grid weights: the train-form
+    convolutions read the stored weights (on the grid), each sample's reset puts them back, so everything up to the optimizer step runs two
+    passes and the eval-form final inference on the tuned weights three.  Same bits as the forced three-pass build: first sample, a second
+    sample after the reset, and a sample after an applied momentum update of the reset state (three passes throughout from then on)."""
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine, TTAConfig
+    sg, rg = synth.GEOMETRIES[student], synth.GEOMETRIES[reward]
+    ssd, rsd = synth.to_fp16_grid(synth.make_state_dict(sg, 11, device=DEV)), synth.to_fp16_grid(synth.make_state_dict(rg, 23, device=DEV))
+    tokens = synth.make_token_bank(sg, n_cls, seed=7, n_ctx=4)
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, 4), device=DEV)].clone()
+    views = synth.make_views(2003, n_views, sg.image_resolution, device=DEV)
+    keys = ("logits", "final_logits", "ln_grad", "ln_after", "vis_grad", "vis_after")
+    outs = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RLCF_X3_WLO0", raising=False)
+        else:
+            monkeypatch.setenv("RLCF_X3_WLO0", env)
+        eng = Engine(sg, rg, n_views, n_cls, L.PREC_F16X3)
+        eng.load_state_dict(L.STUDENT, ssd)
+        eng.load_state_dict(L.REWARD, rsd)
+        eng.finalize()
+        eng.set_class_bank(tokens, 4, ctx0, L.TEXT_SHARED)
+        cfg = TTAConfig(selection_p=0.25, tta_steps=2, lr=1e-4)
+        o = eng.tta_sample_visual(views, cfg)
+        rec = {k: o[k].clone() for k in keys}
+        o2 = eng.tta_sample_visual(views, cfg)
+        for k in keys:
+            assert torch.equal(o2[k], rec[k]), k
+        others = ctypes.c_int(0)
+        rec["on_grid_after_reset"] = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+        eng.momentum_update_visual(o["vis_after"], 0.5, 1.0, True)
+        rec["on_grid_after_ema"] = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+        o3 = eng.tta_sample_visual(views, cfg)
+        rec["ema_final_logits"], rec["ema_vis_grad"] = o3["final_logits"].clone(), o3["vis_grad"].clone()
+        assert int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others))) == rec["on_grid_after_ema"]
+        outs.append(rec)
+        eng.close()
+    assert outs[0]["on_grid_after_reset"] == 0 and outs[1]["on_grid_after_reset"] > outs[1]["on_grid_after_ema"] > 0, \
+        (outs[0]["on_grid_after_reset"], outs[1]["on_grid_after_reset"], outs[1]["on_grid_after_ema"])     # (the text tower stays on the grid)
+    assert not torch.equal(outs[1]["ema_final_logits"], outs[1]["final_logits"])
+    for k in outs[0]:
+        if not k.startswith("on_grid"):
+            assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_resnet_convolutions_on_the_fp16_grid_keep_the_batchnorm_scale_in_the_epilogue(monkeypatch):
     """A ModifiedResNet tower folds its BatchNorms into the convolutions (model.py:18-31 in eval mode), which takes the weights off the fp16
     grid.  For checkpoint weights the engine keeps an UNFOLDED copy (two MFMA passes) and applies gamma / sqrt(var + eps) per output column
