@@ -107,11 +107,16 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     """The harness body TPT/tpt_cls_rl.py:251-262 around the reference's own
     test_time_tuning, with taps on its intermediates."""
     ensemble = "+" in reward
+    grid = bool(hp.pop("fp16_grid", 0))         # GEMM weights rounded to fp16 values, as a released checkpoint holds them (synth.to_fp16_grid)
     s_geo = synth.GEOMETRIES[student]
     s_sd = synth.make_state_dict(s_geo, seed=11)
+    if grid:
+        s_sd = synth.to_fp16_grid(s_sd)
     if not ensemble:
         r_geo = synth.GEOMETRIES[reward]
         r_sd = synth.make_state_dict(r_geo, seed=23)
+        if grid:
+            r_sd = synth.to_fp16_grid(r_sd)
     install_models(ref, {student: (s_geo, s_sd)})
     bank = Bank(s_geo, n_cls, n_ctx)
     ref.custom.tokenize = bank.tokenize
@@ -703,6 +708,20 @@ def main():
                       f"rewards={a_i['rewards']}", flush=True)
             save("tta_b16_n64_stream", arrays, dict(student="ViT-B/16", reward="ViT-B/16", n_views=64, n_cls=1000, student_seed=11,
                                                     reward_seed=23, view_seed0=1113, n_samples=n_s, bank_seed=7, n_ctx=4, **hp))
+        elif grp == "b16gridstream":
+            # the b16stream case on CHECKPOINT-GRID weights (every GEMM weight an fp16 value, synth.to_fp16_grid): the reference's own run on
+            # the weights for which the engine drops the a_hi . w_lo pass — pins the two-pass products to the reference directly
+            hp = dict(BASE_HP, selection_p=0.1)
+            arrays, n_s = {}, int(os.environ.get("STREAM_N", "4"))
+            for i in range(n_s):
+                t0 = time.time()
+                a_i = run_reference_tta(ref, "ViT-B/16", "ViT-B/16", 64, 1000, dict(hp, fp16_grid=1), view_seed=1113 + i)
+                for k in ("selected_idx", "topk_idx", "clip_score", "rewards", "ctx_after", "final_logits", "top5"):
+                    arrays[f"{k}_{i}"] = a_i[k]
+                print(f"  grid stream sample {i}: {time.time() - t0:.1f}s idx={a_i['selected_idx']} top5={a_i['top5']} "
+                      f"rewards={a_i['rewards']}", flush=True)
+            save("tta_b16_n64_grid_stream", arrays, dict(student="ViT-B/16", reward="ViT-B/16", n_views=64, n_cls=1000, student_seed=11,
+                                                         reward_seed=23, view_seed0=1113, n_samples=n_s, bank_seed=7, n_ctx=4, weights="fp16grid", **hp))
         else:
             for name in GROUPS[grp]:
                 student, reward, n, c, over = TTA_CASES[name]

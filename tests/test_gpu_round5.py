@@ -265,6 +265,58 @@ def test_fp16_grid_weights_through_the_tuning_paths(monkeypatch, path):
             assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_checkpoint_grid_weights_against_the_reference_run_on_the_same_weights():
+    """The two-pass products against the REFERENCE itself: tests/golden/tta_b16_n64_grid_stream.npz is the reference's own harness body
+    (TPT/tpt_cls_rl.py:251-262, one image at a time) on ViT-B/16 + ViT-B/16, N = 64, 1000 classes with every GEMM weight rounded to an
+    fp16 value (tests/golden/make_golden.py --only b16gridstream; synth.to_fp16_grid = what a released checkpoint holds).  One image at a
+    time through rlcf_tta_sample (selection, sampled classes, scores, rewards, adapted prompt, final logits) and the whole stream in one
+    pass through rlcf_tta_batch — with every split weight of the student on the grid, i.e. on the two-pass kernels."""
+    from test_gpu_parity import _cfg_from_meta, load_golden
+    from rlcf_amd import synth
+    from rlcf_amd.engine import Engine
+    g, meta = load_golden("tta_b16_n64_grid_stream")
+    assert meta["weights"] == "fp16grid"
+    n, N = meta["n_samples"], meta["n_views"]
+    sg = synth.GEOMETRIES[meta["student"]]
+    ssd = synth.to_fp16_grid(synth.make_state_dict(sg, meta["student_seed"], device=DEV))
+    rsd = synth.to_fp16_grid(synth.make_state_dict(synth.GEOMETRIES[meta["reward"]], meta["reward_seed"], device=DEV))
+    eng = Engine(sg, synth.GEOMETRIES[meta["reward"]], N * n, meta["n_cls"], L.PREC_F16X3)
+    eng.load_state_dict(L.STUDENT, ssd)
+    eng.load_state_dict(L.REWARD, rsd)
+    eng.finalize()
+    others = ctypes.c_int(0)
+    on = int(L.lib().rlcf_engine_f16_grid_weights(eng.h, L.STUDENT, ctypes.byref(others)))
+    assert on > 90 and others.value == 0, (on, others.value)
+    tokens = synth.make_token_bank(sg, meta["n_cls"], seed=meta["bank_seed"], n_ctx=meta["n_ctx"])
+    ctx0 = ssd["token_embedding.weight"][torch.tensor(synth.ctx_token_ids_default(sg, meta["n_ctx"]), device=DEV)].clone()
+    eng.set_class_bank(tokens, meta["n_ctx"], ctx0, L.TEXT_SHARED)
+    cfg = _cfg_from_meta(meta, sparse=True)
+    views = torch.stack([synth.make_views(meta["view_seed0"] + i, N, sg.image_resolution, device=DEV) for i in range(n)])
+    worst, flipped = 0.0, []
+    for i in range(n):
+        o = eng.tta_sample(views[i], cfg)
+        assert o["selected_idx"].cpu().tolist() == g[f"selected_idx_{i}"].tolist()
+        assert o["topk_idx"].cpu().reshape(-1).tolist() == g[f"topk_idx_{i}"].reshape(-1).tolist()
+        assert o["top5"].cpu().tolist() == g[f"top5_{i}"].tolist()
+        torch.testing.assert_close(o["clip_score"].cpu(), g[f"clip_score_{i}"].reshape(-1), atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(o["rewards"].cpu(), g[f"rewards_{i}"].reshape(-1), atol=5e-5, rtol=1e-3)
+        torch.testing.assert_close(o["final_logits"].cpu(), g[f"final_logits_{i}"], atol=1e-3, rtol=0)
+        d = (o["ctx_after"].cpu() - g[f"ctx_after_{i}"]).abs()
+        flipped.append(int((d > 0.1 * meta["lr"]).sum()))
+        assert flipped[-1] <= 0.01 * d.numel(), f"sample {i}: {flipped[-1]} prompt elements off by more than 0.1 lr"
+        worst = max(worst, (o["final_logits"].cpu() - g[f"final_logits_{i}"]).abs().max().item())
+    top5, fl = eng.tta_batch(views, cfg, want_logits=True)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert top5[i].cpu().tolist() == g[f"top5_{i}"].tolist(), f"sample {i} in the batched pass"
+        err = (fl[i].cpu() - g[f"final_logits_{i}"][0]).abs().max().item()
+        worst = max(worst, err)
+        assert err < 1e-3, f"sample {i} in the batched pass: max|dlogit| {err:.2e}"
+    print(f"[grid-weight stream] {n} samples, {on} split weights on the fp16 grid: worst max|dlogit| vs the reference = {worst:.2e}; "
+          f"sign-fragile prompt elements per sample {flipped}")
+    eng.close()
+
+
 @pytest.mark.parametrize("student,reward,n_views,n_cls", [("tiny-rn", "tiny-r64", 32, 40), ("RN50", "ViT-B/32", 16, 64)])
 def test_fp16_grid_weights_through_resnet_every_parameter_tuning(monkeypatch, student, reward, n_views, n_cls):
     """Every-parameter tuning of a ModifiedResNet student (the parser defaults of TPT/tune_cls_rl.py) on checkpoint-grid weights: the train-form
