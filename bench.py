@@ -181,11 +181,11 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
                 v = self.staged[i % len(self.staged)] if self.staged is not None else aug.views(photos[i % len(photos)])
                 yield [x.unsqueeze(0) for x in v.unbind(0)], torch.tensor([i % n_cls])
 
-    def run(n, images_per_pass, staged):
+    def run(n, images_per_pass, staged, in_flight=1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tpt_cls_rl.test_time_adapt_eval(Loader(n, staged), model, optimizer, optim_state, None, args, reward_model=reward_model,
-                                        images_per_pass=images_per_pass)
+                                        images_per_pass=images_per_pass, in_flight=in_flight)
         torch.cuda.synchronize()
         return n / (time.perf_counter() - t0)
 
@@ -197,6 +197,11 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     run(4, 1, staged)                                         # warm-up: engine build, class bank, workspaces
     out["images_per_s_one_image_per_pass_staged_views"] = run(n_one, 1, staged)
     out["images_per_s_one_image_per_pass_views_in_loop"] = run(n_one, 1, None)
+    # still one image per engine call, two samples in flight on two engines / two streams (test_time_adapt_eval(in_flight=2)): one sample's
+    # few-row tail runs under the next sample's 64-view tower pass; per-sample results are the one-at-a-time call's
+    run(4, 1, staged, 2)                                      # (builds the second engine)
+    out["images_per_s_one_image_per_pass_two_in_flight_staged_views"] = run(2 * n_one, 1, staged, 2)
+    out["images_per_s_one_image_per_pass_two_in_flight_views_in_loop"] = run(2 * n_one, 1, None, 2)
     if not one_only:
         run(ipp, ipp, staged)                                     # (batched workspaces)
         out[f"images_per_s_{ipp}_images_per_pass_staged_views"] = run(n_batched, ipp, staged)

@@ -358,6 +358,12 @@ int rlcf_engine_ln_param_count(rlcf_engine*);
  * copies them into float32 parameters) — and how many do not (*others, may be NULL).  For such a weight the a_hi . w_lo MFMA pass of the 256x256
  * split-f16 kernel adds exact zeros and is dropped at launch: the same bits in two passes instead of three (RLCF_X3_WLO0=0 at finalize: off). */
 int rlcf_engine_f16_grid_weights(rlcf_engine*, int which, int* others);
+/* on = 0: one-image calls keep every launch on the caller's stream instead of moving the reward models' pass to the engine's own side
+ * stream (engine_tta_sample; what RLCF_NO_OVERLAP=1 does process-wide).  For engines that serve samples IN FLIGHT side by side from
+ * several host threads (rlcf_amd.tpt_cls_rl.test_time_adapt_eval(in_flight=K), one engine per lane): the overlap comes from the other
+ * lanes, and a side stream that lands on the hardware queue of another lane's stream would serialise the two.  Default on.
+ * Replaces nothing in the reference (its loop runs one sample at a time, TPT/tpt_cls_rl.py:233-262). */
+int rlcf_engine_set_side_stream(rlcf_engine*, int on);
 /* A ModifiedResNet student (arch RN50 .. RN50x64) has BatchNorms where the ViT has LayerNorms: CLIPCLS_TTA(only_norm=True) tunes the
  * weight / bias of every BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485; downsample.1 stays frozen) and
  * rlcf_tta_sample_ln / rlcf_tta_batch_ln / rlcf_engine_{ln_param_count,get_ln_params,set_ln_params,momentum_update} serve them

@@ -132,6 +132,7 @@ SIGNATURES = {
     "rlcf_avg_entropy": (I, [P, I, I, P, P]),
     "rlcf_accuracy": (I, [P, P, I, I, P, P, P]),
     "rlcf_engine_set_bn_prior_strength": (I, [P, I]),
+    "rlcf_engine_set_side_stream": (I, [P, I]),
     "rlcf_engine_bn_stats_count": (I, [P]),
     "rlcf_engine_encode_image_bn": (I, [P, P, I, P, P]),
     "rlcf_engine_encode_image_bn_form": (I, [P, P, I, I, P, P]),

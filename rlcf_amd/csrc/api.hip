@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 12; }   // 12: rlcf_avg_entropy, rlcf_accuracy (the harness mirror's conveniences as kernels); 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 13; }   // 13: rlcf_engine_set_side_stream (lane engines of samples in flight keep to the caller's stream); 12: rlcf_avg_entropy, rlcf_accuracy (the harness mirror's conveniences as kernels); 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -560,6 +560,11 @@ static int norm_ready(rlcf_engine* e, hipStream_t st) {
     const ClipModel& s = e->model[RLCF_STUDENT];
     if (s.finalized && is_resnet(s.cfg) && !s.rn.bn_enabled) return engine_bn_enable(e, st);
     if (e->ln_count <= 0) { rlcf_set_error("the student has no tunable norm layers (not finalized?)"); return RLCF_ERR_STATE; }
+    return RLCF_OK;
+}
+int rlcf_engine_set_side_stream(rlcf_engine* e, int on) {
+    RLCF_ARG_CHECK(e);
+    e->no_side = !on;
     return RLCF_OK;
 }
 int rlcf_engine_set_bn_prior_strength(rlcf_engine* e, int prior_strength) {

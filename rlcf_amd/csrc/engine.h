@@ -182,6 +182,7 @@ struct rlcf_engine {
     // out_proj.weight, out_proj.bias, c_fc.weight, c_fc.bias, c_proj.weight, c_proj.bias (each slot 64-float aligned) in one flat buffer
     DevBuf vw, vw_init, vw_grad, vw_m, vw_v, vw_clip, vw_mom;
     size_t vw_count = 0;
+    bool no_side = false;            // rlcf_engine_set_side_stream(e, 0): one-image calls keep to the caller's stream
     bool vw_dirty = false;           // live weights differ from the reset state
     bool vw_init_is_ckpt = true;     // the reset state (vw_init) still holds the checkpoint's values (no EMA has been applied to it)
     std::vector<VwSlot> vw_slots;

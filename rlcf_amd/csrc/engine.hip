@@ -1518,7 +1518,7 @@ int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_
     if (no_overlap < 0) { const char* ev = getenv("RLCF_NO_OVERLAP"); no_overlap = ev ? atoi(ev) : 0; }
     bool vit_rewards = true;
     for (int m = 0; m < e->n_rewards; ++m) vit_rewards = vit_rewards && !is_resnet(e->model[RLCF_REWARD + m].cfg);
-    const bool overlap = sparse_ok && vit_rewards && !no_overlap && !g_prof.enabled && e->side && prec_x3(e) && !prec_single(e);
+    const bool overlap = sparse_ok && vit_rewards && !no_overlap && !e->no_side && !g_prof.enabled && e->side && prec_x3(e) && !prec_single(e);
     bool fwd_done = false;
     for (int j = 0; j < a->tta_steps; ++j) {
         // step 0 runs on ctx == ctx_init: its text features are the cached txt0 (the dense-backward

@@ -222,6 +222,10 @@ class Engine:
         L.check(self.lib.rlcf_engine_momentum_update(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0, _stream()),
                 "momentum_update")
 
+    def set_side_stream(self, on: bool) -> None:
+        """False: one-image calls stay on the caller's stream (lane engines of samples in flight, rlcf_engine_set_side_stream)."""
+        L.check(self.lib.rlcf_engine_set_side_stream(self.h, 1 if on else 0), "set_side_stream")
+
     def reset_visual_state(self) -> None:
         """State part of CLIPCLS_TTA.reset_classnames_and_state (custom_clip.py:449-454): reset state and EMA back to the checkpoint."""
         L.check(self.lib.rlcf_engine_reset_visual_state(self.h, _stream()), "reset_visual_state")

@@ -30,6 +30,7 @@ class Session:
         self.precision = PRECISIONS[os.environ.get("RLCF_PRECISION", "f16x3")]
         self.text_mode = TEXT_MODES[os.environ.get("RLCF_TEXT_MODE", "shared")]
         self._engine: Optional[Engine] = None
+        self._lanes = []             # [[Engine, bank key]]: further engines for test images in flight side by side (lane_engines)
         self._key = None
         self.image_bank = None       # (student features [n, D], [reward features [n, Dr]]): the bank of the text -> image retrieval direction
         self._bank_version = 0       # bumped by set_bank: the engine re-reads the class bank when its copy is older
@@ -77,33 +78,63 @@ class Session:
         if self._engine is None or key != self._key or n_cls > self._engine.max_classes:
             if self._engine is not None:
                 self._engine.close()
-            eng = Engine(self.student.geometry, [r.geometry for r in self.rewards] or None, self.max_views,
-                         max(n_cls, 1), self.precision)
-            eng.load_state_dict(L.STUDENT, self.student.state_dict)
-            for m, r in enumerate(self.rewards):
-                eng.load_state_dict(L.REWARD + m, r.state_dict)
-            eng.finalize()
-            if self.reward_mix is not None:
-                eng.set_reward_mix(self.reward_mix, self.reward_mean)
-            if self.student.geometry.is_resnet:
-                eng.set_bn_prior_strength(self.bn_prior_strength)
-            self._engine, self._key, self._bank_applied = eng, key, None
-        if self.tokens is not None:
-            bkey = (self._bank_version, self.text_mode)       # a counter, not id()/checksums: no stale bank, no device sync per call
-            if bkey != self._bank_applied:
-                self._engine.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode, getattr(self, "student_tokens", None),
-                                            getattr(self, "ctx_pos", None))
-                self._bank_applied = bkey
-        elif self.image_bank is not None:
-            bkey = (self._bank_version, "images")
-            if bkey != self._bank_applied:
-                self._engine.set_image_bank(*self.image_bank)
-                self._bank_applied = bkey
+            self._close_lanes()
+            self._engine, self._key, self._bank_applied = self._build(n_cls), key, None
+        bkey = self._bank_key()
+        if bkey is not None and bkey != self._bank_applied:
+            self._apply_bank(self._engine)
+            self._bank_applied = bkey
         return self._engine
+
+    def _build(self, n_cls: int) -> Engine:
+        eng = Engine(self.student.geometry, [r.geometry for r in self.rewards] or None, self.max_views, max(n_cls, 1), self.precision)
+        eng.load_state_dict(L.STUDENT, self.student.state_dict)
+        for m, r in enumerate(self.rewards):
+            eng.load_state_dict(L.REWARD + m, r.state_dict)
+        eng.finalize()
+        if self.reward_mix is not None:
+            eng.set_reward_mix(self.reward_mix, self.reward_mean)
+        if self.student.geometry.is_resnet:
+            eng.set_bn_prior_strength(self.bn_prior_strength)
+        return eng
+
+    def _bank_key(self):
+        if self.tokens is not None:
+            return (self._bank_version, self.text_mode)       # a counter, not id()/checksums: no stale bank, no device sync per call
+        if self.image_bank is not None:
+            return (self._bank_version, "images")
+        return None
+
+    def _apply_bank(self, eng: Engine):
+        if self.tokens is not None:
+            eng.set_class_bank(self.tokens, self.n_ctx, self.ctx_init, self.text_mode, getattr(self, "student_tokens", None), getattr(self, "ctx_pos", None))
+        elif self.image_bank is not None:
+            eng.set_image_bank(*self.image_bank)
+
+    def lane_engines(self, lanes: int, n_views: int = 1):
+        """`lanes` engines for test images IN FLIGHT side by side (tpt_cls_rl.test_time_adapt_eval(in_flight=...)): lane 0 is the session's
+        engine, the others are further engines over the same checkpoints and class bank with their own weights copies, scratch and state
+        (an engine serves one call at a time).  Built on first use, kept until the session's engine is rebuilt or closed."""
+        first = self.engine(n_views)
+        n_cls = first.max_classes
+        bkey = self._bank_key()
+        while len(self._lanes) < lanes - 1:
+            self._lanes.append([self._build(n_cls), None])
+        for lane in self._lanes[: lanes - 1]:
+            if bkey is not None and lane[1] != bkey:
+                self._apply_bank(lane[0])
+                lane[1] = bkey
+        return [first] + [lane[0] for lane in self._lanes[: lanes - 1]]
+
+    def _close_lanes(self):
+        for lane in self._lanes:
+            lane[0].close()
+        self._lanes = []
 
     def close(self):
         if self._engine is not None:
             self._engine.close()
+        self._close_lanes()
         self._engine = None
         self._key = self._bank_applied = None
 

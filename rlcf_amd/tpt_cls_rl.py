@@ -173,11 +173,89 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
 
 
-def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1):
+def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
+    """One test image per engine call, as the reference feeds them, with `lanes` images IN FLIGHT: a sample's step is a 64-view tower pass
+    that fills the chip followed by a long tail of few-row launches (the selected views through the reward model, the sampled classes'
+    text passes, the final text pass) that does not — so sample i + 1 starts on another engine and another stream while sample i
+    finishes.  Samples are independent units (per-sample reset, tpt_cls_rl.py:251-255): every sample's arithmetic is exactly the
+    one-at-a-time call's (rlcf_tta_batch with one image), only the wall clock changes.  Lane k takes images k, k + lanes, ..."""
+    import queue
+    import threading
+    cfg = _config(args, optimizer, reward_model)
+    prompt = hasattr(model, "prompt_learner")
+    dev = torch.device("cuda", args.gpu)
+    main = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+    queues = [queue.Queue(maxsize=4) for _ in range(lanes)]
+    engines, results, errors = [], [None] * lanes, []
+
+    def lane(k):
+        try:
+            torch.cuda.set_device(dev)
+            n, s1, s5 = 0, None, None
+            with torch.cuda.stream(streams[k]):
+                while True:
+                    item = queues[k].get()
+                    if item is None:
+                        break
+                    if errors:
+                        continue                             # (keep draining: the producer must not block on a full queue)
+                    views, target, ready = item
+                    streams[k].wait_event(ready)
+                    top5 = (engines[k].tta_batch if prompt else engines[k].tta_batch_ln)(views.unsqueeze(0), cfg).long()
+                    t = target.view(-1, 1)
+                    h1, h5 = (top5[:, :1] == t).any(1).float().sum(), (top5 == t).any(1).float().sum()
+                    s1, s5 = (h1, h5) if s1 is None else (s1 + h1, s5 + h5)
+                    n += 1
+                streams[k].synchronize()
+            results[k] = (n, s1, s5)
+        except BaseException as exc:                         # noqa: BLE001 — reported by the caller's thread
+            errors.append(exc)
+
+    threads = []
+    for i, (images, target) in enumerate(val_loader):
+        if isinstance(images, list):
+            images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
+        else:
+            images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
+        if not threads:                                      # engines are sized by the first image's view count
+            engines.extend(runtime.SESSION.lane_engines(lanes, images.shape[0]))
+            for e_ in engines:
+                e_.set_side_stream(False)                    # the overlap comes from the other lanes (see rlcf_engine_set_side_stream)
+            threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(lanes)]
+            for th in threads:
+                th.start()
+        t = target.reshape(-1)[:1]
+        t = _upload(t, dev) if not t.is_cuda else t.to(dev)
+        k = i % lanes
+        images.record_stream(streams[k])
+        t.record_stream(streams[k])
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # views and label were produced on the caller's stream
+        queues[k].put((images, t, ready))
+        if errors:
+            break
+    for q in queues:
+        q.put(None)
+    for th in threads:
+        th.join()
+    for e_ in engines:
+        e_.set_side_stream(True)
+    if errors:
+        raise errors[0]
+    n = sum(r[0] for r in results if r)
+    s1 = sum(float(r[1]) for r in results if r and r[1] is not None) * 100.0
+    s5 = sum(float(r[2]) for r in results if r and r[2] is not None) * 100.0
+    return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
+
+
+def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1, in_flight=1):
     """TPT/tpt_cls_rl.py:219-279 and its twin TPT/tune_cls_rl.py:183-256 (CLIPCLS_TTA models: model.train() / model.eval() round the
     tuning step, :216-218, and model.momentum_update_model() after the clean-view inference, :240): per test image
     reset -> tune -> clean-view inference -> (EMA) -> top-1/top-5.
-    `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once."""
+    `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once; `in_flight > 1` (not in the reference
+    either) keeps one image per engine call and runs that many samples side by side on their own engines and streams (_eval_in_flight).
+    Both need independent samples: no cross-sample EMA, no per-sample encoder weights."""
     backbone = not hasattr(model, "prompt_learner")                 # CLIPCLS_TTA: the tune_cls_rl.py form of the loop
     full_visual = not hasattr(model, "prompt_learner") and not model.only_norm      # per-sample weights: one sample per pass
     if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:
@@ -185,6 +263,11 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
         with torch.no_grad():
             model.reset()
         return _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass)
+    if in_flight > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:
+        model.eval()
+        with torch.no_grad():
+            model.reset()
+        return _eval_in_flight(val_loader, model, optimizer, args, reward_model, in_flight)
     # The hit counts accumulate ON THE DEVICE (exact: sums of 0 / 100 in float32) and are read at print_freq and at the end: the
     # reference reads them after every image (float(acc1[0])), which makes the host wait for the GPU before it may draw the next
     # image's views — the one place where following the loop line by line would leave the GPU idle.  Same numbers.

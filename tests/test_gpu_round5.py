@@ -419,6 +419,36 @@ def test_two_pass_packed_weight_rows_at_vit_l14_shapes(monkeypatch):
     assert torch.equal(feats[0], feats[1])
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_harness_with_samples_in_flight_counts_what_the_one_by_one_loop_counts(lanes):
+    """test_time_adapt_eval(in_flight=K): still one test image per engine call (the reference's operating point, tpt_cls_rl.py:233-262), K
+    samples side by side on K engines / streams driven by K host threads.  Samples are independent (per-sample reset), so the hit counts
+    must be those of the serial loop — seven samples over 2 and 3 lanes (ragged last round), labels chosen so that top-1 and top-5 differ —
+    and the per-sample predictions of a lane engine must be bit-identical to the session engine's."""
+    from test_gpu_parity import _harness_objects, load_golden
+    from rlcf_amd import runtime, synth, tpt_cls_rl
+    dev = torch.device(DEV)
+    g, meta = load_golden("tta_small_s1")
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    samples = [synth.make_views(1000 + i, meta["n_views"], R) for i in range(7)]
+    res = {}
+    for k in (1, lanes):
+        model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+        loader = [([v.unsqueeze(0) for v in s], torch.tensor([int(g["top5"][0]) if i == 0 else (int(g["top5"][3]) if i % 2 else 0)]))
+                  for i, s in enumerate(samples)]
+        res[k] = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model, in_flight=k)
+        if k > 1:
+            engs = runtime.SESSION.lane_engines(k, meta["n_views"])
+            assert len(engs) == k and len({id(e) for e in engs}) == k
+            cfg = tpt_cls_rl._config(args, optimizer, reward_model)
+            v = torch.stack([s.to(dev) for s in samples[:2]])
+            outs = [e.tta_batch(v, cfg, want_logits=True) for e in engs]
+            for t5, fl in outs[1:]:
+                assert torch.equal(t5, outs[0][0]) and torch.equal(fl, outs[0][1])
+        runtime.reset_session()
+    assert res[1] == res[lanes] and res[1][0] >= 100.0 / 7 - 1e-3, res
+
+
 def test_harness_conveniences_run_as_kernels_and_match_the_reference_expressions():
     """rlcf_amd.tpt_cls_rl.avg_entropy / accuracy on device tensors are single launches (rlcf_avg_entropy, rlcf_accuracy) since round 5:
     against the reference's torch expressions (TPT/tpt_cls_rl.py:38-44, TPT/utils/tools.py:84-98), on logits at CLIP's scale."""

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r5/exp23; mkdir -p $O
+for q in 8 16; do
+echo "GPU_MAX_HW_QUEUES=$q"
+GPU_MAX_HW_QUEUES=$q timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --no-f16-line > $O/bench$q.json 2> $O/bench$q.err
+python - $q <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/r5/exp23/bench{sys.argv[1]}.json").read().strip().splitlines()[-1])
+print(d["value"]); print({k.replace("images_per_s_one_image_per_pass_", ""): (round(v, 1) if isinstance(v, float) else v) for k, v in d["harness"].items() if k != "what"})
+g = d.get("harness_checkpoint_grid_weights"); print(g and {k.replace("images_per_s_one_image_per_pass_", ""): (round(v, 1) if isinstance(v, float) else v) for k, v in g.items() if k != "what"})
+PY
+done
+for q in 4 8; do echo "probe GPU_MAX_HW_QUEUES=$q"; GPU_MAX_HW_QUEUES=$q timeout 300 python tools/two_in_flight_probe.py 24 2>&1 | grep "in flight"; done
