@@ -202,6 +202,9 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     run(4, 1, staged, 2)                                      # (builds the second engine)
     out["images_per_s_one_image_per_pass_two_in_flight_staged_views"] = run(2 * n_one, 1, staged, 2)
     out["images_per_s_one_image_per_pass_two_in_flight_views_in_loop"] = run(2 * n_one, 1, None, 2)
+    run(6, 1, staged, 3)
+    out["images_per_s_one_image_per_pass_three_in_flight_staged_views"] = run(2 * n_one, 1, staged, 3)
+    out["images_per_s_one_image_per_pass_three_in_flight_views_in_loop"] = run(2 * n_one, 1, None, 3)
     if not one_only:
         run(ipp, ipp, staged)                                     # (batched workspaces)
         out[f"images_per_s_{ipp}_images_per_pass_staged_views"] = run(n_batched, ipp, staged)

@@ -449,6 +449,42 @@ def test_harness_with_samples_in_flight_counts_what_the_one_by_one_loop_counts(l
     assert res[1] == res[lanes] and res[1][0] >= 100.0 / 7 - 1e-3, res
 
 
+def test_norm_layer_tuning_harness_with_samples_in_flight():
+    """The tune_cls_rl.py form of the loop (CLIPCLS_TTA(only_norm=True), no cross-sample EMA) with two samples in flight: lanes call
+    rlcf_tta_batch_ln with one image each; same hit counts as the serial loop, and a model with momentum_update=True (samples are NOT
+    independent there) must fall back to the serial loop whatever in_flight says."""
+    import copy
+    import types
+    from test_gpu_parity import load_golden
+    from rlcf_amd import clip_reward, clip_store, custom_clip, runtime, synth, tpt_cls_rl
+    dev = torch.device(DEV)
+    g, meta = load_golden("ln_tiny_s1")
+    sg, rg = synth.GEOMETRIES[meta["student"]], synth.GEOMETRIES[meta["reward"]]
+    samples = [synth.make_views(1000 + i, meta["n_views"], sg.image_resolution) for i in range(5)]
+    res = {}
+    for tag, lanes, ema in (("serial", 1, False), ("lanes", 2, False), ("ema", 2, True)):
+        runtime.reset_session()
+        clip_store.register_checkpoint(meta["student"], sg, synth.make_state_dict(sg, meta["student_seed"]))
+        clip_store.register_checkpoint("tiny-r", rg, synth.make_state_dict(rg, meta["reward_seed"]))
+        bank = clip_store.SyntheticBank(sg, meta["n_cls"], meta["n_ctx"], meta["bank_seed"])
+        clip_store.set_tokenizer(bank.tokenize)
+        args = types.SimpleNamespace(tta_steps=meta["tta_steps"], selection_p=meta["selection_p"], gpu=0, tpt=True, print_freq=1000, min_entropy_reg=0,
+                                     min_entropy_w=0.1, reward_arch="tiny-r", multiple_reward_models=0, sample_k=meta["sample_k"],
+                                     reward_amplify=False, reward_process=True, process_batch=False)
+        model = custom_clip.CLIPCLS_TTA(dev, bank.classnames, arch=meta["student"], prompt_prefix="a_photo_of_a", only_visual=True, only_norm=True,
+                                        momentum_update=ema, update_freq=2, update_w=1.0, momentum=0.9)
+        reward_model = clip_reward.get_reward_model(dev, args)
+        reward_model.set_class_features(tokenized_classes=model.tokenized_prompts)
+        optimizer = torch.optim.AdamW(model.parameters(), meta["lr"], weight_decay=meta["weight_decay"])
+        optim_state = copy.deepcopy(optimizer.state_dict())
+        loader = [([v.unsqueeze(0) for v in s], torch.tensor([int(g["top5"][0]) if i == 0 else (int(g["top5"][2]) if i % 2 else 0)])) for i, s in enumerate(samples)]
+        res[tag] = tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model, in_flight=lanes)
+        if tag == "ema":
+            assert not runtime.SESSION._lanes                      # the serial loop ran: no lane engine was built
+    runtime.reset_session()
+    assert res["serial"] == res["lanes"] and res["serial"][1] >= 20.0, res
+
+
 def test_harness_conveniences_run_as_kernels_and_match_the_reference_expressions():
     """rlcf_amd.tpt_cls_rl.avg_entropy / accuracy on device tensors are single launches (rlcf_avg_entropy, rlcf_accuracy) since round 5:
     against the reference's torch expressions (TPT/tpt_cls_rl.py:38-44, TPT/utils/tools.py:84-98), on logits at CLIP's scale."""
