@@ -190,6 +190,7 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
     engines, results, errors = [], [None] * lanes, []
 
     def lane(k):
+        ended = False
         try:
             torch.cuda.set_device(dev)
             n, s1, s5 = 0, None, None
@@ -197,6 +198,7 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
                 while True:
                     item = queues[k].get()
                     if item is None:
+                        ended = True
                         break
                     if errors:
                         continue                             # (keep draining: the producer must not block on a full queue)
@@ -211,36 +213,40 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
             results[k] = (n, s1, s5)
         except BaseException as exc:                         # noqa: BLE001 — reported by the caller's thread
             errors.append(exc)
+            while not ended and queues[k].get() is not None:  # (the producer must never block on this lane's full queue)
+                pass
 
     threads = []
-    for i, (images, target) in enumerate(val_loader):
-        if isinstance(images, list):
-            images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
-        else:
-            images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
-        if not threads:                                      # engines are sized by the first image's view count
-            engines.extend(runtime.SESSION.lane_engines(lanes, images.shape[0]))
-            for e_ in engines:
-                e_.set_side_stream(False)                    # the overlap comes from the other lanes (see rlcf_engine_set_side_stream)
-            threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(lanes)]
-            for th in threads:
-                th.start()
-        t = target.reshape(-1)[:1]
-        t = _upload(t, dev) if not t.is_cuda else t.to(dev)
-        k = i % lanes
-        images.record_stream(streams[k])
-        t.record_stream(streams[k])
-        ready = torch.cuda.Event()
-        ready.record(main)                                   # views and label were produced on the caller's stream
-        queues[k].put((images, t, ready))
-        if errors:
-            break
-    for q in queues:
-        q.put(None)
-    for th in threads:
-        th.join()
-    for e_ in engines:
-        e_.set_side_stream(True)
+    try:
+        for i, (images, target) in enumerate(val_loader):
+            if isinstance(images, list):
+                images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
+            else:
+                images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
+            if not threads:                                  # engines are sized by the first image's view count
+                engines.extend(runtime.SESSION.lane_engines(lanes, images.shape[0]))
+                for e_ in engines:
+                    e_.set_side_stream(False)                # the overlap comes from the other lanes (see rlcf_engine_set_side_stream)
+                threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(lanes)]
+                for th in threads:
+                    th.start()
+            t = target.reshape(-1)[:1]
+            t = _upload(t, dev) if not t.is_cuda else t.to(dev)
+            k = i % lanes
+            images.record_stream(streams[k])
+            t.record_stream(streams[k])
+            ready = torch.cuda.Event()
+            ready.record(main)                               # views and label were produced on the caller's stream
+            queues[k].put((images, t, ready))
+            if errors:
+                break
+    finally:                                                 # (also when the loader raises: the lanes must end and the engines get their side streams back)
+        for q, th in zip(queues, threads):
+            q.put(None)
+        for th in threads:
+            th.join()
+        for e_ in engines:
+            e_.set_side_stream(True)
     if errors:
         raise errors[0]
     n = sum(r[0] for r in results if r)
