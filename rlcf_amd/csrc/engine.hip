@@ -497,6 +497,7 @@ static int tower_ensure(Tower& t, int T, int width) {
     const size_t n = (size_t)T * width * sizeof(float);
     TRY(t.x.ensure(n)); TRY(t.h.ensure(n)); TRY(t.qkv.ensure(3 * n)); TRY(t.a.ensure(n)); TRY(t.f.ensure(4 * n));
     RLCF_HIP_CHECK(hipMemset(t.a.p, 0, n));
+    RLCF_HIP_CHECK(hipStreamSynchronize(nullptr));     // the fill runs on the NULL stream: done before a caller's non-blocking stream (a lane of samples in flight) writes here
     t.T = T; t.width = width;
     return RLCF_OK;
 }
@@ -507,6 +508,7 @@ static int tower_ensure_saved(Tower& t, int T, int width, int layers) {
     const size_t per_layer = per * (1 + 3 + 1 + 1 + 4) + per_lse;
     TRY(t.saved.ensure(per_layer * layers * sizeof(float)));
     RLCF_HIP_CHECK(hipMemset(t.saved.p, 0, per_layer * layers * sizeof(float)));
+    RLCF_HIP_CHECK(hipStreamSynchronize(nullptr));     // (as in tower_ensure: nothing orders the NULL stream against a non-blocking one)
     t.sv.resize(layers);
     float* p = t.saved.as<float>();
     for (int l = 0; l < layers; ++l) {

@@ -54,5 +54,8 @@ def get_args(argv=None):
     p.add_argument("--augmix", type=int, default=1,
                    help="AugMix op chains in the view pipeline; as in the reference (tpt_cls_rl.py:150) only for the fine-grained sets (len(set_id) > 1)")
     p.add_argument("--prior_strength", type=int, default=-1, help="ResNet student: >= 0 blends running and batch BatchNorm statistics with prior s/(s+1) (tune_cls_rl.py:35-44); -1: train-mode BatchNorm")
+    # not in the reference's parser (default = unset -> the environment, then 1 = the reference's loop): tpt_cls_rl._loop_option
+    p.add_argument("--images_per_pass", type=int, default=None, help="test images handed to the engine per call (RLCF_IMAGES_PER_PASS; 1 = the reference's loop)")
+    p.add_argument("--in_flight", type=int, default=None, help="one image per engine call, this many samples side by side on their own engines / streams (RLCF_IN_FLIGHT)")
     p.add_argument("--clip_root", type=str, default="", help="directory of OpenAI-layout state dicts (<arch>.pt)")
     return p.parse_args(argv)

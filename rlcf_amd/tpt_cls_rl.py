@@ -4,6 +4,7 @@
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import torch
@@ -255,13 +256,29 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
 
 
-def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=1, in_flight=1):
+def _loop_option(value, args, name):
+    """`images_per_pass` / `in_flight` of test_time_adapt_eval: the keyword if the caller gave one, else `args.<name>` (rlcf_amd.params adds
+    --images_per_pass / --in_flight), else the environment (RLCF_IMAGES_PER_PASS / RLCF_IN_FLIGHT) — so that the reference's own main_worker,
+    which calls test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args) and nothing more (TPT/tpt_cls_rl.py:187-188),
+    reaches both forms after the import swap of INTEGRATION.md section A without an edit of the call — else 1 (the reference's loop)."""
+    if value is None:
+        value = getattr(args, name, None)
+    if value is None:
+        value = os.environ.get("RLCF_" + name.upper()) or 1
+    value = int(value)
+    if value < 1:
+        raise ValueError(f"{name} must be >= 1, got {value}")
+    return value
+
+
+def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args, device=None, reward_model=None, images_per_pass=None, in_flight=None):
     """TPT/tpt_cls_rl.py:219-279 and its twin TPT/tune_cls_rl.py:183-256 (CLIPCLS_TTA models: model.train() / model.eval() round the
     tuning step, :216-218, and model.momentum_update_model() after the clean-view inference, :240): per test image
     reset -> tune -> clean-view inference -> (EMA) -> top-1/top-5.
     `images_per_pass > 1` (not in the reference) hands that many test images to the engine at once; `in_flight > 1` (not in the reference
     either) keeps one image per engine call and runs that many samples side by side on their own engines and streams (_eval_in_flight).
     Both need independent samples: no cross-sample EMA, no per-sample encoder weights."""
+    images_per_pass, in_flight = _loop_option(images_per_pass, args, "images_per_pass"), _loop_option(in_flight, args, "in_flight")
     backbone = not hasattr(model, "prompt_learner")                 # CLIPCLS_TTA: the tune_cls_rl.py form of the loop
     full_visual = not hasattr(model, "prompt_learner") and not model.only_norm      # per-sample weights: one sample per pass
     if images_per_pass > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:

@@ -449,6 +449,32 @@ def test_harness_with_samples_in_flight_counts_what_the_one_by_one_loop_counts(l
     assert res[1] == res[lanes] and res[1][0] >= 100.0 / 7 - 1e-3, res
 
 
+def test_harness_takes_the_lanes_from_args_or_the_environment(monkeypatch):
+    """The reference's main_worker passes no keyword to test_time_adapt_eval (TPT/tpt_cls_rl.py:187-188): after the import swap the lanes are
+    asked for through RLCF_IN_FLIGHT or args.in_flight (rlcf_amd.params --in_flight), and the counts are the serial loop's."""
+    from test_gpu_parity import _harness_objects, load_golden
+    from rlcf_amd import runtime, synth, tpt_cls_rl
+    dev = torch.device(DEV)
+    g, meta = load_golden("tta_small_s1")
+    R = synth.GEOMETRIES[meta["student"]].image_resolution
+    samples = [synth.make_views(1000 + i, meta["n_views"], R) for i in range(5)]
+    calls, real = [], tpt_cls_rl._eval_in_flight
+    monkeypatch.setattr(tpt_cls_rl, "_eval_in_flight", lambda *a_: (calls.append(a_[-1]), real(*a_))[1])
+    res = []
+    for env, attr in ((None, None), ("2", None), ("2", 3)):
+        monkeypatch.delenv("RLCF_IN_FLIGHT", raising=False)
+        if env:
+            monkeypatch.setenv("RLCF_IN_FLIGHT", env)
+        model, optimizer, optim_state, reward_model, args = _harness_objects(dev, meta)
+        if attr:
+            args.in_flight = attr
+        loader = [([v.unsqueeze(0) for v in s], torch.tensor([int(g["top5"][0]) if i == 0 else (int(g["top5"][3]) if i % 2 else 0)]))
+                  for i, s in enumerate(samples)]
+        res.append(tpt_cls_rl.test_time_adapt_eval(loader, model, optimizer, optim_state, None, args, reward_model=reward_model))
+        runtime.reset_session()
+    assert calls == [2, 3] and res[0] == res[1] == res[2], (calls, res)
+
+
 def test_norm_layer_tuning_harness_with_samples_in_flight():
     """The tune_cls_rl.py form of the loop (CLIPCLS_TTA(only_norm=True), no cross-sample EMA) with two samples in flight: lanes call
     rlcf_tta_batch_ln with one image each; same hit counts as the serial loop, and a model with momentum_update=True (samples are NOT

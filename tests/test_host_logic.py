@@ -1,5 +1,6 @@
 """CPU tests of host-side logic added in round 5 (no GPU, no compute through the library): the checkpoint-grid rounding of synthetic
 state dicts and the mirror's write tracker."""
+import pytest
 import torch
 
 from rlcf_amd import synth
@@ -50,3 +51,25 @@ def test_reset_tracker_generation_and_lazy_guard_on_cpu_tensors():
     t.check(wait=True)                                # consumed: nothing left
     t.wrote()
     assert not t.at_reset(p)
+
+
+def test_loop_options_come_from_keyword_then_args_then_environment(monkeypatch):
+    """The reference's main_worker calls test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args) with nothing else
+    (TPT/tpt_cls_rl.py:187-188): `images_per_pass` / `in_flight` then come from args (rlcf_amd.params --images_per_pass / --in_flight) or
+    from RLCF_IMAGES_PER_PASS / RLCF_IN_FLIGHT, and default to the reference's one-image loop."""
+    import types
+    from rlcf_amd import params
+    from rlcf_amd.tpt_cls_rl import _loop_option
+    monkeypatch.delenv("RLCF_IN_FLIGHT", raising=False)
+    monkeypatch.delenv("RLCF_IMAGES_PER_PASS", raising=False)
+    bare = types.SimpleNamespace()                                  # the reference's own argparse namespace has neither attribute
+    assert _loop_option(None, bare, "in_flight") == 1 and _loop_option(None, bare, "images_per_pass") == 1
+    monkeypatch.setenv("RLCF_IN_FLIGHT", "2")
+    assert _loop_option(None, bare, "in_flight") == 2 and _loop_option(None, bare, "images_per_pass") == 1
+    a = params.get_args(["--in_flight", "3"])
+    assert a.images_per_pass is None and _loop_option(None, a, "in_flight") == 3          # args before the environment
+    assert _loop_option(1, a, "in_flight") == 1                                            # the keyword before both
+    assert _loop_option(None, params.get_args([]), "in_flight") == 2                       # unset flag -> environment
+    monkeypatch.setenv("RLCF_IMAGES_PER_PASS", "0")
+    with pytest.raises(ValueError):
+        _loop_option(None, bare, "images_per_pass")
