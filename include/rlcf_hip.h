@@ -268,7 +268,8 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
  * torch.mean over models (:255).  n must equal the number of reward slots.  Default: slot 0 alone, weight 1. */
 int rlcf_engine_set_reward_mix(rlcf_engine*, const float* mix, int n, int mean);
 void rlcf_engine_destroy(rlcf_engine*);
-/* Copy one OpenAI-layout state-dict tensor (TPT/clip/model.py:399-436) into the engine. */
+/* Copy one OpenAI-layout state-dict tensor (TPT/clip/model.py:399-436) into the engine.  The call takes no stream: dev_ptr must be complete
+ * on the device when it is made (it is read on the NULL stream); the copy is complete when the call returns. */
 int rlcf_engine_load_weight(rlcf_engine*, int which, const char* key, const float* dev_ptr, int64_t numel);
 /* After all weights: checks completeness, builds transposed / low-precision copies. */
 int rlcf_engine_finalize(rlcf_engine*, rlcf_stream stream);

@@ -358,6 +358,8 @@ int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const fl
     DevBuf& d = e->model[which].raw[key];
     if (d.bytes != (size_t)numel * sizeof(float)) { d.release(); int rc = d.ensure((size_t)numel * sizeof(float)); if (rc) return rc; }
     RLCF_HIP_CHECK(hipMemcpy(d.p, dev_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice));
+    RLCF_HIP_CHECK(hipStreamSynchronize(nullptr));     // a device-to-device hipMemcpy runs on the NULL stream and does not wait for it: the copy is
+                                                       // complete before finalize / a call on a non-blocking stream reads the weight
     e->model[which].finalized = false;
     return RLCF_OK;
 }
