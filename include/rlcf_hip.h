@@ -11,8 +11,12 @@
  *     caller-owned (torch) memory, contiguous row-major, unless marked HOST;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *   - return 0 on success, negative rlcf_status on error (rlcf_last_error() has text);
- *   - an engine is not thread-safe; no allocation happens on the per-sample path: every scratch buffer of the engine calls
- *     belongs to the engine (one engine = one device, one stream at a time; two engines never share memory).  The stateless
+ *   - an engine is not thread-safe; every scratch buffer of the engine calls belongs to the engine (one engine = one device, one
+ *     stream at a time; two engines never share memory).  Workspaces whose size depends on the call (views x tokens, class bank)
+ *     are sized by the FIRST call that needs them and only ever grow: a steady stream of equal-sized samples allocates nothing
+ *     after its first call.  The growth path is hipMalloc (+ hipFree of the smaller buffer: both synchronise the device) and a
+ *     fill enqueued on the CALLER's stream, so it is ordered against the kernels that follow on any kind of stream — blocking,
+ *     non-blocking or the NULL stream (the whole GPU suite runs in both modes: tests/conftest.py, RLCF_TEST_STREAM).  The stateless
  *     op-level calls that need scratch (rlcf_gemm_nt in split-f16 mode, rlcf_reward_loss*) take it from the stream-ordered
  *     allocator of `stream` (hipMallocAsync / hipFreeAsync);
  *   - an engine owns one side stream: rlcf_tta_sample (one test image per call) forks the reward models' tower pass onto it behind
@@ -359,12 +363,43 @@ int rlcf_engine_ln_param_count(rlcf_engine*);
  * copies them into float32 parameters) — and how many do not (*others, may be NULL).  For such a weight the a_hi . w_lo MFMA pass of the 256x256
  * split-f16 kernel adds exact zeros and is dropped at launch: the same bits in two passes instead of three (RLCF_X3_WLO0=0 at finalize: off). */
 int rlcf_engine_f16_grid_weights(rlcf_engine*, int which, int* others);
+/* (ABI version 14) RLCF_PREC_F16 only.  on = 1: the image towers keep the residual stream as f16 rows and fold every LayerNorm into the
+ * product that follows it (the reference's own autocast arithmetic: its LayerNorm casts back to the fp16 input type,
+ * TPT/clip/model.py:157-163, and x + attention(...) adds fp16 tensors, :187-192, under TPT/tpt_cls_rl.py:52) — 7 % faster, and on the
+ * 32-sample reference stream one top-1 of 32 differs from the reference's float32 run.  Default off (f32 residual stream, 32 / 32):
+ * the environment variable RLCF_F16_LNFOLD=1 when the engine is created turns it on as well. */
+int rlcf_engine_set_f16_lnfold(rlcf_engine*, int on);
 /* on = 0: one-image calls keep every launch on the caller's stream instead of moving the reward models' pass to the engine's own side
  * stream (engine_tta_sample; what RLCF_NO_OVERLAP=1 does process-wide).  For engines that serve samples IN FLIGHT side by side from
  * several host threads (rlcf_amd.tpt_cls_rl.test_time_adapt_eval(in_flight=K), one engine per lane): the overlap comes from the other
  * lanes, and a side stream that lands on the hardware queue of another lane's stream would serialise the two.  Default on.
  * Replaces nothing in the reference (its loop runs one sample at a time, TPT/tpt_cls_rl.py:233-262). */
 int rlcf_engine_set_side_stream(rlcf_engine*, int on);
+/* (ABI version 14) Samples IN FLIGHT from ONE host thread.  The reference feeds its loop one test image per call
+ * (TPT/tpt_cls_rl.py:233-262); a sample's step is a 64-view tower pass that fills the chip followed by a long tail of few-row launches
+ * that does not.  A lanes object holds K engines over the same checkpoints and class bank (each with its own weights copies, scratch
+ * and state: rlcf_engine_create x K) and one non-blocking stream per engine; rlcf_lanes_submit enqueues `count` test images (normally
+ * 1) as ONE rlcf_tta_batch / rlcf_tta_batch_ln (norm_layers != 0) call on the next lane, round robin, behind an event recorded on
+ * `producer` (the stream the views were produced on), and returns that lane's index (>= 0) or a negative rlcf_status.  Nothing waits
+ * on the host: the caller's thread enqueues lane after lane and the device runs them side by side — sample i + 1's tower pass under
+ * sample i's tail.  Per-sample arithmetic is exactly the one-image call's (bit-identical results).  rlcf_lanes_join makes `consumer`
+ * wait for everything submitted so far (events; no host wait); views / outputs of a sample must stay alive until its lane has run
+ * (rlcf_lanes_stream exposes lane k's hipStream_t, e.g. for torch's record_stream).  Creating a lanes object turns the engines' side
+ * stream off (rlcf_engine_set_side_stream(e, 0)); destroying it waits for the lanes and restores the setting; the engines stay the
+ * caller's.  rlcf_tta_lanes = create + `count` submits of one image each + join + destroy, for callers that hold a whole batch.
+ * rlcf_top5_hits: out[0] += #(target[b] == top5[b, 0]), out[1] += #(target[b] in top5[b, :]) — the loop's hit counters
+ * (accuracy() + AverageMeter, TPT/tpt_cls_rl.py:265-268) from the engine's own top-5 output, accumulated on the device. */
+typedef struct rlcf_lanes rlcf_lanes;
+rlcf_lanes* rlcf_lanes_create(rlcf_engine* const* engines, int n);
+void rlcf_lanes_destroy(rlcf_lanes*);
+int rlcf_lanes_count(const rlcf_lanes*);
+rlcf_stream rlcf_lanes_stream(const rlcf_lanes*, int k);
+int rlcf_lanes_submit(rlcf_lanes*, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
+                      int norm_layers, rlcf_stream producer);
+int rlcf_lanes_join(rlcf_lanes*, rlcf_stream consumer);
+int rlcf_tta_lanes(rlcf_engine* const* engines, int lanes, const float* views, int count, int N, const rlcf_tta_args* args,
+                   float* final_logits, int32_t* top5, int norm_layers, rlcf_stream stream);
+int rlcf_top5_hits(const int32_t* top5, const int64_t* target, int B, float* out, rlcf_stream stream);
 /* A ModifiedResNet student (arch RN50 .. RN50x64) has BatchNorms where the ViT has LayerNorms: CLIPCLS_TTA(only_norm=True) tunes the
  * weight / bias of every BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485; downsample.1 stays frozen) and
  * rlcf_tta_sample_ln / rlcf_tta_batch_ln / rlcf_engine_{ln_param_count,get_ln_params,set_ln_params,momentum_update} serve them

@@ -133,6 +133,15 @@ SIGNATURES = {
     "rlcf_accuracy": (I, [P, P, I, I, P, P, P]),
     "rlcf_engine_set_bn_prior_strength": (I, [P, I]),
     "rlcf_engine_set_side_stream": (I, [P, I]),
+    "rlcf_engine_set_f16_lnfold": (I, [P, I]),
+    "rlcf_lanes_create": (P, [P, I]),
+    "rlcf_lanes_destroy": (None, [P]),
+    "rlcf_lanes_count": (I, [P]),
+    "rlcf_lanes_stream": (P, [P, I]),
+    "rlcf_lanes_submit": (I, [P, P, I, I, C.POINTER(TTAArgs), P, P, I, P]),
+    "rlcf_lanes_join": (I, [P, P]),
+    "rlcf_tta_lanes": (I, [P, I, P, I, I, C.POINTER(TTAArgs), P, P, I, P]),
+    "rlcf_top5_hits": (I, [P, P, I, P, P]),
     "rlcf_engine_bn_stats_count": (I, [P]),
     "rlcf_engine_encode_image_bn": (I, [P, P, I, P, P]),
     "rlcf_engine_encode_image_bn_form": (I, [P, P, I, I, P, P]),

@@ -33,7 +33,7 @@ int rlcf_func_lds(const void* fn, size_t bytes) {
 extern "C" {
 
 const char* rlcf_last_error(void) { return g_err; }
-int rlcf_version(void) { return 13; }   // 13: rlcf_engine_set_side_stream (lane engines of samples in flight keep to the caller's stream); 12: rlcf_avg_entropy, rlcf_accuracy (the harness mirror's conveniences as kernels); 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
+int rlcf_version(void) { return 14; }   // 14: samples in flight from one host thread (rlcf_lanes_*, rlcf_tta_lanes), rlcf_top5_hits; 13: rlcf_engine_set_side_stream (lane engines of samples in flight keep to the caller's stream); 12: rlcf_avg_entropy, rlcf_accuracy (the harness mirror's conveniences as kernels); 11: rlcf_engine_f16_grid_weights (two-pass products for weights on the fp16 grid); 10: rlcf_gemm_f16_ln / rlcf_ln_stats_final / rlcf_resid16_init (LayerNorm folded into the single-pass f16 products); 9: rlcf_gemm_f16 (single-pass f16 GEMM of the performance mode); 8: rlcf_make_views_hard (the hard_aug pre-augmentation); 7: every-parameter tuning of a ModifiedResNet student (rlcf_tta_sample_visual, rlcf_engine_encode_image_bn_form); 6: pair-operand attention, BatchNorm tuning of a ResNet student (rlcf_engine_*bn*), profile kinds 12 / 13; 5: text -> image retrieval; 4: rlcf_tta_args.n_sel, rlcf_tta_out.step_skipped, rlcf_engine_reset_visual_state, engine-owned scratch
 //    // 2: rlcf_clip_cfg.vision_stages, reward slots, views, LN batch; 3: rlcf_tta_out.vis_*, rlcf_tta_sample_visual
 
 // ------------------------------------------------------------------ op level
@@ -157,12 +157,17 @@ int rlcf_gemm_skinny(const float* A, int lda, const void* W_pairs, const float* 
     // stateless call: the K-slice scratch (and the inverse-scale word behind it) comes from the stream-ordered allocator of the CURRENT
     // device, per call — two callers on different streams / threads / GPUs never share it (the engine passes its own workspace)
     hipStream_t st = (hipStream_t)stream;
-    const size_t ws_bytes = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)8 * M * N * sizeof(float), 4096));     // <= 8 K slices of [M, N]
+    // sized by the launcher's own K-slice rule (min(K / 256, 256 / tiles) slices of [M, N], gemm_f16x3.hip) up to the engine's workspace
+    // size, so that this call and the engine's pick the same number of slices and sum in the same order (bit-identical results)
+    const int tiles = ((N + 31) / 32) * ((M + 127) / 128);
+    const size_t slices = (size_t)std::max(1, std::min(K / 256, std::max(1, 256 / tiles)));
+    const size_t ws_bytes = std::min<size_t>((size_t)X3_SPLITK_WS_BYTES, std::max<size_t>(slices * M * N * sizeof(float), 4096));
     float* ws = nullptr;
     RLCF_HIP_CHECK(hipMallocAsync((void**)&ws, ws_bytes + 256, st));
     const int rc = launch_gemm_skinny_x3(A, lda, W_pairs, bias, residual, ldr, aux, ldaux, C, ldc, M, N, K, alpha, epilogue, amax_in, nullptr, ws,
                                          ws_bytes, (float*)((char*)ws + ws_bytes), st, local_amax);
-    (void)hipFreeAsync(ws, st);
+    const hipError_t fe = hipFreeAsync(ws, st);
+    if (fe != hipSuccess && rc == RLCF_OK) { rlcf_set_error("rlcf_gemm_skinny: hipFreeAsync: %s", hipGetErrorString(fe)); return RLCF_ERR_HIP; }
     return rc;
 }
 int rlcf_split_pairs(const float* x, void* pairs, int64_t n, int precision, rlcf_stream stream) {
@@ -295,6 +300,7 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
     rlcf_engine* e = new (std::nothrow) rlcf_engine();
     if (!e) return nullptr;
     e->precision = precision; e->max_views = max_views; e->max_classes = max_classes;
+    { const char* ev = getenv("RLCF_F16_LNFOLD"); e->f16_lnfold = ev ? (atoi(ev) != 0) : 0; }
     e->model[0].cfg = *student; e->model[0].present = true;
     e->n_rewards = n_rewards;
     for (int m = 0; m < n_rewards; ++m) { e->model[1 + m].cfg = rewards[m]; e->model[1 + m].present = true; }
@@ -344,7 +350,11 @@ rlcf_engine* rlcf_engine_create_ensemble(const rlcf_clip_cfg* student, const rlc
 
 void rlcf_engine_destroy(rlcf_engine* e) {
     if (!e) return;
-    (void)hipDeviceSynchronize();
+    // wait for THIS engine's work only: the streams its calls were enqueued on and its own side stream — not hipDeviceSynchronize, which
+    // would also wait for every other lane's queue.  (The hipFree of each buffer below still synchronises the device by HIP's own rules:
+    // engines are created and destroyed at session boundaries, not per sample.)
+    for (hipStream_t s : e->used_streams) (void)hipStreamSynchronize(s);
+    if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -366,37 +376,37 @@ int rlcf_engine_load_weight(rlcf_engine* e, int which, const char* key, const fl
 int rlcf_engine_finalize(rlcf_engine* e, rlcf_stream stream) {
     RLCF_ARG_CHECK(e);
     for (int w = 0; w <= RLCF_MAX_REWARDS; ++w)
-        if (e->model[w].present) { int rc = engine_finalize(e, w, (hipStream_t)stream); if (rc) return rc; }
+        if (e->model[w].present) { int rc = engine_finalize(e, w, engine_stream(e, stream)); if (rc) return rc; }
     return RLCF_OK;
 }
 int rlcf_engine_set_class_bank(rlcf_engine* e, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
                                rlcf_stream stream) {
     RLCF_ARG_CHECK(e && tokens_host && (ctx_init || n_ctx == 0));
-    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream);
+    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, engine_stream(e, stream));
 }
 int rlcf_engine_set_class_bank_ex(rlcf_engine* e, const int32_t* tokens_host, int C, int n_ctx, const float* ctx_init, int text_mode,
                                   const int32_t* student_tokens_host, const int32_t* ctx_pos_host, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && tokens_host && ctx_init && student_tokens_host && ctx_pos_host && n_ctx > 0);
     for (int i = 0; i < C * n_ctx; ++i) RLCF_ARG_CHECK(ctx_pos_host[i] >= 1 && ctx_pos_host[i] < e->model[RLCF_STUDENT].cfg.context_length);
-    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, (hipStream_t)stream, student_tokens_host, ctx_pos_host);
+    return engine_set_class_bank(e, tokens_host, C, n_ctx, ctx_init, text_mode, engine_stream(e, stream), student_tokens_host, ctx_pos_host);
 }
 int rlcf_encode_image(rlcf_engine* e, int which, const float* images, int n, float* feats, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && which_ok(e, which) && images && feats);
-    return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream);
+    return engine_encode_image(e, which, images, n, feats, engine_stream(e, stream));
 }
 int rlcf_encode_image_resized(rlcf_engine* e, int which, const float* images, int n, int in_res, float* feats, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && which_ok(e, which) && images && feats && in_res > 0);
-    return engine_encode_image(e, which, images, n, feats, (hipStream_t)stream, in_res);
+    return engine_encode_image(e, which, images, n, feats, engine_stream(e, stream), in_res);
 }
 int rlcf_text_features(rlcf_engine* e, const float* ctx, float* txt, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && txt && (ctx || e->n_ctx == 0));
-    return engine_text_features(e, RLCF_STUDENT, ctx, txt, (hipStream_t)stream);
+    return engine_text_features(e, RLCF_STUDENT, ctx, txt, engine_stream(e, stream));
 }
 int rlcf_reward_class_features(rlcf_engine* e, int which, float* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && out && which >= RLCF_REWARD && which_ok(e, which));
     if (e->C <= 0) { rlcf_set_error("reward class bank not set"); return RLCF_ERR_STATE; }
     RLCF_HIP_CHECK(hipMemcpyAsync(out, e->reward_cls[which - RLCF_REWARD].p, (size_t)e->C * e->model[which].cfg.embed_dim * sizeof(float),
-                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                                  hipMemcpyDeviceToDevice, engine_stream(e, stream)));
     return RLCF_OK;
 }
 int rlcf_engine_set_reward_mix(rlcf_engine* e, const float* mix, int n, int mean) {
@@ -407,47 +417,47 @@ int rlcf_engine_set_reward_mix(rlcf_engine* e, const float* mix, int n, int mean
 }
 int rlcf_logits(rlcf_engine* e, const float* img, int n, const float* txt, int C, float* logits, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && img && txt && logits && n > 0 && C > 0);
-    return engine_logits(e, img, n, txt, C, logits, (hipStream_t)stream);
+    return engine_logits(e, img, n, txt, C, logits, engine_stream(e, stream));
 }
 int rlcf_text_backward_dense(rlcf_engine* e, const float* ctx, const float* img, int n, const float* dlogits, float* dctx,
                              rlcf_stream stream) {
     RLCF_ARG_CHECK(e && ctx && img && dlogits && dctx && n > 0);
-    return engine_text_backward_dense(e, ctx, img, n, dlogits, dctx, (hipStream_t)stream);
+    return engine_text_backward_dense(e, ctx, img, n, dlogits, dctx, engine_stream(e, stream));
 }
 int rlcf_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args);
-    return engine_tta_sample(e, views, N, args, out, (hipStream_t)stream);
+    return engine_tta_sample(e, views, N, args, out, engine_stream(e, stream));
 }
 int rlcf_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args);
-    return engine_tta_sample_ln(e, views, N, args, out, (hipStream_t)stream);
+    return engine_tta_sample_ln(e, views, N, args, out, engine_stream(e, stream));
 }
 int rlcf_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args);
-    return engine_tta_sample_visual(e, views, N, args, out, (hipStream_t)stream);
+    return engine_tta_sample_visual(e, views, N, args, out, engine_stream(e, stream));
 }
 int rlcf_tta_retrieval_image(rlcf_engine* e, const float* images, int n, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && images && args && n > 0);
     rlcf_tta_args a = *args;
     a.selection_p = 1.0f; a.n_sel = n; a.flags |= RLCF_F_NO_SELECTION;     // every query image carries reward and gradient, in loader order
-    return engine_tta_sample_visual(e, images, n, &a, out, (hipStream_t)stream);
+    return engine_tta_sample_visual(e, images, n, &a, out, engine_stream(e, stream));
 }
 int rlcf_engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, rlcf_stream stream) {
     RLCF_ARG_CHECK(e);
-    return engine_set_image_bank(e, student_feats, reward_feats, n, (hipStream_t)stream);
+    return engine_set_image_bank(e, student_feats, reward_feats, n, engine_stream(e, stream));
 }
 int rlcf_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens_host, const rlcf_tta_args* args, const rlcf_tta_out* out, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && tokens_host && args);
-    return engine_tta_retrieval_text(e, tokens_host, args, out, (hipStream_t)stream);
+    return engine_tta_retrieval_text(e, tokens_host, args, out, engine_stream(e, stream));
 }
 int64_t rlcf_engine_text_param_count(rlcf_engine* e, int* ln_count, rlcf_stream stream) {
-    if (!e || engine_text_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;
+    if (!e || engine_text_enable(e, engine_stream(e, stream)) != RLCF_OK) return 0;
     if (ln_count) *ln_count = e->tln_count;
     return (int64_t)e->tw_count;
 }
 int rlcf_engine_text_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && offsets && numels);
-    int rc = engine_text_enable(e, (hipStream_t)stream);
+    int rc = engine_text_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     RLCF_ARG_CHECK(max_entries >= (int)e->tw_slots.size());
     for (size_t i = 0; i < e->tw_slots.size(); ++i) { offsets[i] = (int64_t)e->tw_slots[i].off; numels[i] = (int64_t)e->tw_slots[i].numel; }
@@ -455,16 +465,16 @@ int rlcf_engine_text_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* num
 }
 int rlcf_engine_get_text_params(rlcf_engine* e, float* flat, float* ln, int which, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && (flat || ln) && which >= 0 && which <= 1);
-    int rc = engine_text_enable(e, (hipStream_t)stream);
+    int rc = engine_text_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
-    if (flat) RLCF_HIP_CHECK(hipMemcpyAsync(flat, (which ? e->tw_init : e->tw).p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (ln) RLCF_HIP_CHECK(hipMemcpyAsync(ln, (which ? e->tln_init : e->tln).p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (flat) RLCF_HIP_CHECK(hipMemcpyAsync(flat, (which ? e->tw_init : e->tw).p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
+    if (ln) RLCF_HIP_CHECK(hipMemcpyAsync(ln, (which ? e->tln_init : e->tln).p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
     return RLCF_OK;
 }
 int rlcf_engine_momentum_update_text(rlcf_engine* e, const float* cur_flat, const float* cur_ln, double momentum, double update_w, int apply,
                                      rlcf_stream stream) {
     RLCF_ARG_CHECK(e && cur_flat && cur_ln && momentum >= 0.0 && momentum <= 1.0);
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = engine_stream(e, stream);
     int rc = engine_text_enable(e, st);
     if (rc != RLCF_OK) return rc;
     rc = launch_momentum_update(e->tw_mom.as<float>(), cur_flat, e->tw_clip.as<float>(), e->tw_init.as<float>(), (int64_t)e->tw_count, momentum,
@@ -476,12 +486,12 @@ int rlcf_engine_momentum_update_text(rlcf_engine* e, const float* cur_flat, cons
     return apply ? engine_text_reset(e, st, true) : RLCF_OK;      // reset_initial() loads the new initial_state_dict: live copy + derived forms follow
 }
 int64_t rlcf_engine_visual_param_count(rlcf_engine* e, rlcf_stream stream) {
-    if (!e || engine_visual_enable(e, (hipStream_t)stream) != RLCF_OK) return 0;
+    if (!e || engine_visual_enable(e, engine_stream(e, stream)) != RLCF_OK) return 0;
     return (int64_t)e->vw_count;
 }
 int rlcf_engine_visual_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* numels, int max_entries, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && offsets && numels);
-    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    int rc = engine_visual_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     RLCF_ARG_CHECK(max_entries >= (int)e->vw_slots.size());
     for (size_t i = 0; i < e->vw_slots.size(); ++i) { offsets[i] = (int64_t)e->vw_slots[i].off; numels[i] = (int64_t)e->vw_slots[i].numel; }
@@ -489,32 +499,32 @@ int rlcf_engine_visual_param_layout(rlcf_engine* e, int64_t* offsets, int64_t* n
 }
 int rlcf_engine_get_visual_params(rlcf_engine* e, float* out, int which, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && out && which >= 0 && which <= 3);
-    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    int rc = engine_visual_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     const DevBuf* src[4] = {&e->vw, &e->vw_init, &e->vw_clip, &e->vw_mom};
-    RLCF_HIP_CHECK(hipMemcpyAsync(out, src[which]->p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    RLCF_HIP_CHECK(hipMemcpyAsync(out, src[which]->p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
     return RLCF_OK;
 }
 int rlcf_engine_set_visual_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && in);
-    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    int rc = engine_visual_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, in, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, in, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
     e->vw_dirty = true;                  // (a later tuning call starts with its own reset)
-    return engine_visual_refresh(e, (hipStream_t)stream);
+    return engine_visual_refresh(e, engine_stream(e, stream));
 }
 int rlcf_engine_momentum_update_visual(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && current && momentum >= 0.0 && momentum <= 1.0);
-    int rc = engine_visual_enable(e, (hipStream_t)stream);
+    int rc = engine_visual_enable(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     rc = launch_momentum_update(e->vw_mom.as<float>(), current, e->vw_clip.as<float>(), e->vw_init.as<float>(), (int64_t)e->vw_count, momentum,
-                                update_w, apply, (hipStream_t)stream);
+                                update_w, apply, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     if (apply) {         // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy and its derived forms follow
-        RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
         e->vw_dirty = false;
         e->vw_init_is_ckpt = false;      // (an averaged reset state is off the fp16 grid: three MFMA passes from here on)
-        return engine_visual_refresh(e, (hipStream_t)stream);
+        return engine_visual_refresh(e, engine_stream(e, stream));
     }
     return RLCF_OK;
 }
@@ -564,6 +574,11 @@ static int norm_ready(rlcf_engine* e, hipStream_t st) {
     if (e->ln_count <= 0) { rlcf_set_error("the student has no tunable norm layers (not finalized?)"); return RLCF_ERR_STATE; }
     return RLCF_OK;
 }
+int rlcf_engine_set_f16_lnfold(rlcf_engine* e, int on) {
+    RLCF_ARG_CHECK(e);
+    e->f16_lnfold = on ? 1 : 0;
+    return RLCF_OK;
+}
 int rlcf_engine_set_side_stream(rlcf_engine* e, int on) {
     RLCF_ARG_CHECK(e);
     e->no_side = !on;
@@ -578,8 +593,8 @@ int rlcf_engine_encode_image_bn_form(rlcf_engine* e, const float* images, int n,
     RLCF_ARG_CHECK(e && images && out && n > 0 && n <= e->max_views && form <= 0);      // feat_raw / the GEMM scratch are sized for max_views
     ClipModel& s = e->model[RLCF_STUDENT];
     if (!s.finalized || !is_resnet(s.cfg)) { rlcf_set_error("rlcf_engine_encode_image_bn needs a finalized ModifiedResNet student"); return RLCF_ERR_STATE; }
-    const int rc = engine_bn_enable(e, (hipStream_t)stream);
-    return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, (hipStream_t)stream, form < 0 ? -1 : 0);
+    const int rc = engine_bn_enable(e, engine_stream(e, stream));
+    return rc != RLCF_OK ? rc : rn_forward_train(e, s, images, n, out, engine_stream(e, stream), form < 0 ? -1 : 0);
 }
 int rlcf_engine_encode_image_bn(rlcf_engine* e, const float* images, int n, float* out, rlcf_stream stream) {
     return rlcf_engine_encode_image_bn_form(e, images, n, -1, out, stream);
@@ -596,42 +611,42 @@ int rlcf_engine_get_bn_stats(rlcf_engine* e, float* out, int pristine, rlcf_stre
     RLCF_ARG_CHECK(e && out);
     const int n = rlcf_engine_bn_stats_count(e);
     if (n <= 0) { rlcf_set_error("the student has no BatchNorm statistics (VisionTransformer, RLCF_PREC_F16, or not finalized)"); return RLCF_ERR_STATE; }
-    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
+    { const int rc = norm_ready(e, engine_stream(e, stream)); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->bn_stats_init.p : e->bn_stats.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice,
-                                  (hipStream_t)stream));
+                                  engine_stream(e, stream)));
     return RLCF_OK;
 }
 int rlcf_engine_get_ln_params(rlcf_engine* e, float* out, int pristine, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && out);
-    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
+    { const int rc = norm_ready(e, engine_stream(e, stream)); if (rc != RLCF_OK) return rc; }
     RLCF_HIP_CHECK(hipMemcpyAsync(out, pristine ? e->ln_init.p : e->ln_params.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
-                                  (hipStream_t)stream));
+                                  engine_stream(e, stream)));
     return RLCF_OK;
 }
 int rlcf_engine_set_ln_params(rlcf_engine* e, const float* in, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && in);
-    { const int rc = norm_ready(e, (hipStream_t)stream); if (rc != RLCF_OK) return rc; }
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    { const int rc = norm_ready(e, engine_stream(e, stream)); if (rc != RLCF_OK) return rc; }
+    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, in, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice, engine_stream(e, stream)));
     e->lnfold_stale = true;          // (RLCF_PREC_F16: weights with the finalize-time gamma / beta folded in are no longer valid)
     return RLCF_OK;
 }
 int rlcf_engine_momentum_update(rlcf_engine* e, const float* current, double momentum, double update_w, int apply, rlcf_stream stream) {
     RLCF_ARG_CHECK(e && current && momentum >= 0.0 && momentum <= 1.0);
-    int rc = norm_ready(e, (hipStream_t)stream);
+    int rc = norm_ready(e, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     rc = launch_momentum_update(e->ln_mom.as<float>(), current, e->ln_clip.as<float>(), e->ln_init.as<float>(), e->ln_count, momentum,
-                                    update_w, apply, (hipStream_t)stream);
+                                    update_w, apply, engine_stream(e, stream));
     if (rc != RLCF_OK) return rc;
     if (apply) {         // model.reset() loads the new initial_state_dict (custom_clip.py:456-458): the live copy follows
         RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, (size_t)e->ln_count * sizeof(float), hipMemcpyDeviceToDevice,
-                                      (hipStream_t)stream));
+                                      engine_stream(e, stream)));
         e->lnfold_stale = true;
     }
     return RLCF_OK;
 }
 int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
     RLCF_ARG_CHECK(e);
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = engine_stream(e, stream);
     { const int rc = norm_ready(e, st); if (rc != RLCF_OK) return rc; }
     const size_t nb = (size_t)e->ln_count * sizeof(float);
     for (DevBuf* d : {&e->ln_params, &e->ln_init, &e->ln_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->ln_clip.p, nb, hipMemcpyDeviceToDevice, st));
@@ -640,20 +655,98 @@ int rlcf_engine_reset_visual_state(rlcf_engine* e, rlcf_stream stream) {
         for (DevBuf* d : {&e->vw, &e->vw_init, &e->vw_mom}) RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->vw_clip.p, vb, hipMemcpyDeviceToDevice, st));
         e->vw_dirty = false;
         e->vw_init_is_ckpt = true;
+        e->lnfold_stale = false;
         return engine_visual_refresh(e, st, true);
     }
+    e->lnfold_stale = false;         // the live LayerNorm parameters are the checkpoint's again: the gamma / beta folded at finalize match them
     return RLCF_OK;
 }
 int rlcf_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                    rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
-    return engine_tta_batch(e, views, count, N, args, final_logits, top5, (hipStream_t)stream);
+    return engine_tta_batch(e, views, count, N, args, final_logits, top5, engine_stream(e, stream));
 }
 int rlcf_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
                       rlcf_stream stream) {
     RLCF_ARG_CHECK(e && views && args && count > 0 && top5);
-    return engine_tta_batch_ln(e, views, count, N, args, final_logits, top5, (hipStream_t)stream);
+    return engine_tta_batch_ln(e, views, count, N, args, final_logits, top5, engine_stream(e, stream));
 }
+// ------------------------------------------------------------------ samples in flight (ABI 14)
+// K engines over the same checkpoints, one non-blocking stream each; sample i runs on lane i mod K as exactly the one-image call
+// (engine_tta_batch with one image), enqueued from the CALLER's thread: the hand-offs are events, there is no host thread and no queue.
+struct rlcf_lanes {
+    std::vector<rlcf_engine*> eng;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> done;        // recorded on lane k after its last submitted sample
+    std::vector<bool> side_was_off;
+    hipEvent_t ready = nullptr;          // "the producer's work so far" (views, labels), re-recorded per submit
+    int next = 0;
+};
+void rlcf_lanes_destroy(rlcf_lanes* l) {
+    if (!l) return;
+    for (size_t k = 0; k < l->st.size(); ++k) if (l->st[k]) { (void)hipStreamSynchronize(l->st[k]); (void)hipStreamDestroy(l->st[k]); }
+    for (hipEvent_t ev : l->done) if (ev) (void)hipEventDestroy(ev);
+    if (l->ready) (void)hipEventDestroy(l->ready);
+    for (size_t k = 0; k < l->eng.size() && k < l->side_was_off.size(); ++k) l->eng[k]->no_side = l->side_was_off[k];
+    delete l;
+}
+rlcf_lanes* rlcf_lanes_create(rlcf_engine* const* engines, int n) {
+    if (!engines || n < 1 || n > 16) { rlcf_set_error("rlcf_lanes_create: 1..16 engines"); return nullptr; }
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j <= k; ++j)
+            if (!engines[k] || (j < k && engines[j] == engines[k])) { rlcf_set_error("rlcf_lanes_create: engines must be distinct (an engine serves one call at a time)"); return nullptr; }
+    rlcf_lanes* l = new rlcf_lanes();
+    bool ok = hipEventCreateWithFlags(&l->ready, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < n && ok; ++k) {
+        hipStream_t s = nullptr; hipEvent_t ev = nullptr;
+        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        l->st.push_back(s); l->done.push_back(ev);
+    }
+    if (!ok) { rlcf_set_error("rlcf_lanes_create: stream / event creation failed"); rlcf_lanes_destroy(l); return nullptr; }
+    for (int k = 0; k < n; ++k) {
+        l->eng.push_back(engines[k]);
+        l->side_was_off.push_back(engines[k]->no_side);
+        engines[k]->no_side = true;      // the overlap comes from the other lanes: a lane's one-image call keeps to the lane's stream
+    }
+    return l;
+}
+int rlcf_lanes_count(const rlcf_lanes* l) { return l ? (int)l->eng.size() : 0; }
+rlcf_stream rlcf_lanes_stream(const rlcf_lanes* l, int k) { return (l && k >= 0 && k < (int)l->st.size()) ? (rlcf_stream)l->st[k] : nullptr; }
+int rlcf_lanes_submit(rlcf_lanes* l, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits, int32_t* top5,
+                      int norm_layers, rlcf_stream producer) {
+    RLCF_ARG_CHECK(l && views && args && count > 0 && top5);
+    const int k = l->next;
+    RLCF_HIP_CHECK(hipEventRecord(l->ready, (hipStream_t)producer));
+    RLCF_HIP_CHECK(hipStreamWaitEvent(l->st[k], l->ready, 0));
+    rlcf_engine* e = l->eng[k];
+    const int rc = norm_layers ? engine_tta_batch_ln(e, views, count, N, args, final_logits, top5, engine_stream(e, (rlcf_stream)l->st[k]))
+                               : engine_tta_batch(e, views, count, N, args, final_logits, top5, engine_stream(e, (rlcf_stream)l->st[k]));
+    RLCF_HIP_CHECK(hipEventRecord(l->done[k], l->st[k]));       // (also after an error: a join must not miss what was enqueued)
+    l->next = (k + 1) % (int)l->eng.size();
+    return rc < 0 ? rc : k;
+}
+int rlcf_lanes_join(rlcf_lanes* l, rlcf_stream consumer) {
+    RLCF_ARG_CHECK(l);
+    for (size_t k = 0; k < l->st.size(); ++k) RLCF_HIP_CHECK(hipStreamWaitEvent((hipStream_t)consumer, l->done[k], 0));
+    return RLCF_OK;
+}
+int rlcf_tta_lanes(rlcf_engine* const* engines, int lanes, const float* views, int count, int N, const rlcf_tta_args* args, float* final_logits,
+                   int32_t* top5, int norm_layers, rlcf_stream stream) {
+    RLCF_ARG_CHECK(engines && lanes >= 1 && views && args && count > 0 && top5);
+    rlcf_lanes* l = rlcf_lanes_create(engines, lanes);
+    if (!l) return RLCF_ERR_HIP;
+    const rlcf_clip_cfg& c = engines[0]->model[RLCF_STUDENT].cfg;
+    const size_t per = (size_t)N * 3 * c.image_resolution * c.image_resolution;
+    int rc = RLCF_OK;
+    for (int i = 0; i < count && rc >= 0; ++i)
+        rc = rlcf_lanes_submit(l, views + (size_t)i * per, 1, N, args, final_logits ? final_logits + (size_t)i * engines[0]->C : nullptr, top5 + (size_t)i * 5,
+                               norm_layers, stream);
+    const int rj = rlcf_lanes_join(l, stream);
+    rlcf_lanes_destroy(l);               // (waits for the lanes: this convenience form is synchronous at its end; a loop keeps a lanes object)
+    return rc < 0 ? rc : rj;
+}
+int rlcf_top5_hits(const int32_t* top5, const int64_t* target, int B, float* out, rlcf_stream stream) { return launch_top5_hits(top5, target, B, out, (hipStream_t)stream); }
+
 double rlcf_engine_last_flops(rlcf_engine* e) { return e ? e->last_flops : 0.0; }
 int rlcf_engine_text_rows(rlcf_engine* e) { return e ? e->lay[0].T : 0; }
 

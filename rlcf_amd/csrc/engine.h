@@ -217,6 +217,7 @@ struct rlcf_engine {
     // passes), `--prior_strength` (< 0: torch's train-mode BatchNorm), activations saved by the train-form forward
     DevBuf rn_wg_tmp;                // GEMM-layout weight gradient of one 3x3 convolution / the k|v projection (every-parameter tuning)
     DevBuf bn_stats, bn_stats_init, bn_scratch, bn_saved, bn_grad_a, bn_grad_b, bn_grad_c, bn_dlog, bn_amax;
+    int f16_lnfold = 0;              // RLCF_PREC_F16 image towers: f16 residual stream with the LayerNorms folded into the products (opt-in: RLCF_F16_LNFOLD=1 at create / rlcf_engine_set_f16_lnfold)
     bool lnfold_stale = false;       // the student's LayerNorm parameters were written after finalize (rlcf_engine_set_ln_params, an applied EMA): the
                                      // gamma / beta folded into the RLCF_PREC_F16 image-tower weights no longer match them -> the unfolded pipeline runs
     DevBuf zpage;                    // 4 KB of zeros: what the implicit 3x3 convolution reads outside the image
@@ -234,6 +235,9 @@ struct rlcf_engine {
     int ws_sel = 0;                  // which workspace the GEMM launchers hand out (1 while the side stream's launches are enqueued)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the caller's streams this engine has enqueued work on (api.hip: engine_stream; a handful at most — a lane uses one): what
+    // rlcf_engine_destroy waits for, instead of the whole device
+    std::vector<hipStream_t> used_streams;
     DevBuf rl_stats;                 // per-row scratch of the reward / loss kernels
     DevBuf step_skip;                // int32 per test sample: gradient held an inf / NaN -> optimizer step skipped (GradScaler semantics)
     // packed class-sequence runs of the text pass being enqueued (set by text_forward around transformer_forward)
@@ -254,6 +258,15 @@ struct GemmProfile {                 // optional per-launch timing of the domina
 extern int g_last_x3_variant;
 extern GemmProfile g_prof;
 
+static inline hipStream_t engine_stream(rlcf_engine* e, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (e) {
+        bool seen = false;
+        for (hipStream_t s : e->used_streams) seen = seen || s == st;
+        if (!seen && e->used_streams.size() < 64) e->used_streams.push_back(st);
+    }
+    return st;
+}
 static inline bool is_resnet(const rlcf_clip_cfg& c) { return c.vision_stages[0] > 0; }
 // RLCF_PREC_F16 is the split-f16 engine with ONE change: the forward tower pipeline (LayerNorm -> GEMM -> attention -> GEMM ... of
 // transformer_forward, the patch embedding) carries plain f16 operands and spends one MFMA per product — the arithmetic of the

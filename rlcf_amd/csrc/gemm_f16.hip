@@ -181,10 +181,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
 //     stream in place and leaves per-row partial (sum, sum of squares) for the next LayerNorm's statistics;
 //   * the two wave groups line up for the epilogue (one extra barrier each per tile) so that both run it at the same time.
 // What was measured and dropped on the way (start-time cohorts, deferred stores, an early touch of the residual tile): r5_notes.md.
-template <int EPI, int MODE = 0>
+//   * DEFER (round 6, MODE 0): half of a tile's output leaves under the NEXT tile's K loop instead of in the epilogue's burst.  The
+//     epilogue converts the whole tile but stores only the upper 64 rows of every wave's 128 (8 of its 16 store instructions); the
+//     lower 64 rows wait as 32 packed registers and go out ONE instruction per K tile, K tiles 2 .. 9 of the next tile, each placed
+//     right in front of that K tile's counted wait, which is raised by one (vmcnt(7)): the store is YOUNGER than the six prefetch pieces it
+//     is issued behind, so no load of the ring ever waits for it, and it has a whole K tile to retire before the next wait covers it.
+//     Round 5 had tried the registers but issued all 8 stores under K tiles 0 and 1 — directly behind the burst of the other half,
+//     where every wait of those K tiles then sat behind a congested store; spread over the K loop the chip sees them at 1/12 of the
+//     burst rate.  RLCF_F16_PP_DEFER=0: off (A/B).  profiles/r6_notes.md section 1.
+template <int EPI, int MODE = 0, int DEFER = 0, int TRACE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR]
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR] + 1 KB: the tile's bias slice
     const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + 255) / 256, ntiles = tiles_m * tiles_n;
     // XCD x owns a contiguous range of the tile order; its G/8 workgroups walk it G/8 tiles at a time
     const int wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
@@ -224,6 +232,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         const size_t bytes = (size_t)(g.N - n0_) * g.ldw * 2;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(g.Whi + (size_t)n0_ * g.ldw), 0, (int)(unsigned)(bytes > 0xfffff000u ? 0xfffff000u : bytes), 0x00020000);
     };
+    // The tile's 256 bias values travel through LDS (round 6): one LDS-DMA piece (64 lanes x 16 B; columns beyond N read as zeros by the
+    // descriptor's range check) issued by EVERY wave (identical bytes: the vmcnt bookkeeping stays wave-uniform) at the head of K tile
+    // nk - 2, i.e. older than that K tile's own pieces and covered by its counted wait; the epilogue reads them with ds_read_b128.  Before,
+    // the epilogue's global loads of the bias made the compiler wait vmcnt(0) in front of the first output value — for the next tile's
+    // whole prefetch including the B_lo pieces issued a few instructions earlier.
+    const bool has_bias = g.bias != nullptr && (((uintptr_t)g.bias) & 3) == 0;
+    auto rsrc_bias = [&](int n0_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(has_bias ? g.bias + n0_ : (const float*)g.Whi), 0, has_bias ? (int)((g.N - n0_) * 4) : 0, 0x00020000);
+    };
+    const unsigned vbias = (unsigned)lane * 16u;
+#define PP_STAGE_BIAS(rs) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + 2 * P8_PAR), 16, vbias, 0, 0, 0);
 #define PP_STAGE_A(hf, par, rs, kt)                                                                                                 \
     {                                                                                                                               \
         char* d_ = smem + (par) * P8_PAR + (hf) * P8_HALF + wave_s * 2048;                                                           \
@@ -306,6 +325,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         H_(3)                                                                                                                       \
         P8_MID MMA_(1, 0) P8_END                                                                                                    \
     }
+// a steady-state K tile that also sends pending store IDX (0..7) of the PREVIOUS tile: row block 2 + (IDX >> 2), column group IDX & 3
+#define PP_KTILE_ST(kt, par, IDX)                                                                                                   \
+    {                                                                                                                               \
+        P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
+        PP_STAGE_B(0, (par) ^ 1, rw, (kt) + 1)                                                                                      \
+        P8_MID PP_MMA(0, 0) P8_END                                                                                                  \
+        P8_LDB(1, par)                                                                                                              \
+        PP_STAGE_A(0, par, ra, (kt) + 2)                                                                                            \
+        P8_MID PP_MMA(0, 1) P8_END                                                                                                  \
+        P8_LDA(1, par)                                                                                                              \
+        PP_STAGE_B(1, par, rw, (kt) + 2)                                                                                            \
+        P8_MID PP_MMA(1, 1) P8_END                                                                                                  \
+        P8_LDB(0, par)                                                                                                              \
+        PP_STAGE_A(1, par, ra, (kt) + 2)                                                                                            \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[IDX]), rs_pend, vout,                                 \
+                                               ((2 + ((IDX) >> 2)) * 32 * g.ldch + ((IDX) & 3) * 16) * 2, 0);                        \
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                                            \
+        P8_MID PP_MMA(1, 0) P8_END                                                                                                  \
+    }
 #define PP_NOHOOK(n)
 #define PP_WAIT_PP_NOHOOK asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #define PP_ST(v, p) { if (g.sk_epoch) __builtin_nontemporal_store(v, (h16x8*)(p)); else *(h16x8*)(p) = v; }      // (g.sk_epoch: RLCF_F16_PP_NT)
@@ -335,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         PP_STAGE_A(1, 0, ra, 2)                                                                                                     \
         if (nst == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                              \
         else if (nst == 1) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                                                        \
+        else if (nst == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                                        \
         else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                                                                      \
         P8_MID MMA_(1, 0) P8_END                                                                                                    \
     }
@@ -343,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 // K tile nk-1 stages the next tile's B_lo of K tile 0 and A_lo / B_hi / A_hi of its K tile 1 (nothing when this is the last tile)
 #define PP_KTILE_TAIL(par, first)                                                                                                   \
     {                                                                                                                               \
+        if (first) PP_STAGE_BIAS(rb)                                                                                                \
         P8_LDB(0, par) P8_LDA(0, par)                                                                                               \
         if (first) PP_STAGE_B(0, (par) ^ 1, rw, nk - 1)                                                                             \
         else if (have_next) PP_STAGE_B(0, (par) ^ 1, rwn, 0)                                                                        \
@@ -364,11 +404,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
     if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }       // the second group runs one barrier behind
     // (measurement: g.ws != null -> s_memtime stamps of waves 0 / 4 for the first 64 tiles of every workgroup: K loop start, K loop end,
     //  groups lined up, epilogue issued)
-    unsigned long long* trace = (unsigned long long*)g.ws;
+    unsigned long long* trace = TRACE ? (unsigned long long*)g.ws : nullptr;
     int tile_it = 0;
     int nst = 0;                                 // what the previous epilogue of this wave left outstanding (see PP_KTILE_FIRST)
     static_assert(MODE == 0 || MODE == 1 || MODE == 2, "epilogue mode");
-#define PP_STAMP(k) if (trace && (wave & 3) == 0 && lane == 0 && tile_it < 64) trace[(((size_t)blockIdx.x * 64 + tile_it) * 2 + wm) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+    static_assert(DEFER == 0 || MODE == 0, "deferred stores: MODE 0 only");
+    // DEFER: the previous tile's lower 64 rows of this wave (row blocks 2 / 3 x 4 column groups), packed, and their two row pointers
+    h16x8 pend[DEFER ? 8 : 1];
+    // whole tiles leave through BUFFER stores: a per-tile descriptor in scalar registers (base = the tile's first element, 256 rows of
+    // range), ONE per-lane byte offset that is the same for every tile (row l32 of the wave's block, 8 columns at 8 h) and the row block /
+    // column group as the scalar offset — no 64-bit address arithmetic per store, and a deferred store needs no address registers at all
+    const unsigned vout = (unsigned)(((wm * 128 + l32) * g.ldch + wn * 64 + 8 * h) * 2);
+    auto rsrc_out = [&](int m0_, int n0_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(g.Chi + (size_t)m0_ * g.ldch + n0_), 0, (int)(unsigned)((size_t)256 * g.ldch * 2), 0x00020000);
+    };
+    auto rs_pend = rsrc_out(0, 0);
+    bool have_pend = false;                      // (wave-uniform: set by the epilogue of a whole tile that has a successor)
+    const bool can_defer = DEFER && nk >= 12 && g.ksplit == 0 && !g.sk_epoch && (size_t)256 * g.ldch * 2 < 0xfffff000u;
+// (TRACE is its own instantiation: the stamp code costs the production kernel registers it needs for the deferred stores)
+#define PP_STAMP(k) if constexpr (TRACE != 0) { if (trace && (wave & 3) == 0 && lane == 0 && tile_it < 64) trace[(((size_t)blockIdx.x * 64 + tile_it) * 2 + wm) * 16 + (k)] = __builtin_amdgcn_s_memtime(); }
     for (;;) {
         const int nlin = lin + wpx;
         const bool have_next = nlin < xend;
@@ -376,13 +430,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         int m0n = 0, n0n = 0;
         if (have_next) tile_origin(g.ksplit == 8 ? lin : nlin, m0n, n0n);          // (ksplit 8: measurement — every tile of a workgroup is its first)
         auto ran = rsrc_a(m0n), rwn = rsrc_w(n0n);
+        auto rb = rsrc_bias(n0);
         PP_KTILE_FIRST(PP_MMA0)
         PP_KTILE(1, 1)
-        if (trace) { PP_STAMP(4) }
-        for (int kt = 2; kt + 2 < nk; kt += 2) {
+        PP_STAMP(4)
+        int kt0 = 2;
+        if constexpr (DEFER != 0) {
+            if (have_pend) {                     // (nk >= 12: K tiles 2 .. 9 exist below the tail)
+                PP_KTILE_ST(2, 0, 0) PP_KTILE_ST(3, 1, 1)
+                PP_STAMP(5)
+                PP_KTILE_ST(4, 0, 2) PP_KTILE_ST(5, 1, 3)
+                PP_STAMP(6)
+                PP_KTILE_ST(6, 0, 4) PP_KTILE_ST(7, 1, 5)
+                PP_STAMP(7)
+                PP_KTILE_ST(8, 0, 6) PP_KTILE_ST(9, 1, 7)
+                PP_STAMP(8)
+                kt0 = 10;
+                have_pend = false;
+            }
+        }
+        for (int kt = kt0; kt + 2 < nk; kt += 2) {
             PP_KTILE(kt, 0)
             PP_KTILE(kt + 1, 1)
-            if (trace && kt < 20) { PP_STAMP(4 + (kt >> 1)) }
+            if (kt < 20) { PP_STAMP(4 + (kt >> 1)) }
         }
         PP_KTILE_TAIL(0, true)
         PP_KTILE_TAIL(1, false)
@@ -403,19 +473,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
             const int orow = m0 + wm * 128 + l32;
             const bool inside = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;       // (whole tile, 16-byte aligned rows: no masks)
             _Float16* obase = g.Chi + (size_t)orow * g.ldch + ocol;
+            const bool defer_now = DEFER && can_defer && inside && have_next;
+            const bool bufst = inside && !g.sk_epoch && (size_t)256 * g.ldch * 2 < 0xfffff000u;
+            auto rs_out = rsrc_out(m0, n0);
+            if constexpr (DEFER != 0) {
+                if (defer_now) rs_pend = rs_out;
+            }
             float bj[4][8];
-            if (g.bias && n0 + 256 <= g.N && (((uintptr_t)g.bias) & 15) == 0) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const float4 b0 = *(const float4*)(g.bias + ocol + gq * 16), b1 = *(const float4*)(g.bias + ocol + gq * 16 + 4);
-                    bj[gq][0] = b0.x; bj[gq][1] = b0.y; bj[gq][2] = b0.z; bj[gq][3] = b0.w;
-                    bj[gq][4] = b1.x; bj[gq][5] = b1.y; bj[gq][6] = b1.z; bj[gq][7] = b1.w;
-                }
-            } else {
+            if (has_bias) {              // from LDS (PP_STAGE_BIAS): landed behind the counted wait of K tile nk - 2; zeros beyond N
+                // (inline asm: a C++ read of LDS here gets a compiler-inserted s_waitcnt vmcnt(0) in front of it — the pass orders LDS reads
+                //  behind every LDS-DMA in flight, i.e. behind the next tile's prefetch.  This wave's own copy of the slice IS complete: it
+                //  was issued ahead of K tile nk - 2's pieces, which that K tile's counted wait covered two K tiles ago.)
+                //  The LDS address is formed INSIDE the statement: as a loop-invariant C++ value the compiler keeps it in a register across the K
+                //  loop, runs out of registers in the DEFER build and spills it — and a scratch reload is a vector-memory load with its own vmcnt(0).
+                const unsigned bias_base = (unsigned)(uintptr_t)(lptr_t)(smem + 2 * P8_PAR), bias_col = (unsigned)(wn * 64 + 8 * h);
+                unsigned bl;
+                f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile("v_lshl_add_u32 %8, %9, 2, %10\n\t"
+                             "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
+                             "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:144\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:208\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(bl)
+                             : "v"(bias_col), "s"(bias_base) : "memory");
+                const f32x4 tq[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bj[gq][e] = (g.bias && ocol + gq * 16 + e < g.N) ? g.bias[ocol + gq * 16 + e] : 0.f;
+                    for (int e = 0; e < 8; ++e) bj[gq][e] = tq[gq * 2 + (e >> 2)][e & 3];
+            } else {                     // (no bias; a float pointer is always dword-aligned, so has_bias == (bias != null): no global load here —
+                                         //  one in EITHER arm would make the compiler wait vmcnt(0) at the join)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bj[gq][e] = 0.f;
             }
             if constexpr (MODE == 2) {
                 // residual rows: every load is issued before the first store (stores count in vmcnt: a load behind one would wait for it)
@@ -486,7 +576,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                         }
                     _Float16* op = obase + (size_t)(i * 32) * g.ldch + gq * 16;
                     if (g.ksplit == 1 && o[0] != (_Float16)123.0f) continue;            // (measurement: no stores)
-                    if (inside) {
+                    if constexpr (DEFER != 0) {
+                        if (i >= 2 && defer_now) { pend[(i - 2) * 4 + gq] = o; continue; }
+                    }
+                    if (bufst) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, vout, (i * 32 * g.ldch + gq * 16) * 2, 0);
+                    } else if (inside) {
                         PP_ST(o, op)
                     } else if (orow + i * 32 < g.M) {
                         const int c0 = ocol + gq * 16;
@@ -509,6 +604,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
             const bool whole = g.ksplit == 0 && m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;
             if (g.ksplit == 0 && !whole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             nst = whole ? (MODE == 2 ? 2 : 1) : 0;
+            if constexpr (DEFER != 0) {
+                if (whole && can_defer) { nst = 3; have_pend = true; }            // (have_next holds here: 8 stores went out, 8 wait in pend)
+            }
         }
         if (wm == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // back to one barrier behind
         lin = nlin; m0 = m0n; n0 = n0n; ra = ran; rw = rwn;
@@ -568,7 +666,7 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     }
     const int blocks = ((M + 255) / 256) * (N / 256);
     const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
-    const size_t shp = (size_t)2 * P8_PAR;
+    const size_t shp = (size_t)2 * P8_PAR + 1024;      // + the tile's bias slice
 #define PP_LN_GO(E, MD)                                                                                                             \
     {                                                                                                                               \
         int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD>, shp);                                                      \
@@ -603,7 +701,7 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
             if (ncu <= 0) ncu = 256;
         }
         const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
-        const size_t shp = (size_t)2 * P8_PAR;
+        const size_t shp = (size_t)2 * P8_PAR + 1024;      // + the tile's bias slice
         g.ksplit = abl;
         g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
         static int desync = -1;                              // RLCF_F16_PP_DESYNC=P: start-time cohorts (1 = all together)
@@ -619,15 +717,20 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
             RLCF_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
             g.ws = (float*)trace_buf;
         }
-        if (epilogue == RLCF_EPI_QUICKGELU) {
-            int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<RLCF_EPI_QUICKGELU>, shp);
-            if (rc != RLCF_OK) return rc;
-            gemm_nt_f16_pp_kernel<RLCF_EPI_QUICKGELU><<<dim3(grid), dim3(512), shp, st>>>(g);
-        } else {
-            int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<RLCF_EPI_NONE>, shp);
-            if (rc != RLCF_OK) return rc;
-            gemm_nt_f16_pp_kernel<RLCF_EPI_NONE><<<dim3(grid), dim3(512), shp, st>>>(g);
-        }
+        // RLCF_F16_PP_DEFER (read per launch: A/B inside one process): 1 = half of every tile's stores ride under the next tile's K loop
+        const char* de = getenv("RLCF_F16_PP_DEFER");
+        const bool defer = (de ? atoi(de) : 1) != 0 && abl == 0 && blocks > grid && K >= 768;
+#define PP_GO(E, D, T)                                                                                                              \
+    {                                                                                                                               \
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, 0, D, T>, shp);                                                 \
+        if (rc != RLCF_OK) return rc;                                                                                               \
+        gemm_nt_f16_pp_kernel<E, 0, D, T><<<dim3(grid), dim3(512), shp, st>>>(g);                                                    \
+    }
+#define PP_GO_T(E, D) { if (trace_on) PP_GO(E, D, 1) else PP_GO(E, D, 0) }
+        if (epilogue == RLCF_EPI_QUICKGELU) { if (defer) PP_GO_T(RLCF_EPI_QUICKGELU, 1) else PP_GO_T(RLCF_EPI_QUICKGELU, 0) }
+        else { if (defer) PP_GO_T(RLCF_EPI_NONE, 1) else PP_GO_T(RLCF_EPI_NONE, 0) }
+#undef PP_GO_T
+#undef PP_GO
         RLCF_LAUNCH_CHECK();
         if (trace_on) {
             static unsigned long long* host = nullptr;

@@ -67,6 +67,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, int st
 int launch_grad_nonfinite(const float* g, int64_t per_group, int groups, int32_t* flag, hipStream_t st, bool accumulate = false);   // accumulate: OR into flags already set (a second gradient buffer of the same optimizer)
 int launch_avg_entropy(const float* logits, int n, int C, float* out, hipStream_t st);
 int launch_accuracy(const float* logits, const int64_t* target, int B, int C, int32_t* top5_scratch, float* out, hipStream_t st);
+int launch_top5_hits(const int32_t* top5, const int64_t* target, int B, float* out, hipStream_t st);
 int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st);
 int launch_quickgelu(const float* f, float* g, int64_t n, hipStream_t st);
 int launch_build_sparse_layout(const int32_t* cls, int groups, int n_e, const int32_t* class_start, const int32_t* class_len,

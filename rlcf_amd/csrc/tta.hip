@@ -465,10 +465,13 @@ int launch_top5(const float* logits, int C, int32_t* top5, hipStream_t st) {
 __global__ __launch_bounds__(TTA_THREADS) void avg_entropy_kernel(const float* __restrict__ x, int n, int C, float* __restrict__ out) {
     extern __shared__ float lse[];                    // [n]
     __shared__ float red[TTA_THREADS / 64];
+    // a NaN or +inf logit makes the reference's result NaN (x - logsumexp(x) is NaN there and torch.clamp / logsumexp carry it on);
+    // fmaxf would drop it silently, so such inputs are counted and answered with NaN
+    float bad = 0.f;
     for (int r = 0; r < n; ++r) {
         const float* row = x + (size_t)r * C;
         float m = -INFINITY;
-        for (int c = threadIdx.x; c < C; c += TTA_THREADS) m = fmaxf(m, row[c]);
+        for (int c = threadIdx.x; c < C; c += TTA_THREADS) { const float v = row[c]; bad += (v != v || v == INFINITY) ? 1.f : 0.f; m = fmaxf(m, v); }
         m = block_max(m, red);
         float sum = 0.f;
         for (int c = threadIdx.x; c < C; c += TTA_THREADS) sum += expf(row[c] - m);
@@ -488,7 +491,8 @@ __global__ __launch_bounds__(TTA_THREADS) void avg_entropy_kernel(const float* _
         acc -= a * expf(a);
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) out[0] = acc;
+    bad = block_sum(bad, red);
+    if (threadIdx.x == 0) out[0] = bad > 0.f ? NAN : acc;
 }
 int launch_avg_entropy(const float* logits, int n, int C, float* out, hipStream_t st) {
     RLCF_ARG_CHECK(logits && out && n > 0 && n <= 4096 && C > 0);
@@ -518,6 +522,30 @@ int launch_accuracy(const float* logits, const int64_t* target, int B, int C, in
     top5_kernel<<<dim3(B), dim3(TTA_THREADS), 0, st>>>(logits, C, top5_scratch);
     RLCF_LAUNCH_CHECK();
     accuracy_kernel<<<dim3(1), dim3(256), 0, st>>>(top5_scratch, target, B, C, out);
+    RLCF_LAUNCH_CHECK();
+    return RLCF_OK;
+}
+
+// Hit counts of a harness loop from the engine's own top-5 indices (rlcf_tta_batch / rlcf_lanes_submit outputs): out[0] += #(target ==
+// top5[b, 0]), out[1] += #(target in top5[b, :]) — what the reference accumulates per image through accuracy() + AverageMeter
+// (TPT/tpt_cls_rl.py:265-268), as counts.  Accumulating: the loop calls it once per pass / per group of samples on one float[2].
+__global__ void top5_hits_kernel(const int32_t* __restrict__ top5, const int64_t* __restrict__ target, int B, float* __restrict__ out) {
+    __shared__ int h1, h5;
+    if (threadIdx.x == 0) { h1 = 0; h5 = 0; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int t = (int)target[b];
+        int a5 = 0;
+        for (int k = 0; k < 5; ++k) a5 |= (top5[b * 5 + k] == t);
+        if (top5[b * 5] == t) atomicAdd(&h1, 1);
+        if (a5) atomicAdd(&h5, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] += (float)h1; out[1] += (float)h5; }
+}
+int launch_top5_hits(const int32_t* top5, const int64_t* target, int B, float* out, hipStream_t st) {
+    RLCF_ARG_CHECK(top5 && target && out && B > 0);
+    top5_hits_kernel<<<dim3(1), dim3(256), 0, st>>>(top5, target, B, out);
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

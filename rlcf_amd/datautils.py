@@ -304,11 +304,12 @@ class AugMixAugmenter:
         self.hard_aug = bool(hard_aug)
         self.preaugment = get_preaugment(hard_aug=hard_aug, resolution=resolution, crop_min=0.2)
 
-    def views(self, x) -> torch.Tensor:
-        img = _as_u8_hwc(x)
-        H, W = int(img.shape[0]), int(img.shape[1])
+    def draw(self, H: int, W: int):
+        """The HOST half of one call: the random draws of the n_views views of an H x W image — per view the pre-augmentation draws (torch's
+        global generator, torchvision's order), then the AugMix draws (numpy's global stream).  -> (crops, augmix plans | None, hard plans |
+        None).  Depends on the image's size only, so a loader may run it ahead of the loop (ViewPrefetcher)."""
         crops, plans, hard = [], [] if self.aug_list else None, [] if self.hard_aug else None
-        for _ in range(self.n_views):                                  # per view: the pre-augmentation draws (torch), then the AugMix draws (numpy)
+        for _ in range(self.n_views):
             if self.hard_aug:
                 box, hp = self.preaugment(H, W)
                 crops.append(box)
@@ -317,7 +318,74 @@ class AugMixAugmenter:
                 crops.append(self.preaugment(H, W))
             if self.aug_list:
                 plans.append(draw_augmix_plan(self.severity))
+        return crops, plans, hard
+
+    def apply(self, img: torch.Tensor, params) -> torch.Tensor:
+        """The DEVICE half: the decoded uint8 image + the draws of `draw` -> [1 + n_views, 3, R, R] on the GPU (rlcf_make_views*)."""
+        crops, plans, hard = params
         return make_views(img, crops, self.resolution, device=self.device, augmix_plans=plans, hard_plans=hard)
+
+    def views(self, x) -> torch.Tensor:
+        img = _as_u8_hwc(x)
+        return self.apply(img, self.draw(int(img.shape[0]), int(img.shape[1])))
 
     def __call__(self, x):
         return list(self.views(x).unbind(0))
+
+
+
+class ViewPrefetcher:
+    """The reference draws a test image's 63 crop boxes (and AugMix plans) inside DataLoader workers — `DataLoader(val_dataset, ...,
+    num_workers=args.workers)`, TPT/tpt_cls_rl.py:187-188, with the transform `AugMixAugmenter` running in `__getitem__`
+    (TPT/data/datautils.py:113-128) — so the draws of image i + 1 happen while image i is being tuned.  The device-side augmenter
+    cannot run in forked workers; this is its equivalent: ONE loader thread walks `dataset` (any iterable / indexable of (image,
+    target)), decodes the image to uint8 [H, W, 3] and makes the host-side draws (`AugMixAugmenter.draw`: ~1 ms of generator calls per
+    image) up to `depth` images ahead; the consuming loop's thread only launches the device half (`apply`, ~0.1 ms of host time).
+    One thread draws, in dataset order: a seeded run makes the same draws as the plain loop.  Yields what the reference's loader
+    yields with batch size 1: ([view [1, 3, R, R]] * N, target)."""
+
+    def __init__(self, dataset, augmenter: "AugMixAugmenter", depth: int = 2, as_list: bool = True):
+        self.dataset, self.aug, self.depth, self.as_list = dataset, augmenter, max(1, int(depth)), as_list
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def work():
+            try:
+                for image, target in self.dataset:
+                    if stop.is_set():
+                        return
+                    img = _as_u8_hwc(image)
+                    item = (img, self.aug.draw(int(img.shape[0]), int(img.shape[1])), target)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                q.put(None)
+            except BaseException as exc:                  # noqa: BLE001 — re-raised in the consuming thread
+                q.put(exc)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                img, params, target = item
+                v = self.aug.apply(img, params)
+                t = target if isinstance(target, torch.Tensor) else torch.tensor([int(target)])
+                yield ([x.unsqueeze(0) for x in v.unbind(0)] if self.as_list else v), t
+        finally:
+            stop.set()
+            th.join(timeout=5)

@@ -89,6 +89,7 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.n_cls = 0
         self.n_ctx = 0
+        self.reset_moved = False     # an applied cross-sample EMA has moved the reset state away from the checkpoint's (momentum_update*)
 
     def close(self):
         if getattr(self, "h", None):
@@ -221,6 +222,11 @@ class Engine:
         cur = current.detach().to(self.device, torch.float32).contiguous()
         L.check(self.lib.rlcf_engine_momentum_update(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0, _stream()),
                 "momentum_update")
+        self.reset_moved = self.reset_moved or bool(apply)
+
+    def set_f16_lnfold(self, on: bool) -> None:
+        """RLCF_PREC_F16: f16 residual stream with the LayerNorms folded into the products (opt-in; rlcf_engine_set_f16_lnfold)."""
+        L.check(self.lib.rlcf_engine_set_f16_lnfold(self.h, 1 if on else 0), "set_f16_lnfold")
 
     def set_side_stream(self, on: bool) -> None:
         """False: one-image calls stay on the caller's stream (lane engines of samples in flight, rlcf_engine_set_side_stream)."""
@@ -229,6 +235,7 @@ class Engine:
     def reset_visual_state(self) -> None:
         """State part of CLIPCLS_TTA.reset_classnames_and_state (custom_clip.py:449-454): reset state and EMA back to the checkpoint."""
         L.check(self.lib.rlcf_engine_reset_visual_state(self.h, _stream()), "reset_visual_state")
+        self.reset_moved = False
 
     def tta_sample_ln(self, views: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
         """LayerNorm-tuning step (reference TPT/tune_cls_rl.py with CLIPCLS_TTA(only_norm=True))."""
@@ -370,6 +377,7 @@ class Engine:
         cur = current.detach().to(self.device, torch.float32).contiguous()
         L.check(self.lib.rlcf_engine_momentum_update_visual(self.h, _ptr(cur), float(momentum), float(update_w), 1 if apply else 0,
                                                             _stream()), "momentum_update_visual")
+        self.reset_moved = self.reset_moved or bool(apply)
 
     def tta_retrieval_image(self, images: torch.Tensor, cfg: TTAConfig, skip_final: bool = False) -> Dict[str, torch.Tensor]:
         """Image -> text retrieval step: tune_image + the evaluation of its loop (retrieval/clip_ret_policy.py:76-103,171-176) over the
@@ -506,3 +514,49 @@ class Engine:
 
     def text_rows(self) -> int:
         return int(self.lib.rlcf_engine_text_rows(self.h))
+
+
+class Lanes:
+    """K engines with one non-blocking stream each for test images IN FLIGHT (include/rlcf_hip.h, rlcf_lanes_*): `submit` enqueues one
+    sample on the next lane from the caller's thread and returns at once; nothing waits on the host."""
+
+    def __init__(self, engines):
+        self.lib = L.lib()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        self.h = self.lib.rlcf_lanes_create(arr, len(self.engines))
+        if not self.h:
+            raise L.RlcfError("rlcf_lanes_create: " + self.lib.rlcf_last_error().decode())
+        dev = self.engines[0].device
+        self.streams = [torch.cuda.ExternalStream(self.lib.rlcf_lanes_stream(self.h, k), device=dev) for k in range(len(self.engines))]
+
+    def submit(self, views: torch.Tensor, cfg: TTAConfig, top5_row: torch.Tensor, norm_layers: bool = False,
+               final_logits: Optional[torch.Tensor] = None) -> int:
+        """views [N,3,R,R] (one test image) or [count,N,3,R,R]; top5_row int32 [count*5]; -> the lane that took it."""
+        assert views.is_cuda and views.dtype == torch.float32 and views.is_contiguous()
+        count = 1 if views.dim() == 4 else views.shape[0]
+        N = views.shape[-4]
+        a = cfg.c_args(N)
+        k = self.lib.rlcf_lanes_submit(self.h, _ptr(views), count, N, C.byref(a), _ptr(final_logits), top5_row.data_ptr(), 1 if norm_layers else 0,
+                                       _stream())
+        if k < 0:
+            L.check(k, "rlcf_lanes_submit")
+        for t in (views, top5_row, final_logits):
+            if t is not None:
+                t.record_stream(self.streams[k])       # the caching allocator must not hand the block out again before the lane has run
+        return k
+
+    def join(self) -> None:
+        """the current stream waits (on the device) for everything submitted so far"""
+        L.check(self.lib.rlcf_lanes_join(self.h, _stream()), "rlcf_lanes_join")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rlcf_lanes_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

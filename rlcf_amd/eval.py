@@ -39,7 +39,7 @@ def run(args) -> dict:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    local = local % torch.cuda.device_count()
+    local = shard.local_device(local, args.dist_backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or bool(os.environ.get("RLCF_FORCE_DIST"))     # RLCF_FORCE_DIST: the RCCL path with one rank (tests)

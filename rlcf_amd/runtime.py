@@ -126,6 +126,11 @@ class Session:
                 lane[1] = bkey
         return [first] + [lane[0] for lane in self._lanes[: lanes - 1]]
 
+    def reset_state_moved(self) -> bool:
+        """True when an applied cross-sample EMA (momentum_update_model) has moved the session engine's reset state away from the
+        checkpoint's: further lane engines are built from the checkpoint and would tune from another state than lane 0."""
+        return self._engine is not None and self._engine.reset_moved
+
     def _close_lanes(self):
         for lane in self._lanes:
             lane[0].close()

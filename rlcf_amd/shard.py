@@ -36,6 +36,20 @@ def reduce_hits(top1_hits: int, top5_hits: int, n: int, device="cpu") -> Tuple[f
     return 100.0 * a / max(c, 1), 100.0 * b / max(c, 1), c
 
 
+def local_device(local_rank: int, backend: str) -> int:
+    """The GPU index of local rank `local_rank`.  Under `nccl` (= RCCL) every rank needs a device of its own: more ranks than visible
+    GPUs is an error HERE, with a message — stacked on one device they would die inside RCCL with a duplicate-device error.  `gloo`
+    (CPU / one-GPU smoke tests) may share a device."""
+    n = torch.cuda.device_count()
+    if n <= 0:
+        raise RuntimeError("no visible GPU (the RLCF HIP path has no CPU fallback)")
+    if local_rank >= n and backend == "nccl":
+        raise RuntimeError(f"local rank {local_rank} has no GPU of its own: {n} visible device(s) but the launch asks for more ranks "
+                           f"(--gpus / --nproc-per-node > visible devices); RCCL needs one GPU per rank — lower --gpus, or use "
+                           f"--dist-backend gloo to share a device in a smoke test")
+    return local_rank % n
+
+
 def self_launch(n_gpus: int, script_argv: List[str], module: Optional[str] = None) -> Optional[int]:
     """`python bench.py --gpus N` / `python -m rlcf_amd.eval --gpus N` typed WITHOUT a launcher: when N > 1 and no rank environment is
     present (WORLD_SIZE unset), start the same command line as N ranks — one process per GPU — under `python -m torch.distributed.run

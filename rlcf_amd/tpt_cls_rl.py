@@ -36,7 +36,7 @@ def avg_entropy(outputs):
         x = outputs.detach().float().contiguous()
         out = torch.empty((), device=x.device, dtype=torch.float32)
         L.check(L.lib().rlcf_avg_entropy(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), torch.cuda.current_stream().cuda_stream), "avg_entropy")
-        return out
+        return out.to(outputs.dtype)               # (the reference's expression keeps the input dtype: fp16 logits under autocast)
     logits = outputs - outputs.logsumexp(dim=-1, keepdim=True)
     avg_logits = logits.logsumexp(dim=0) - math.log(logits.shape[0])
     avg_logits = torch.clamp(avg_logits, min=torch.finfo(avg_logits.dtype).min)
@@ -79,7 +79,10 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
             raise NotImplementedError("image-encoder tuning starts from the reset state (model.reset(), tune_cls_rl.py:210)")
         if at_reset:
             trk.guard(model.ln.data, model._ln_init, "CLIPCLS_TTA: the norm-layer parameters were not the reset state when test_time_tuning ran")
-            if full:
+            # (every-parameter tuning: comparing the whole visual vector — 1e8 floats and a bool temporary of the same length — per test
+            # image is a debugging aid, not a default: RLCF_GUARD_VISUAL=1.  The small norm-layer vector above is always guarded.  A guard
+            # reports one sample late: the offending sample's prediction is already in the hit counts when it raises.)
+            if full and os.environ.get("RLCF_GUARD_VISUAL", "0") == "1":
                 trk.guard(model.vis.data, model._vis_init, "CLIPCLS_TTA: the visual parameters were not the reset state when test_time_tuning ran")
         out = (eng.tta_sample_visual if full else eng.tta_sample_ln)(inputs, cfg, skip_final=True)
         with torch.no_grad():
@@ -118,7 +121,8 @@ def test_time_tuning(model, inputs, optimizer, scaler, args, reward_model=None):
 def accuracy(output, target, topk=(1,)):
     """TPT/utils/tools.py:84-98.  topk drawn from {1, 5} on device tensors: top5_kernel + accuracy_kernel (rlcf_accuracy; ties go to the
     lower class index); anything else takes the reference's torch expression."""
-    if output.is_cuda and output.dim() == 2 and target.is_cuda and set(topk) <= {1, 5} and not output.requires_grad:
+    if output.is_cuda and output.dim() == 2 and target.is_cuda and set(topk) <= {1, 5} and not output.requires_grad and output.shape[1] >= max(topk):
+        # (fewer classes than max(topk): the reference's output.topk raises — the torch expression below does the same)
         x = output.detach().float().contiguous()
         t = target.detach().to(torch.int64).contiguous()
         B, C = x.shape
@@ -136,27 +140,33 @@ def accuracy(output, target, topk=(1,)):
         return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]
 
 
+def _hits(top5: torch.Tensor, targets, hits: torch.Tensor) -> None:
+    """hits[0] += top-1 hits, hits[1] += top-5 hits of the engine's top-5 rows against the labels (rlcf_top5_hits: one launch)."""
+    dev = top5.device
+    t = torch.stack([x.reshape(-1)[0] for x in targets]) if not isinstance(targets, torch.Tensor) else targets
+    t = (_upload(t, dev) if not t.is_cuda else t.to(dev)).to(torch.int64).contiguous()
+    L.check(L.lib().rlcf_top5_hits(top5.data_ptr(), t.data_ptr(), top5.shape[0], hits.data_ptr(), torch.cuda.current_stream().cuda_stream), "top5_hits")
+
+
 def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass):
     """Throughput form of the harness: test images are independent units (per-sample reset, tpt_cls_rl.py:251-255), so
     `images_per_pass` of them share every tower pass inside the engine (rlcf_tta_batch / rlcf_tta_batch_ln); same predictions."""
     cfg = _config(args, optimizer, reward_model)
     prompt = hasattr(model, "prompt_learner")
-    n, s1_t, s5_t, buf, tgt = 0, None, None, [], []
+    n, hits, buf, tgt = 0, None, [], []
 
     def flush():
         # (hit counts stay on the device until the end: reading them per pass would stop the host from preparing the next pass's views
         # while this one runs; labels go up on a side stream for the same reason)
-        nonlocal n, s1_t, s5_t, buf, tgt
+        nonlocal n, hits, buf, tgt
         if not buf:
             return
         views = torch.stack(buf)
         eng = runtime.SESSION.engine(views.shape[0] * views.shape[1])
-        top5 = (eng.tta_batch if prompt else eng.tta_batch_ln)(views, cfg).long()
-        t = torch.stack(tgt).view(-1, 1)
-        t = _upload(t, top5.device) if not t.is_cuda else t.to(top5.device)
-        h1, h5 = (top5[:, :1] == t).any(1).float().sum(), (top5 == t).any(1).float().sum()
-        s1_t = h1 if s1_t is None else s1_t + h1
-        s5_t = h5 if s5_t is None else s5_t + h5
+        top5 = (eng.tta_batch if prompt else eng.tta_batch_ln)(views, cfg)
+        if hits is None:
+            hits = torch.zeros(2, device=top5.device)
+        _hits(top5, tgt, hits)
         n += len(buf)
         buf, tgt = [], []
 
@@ -170,7 +180,7 @@ def _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_p
         if len(buf) == images_per_pass:
             flush()
     flush()
-    s1, s5 = (float(s1_t) * 100.0, float(s5_t) * 100.0) if n else (0.0, 0.0)
+    s1, s5 = (float(hits[0]) * 100.0, float(hits[1]) * 100.0) if n else (0.0, 0.0)
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
 
 
@@ -179,80 +189,48 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
     that fills the chip followed by a long tail of few-row launches (the selected views through the reward model, the sampled classes'
     text passes, the final text pass) that does not — so sample i + 1 starts on another engine and another stream while sample i
     finishes.  Samples are independent units (per-sample reset, tpt_cls_rl.py:251-255): every sample's arithmetic is exactly the
-    one-at-a-time call's (rlcf_tta_batch with one image), only the wall clock changes.  Lane k takes images k, k + lanes, ..."""
-    import queue
-    import threading
+    one-at-a-time call's (rlcf_tta_batch with one image), only the wall clock changes.  Lane k takes images k, k + lanes, ...
+    ONE host thread (this one) enqueues every lane through rlcf_lanes_submit: the hand-offs between the producer's stream and the lanes
+    are device-side events, there are no Python threads, queues or per-sample torch expressions (round 5 ran one Python thread per lane;
+    its legs scattered by 30 % with the GIL's scheduling)."""
+    from collections import deque
+    from .engine import Lanes
     cfg = _config(args, optimizer, reward_model)
     prompt = hasattr(model, "prompt_learner")
     dev = torch.device("cuda", args.gpu)
-    main = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-    queues = [queue.Queue(maxsize=4) for _ in range(lanes)]
-    engines, results, errors = [], [None] * lanes, []
-
-    def lane(k):
-        ended = False
-        try:
-            torch.cuda.set_device(dev)
-            n, s1, s5 = 0, None, None
-            with torch.cuda.stream(streams[k]):
-                while True:
-                    item = queues[k].get()
-                    if item is None:
-                        ended = True
-                        break
-                    if errors:
-                        continue                             # (keep draining: the producer must not block on a full queue)
-                    views, target, ready = item
-                    streams[k].wait_event(ready)
-                    top5 = (engines[k].tta_batch if prompt else engines[k].tta_batch_ln)(views.unsqueeze(0), cfg).long()
-                    t = target.view(-1, 1)
-                    h1, h5 = (top5[:, :1] == t).any(1).float().sum(), (top5 == t).any(1).float().sum()
-                    s1, s5 = (h1, h5) if s1 is None else (s1 + h1, s5 + h5)
-                    n += 1
-                streams[k].synchronize()
-            results[k] = (n, s1, s5)
-        except BaseException as exc:                         # noqa: BLE001 — reported by the caller's thread
-            errors.append(exc)
-            while not ended and queues[k].get() is not None:  # (the producer must never block on this lane's full queue)
-                pass
-
-    threads = []
+    CHUNK = 256                                                  # samples per output block (top-5 rows live until the final count)
+    ln, blocks, targets, n = None, [], [], 0
+    in_queue = deque()                                           # one event per submitted sample: bounds how far the host runs ahead
     try:
         for i, (images, target) in enumerate(val_loader):
             if isinstance(images, list):
                 images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
             else:
                 images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
-            if not threads:                                  # engines are sized by the first image's view count
-                engines.extend(runtime.SESSION.lane_engines(lanes, images.shape[0]))
-                for e_ in engines:
-                    e_.set_side_stream(False)                # the overlap comes from the other lanes (see rlcf_engine_set_side_stream)
-                threads = [threading.Thread(target=lane, args=(k,), daemon=True) for k in range(lanes)]
-                for th in threads:
-                    th.start()
-            t = target.reshape(-1)[:1]
-            t = _upload(t, dev) if not t.is_cuda else t.to(dev)
-            k = i % lanes
-            images.record_stream(streams[k])
-            t.record_stream(streams[k])
-            ready = torch.cuda.Event()
-            ready.record(main)                               # views and label were produced on the caller's stream
-            queues[k].put((images, t, ready))
-            if errors:
-                break
-    finally:                                                 # (also when the loader raises: the lanes must end and the engines get their side streams back)
-        for q, th in zip(queues, threads):
-            q.put(None)
-        for th in threads:
-            th.join()
-        for e_ in engines:
-            e_.set_side_stream(True)
-    if errors:
-        raise errors[0]
-    n = sum(r[0] for r in results if r)
-    s1 = sum(float(r[1]) for r in results if r and r[1] is not None) * 100.0
-    s5 = sum(float(r[2]) for r in results if r and r[2] is not None) * 100.0
+            if ln is None:                                       # engines are sized by the first image's view count
+                ln = Lanes(runtime.SESSION.lane_engines(lanes, images.shape[0]))
+            if i % CHUNK == 0:
+                blocks.append(torch.empty(CHUNK, 5, dtype=torch.int32, device=dev))
+            views = images.to(dev, torch.float32).contiguous()
+            k = ln.submit(views, cfg, blocks[-1][i % CHUNK], norm_layers=not prompt)
+            targets.append(target.reshape(-1)[0])
+            n += 1
+            ev = torch.cuda.Event()
+            ev.record(ln.streams[k])
+            in_queue.append(ev)
+            if len(in_queue) > 4 * lanes:                        # (a sample's 64 views are 38 MB: at most 4 per lane wait in the queues)
+                in_queue.popleft().synchronize()
+        if ln is None:
+            return [0.0, 0.0]
+        ln.join()
+        hits = torch.zeros(2, device=dev)
+        for b, blk in enumerate(blocks):
+            m = min(CHUNK, n - b * CHUNK)
+            _hits(blk[:m], targets[b * CHUNK: b * CHUNK + m], hits)
+        s1, s5 = float(hits[0]) * 100.0, float(hits[1]) * 100.0
+    finally:
+        if ln is not None:
+            ln.close()                                           # (waits for the lanes; the engines get their side streams back)
     return [round(x, 3) for x in [s1 / max(n, 1), s5 / max(n, 1)]]
 
 
@@ -286,7 +264,8 @@ def test_time_adapt_eval(val_loader, model, optimizer, optim_state, scaler, args
         with torch.no_grad():
             model.reset()
         return _eval_batched(val_loader, model, optimizer, args, reward_model, images_per_pass)
-    if in_flight > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual:
+    if in_flight > 1 and args.tta_steps > 0 and not getattr(model, "momentum_update", False) and not full_visual and not (
+            backbone and runtime.SESSION.reset_state_moved()):      # (an earlier EMA run left lane 0 another reset state than the lanes built from the checkpoint: serial loop)
         model.eval()
         with torch.no_grad():
             model.reset()

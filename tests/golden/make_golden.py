@@ -24,6 +24,7 @@ import warnings
 
 import numpy as np
 import torch
+import torch.utils._python_dispatch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -89,6 +90,19 @@ class Bank:
         return torch.stack(rows)
 
 
+class _FastHalfMM(torch.utils._python_dispatch.TorchDispatchMode):
+    """torch's CPU kernel for a float16 mm whose SECOND operand is a contiguous [K, N] matrix (the `grad_out @ W` of every nn.Linear's
+    backward) is a scalar loop, 150x slower than the same product against a transposed view (measured here: 10.1 s vs 0.07 s at
+    3850 x 2048 x 512) — hours per test image at 1000 classes.  The fp16-autocast fixture therefore runs the reference under this
+    dispatch mode, which hands such products to the fast kernel (same operands, same mathematical product, fp32 accumulation inside the
+    library either way); nothing of the reference's code is touched."""
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if func is torch.ops.aten.mm.default and args[0].dtype == torch.float16 and args[1].is_contiguous():
+            return func(args[0], args[1].t().contiguous().t())
+        return func(*args, **(kwargs or {}))
+
+
 def install_models(ref, sds):
     """sds: arch name -> (geometry, state dict).  Makes every `load` in the
     reference return the reference's own CLIP class with our weights."""
@@ -108,6 +122,10 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     test_time_tuning, with taps on its intermediates."""
     ensemble = "+" in reward
     grid = bool(hp.pop("fp16_grid", 0))         # GEMM weights rounded to fp16 values, as a released checkpoint holds them (synth.to_fp16_grid)
+    # fp16_autocast: the arithmetic of the reference's GPU path (TPT/tpt_cls_rl.py:52,261 wrap every model call in
+    # torch.cuda.amp.autocast(); :127 GradScaler(init_scale=1000)) reproduced on this CPU-only box: the SAME reference code with
+    # torch.cuda.amp.autocast bound to torch.autocast("cpu", float16) and an ENABLED GradScaler (torch.amp.GradScaler("cpu")).
+    amp16 = bool(hp.pop("fp16_autocast", 0))
     s_geo = synth.GEOMETRIES[student]
     s_sd = synth.make_state_dict(s_geo, seed=11)
     if grid:
@@ -157,8 +175,11 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     rm.set_class_features(tokenized_classes=model.prompt_learner.tokenized_prompts)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        scaler = torch.cuda.amp.GradScaler(init_scale=1000)
+        scaler = torch.amp.GradScaler("cpu", init_scale=1000) if amp16 else torch.cuda.amp.GradScaler(init_scale=1000)
     views = synth.make_views(view_seed, n_views, s_geo.image_resolution)
+    orig_autocast = torch.cuda.amp.autocast
+    if amp16:
+        torch.cuda.amp.autocast = lambda *a, **k: torch.autocast("cpu", dtype=torch.float16)
 
     taps = {}
     orig_select = ref.tpt.select_confident_samples
@@ -193,16 +214,21 @@ def run_reference_tta(ref, student, reward, n_views, n_cls, hp, view_seed=1000, 
     with torch.no_grad():
         model.reset()
     t0 = time.time()
-    with warnings.catch_warnings():
+    import contextlib
+    with warnings.catch_warnings(), (_FastHalfMM() if amp16 else contextlib.nullcontext()):
         warnings.simplefilter("ignore")
         ref.tpt.test_time_tuning(model, views, optimizer, scaler, args, reward_model=rm)
         t1 = time.time()
         with torch.no_grad():
-            final = model(views[:1])
+            with torch.cuda.amp.autocast():            # (tpt_cls_rl.py:260-262; a disabled context on this box unless amp16)
+                final = model(views[:1])
     t2 = time.time()
+    torch.cuda.amp.autocast = orig_autocast
+    final = final.float()
     ref.tpt.select_confident_samples = orig_select
-    lg = taps["logits"]
+    lg = taps["logits"].float()
     lp = lg.log_softmax(1)
+    taps["clip_score"], taps["rewards"] = taps["clip_score"].float(), taps["rewards"].float()
     out = dict(
         logits=lg, entropy=-(lp.exp() * lp).sum(1), selected_idx=taps["selected_idx"],
         topk_idx=taps["topk_idx"].reshape(-1, hp["sample_k"]), clip_score=taps["clip_score"],
@@ -582,7 +608,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="tiny,small,ops")
     a = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
     ref = import_reference()
     for grp in a.only.split(","):
         if grp == "ops":
@@ -708,6 +734,22 @@ def main():
                       f"rewards={a_i['rewards']}", flush=True)
             save("tta_b16_n64_stream", arrays, dict(student="ViT-B/16", reward="ViT-B/16", n_views=64, n_cls=1000, student_seed=11,
                                                     reward_seed=23, view_seed0=1113, n_samples=n_s, bank_seed=7, n_ctx=4, **hp))
+        elif grp == "b16stream_fp16":
+            # the b16stream case in the arithmetic of the reference's GPU path: the reference's own code under fp16 autocast with an enabled
+            # GradScaler (see run_reference_tta, fp16_autocast).  Pins what RLCF_PREC_F16 is a performance mode OF: the test reports the
+            # engine's distance to this run next to its distance to the float32 run (tests/test_gpu_round2.py).
+            hp = dict(BASE_HP, selection_p=0.1)
+            arrays, n_s = {}, int(os.environ.get("STREAM_N", "32"))
+            for i in range(n_s):
+                t0 = time.time()
+                a_i = run_reference_tta(ref, "ViT-B/16", "ViT-B/16", 64, 1000, dict(hp, fp16_autocast=1), view_seed=1113 + i)
+                for k in ("selected_idx", "topk_idx", "clip_score", "rewards", "ctx_after", "final_logits", "top5", "entropy"):
+                    arrays[f"{k}_{i}"] = a_i[k]
+                print(f"  fp16 stream sample {i}: {time.time() - t0:.1f}s idx={a_i['selected_idx']} top5={a_i['top5']} "
+                      f"rewards={a_i['rewards']}", flush=True)
+                save("tta_b16_n64_stream_fp16ref", arrays, dict(student="ViT-B/16", reward="ViT-B/16", n_views=64, n_cls=1000, student_seed=11,
+                                                                reward_seed=23, view_seed0=1113, n_samples=i + 1, bank_seed=7, n_ctx=4,
+                                                                arithmetic="torch.autocast(cpu, float16) + GradScaler(init_scale=1000)", **hp))
         elif grp == "b16gridstream":
             # the b16stream case on CHECKPOINT-GRID weights (every GEMM weight an fp16 value, synth.to_fp16_grid): the reference's own run on
             # the weights for which the engine drops the a_hi . w_lo pass — pins the two-pass products to the reference directly

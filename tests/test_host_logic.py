@@ -73,3 +73,45 @@ def test_loop_options_come_from_keyword_then_args_then_environment(monkeypatch):
     monkeypatch.setenv("RLCF_IMAGES_PER_PASS", "0")
     with pytest.raises(ValueError):
         _loop_option(None, bare, "images_per_pass")
+
+
+def test_view_prefetcher_makes_the_draws_of_the_plain_loop():
+    """datautils.ViewPrefetcher runs the host half of the augmenter (crop boxes, AugMix plans) on ONE loader thread ahead of the loop:
+    for a seeded run the draws, their order and the targets are those of the plain loop (the device half is stubbed: no GPU here)."""
+    import numpy as np
+    import torch
+    from rlcf_amd import datautils
+
+    class Aug(datautils.AugMixAugmenter):
+        def apply(self, img, params):
+            self.seen.append((tuple(img.shape), params))
+            return torch.zeros(1 + self.n_views, 3, 2, 2)
+
+    imgs = [(torch.zeros(30 + 3 * i, 40 + i, 3, dtype=torch.uint8), i) for i in range(6)]
+    for augmix in (False, True):
+        a = Aug(n_views=7, augmix=augmix)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        plain = [(tuple(im.shape), a.draw(im.shape[0], im.shape[1])) for im, _ in imgs]
+        a.seen = []
+        torch.manual_seed(3)
+        np.random.seed(3)
+        got = list(datautils.ViewPrefetcher(imgs, a, depth=2))
+        assert [int(t) for _, t in got] == list(range(6)) and all(len(v) == 8 and v[0].shape == (1, 3, 2, 2) for v, _ in got)
+        assert len(a.seen) == 6
+        for (s0, p0), (s1, p1) in zip(plain, a.seen):
+            assert s0 == s1 and p0[0] == p1[0]
+            if augmix:
+                for (w0, m0, c0), (w1, m1, c1) in zip(p0[1], p1[1]):
+                    assert np.array_equal(w0, w1) and m0 == m1 and c0 == c1
+    # an exception of the dataset reaches the consuming loop
+    def bad():
+        yield imgs[0]
+        raise ValueError("decode failed")
+    a = Aug(n_views=2)
+    a.seen = []
+    try:
+        list(datautils.ViewPrefetcher(bad(), a))
+        raise AssertionError("the loader's exception was swallowed")
+    except ValueError as exc:
+        assert "decode failed" in str(exc)
