@@ -391,6 +391,9 @@ int rlcf_engine_set_side_stream(rlcf_engine*, int on);
  * (accuracy() + AverageMeter, TPT/tpt_cls_rl.py:265-268) from the engine's own top-5 output, accumulated on the device. */
 typedef struct rlcf_lanes rlcf_lanes;
 rlcf_lanes* rlcf_lanes_create(rlcf_engine* const* engines, int n);
+/* the same on the CALLER's streams (one per lane, e.g. torch.cuda.Stream objects, whose allocator then understands record_stream on them):
+ * used, synchronised at destroy time, never destroyed */
+rlcf_lanes* rlcf_lanes_create_on(rlcf_engine* const* engines, int n, const rlcf_stream* streams);
 void rlcf_lanes_destroy(rlcf_lanes*);
 int rlcf_lanes_count(const rlcf_lanes*);
 rlcf_stream rlcf_lanes_stream(const rlcf_lanes*, int k);

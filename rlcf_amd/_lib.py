@@ -135,6 +135,7 @@ SIGNATURES = {
     "rlcf_engine_set_side_stream": (I, [P, I]),
     "rlcf_engine_set_f16_lnfold": (I, [P, I]),
     "rlcf_lanes_create": (P, [P, I]),
+    "rlcf_lanes_create_on": (P, [P, I, P]),
     "rlcf_lanes_destroy": (None, [P]),
     "rlcf_lanes_count": (I, [P]),
     "rlcf_lanes_stream": (P, [P, I]),

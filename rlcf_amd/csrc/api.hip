@@ -681,25 +681,36 @@ struct rlcf_lanes {
     std::vector<bool> side_was_off;
     hipEvent_t ready = nullptr;          // "the producer's work so far" (views, labels), re-recorded per submit
     int next = 0;
+    bool own_streams = true;             // false: the caller's streams (rlcf_lanes_create_on): never destroyed here
 };
 void rlcf_lanes_destroy(rlcf_lanes* l) {
     if (!l) return;
-    for (size_t k = 0; k < l->st.size(); ++k) if (l->st[k]) { (void)hipStreamSynchronize(l->st[k]); (void)hipStreamDestroy(l->st[k]); }
+    for (size_t k = 0; k < l->st.size(); ++k) if (l->st[k]) { (void)hipStreamSynchronize(l->st[k]); if (l->own_streams) (void)hipStreamDestroy(l->st[k]); }
     for (hipEvent_t ev : l->done) if (ev) (void)hipEventDestroy(ev);
     if (l->ready) (void)hipEventDestroy(l->ready);
     for (size_t k = 0; k < l->eng.size() && k < l->side_was_off.size(); ++k) l->eng[k]->no_side = l->side_was_off[k];
     delete l;
 }
-rlcf_lanes* rlcf_lanes_create(rlcf_engine* const* engines, int n) {
+static rlcf_lanes* lanes_create(rlcf_engine* const* engines, int n, const rlcf_stream* streams);
+rlcf_lanes* rlcf_lanes_create(rlcf_engine* const* engines, int n) { return lanes_create(engines, n, nullptr); }
+rlcf_lanes* rlcf_lanes_create_on(rlcf_engine* const* engines, int n, const rlcf_stream* streams) {
+    if (!streams) { rlcf_set_error("rlcf_lanes_create_on: streams"); return nullptr; }
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < k; ++j)
+            if (streams[j] == streams[k]) { rlcf_set_error("rlcf_lanes_create_on: one stream per lane"); return nullptr; }
+    return lanes_create(engines, n, streams);
+}
+static rlcf_lanes* lanes_create(rlcf_engine* const* engines, int n, const rlcf_stream* streams) {
     if (!engines || n < 1 || n > 16) { rlcf_set_error("rlcf_lanes_create: 1..16 engines"); return nullptr; }
     for (int k = 0; k < n; ++k)
         for (int j = 0; j <= k; ++j)
             if (!engines[k] || (j < k && engines[j] == engines[k])) { rlcf_set_error("rlcf_lanes_create: engines must be distinct (an engine serves one call at a time)"); return nullptr; }
     rlcf_lanes* l = new rlcf_lanes();
+    l->own_streams = streams == nullptr;
     bool ok = hipEventCreateWithFlags(&l->ready, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < n && ok; ++k) {
-        hipStream_t s = nullptr; hipEvent_t ev = nullptr;
-        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        hipStream_t s = streams ? (hipStream_t)streams[k] : nullptr; hipEvent_t ev = nullptr;
+        ok = (streams || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         l->st.push_back(s); l->done.push_back(ev);
     }
     if (!ok) { rlcf_set_error("rlcf_lanes_create: stream / event creation failed"); rlcf_lanes_destroy(l); return nullptr; }

@@ -524,11 +524,13 @@ class Lanes:
         self.lib = L.lib()
         self.engines = list(engines)
         arr = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
-        self.h = self.lib.rlcf_lanes_create(arr, len(self.engines))
+        # torch's own (pool, non-blocking) streams: the caching allocator keeps a recorded stream's handle for as long as the block lives,
+        # so the lanes must not run on streams that are destroyed with the lanes object
+        self.streams = [torch.cuda.Stream(device=self.engines[0].device) for _ in self.engines]
+        sarr = (C.c_void_p * len(self.engines))(*[s.cuda_stream for s in self.streams])
+        self.h = self.lib.rlcf_lanes_create_on(arr, len(self.engines), sarr)
         if not self.h:
-            raise L.RlcfError("rlcf_lanes_create: " + self.lib.rlcf_last_error().decode())
-        dev = self.engines[0].device
-        self.streams = [torch.cuda.ExternalStream(self.lib.rlcf_lanes_stream(self.h, k), device=dev) for k in range(len(self.engines))]
+            raise L.RlcfError("rlcf_lanes_create_on: " + self.lib.rlcf_last_error().decode())
 
     def submit(self, views: torch.Tensor, cfg: TTAConfig, top5_row: torch.Tensor, norm_layers: bool = False,
                final_logits: Optional[torch.Tensor] = None) -> int:
