@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NW == 4 ? 2 : 1)) void atte
                 if (kc >= nkeys) break;
                 if constexpr (!(VAR & 64)) ap_sub<SINGLE, VAR, QB>(acc, qh, ql, sk_ + kb_e + sub * 32 * 64, sk_ + kb_o + sub * 32 * 64, vl_ + sub * 32 * 64, kc, nkeys, h,
                                                                    (c == 1 && sub == 1) ? trc : nullptr);
-                if (c < 4) AP_STAMP(4 + 4 * c + sub)
+                if (c < 4 && sub < 2) AP_STAMP(4 + 4 * c + sub)
             }
         }
     }
@@ -362,6 +362,14 @@ static int ap_launch(bool single, dim3 grid, hipStream_t st, const _Float16* qkv
         return RLCF_OK;                                                                                                   \
     }
     if (single) {
+#ifdef RLCF_ATTN_ABLATION                                    // (measurement builds: the single-pass form's ablations, as below for the pair form)
+        if constexpr (NW == 8 && SK == 64) {
+            if (var == 8) AP_GO(true, 8, lds_single)
+            if (var == 32) AP_GO(true, 32, lds_single)
+            if (var == 40) AP_GO(true, 40, lds_single)
+            if (var == 64) AP_GO(true, 64, lds_single)
+        }
+#endif
         if (var & 1) AP_GO(true, 1, lds_single)
         AP_GO(true, 0, lds_single)
     }
@@ -411,7 +419,13 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
         const int full = max_q_len / 256, tail = max_q_len - full * 256;
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch
         dim3 grid(split_tail ? full : (max_q_len + 255) / 256, n_seq, H);
-        int rc = ap_launch<8, 64>(single, grid, st, q2, seqs, width, out, oh, il, 0, lse);
+        // RLCF_ATTN_SK=128 (measurement, single-pass f16 operands only — the pair form would need 128 KB of LDS per workgroup): stages of
+        // 128 keys, ONE barrier per 128 keys instead of per 64 (round 3 traced 24 % of a wave's time at the chunk barriers).  Built and
+        // measured in round 6: profiles/r6_attention_breakdown.txt.
+        const char* ske = getenv("RLCF_ATTN_SK");                 // (read per launch: in-process A/B)
+        const bool sk128 = ske && atoi(ske) == 128;
+        int rc = (single && sk128) ? ap_launch<8, 128>(single, grid, st, q2, seqs, width, out, oh, il, 0, lse)
+                                   : ap_launch<8, 64>(single, grid, st, q2, seqs, width, out, oh, il, 0, lse);
         if (rc != RLCF_OK) return rc;
         if (split_tail) return ap_launch<1, 32>(single, dim3(1, n_seq, H), st, q2, seqs, width, out, oh, il, full * 8, lse);
         return RLCF_OK;
