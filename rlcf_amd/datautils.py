@@ -340,11 +340,11 @@ class ViewPrefetcher:
     (TPT/data/datautils.py:113-128) — so the draws of image i + 1 happen while image i is being tuned.  The device-side augmenter
     cannot run in forked workers; this is its equivalent: ONE loader thread walks `dataset` (any iterable / indexable of (image,
     target)), decodes the image to uint8 [H, W, 3] and makes the host-side draws (`AugMixAugmenter.draw`: ~1 ms of generator calls per
-    image) up to `depth` images ahead; the consuming loop's thread only launches the device half (`apply`, ~0.1 ms of host time).
+    image) up to `depth` images ahead (a queued item is the uint8 image + its draws, ~0.5 MB: a pass of 32 images is drawn while the previous one runs); the consuming loop's thread only launches the device half (`apply`, ~0.1 ms of host time).
     One thread draws, in dataset order: a seeded run makes the same draws as the plain loop.  Yields what the reference's loader
     yields with batch size 1: ([view [1, 3, R, R]] * N, target)."""
 
-    def __init__(self, dataset, augmenter: "AugMixAugmenter", depth: int = 2, as_list: bool = True):
+    def __init__(self, dataset, augmenter: "AugMixAugmenter", depth: int = 32, as_list: bool = True):
         self.dataset, self.aug, self.depth, self.as_list = dataset, augmenter, max(1, int(depth)), as_list
 
     def __len__(self):

@@ -115,3 +115,18 @@ def test_view_prefetcher_makes_the_draws_of_the_plain_loop():
         raise AssertionError("the loader's exception was swallowed")
     except ValueError as exc:
         assert "decode failed" in str(exc)
+
+
+def test_local_device_refuses_more_nccl_ranks_than_gpus(monkeypatch):
+    """shard.local_device: under nccl (= RCCL) a local rank beyond the visible devices is an error with a message (bench.py / eval.py used
+    to wrap it modulo the device count and die inside RCCL); gloo may share a device; no device at all is an error either way."""
+    import pytest
+    import torch
+    from rlcf_amd import shard
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert shard.local_device(1, "nccl") == 1 and shard.local_device(3, "gloo") == 1
+    with pytest.raises(RuntimeError, match="visible"):
+        shard.local_device(2, "nccl")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(RuntimeError, match="no visible GPU"):
+        shard.local_device(0, "gloo")
