@@ -556,7 +556,7 @@ def main():
             # HBM/fabric bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters perturb timing
             # and cannot be read in-process); they are quoted only from a committed profile of this exact pass size
             traffic, tsrc = None, None
-            tname = next((n for n in ("r5_gemm_hbm_traffic.json", "r4_gemm_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+            tname = next((n for n in ("r6_gemm_hbm_traffic.json", "r5_gemm_hbm_traffic.json", "r4_gemm_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
             if a.precision == "f16x3" and tname and a.config == 1 and is_default_wl:
                 rec = json.load(open(os.path.join(ROOT, "profiles", tname))).get("bytes_per_launch_by_images_per_pass", {}).get(str(pass_images))
                 if rec:
@@ -565,10 +565,11 @@ def main():
             # MFMA-pipe utilisation by COUNTER (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)) of the dominant kernel on this round's build:
             # like `traffic`, read from the committed rocprofv3 --pmc profile of the same GEMM shapes (counters cannot be read in-process)
             busy, bsrc = None, None
-            cpath = os.path.join(ROOT, "profiles", "r5_sq_counters.json")
-            if a.precision == "f16x3" and os.path.exists(cpath) and a.config == 1 and is_default_wl:
+            cname = next((n for n in ("r6_sq_counters.json", "r5_sq_counters.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+            cpath = os.path.join(ROOT, "profiles", cname or "none")
+            if a.precision == "f16x3" and cname and a.config == 1 and is_default_wl:
                 busy = json.load(open(cpath)).get("summary", {}).get("dominant_gemm_parity_mode_mfma_busy")
-                bsrc = ("profiles/r5_sq_counters.txt: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA over the four layer products "
+                bsrc = (f"profiles/{cname[:-5]}.txt: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA over the four layer products "
                         "at 20 images per pass (tools/r5_sq_counters.sh), cycles summed over the launches; at the clock the part sustains under the counters")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -425,6 +425,13 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
         // workgroup, one workgroup per CU.  RLCF_ATTN_SK=64 (read per launch): the 64-key stages for the single form too.
         const char* ske = getenv("RLCF_ATTN_SK");
         const bool sk128 = !(ske && atoi(ske) == 64);
+        // RLCF_ATTN_NW=4 (measurement, single-pass form): workgroups of FOUR waves = 128 queries — a 197-token sequence is two workgroups
+        // that each stage all of K / V (twice the K / V reads, from L2 at best), four independent workgroups per CU instead of two
+        const char* nwe = getenv("RLCF_ATTN_NW");
+        if (single && nwe && atoi(nwe) == 4) {
+            dim3 g4((max_q_len + 127) / 128, n_seq, H);
+            return sk128 ? ap_launch<4, 128>(single, g4, st, q2, seqs, width, out, oh, il, 0, lse) : ap_launch<4, 64>(single, g4, st, q2, seqs, width, out, oh, il, 0, lse);
+        }
         int rc = (single && sk128) ? ap_launch<8, 128>(single, grid, st, q2, seqs, width, out, oh, il, 0, lse)
                                    : ap_launch<8, 64>(single, grid, st, q2, seqs, width, out, oh, il, 0, lse);
         if (rc != RLCF_OK) return rc;

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
 //     is issued behind, so no load of the ring ever waits for it, and it has a whole K tile to retire before the next wait covers it.
 //     Round 5 had tried the registers but issued all 8 stores under K tiles 0 and 1 — directly behind the burst of the other half,
 //     where every wait of those K tiles then sat behind a congested store; spread over the K loop the chip sees them at 1/12 of the
-//     burst rate.  RLCF_F16_PP_DEFER=0: off (A/B).  profiles/r6_notes.md section 1.
+//     burst rate.  MEASURED SLOWER (2-3 % on the layer): the K loop is bound by vector-memory issue, a store costs it what a DMA piece costs.
+//     Off by default, RLCF_F16_PP_DEFER=1 turns it on (A/B, tests).  profiles/r6_notes.md section 1.
 template <int EPI, int MODE = 0, int DEFER = 0, int TRACE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
@@ -717,9 +718,11 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
             RLCF_HIP_CHECK(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
             g.ws = (float*)trace_buf;
         }
-        // RLCF_F16_PP_DEFER (read per launch: A/B inside one process): 1 = half of every tile's stores ride under the next tile's K loop
+        // RLCF_F16_PP_DEFER=1 (read per launch: A/B inside one process): half of every tile's stores ride under the next tile's K loop.
+        // OFF by default: bit-identical, but 2-3 % SLOWER on the layer's four products (in_proj +-0, out_proj -9 %, c_fc -3.5 %) — the K
+        // loop has no spare vector-memory issue capacity, a deferred store costs it what a DMA piece costs (profiles/r6_notes.md section 1)
         const char* de = getenv("RLCF_F16_PP_DEFER");
-        const bool defer = (de ? atoi(de) : 1) != 0 && abl == 0 && blocks > grid && K >= 768;
+        const bool defer = (de ? atoi(de) : 0) != 0 && abl == 0 && blocks > grid && K >= 768;
 #define PP_GO(E, D, T)                                                                                                              \
     {                                                                                                                               \
         int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, 0, D, T>, shp);                                                 \

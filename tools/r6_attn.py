@@ -35,15 +35,17 @@ for mode, prec, bytes_per in (("pair (parity mode)", L.PREC_F16X3, 16.0), ("sing
     if abl:
         builds += [("no MFMAs", 8, sk_abl), ("no K/V DMA", 32, sk_abl), ("no DMA, no MFMAs", 40, sk_abl), ("streaming only", 64, sk_abl)]
     if prec == L.PREC_F16:
-        builds += [("64-key stages", 1, "64")]
+        builds += [("64-key stages", 1, "64"), ("4-wave WGs, 128-key", 1, "nw4"), ("4-wave WGs, 64-key", 1, "nw4_64")]
     times = {b[0]: [] for b in builds}
     for r in range(rounds + 1):
         for name, var, sk in builds:
             lib.rlcf_attention_debug(0, var)
-            if sk:
-                os.environ["RLCF_ATTN_SK"] = sk
-            else:
-                os.environ.pop("RLCF_ATTN_SK", None)                 # (default: 128-key stages for the single-pass form since round 6)
+            os.environ.pop("RLCF_ATTN_SK", None)                     # (default: 128-key stages for the single-pass form since round 6)
+            os.environ.pop("RLCF_ATTN_NW", None)
+            if sk in ("64", "nw4_64"):
+                os.environ["RLCF_ATTN_SK"] = "64"
+            if sk in ("nw4", "nw4_64"):
+                os.environ["RLCF_ATTN_NW"] = "4"
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,6 +58,28 @@ for mode, prec, bytes_per in (("pair (parity mode)", L.PREC_F16X3, 16.0), ("sing
                 times[name].append(e0.elapsed_time(e1) / 5 * 1e3)
     lib.rlcf_attention_debug(0, 1)
     os.environ.pop("RLCF_ATTN_SK", None)
+    os.environ.pop("RLCF_ATTN_NW", None)
+    # the structure variants (not the ablations) must give the shipped kernel's bits
+    ref_out = None
+    for name, var, sk in builds:
+        if var != 1:
+            continue
+        lib.rlcf_attention_debug(0, 1)
+        os.environ.pop("RLCF_ATTN_SK", None)
+        os.environ.pop("RLCF_ATTN_NW", None)
+        if sk in ("64", "nw4_64"):
+            os.environ["RLCF_ATTN_SK"] = "64"
+        if sk in ("nw4", "nw4_64"):
+            os.environ["RLCF_ATTN_NW"] = "4"
+        op.fill_(float("nan"))
+        run()
+        torch.cuda.synchronize()
+        if ref_out is None:
+            ref_out = op.clone()
+        else:
+            print(f"   [{name}] == shipped: bit-equal {torch.equal(op, ref_out)}, max|d| {(op.float() - ref_out.float()).abs().max().item():.2e}")
+    os.environ.pop("RLCF_ATTN_SK", None)
+    os.environ.pop("RLCF_ATTN_NW", None)
     hbm_us = T * W * bytes_per / 8000e9 * 1e6
     print(f"== {mode}: algorithmic bytes {T * W * bytes_per / 1e9:.3f} GB -> HBM roofline {hbm_us:.0f} us at 8 TB/s; {flops / 1e9:.1f} GFLOP")
     for name, _, _ in builds:
