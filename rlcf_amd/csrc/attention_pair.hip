@@ -419,12 +419,12 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
         const int full = max_q_len / 256, tail = max_q_len - full * 256;
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch
         dim3 grid(split_tail ? full : (max_q_len + 255) / 256, n_seq, H);
-        // Single-pass f16 operands (round 6): stages of 128 keys — ONE barrier per 128 keys instead of per 64 (round 3 traced 24 % of a
-        // wave's time at the chunk barriers; a 197-token sequence is two stages instead of four): 406.8 -> 389.9 us in-process A/B at
-        // 1 280 sequences (profiles/r6_attention_breakdown.txt).  The pair form keeps 64-key stages: 128 would need 128 KB of LDS per
-        // workgroup, one workgroup per CU.  RLCF_ATTN_SK=64 (read per launch): the 64-key stages for the single form too.
+        // RLCF_ATTN_SK=128 (measurement, read per launch; single-pass f16 operands only — the pair form would need 128 KB of LDS per
+        // workgroup): stages of 128 keys, ONE barrier per 128 keys instead of per 64.  Round 6, order-controlled in-process A/B at 1 280
+        // sequences: 399.5 - 402.9 us against 384.3 - 385.8 for the 64-key stages — 3.7 % SLOWER (a first A/B that ran it right behind a
+        // streaming-only ablation build had shown it 4 % faster: a clock carry-over, not the kernel).  profiles/r6_attention_breakdown.txt.
         const char* ske = getenv("RLCF_ATTN_SK");
-        const bool sk128 = !(ske && atoi(ske) == 64);
+        const bool sk128 = ske && atoi(ske) == 128;
         // RLCF_ATTN_NW=4 (measurement, single-pass form): workgroups of FOUR waves = 128 queries — a 197-token sequence is two workgroups
         // that each stage all of K / V (twice the K / V reads, from L2 at best), four independent workgroups per CU instead of two
         const char* nwe = getenv("RLCF_ATTN_NW");
