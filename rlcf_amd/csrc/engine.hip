@@ -1393,1088 +1393,7 @@ int engine_text_backward_dense(rlcf_engine* e, const float* ctx, const float* im
     return RLCF_OK;
 }
 
-// Sparse backward layout for n_e = n_sel*K sampled (view, class) pairs.
-static int sparse_ensure(rlcf_engine* e, int n_e_per_group, hipStream_t st, int groups = 1) {
-    if (n_e_per_group <= e->sp_max_e && groups <= e->sp_groups) return RLCF_OK;
-    ClipModel& m = e->model[RLCF_STUDENT];
-    const TextLayout& L = e->lay[0];
-    const int Wt = m.cfg.text_width, D = m.cfg.embed_dim;
-    groups = std::max(groups, e->sp_groups);
-    n_e_per_group = std::max(n_e_per_group, e->sp_max_e);
-    const int T = groups * (L.pre_rows + n_e_per_group * L.lmax);
-    const int n_e = groups * n_e_per_group;
-    TRY(e->sp_seqs.ensure((size_t)(n_e + groups) * sizeof(rlcf_seq))); TRY(e->sp_eot_rows.ensure(n_e * sizeof(int32_t)));
-    TRY(e->sp_row_src.ensure((size_t)T * sizeof(int32_t)));
-    std::vector<int32_t> list;
-    if (L.pre_rows > 0) for (int j = 0; j < L.n_ctx; ++j) list.push_back(1 + j);
-    else for (int k = 0; k < n_e_per_group; ++k) for (int j = 0; j < L.n_ctx; ++j) list.push_back(k * L.lmax + 1 + j);
-    TRY(upload(e->sp_ctx_rows_list, list, st));
-    TRY(e->sp_dtxt.ensure((size_t)n_e * D * sizeof(float))); TRY(e->sp_txt.ensure((size_t)n_e * D * sizeof(float)));
-    TRY(e->sp_inv_norm.ensure(n_e * sizeof(float))); TRY(e->sp_eot_x.ensure((size_t)n_e * Wt * sizeof(float)));
-    TRY(e->sp_eot_ln.ensure((size_t)n_e * Wt * sizeof(float))); TRY(e->sp_u.ensure((size_t)n_e * D * sizeof(float)));
-    TRY(e->sp_du.ensure((size_t)std::max(n_e, L.C) * D * sizeof(float))); TRY(e->sp_dxe.ensure((size_t)std::max(n_e, L.C) * Wt * sizeof(float)));
-    TRY(tower_ensure(e->st, T, Wt, st));
-    TRY(tower_ensure_saved(e->st, T, Wt, m.cfg.text_layers, st));
-    TRY(bwd_ensure(e, T, Wt));
-    e->sp_max_e = n_e_per_group; e->sp_T = T; e->sp_groups = groups;
-    return RLCF_OK;
-}
-
-// the two halves of the sparse pass: the forward over the sampled (view, class) pairs needs only their class indices (top-K of the
-// student's own logits) — the one-image call runs it next to the reward models' tower pass —, the backward needs the rewards
-static TextPassIO sparse_io(rlcf_engine* e, int n_e) {
-    const TextLayout& L = e->lay[0];
-    TextPassIO io{};
-    io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = n_e + (L.pre_rows > 0 ? 1 : 0); io.max_q_len = L.max_q_len; io.T = L.pre_rows + n_e * L.lmax;
-    io.n_cls = n_e;
-    io.attn_pairs = (long)(n_e * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
-    io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
-    io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
-    io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
-    io.ctx_row_tab = L.ctx_general ? L.ctx_row.as<int32_t>() : nullptr;
-    return io;
-}
-static int sparse_forward(rlcf_engine* e, const float* ctx, const int32_t* cls, int n_e, hipStream_t st) {
-    ClipModel& m = e->model[RLCF_STUDENT];
-    const TextLayout& L = e->lay[0];
-    TRY(launch_build_sparse_layout(cls, 1, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(), L.class_eot_off.as<int32_t>(),
-                                   L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
-                                   e->sp_row_src.as<int32_t>(), st));
-    return text_forward(e, m, L, e->st, ctx, sparse_io(e, n_e), true, st);
-}
-static int sparse_backward_only(rlcf_engine* e, const float* sel_feat, const int32_t* cls, int n_e, int K, const float* dlogits, float* dctx,
-                                hipStream_t st) {
-    ClipModel& m = e->model[RLCF_STUDENT];
-    const TextLayout& L = e->lay[0];
-    const int D = m.cfg.embed_dim;
-    TRY(launch_dtxt_sparse(dlogits, cls, sel_feat, n_e, K, L.C, D, m.logit_scale_exp, e->sp_dtxt.as<float>(), st));
-    return text_backward(e, m, e->st, sparse_io(e, n_e), L.max_keys, e->sp_dtxt.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
-                         e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, L.n_ctx, dctx, st);
-}
-static int sparse_backward(rlcf_engine* e, const float* ctx, const float* sel_feat, const int32_t* cls, int n_e, int K,
-                           const float* dlogits, float* dctx, hipStream_t st) {
-    TRY(sparse_forward(e, ctx, cls, n_e, st));
-    return sparse_backward_only(e, sel_feat, cls, n_e, K, dlogits, dctx, st);
-}
-
-// ------------------------------------------------------------------ one test sample
-// set_image_features of every reward model on the selected views (clip_reward.py:59-61,130-137,259-270); the optional
-// output is the per-model blocks [rows, Dr_m] one after another.
-static int reward_encode(rlcf_engine* e, int rows, int in_res, float* out_concat, hipStream_t st) {
-    for (int m = 0; m < e->n_rewards; ++m) {
-        const int Dr = e->model[RLCF_REWARD + m].cfg.embed_dim;
-        TRY(engine_encode_image(e, RLCF_REWARD + m, e->views_sel.as<float>(), rows, e->rimg[m].as<float>(), st, in_res));
-        if (out_concat) {
-            RLCF_HIP_CHECK(hipMemcpyAsync(out_concat, e->rimg[m].p, (size_t)rows * Dr * sizeof(float), hipMemcpyDeviceToDevice, st));
-            out_concat += (size_t)rows * Dr;
-        }
-    }
-    return RLCF_OK;
-}
-static RewardBank reward_bank(const rlcf_engine* e) {
-    RewardBank b{};
-    b.n = e->n_rewards;
-    for (int m = 0; m < e->n_rewards; ++m) {
-        b.class_feat[m] = e->reward_cls[m].as<float>(); b.reward_img[m] = e->rimg[m].as<float>();
-        b.Dr[m] = e->model[RLCF_REWARD + m].cfg.embed_dim;
-        b.mix[m] = e->reward_mean ? 1.f : e->reward_mix[m];
-    }
-    b.post_div = e->reward_mean ? (float)e->n_rewards : 1.f;
-    return b;
-}
-
-// Harness body TPT/tpt_cls_rl.py:251-262 around test_time_tuning (:47-79).
-#define COPY_OUT(dst, src, bytes) do { if (dst) RLCF_HIP_CHECK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, st)); } while (0)
-int engine_tta_sample(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (e->C <= 0 || e->image_bank || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    if (e->n_ctx <= 0) { rlcf_set_error("prompt tuning needs a class bank with learnable context rows (n_ctx > 0)"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32);
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
-    const int n_sel = n_selected(a, N);                       // int() truncation, tpt_cls_rl.py:34
-    RLCF_ARG_CHECK(K <= C);
-    if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
-    const size_t cb = (size_t)n_ctx * Wt * sizeof(float);
-    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const rlcf_tta_out none{};
-    if (!out) out = &none;
-    const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
-                           !(a->flags & RLCF_F_MIN_ENTROPY) && K > 1;
-    const int n_e = n_sel * K;
-    if (a->tta_steps > 0) {
-        if (sparse_ok) TRY(sparse_ensure(e, n_e, st));
-        else {
-            TRY(tower_ensure_saved(e->tt, e->lay[0].T, Wt, s.cfg.text_layers, st));
-            TRY(bwd_ensure(e, e->lay[0].T, Wt));
-            TRY(e->sp_du.ensure((size_t)C * D * sizeof(float))); TRY(e->sp_dxe.ensure((size_t)C * Wt * sizeof(float)));
-        }
-    }
-    e->last_flops = 0.0;
-    float* ctx = e->ctx.as<float>();
-    // model.reset() + optimizer.load_state_dict(optim_state): custom_clip.py:161-164, tpt_cls_rl.py:251-255
-    RLCF_HIP_CHECK(hipMemcpyAsync(ctx, a->ctx_in ? (const void*)a->ctx_in : e->ctx_init.p, cb, hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->adam_m.p, 0, cb, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->adam_v.p, 0, cb, st));
-    // student image features of all N views: computed once (the image tower is frozen, custom_clip.py:325-327)
-    TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
-    TextPassIO io = full_io(e, e->lay[0]);
-    static int no_overlap = -1;                              // RLCF_NO_OVERLAP=1: everything on the caller's stream (benchmarks)
-    if (no_overlap < 0) { const char* ev = getenv("RLCF_NO_OVERLAP"); no_overlap = ev ? atoi(ev) : 0; }
-    bool vit_rewards = true;
-    for (int m = 0; m < e->n_rewards; ++m) vit_rewards = vit_rewards && !is_resnet(e->model[RLCF_REWARD + m].cfg);
-    const bool overlap = sparse_ok && vit_rewards && !no_overlap && !e->no_side && !g_prof.enabled && e->side && prec_x3(e) && !prec_single(e);
-    bool fwd_done = false;
-    for (int j = 0; j < a->tta_steps; ++j) {
-        // step 0 runs on ctx == ctx_init: its text features are the cached txt0 (the dense-backward
-        // path still needs this pass for its saved activations)
-        const bool cached = (j == 0 && sparse_ok && !a->ctx_in);
-        if (!cached) TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, !sparse_ok, st));
-        const float* txt_j = cached ? e->txt0.as<float>() : e->txt.as<float>();
-        const float* rows_logits;
-        if (j == 0) {   // tpt_cls_rl.py:57-59
-            TRY(engine_logits(e, e->img_feat.as<float>(), N, txt_j, C, e->logits.as<float>(), st));
-            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-            TRY(launch_gather_rows(e->img_feat.as<float>(), D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, n_sel, D, st));
-            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            // the reward models' pass over the selected views depends on nothing the student does from here to the loss, and at one
-            // image's sizes neither it nor the sparse text forward fills the chip: second stream, joined before the loss kernel
-            if (overlap) {
-                // the side stream's own A-operand buffer: the patch matrix of the selected views or a <= 512-row token matrix against a
-                // W x 4W weight, whichever reward model needs more (the main stream keeps a_hi for the text passes it runs meanwhile)
-                size_t need2 = 0;
-                for (int m = 0; m < e->n_rewards; ++m) {
-                    const ClipModel& rm = e->model[RLCF_REWARD + m];
-                    need2 = std::max(need2, (size_t)n_sel * rm.tokens * std::max(rm.Kp, 4 * rm.cfg.vision_width));
-                }
-                if (need2 > e->a_split2_elems) { TRY(e->a_hi2.ensure(need2 * 4)); e->a_split2_elems = need2; }
-                RLCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-                RLCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-                e->ws_sel = 1;
-                const int rc_side = reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, e->side);
-                e->ws_sel = 0;
-                const hipError_t er = hipEventRecord(e->ev_join, e->side);      // (recorded even after an error: the main stream must not run ahead)
-                if (rc_side != RLCF_OK || er != hipSuccess) {
-                    (void)hipStreamWaitEvent(st, e->ev_join, 0);
-                    if (er != hipSuccess) { (void)hipStreamSynchronize(e->side); rlcf_set_error("hipEventRecord(ev_join): %s", hipGetErrorString(er)); return RLCF_ERR_HIP; }
-                    return rc_side;
-                }
-            } else {
-                TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
-            }
-            TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
-            rows_logits = e->sel_logits.as<float>();
-            if (overlap) {
-                // whatever happens on the main stream, it joins the side stream before this call returns: the side stream writes
-                // e->vt, e->rimg and the caller's reward_image_features
-                int rc_main = launch_topk_rows(rows_logits, C, n_sel, C, K, e->topk_idx.as<int32_t>(), e->rl_stats.as<float>(), st);
-                if (rc_main == RLCF_OK) rc_main = sparse_forward(e, ctx, e->topk_idx.as<int32_t>(), n_e, st);
-                fwd_done = true;
-                const hipError_t ej = hipStreamWaitEvent(st, e->ev_join, 0);
-                if (rc_main != RLCF_OK) { if (ej != hipSuccess) (void)hipStreamSynchronize(e->side); return rc_main; }
-                if (ej != hipSuccess) { (void)hipStreamSynchronize(e->side); rlcf_set_error("hipStreamWaitEvent(ev_join): %s", hipGetErrorString(ej)); return RLCF_ERR_HIP; }
-            }
-            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
-            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
-            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
-        } else {        // tpt_cls_rl.py:55 — selected views only; their image features are unchanged
-            TRY(engine_logits(e, e->sel_feat.as<float>(), n_sel, txt_j, C, e->sel_logits.as<float>(), st));
-            rows_logits = e->sel_logits.as<float>();
-        }
-        TRY(launch_reward_loss_bank(rows_logits, C, nullptr, 1, n_sel, C, K, reward_bank(e),
-                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
-                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        if (sparse_ok && fwd_done) {
-            TRY(sparse_backward_only(e, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(), e->ctx_grad.as<float>(), st));
-            fwd_done = false;
-        } else if (sparse_ok) {
-            TRY(sparse_backward(e, ctx, e->sel_feat.as<float>(), e->topk_idx.as<int32_t>(), n_e, K, e->dlogits.as<float>(),
-                                e->ctx_grad.as<float>(), st));
-        } else {
-            TRY(launch_dtxt_dense(e->dlogits.as<float>(), e->sel_feat.as<float>(), n_sel, C, D, s.logit_scale_exp, e->dtxt_dense.as<float>(), st));
-            TRY(text_backward(e, s, e->tt, io, e->lay[0].max_keys, e->dtxt_dense.as<float>(), e->sp_du.as<float>(), e->sp_dxe.as<float>(),
-                              e->lay[0].ctx_rows_list.as<int32_t>(), e->lay[0].n_copies, n_ctx, e->ctx_grad.as<float>(), st));
-        }
-        if (j == 0) {
-            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
-            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->loss, e->loss.p, sizeof(float));
-            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
-            COPY_OUT(out->ctx_grad, e->ctx_grad.p, cb);
-        }
-        // scaler.step(optimizer) (tpt_cls_rl.py:78): a gradient with an inf / NaN skips the update (the same inputs give the same
-        // gradient at the following steps, so the host-side step number j + 1 never meets an applied step after a skipped one)
-        TRY(launch_grad_nonfinite(e->ctx_grad.as<float>(), (int64_t)n_ctx * Wt, 1, e->step_skip.as<int32_t>(), st));
-        TRY(launch_adamw(ctx, e->ctx_grad.as<float>(), e->adam_m.as<float>(), e->adam_v.as<float>(), (int64_t)n_ctx * Wt, j + 1, a->lr,
-                         a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)n_ctx * Wt));
-        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
-    }
-    // final inference on the clean view (views[0]) with the adapted prompt, tpt_cls_rl.py:260-262;
-    // its image feature is row 0 of img_feat (frozen image tower: identical to re-encoding it).
-    COPY_OUT(out->ctx_after, ctx, cb);
-    if (a->skip_final) return RLCF_OK;
-    TRY(text_forward(e, s, e->lay[0], e->tt, ctx, io, false, st));
-    TRY(engine_logits(e, e->img_feat.as<float>(), 1, e->txt.as<float>(), C, e->final_logits.as<float>(), st));
-    TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
-    COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
-    COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
-    return RLCF_OK;
-}
-
-// ------------------------------------------------------------------ B test samples per pass
-// Same arithmetic per sample as engine_tta_sample (default RLCF configuration: one tuning step, sparse class backward),
-// but every tower pass runs once for the whole batch: B*N views through the student image tower, B*n_sel views through
-// the reward tower, B*n_sel*K class prompts through the sparse forward/backward (each sample with its own copy of the
-// prompt prefix), B adapted prompts through one replicated final text pass.  Samples stay independent (no cross-sample
-// arithmetic); larger M per GEMM is what fills 256 CUs.
-static int batch_ensure(rlcf_engine* e, int B, hipStream_t st) {
-    if (B <= e->b_cap) return RLCF_OK;
-    ClipModel& s = e->model[RLCF_STUDENT];
-    const TextLayout& L = e->lay[0];
-    const int Wt = s.cfg.text_width, D = s.cfg.embed_dim, C = L.C;
-    TRY(e->b_seqs_rep.ensure((size_t)B * L.n_seq * sizeof(rlcf_seq))); TRY(e->b_eot_rep.ensure((size_t)B * C * sizeof(int32_t)));
-    TRY(launch_replicate_layout(L.seqs.as<rlcf_seq>(), L.n_seq, L.eot_rows.as<int32_t>(), C, L.T, B, e->b_seqs_rep.as<rlcf_seq>(),
-                                e->b_eot_rep.as<int32_t>(), st));
-    if (L.n_pk > 0) {        // packed runs: the descriptors shift like the sequences, the per-row sequence starts like row ids
-        TRY(e->b_pk_rep.ensure((size_t)B * L.n_pk * sizeof(rlcf_seq))); TRY(e->b_rss_rep.ensure((size_t)B * L.T * sizeof(int32_t)));
-        TRY(launch_replicate_layout(L.pk_seqs.as<rlcf_seq>(), L.n_pk, L.pk_rss.as<int32_t>(), L.T, L.T, B, e->b_pk_rep.as<rlcf_seq>(),
-                                    e->b_rss_rep.as<int32_t>(), st));
-    }
-    const size_t cb = (size_t)B * e->n_ctx * Wt * sizeof(float);
-    TRY(e->b_ctx.ensure(cb)); TRY(e->b_m.ensure(cb)); TRY(e->b_v.ensure(cb)); TRY(e->b_grad.ensure(cb));
-    TRY(e->b_txt.ensure((size_t)B * C * D * sizeof(float))); TRY(e->b_u.ensure((size_t)B * C * D * sizeof(float)));
-    TRY(e->b_eot_x.ensure((size_t)B * C * Wt * sizeof(float))); TRY(e->b_eot_ln.ensure((size_t)B * C * Wt * sizeof(float)));
-    TRY(e->b_inv.ensure((size_t)B * C * sizeof(float))); TRY(e->b_logits.ensure((size_t)B * C * sizeof(float)));
-    TRY(tower_ensure(e->tt, B * L.T, Wt, st));
-    if (prec_x3(e) && (size_t)B * L.T * Wt * 4 > e->a_split_elems) {
-        e->a_split_elems = (size_t)B * L.T * Wt * 4;
-        TRY(e->a_hi.ensure(e->a_split_elems * 4));
-    }
-    RLCF_HIP_CHECK(hipStreamSynchronize(st));
-    e->b_cap = B;
-    return RLCF_OK;
-}
-
-// img_feat: the student image features [B*N, D] of these views — nullptr: computed here (the whole pass on one stream); else they
-// were produced by the caller (tta_batch_pipelined: the tower of this part ran on the other stream) and only the rest of the pass runs
-static int tta_batch_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
-                           hipStream_t st, const float* img_feat = nullptr) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    const TextLayout& L = e->lay[0];
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, n_ctx = e->n_ctx;
-    const int n_sel = n_selected(a, N), n_e = n_sel * K, BN = B * N, BS = B * n_sel;
-    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    if (!img_feat) {
-        TRY(batch_ensure(e, B, st));
-        TRY(sparse_ensure(e, n_e, st, B));
-        e->last_flops = 0.0;
-        // 1. student image features of all B*N views
-        TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
-        img_feat = e->img_feat.as<float>();
-    }
-    // first-step logits against the cached pristine-prompt text features
-    TRY(engine_logits(e, img_feat, BN, e->txt0.as<float>(), C, e->logits.as<float>(), st));
-    // 2. per-sample confidence selection (global row ids), gathers, reward features of the selected views
-    TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-    TRY(launch_gather_rows(img_feat, D, e->sel_idx.as<int32_t>(), e->sel_feat.as<float>(), D, BS, D, st));
-    TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
-    TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
-    TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, BS, C, st));
-    const int gT = L.pre_rows + n_e * L.lmax, T = B * gT, nE = B * n_e;
-    const int64_t np = (int64_t)n_ctx * Wt;
-    // reset state of every sample: ctx = ctx_init, Adam moments zero (custom_clip.py:161-164, tpt_cls_rl.py:251-255)
-    TRY(launch_broadcast_rows(e->ctx_init.as<float>(), e->b_ctx.as<float>(), (int)np, B, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->b_m.p, 0, (size_t)B * np * sizeof(float), st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->b_v.p, 0, (size_t)B * np * sizeof(float), st));
-    TextPassIO fo{};                 // full class bank, one replica (and one prompt) per sample
-    fo.seqs = e->b_seqs_rep.as<rlcf_seq>(); fo.n_seq = B * L.n_seq; fo.max_q_len = L.max_q_len; fo.T = B * L.T; fo.n_cls = B * C;
-    fo.attn_pairs = (long)B * L.attn_pairs; fo.eot_rows = e->b_eot_rep.as<int32_t>(); fo.row_src = nullptr;
-    fo.eot_x = e->b_eot_x.as<float>(); fo.eot_ln = e->b_eot_ln.as<float>(); fo.u = e->b_u.as<float>(); fo.inv_norm = e->b_inv.as<float>();
-    fo.txt = e->b_txt.as<float>(); fo.rep_rows = L.T; fo.ctx_stride = (int)np;
-    if (L.n_pk > 0) { fo.pk_seqs = e->b_pk_rep.as<rlcf_seq>(); fo.n_pk = B * L.n_pk; fo.pk_rss = e->b_rss_rep.as<int32_t>(); }
-    for (int j = 0; j < a->tta_steps; ++j) {
-        if (j > 0) {
-            // tpt_cls_rl.py:55: logits of the selected views under each sample's current prompt
-            TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
-            TRY(launch_group_logits(e->sel_feat.as<float>(), n_sel, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, e->sel_logits.as<float>(), st));
-            e->last_flops += 2.0 * BS * C * D;
-        }
-        // 3. top-K sampling, CLIP reward, baseline, reward-weighted CE and dlogits, grouped per sample
-        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e),
-                                    a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
-                                    e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        // 4. sparse backward of all B*n_e sampled (view, class) pairs; each sample owns a copy of the prompt prefix
-        TRY(launch_build_sparse_layout(e->topk_idx.as<int32_t>(), B, n_e, L.class_start.as<int32_t>(), L.class_len.as<int32_t>(),
-                                       L.class_eot_off.as<int32_t>(), L.lmax, L.pre_rows, e->sp_seqs.as<rlcf_seq>(), e->sp_eot_rows.as<int32_t>(),
-                                       e->sp_row_src.as<int32_t>(), st));
-        TextPassIO io{};
-        io.seqs = e->sp_seqs.as<rlcf_seq>(); io.n_seq = B * (n_e + (L.pre_rows > 0 ? 1 : 0)); io.max_q_len = L.max_q_len; io.T = T; io.n_cls = nE;
-        io.attn_pairs = (long)(nE * (L.mean_len * (L.pre_rows + (L.mean_len + 1) * 0.5)));
-        io.eot_rows = e->sp_eot_rows.as<int32_t>(); io.row_src = e->sp_row_src.as<int32_t>();
-        io.eot_x = e->sp_eot_x.as<float>(); io.eot_ln = e->sp_eot_ln.as<float>(); io.u = e->sp_u.as<float>();
-        io.inv_norm = e->sp_inv_norm.as<float>(); io.txt = e->sp_txt.as<float>();
-        io.rep_rows = gT; io.ctx_stride = (int)np;                  // group b of gT rows reads prompt b
-        TRY(text_forward(e, s, L, e->st, e->b_ctx.as<float>(), io, true, st));
-        TRY(launch_dtxt_sparse(e->dlogits.as<float>(), e->topk_idx.as<int32_t>(), e->sel_feat.as<float>(), nE, K, C, D, s.logit_scale_exp,
-                               e->sp_dtxt.as<float>(), st));
-        {   // text_backward with the per-sample (grouped) ctx-gradient reduction
-            TRY(launch_l2norm_bwd(io.txt, e->sp_dtxt.as<float>(), io.inv_norm, e->sp_du.as<float>(), nE, D, st));
-            TRY(gemm(e, e->sp_du.as<float>(), D, s.tproj, D, nullptr, nullptr, 0, nullptr, 0, e->sp_dxe.as<float>(), Wt, nE, Wt, D, 1.f, RLCF_EPI_NONE, st));
-            TRY(launch_layernorm_bwd(io.eot_x, s.lnf_w, e->sp_dxe.as<float>(), nullptr, e->sp_dxe.as<float>(), nullptr, nullptr, nE, Wt, st));
-            RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wt * sizeof(float), st));
-            TRY(launch_scatter_rows(e->sp_dxe.as<float>(), io.eot_rows, e->dX.as<float>(), nE, Wt, st));
-            TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, L.max_keys, io.attn_pairs, 1, T, st));
-            if (L.ctx_general)
-                TRY(launch_ctx_grad_scan(e->dX.as<float>(), io.row_src, L.ctx_row.as<int32_t>(), B, gT, n_ctx, Wt, e->b_grad.as<float>(), st));
-            else
-                TRY(launch_ctx_grad_grouped(e->dX.as<float>(), e->sp_ctx_rows_list.as<int32_t>(), L.pre_rows > 0 ? 1 : n_e, n_ctx, Wt, B, gT,
-                                            e->b_grad.as<float>(), st));
-        }
-        // 5. AdamW step j+1 of every sample (tpt_cls_rl.py:76-79)
-        TRY(launch_grad_nonfinite(e->b_grad.as<float>(), np, B, e->step_skip.as<int32_t>(), st));
-        TRY(launch_adamw(e->b_ctx.as<float>(), e->b_grad.as<float>(), e->b_m.as<float>(), e->b_v.as<float>(), B * np, j + 1, a->lr, a->beta1,
-                         a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), np));
-    }
-    // 6. final clean-view inference: B adapted prompts through one replicated text pass
-    TRY(text_forward(e, s, L, e->tt, e->b_ctx.as<float>(), fo, false, st));
-    float* fl = final_logits ? final_logits : e->b_logits.as<float>();
-    TRY(launch_final_logits_batched(img_feat, N, e->b_txt.as<float>(), B, C, D, s.logit_scale_exp, fl, st));
-    e->last_flops += 2.0 * B * C * D;
-    TRY(launch_top5_batched(fl, B, C, top5, st));
-    return RLCF_OK;
-}
-
-// One pass of B test images in `parts` parts on TWO streams: the student image tower of part k+1 (chip-filling GEMMs) runs on the
-// caller's stream while everything behind the tower of part k — reward models' pass over the selected views, loss, sparse text
-// forward / backward, AdamW, the replicated final text pass: small launch-bound kernels, ~20 % of a pass — runs on the side stream
-// with the side stream's own scratch (ws_sel: A-operand buffer, split-K workspace, image-tower scratch).  Samples are independent, so
-// the per-sample results are those of the one-stream pass up to the round-off of the GEMM forms the part sizes select
-// (test_batch_pipeline_equals_single_stream).  MEASURED SLOWER than the one-stream pass on BASELINE configs[1] (115.7 images/s
-// against 114.1 / 109.3 in 2 / 4 parts: a workgroup of the small kernels blocks a CU for the 139-KB GEMM workgroups of the tower just as
-// it does alone, so the two-stream form hides nothing) — built only when RLCF_BATCH_PARTS=n asks for it.
-static int tta_batch_pipelined(rlcf_engine* e, const float* views, int B, int N, int parts, const rlcf_tta_args* a, float* final_logits,
-                               int32_t* top5, hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    const int D = s.cfg.embed_dim, n_sel = n_selected(a, N), n_e = n_sel * a->sample_k;
-    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const int Bp = (B + parts - 1) / parts;
-    TRY(batch_ensure(e, Bp, st));
-    TRY(sparse_ensure(e, n_e, st, Bp));
-    {   // side-stream operand buffer: the text passes of a part and the reward models' patch matrices
-        size_t need2 = (size_t)Bp * e->lay[0].T * s.cfg.text_width * 4;
-        for (int m = 0; m < e->n_rewards; ++m) {
-            const ClipModel& rm = e->model[RLCF_REWARD + m];
-            need2 = std::max(need2, (size_t)Bp * n_sel * rm.tokens * std::max(rm.Kp, 4 * rm.cfg.vision_width));
-        }
-        if (need2 > e->a_split2_elems) { TRY(e->a_hi2.ensure(need2 * 4)); e->a_split2_elems = need2; }
-    }
-    for (int k = 0; k < parts && k < 8; ++k)
-        if (!e->ev_part[k]) RLCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_part[k], hipEventDisableTiming));
-    e->last_flops = 0.0;
-    RLCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
-    RLCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-    int rc = RLCF_OK;
-    for (int k = 0, b0 = 0; k < parts && b0 < B && rc == RLCF_OK; ++k, b0 += Bp) {
-        const int Bk = std::min(Bp, B - b0);
-        float* feat_k = e->img_feat.as<float>() + (size_t)b0 * N * D;
-        rc = engine_encode_image(e, RLCF_STUDENT, views + (size_t)b0 * per, Bk * N, feat_k, st);
-        if (rc != RLCF_OK) break;
-        if (hipEventRecord(e->ev_part[k], st) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_part[k], 0) != hipSuccess) { rc = RLCF_ERR_HIP; break; }
-        e->ws_sel = 1;
-        rc = tta_batch_fused(e, views + (size_t)b0 * per, Bk, N, a, final_logits ? final_logits + (size_t)b0 * e->C : nullptr, top5 + (size_t)b0 * 5,
-                             e->side, feat_k);
-        e->ws_sel = 0;
-    }
-    // the caller's stream joins the side stream whatever happened
-    const hipError_t e1 = hipEventRecord(e->ev_join, e->side);
-    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, e->ev_join, 0) : e1;
-    if (e2 != hipSuccess) { (void)hipStreamSynchronize(e->side); if (rc == RLCF_OK) { rlcf_set_error("tta_batch_pipelined: join: %s", hipGetErrorString(e2)); rc = RLCF_ERR_HIP; } }
-    return rc;
-}
-
-int engine_tta_batch(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
-                     hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (e->C <= 0 || e->image_bank || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    if (e->n_ctx <= 0) { rlcf_set_error("prompt tuning needs a class bank with learnable context rows (n_ctx > 0)"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
-    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const int n_sel = n_selected(a, N);
-    const bool sparse_ok = a->sparse_backward && (a->flags & RLCF_F_REWARD_PROCESS) && !(a->flags & RLCF_F_PROCESS_BATCH) &&
-                           !(a->flags & RLCF_F_MIN_ENTROPY) && a->sample_k > 1;
-    const int Bmax = e->max_views / N;
-    const bool fused = Bmax >= 2 && a->tta_steps >= 1 && sparse_ok && !a->ctx_in && !a->skip_final && n_sel > 0;
-    double flops = 0.0;
-    int i = 0;
-    while (i < count) {
-        const int B = fused ? std::min(Bmax, count - i) : 1;
-        if (fused && B >= 2) {
-            // parts of a pass on two streams (tta_batch_pipelined): needs the side stream, ViT towers everywhere (the ModifiedResNet
-            // pass keeps its scratch in the engine), no per-launch profile (its event pairs serialise), one tuning step
-            static int parts_env = -1;
-            if (parts_env < 0) { const char* ev = getenv("RLCF_BATCH_PARTS"); parts_env = ev ? atoi(ev) : 0; }
-            bool vit_all = !is_resnet(s.cfg);
-            for (int m = 0; m < e->n_rewards; ++m) vit_all = vit_all && !is_resnet(e->model[RLCF_REWARD + m].cfg);
-            int parts = parts_env > 0 ? parts_env : 1;          // (measured slower than one stream on BASELINE configs[1]: off unless asked for)
-            parts = std::min(std::min(parts, 8), B / 2);
-            if (parts >= 2 && vit_all && e->side && !g_prof.enabled && prec_x3(e)) {
-                TRY(tta_batch_pipelined(e, views + (size_t)i * per, B, N, parts, a, final_logits ? final_logits + (size_t)i * e->C : nullptr,
-                                        top5 + (size_t)i * 5, st));
-            } else
-            TRY(tta_batch_fused(e, views + (size_t)i * per, B, N, a, final_logits ? final_logits + (size_t)i * e->C : nullptr, top5 + (size_t)i * 5, st));
-        } else {
-            rlcf_tta_out o{};
-            o.top5 = top5 + (size_t)i * 5;
-            o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
-            TRY(engine_tta_sample(e, views + (size_t)i * per, N, a, &o, st));
-        }
-        flops += e->last_flops;
-        i += B;
-    }
-    e->last_flops = flops / count;
-    return RLCF_OK;
-}
-
-// ------------------------------------------------------------------ LayerNorm-tuning step (BASELINE configs[2])
-// Image tower forward of n views WITH saved activations (CLIPCLS_TTA.forward, custom_clip.py:423-432).
-static int vit_forward_saved(rlcf_engine* e, ClipModel& m, const float* images, int n, float* feats, hipStream_t st) {
-    const rlcf_clip_cfg& c = m.cfg;
-    const int Wv = c.vision_width, tok = m.tokens, G2 = tok - 1, T = n * tok, D = c.embed_dim;
-    TRY(tower_ensure_saved(e->vt, T, Wv, c.vision_layers, st));
-    TRY(launch_im2col(images, e->patches.as<float>(), nullptr, nullptr, n, c.image_resolution, c.vision_patch_size, m.Kp, st));
-    TRY(gemm(e, e->patches.as<float>(), m.Kp, m.conv_w, m.Kp, nullptr, nullptr, 0, nullptr, 0, e->patch_out.as<float>(), Wv, n * G2, Wv, m.Kp,
-             1.f, RLCF_EPI_NONE, st));
-    {
-        const LnRef gw = ln_ref(e, m.lnpre_w, 1), gb = ln_ref(e, m.lnpre_b, 1);
-        TRY(launch_vit_assemble(e->patch_out.as<float>(), m.cls, m.vpos, gw.p, gb.p, e->vt.sv[0].x, n, tok, Wv, st, gw.group_rows, gw.group_stride));
-    }
-    TRY(transformer_forward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, true, st));
-    TRY(launch_gather_rows(e->vt.x.as<float>(), tok * Wv, nullptr, e->cls_rows.as<float>(), Wv, n, Wv, st));
-    {
-        const LnRef gw = ln_ref(e, m.lnpost_w, 1), gb = ln_ref(e, m.lnpost_b, 1);
-        TRY(launch_layernorm_fwd(e->cls_rows.as<float>(), gw.p, gb.p, e->cls_ln.as<float>(), n, Wv, st, gw.group_rows, gw.group_stride));
-    }
-    TRY(gemm(e, e->cls_ln.as<float>(), Wv, m.vprojT, Wv, nullptr, nullptr, 0, nullptr, 0, e->feat_raw.as<float>(), D, n, D, Wv, 1.f,
-             RLCF_EPI_NONE, st));
-    TRY(launch_l2norm_rows(e->feat_raw.as<float>(), feats, e->vit_inv_norm.as<float>(), n, D, st));
-    return RLCF_OK;
-}
-// d loss / d (visual LN parameters) given dlogits [n, C] of the n views whose activations vit_forward_saved holds.
-// groups > 1: the n views belong to `groups` test samples (n / groups consecutive views each) and ln_grad is [groups, ln_count]
-// wgrad_base (single sample only): also the gradient of every other visual parameter, into the flat e->vw_slots layout
-static int vit_backward_ln(rlcf_engine* e, ClipModel& m, const float* feats, int n, const float* dlogits, float* ln_grad, hipStream_t st,
-                           int groups = 1, float* wgrad_base = nullptr) {
-    const rlcf_clip_cfg& c = m.cfg;
-    const int Wv = c.vision_width, tok = m.tokens, T = n * tok, D = c.embed_dim, C = e->C, L = c.vision_layers;
-    const int per = n / groups, gs = groups > 1 ? e->ln_count : 0;
-    TRY(bwd_ensure(e, T, Wv));
-    TRY(e->dfeat.ensure((size_t)e->max_views * D * sizeof(float))); TRY(e->dcls.ensure((size_t)e->max_views * Wv * sizeof(float)));
-    RLCF_HIP_CHECK(hipMemsetAsync(ln_grad, 0, (size_t)groups * e->ln_count * sizeof(float), st));
-    // d feat = scale * dlogits @ class_features  (logits = scale * feat @ class_features^T, custom_clip.py:429-430)
-    TRY(launch_dimg(dlogits, e->txt0.as<float>(), n, C, D, m.logit_scale_exp, e->dfeat.as<float>(), st));
-    TRY(launch_l2norm_bwd(feats, e->dfeat.as<float>(), e->vit_inv_norm.as<float>(), e->dfeat.as<float>(), n, D, st));
-    if (wgrad_base)                        // visual.proj [Wv, D]: feat = ln_post(cls) @ proj  (model.py:237-238)
-        TRY(wgrad(e, e->cls_ln.as<float>(), Wv, Wv, e->dfeat.as<float>(), D, D, n, wgrad_base + e->vw_slots[2].off, nullptr, st));
-    TRY(gemm(e, e->dfeat.as<float>(), D, m.vproj, D, nullptr, nullptr, 0, nullptr, 0, e->dcls.as<float>(), Wv, n, Wv, D, 1.f, RLCF_EPI_NONE, st));
-    float* gpost = ln_grad + (size_t)(2 + 4 * L) * Wv;
-    const LnRef gpw = ln_ref(e, m.lnpost_w, 1);
-    TRY(e->parts_ws.ensure(RLCF_PARTS_WS_FLOATS * sizeof(float)));
-    TRY(launch_layernorm_bwd(e->cls_rows.as<float>(), gpw.p, e->dcls.as<float>(), nullptr, e->dcls.as<float>(), gpost, gpost + Wv, n, Wv, st,
-                             groups > 1 ? per : 0, gs, groups > 1 ? gpw.group_stride : 0, PARTS_WS(e)));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)T * Wv * sizeof(float), st));
-    TRY(launch_scatter_rows(e->dcls.as<float>(), e->cls_row_idx.as<int32_t>(), e->dX.as<float>(), n, Wv, st));
-    TRY(transformer_backward(e, m.vis, e->vt, e->vit_seqs.as<rlcf_seq>(), n, tok, (long)n * tok * tok, 0, T, st, ln_grad, tok,
-                             groups > 1 ? per * tok : 0, gs, wgrad_base));
-    if (!wgrad_base) {
-        TRY(launch_vit_assemble_bwd(e->patch_out.as<float>(), m.cls, m.vpos, e->dX.as<float>(), ln_grad, ln_grad + Wv, n, tok, Wv, st,
-                                    groups > 1 ? per : 0, gs, PARTS_WS(e)));
-        return RLCF_OK;
-    }
-    // through ln_pre into the embedding (model.py:224-229): pre = [class_embedding | conv1(patches)] + positional_embedding
-    float *pre = e->dH.as<float>(), *dpre = e->dA.as<float>(), *dpatch = e->dF.as<float>();      // backward scratch, free by now
-    const int G2 = tok - 1, K = 3 * m.cfg.vision_patch_size * m.cfg.vision_patch_size;
-    TRY(launch_vit_preln(e->patch_out.as<float>(), m.cls, m.vpos, pre, n, tok, Wv, st));
-    TRY(launch_layernorm_bwd(pre, m.lnpre_w, e->dX.as<float>(), nullptr, dpre, ln_grad, ln_grad + Wv, T, Wv, st, 0, 0, 0, PARTS_WS(e)));
-    float* gpos = wgrad_base + e->vw_slots[1].off;
-    TRY(launch_colsum(dpre, tok * Wv, n, tok * Wv, gpos, st, PARTS_WS(e)));                                     // d positional_embedding = sum over views
-    RLCF_HIP_CHECK(hipMemcpyAsync(wgrad_base + e->vw_slots[0].off, gpos, Wv * sizeof(float), hipMemcpyDeviceToDevice, st));   // d class_embedding = its row 0
-    for (int v = 0; v < n; ++v)
-        RLCF_HIP_CHECK(hipMemcpyAsync(dpatch + (size_t)v * G2 * Wv, dpre + ((size_t)v * tok + 1) * Wv, (size_t)G2 * Wv * sizeof(float),
-                                      hipMemcpyDeviceToDevice, st));
-    // conv1.weight [Wv, 3*ps*ps] (stride == kernel convolution = patches @ W^T, model.py:224): the patch matrix of vit_forward_saved is still there
-    TRY(wgrad(e, dpatch, Wv, Wv, e->patches.as<float>(), m.Kp, K, n * G2, wgrad_base + e->vw_slots[3].off, nullptr, st));
-    return RLCF_OK;
-}
-
-// LayerNorm tuning of B test images per tower pass (one AdamW step): every sample starts from the same reset state, so the
-// selection forward, the reward pass and the saved forward of the selected views run on all B samples at once; the backward
-// keeps the LayerNorm gradients per sample (grouped reductions), AdamW updates B parameter sets, and the clean-view inference
-// runs once per sample with its own adapted LayerNorms (tune_cls_rl.py:206-227).
-static int tta_batch_ln_fused(rlcf_engine* e, const float* views, int B, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
-                              hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
-    const int n_sel = n_selected(a, N), BN = B * N, BS = B * n_sel;
-    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const size_t nb = (size_t)e->ln_count * sizeof(float), np = (size_t)e->ln_count;
-    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
-    TRY(e->b_ln.ensure(B * nb)); TRY(e->b_ln_m.ensure(B * nb)); TRY(e->b_ln_v.ensure(B * nb)); TRY(e->b_ln_grad.ensure(B * nb));
-    TRY(e->b_logits.ensure((size_t)B * C * sizeof(float)));
-    e->last_flops = 0.0;
-    const float* cls_feat = e->txt0.as<float>();
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
-    // 1. selection on all B*N views (pristine LayerNorms), 2. reward features of the selected views
-    TRY(engine_encode_image(e, RLCF_STUDENT, views, BN, e->img_feat.as<float>(), st));
-    TRY(engine_logits(e, e->img_feat.as<float>(), BN, cls_feat, C, e->logits.as<float>(), st));
-    TRY(launch_entropy_select_batched(e->logits.as<float>(), B, N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-    TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, BS, (int)img_elems, st));
-    TRY(reward_encode(e, BS, s.cfg.image_resolution, nullptr, st));
-    // reset state of every sample (custom_clip.py:456-458 + optimizer.load_state_dict)
-    TRY(launch_broadcast_rows(e->ln_init.as<float>(), e->b_ln.as<float>(), (int)np, B, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_m.p, 0, B * nb, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->b_ln_v.p, 0, B * nb, st));
-    for (int j = 0; j < a->tta_steps; ++j) {
-        // 3. forward with saved activations on the selected views (each sample under its own LayerNorms), loss per sample,
-        // 4. backward with per-sample LayerNorm gradients, 5. AdamW step j+1 of every sample
-        e->lng_base = e->b_ln.as<float>(); e->lng_views = n_sel;
-        int rc = vit_forward_saved(e, s, e->views_sel.as<float>(), BS, e->ln_feat.as<float>(), st);
-        if (rc == RLCF_OK) rc = engine_logits(e, e->ln_feat.as<float>(), BS, cls_feat, C, e->sel_logits.as<float>(), st);
-        if (rc == RLCF_OK) rc = launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, B, n_sel, C, K, reward_bank(e), a->clipscore_weight,
-                                                        a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), nullptr, nullptr, nullptr,
-                                                        e->dlogits.as<float>(), e->rl_stats.as<float>(), st);
-        if (rc == RLCF_OK) rc = vit_backward_ln(e, s, e->ln_feat.as<float>(), BS, e->dlogits.as<float>(), e->b_ln_grad.as<float>(), st, B);
-        e->lng_base = nullptr; e->lng_views = 1;
-        TRY(rc);
-        TRY(launch_grad_nonfinite(e->b_ln_grad.as<float>(), (int64_t)np, B, e->step_skip.as<int32_t>(), st));
-        TRY(launch_adamw(e->b_ln.as<float>(), e->b_ln_grad.as<float>(), e->b_ln_m.as<float>(), e->b_ln_v.as<float>(), (int64_t)B * np, j + 1,
-                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)np));
-    }
-    // 6. clean-view inference of the B samples in one pass: view b reads LayerNorm set b (tune_cls_rl.py:219-221)
-    float* fl = final_logits ? final_logits : e->b_logits.as<float>();
-    for (int b = 0; b < B; ++b)
-        RLCF_HIP_CHECK(hipMemcpyAsync(e->views_sel.as<float>() + (size_t)b * img_elems, views + (size_t)b * N * img_elems,
-                                      img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
-    e->lng_base = e->b_ln.as<float>(); e->lng_views = 1;
-    int rc = engine_encode_image(e, RLCF_STUDENT, e->views_sel.as<float>(), B, e->sel_feat.as<float>(), st);
-    e->lng_base = nullptr;
-    TRY(rc);
-    TRY(engine_logits(e, e->sel_feat.as<float>(), B, cls_feat, C, fl, st));
-    TRY(launch_top5_batched(fl, B, C, top5, st));
-    return RLCF_OK;
-}
-
-int engine_tta_batch_ln(rlcf_engine* e, const float* views, int count, int N, const rlcf_tta_args* a, float* final_logits, int32_t* top5,
-                        hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (e->C <= 0 || e->image_bank || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
-    const bool rn = is_resnet(s.cfg);         // BatchNorm tuning: the batch statistics couple one sample's views, samples run one by one
-    RLCF_ARG_CHECK(rn || s.tokens <= 320);
-    const size_t per = (size_t)N * 3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const int n_sel = n_selected(a, N), Bmax = e->max_views / N;
-    const bool fused = !rn && Bmax >= 2 && a->tta_steps >= 1 && !a->skip_final && n_sel > 0;
-    double flops = 0.0;
-    int i = 0;
-    while (i < count) {
-        const int B = fused ? std::min(Bmax, count - i) : 1;
-        if (fused && B >= 2) {
-            TRY(tta_batch_ln_fused(e, views + (size_t)i * per, B, N, a, final_logits ? final_logits + (size_t)i * e->C : nullptr, top5 + (size_t)i * 5, st));
-        } else {
-            rlcf_tta_out o{};
-            o.top5 = top5 + (size_t)i * 5;
-            o.final_logits = final_logits ? final_logits + (size_t)i * e->C : nullptr;
-            TRY(engine_tta_sample_ln(e, views + (size_t)i * per, N, a, &o, st));
-        }
-        flops += e->last_flops;
-        i += B;
-    }
-    e->last_flops = flops / count;
-    return RLCF_OK;
-}
-
-// ------------------------------------------------------------------ BatchNorm tuning of a ModifiedResNet student
-// One iteration of tune_cls_rl.py:183-256 with CLIPCLS_TTA(arch=RN*, only_norm=True): the tuned tensors are the weight / bias of every
-// BatchNorm2d whose name contains 'bn' (custom_clip.py:481-485: the downsample BatchNorms stay frozen).  The tuning passes run the
-// BatchNorms on BATCH statistics (nn.BatchNorm2d in train mode, running statistics updated, or `_modified_bn_forward` under
-// --prior_strength >= 0, tune_cls_rl.py:35-44), step 0 over all N views (the selection reads its logits; the statistics couple the
-// views, so the backward covers all N with zero logit gradients outside the selection), later steps over the selected views.
-// CLIPCLS_TTA.train() (custom_clip.py:487-497) puts the norm layers in train mode whatever `mode` is, so the final clean-view
-// inference ALSO normalises with batch statistics (of that one image): reproduced.  The running statistics the sample leaves behind
-// stay in e->bn_stats (rlcf_engine_get_bn_stats) until the next sample resets them.
-static int rn_visual_reset(rlcf_engine* e, hipStream_t st) {   // visual.load_state_dict(initial_state_dict) for the flat buffer of a ResNet student
-    if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
-    e->vw_dirty = false;
-    return rn_visual_refresh(e, st, e->vw_init_is_ckpt);
-}
-// full: every visual parameter is tuned (CLIPCLS_TTA(only_norm=False) on a ModifiedResNet — the parser defaults of tune_cls_rl.py,
-// TPT/params.py:23,73): convolution / downsample.1 / attention-pool gradients into e->vw_grad, a second AdamW launch, the derived
-// weight forms rebuilt after every step, and the final clean-view inference with the BatchNorms in EVAL form on the running statistics
-// the tuning passes left behind (model.eval() is plain nn.Module.eval() when only_norm is off, custom_clip.py:487-497)
-int engine_tta_sample_bn(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    TRY(engine_bn_enable(e, st));
-    if (full) TRY(engine_rn_visual_enable(e, st));
-    if (!full && s.rn.full_enabled && e->vw_dirty) TRY(rn_visual_reset(e, st));
-    const size_t vb = full ? e->vw_count * sizeof(float) : 0;
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
-    const int n_sel = n_selected(a, N), n_e = n_sel * K;
-    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const size_t nb = (size_t)e->ln_count * sizeof(float);
-    const rlcf_tta_out none{};
-    if (!out) out = &none;
-    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
-    TRY(e->dfeat.ensure((size_t)e->max_views * D * sizeof(float)));
-    TRY(e->bn_dlog.ensure((size_t)N * C * sizeof(float)));
-    e->last_flops = 0.0;
-    // model.reset(): visual.load_state_dict(initial_state_dict) restores parameters AND buffers (running statistics)
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->bn_stats.p, e->bn_stats_init.p, (size_t)s.rn.n_stats * sizeof(float), hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
-    if (full) {
-        TRY(rn_visual_reset(e, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_m.p, 0, vb, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_v.p, 0, vb, st));
-    }
-    const float* cls_feat = e->txt0.as<float>();
-    for (int j = 0; j < a->tta_steps; ++j) {
-        const int n = j == 0 ? N : n_sel;
-        TRY(rn_forward_train(e, s, j == 0 ? views : e->views_sel.as<float>(), n, e->ln_feat.as<float>(), st));
-        const float* dlog = e->dlogits.as<float>();
-        if (j == 0) {
-            TRY(engine_logits(e, e->ln_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
-            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
-            TRY(launch_gather_rows(e->logits.as<float>(), C, e->sel_idx.as<int32_t>(), e->sel_logits.as<float>(), C, n_sel, C, st));
-            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
-            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
-            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
-        } else {
-            TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
-        }
-        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
-                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
-                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        if (j == 0) {
-            RLCF_HIP_CHECK(hipMemsetAsync(e->bn_dlog.p, 0, (size_t)N * C * sizeof(float), st));
-            TRY(launch_scatter_rows(e->dlogits.as<float>(), e->sel_idx.as<int32_t>(), e->bn_dlog.as<float>(), n_sel, C, st));
-            dlog = e->bn_dlog.as<float>();
-        }
-        // d feat = scale * dlogits @ class_features (custom_clip.py:429-430), then the tower's backward down to the stem's first BatchNorm
-        TRY(launch_dimg(dlog, cls_feat, n, C, D, s.logit_scale_exp, e->dfeat.as<float>(), st));
-        if (full) RLCF_HIP_CHECK(hipMemsetAsync(e->vw_grad.p, 0, vb, st));
-        TRY(rn_backward_bn(e, s, n, e->ln_feat.as<float>(), e->dfeat.as<float>(), e->ln_grad.as<float>(), st, full ? e->vw_grad.as<float>() : nullptr));
-        if (j == 0) {
-            if (full) COPY_OUT(out->vis_grad, e->vw_grad.p, vb);
-            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
-            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->loss, e->loss.p, sizeof(float));
-            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
-            COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
-        }
-        TRY(launch_grad_nonfinite(e->ln_grad.as<float>(), e->ln_count, 1, e->step_skip.as<int32_t>(), st));
-        if (full) TRY(launch_grad_nonfinite(e->vw_grad.as<float>(), (int64_t)e->vw_count, 1, e->step_skip.as<int32_t>(), st, true));
-        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
-        TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
-                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->ln_count));
-        if (full) {
-            TRY(launch_adamw(e->vw.as<float>(), e->vw_grad.as<float>(), e->vw_m.as<float>(), e->vw_v.as<float>(), (int64_t)e->vw_count, j + 1,
-                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)e->vw_count));
-            e->vw_dirty = true;
-            TRY(rn_visual_refresh(e, st));
-        }
-    }
-    COPY_OUT(out->ln_after, e->ln_params.p, nb);
-    if (full) COPY_OUT(out->vis_after, e->vw.p, vb);
-    if (!a->skip_final) {
-        // norm-layer tuning: the BatchNorms stay in train form (see the header comment); every-parameter tuning: eval form
-        TRY(rn_forward_train(e, s, views, 1, e->img_feat.as<float>(), st, full ? 0 : -1));
-        TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
-        TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
-        COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
-        COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
-    }
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
-    if (full) TRY(rn_visual_reset(e, st));
-    return RLCF_OK;
-}
-
-static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full);
-int engine_tta_sample_ln(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
-    return tta_sample_backbone(e, views, N, a, out, st, false);
-}
-// every visual parameter tuned (CLIPCLS_TTA only_norm=False, custom_clip.py:477-479)
-int engine_tta_sample_visual(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
-    TRY(engine_visual_enable(e, st));
-    return tta_sample_backbone(e, views, N, a, out, st, true);
-}
-static int visual_reset(rlcf_engine* e, hipStream_t st) {      // visual.load_state_dict(initial_state_dict) for the flat buffer
-    if (!e->vw_count || !e->vw_dirty) return RLCF_OK;
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->vw.p, e->vw_init.p, e->vw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
-    e->vw_dirty = false;
-    return engine_visual_refresh(e, st, e->vw_init_is_ckpt);
-}
-static int tta_sample_backbone(rlcf_engine* e, const float* views, int N, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st, bool full) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (e->C <= 0 || e->image_bank || e->n_rewards <= 0) { rlcf_set_error("class bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(N > 0 && N <= e->max_views && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim;
-    const int n_sel = n_selected(a, N), n_e = n_sel * K;
-    if (a->tta_steps > 0 && n_sel <= 0) { rlcf_set_error("int(N*selection_p) == 0 views selected (N=%d, p=%g)", N, a->selection_p); return RLCF_ERR_ARG; }
-    if (is_resnet(s.cfg)) {
-        return engine_tta_sample_bn(e, views, N, a, out, st, full);
-    }
-    RLCF_ARG_CHECK(s.tokens <= 320);
-    const size_t img_elems = (size_t)3 * s.cfg.image_resolution * s.cfg.image_resolution;
-    const size_t nb = (size_t)e->ln_count * sizeof(float);
-    const rlcf_tta_out none{};
-    if (!out) out = &none;
-    TRY(e->ln_feat.ensure((size_t)e->max_views * D * sizeof(float)));
-    e->last_flops = 0.0;
-    // model.reset() (visual.load_state_dict(initial_state_dict), custom_clip.py:456-458) + optimizer state reset
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_m.p, 0, nb, st));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->ln_v.p, 0, nb, st));
-    const size_t vb = full ? e->vw_count * sizeof(float) : 0;
-    if (full) {
-        TRY(visual_reset(e, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_m.p, 0, vb, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->vw_v.p, 0, vb, st));
-    }
-    const float* cls_feat = e->txt0.as<float>();           // cached class text features (custom_clip.py:405-409)
-    for (int j = 0; j < a->tta_steps; ++j) {
-        if (j == 0) {
-            // all N views decide the selection; only the selected ones carry gradient (rows outside idx get zero grad)
-            TRY(engine_encode_image(e, RLCF_STUDENT, views, N, e->img_feat.as<float>(), st));
-            TRY(engine_logits(e, e->img_feat.as<float>(), N, cls_feat, C, e->logits.as<float>(), st));
-            TRY(launch_entropy_select(e->logits.as<float>(), N, C, n_sel, e->entropy.as<float>(), e->sel_idx.as<int32_t>(), st));
-            if (a->flags & RLCF_F_NO_SELECTION) TRY(launch_iota(e->sel_idx.as<int32_t>(), n_sel, st));     // retrieval: every row, in order
-            TRY(launch_gather_rows(views, (int)img_elems, e->sel_idx.as<int32_t>(), e->views_sel.as<float>(), (int)img_elems, n_sel, (int)img_elems, st));
-            TRY(reward_encode(e, n_sel, s.cfg.image_resolution, out->reward_image_features, st));
-            COPY_OUT(out->logits, e->logits.p, (size_t)N * C * sizeof(float));
-            COPY_OUT(out->entropy, e->entropy.p, N * sizeof(float));
-            COPY_OUT(out->selected_idx, e->sel_idx.p, n_sel * sizeof(int32_t));
-        }
-        TRY(vit_forward_saved(e, s, e->views_sel.as<float>(), n_sel, e->ln_feat.as<float>(), st));
-        TRY(engine_logits(e, e->ln_feat.as<float>(), n_sel, cls_feat, C, e->sel_logits.as<float>(), st));
-        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, n_sel, C, K, reward_bank(e),
-                               a->clipscore_weight, a->flags, a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(),
-                               e->rewards.as<float>(), e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        if (full) RLCF_HIP_CHECK(hipMemsetAsync(e->vw_grad.p, 0, vb, st));
-        TRY(vit_backward_ln(e, s, e->ln_feat.as<float>(), n_sel, e->dlogits.as<float>(), e->ln_grad.as<float>(), st, 1,
-                            full ? e->vw_grad.as<float>() : nullptr));
-        if (j == 0) {
-            if (full) COPY_OUT(out->vis_grad, e->vw_grad.p, vb);
-            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)n_e * sizeof(int32_t));
-            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->rewards, e->rewards.p, (size_t)n_e * sizeof(float));
-            COPY_OUT(out->loss, e->loss.p, sizeof(float));
-            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)n_sel * C * sizeof(float));
-            COPY_OUT(out->ln_grad, e->ln_grad.p, nb);
-        }
-        // one optimizer over both buffers: an inf / NaN anywhere skips the whole step (GradScaler.step, tpt_cls_rl.py:78)
-        TRY(launch_grad_nonfinite(e->ln_grad.as<float>(), e->ln_count, 1, e->step_skip.as<int32_t>(), st));
-        if (full) TRY(launch_grad_nonfinite(e->vw_grad.as<float>(), (int64_t)e->vw_count, 1, e->step_skip.as<int32_t>(), st, true));
-        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
-        TRY(launch_adamw(e->ln_params.as<float>(), e->ln_grad.as<float>(), e->ln_m.as<float>(), e->ln_v.as<float>(), e->ln_count, j + 1,
-                         a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->ln_count));
-        if (full) {
-            TRY(launch_adamw(e->vw.as<float>(), e->vw_grad.as<float>(), e->vw_m.as<float>(), e->vw_v.as<float>(), (int64_t)e->vw_count, j + 1,
-                             a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)e->vw_count));
-            e->vw_dirty = true;
-            TRY(engine_visual_refresh(e, st));
-        }
-    }
-    COPY_OUT(out->ln_after, e->ln_params.p, nb);
-    if (full) COPY_OUT(out->vis_after, e->vw.p, vb);
-    if (!a->skip_final) {
-        // final clean-view inference with the adapted LayerNorms (tune_cls_rl.py:219-221)
-        TRY(engine_encode_image(e, RLCF_STUDENT, views, 1, e->img_feat.as<float>(), st));
-        TRY(engine_logits(e, e->img_feat.as<float>(), 1, cls_feat, C, e->final_logits.as<float>(), st));
-        TRY(launch_top5(e->final_logits.as<float>(), C, e->top5.as<int32_t>(), st));
-        COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
-        COPY_OUT(out->top5, e->top5.p, 5 * sizeof(int32_t));
-    }
-    // leave the engine in its pristine state for the prompt path (which assumes frozen, pristine weights)
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->ln_params.p, e->ln_init.p, nb, hipMemcpyDeviceToDevice, st));
-    if (full) TRY(visual_reset(e, st));
-    return RLCF_OK;
-}
-
-// ------------------------------------------------------------------ text-encoder tuning (retrieval, text -> image)
-// retrieval/clip_ret_policy.py:106-137 (tune_text) with CLIPRet_TTA(only_visual=False): parameters() = every parameter of the CLIP
-// model whose name does not contain 'visual' (custom_models.py:139-147) — token_embedding.weight, positional_embedding, the text
-// transformer, ln_final, text_projection and logit_scale — tuned on ONE query caption against a fixed bank of image features.
-// Same buffer scheme as the image encoder (engine_visual_enable): the LayerNorm tensors in one small buffer, everything else in a
-// flat one, the tower reads the live weights from them, derived copies (transposes, split-f16 pairs, the query's embedding rows)
-// follow after every optimizer step and after the reset.
-int engine_text_enable(rlcf_engine* e, hipStream_t st) {
-    if (e->tw_count) return RLCF_OK;
-    ClipModel& m = e->model[RLCF_STUDENT];
-    if (!m.finalized) { rlcf_set_error("student model not finalized"); return RLCF_ERR_STATE; }
-    if (prec_single(e)) { rlcf_set_error("encoder tuning runs in RLCF_PREC_F32 / RLCF_PREC_F16X3 (RLCF_PREC_F16 is the prompt path's performance mode)"); return RLCF_ERR_STATE; }
-    const rlcf_clip_cfg& c = m.cfg;
-    const size_t Wt = c.text_width, D = c.embed_dim, W2 = Wt * Wt;
-    struct Item { const float** slot; size_t numel; };
-    std::vector<Item> items = {{&m.tok_emb, (size_t)c.vocab_size * Wt}, {&m.tpos, (size_t)c.context_length * Wt}, {&m.tproj, Wt * D}};
-    for (BlockW& b : m.txt.blk) {
-        items.push_back({&b.in_w, 3 * W2}); items.push_back({&b.in_b, 3 * Wt}); items.push_back({&b.out_w, W2}); items.push_back({&b.out_b, Wt});
-        items.push_back({&b.fc_w, 4 * W2}); items.push_back({&b.fc_b, 4 * Wt}); items.push_back({&b.proj_w, 4 * W2}); items.push_back({&b.proj_b, Wt});
-    }
-    size_t total = 0;
-    e->tw_slots.clear();
-    for (const Item& it : items) { e->tw_slots.push_back(VwSlot{total, it.numel}); total += (it.numel + 63) / 64 * 64; }
-    e->tw_slots.push_back(VwSlot{total, 1});              // logit_scale (the parameter, not its exponential)
-    total += 64;
-    const size_t nb = total * sizeof(float);
-    for (DevBuf* d : {&e->tw, &e->tw_init, &e->tw_grad, &e->tw_m, &e->tw_v}) TRY(d->ensure(nb));
-    RLCF_HIP_CHECK(hipMemsetAsync(e->tw.p, 0, nb, st));
-    for (size_t i = 0; i < items.size(); ++i) {
-        const float* old = *items[i].slot;
-        float* dst = e->tw.as<float>() + e->tw_slots[i].off;
-        RLCF_HIP_CHECK(hipMemcpyAsync(dst, old, items[i].numel * sizeof(float), hipMemcpyDeviceToDevice, st));
-        auto sp = m.split_of.find(old);
-        if (sp != m.split_of.end()) { const ClipModel::SplitW s = sp->second; m.split_of.erase(sp); m.split_of[dst] = s; }
-        *items[i].slot = dst;
-    }
-    const float* ls = rawp(m, "logit_scale", 1);
-    NEED(ls);
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->tw.as<float>() + e->tw_slots.back().off, ls, sizeof(float), hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->tw_init.p, e->tw.p, nb, hipMemcpyDeviceToDevice, st));
-    for (DevBuf* d : {&e->tw_clip, &e->tw_mom}) { TRY(d->ensure(nb)); RLCF_HIP_CHECK(hipMemcpyAsync(d->p, e->tw.p, nb, hipMemcpyDeviceToDevice, st)); }
-    // LayerNorms: [ln_final.weight | ln_final.bias | per block ln_1.weight ln_1.bias ln_2.weight ln_2.bias] (transformer_backward's layout)
-    const int L = c.text_layers;
-    e->tln_count = (int)((4 * L + 2) * Wt);
-    const size_t lb = (size_t)e->tln_count * sizeof(float);
-    for (DevBuf* d : {&e->tln, &e->tln_init, &e->tln_grad, &e->tln_m, &e->tln_v}) TRY(d->ensure(lb));
-    {
-        float* P = e->tln.as<float>();
-        std::vector<const float**> slots = {&m.lnf_w, &m.lnf_b};
-        for (BlockW& b : m.txt.blk) { slots.push_back(&b.ln1_w); slots.push_back(&b.ln1_b); slots.push_back(&b.ln2_w); slots.push_back(&b.ln2_b); }
-        for (size_t i = 0; i < slots.size(); ++i) {
-            RLCF_HIP_CHECK(hipMemcpyAsync(P + i * Wt, *slots[i], Wt * sizeof(float), hipMemcpyDeviceToDevice, st));
-            *slots[i] = P + i * Wt;
-        }
-        RLCF_HIP_CHECK(hipMemcpyAsync(e->tln_init.p, P, lb, hipMemcpyDeviceToDevice, st));
-        for (DevBuf* d : {&e->tln_clip, &e->tln_mom}) { TRY(d->ensure(lb)); RLCF_HIP_CHECK(hipMemcpyAsync(d->p, P, lb, hipMemcpyDeviceToDevice, st)); }
-    }
-    e->tw_refresh.clear();
-    auto add_split = [&](const float* w, size_t numel) {
-        auto it = m.split_of.find(w);
-        if (it != m.split_of.end()) it->second.lo_zero = false;          // (a TUNED weight leaves the fp16 grid at its first step: three passes)
-        if (it != m.split_of.end())
-            e->tw_refresh.push_back(VwRefresh{VW_SPLIT, w, nullptr, numel, 0, it->second.hi, it->second.lo, 1.0f / it->second.inv_scale,
-                                              it->second.lo == lo_of(it->second.hi)});
-    };
-    auto add_T = [&](const float* w, const float* wT, size_t rows, size_t cols) {
-        if (!wT) return;
-        e->tw_refresh.push_back(VwRefresh{VW_TRANSPOSE, w, (float*)wT, rows, cols, nullptr, nullptr, 1.f, 0});
-        add_split(wT, rows * cols);
-    };
-    add_T(m.tproj, m.tprojT, Wt, D);
-    for (BlockW& b : m.txt.blk) {
-        add_split(b.in_w, 3 * W2); add_split(b.out_w, W2); add_split(b.fc_w, 4 * W2); add_split(b.proj_w, 4 * W2);
-        add_T(b.in_w, b.in_wT, 3 * Wt, Wt); add_T(b.out_w, b.out_wT, Wt, Wt); add_T(b.fc_w, b.fc_wT, 4 * Wt, Wt); add_T(b.proj_w, b.proj_wT, Wt, 4 * Wt);
-    }
-    e->tw_count = total;
-    e->tw_dirty = false;
-    RLCF_HIP_CHECK(hipStreamSynchronize(st));
-    return RLCF_OK;
-}
-
-// x[i] *= exp(*log_scale)
-__global__ void scale_by_exp_kernel(float* __restrict__ x, const float* __restrict__ log_scale, int n) {
-    const float s = expf(*log_scale);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] *= s;
-}
-// out[0] = sum_i a[i] * b[i]  (one block, fixed reduction order)
-__global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ out) {
-    __shared__ float red[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0];
-}
-// embedding gradients of one packed text: x[r] = token_embedding[token[r]] + positional_embedding[pos[r]] (model.py:344-346), so
-// d positional_embedding[pos[r]] += dX[r], d token_embedding[token[r]] += dX[r].  One thread per column walks the rows in order:
-// repeated tokens accumulate in a fixed order, no atomics.
-__global__ void embed_grad_kernel(const float* __restrict__ dX, const int32_t* __restrict__ row_token, const int32_t* __restrict__ row_pos,
-                                  float* __restrict__ g_tok, float* __restrict__ g_pos, int rows, int width) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    for (int r = 0; r < rows; ++r) {
-        const float g = dX[(size_t)r * width + c];
-        g_pos[(size_t)row_pos[r] * width + c] += g;
-        const int t = row_token[r];
-        if (t >= 0) g_tok[(size_t)t * width + c] += g;
-    }
-}
-
-// the bank of the text -> image direction: n images, their features under the student (the fixed side of logits_per_text,
-// CLIPRet_TTA.set_image_features, custom_models.py:91-95) and under every reward model (CLIPRewards.set_image_features,
-// retrieval/clip_reward.py:130-137), blocks [n, Dr_m] one after another.  Device pointers, copied.
-int engine_set_image_bank(rlcf_engine* e, const float* student_feats, const float* reward_feats, int n, hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (!s.finalized || e->n_rewards <= 0) { rlcf_set_error("student / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(student_feats && reward_feats && n > 0 && n <= e->max_classes);
-    const int D = s.cfg.embed_dim;
-    e->C = n; e->image_bank = true; e->n_ctx = 0;
-    e->sp_max_e = 0; e->sp_groups = 0; e->b_cap = 0;
-    TRY(tta_scratch_ensure(e, n));
-    TRY(e->txt0.ensure((size_t)n * D * sizeof(float)));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->txt0.p, student_feats, (size_t)n * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (int m = 0; m < e->n_rewards; ++m) {
-        ClipModel& r = e->model[RLCF_REWARD + m];
-        if (!r.finalized) { rlcf_set_error("reward model %d not finalized", m); return RLCF_ERR_STATE; }
-        const int Dr = r.cfg.embed_dim;
-        TRY(e->rimg[m].ensure((size_t)e->max_views * Dr * sizeof(float)));
-        TRY(e->reward_cls[m].ensure((size_t)n * Dr * sizeof(float)));
-        RLCF_HIP_CHECK(hipMemcpyAsync(e->reward_cls[m].p, reward_feats, (size_t)n * Dr * sizeof(float), hipMemcpyDeviceToDevice, st));
-        reward_feats += (size_t)n * Dr;
-    }
-    RLCF_HIP_CHECK(hipStreamSynchronize(st));
-    return RLCF_OK;
-}
-
-int engine_text_reset(rlcf_engine* e, hipStream_t st, bool force) {      // clip_model.load_state_dict(initial_state_dict) for the text side
-    if (!e->tw_count || (!e->tw_dirty && !force)) return RLCF_OK;
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->tw.p, e->tw_init.p, e->tw_count * sizeof(float), hipMemcpyDeviceToDevice, st));
-    RLCF_HIP_CHECK(hipMemcpyAsync(e->tln.p, e->tln_init.p, (size_t)e->tln_count * sizeof(float), hipMemcpyDeviceToDevice, st));
-    e->tw_dirty = false;
-    return refresh_derived(e->tw_refresh, 0, st);
-}
-static int rebuild_E(ClipModel& m, TextLayout& L, hipStream_t st) {
-    build_E_kernel<<<dim3(L.T), dim3(128), 0, st>>>(m.tok_emb, m.tpos, L.row_token.as<int32_t>(), L.row_pos.as<int32_t>(), L.E.as<float>(), L.T,
-                                                     m.cfg.text_width);
-    RLCF_LAUNCH_CHECK();
-    return RLCF_OK;
-}
-
-// tokens: HOST [context_length], the query caption.  Per step: logits_per_text [1, n] of the query against the image bank, top-K
-// images, CLIPScore(images_index=...) of the reward model, REINFORCE loss, backward through the whole text encoder, AdamW over the
-// two parameter buffers.  Then logits_per_text of the tuned encoder (clip_ret_policy.py:193-195) and the reset (:196).
-// Outputs (rlcf_tta_out): logits [n], topk_idx, clip_score, rewards, loss, dlogits [n] of the first step; vis_grad / vis_after = the flat
-// text buffer (rlcf_engine_text_param_layout), ln_grad / ln_after = the text LayerNorm buffer; final_logits [n]; step_skipped.
-int engine_tta_retrieval_text(rlcf_engine* e, const int32_t* tokens, const rlcf_tta_args* a, const rlcf_tta_out* out, hipStream_t st) {
-    ClipModel& s = e->model[RLCF_STUDENT];
-    if (e->C <= 0 || !e->image_bank || e->n_rewards <= 0) { rlcf_set_error("image bank / reward model not set"); return RLCF_ERR_STATE; }
-    RLCF_ARG_CHECK(tokens && a && a->tta_steps >= 0 && a->sample_k > 0 && a->sample_k <= 32 && a->sample_k <= e->C);
-    TRY(engine_text_enable(e, st));
-    const int C = e->C, K = a->sample_k, D = s.cfg.embed_dim, Wt = s.cfg.text_width, L = s.cfg.text_layers;
-    const rlcf_tta_out none{};
-    if (!out) out = &none;
-    e->last_flops = 0.0;
-    // model.reset_initial() + a fresh optimizer state (clip_ret_policy.py:186-190)
-    TRY(engine_text_reset(e, st, false));
-    const size_t wb = e->tw_count * sizeof(float), lb = (size_t)e->tln_count * sizeof(float);
-    for (DevBuf* d : {&e->tw_m, &e->tw_v}) RLCF_HIP_CHECK(hipMemsetAsync(d->p, 0, wb, st));
-    for (DevBuf* d : {&e->tln_m, &e->tln_v}) RLCF_HIP_CHECK(hipMemsetAsync(d->p, 0, lb, st));
-    // layouts of the query under the student and under every reward model (one packed sequence each)
-    TextLayout& Q = e->qlay[0];
-    TRY(build_layout(e, s, Q, tokens, 1, 0, false, RLCF_TEXT_PACKED, st));
-    int Wmax = Wt, Dmax = D, Tmax = Q.T;
-    for (int m = 0; m < e->n_rewards; ++m) {
-        ClipModel& r = e->model[RLCF_REWARD + m];
-        RLCF_ARG_CHECK(r.cfg.context_length == s.cfg.context_length);
-        TRY(build_layout(e, r, e->qlay[1 + m], tokens, 1, 0, false, RLCF_TEXT_PACKED, st));
-        Wmax = std::max(Wmax, r.cfg.text_width); Dmax = std::max(Dmax, r.cfg.embed_dim); Tmax = std::max(Tmax, e->qlay[1 + m].T);
-    }
-    TRY(tower_ensure(e->tt, Tmax, Wmax, st));
-    TRY(tower_ensure(e->st, Q.T, Wt, st));
-    TRY(tower_ensure_saved(e->st, Q.T, Wt, L, st));
-    TRY(bwd_ensure(e, Q.T, Wt));
-    if (prec_x3(e) && (size_t)Tmax * Wmax * 4 > e->a_split_elems) {
-        e->a_split_elems = (size_t)Tmax * Wmax * 4;
-        TRY(e->a_hi.ensure(e->a_split_elems * 4));
-    }
-    TRY(e->eot_x.ensure((size_t)Wmax * sizeof(float))); TRY(e->eot_ln.ensure((size_t)Wmax * sizeof(float)));
-    TRY(e->u.ensure((size_t)Dmax * sizeof(float))); TRY(e->inv_norm.ensure(sizeof(float))); TRY(e->txt.ensure((size_t)Dmax * sizeof(float)));
-    TRY(e->q_feat.ensure((size_t)D * sizeof(float))); TRY(e->q_dfeat.ensure((size_t)D * sizeof(float))); TRY(e->q_ls.ensure(64 * sizeof(float)));
-    TRY(e->sp_du.ensure((size_t)D * sizeof(float))); TRY(e->sp_dxe.ensure((size_t)Wt * sizeof(float)));
-    auto query_io = [&](const TextLayout& Lq, float* txt) {
-        TextPassIO io{};
-        io.seqs = Lq.seqs.as<rlcf_seq>(); io.n_seq = Lq.n_seq; io.max_q_len = Lq.max_q_len; io.T = Lq.T; io.n_cls = 1;
-        io.attn_pairs = Lq.attn_pairs; io.eot_rows = Lq.eot_rows.as<int32_t>(); io.row_src = nullptr;
-        io.eot_x = e->eot_x.as<float>(); io.eot_ln = e->eot_ln.as<float>(); io.u = e->u.as<float>(); io.inv_norm = e->inv_norm.as<float>();
-        io.txt = txt;
-        return io;
-    };
-    // reward_model.set_text_features(captions=text) (clip_ret_policy.py:117): the query under every reward model, frozen
-    for (int m = 0; m < e->n_rewards; ++m)
-        TRY(text_forward(e, e->model[RLCF_REWARD + m], e->qlay[1 + m], e->tt, nullptr, query_io(e->qlay[1 + m], e->rimg[m].as<float>()), false, st));
-    const TextPassIO io = query_io(Q, e->q_feat.as<float>());
-    float* const ls = e->tw.as<float>() + e->tw_slots.back().off;
-    float* const G = e->tw_grad.as<float>();
-    float* const GL = e->tln_grad.as<float>();
-    auto logits_per_text = [&](float* dst) -> int {
-        TRY(gemm(e, e->q_feat.as<float>(), D, e->txt0.as<float>(), D, nullptr, nullptr, 0, nullptr, 0, dst, C, 1, C, D, 1.f, RLCF_EPI_NONE, st));
-        scale_by_exp_kernel<<<dim3(std::min((C + 255) / 256, 1024)), dim3(256), 0, st>>>(dst, ls, C);
-        RLCF_LAUNCH_CHECK();
-        return RLCF_OK;
-    };
-    for (int j = 0; j < a->tta_steps; ++j) {
-        TRY(text_forward(e, s, Q, e->st, nullptr, io, true, st));
-        TRY(logits_per_text(e->sel_logits.as<float>()));
-        TRY(launch_reward_loss_bank(e->sel_logits.as<float>(), C, nullptr, 1, 1, C, K, reward_bank(e), a->clipscore_weight, a->flags,
-                                    a->min_entropy_w, e->topk_idx.as<int32_t>(), e->clip_score.as<float>(), e->rewards.as<float>(),
-                                    e->loss.as<float>(), e->dlogits.as<float>(), e->rl_stats.as<float>(), st));
-        RLCF_HIP_CHECK(hipMemsetAsync(G, 0, wb, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(GL, 0, lb, st));
-        // logits = exp(logit_scale) * <feat, bank>:  d logit_scale = <dlogits, logits>,  d feat = exp(logit_scale) * dlogits @ bank
-        dot_kernel<<<dim3(1), dim3(256), 0, st>>>(e->dlogits.as<float>(), e->sel_logits.as<float>(), C, G + e->tw_slots.back().off);
-        RLCF_LAUNCH_CHECK();
-        TRY(launch_dimg(e->dlogits.as<float>(), e->txt0.as<float>(), 1, C, D, 1.0f, e->q_dfeat.as<float>(), st));
-        scale_by_exp_kernel<<<dim3(1), dim3(256), 0, st>>>(e->q_dfeat.as<float>(), ls, D);
-        RLCF_LAUNCH_CHECK();
-        // text_features = normalize(ln_final(x[eot]) @ text_projection) (model.py:351-356, custom_models.py:82-83)
-        float *du = e->sp_du.as<float>(), *dxe = e->sp_dxe.as<float>();
-        TRY(launch_l2norm_bwd(io.txt, e->q_dfeat.as<float>(), io.inv_norm, du, 1, D, st));
-        TRY(wgrad(e, io.eot_ln, Wt, Wt, du, D, D, 1, G + e->tw_slots[2].off, nullptr, st));
-        TRY(gemm(e, du, D, s.tproj, D, nullptr, nullptr, 0, nullptr, 0, dxe, Wt, 1, Wt, D, 1.f, RLCF_EPI_NONE, st));
-        TRY(launch_layernorm_bwd(io.eot_x, s.lnf_w, dxe, nullptr, dxe, GL, GL + Wt, 1, Wt, st));
-        RLCF_HIP_CHECK(hipMemsetAsync(e->dX.p, 0, (size_t)io.T * Wt * sizeof(float), st));
-        TRY(launch_scatter_rows(dxe, io.eot_rows, e->dX.as<float>(), 1, Wt, st));
-        TRY(transformer_backward(e, s.txt, e->st, io.seqs, io.n_seq, Q.max_keys, io.attn_pairs, 1, io.T, st, GL, 0, 0, 0, G, e->tw_slots.data() + 3));
-        embed_grad_kernel<<<dim3((Wt + 127) / 128), dim3(128), 0, st>>>(e->dX.as<float>(), Q.row_token.as<int32_t>(), Q.row_pos.as<int32_t>(),
-                                                                       G + e->tw_slots[0].off, G + e->tw_slots[1].off, io.T, Wt);
-        RLCF_LAUNCH_CHECK();
-        if (j == 0) {
-            COPY_OUT(out->logits, e->sel_logits.p, (size_t)C * sizeof(float));
-            COPY_OUT(out->topk_idx, e->topk_idx.p, (size_t)K * sizeof(int32_t));
-            COPY_OUT(out->clip_score, e->clip_score.p, (size_t)K * sizeof(float));
-            COPY_OUT(out->rewards, e->rewards.p, (size_t)K * sizeof(float));
-            COPY_OUT(out->loss, e->loss.p, sizeof(float));
-            COPY_OUT(out->dlogits, e->dlogits.p, (size_t)C * sizeof(float));
-            COPY_OUT(out->vis_grad, G, wb);
-            COPY_OUT(out->ln_grad, GL, lb);
-            COPY_OUT(out->reward_image_features, e->rimg[0].p, (size_t)e->model[RLCF_REWARD].cfg.embed_dim * sizeof(float));
-        }
-        TRY(launch_grad_nonfinite(GL, e->tln_count, 1, e->step_skip.as<int32_t>(), st));
-        TRY(launch_grad_nonfinite(G, (int64_t)e->tw_count, 1, e->step_skip.as<int32_t>(), st, true));
-        if (out->step_skipped) COPY_OUT(out->step_skipped + j, e->step_skip.p, sizeof(int32_t));
-        TRY(launch_adamw(e->tln.as<float>(), GL, e->tln_m.as<float>(), e->tln_v.as<float>(), e->tln_count, j + 1, a->lr, a->beta1, a->beta2,
-                         a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), e->tln_count));
-        TRY(launch_adamw(e->tw.as<float>(), G, e->tw_m.as<float>(), e->tw_v.as<float>(), (int64_t)e->tw_count, j + 1, a->lr, a->beta1, a->beta2,
-                         a->eps, a->weight_decay, st, e->step_skip.as<int32_t>(), (int64_t)e->tw_count));
-        e->tw_dirty = true;
-        TRY(refresh_derived(e->tw_refresh, 0, st));
-        TRY(rebuild_E(s, Q, st));
-    }
-    COPY_OUT(out->vis_after, e->tw.p, wb);
-    COPY_OUT(out->ln_after, e->tln.p, lb);
-    if (!a->skip_final) {
-        TRY(text_forward(e, s, Q, e->st, nullptr, io, false, st));
-        TRY(logits_per_text(e->final_logits.as<float>()));
-        COPY_OUT(out->final_logits, e->final_logits.p, (size_t)C * sizeof(float));
-    }
-    TRY(engine_text_reset(e, st, false));
-    return RLCF_OK;
-}
+// The per-path parts of this translation unit (they share the static helpers above: one TU, three files by path)
+#include "engine_prompt.inl"        // sparse class passes, engine_tta_sample, engine_tta_batch
+#include "engine_tuning.inl"        // LayerNorm / BatchNorm / every-parameter tuning of the image encoder
+#include "engine_retrieval.inl"     // text-encoder tuning (retrieval, text -> image)
