@@ -14,7 +14,8 @@ the max-over-ranks of the elapsed time use RCCL.  `--total-images T` switches fr
 
 Legs, in order (all on the launch stream of the engine = torch's current stream):
   1. warm-up (`--warmup` images, untimed) and the TIMED region: exactly `--steps` images, barrier + synchronize on
-     both sides, max over ranks -> `value`, `ms_per_step`;
+     both sides, max over ranks -> `value`, `ms_per_step`; run `--timed-repeats` times (default 2) and the SLOWEST region is the
+     one reported (`timed_regions_seconds` lists them all);
   2. sustained leg: full passes repeated for >= `--sustain-seconds` with a HIP event pair per pass -> mean / p50 / min / max ms
      per image (`sustained`; N=1 runs).  Multi-rank runs: every rank first settles its GPU's clock with untimed passes
      (`--settle-seconds`), the timed region reports each rank's own seconds and the slowest / fastest ratio, and the sustained leg
@@ -34,7 +35,9 @@ Every config prints the same JSON shape: whole-step TF/s, F_exec per image, the 
 built from ALL profiled launches of one pass (GEMMs by kernel kind and shape incl. the weight-gradient / dX GEMMs, attention forward
 and backward, LayerNorm forward and backward).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The numbers a review leans on are repeated as FLAT top-level keys next to `value`
+(`value_sustained`, `roofline_frac`, `f16_images_per_s`, `f16_in_proj_frac`, `f16_c_fc_frac`, `f16_attention_frac`,
+`f16_lnfold_*`, `grid_weights_images_per_s`, `harness_one_image_per_call`, `harness_three_in_flight`, ...).
 """
 import os as _os
 if int(_os.environ.get("WORLD_SIZE", "1")) == 1:         # one rank: the CPU-oracle leg pins one thread per core (read at OpenMP start-up)
