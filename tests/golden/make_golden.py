@@ -448,7 +448,9 @@ def save(name, arrays, meta):
     if "reward_class_features" in arrays and arrays["reward_class_features"].shape[0] > 64:
         arrays["reward_class_features"] = arrays["reward_class_features"][:64]     # 64 classes pin the reward bank; keeps the file small
     path = os.path.join(HERE, name + ".npz")
-    np.savez_compressed(path, **arrays, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    tmp = path + ".tmp.npz"                     # (written next to the target and renamed: a reader never sees half a file)
+    np.savez_compressed(tmp, **arrays, **{"meta_" + k: np.asarray(v) for k, v in meta.items()})
+    os.replace(tmp, path)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
