@@ -1,6 +1,7 @@
 // extern "C" surface of librlcf_hip.so (include/rlcf_hip.h): argument validation, error text,
 // engine construction.  No torch types cross this boundary.
 #include "engine.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 #include <cstdlib>
@@ -685,7 +686,17 @@ struct rlcf_lanes {
 };
 void rlcf_lanes_destroy(rlcf_lanes* l) {
     if (!l) return;
-    for (size_t k = 0; k < l->st.size(); ++k) if (l->st[k]) { (void)hipStreamSynchronize(l->st[k]); if (l->own_streams) (void)hipStreamDestroy(l->st[k]); }
+    for (size_t k = 0; k < l->st.size(); ++k)
+        if (l->st[k]) {
+            (void)hipStreamSynchronize(l->st[k]);
+            if (l->own_streams) {            // the engine of this lane must not keep (and later wait for) a handle that is about to die
+                if (k < l->eng.size()) {
+                    auto& us = l->eng[k]->used_streams;
+                    us.erase(std::remove(us.begin(), us.end(), l->st[k]), us.end());
+                }
+                (void)hipStreamDestroy(l->st[k]);
+            }
+        }
     for (hipEvent_t ev : l->done) if (ev) (void)hipEventDestroy(ev);
     if (l->ready) (void)hipEventDestroy(l->ready);
     for (size_t k = 0; k < l->eng.size() && k < l->side_was_off.size(); ++k) l->eng[k]->no_side = l->side_was_off[k];
