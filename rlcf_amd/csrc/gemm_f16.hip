@@ -190,10 +190,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
 //     where every wait of those K tiles then sat behind a congested store; spread over the K loop the chip sees them at 1/12 of the
 //     burst rate.  MEASURED SLOWER (2-3 % on the layer): the K loop is bound by vector-memory issue, a store costs it what a DMA piece costs.
 //     Off by default, RLCF_F16_PP_DEFER=1 turns it on (A/B, tests).  profiles/r6_notes.md section 1.
-template <int EPI, int MODE = 0, int DEFER = 0, int TRACE = 0>
+//   * TS (round 6, MODE 0): FULL-LINE stores.  The transpose-free epilogue above writes 32 rows x 32 B per store instruction: a lane owns
+//     one row, so the 64 lanes of an instruction touch 32 different 128-byte lines — and the round-6 trace shows the epilogue paced at
+//     ~80 ticks per store instruction and CU (12.5 B per tick) WHATEVER the other CUs do (start-time cohorts of 1/4 or 1/8 of the CUs:
+//     the same 6 400 / 10 200 ticks): it is bound by line requests per CU, not by bytes and not by the chip-wide burst.  With TS a wave
+//     moves each 32-row block of its tile through a private 4-KB LDS slab (ds_write_b128 lane = row, ds_read_b128 lane = (row of 8,
+//     16-byte chunk), XOR-swizzled) and stores 8 rows x 128 B per instruction: a quarter of the line requests.  LDS: the 32 KB behind
+//     the ring, 4 KB per wave; the wave's bias slice sits in the first KB of its own slab (read into registers before the slab is re-used).
+template <int EPI, int MODE = 0, int DEFER = 0, int TRACE = 0, int TS = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
 #if defined(__HIP_DEVICE_COMPILE__)          // (the host pass only needs the stub: the buffer-descriptor type below is a device-only type)
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR] + 1 KB: the tile's bias slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][P8_PAR] + 8 x 4 KB: one slab per wave (bias slice, TS transposes)
     const int tiles_n = (g.N + 255) / 256, tiles_m = (g.M + 255) / 256, ntiles = tiles_m * tiles_n;
     // XCD x owns a contiguous range of the tile order; its G/8 workgroups walk it G/8 tiles at a time
     const int wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(has_bias ? g.bias + n0_ : (const float*)g.Whi), 0, has_bias ? (int)((g.N - n0_) * 4) : 0, 0x00020000);
     };
     const unsigned vbias = (unsigned)lane * 16u;
-#define PP_STAGE_BIAS(rs) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + 2 * P8_PAR), 16, vbias, 0, 0, 0);
+#define PP_STAGE_BIAS(rs) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + 2 * P8_PAR + wave_s * 4096), 16, vbias, 0, 0, 0);     // (every wave its own copy, in its own slab)
 #define PP_STAGE_A(hf, par, rs, kt)                                                                                                 \
     {                                                                                                                               \
         char* d_ = smem + (par) * P8_PAR + (hf) * P8_HALF + wave_s * 2048;                                                           \
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
         PP_STAMP(2)
         // B_lo of the next tile's K tile 1, BEFORE this tile's stores (see PP_KTILE_FIRST)
         if (have_next) PP_STAGE_B(0, 1, rwn, 1)
+        PP_STAMP(10)
         if (g.ksplit != 2) {                                                // (ksplit 2: measurement without any epilogue)
             // The MFMAs ran with the operands swapped (W fragment first): an accumulator tile is C^T, so lane l32 owns ROW l32 of the 32-row
             // tile i and register r the tile column c = 8 (r >> 2) + 4 h + (r & 3), i.e. (B half tiles interleaved at 4-column granularity,
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                 //  was issued ahead of K tile nk - 2's pieces, which that K tile's counted wait covered two K tiles ago.)
                 //  The LDS address is formed INSIDE the statement: as a loop-invariant C++ value the compiler keeps it in a register across the K
                 //  loop, runs out of registers in the DEFER build and spills it — and a scratch reload is a vector-memory load with its own vmcnt(0).
-                const unsigned bias_base = (unsigned)(uintptr_t)(lptr_t)(smem + 2 * P8_PAR), bias_col = (unsigned)(wn * 64 + 8 * h);
+                const unsigned bias_base = (unsigned)(uintptr_t)(lptr_t)(smem + 2 * P8_PAR + wave_s * 4096), bias_col = (unsigned)(wn * 64 + 8 * h);
                 unsigned bl;
                 f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
                 asm volatile("v_lshl_add_u32 %8, %9, 2, %10\n\t"
@@ -560,8 +568,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                     rA[i] = al * mr.y; rB[i] = -mr.y * mr.x;          // rstd (alpha acc - mu s) + b' = (alpha rstd) acc + ((-rstd mu) s + b')
                 }
             }
+            // TS: lane constants of the wave's private slab.  write: row l32, 16-byte chunk (2 gq + h) XOR (l32 & 7); read: row 8 k + (lane >> 3),
+            // chunk (lane & 7) XOR (lane >> 3); store: the same row and chunk of the output tile
+            const unsigned ts_slab = (unsigned)(uintptr_t)(lptr_t)(smem + 2 * P8_PAR + wave_s * 4096);
+            const unsigned ts_w0 = ts_slab + (unsigned)l32 * 128u + (unsigned)((h ^ (l32 & 7)) << 4);      // (chunk 2 gq + h: XOR with gq << 5 below)
+            const unsigned ts_r0 = ts_slab + (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+            const unsigned ts_v0 = (unsigned)(((wm * 128 + (lane >> 3)) * g.ldch + wn * 64 + (lane & 7) * 8) * 2);
+            const bool ts_now = TS && MODE != 2 && bufst;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                h16x8 oq[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     h16x8 o;
@@ -575,6 +591,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                             if constexpr (EPI == RLCF_EPI_QUICKGELU) r = quick_gelu_fast(r);
                             o[j * 4 + q] = (_Float16)r;
                         }
+                    oq[gq] = o;
+                    if constexpr (TS != 0) { if (ts_now) continue; }
                     _Float16* op = obase + (size_t)(i * 32) * g.ldch + gq * 16;
                     if (g.ksplit == 1 && o[0] != (_Float16)123.0f) continue;            // (measurement: no stores)
                     if constexpr (DEFER != 0) {
@@ -591,6 +609,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                             if (c0 + 4 <= g.N) *(h16x4*)op = h16x4{o[0], o[1], o[2], o[3]};
                             if (c0 + 8 <= g.N) *(h16x4*)(op + 4) = h16x4{o[4], o[5], o[6], o[7]};
                         }
+                    }
+                    if (gq == 0 && i == 0) { PP_STAMP(11) }       // (trace: first store issued; then after 4 / 8 / 12 of the wave's 16)
+                    if (gq == 3 && i == 0) { PP_STAMP(12) }
+                    if (gq == 3 && i == 1) { PP_STAMP(13) }
+                    if (gq == 3 && i == 2) { PP_STAMP(14) }
+                }
+                if constexpr (TS != 0) {
+                    if (ts_now) {
+                        // the 32-row block through the slab (inline asm: a C++ access of LDS gets a compiler vmcnt(0) for the LDS-DMA in flight);
+                        // the slab is this wave's alone: no barrier, its own lgkmcnt orders write -> read -> next block's write
+                        u32x4 t0, t1, t2, t3;
+                        asm volatile("ds_write_b128 %4, %8\n\tds_write_b128 %5, %9\n\tds_write_b128 %6, %10\n\tds_write_b128 %7, %11\n\t"
+                                     "s_waitcnt lgkmcnt(0)\n\t"
+                                     "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:1024\n\tds_read_b128 %2, %12 offset:2048\n\tds_read_b128 %3, %12 offset:3072\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                                     : "v"(ts_w0), "v"(ts_w0 ^ 32u), "v"(ts_w0 ^ 64u), "v"(ts_w0 ^ 96u),
+                                       "v"(__builtin_bit_cast(u32x4, oq[0])), "v"(__builtin_bit_cast(u32x4, oq[1])), "v"(__builtin_bit_cast(u32x4, oq[2])),
+                                       "v"(__builtin_bit_cast(u32x4, oq[3])), "v"(ts_r0)
+                                     : "memory");
+                        const int so = (i * 32) * g.ldch * 2;
+                        __builtin_amdgcn_raw_buffer_store_b128(t0, rs_out, ts_v0, so, 0);
+                        if (i == 0) { PP_STAMP(11) }
+                        __builtin_amdgcn_raw_buffer_store_b128(t1, rs_out, ts_v0, so + 8 * g.ldch * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(t2, rs_out, ts_v0, so + 16 * g.ldch * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(t3, rs_out, ts_v0, so + 24 * g.ldch * 2, 0);
+                        if (i == 0) { PP_STAMP(12) }
+                        if (i == 1) { PP_STAMP(13) }
+                        if (i == 2) { PP_STAMP(14) }
                     }
                 }
             }
@@ -667,16 +714,18 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     }
     const int blocks = ((M + 255) / 256) * (N / 256);
     const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
-    const size_t shp = (size_t)2 * P8_PAR + 1024;      // + the tile's bias slice
-#define PP_LN_GO(E, MD)                                                                                                             \
+    const size_t shp = (size_t)2 * P8_PAR + 8 * 4096;      // + a 4-KB slab per wave (bias slice; TS: the transposing epilogue)
+    const char* tse = getenv("RLCF_F16_PP_TSTORE");          // (mode 1: full-line stores through the per-wave LDS slab, as the plain products)
+    const bool tstore = (tse ? atoi(tse) : 1) != 0;
+#define PP_LN_GO(E, MD, S)                                                                                                          \
     {                                                                                                                               \
-        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD>, shp);                                                      \
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD, 0, 0, S>, shp);                                             \
         if (rc != RLCF_OK) return rc;                                                                                               \
-        gemm_nt_f16_pp_kernel<E, MD><<<dim3(grid), dim3(512), shp, st>>>(g);                                                         \
+        gemm_nt_f16_pp_kernel<E, MD, 0, 0, S><<<dim3(grid), dim3(512), shp, st>>>(g);                                                \
     }
-    if (mode == 2) PP_LN_GO(RLCF_EPI_NONE, 2)
-    else if (epilogue == RLCF_EPI_QUICKGELU) PP_LN_GO(RLCF_EPI_QUICKGELU, 1)
-    else PP_LN_GO(RLCF_EPI_NONE, 1)
+    if (mode == 2) PP_LN_GO(RLCF_EPI_NONE, 2, 0)
+    else if (epilogue == RLCF_EPI_QUICKGELU) { if (tstore) PP_LN_GO(RLCF_EPI_QUICKGELU, 1, 1) else PP_LN_GO(RLCF_EPI_QUICKGELU, 1, 0) }
+    else { if (tstore) PP_LN_GO(RLCF_EPI_NONE, 1, 1) else PP_LN_GO(RLCF_EPI_NONE, 1, 0) }
 #undef PP_LN_GO
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
@@ -702,7 +751,7 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
             if (ncu <= 0) ncu = 256;
         }
         const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
-        const size_t shp = (size_t)2 * P8_PAR + 1024;      // + the tile's bias slice
+        const size_t shp = (size_t)2 * P8_PAR + 8 * 4096;      // + a 4-KB slab per wave (bias slice; TS: the transposing epilogue)
         g.ksplit = abl;
         g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
         static int desync = -1;                              // RLCF_F16_PP_DESYNC=P: start-time cohorts (1 = all together)
@@ -723,13 +772,16 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
         // loop has no spare vector-memory issue capacity, a deferred store costs it what a DMA piece costs (profiles/r6_notes.md section 1)
         const char* de = getenv("RLCF_F16_PP_DEFER");
         const bool defer = (de ? atoi(de) : 0) != 0 && abl == 0 && blocks > grid && K >= 768;
-#define PP_GO(E, D, T)                                                                                                              \
+        // RLCF_F16_PP_TSTORE (read per launch): 1 = full-line stores through the per-wave LDS slab (TS), 0 = 32 rows x 32 B per instruction
+        const char* tse = getenv("RLCF_F16_PP_TSTORE");
+        const bool tstore = (tse ? atoi(tse) : 1) != 0 && !defer && abl == 0;
+#define PP_GO(E, D, T, S)                                                                                                           \
     {                                                                                                                               \
-        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, 0, D, T>, shp);                                                 \
+        int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, 0, D, T, S>, shp);                                              \
         if (rc != RLCF_OK) return rc;                                                                                               \
-        gemm_nt_f16_pp_kernel<E, 0, D, T><<<dim3(grid), dim3(512), shp, st>>>(g);                                                    \
+        gemm_nt_f16_pp_kernel<E, 0, D, T, S><<<dim3(grid), dim3(512), shp, st>>>(g);                                                 \
     }
-#define PP_GO_T(E, D) { if (trace_on) PP_GO(E, D, 1) else PP_GO(E, D, 0) }
+#define PP_GO_T(E, D) { if (tstore) { if (trace_on) PP_GO(E, 0, 1, 1) else PP_GO(E, 0, 0, 1) } else if (trace_on) PP_GO(E, D, 1, 0) else PP_GO(E, D, 0, 0) }
         if (epilogue == RLCF_EPI_QUICKGELU) { if (defer) PP_GO_T(RLCF_EPI_QUICKGELU, 1) else PP_GO_T(RLCF_EPI_QUICKGELU, 0) }
         else { if (defer) PP_GO_T(RLCF_EPI_NONE, 1) else PP_GO_T(RLCF_EPI_NONE, 0) }
 #undef PP_GO_T
@@ -760,6 +812,17 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
                     }
                     if (n) fprintf(stderr, "[pp trace] M=%d N=%d K=%d wg %3d group %d: tiles %2d  K loop %.0f  line-up %.0f  epilogue %.0f  tile-to-tile %.0f (s_memtime ticks)\n",
                                    M, N, K, wgi, grp, n, kl / n, lu / n, ep / n, tt / n);
+                    if (n && K / 64 <= 12) {     // inside the epilogue (slots 10 .. 14 are free at K = 768): ticks since the groups lined up
+                        double e[5] = {0, 0, 0, 0, 0}; int m = 0;
+                        for (int ti = 1; ti < 64; ++ti) {
+                            const unsigned long long* r = host + (((size_t)wgi * 64 + ti) * 2 + grp) * 16;
+                            if (!r[3] || !r[14]) break;
+                            for (int q = 0; q < 5; ++q) e[q] += (double)(r[10 + q] - r[2]);
+                            ++m;
+                        }
+                        if (m) fprintf(stderr, "[pp trace]   epilogue, since line-up: next-tile B_lo staged %.0f | first store issued %.0f | 4 stores %.0f | 8 stores %.0f | 12 stores %.0f | 16 stores %.0f\n",
+                                       e[0] / m, e[1] / m, e[2] / m, e[3] / m, e[4] / m, ep / n);
+                    }
                 }
             }
         }

@@ -107,20 +107,23 @@ def test_in_flight_falls_back_to_the_serial_loop_after_an_applied_ema():
 @pytest.mark.parametrize("M,N,K,epi", [(70000 + 37, 768, 768, 0), (66000, 2304, 768, 0), (66000, 3072, 768, 1), (70000 + 37, 768, 3072, 0), (66816, 1024, 1024, 0)])
 def test_f16_gemm_deferred_stores_equal_epilogue_stores(M, N, K, epi, monkeypatch):
     """gemm_nt_f16_pp_kernel<.., DEFER = 1> (half of a tile's output leaves under the next tile's K loop, one store per K tile behind a
-    counted wait) writes the SAME bits as the epilogue-only form, on matrices with more tiles than workgroups (every workgroup carries
+    counted wait) and <.., TS = 1> (full-line stores: every 32-row block of a wave's tile through a private LDS slab, 8 rows x 128 B per
+    store instruction) write the SAME bits as the epilogue-only form with 32 rows x 32 B per instruction, on matrices with more tiles than workgroups (every workgroup carries
     pending stores across tiles), a ragged last row tile, both epilogues and both K depths; every element is written (NaN pre-fill)."""
     a = torch.randn(M, K, device=DEV).half()
     w = (torch.randn(N, K, device=DEV) * K ** -0.5).half()
     b = torch.randn(N, device=DEV) * 0.1
     outs = []
-    for d in ("0", "1", "1"):
+    for d, ts in (("0", "0"), ("1", "0"), ("1", "0"), ("0", "1"), ("0", "1")):          # epilogue-only 32 x 32-B stores; deferred (twice); full-line stores through LDS (twice)
         monkeypatch.setenv("RLCF_F16_PP_DEFER", d)
+        monkeypatch.setenv("RLCF_F16_PP_TSTORE", ts)
         c = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
         L.check(L.lib().rlcf_gemm_f16(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), None, N, None, N, c.data_ptr(), N, M, N, K, 1.0, epi, _st()))
         torch.cuda.current_stream().synchronize()
         outs.append(c)
     assert not torch.isnan(outs[1]).any()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[0], outs[3]) and torch.equal(outs[3], outs[4]) and not torch.isnan(outs[3]).any()
     rows = torch.randint(0, M, (128,), device=DEV)
     ref = a[rows].double() @ w.double().t() + b.double()
     if epi == 1:
