@@ -157,10 +157,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_p8_kernel(GemmX3Args g) {
     const int ek = x3_epilogue_kind(g);
     float* parkf = (float*)smem + wave * (64 * 68);
     __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
-        X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
-                         m0 + wm * 128 + half * 64, n0 + wn * 64, lane, am)
+    X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], parkf, m0 + wm * 128, n0 + wn * 64, lane, am)          // (the two halves written out: see gemm_f16x3.hip)
+    X3_EPILOGUE_SLAB(ek, g, acc[2][0], acc[2][1], acc[3][0], acc[3][1], parkf, m0 + wm * 128 + 64, n0 + wn * 64, lane, am)
     amax_commit(g.amax_out, am); x3_publish_scale(g);
 }
 

@@ -962,10 +962,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16x3_v3i_kernel(GemmX3Args g)
     if (const int ek = x3_epilogue_kind(g)) {
         float* parkf = (float*)smem + wave * (64 * 68);
         __syncthreads();
-#pragma unroll
-        for (int half = 0; half < MT / 2; ++half)
-            X3_EPILOGUE_SLAB(ek, g, acc[half * 2][0], acc[half * 2][1], acc[half * 2 + 1][0], acc[half * 2 + 1][1], parkf,
-                             m0 + wm * (MT * 32) + half * 64, n0 + wn * 64, lane, am)
+        // (written out, not a `#pragma unroll` loop over the halves: with every epilogue kind inlined the loop body exceeds the pragma-unroll
+        //  size limit once the pair kinds carry the line-complete stores — the loop then stays a loop and acc[half * 2] becomes scratch)
+        X3_EPILOGUE_SLAB(ek, g, acc[0][0], acc[0][1], acc[1][0], acc[1][1], parkf, m0 + wm * (MT * 32), n0 + wn * 64, lane, am)
+        if constexpr (MT == 4)
+            X3_EPILOGUE_SLAB(ek, g, acc[2][0], acc[2][1], acc[3][0], acc[3][1], parkf, m0 + wm * (MT * 32) + 64, n0 + wn * 64, lane, am)
         if constexpr (MT == 3)           // the third 32-row tile: half a slab
             X3_EPILOGUE_HALFSLAB(ek, g, acc[2][0], acc[2][1], acc[2][0], acc[2][1], parkf, m0 + wm * 96 + 64, n0 + wn * 64, lane, am)
         amax_commit(g.amax_out, am); x3_publish_scale(g);
@@ -1514,7 +1515,9 @@ int launch_gemm_f16x3(const void* Ahi, const void* Alo, int lda, const void* Whi
     if (nofast < 0) { const char* e = getenv("RLCF_X3_NOFASTEPI"); nofast = e ? atoi(e) : 0; }
     static int x3nt = -1;
     if (x3nt < 0) { const char* e = getenv("RLCF_X3_NT"); x3nt = e ? atoi(e) : 1; }      // (on since round 5: +0.5-0.8 % on the layer's four products, bit-identical results; fabric traffic unchanged)
-    g.no_fast_epi = (nofast ? 1 : 0) | (x3nt ? 2 : 0);
+    static int linest = -1;                                  // RLCF_X3_LINEST=0: the pair epilogues keep the 8-byte hi / lo stores (A/B)
+    if (linest < 0) { const char* e = getenv("RLCF_X3_LINEST"); linest = e ? atoi(e) : 1; }
+    g.no_fast_epi = (nofast ? 1 : 0) | (x3nt ? 2 : 0) | (linest ? 0 : 4);
     static int tgroup = -1;
     if (tgroup < 0) { const char* e = getenv("RLCF_X3_GROUP"); tgroup = e ? atoi(e) : 0; }
     g.tile_group = tgroup;

@@ -133,6 +133,14 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         park[pr] = a0[r]; park[pr + 32] = a1[r];
         if constexpr (NIT == 16) { park[pr + 32 * ELD] = a2[r]; park[pr + 32 * ELD + 32] = a3[r]; }        // (NIT = 8: a 32-row half slab, a0 / a1 only)
     }
+    // Round 6: LINE-COMPLETE pair stores (kinds 3 / 4: in_proj -> Q / K / V pairs, c_fc + QuickGELU -> pairs; interleaved layout, 64 whole columns).
+    // A lane holds 4 columns of a row; its hi halves (8 B) and lo halves (8 B) used to go out as two instructions that each wrote HALF of
+    // every 128-byte line they touched ([hi c0-31 | lo c0-31] per 32-column block): every line requested twice, 256 line requests per 64x64
+    // slab.  The single-pass f16 kernel showed (profiles/r6_notes.md section 1b) that a CU's store burst is paced by LINE REQUESTS, not bytes.
+    // Now the 16 lanes of a row swap with lane ^ 8 what the partner's line needs (the lanes of block 0 send their lo halves and receive block
+    // 1's hi halves): instruction A writes the whole line of block 0, instruction B the whole line of block 1 — each line requested once.
+    // Same values, same bits, same number of store instructions.  RLCF_X3_LINEST=0: off.
+    const bool line_ok = PAIR && !RES && !F32OUT && !LEAN && g.c_il && g.Clo == g.Chi + 32 && !(g.no_fast_epi & 4) && col0 + 64 <= g.N && (g.ldch & 3) == 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const float4 a4 = *(const float4*)(park + (it * 4 + rsub) * ELD + c4);
@@ -148,13 +156,41 @@ __device__ __forceinline__ void x3_epilogue_slab(const GemmX3Args& g, const f32x
         } else {                                                                                     // into the store loop (IR sinking re-fuses the phases)
             const int row = rbase + it * 4;
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            // (the lane exchange of the line-complete stores sits OUTSIDE every per-lane condition: a cross-lane operation under a branch the
+            //  compiler cannot prove uniform stops it from unrolling this loop, and the un-unrolled loop indexes rr[] dynamically = scratch)
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            h16x4 hh_, ll_;
+            u32x2_ ld0 = {0u, 0u}, ld1 = {0u, 0u};
+            if constexpr (PAIR && !F32OUT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float vs = v[q] * os; hh_[q] = (_Float16)vs; ll_[q] = (_Float16)(vs - (float)hh_[q]); }
+                const u32x2_ hv = __builtin_bit_cast(u32x2_, hh_), lv = __builtin_bit_cast(u32x2_, ll_);
+                const bool up = (lane & 8) != 0;                 // this lane's columns belong to block 1 of the slab (columns 32-63)
+                const u32x2_ send = up ? hv : lv;
+                // the swap with lane ^ 8 goes through the slab this wave has just read (the lane's own four floats of this pass are consumed:
+                // it overwrites two of them and reads its partner's two; LDS operations of one wave execute in order) — plain LDS accesses,
+                // NOT a cross-lane intrinsic: a convergent operation in this loop keeps the compiler from unrolling it, and the loop that
+                // is not unrolled indexes its register arrays dynamically (= scratch)
+                float2* slot = (float2*)(park + (it * 4 + rsub) * ELD + c4);
+                *slot = __builtin_bit_cast(float2, send);
+                const u32x2_ recv = __builtin_bit_cast(u32x2_, *(const float2*)(park + (it * 4 + rsub) * ELD + (c4 ^ 32)));
+                ld0 = up ? recv : hv; ld1 = up ? lv : recv;      // line of block 0 = [hi | lo] of columns 0-31; line of block 1
+            }
             if (colok && row < g.M) {
                 if (want_amax) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if constexpr (F32OUT) { const f32x4 o4_ = {v[0], v[1], v[2], v[3]}; if (nt) __builtin_nontemporal_store(o4_, (f32x4*)(g.C + (size_t)row * g.ldc + col)); else *(f32x4*)(g.C + (size_t)row * g.ldc + col) = o4_; }
                 if constexpr (PAIR) {
                     h16x4 hh, ll;
+                    if constexpr (!F32OUT) { hh = hh_; ll = ll_; }        // (split once, above)
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float vs = v[q] * os; hh[q] = (_Float16)vs; ll[q] = (_Float16)(vs - (float)hh[q]); }
+                        for (int q = 0; q < 4; ++q) { const float vs = v[q] * os; hh[q] = (_Float16)vs; ll[q] = (_Float16)(vs - (float)hh[q]); }
+                    }
+                    if (line_ok) {
+                        _Float16* op = g.Chi + (size_t)row * g.ldch + 2 * (size_t)col0 + (lane & 15) * 4;
+                        if (nt) { __builtin_nontemporal_store(ld0, (u32x2_*)op); __builtin_nontemporal_store(ld1, (u32x2_*)(op + 64)); }
+                        else { *(u32x2_*)op = ld0; *(u32x2_*)(op + 64) = ld1; }
+                    } else
                     if (nt) { __builtin_nontemporal_store(hh, (h16x4*)(g.Chi + (size_t)row * g.ldch + ocol)); if (g.Clo) __builtin_nontemporal_store(ll, (h16x4*)(g.Clo + (size_t)row * g.ldch + ocol)); }
                     else {
                     *(h16x4*)(g.Chi + (size_t)row * g.ldch + ocol) = hh;
