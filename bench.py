@@ -213,11 +213,18 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     # few-row tail runs under the next sample's 64-view tower pass; per-sample results are the one-at-a-time call's
     # round 6: ONE host thread enqueues every lane (rlcf_lanes_submit, events between the streams); round 5 ran a Python thread per lane and
     # its legs scattered 72-116 images/s for one setting.  Every in-flight row is still the median of three legs, all three kept next to it
+    # (legs are kept in RUN ORDER; a setting with views made in the loop is run once untimed first: with K lanes the view tensors of K
+    #  samples are alive at a time on K streams, and the first loop of such a setting grows torch's caching allocator to that pool — up to
+    #  round 6's first captures that growth sat in the first timed leg of every views-in-loop setting: 70 against 91 - 95 images/s)
     def run3(key, st, k):
-        legs = sorted(run(2 * n_one, 1, st, k) for _ in range(3))
-        out[key], out[key + "_legs"] = legs[1], [round(x, 2) for x in legs]
+        if st is None:
+            run(12, 1, None, k)
+        legs = [run(2 * n_one, 1, st, k) for _ in range(3)]
+        out[key], out[key + "_legs"] = sorted(legs)[1], [round(x, 2) for x in legs]
         if key.endswith("three_in_flight_staged_views"):
-            out["three_in_flight_staged_legs_max_over_min"] = legs[-1] / legs[0]
+            out["three_in_flight_staged_legs_max_over_min"] = max(legs) / min(legs)
+        if key.endswith("three_in_flight_views_in_loop"):
+            out["three_in_flight_views_in_loop_legs_max_over_min"] = max(legs) / min(legs)
 
     run(12, 1, None)                                          # (views made in the loop allocate per image: let the caching allocator reach its steady pool first)
     run(4, 1, staged, 2)                                      # (builds the second engine)
@@ -791,6 +798,7 @@ def main():
                            ("harness_three_in_flight", ("harness", "images_per_s_one_image_per_pass_three_in_flight_staged_views")),
                            ("harness_three_in_flight_views_in_loop", ("harness", "images_per_s_one_image_per_pass_three_in_flight_views_in_loop")),
                            ("harness_three_in_flight_legs_spread", ("harness", "three_in_flight_staged_legs_max_over_min")),
+                           ("harness_three_in_flight_views_in_loop_legs_spread", ("harness", "three_in_flight_views_in_loop_legs_max_over_min")),
                            ("view_generation_ms_per_image", ("harness", "view_generation_ms_per_image")),
                            ("cpu_baseline_images_per_s", ("cpu_baseline", "value"))):
             out[k_flat] = _g(out, *ks)

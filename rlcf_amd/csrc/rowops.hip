@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             _Float16* yh,
                                                             _Float16* __restrict__ yl, int rows, int width, int group_rows, int group_stride,
-                                                            int il, const _Float16* add16 = nullptr, float* xout = nullptr) {
+                                                            int ilf, const _Float16* add16 = nullptr, float* xout = nullptr) {
+    const int il = ilf & 1;                     // bit 1 of ilf: whole-line stores of the interleaved pair rows (below)
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -89,8 +90,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
                     const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hh[q] = (_Float16)ov[q]; ll[q] = (_Float16)(ov[q] - (float)hh[q]); }
-                    *(h16x4*)(yh + pair_off(row, c, width, il)) = hh;
-                    if (yl) *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;       // (yl null: plain f16 output, RLCF_PREC_F16)
+                    if ((ilf & 2) && yl == yh + 32) {
+                        // interleaved pair rows: a 128-byte line = [hi of 32 columns | lo of the same 32 columns].  Written as they fall (all hi
+                        // halves, then all lo halves) every line is requested twice, half a line each time; the lanes of a line pair swap
+                        // with lane ^ 8 what the partner's line needs, and each instruction writes whole lines (round 6: a CU's stores are
+                        // paced by line requests, profiles/r6_notes.md section 1b).  Same bits at the same addresses.
+                        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                        const u32x2_ hv = __builtin_bit_cast(u32x2_, hh), lv = __builtin_bit_cast(u32x2_, ll);
+                        const bool up = (lane & 8) != 0;                          // this lane's columns sit in the odd 32-column block
+                        const u32x2_ send = up ? hv : lv;
+                        u32x2_ recv;
+                        recv[0] = (unsigned)__shfl_xor((int)send[0], 8); recv[1] = (unsigned)__shfl_xor((int)send[1], 8);
+                        const u32x2_ even_line = up ? recv : hv, odd_line = up ? lv : recv;
+                        _Float16* lp = yh + (size_t)row * 2 * width + (size_t)(c >> 6) * 128 + (lane & 15) * 4;      // the even block's line of this 64-column pair
+                        *(u32x2_*)lp = even_line; *(u32x2_*)(lp + 64) = odd_line;
+                    } else {
+                        *(h16x4*)(yh + pair_off(row, c, width, il)) = hh;
+                        if (yl) *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;       // (yl null: plain f16 output, RLCF_PREC_F16)
+                    }
                 }
             }
     } else {
@@ -117,9 +134,12 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* beta, float* y, void* yh, void* yl, int rows, int width,
                                hipStream_t st, int group_rows, int group_stride, int il) {
     RLCF_ARG_CHECK(rows > 0 && width > 0 && width <= 64 * MAX_PER_LANE && group_rows >= 0);
+    static int linest = -1;                     // RLCF_LN_LINEST=0: hi halves and lo halves of the interleaved pair rows as two half-line stores (A/B)
+    if (linest < 0) { const char* e = getenv("RLCF_LN_LINEST"); linest = e ? atoi(e) : 1; }
     layernorm_fwd_kernel<false><<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
                                                                                                           (_Float16*)yl, rows, width, group_rows,
-                                                                                                          group_rows > 0 ? group_stride : 0, il);
+                                                                                                          group_rows > 0 ? group_stride : 0,
+                                                                                                          (il ? 1 : 0) | (il && linest ? 2 : 0));
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }

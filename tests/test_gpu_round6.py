@@ -203,3 +203,32 @@ def test_bench_refuses_more_ranks_than_visible_gpus_under_nccl():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "nccl", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)
+
+
+# ------------------------------------------------------------------ the parity kernel's line-complete pair stores move bytes, not bits
+_LINEST_PROBE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from rlcf_amd import _lib as L, synth
+from rlcf_amd.engine import Engine
+g = synth.GEOMETRIES["ViT-B/16"]; dev = torch.device("cuda:0")
+eng = Engine(g, g, 64, 8, L.PREC_F16X3)
+sd = synth.make_state_dict(g, 11, device=dev)
+eng.load_state_dict(L.STUDENT, sd); eng.load_state_dict(L.REWARD, sd); eng.finalize()
+f = eng.encode_image(L.STUDENT, synth.make_views(4242, 64, g.image_resolution, device=dev))
+print("FEATURES", hashlib.sha256(f.cpu().numpy().tobytes()).hexdigest(), float(f.abs().sum()))
+"""
+
+
+def test_x3_line_complete_pair_stores_bit_identical():
+    """RLCF_X3_LINEST (read once per process): the in_proj / c_fc epilogues of the 256x256 split-f16 kernel write the interleaved hi / lo
+    pair rows either as half lines (0) or as whole 128-byte lines after a lane exchange through the park slab (1, default).  One ViT-B/16
+    image tower pass over 64 views (12 608 token rows: both products run on that kernel) must give the same feature BITS either way."""
+    outs = []
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _LINEST_PROBE, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env=dict(os.environ, RLCF_X3_LINEST=v))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([x for x in r.stdout.splitlines() if x.startswith("FEATURES")][-1])
+    assert outs[0] == outs[1], outs
+    assert float(outs[0].split()[2]) > 0.0
