@@ -203,6 +203,34 @@ __device__ __forceinline__ void ap_sub(ApAcc& a, const h16x8 (&qh)[4], const h16
 #undef AP_SUBSTAMP
 }
 
+// Four normalised output values -> their 8-byte piece of hi halves and (pair rows) the piece of lo halves.  The roundings are PINNED: the
+// product o * inv is made opaque before anything consumes it and both conversions are v_cvt_pk_f16_f32.  Left to itself the compiler
+// contracts o * inv - hi into one FMA or rounds a product straight to f16 (v_fma_mixlo_f16) in one of the two store forms below and not in
+// the other — an ulp of lo (or, rarely, of a plain-f16 value) between two builds of the same arithmetic.  vout: the f32 values.
+typedef unsigned ap_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ap_h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ap_pk_f16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool LO>
+__device__ __forceinline__ void ap_piece(float o_0, float o_1, float o_2, float o_3, float inv, h16x4& hi, h16x4& lo, float* vout) {
+    float v[4] = {o_0 * inv, o_1 * inv, o_2 * inv, o_3 * inv};
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    ap_u32x2 hp = {ap_pk_f16(v[0], v[1]), ap_pk_f16(v[2], v[3])};
+    hi = __builtin_bit_cast(h16x4, hp);
+    if constexpr (LO) {
+        float d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = v[q] - (float)hi[q];           // exact: hi is within half an f16 ulp of v
+        ap_u32x2 lp = {ap_pk_f16(d[0], d[1]), ap_pk_f16(d[2], d[3])};
+        lo = __builtin_bit_cast(h16x4, lp);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vout[q] = v[q];
+}
+
 // normalise and store one query row (lane (q, h): d = 8g + 4h + [0,4) of both 32-column blocks for g = 0..3); a.lsum already summed
 // over the two half-waves
 __device__ __forceinline__ void ap_store(const ApAcc& a, size_t row, int head, int width, int h, float* __restrict__ out, _Float16* __restrict__ oh,
@@ -216,22 +244,14 @@ __device__ __forceinline__ void ap_store(const ApAcc& a, size_t row, int head, i
     for (int g = 0; g < 4; ++g) {
         const int d = 8 * g + 4 * h;
         float v0[4], v1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v0[q] = a.o0[4 * g + q] * inv;
-            v1[q] = a.o1[4 * g + q] * inv;
-        }
+        h16x4 h0, l0, h1, l1;
+        ap_piece<true>(a.o0[4 * g], a.o0[4 * g + 1], a.o0[4 * g + 2], a.o0[4 * g + 3], inv, h0, l0, v0);
+        ap_piece<true>(a.o1[4 * g], a.o1[4 * g + 1], a.o1[4 * g + 2], a.o1[4 * g + 3], inv, h1, l1, v1);
         if (out) {
             *(float4*)(out + obase + d) = make_float4(v0[0], v0[1], v0[2], v0[3]);
             *(float4*)(out + obase + 32 + d) = make_float4(v1[0], v1[1], v1[2], v1[3]);
         }
         if (oh) {
-            h16x4 h0, l0, h1, l1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                h0[q] = (_Float16)v0[q]; l0[q] = (_Float16)(v0[q] - (float)h0[q]);
-                h1[q] = (_Float16)v1[q]; l1[q] = (_Float16)(v1[q] - (float)h1[q]);
-            }
             // interleaved pair layout (il): the head's two 32-column blocks sit at row*2W + head*128 (+64), lo 32 halves after hi
             const size_t p0 = il ? row * 2 * width + head * 128 + d : obase + d;
             const size_t p1 = il ? p0 + 64 : p0 + 32;
@@ -241,12 +261,59 @@ __device__ __forceinline__ void ap_store(const ApAcc& a, size_t row, int head, i
     }
 }
 
+// Round 6: the same rows as WHOLE 128-byte lines.  ap_store writes the accumulator layout as it falls: one instruction = 32 rows x 16 bytes, every
+// line of the output requested 8 times (pair rows: 16 instructions x 32 line requests for 64 lines).  A CU's stores are paced by line
+// requests (profiles/r6_notes.md section 1b), so the block goes through LDS instead: 16 rows at a time into the wave's slab (RB bytes per
+// row: 256 = the head's interleaved pair row [hi b0 | lo b0 | hi b1 | lo b1], 128 = plain f16 [b0 | b1]; 16-byte slots XOR-ed with the row
+// so that neither side of the transpose piles up on a bank), read back as 16 bytes per lane, one instruction = 1 KB of whole lines.
+// Same bits at the same addresses, half as many store instructions, an eighth of the line requests.
+template <int RB>
+__device__ __forceinline__ void ap_store_lines(const ApAcc& a, char* slab, int lane, int nvalid, _Float16* __restrict__ orow0, size_t row_halves) {
+    constexpr int SLOTS = RB / 16, RPI = 1024 / RB;            // 16-byte slots per row; rows per store instruction
+    const int l32 = lane & 31, h = lane >> 5, rl = l32 & 15;
+    const float inv = 1.0f / a.lsum;
+    constexpr int NP = RB / 64;                                 // 8-byte pieces per lane and g: hi b0, lo b0, hi b1, lo b1 (pair rows) or b0, b1
+    h16x4 pc[4][NP];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float vv[4];
+        h16x4 lo_;
+        if constexpr (RB == 256) {
+            ap_piece<true>(a.o0[4 * g], a.o0[4 * g + 1], a.o0[4 * g + 2], a.o0[4 * g + 3], inv, pc[g][0], pc[g][1], vv);
+            ap_piece<true>(a.o1[4 * g], a.o1[4 * g + 1], a.o1[4 * g + 2], a.o1[4 * g + 3], inv, pc[g][2], pc[g][3], vv);
+        } else {
+            ap_piece<false>(a.o0[4 * g], a.o0[4 * g + 1], a.o0[4 * g + 2], a.o0[4 * g + 3], inv, pc[g][0], lo_, vv);
+            ap_piece<false>(a.o1[4 * g], a.o1[4 * g + 1], a.o1[4 * g + 2], a.o1[4 * g + 3], inv, pc[g][1], lo_, vv);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if ((l32 >> 4) == p) {
+            char* wr = slab + rl * RB + 8 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) *(h16x4*)(wr + (((4 * i + g) ^ (rl & 7)) * 16)) = pc[g][i];
+        }
+        __builtin_amdgcn_wave_barrier();                          // (one wave: its LDS operations execute in order; this keeps the compiler from reordering them)
+#pragma unroll
+        for (int k = 0; k < 16 / RPI; ++k) {
+            const int r = k * RPI + lane / SLOTS, sl = lane % SLOTS;
+            // (read with the element type it was written with: under type-based alias analysis a load of `unsigned` may be moved above
+            //  stores of `_Float16` — the first build of this function did exactly that and stored the slab's previous contents)
+            const h16x8 v = *(const h16x8*)(slab + r * RB + ((sl ^ (r & 7)) * 16));
+            if (16 * p + r < nvalid) *(h16x8*)(orow0 + (size_t)(16 * p + r) * row_halves + sl * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // one-shot kernel: NW waves = NW blocks of 32 queries of one (sequence, head); SK keys per ring stage; every wave stages and computes
 template <int NW, int SK, bool SINGLE, int VAR = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NW == 4 ? 2 : 1)) void attention_fwd_pair_kernel(
     const _Float16* __restrict__ qkv2, const rlcf_seq* __restrict__ seqs, int width, float* __restrict__ out, _Float16* __restrict__ oh,
-    int il, int qb0, float* __restrict__ lse) {
+    int ilf, int qb0, float* __restrict__ lse) {
     constexpr int NQ = SINGLE ? 2 : 4;                // 64-B quads of a key's K (or V) row of one head: (d block) x (hi / lo)
     constexpr int QB = SK * 64;                       // bytes of one quad of a stage: [key][64 B]
     constexpr int REGION = NQ * QB;                   // K (or V) part of a stage
@@ -333,6 +400,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NW == 4 ? 2 : 1)) void atte
 #undef AP_ISSUE
     if (active) {
         acc.lsum += __shfl_xor(acc.lsum, 32);
+        const int il = ilf & 1;
+        // whole-line stores (ilf & 2) go through the stage that chunk nchunk-2 left: every wave is past the last chunk's barrier (nobody reads
+        // it any more), nothing was issued into it after that chunk — each wave owns STAGE / NW bytes of it, no further barrier
+        constexpr int RB = SINGLE ? 128 : 256;                      // bytes of a head's output row: plain f16 / interleaved pair
+        if constexpr (STAGE / NW >= 16 * RB && !(VAR & 16)) {
+            if ((ilf & 2) && !out && oh && il == (SINGLE ? 0 : 1)) {
+                const int nvalid = min(32, sq.q_len - qb * 32);
+                if (lse && h == 0 && l32 < nvalid)
+                    lse[(size_t)(sq.q_start + qi) * (width / HEAD_DIM) + head] = acc.m * 0.125f + logf(acc.lsum * 0.015625f);
+                char* slab = smem + (nchunk & 1) * STAGE + wave * (STAGE / NW);
+                const size_t row0 = (size_t)sq.q_start + (size_t)qb * 32;
+                if constexpr (!SINGLE) ap_store_lines<256>(acc, slab, lane, nvalid, oh + row0 * 2 * width + head * 128, (size_t)2 * width);
+                else ap_store_lines<128>(acc, slab, lane, nvalid, oh + row0 * width + head * HEAD_DIM, (size_t)width);
+                return;
+            }
+        }
         if (qb * 32 + l32 < sq.q_len)
             ap_store(acc, (size_t)(sq.q_start + qi), head, width, h, out, oh, il, (VAR & 16) ? nullptr : lse);
     }
@@ -414,7 +497,9 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
     RLCF_ARG_CHECK(n_seq <= 65535);
     const _Float16* q2 = (const _Float16*)qkv2;
     _Float16* oh = (_Float16*)out_pairs;
-    const int il = single ? 0 : 1, H = width / HEAD_DIM;
+    const char* lse_ = getenv("RLCF_ATTN_LINEST");      // =0: the output rows as 16-byte pieces per lane, as the accumulators hold them (A/B; read per launch)
+    const int linest = lse_ ? atoi(lse_) : 1;
+    const int il = (single ? 0 : 1) | (linest ? 2 : 0), H = width / HEAD_DIM;       // bit 0: interleaved pair rows; bit 1: whole-line stores
     if (max_q_len > 128) {          // ViT sequences (197 / 257 / 577 tokens): 8 query blocks share every K / V stage
         const int full = max_q_len / 256, tail = max_q_len - full * 256;
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch

@@ -232,3 +232,43 @@ def test_x3_line_complete_pair_stores_bit_identical():
         outs.append([x for x in r.stdout.splitlines() if x.startswith("FEATURES")][-1])
     assert outs[0] == outs[1], outs
     assert float(outs[0].split()[2]) > 0.0
+
+
+# ------------------------------------------------------------------ attention forward: the output block as whole lines through LDS
+def _attention_line_store_cases():
+    from test_gpu_round3 import PAIR_CASES
+    return PAIR_CASES
+
+
+@pytest.mark.parametrize("prec_name", ["f16x3", "f16"])
+@pytest.mark.parametrize("case", range(9))
+def test_attention_whole_line_stores_bit_identical(prec_name, case):
+    """attention_fwd_pair_kernel with only the operand-layout output requested (what the engine's image towers ask for): the 32-query block of
+    a wave leaves either as 16-byte pieces per lane (RLCF_ATTN_LINEST=0, the accumulator layout) or transposed through the wave's LDS slab as
+    whole 128-byte lines (default).  Same BITS in the output rows and in the log-sum-exp, rows of no sequence untouched — on every
+    sequence-set of the round-3 parity cases (197 / 257 / 577 tokens, ragged, prefixes, one-query blocks), both operand forms."""
+    from test_gpu_round3 import _seq_buf
+    name, seqs, T, W = _attention_line_store_cases()[case]
+    prec = L.PREC_F16X3 if prec_name == "f16x3" else L.PREC_F16
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    qkv = synth.normal(3, "att." + name, (T, 3 * W), 1.5).to(DEV)
+    pairs = torch.empty(T, 3 * W, device=DEV)
+    L.check(lib.rlcf_split_pairs(qkv.data_ptr(), pairs.data_ptr(), T * 3 * W, prec, st))
+    sbuf = _seq_buf(L, seqs, DEV)
+    mq = max(s[1] for s in seqs)
+    got = {}
+    try:
+        for v in ("0", "1"):
+            os.environ["RLCF_ATTN_LINEST"] = v
+            op = torch.full((T, W), 7.25, device=DEV)                        # (rows no sequence owns must keep this)
+            lse = torch.full((T, W // 64), -3.0, device=DEV)
+            L.check(lib.rlcf_attention_fwd_pairs(pairs.data_ptr(), sbuf.data_ptr(), len(seqs), mq, W, None, op.data_ptr(), lse.data_ptr(), prec, st))
+            torch.cuda.synchronize()
+            got[v] = (op.cpu(), lse.cpu())
+    finally:
+        os.environ.pop("RLCF_ATTN_LINEST", None)
+    assert torch.equal(got["0"][0].view(torch.int32), got["1"][0].view(torch.int32))
+    assert torch.equal(got["0"][1].view(torch.int32), got["1"][1].view(torch.int32))
+    rows = sorted({r for (qs, ql, _, _) in seqs for r in range(qs, qs + ql)})
+    assert not torch.equal(got["1"][0][rows], torch.full((len(rows), W), 7.25))
