@@ -184,11 +184,15 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
                 # views made IN the loop: the decoded image and its 63 crop boxes come from a loader thread one or two images ahead
                 # (datautils.ViewPrefetcher — what the reference's DataLoader workers do, TPT/tpt_cls_rl.py:187-188), the device half
                 # (rlcf_make_views) is launched by the loop's own thread
-                yield from datautils.ViewPrefetcher([(photos[i % len(photos)], i % n_cls) for i in range(self.n)], aug)
+                pf = datautils.ViewPrefetcher([(photos[i % len(photos)], i % n_cls) for i in range(self.n)], aug)
+                yield from pf
+                loader_stats.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in pf.stats.items()})
                 return
             for i in range(self.n):
                 v = self.staged[i % len(self.staged)]
                 yield [x.unsqueeze(0) for x in v.unbind(0)], torch.tensor([i % n_cls])
+
+    loader_stats = []                                           # one entry per views-in-loop run: the loop thread's seconds waiting for the loader / in `apply`
 
     def run(n, images_per_pass, staged, in_flight=1):
         torch.cuda.synchronize()
@@ -213,14 +217,18 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     # few-row tail runs under the next sample's 64-view tower pass; per-sample results are the one-at-a-time call's
     # round 6: ONE host thread enqueues every lane (rlcf_lanes_submit, events between the streams); round 5 ran a Python thread per lane and
     # its legs scattered 72-116 images/s for one setting.  Every in-flight row is still the median of three legs, all three kept next to it
-    # (legs are kept in RUN ORDER; a setting with views made in the loop is run once untimed first: with K lanes the view tensors of K
-    #  samples are alive at a time on K streams, and the first loop of such a setting grows torch's caching allocator to that pool — up to
-    #  round 6's first captures that growth sat in the first timed leg of every views-in-loop setting: 70 against 91 - 95 images/s)
+    # (legs are kept in RUN ORDER, with the loop thread's own account of a views-in-loop leg next to them — seconds waiting for the loader
+    #  thread / inside `apply`.  That account found round 6's bimodal legs, 70 - 82 against 91 - 97 images/s: the decoded image was copied from
+    #  PAGEABLE memory, which blocks the host until the device has run the copy, behind whatever shared its hardware queue — a lane's whole step
+    #  in the legs where the streams fell that way.  The image is pinned on the loader thread now: datautils._upload.)
     def run3(key, st, k):
         if st is None:
             run(12, 1, None, k)
+        n0 = len(loader_stats)
         legs = [run(2 * n_one, 1, st, k) for _ in range(3)]
         out[key], out[key + "_legs"] = sorted(legs)[1], [round(x, 2) for x in legs]
+        if st is None:
+            out[key + "_legs_loop_thread"] = loader_stats[n0:]
         if key.endswith("three_in_flight_staged_views"):
             out["three_in_flight_staged_legs_max_over_min"] = max(legs) / min(legs)
         if key.endswith("three_in_flight_views_in_loop"):

@@ -346,6 +346,7 @@ class ViewPrefetcher:
 
     def __init__(self, dataset, augmenter: "AugMixAugmenter", depth: int = 32, as_list: bool = True):
         self.dataset, self.aug, self.depth, self.as_list = dataset, augmenter, max(1, int(depth)), as_list
+        self.stats = {"items": 0, "wait_s": 0.0, "apply_s": 0.0}      # consuming thread: seconds blocked on the loader thread / in `apply`
 
     def __len__(self):
         return len(self.dataset)
@@ -355,6 +356,8 @@ class ViewPrefetcher:
         import threading
         q = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
+        dev = torch.device(getattr(self.aug, "device", None) or "cuda") if torch.cuda.is_available() else None
+        up = torch.cuda.Stream(device=dev) if dev is not None else None
 
         def work():
             try:
@@ -362,7 +365,18 @@ class ViewPrefetcher:
                     if stop.is_set():
                         return
                     img = _as_u8_hwc(image)
-                    item = (img, self.aug.draw(int(img.shape[0]), int(img.shape[1])), target)
+                    ev = None
+                    if dev is not None and not img.is_cuda:
+                        # the decoded image goes to the device HERE, images ahead of the loop: a copy from pageable memory blocks its caller
+                        # until the device has run it, behind whatever shares the copy stream's hardware queue — with samples in flight that
+                        # was a lane's whole step in one leg out of two (~10 ms per image inside `apply` on the loop's thread: 82 instead
+                        # of 97 images/s, round 6).  Blocked here it costs the loader's lead, not the loop.  (Pinned staging is no way out
+                        # on this platform: CPU writes into pinned memory ran at tens of MB/s — measured, three variants.)
+                        with torch.cuda.stream(up):
+                            img = img.to(dev)
+                            ev = torch.cuda.Event()
+                            ev.record()
+                    item = (img, self.aug.draw(int(img.shape[0]), int(img.shape[1])), target, ev)
                     while not stop.is_set():
                         try:
                             q.put(item, timeout=0.1)
@@ -376,14 +390,24 @@ class ViewPrefetcher:
         th = threading.Thread(target=work, daemon=True)
         th.start()
         try:
+            import time
             while True:
+                t0 = time.perf_counter()
                 item = q.get()
+                t1 = time.perf_counter()
                 if item is None:
                     return
                 if isinstance(item, BaseException):
                     raise item
-                img, params, target = item
+                img, params, target, ev = item
+                if ev is not None:                        # (device-side: the copy ran images ago)
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(ev)
+                    img.record_stream(cur)
                 v = self.aug.apply(img, params)
+                self.stats["items"] += 1
+                self.stats["wait_s"] += t1 - t0
+                self.stats["apply_s"] += time.perf_counter() - t1
                 t = target if isinstance(target, torch.Tensor) else torch.tensor([int(target)])
                 yield ([x.unsqueeze(0) for x in v.unbind(0)] if self.as_list else v), t
         finally:
