@@ -175,6 +175,7 @@ def harness_leg(dev, student_arch, reward_arch, ssd, rsd, n_cls, n_views, select
     class Loader:                                            # one (list of N views [1, 3, R, R], target) per test image, views made on the device
         def __init__(self, n, staged=None):
             self.n, self.staged = n, staged
+            self.on_device = staged is None                  # (views made on the device inside next(): tpt_cls_rl._eval_in_flight advances it under the lane's stream)
 
         def __len__(self):
             return self.n

@@ -344,6 +344,8 @@ class ViewPrefetcher:
     One thread draws, in dataset order: a seeded run makes the same draws as the plain loop.  Yields what the reference's loader
     yields with batch size 1: ([view [1, 3, R, R]] * N, target)."""
 
+    on_device = True            # the views are made on the device inside next(), on the CALLER's current stream (tpt_cls_rl._eval_in_flight)
+
     def __init__(self, dataset, augmenter: "AugMixAugmenter", depth: int = 32, as_list: bool = True):
         self.dataset, self.aug, self.depth, self.as_list = dataset, augmenter, max(1, int(depth)), as_list
         self.stats = {"items": 0, "wait_s": 0.0, "apply_s": 0.0}      # consuming thread: seconds blocked on the loader thread / in `apply`

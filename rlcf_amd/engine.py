@@ -531,6 +531,7 @@ class Lanes:
         self.h = self.lib.rlcf_lanes_create_on(arr, len(self.engines), sarr)
         if not self.h:
             raise L.RlcfError("rlcf_lanes_create_on: " + self.lib.rlcf_last_error().decode())
+        self.next_lane = 0                                  # the lane the next `submit` takes (round robin, rlcf_lanes_submit)
 
     def submit(self, views: torch.Tensor, cfg: TTAConfig, top5_row: torch.Tensor, norm_layers: bool = False,
                final_logits: Optional[torch.Tensor] = None) -> int:
@@ -543,6 +544,7 @@ class Lanes:
                                        _stream())
         if k < 0:
             L.check(k, "rlcf_lanes_submit")
+        self.next_lane = (k + 1) % len(self.engines)
         for t in (views, top5_row, final_logits):
             if t is not None:
                 t.record_stream(self.streams[k])       # the caching allocator must not hand the block out again before the lane has run

@@ -3,6 +3,7 @@
 `accuracy` (TPT/utils/tools.py:84-98).  Same signatures; the arithmetic is one call into the HIP engine."""
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import time
@@ -201,18 +202,47 @@ def _eval_in_flight(val_loader, model, optimizer, args, reward_model, lanes):
     CHUNK = 256                                                  # samples per output block (top-5 rows live until the final count)
     ln, blocks, targets, n = None, [], [], 0
     in_queue = deque()                                           # one event per submitted sample: bounds how far the host runs ahead
+    # Views that are ALREADY on the device (a device-side augmenter) are gathered on the LANE's stream, not on the loop's: the loop's stream then
+    # carries no work at all, and no lane waits for it.  With the gather (`torch.cat`, the reference's own, tpt_cls_rl.py:246) on the loop's
+    # stream every lane depended on a stream that shares a hardware queue with one of them in some stream assignments — its copy kernel then
+    # sat behind that lane's whole step and the other lanes starved (round 6: one staged leg in three at 85 instead of 97 images/s).  A loader
+    # that makes its views on the device inside next() (datautils.ViewPrefetcher: `on_device`) is advanced under the lane's stream as well.
+    main = torch.cuda.current_stream(dev)
+    on_device = bool(getattr(val_loader, "on_device", False))
+    it = iter(val_loader)
+    i = -1
     try:
-        for i, (images, target) in enumerate(val_loader):
-            if isinstance(images, list):
-                images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
-            else:
-                images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
-            if ln is None:                                       # engines are sized by the first image's view count
-                ln = Lanes(runtime.SESSION.lane_engines(lanes, images.shape[0]))
-            if i % CHUNK == 0:
-                blocks.append(torch.empty(CHUNK, 5, dtype=torch.int32, device=dev))
-            views = images.to(dev, torch.float32).contiguous()
-            k = ln.submit(views, cfg, blocks[-1][i % CHUNK], norm_layers=not prompt)
+        while True:
+            lane_st = ln.streams[ln.next_lane] if ln is not None else None
+            try:
+                if lane_st is not None and on_device:
+                    with torch.cuda.stream(lane_st):
+                        images, target = next(it)
+                else:
+                    images, target = next(it)
+            except StopIteration:
+                break
+            i += 1
+            first = images[0] if isinstance(images, list) else images
+            use_lane = lane_st is not None and first.is_cuda
+            if use_lane and not on_device:
+                lane_st.wait_stream(main)                        # (whatever produced the views on the loop's stream)
+            with (torch.cuda.stream(lane_st) if use_lane else contextlib.nullcontext()):
+                if isinstance(images, list):
+                    if use_lane:
+                        for im in images:
+                            im.record_stream(lane_st)
+                    images = torch.cat([im.cuda(args.gpu, non_blocking=True) for im in images], dim=0)
+                else:
+                    if use_lane:
+                        images.record_stream(lane_st)
+                    images = (images.squeeze(0) if images.dim() > 4 else images).cuda(args.gpu, non_blocking=True)
+                if ln is None:                                   # engines are sized by the first image's view count
+                    ln = Lanes(runtime.SESSION.lane_engines(lanes, images.shape[0]))
+                if i % CHUNK == 0:
+                    blocks.append(torch.empty(CHUNK, 5, dtype=torch.int32, device=dev))
+                views = images.to(dev, torch.float32).contiguous()
+                k = ln.submit(views, cfg, blocks[-1][i % CHUNK], norm_layers=not prompt)
             targets.append(target.reshape(-1)[0])
             n += 1
             ev = torch.cuda.Event()
