@@ -334,6 +334,9 @@ class AugMixAugmenter:
 
 
 
+_UPLOAD_STREAMS: dict = {}
+
+
 class ViewPrefetcher:
     """The reference draws a test image's 63 crop boxes (and AugMix plans) inside DataLoader workers — `DataLoader(val_dataset, ...,
     num_workers=args.workers)`, TPT/tpt_cls_rl.py:187-188, with the transform `AugMixAugmenter` running in `__getitem__`
@@ -359,7 +362,12 @@ class ViewPrefetcher:
         q = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
         dev = torch.device(getattr(self.aug, "device", None) or "cuda") if torch.cuda.is_available() else None
-        up = torch.cuda.Stream(device=dev) if dev is not None else None
+        up = None
+        if dev is not None:                               # (one upload stream per device for the process: torch's pool of 32 is shared with everybody)
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            up = _UPLOAD_STREAMS.get(key)
+            if up is None:
+                up = _UPLOAD_STREAMS[key] = torch.cuda.Stream(device=dev)
 
         def work():
             try:

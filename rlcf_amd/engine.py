@@ -516,6 +516,9 @@ class Engine:
         return int(self.lib.rlcf_engine_text_rows(self.h))
 
 
+_LANE_STREAMS: dict = {}                  # device index -> the lanes' streams (torch pool streams, drawn once)
+
+
 class Lanes:
     """K engines with one non-blocking stream each for test images IN FLIGHT (include/rlcf_hip.h, rlcf_lanes_*): `submit` enqueues one
     sample on the next lane from the caller's thread and returns at once; nothing waits on the host."""
@@ -526,7 +529,17 @@ class Lanes:
         arr = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
         # torch's own (pool, non-blocking) streams: the caching allocator keeps a recorded stream's handle for as long as the block lives,
         # so the lanes must not run on streams that are destroyed with the lanes object
-        self.streams = [torch.cuda.Stream(device=self.engines[0].device) for _ in self.engines]
+        # ... and they are a process-wide resource, drawn ONCE per device and shared by every Lanes object after that: torch hands pool streams
+        # out round robin from 32, so lanes that drew fresh ones each time ended up, ten objects later, on streams other parts of the process
+        # own (a loader's upload stream) and on triples that were not created together — which share hardware queues (round 6: every third
+        # leg of the bench's three-lane setting, the one whose draw wrapped the pool, read 85 instead of 97 images/s).  Two Lanes objects alive
+        # at once on one device share streams: correct, serialised.
+        dev = torch.device(self.engines[0].device)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        pool = _LANE_STREAMS.setdefault(key, [])
+        while len(pool) < len(self.engines):
+            pool.append(torch.cuda.Stream(device=dev))
+        self.streams = pool[:len(self.engines)]
         sarr = (C.c_void_p * len(self.engines))(*[s.cuda_stream for s in self.streams])
         self.h = self.lib.rlcf_lanes_create_on(arr, len(self.engines), sarr)
         if not self.h:
