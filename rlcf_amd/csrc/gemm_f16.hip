@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
             const bool inside = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.ldch & 7) == 0;       // (whole tile, 16-byte aligned rows: no masks)
             _Float16* obase = g.Chi + (size_t)orow * g.ldch + ocol;
             const bool defer_now = DEFER && can_defer && inside && have_next;
-            const bool bufst = inside && !g.sk_epoch && (size_t)256 * g.ldch * 2 < 0xfffff000u;
+            const bool bufst = inside && (!g.sk_epoch || TS != 0) && (size_t)256 * g.ldch * 2 < 0xfffff000u;      // (RLCF_F16_PP_NT: the whole-line path carries its own nt form)
             auto rs_out = rsrc_out(m0, n0);
             if constexpr (DEFER != 0) {
                 if (defer_now) rs_pend = rs_out;
@@ -649,11 +649,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_f16_pp_kernel(GemmX3Args g) {
                                        "v"(__builtin_bit_cast(u32x4, oq[3])), "v"(ts_r0)
                                      : "memory");
                         const int so = (i * 32) * g.ldch * 2;
+                        if (g.sk_epoch) {                                  // RLCF_F16_PP_NT: the cache-policy operand is an immediate (2 = nt)
+                            __builtin_amdgcn_raw_buffer_store_b128(t0, rs_out, ts_v0, so, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(t1, rs_out, ts_v0, so + 8 * g.ldch * 2, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(t2, rs_out, ts_v0, so + 16 * g.ldch * 2, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(t3, rs_out, ts_v0, so + 24 * g.ldch * 2, 2);
+                        } else {
                         __builtin_amdgcn_raw_buffer_store_b128(t0, rs_out, ts_v0, so, 0);
                         if (i == 0) { PP_STAMP(11) }
                         __builtin_amdgcn_raw_buffer_store_b128(t1, rs_out, ts_v0, so + 8 * g.ldch * 2, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(t2, rs_out, ts_v0, so + 16 * g.ldch * 2, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(t3, rs_out, ts_v0, so + 24 * g.ldch * 2, 0);
+                        }
                         if (i == 0) { PP_STAMP(12) }
                         if (i == 1) { PP_STAMP(13) }
                         if (i == 2) { PP_STAMP(14) }
@@ -706,11 +713,15 @@ static int f16_pp_enabled() {
 // RLCF_F16_PP_NT=1: non-temporal output stores.  The first (transposing) epilogue wrote whole 128-byte lines per instruction and gained ~2 %
 // from them; the transpose-free epilogue writes 32 rows x 32 B per instruction, and a non-temporal store of a PART of a line is a partial
 // write at the memory (tools/probes/store_rate.hip: 32x32-B pieces, 256 CUs: 5.6 TB/s with the default policy, 0.97 TB/s non-temporal)
+// Round 6: the whole-line epilogue (TS) is back, and with it the gain: non-temporal WHOLE-line stores take 2 % off in_proj and 1.5 - 5 % off c_fc
+// at op level, +0.4 - 0.55 % on the f16 mode's step (profiles/r6_f16_gemm_nt_whole_lines_ab.txt) — so the default is "auto": non-temporal
+// exactly where the tile leaves as whole lines, the default policy everywhere else.  =0: never; =1: everywhere (the round-5 measurement form).
 static int pp_nt_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("RLCF_F16_PP_NT"); on = e ? atoi(e) : 0; }
+    if (on < 0) { const char* e = getenv("RLCF_F16_PP_NT"); on = e ? atoi(e) : 2; }
     return on;
 }
+static unsigned pp_nt_for(bool whole_lines) { const int m = pp_nt_enabled(); return (m == 1 || (m == 2 && whole_lines)) ? 1u : 0u; }
 // LayerNorm-folded products of the single-pass f16 image towers (GemmX3Args::ln_*): always the persistent kernel.
 //   mode 1: out[M, N] (f16) = epi(rstd_r (alpha A.W'^T - mu_r s) + bias'),  A = the f16 residual stream, ln_mr [M][2], ln_s [N]
 //   mode 2: x[M, N] (f16, in place) += alpha A.W^T + bias;  ln_part [(N / 256) * 4][M][2] receives the partial row statistics
@@ -723,7 +734,6 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     g.Ahi = (const _Float16*)A; g.lda = lda; g.Whi = (const _Float16*)W; g.ldw = ldw; g.bias = bias; g.Chi = (_Float16*)out16; g.ldch = ldo;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.epilogue = epilogue; g.kstep = 64; g.ksplit = 0; g.tile_group = 0; g.sk_blocks = 1;
     g.ln_mr = ln_mr; g.ln_s = ln_s; g.ln_part = ln_part;
-    g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -736,6 +746,7 @@ int launch_gemm_f16_pp_ln(const void* A, int lda, const void* W, int ldw, const 
     const size_t shp = (size_t)2 * P8_PAR + 8 * 4096;      // + a 4-KB slab per wave (bias slice; TS: the transposing epilogue)
     const char* tse = getenv("RLCF_F16_PP_TSTORE");          // (mode 1: full-line stores through the per-wave LDS slab, as the plain products)
     const bool tstore = (tse ? atoi(tse) : 1) != 0;
+    g.sk_epoch = pp_nt_for(tstore && mode == 1);
 #define PP_LN_GO(E, MD, S)                                                                                                          \
     {                                                                                                                               \
         int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, MD, 0, 0, S>, shp);                                             \
@@ -772,7 +783,6 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
         const int grid = std::min((ncu / 8) * 8, ((blocks + 7) / 8) * 8);
         const size_t shp = (size_t)2 * P8_PAR + 8 * 4096;      // + a 4-KB slab per wave (bias slice; TS: the transposing epilogue)
         g.ksplit = abl;
-        g.sk_epoch = pp_nt_enabled() ? 1u : 0u;
         static int desync = -1;                              // RLCF_F16_PP_DESYNC=P: start-time cohorts (1 = all together)
         if (desync < 0) { const char* e = getenv("RLCF_F16_PP_DESYNC"); desync = e ? atoi(e) : 1; }
         g.sk_blocks = blocks > grid ? desync : 1;            // (one tile per workgroup: nothing to interleave)
@@ -794,6 +804,7 @@ int launch_gemm_f16_p8(const void* A, int lda, const void* W, int ldw, const flo
         // RLCF_F16_PP_TSTORE (read per launch): 1 = full-line stores through the per-wave LDS slab (TS), 0 = 32 rows x 32 B per instruction
         const char* tse = getenv("RLCF_F16_PP_TSTORE");
         const bool tstore = (tse ? atoi(tse) : 1) != 0 && !defer && abl == 0;
+        g.sk_epoch = pp_nt_for(tstore);
 #define PP_GO(E, D, T, S)                                                                                                           \
     {                                                                                                                               \
         int rc = rlcf_func_lds((const void*)gemm_nt_f16_pp_kernel<E, 0, D, T, S>, shp);                                              \
