@@ -268,7 +268,7 @@ __device__ __forceinline__ void ap_store(const ApAcc& a, size_t row, int head, i
 // so that neither side of the transpose piles up on a bank), read back as 16 bytes per lane, one instruction = 1 KB of whole lines.
 // Same bits at the same addresses, half as many store instructions, an eighth of the line requests.
 template <int RB>
-__device__ __forceinline__ void ap_store_lines(const ApAcc& a, char* slab, int lane, int nvalid, _Float16* __restrict__ orow0, size_t row_halves) {
+__device__ __forceinline__ void ap_store_lines(const ApAcc& a, char* slab, int lane, int nvalid, _Float16* __restrict__ orow0, size_t row_halves, bool nt) {
     constexpr int SLOTS = RB / 16, RPI = 1024 / RB;            // 16-byte slots per row; rows per store instruction
     const int l32 = lane & 31, h = lane >> 5, rl = l32 & 15;
     const float inv = 1.0f / a.lsum;
@@ -302,7 +302,10 @@ __device__ __forceinline__ void ap_store_lines(const ApAcc& a, char* slab, int l
             // (read with the element type it was written with: under type-based alias analysis a load of `unsigned` may be moved above
             //  stores of `_Float16` — the first build of this function did exactly that and stored the slab's previous contents)
             const h16x8 v = *(const h16x8*)(slab + r * RB + ((sl ^ (r & 7)) * 16));
-            if (16 * p + r < nvalid) *(h16x8*)(orow0 + (size_t)(16 * p + r) * row_halves + sl * 8) = v;
+            if (16 * p + r < nvalid) {
+                if (nt) __builtin_nontemporal_store(v, (h16x8*)(orow0 + (size_t)(16 * p + r) * row_halves + sl * 8));      // (RLCF_ATTN_LINEST=2: measurement)
+                else *(h16x8*)(orow0 + (size_t)(16 * p + r) * row_halves + sl * 8) = v;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NW == 4 ? 2 : 1)) void atte
                     lse[(size_t)(sq.q_start + qi) * (width / HEAD_DIM) + head] = acc.m * 0.125f + logf(acc.lsum * 0.015625f);
                 char* slab = smem + (nchunk & 1) * STAGE + wave * (STAGE / NW);
                 const size_t row0 = (size_t)sq.q_start + (size_t)qb * 32;
-                if constexpr (!SINGLE) ap_store_lines<256>(acc, slab, lane, nvalid, oh + row0 * 2 * width + head * 128, (size_t)2 * width);
-                else ap_store_lines<128>(acc, slab, lane, nvalid, oh + row0 * width + head * HEAD_DIM, (size_t)width);
+                if constexpr (!SINGLE) ap_store_lines<256>(acc, slab, lane, nvalid, oh + row0 * 2 * width + head * 128, (size_t)2 * width, (ilf & 4) != 0);
+                else ap_store_lines<128>(acc, slab, lane, nvalid, oh + row0 * width + head * HEAD_DIM, (size_t)width, (ilf & 4) != 0);
                 return;
             }
         }
@@ -499,7 +502,7 @@ int launch_attention_fwd_pair(const void* qkv2, const rlcf_seq* seqs, int n_seq,
     _Float16* oh = (_Float16*)out_pairs;
     const char* lse_ = getenv("RLCF_ATTN_LINEST");      // =0: the output rows as 16-byte pieces per lane, as the accumulators hold them (A/B; read per launch)
     const int linest = lse_ ? atoi(lse_) : 1;
-    const int il = (single ? 0 : 1) | (linest ? 2 : 0), H = width / HEAD_DIM;       // bit 0: interleaved pair rows; bit 1: whole-line stores
+    const int il = (single ? 0 : 1) | (linest ? 2 : 0) | (linest == 2 ? 4 : 0), H = width / HEAD_DIM;       // bit 0: interleaved pair rows; bit 1: whole-line stores
     if (max_q_len > 128) {          // ViT sequences (197 / 257 / 577 tokens): 8 query blocks share every K / V stage
         const int full = max_q_len / 256, tail = max_q_len - full * 256;
         const bool split_tail = full >= 1 && tail > 0 && tail <= 32;        // 257 tokens: the odd query goes to a one-wave launch

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
                         recv[0] = (unsigned)__shfl_xor((int)send[0], 8); recv[1] = (unsigned)__shfl_xor((int)send[1], 8);
                         const u32x2_ even_line = up ? recv : hv, odd_line = up ? lv : recv;
                         _Float16* lp = yh + (size_t)row * 2 * width + (size_t)(c >> 6) * 128 + (lane & 15) * 4;      // the even block's line of this 64-column pair
-                        *(u32x2_*)lp = even_line; *(u32x2_*)(lp + 64) = odd_line;
+                        if (ilf & 4) { __builtin_nontemporal_store(even_line, (u32x2_*)lp); __builtin_nontemporal_store(odd_line, (u32x2_*)(lp + 64)); }     // (RLCF_LN_LINEST=2: measurement)
+                        else { *(u32x2_*)lp = even_line; *(u32x2_*)(lp + 64) = odd_line; }
                     } else {
                         *(h16x4*)(yh + pair_off(row, c, width, il)) = hh;
                         if (yl) *(h16x4*)(yl + pair_off(row, c, width, il)) = ll;       // (yl null: plain f16 output, RLCF_PREC_F16)
@@ -139,7 +140,7 @@ int launch_layernorm_fwd_split(const float* x, const float* gamma, const float* 
     layernorm_fwd_kernel<false><<<dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st>>>(x, gamma, beta, y, (_Float16*)yh,
                                                                                                           (_Float16*)yl, rows, width, group_rows,
                                                                                                           group_rows > 0 ? group_stride : 0,
-                                                                                                          (il ? 1 : 0) | (il && linest ? 2 : 0));
+                                                                                                          (il ? 1 : 0) | (il && linest ? 2 : 0) | (il && linest == 2 ? 4 : 0));
     RLCF_LAUNCH_CHECK();
     return RLCF_OK;
 }
