@@ -38,24 +38,32 @@ class RandomResizedCropParams:
         self.scale, self.ratio, self.flip_p = scale, ratio, flip_p
         lr = torch.log(torch.tensor(self.ratio))           # float32, as torchvision computes it; the bounds reach uniform_ as Python floats
         self._log_ratio = (lr[0].item(), lr[1].item())
+        # The draws run IN PLACE on two one-element scratch tensors: `torch.empty(1).uniform_(a, b)`, `torch.rand(1)`, `torch.randint(0, n, (1,))`
+        # and `torch.exp(t)` are `t.uniform_(a, b)`, `t.uniform_(0, 1)`, `t.random_(0, n)` and `t.exp_()` on a fresh tensor — the same kernels, the
+        # same words of the generator in the same order (tests/test_views.py compares the boxes AND the generator state afterwards) — at a
+        # third of the dispatches: 63 views cost 0.4 instead of 0.9 ms of host time.  (One instance = one drawing thread.)
+        self._f = torch.empty(1)
+        self._i = torch.empty(1, dtype=torch.int64)
+        self._p32 = float(torch.tensor(float(flip_p), dtype=torch.float32))      # (`tensor < p` compares in float32)
 
     def __call__(self, height: int, width: int) -> Tuple[int, int, int, int, bool]:
         box = self.draw_box(height, width)
-        flip = bool(torch.rand(1) < self.flip_p)
+        flip = self._f.uniform_(0.0, 1.0).item() < self._p32
         return (*box, flip)
 
     def draw_box(self, height: int, width: int) -> Tuple[int, int, int, int]:
         area = height * width
         log_ratio = self._log_ratio
         box = None
+        f, it = self._f, self._i
         for _ in range(10):
-            target_area = area * torch.empty(1).uniform_(self.scale[0], self.scale[1]).item()
-            aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+            target_area = area * f.uniform_(self.scale[0], self.scale[1]).item()
+            aspect_ratio = f.uniform_(log_ratio[0], log_ratio[1]).exp_().item()
             w = int(round(math.sqrt(target_area * aspect_ratio)))
             h = int(round(math.sqrt(target_area / aspect_ratio)))
             if 0 < w <= width and 0 < h <= height:
-                i = torch.randint(0, height - h + 1, size=(1,)).item()
-                j = torch.randint(0, width - w + 1, size=(1,)).item()
+                i = it.random_(0, height - h + 1).item()
+                j = it.random_(0, width - w + 1).item()
                 box = (i, j, h, w)
                 break
         if box is None:                       # fallback to a central crop

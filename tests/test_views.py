@@ -71,6 +71,57 @@ def test_random_resized_crop_params_host_mirror():
     assert (ch, cw) == (10, 13) and (t, l) == (0, (400 - 13) // 2)
 
 
+def test_in_place_draws_consume_the_generator_like_the_plain_calls():
+    """datautils draws on one-element scratch tensors in place (t.uniform_, t.exp_, t.random_); torchvision 0.14.1 makes the same draws as
+    fresh tensors (RandomResizedCrop.get_params: torch.empty(1).uniform_, torch.exp, torch.randint; RandomHorizontalFlip.forward:
+    torch.rand(1) < p).  Written out literally here: 63 views per image, many seeds, ordinary and degenerate image shapes (the ten-attempt
+    fallback), two parameter sets — same boxes, same flips, and the SAME generator state afterwards."""
+    import math
+
+    from rlcf_amd import datautils as D
+
+    def plain(height, width, scale, ratio, p):
+        area = height * width
+        log_ratio = torch.log(torch.tensor(ratio))
+        box = None
+        for _ in range(10):
+            target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+            aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+            w = int(round(math.sqrt(target_area * aspect_ratio)))
+            h = int(round(math.sqrt(target_area / aspect_ratio)))
+            if 0 < w <= width and 0 < h <= height:
+                i = torch.randint(0, height - h + 1, size=(1,)).item()
+                j = torch.randint(0, width - w + 1, size=(1,)).item()
+                box = (i, j, h, w)
+                break
+        if box is None:
+            in_ratio = float(width) / float(height)
+            if in_ratio < min(ratio):
+                w = width
+                h = int(round(w / min(ratio)))
+            elif in_ratio > max(ratio):
+                h = height
+                w = int(round(h * max(ratio)))
+            else:
+                w, h = width, height
+            box = ((height - h) // 2, (width - w) // 2, h, w)
+        return (*box, bool(torch.rand(1) < p))
+
+    shapes = [(375, 500), (500, 333), (64, 2000), (3000, 40), (224, 224), (17, 9000)]
+    for scale, p in (((0.08, 1.0), 0.5), ((0.3, 1.0), 0.3)):
+        ratio = (3.0 / 4.0, 4.0 / 3.0)
+        mine = D.RandomResizedCropParams(scale=scale, ratio=ratio, flip_p=p)
+        for seed in range(60):
+            H, W = shapes[seed % len(shapes)]
+            torch.manual_seed(seed)
+            a = [plain(H, W, scale, ratio, p) for _ in range(63)]
+            sa = torch.get_rng_state()
+            torch.manual_seed(seed)
+            b = [mine(H, W) for _ in range(63)]
+            assert a == b, (seed, H, W)
+            assert torch.equal(sa, torch.get_rng_state())
+
+
 def test_make_views_refuses_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
